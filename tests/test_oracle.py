@@ -152,7 +152,7 @@ def test_riccati_constrained_bench_shape(oracle):
     ref = dense_kkt.dense_solve(prob, mueq)
     for a, b in zip(sol[:2], ref[:2]):                      # xs, us
         assert _maxdiff(a, b) <= 5e-3
-    assert _maxdiff(sol[2], ref[2]) <= 1e-4 * vnorm          # vs
+    assert _maxdiff(sol[2], ref[2]) <= 1e-3 * vnorm          # vs = (Cx+d)/mu
 
 
 def test_riccati_parametric(oracle):
