@@ -1,0 +1,415 @@
+// gar_device.hpp -- workgroup-level dense building blocks for the gar kernels
+// (gfx950 / CDNA4, wave64).  Everything here runs on operands resident in LDS
+// (or, for the rare large case, in HBM through the same generic pointers).
+//
+//  * wg_gemm      : D = C0 + sgn * A * B on v_mfma_f64_16x16x4_f64 tiles, the
+//                   output tiles round-robined over the workgroup's waves.
+//                   Replaces every Eigen `noalias() +=` product of
+//                   riccati-kernel.hxx:216-311.
+//  * wg_bk_factor : Bunch-Kaufman LDL^T with 1x1/2x2 pivots (alpha =
+//                   (1+sqrt 17)/8), same pivot rule and same stored
+//                   representation (unit-lower L, INVERSE D blocks, signed
+//                   pivots) as core/bunchkaufman.hpp:23-169,348-420.
+//  * wg_bk_solve  : in-place solve, core/bunchkaufman.hpp:451-518.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gar {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// strided view: element (i,j) at p[i*rs + j*cs]
+struct MatV {
+  double *p;
+  int rs, cs;
+  __device__ __forceinline__ double &operator()(int i, int j) const {
+    return p[i * rs + j * cs];
+  }
+  __device__ __forceinline__ MatV T() const { return MatV{p, cs, rs}; }
+  __device__ __forceinline__ MatV sub(int i, int j) const {
+    return MatV{p + i * rs + j * cs, rs, cs};
+  }
+};
+__device__ __forceinline__ MatV colmajor(double *p, int ld) { return MatV{p, 1, ld}; }
+__device__ __forceinline__ MatV rowmajor(double *p, int ld) { return MatV{p, ld, 1}; }
+
+struct WG { // who am I inside the workgroup
+  int tid, nthr, lane, wave, nwaves;
+};
+__device__ __forceinline__ WG wg_self() {
+  WG w;
+  w.tid = (int)threadIdx.x;
+  w.nthr = (int)blockDim.x;
+  w.lane = w.tid & 63;
+  w.wave = w.tid >> 6;
+  w.nwaves = w.nthr >> 6;
+  return w;
+}
+
+// D(MxN) = C0(MxN) + sgn * A(MxK) * B(KxN).  C0.p may be null (zero).
+// f64 MFMA 16x16x4 operand maps (cdna_hip_programming.md section 3):
+//   A: lane l holds A[i = l&15][k = l>>4];  B: lane l holds B[k = l>>4][j = l&15]
+//   C/D: lane l, reg r holds D[row = (l>>4) + 4r][col = l&15].
+// Out-of-range rows/cols/k are fed as zeros, so any M,N,K works.
+// D may alias C0; D must not alias A or B.  No barrier inside.
+__device__ inline void wg_gemm(const WG &w, int M, int N, int K, MatV A, MatV B, MatV C0,
+                               MatV D, double sgn) {
+  if (M <= 0 || N <= 0)
+    return;
+  const int tN = (N + 15) >> 4;
+  const int nt = ((M + 15) >> 4) * tN;
+  const int li = w.lane & 15, lk = w.lane >> 4;
+  for (int t = w.wave; t < nt; t += w.nwaves) {
+    const int i0 = (t / tN) << 4, j0 = (t % tN) << 4;
+    const int col = j0 + li;
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + lk + 4 * r;
+      acc[r] = (C0.p != nullptr && row < M && col < N) ? C0(row, col) : 0.0;
+    }
+    const int ai = i0 + li;
+    const bool aok = ai < M, bok = col < N;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const int k = k0 + lk;
+      const double a = (aok && k < K) ? sgn * A(ai, k) : 0.0;
+      const double b = (bok && k < K) ? B(k, col) : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + lk + 4 * r;
+      if (row < M && col < N)
+        D(row, col) = acc[r];
+    }
+  }
+}
+
+// y(M) = y0(M) + sgn * A(MxK) x(K); one thread per output row.
+__device__ inline void wg_gemv(const WG &w, int M, int K, MatV A, const double *x, int xs,
+                               const double *y0, int y0s, double *y, int ys, double sgn) {
+  for (int i = w.tid; i < M; i += w.nthr) {
+    double s = 0.0;
+    for (int k = 0; k < K; ++k)
+      s += A(i, k) * x[k * xs];
+    y[i * ys] = (y0 ? y0[i * y0s] : 0.0) + sgn * s;
+  }
+}
+
+// copy src (contiguous, n doubles) -> dst view, element e -> (e % rows, e / rows)
+// i.e. src is a column-major rows x cols block
+__device__ inline void wg_load_colmajor(const WG &w, const double *src, int rows, int cols,
+                                        MatV dst) {
+  const int n = rows * cols;
+  for (int e = w.tid; e < n; e += w.nthr) {
+    const int j = e / rows, i = e - j * rows;
+    dst(i, j) = src[e];
+  }
+}
+__device__ inline void wg_store_colmajor(const WG &w, MatV src, int rows, int cols, double *dst) {
+  const int n = rows * cols;
+  for (int e = w.tid; e < n; e += w.nthr) {
+    const int j = e / rows, i = e - j * rows;
+    dst[e] = src(i, j);
+  }
+}
+// dst is a ROW-major rows x cols contiguous block
+__device__ inline void wg_store_rowmajor(const WG &w, MatV src, int rows, int cols, double *dst) {
+  const int n = rows * cols;
+  for (int e = w.tid; e < n; e += w.nthr) {
+    const int i = e / cols, j = e - i * cols;
+    dst[e] = src(i, j);
+  }
+}
+__device__ inline void wg_fill(const WG &w, double *dst, int n, double v) {
+  for (int e = w.tid; e < n; e += w.nthr)
+    dst[e] = v;
+}
+
+// ---------------------------------------------------------------------------
+// Bunch-Kaufman, whole workgroup, matrix `a` (n x n, lower triangle used,
+// column-major with leading dimension lda) factorised in place.
+//   piv[k] >= 0 : 1x1 pivot, row interchanged with piv[k]
+//   piv[k] = piv[k+1] = -1-p : 2x2 pivot, row k+1 interchanged with p
+// ctrl: >= 4 ints of scratch.  Returns 0 on success, 1 on an exactly-zero
+// pivot column (NumericalIssue, bunchkaufman.hpp:58-59).  Ends with a barrier.
+__device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, double *subdiag,
+                                   int *piv, int *ctrl) {
+#define GA(i, j) a[(j) * lda + (i)]
+  const double alpha = (1.0 + 4.123105625617661) / 8.0; // (1+sqrt(17))/8, :29
+  if (n == 0)
+    return 0;
+  if (n == 1) { // :36-43
+    __syncthreads();
+    int bad = (fabs(GA(0, 0)) == 0.0);
+    __syncthreads();
+    if (w.tid == 0) {
+      if (!bad)
+        GA(0, 0) = 1.0 / GA(0, 0);
+      piv[0] = 0;
+      subdiag[0] = 0.0;
+    }
+    __syncthreads();
+    return bad;
+  }
+  int k = 0;
+  int info = 0;
+  while (k < n) {
+    __syncthreads();
+    if (w.tid == 0) { // pivot search, :46-83
+      int k_step = 1, kp, fail = 0;
+      const double abs_akk = fabs(GA(k, k));
+      int imax = k + 1;
+      double colmax = 0.0;
+      if (k + 1 < n) {
+        colmax = fabs(GA(k + 1, k));
+        for (int i = k + 2; i < n; ++i) {
+          const double v = fabs(GA(i, k));
+          if (v > colmax) {
+            colmax = v;
+            imax = i;
+          }
+        }
+      }
+      if (fmax(abs_akk, colmax) == 0.0) {
+        fail = 1;
+        kp = k;
+      } else if (abs_akk >= colmax * alpha) {
+        kp = k;
+      } else {
+        double rowmax = 0.0;
+        for (int j = k; j < imax; ++j)
+          rowmax = fmax(rowmax, fabs(GA(imax, j)));
+        for (int i = imax + 1; i < n; ++i)
+          rowmax = fmax(rowmax, fabs(GA(i, imax)));
+        if (abs_akk >= (alpha * colmax) * (colmax / rowmax)) {
+          kp = k;
+        } else if (fabs(GA(imax, imax)) >= alpha * rowmax) {
+          kp = imax;
+        } else {
+          kp = imax;
+          k_step = 2;
+        }
+      }
+      ctrl[0] = k_step;
+      ctrl[1] = kp;
+      ctrl[2] = fail;
+    }
+    __syncthreads();
+    const int k_step = ctrl[0], kp = ctrl[1];
+    if (ctrl[2]) { // NumericalIssue: keep the remaining pivots in range and stop
+      for (int i = k + w.tid; i < n; i += w.nthr)
+        piv[i] = i;
+      info = 1;
+      break;
+    }
+    const int kk = k + k_step - 1;
+    if (kp != kk) { // symmetric interchange, :86-102 (disjoint element pairs)
+      for (int i = kk + 1 + w.tid; i < n; i += w.nthr) {
+        if (i < kp) {
+          const double t = GA(i, kk);
+          GA(i, kk) = GA(kp, i);
+          GA(kp, i) = t;
+        } else if (i > kp) {
+          const double t = GA(i, kk);
+          GA(i, kk) = GA(i, kp);
+          GA(i, kp) = t;
+        }
+      }
+      if (w.tid == 0) {
+        const double t = GA(kk, kk);
+        GA(kk, kk) = GA(kp, kp);
+        GA(kp, kp) = t;
+        if (k_step == 2) {
+          const double t2 = GA(k + 1, k);
+          GA(k + 1, k) = GA(kp, k);
+          GA(kp, k) = t2;
+        }
+      }
+      __syncthreads();
+    }
+    if (k_step == 1) { // :104-121
+      const int m = n - k - 1;
+      const double d11 = 1.0 / GA(k, k);
+      for (int e = w.tid; e < m * m; e += w.nthr) {
+        const int j = e / m, i = e - j * m;
+        if (i >= j) {
+          const double d11xj = GA(k + 1 + j, k) * d11;
+          GA(k + 1 + i, k + 1 + j) -= d11xj * GA(k + 1 + i, k);
+        }
+      }
+      __syncthreads();
+      for (int i = w.tid; i < m; i += w.nthr)
+        GA(k + 1 + i, k) *= d11;
+      if (w.tid == 0) {
+        GA(k, k) = d11;
+        piv[k] = kp;
+      }
+    } else { // 2x2 pivot, :122-149
+      const double d21_abs = fabs(GA(k + 1, k));
+      const double d21_inv = 1.0 / d21_abs;
+      const double d11 = d21_inv * GA(k + 1, k + 1);
+      const double d22 = d21_inv * GA(k, k);
+      const double t = 1.0 / ((d11 * d22) - 1.0);
+      const double d = t * d21_inv;
+      const double d21 = GA(k + 1, k) * d21_inv;
+      const int m = n - k - 2;
+      for (int e = w.tid; e < m * m; e += w.nthr) {
+        const int jj = e / m, ii = e - jj * m;
+        if (ii >= jj) {
+          const int j = k + 2 + jj, i = k + 2 + ii;
+          const double wk = ((GA(j, k) * d11) - (GA(j, k + 1) * d21)) * d;
+          const double wkp1 = ((GA(j, k + 1) * d22) - (GA(j, k) * d21)) * d;
+          GA(i, j) -= GA(i, k) * wk + GA(i, k + 1) * wkp1;
+        }
+      }
+      double wk_r[2] = {0.0, 0.0}, wkp1_r[2] = {0.0, 0.0};
+      // each thread owns rows j = k+2+tid (+nthr): n <= 2*nthr supported
+      for (int q = 0; q < 2; ++q) {
+        const int j = k + 2 + w.tid + q * w.nthr;
+        if (j < n) {
+          wk_r[q] = ((GA(j, k) * d11) - (GA(j, k + 1) * d21)) * d;
+          wkp1_r[q] = ((GA(j, k + 1) * d22) - (GA(j, k) * d21)) * d;
+        }
+      }
+      __syncthreads();
+      for (int q = 0; q < 2; ++q) {
+        const int j = k + 2 + w.tid + q * w.nthr;
+        if (j < n) {
+          GA(j, k) = wk_r[q];
+          GA(j, k + 1) = wkp1_r[q];
+        }
+      }
+      if (w.tid == 0) {
+        GA(k, k) = d11 * d;
+        GA(k + 1, k) = -d21 * d;
+        GA(k + 1, k + 1) = d22 * d;
+        piv[k] = -1 - kp;
+        piv[k + 1] = -1 - kp;
+      }
+    }
+    k += k_step;
+  }
+  __syncthreads();
+  // subdiag extraction (:393-404) and row interchanges of the L part (:406-417).
+  // Thread c applies the interchange sequence to column c of L.
+  for (int c = w.tid; c < n; c += w.nthr) {
+    int kq = 0;
+    while (kq < n) {
+      int p = piv[kq];
+      int row, step;
+      if (p < 0) {
+        p = -1 - p;
+        row = kq + 1;
+        step = 2;
+      } else {
+        row = kq;
+        step = 1;
+      }
+      if (c < kq && row != p) {
+        const double t = GA(row, c);
+        GA(row, c) = GA(p, c);
+        GA(p, c) = t;
+      }
+      kq += step;
+    }
+  }
+  __syncthreads();
+  for (int kq = w.tid; kq < n; kq += w.nthr)
+    subdiag[kq] = 0.0;
+  __syncthreads();
+  if (w.tid == 0) { // pairs are rare; serial pass keeps the pairing unambiguous
+    int kq = 0;
+    while (kq < n) {
+      if (piv[kq] < 0) {
+        subdiag[kq] = GA(kq + 1, kq);
+        subdiag[kq + 1] = 0.0;
+        GA(kq + 1, kq) = 0.0;
+        kq += 2;
+      } else {
+        kq += 1;
+      }
+    }
+  }
+  __syncthreads();
+  return info;
+#undef GA
+}
+
+// In-place solve of (L D L^T with interchanges) X = X for an n x ncols block X
+// with strides (xrs, xcs); bunchkaufman.hpp:451-518.  One thread per column of
+// X (columns are independent); ends with a barrier.
+__device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
+                                   const double *subdiag, const int *piv, double *x, int xrs,
+                                   int xcs, int ncols) {
+#define GA(i, j) a[(j) * lda + (i)]
+#define GX(i) xc[(i) * xrs]
+  for (int c = w.tid; c < ncols; c += w.nthr) {
+    double *xc = x + c * xcs;
+    int k = 0;
+    while (k < n) { // :458-468
+      int p = piv[k];
+      int row = k;
+      if (p < 0) {
+        p = -1 - p;
+        row = k + 1;
+        k += 2;
+      } else {
+        k += 1;
+      }
+      if (row != p) {
+        const double t = GX(row);
+        GX(row) = GX(p);
+        GX(p) = t;
+      }
+    }
+    for (int i = 1; i < n; ++i) { // unit-lower solve (:472)
+      double s = GX(i);
+      for (int j = 0; j < i; ++j)
+        s -= GA(i, j) * GX(j);
+      GX(i) = s;
+    }
+    k = 0;
+    while (k < n) { // inverse-D multiply (:474-502)
+      if (piv[k] < 0) {
+        const double akp1k = subdiag[k], ak = GA(k, k), akp1 = GA(k + 1, k + 1);
+        const double xk = GX(k), xkp1 = GX(k + 1);
+        GX(k) = xk * ak + xkp1 * akp1k;
+        GX(k + 1) = xkp1 * akp1 + xk * akp1k;
+        k += 2;
+      } else {
+        GX(k) *= GA(k, k);
+        k += 1;
+      }
+    }
+    for (int j = n - 2; j >= 0; --j) { // unit-upper (L^T) solve (:504)
+      double s = GX(j);
+      for (int i = j + 1; i < n; ++i)
+        s -= GA(i, j) * GX(i);
+      GX(j) = s;
+    }
+    k = n;
+    while (k > 0) { // reverse interchanges (:506-517)
+      k -= 1;
+      int p = piv[k];
+      if (p < 0) {
+        p = -1 - p;
+        if (k != p) {
+          const double t = GX(k);
+          GX(k) = GX(p);
+          GX(p) = t;
+        }
+        k -= 1;
+      } else if (k != p) {
+        const double t = GX(k);
+        GX(k) = GX(p);
+        GX(p) = t;
+      }
+    }
+  }
+  __syncthreads();
+#undef GA
+#undef GX
+}
+
+} // namespace gar

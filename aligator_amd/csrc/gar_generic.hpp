@@ -1,0 +1,741 @@
+// gar_generic.hpp -- dimension-generic gar kernels (any per-stage nx,nu,nc,nx2,
+// nth that fits one CU's LDS).  One 256-thread workgroup owns one (problem,
+// leg) pair and walks its stages; the value function (Vxx, vx, Vxt, Vtt, vt)
+// stays resident in LDS across stages (ping-pong), each knot record is streamed
+// once from HBM, each factor record written once.
+//
+// Restates, with MFMA tiles instead of Eigen expressions:
+//   gar_backward_generic : ProximalRiccatiKernel::backwardImpl / terminalSolve /
+//                          stageKernelSolve (gar/riccati-kernel.hxx:104-312) and the
+//                          initial-stage block of ProximalRiccatiSolver::backward
+//                          (gar/proximal-riccati.hxx:42-60); in leg mode the
+//                          per-leg body of ParallelRiccatiSolver::backward
+//                          (gar/parallel-solver.hxx:136-164).
+//   gar_forward_generic  : computeInitial + forwardImpl (riccati-kernel.hxx:195-207,
+//                          314-377), per leg as parallel-solver.hxx:215-240.
+//   gar_condensed_generic: assembleCondensedSystem + symmetricBlockTridiagSolve +
+//                          refinement (parallel-solver.hxx:85-129,169-202,
+//                          block-tridiagonal.hpp:52-182).
+#pragma once
+#include "gar_device.hpp"
+#include "gar_layout.h"
+
+namespace gar {
+
+// LDS plan (offsets in doubles), computed on the host from the maximum
+// per-stage dimensions (gar_hip.cpp: plan_generic_lds).
+struct LdsPlan {
+  int V[2], v[2], Vxt[2], Vtt[2], vt[2];
+  int H, h, F, fv, P, vp, CD, dd, Gu, Guh, Gv, M, msub, piv, G, Yth, yff;
+  int k0mat, k0rhs, k0sub, k0piv; // initial-stage KKT (aliases the stage buffers)
+  int total;                      // doubles (backward kernel)
+  int fx, fxn, fth, ftotal;       // forward kernel: x, x', theta
+};
+
+struct GenericParams {
+  const gar_stage_meta *meta; // horizon+1 entries (device)
+  const double *prob;         // packed problems
+  double *fac;                // factor records
+  double *sol;                // xs|us|vs|lbdas
+  double *init;               // per problem: kkt0.ff | kkt0.fth | thGrad | thHess
+  int *status;                // per problem: 1 if a factorisation failed
+  double *boundary;           // leg mode: [problem][local leg][tuple]
+  const double *csol;         // leg mode: condensed solution [problem][2*legs][nx]
+  const double *theta;        // forward: device theta [problem][ntheta] or null
+  long long prob_stride, fac_stride, sol_stride, init_stride, boundary_stride;
+  long long G0_off, g0_off;
+  int horizon, nc0, nx0, nth0;
+  int num_legs, leg_begin, local_legs;
+  int tuple_doubles, nxb; // boundary tuple size, boundary block dim
+  double mueq;
+  LdsPlan lds;
+};
+
+extern __shared__ double gar_smem[];
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gar_backward_generic(GenericParams P) {
+  const WG w = wg_self();
+  double *sm = gar_smem;
+  const int leg = (int)blockIdx.x + P.leg_begin;
+  const int b = (int)blockIdx.y;
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  double *fac = P.fac + (long long)b * P.fac_stride;
+  int t_beg, t_end;
+  gar_get_work(P.horizon, leg, P.num_legs, &t_beg, &t_end);
+  const LdsPlan &L = P.lds;
+  int *piv = (int *)(sm + L.piv);
+  int *ctrl = piv + 512;
+  int cur = 0; // ping-pong index of the value function being produced
+  int failed = 0;
+
+  for (int t = t_end - 1; t >= t_beg; --t) {
+    const gar_stage_meta m = P.meta[t];
+    const int nx = m.nx, nu = m.nu, nc = m.nc, nx2 = m.nx2, nth = m.nth;
+    const int nw = nx + nu, nk = nu + nc, nr = nk + nx2;
+    const bool terminal = (t == t_end - 1);
+    const int nth_st = (m.flags & GAR_KNOT_HAS_PARAM) ? nth : 0;
+    const gar_knot_offsets ko = gar_knot_layout(nx, nu, nc, nx2, nth_st);
+    const gar_factor_offsets fo = gar_factor_layout(nx, nu, nc, nx2, nth);
+    const double *rec = prob + m.in_off;
+    double *out = fac + m.fac_off;
+    const int nxt = cur ^ 1; // value function of stage t+1
+    MatV H = colmajor(sm + L.H, nw);
+    double *h = sm + L.h;
+    MatV F = colmajor(sm + L.F, nx2); // [A B], nx2 x nw
+    double *fv = sm + L.fv;
+    MatV Pm = colmajor(sm + L.P, nx2); // V' [A B]
+    double *vp = sm + L.vp;
+    MatV CD = colmajor(sm + L.CD, nc); // [C D], nc x nw
+    double *dd = sm + L.dd;
+    MatV Gu = colmajor(sm + L.Gu, nu), Gv = colmajor(sm + L.Gv, nc);
+    MatV Guh = colmajor(sm + L.Guh, nu);
+    MatV Mk = colmajor(sm + L.M, nk);
+    const int gld = 1 + nx + nth;
+    MatV G = rowmajor(sm + L.G, gld); // [kff K Kth; zff Z Zth]
+    MatV Vn = colmajor(sm + L.V[nxt], nx2), Vc = colmajor(sm + L.V[cur], nx);
+    double *vn = sm + L.v[nxt], *vc = sm + L.v[cur];
+    MatV Vxtn = colmajor(sm + L.Vxt[nxt], nx2), Vxtc = colmajor(sm + L.Vxt[cur], nx);
+    MatV Vttn = colmajor(sm + L.Vtt[nxt], nth), Vttc = colmajor(sm + L.Vtt[cur], nth);
+    double *vtn = sm + L.vt[nxt], *vtc = sm + L.vt[cur];
+    MatV Aff = rowmajor(sm + L.P, nx); // aliases P (dead once H is formed)
+    MatV Yth = rowmajor(sm + L.Yth, nth);
+    double *yff = sm + L.yff;
+
+    // ---- S0: stream the knot record HBM -> LDS ---------------------------
+    // H = [Q S; S^T R] (lqr-problem.hpp:16-22), h = [q; r]
+    wg_load_colmajor(w, rec + ko.Q, nx, nx, H);
+    for (int e = w.tid; e < nx * nu; e += w.nthr) {
+      const int j = e / nx, i = e - j * nx;
+      const double s = rec[ko.S + e];
+      H(i, nx + j) = s;
+      H(nx + j, i) = s;
+    }
+    wg_load_colmajor(w, rec + ko.R, nu, nu, H.sub(nx, nx));
+    for (int e = w.tid; e < nw; e += w.nthr)
+      h[e] = rec[ko.q + e]; // q then r are contiguous in the record
+    for (int e = w.tid; e < nx2 * nw; e += w.nthr)
+      F.p[e] = rec[ko.A + e]; // A then B contiguous == [A B] column-major
+    for (int e = w.tid; e < nx2; e += w.nthr)
+      fv[e] = rec[ko.f + e];
+    for (int e = w.tid; e < nc * nw; e += w.nthr)
+      CD.p[e] = rec[ko.C + e]; // C then D contiguous == [C D] column-major
+    for (int e = w.tid; e < nc; e += w.nthr)
+      dd[e] = rec[ko.d + e];
+    if (nth > 0) { // Gx -> Vxt(cur), Gth -> Vtt(cur), gamma -> vt(cur)
+      if (m.flags & GAR_KNOT_HAS_PARAM) {
+        wg_load_colmajor(w, rec + ko.Gx, nx, nth, Vxtc);
+        wg_load_colmajor(w, rec + ko.Gth, nth, nth, Vttc);
+        wg_load_colmajor(w, rec + ko.Gu, nu, nth, Gu);
+        wg_load_colmajor(w, rec + ko.Gv, nc, nth, Gv);
+        for (int e = w.tid; e < nth; e += w.nthr)
+          vtc[e] = rec[ko.gamma + e];
+      } else if (m.flags & GAR_KNOT_LEG_END) {
+        // configure_knot (parallel-solver.hxx:136-141): Gx=A^T Gu=B^T Gth=0 gamma=f
+        for (int e = w.tid; e < nx * nth; e += w.nthr) {
+          const int j = e / nx, i = e - j * nx;
+          Vxtc(i, j) = rec[ko.A + i * nx2 + j];
+        }
+        for (int e = w.tid; e < nu * nth; e += w.nthr) {
+          const int j = e / nu, i = e - j * nu;
+          Gu(i, j) = rec[ko.B + i * nx2 + j];
+        }
+        wg_fill(w, Vttc.p, nth * nth, 0.0);
+        wg_fill(w, Gv.p, nc * nth, 0.0);
+        for (int e = w.tid; e < nth; e += w.nthr)
+          vtc[e] = rec[ko.f + e];
+      } else { // addParameterization zeros (lqr-problem.hxx:232-241)
+        wg_fill(w, Vxtc.p, nx * nth, 0.0);
+        wg_fill(w, Vttc.p, nth * nth, 0.0);
+        wg_fill(w, Gu.p, nu * nth, 0.0);
+        wg_fill(w, Gv.p, nc * nth, 0.0);
+        wg_fill(w, vtc, nth, 0.0);
+      }
+    }
+    __syncthreads();
+
+    if (!terminal) {
+      // ---- S1: P = V' [A B]; vplus = vx' + V' f  (riccati-kernel.hxx:216-221)
+      wg_gemm(w, nx2, nw, nx2, Vn, F, MatV{nullptr, 0, 0}, Pm, 1.0);
+      wg_gemv(w, nx2, nx2, Vn, fv, 1, vn, 1, vp, 1, 1.0);
+      if (nth > 0) // Ghat_u = Gu + B^T Vxt'  (:286-287; Ghat_x is unused downstream)
+        wg_gemm(w, nu, nth, nx2, F.sub(0, nx).T(), Vxtn, Gu, Guh, 1.0);
+      __syncthreads();
+      // ---- S2: H += [A B]^T P ; h += [A B]^T vplus        (:224-228)
+      wg_gemm(w, nw, nw, nx2, F.T(), Pm, H, H, 1.0);
+      wg_gemv(w, nw, nx2, F.T(), vp, 1, h, 1, h, 1, 1.0);
+      __syncthreads();
+    }
+
+    // ---- S3: reduced KKT [Rhat D^T; D -mu I] and its right-hand sides ------
+    // lower triangle only: BunchKaufman::compute reads Lower (bunchkaufman.hpp:670)
+    for (int e = w.tid; e < nk * nk; e += w.nthr) {
+      const int j = e / nk, i = e - j * nk;
+      double v;
+      if (j < nu)
+        v = (i < nu) ? H(nx + i, nx + j) : CD(i - nu, nx + j);
+      else
+        v = (i < nu) ? CD(j - nu, nx + i) : ((i == j) ? -P.mueq : 0.0);
+      Mk(i, j) = v;
+    }
+    // G = -[rhat Shat^T Ghat_u ; d C Gv]   (:248-256, :288-291)
+    for (int e = w.tid; e < nk * (1 + nx); e += w.nthr) {
+      const int i = e / (1 + nx), j = e - i * (1 + nx);
+      double v;
+      if (i < nu)
+        v = (j == 0) ? h[nx + i] : H(j - 1, nx + i); // Shat^T from Shat = S + AtV B
+      else
+        v = (j == 0) ? dd[i - nu] : CD(i - nu, j - 1);
+      G(i, j) = -v;
+    }
+    if (nth > 0) { // Kth rhs = -Ghat_u (Ghat_u = Gu at the terminal knot), Zth rhs = -Gv
+      for (int e = w.tid; e < nk * nth; e += w.nthr) {
+        const int i = e / nth, j = e - i * nth;
+        double v;
+        if (i < nu)
+          v = terminal ? Gu(i, j) : Guh(i, j);
+        else
+          v = terminal ? 0.0 : Gv(i - nu, j); // terminalSolve: Zth.setZero() (:168)
+        G(i, 1 + nx + j) = -v;
+      }
+    }
+    __syncthreads();
+
+    // ---- S4: factor + solve ------------------------------------------------
+    if (nu == 0) { // terminalSolve, nu == 0 branch (:146-149): Z = C/mu, zff = d/mu
+      for (int e = w.tid; e < nc * gld; e += w.nthr) {
+        const int i = e / gld, j = e - i * gld;
+        double v = 0.0;
+        if (j == 0)
+          v = dd[i] / P.mueq;
+        else if (j <= nx)
+          v = CD(i, j - 1) / P.mueq;
+        G(i, j) = v;
+      }
+      __syncthreads();
+    } else {
+      failed |= wg_bk_factor(w, nk, Mk.p, nk, sm + L.msub, piv, ctrl);
+      wg_bk_solve(w, nk, Mk.p, nk, sm + L.msub, piv, G.p, gld, 1, gld);
+    }
+
+    // ---- S5: closed loop + value function  (:266-277) ----------------------
+    MatV K = G.sub(0, 1), Z = G.sub(nu, 1);
+    MatV Kth = G.sub(0, 1 + nx), Zth = G.sub(nu, 1 + nx);
+    if (!terminal) {
+      // yff = f + B kff ; Aff = A + B K
+      wg_gemv(w, nx2, nu, F.sub(0, nx), G.p, gld, fv, 1, yff, 1, 1.0);
+      wg_gemm(w, nx2, nx, nu, F.sub(0, nx), K, F, Aff, 1.0);
+      if (nth > 0) // Yth = B Kth (:295)
+        wg_gemm(w, nx2, nth, nu, F.sub(0, nx), Kth, MatV{nullptr, 0, 0}, Yth, 1.0);
+    }
+    // Vxx = Qhat + Shat K ; vx = qhat + Shat kff
+    wg_gemm(w, nx, nx, nu, H.sub(0, nx), K, H, Vc, 1.0);
+    wg_gemv(w, nx, nu, H.sub(0, nx), G.p, gld, h, 1, vc, 1, 1.0);
+    __syncthreads();
+    if (nc > 0) { // + C^T Z, + C^T zff
+      wg_gemm(w, nx, nx, nc, CD.T(), Z, Vc, Vc, 1.0);
+      wg_gemv(w, nx, nc, CD.T(), G.p + nu * gld, gld, vc, 1, vc, 1, 1.0);
+      __syncthreads();
+    }
+    if (nth > 0) { // (:298-310) / terminal (:185-192)
+      // vt = gamma [+ vt'] + Gu^T kff [+ Vxt'^T yff]
+      for (int i = w.tid; i < nth; i += w.nthr) {
+        double s = vtc[i];
+        if (!terminal)
+          s += vtn[i];
+        double a1 = 0.0;
+        for (int k = 0; k < nu; ++k)
+          a1 += Gu(k, i) * G(k, 0);
+        s += a1;
+        if (!terminal) {
+          double a2 = 0.0;
+          for (int k = 0; k < nx2; ++k)
+            a2 += Vxtn(k, i) * yff[k];
+          s += a2;
+        }
+        vtc[i] = s;
+      }
+      // Vxt = Gx + K^T Gu [+ Aff^T Vxt']
+      wg_gemm(w, nx, nth, nu, K.T(), Gu, Vxtc, Vxtc, 1.0);
+      __syncthreads();
+      if (!terminal) {
+        wg_gemm(w, nx, nth, nx2, Aff.T(), Vxtn, Vxtc, Vxtc, 1.0);
+        // Vtt = Gth + Vtt' (elementwise) -- then the two products
+        for (int e = w.tid; e < nth * nth; e += w.nthr)
+          Vttc.p[e] += Vttn.p[e];
+        __syncthreads();
+      }
+      wg_gemm(w, nth, nth, nu, Gu.T(), Kth, Vttc, Vttc, 1.0);
+      __syncthreads();
+      if (!terminal) {
+        wg_gemm(w, nth, nth, nx2, Vxtn.T(), Yth, Vttc, Vttc, 1.0);
+        __syncthreads();
+      }
+    }
+
+    // ---- S6: symmetrise (as the consumer stage does, :216) and write out ----
+    if (t > t_beg) {
+      for (int e = w.tid; e < nx * nx; e += w.nthr) {
+        const int j = e / nx, i = e - j * nx;
+        if (i < j)
+          Vc(i, j) = Vc(j, i);
+      }
+    }
+    // ff = [kff; zff; yff], fb = [K; Z; Aff], fth = [Kth; Zth; Yth]
+    for (int e = w.tid; e < nr; e += w.nthr)
+      out[fo.ff + e] = (e < nk) ? G(e, 0) : (terminal ? 0.0 : yff[e - nk]);
+    for (int e = w.tid; e < nr * nx; e += w.nthr) {
+      const int i = e / nx, j = e - i * nx;
+      out[fo.fb + e] = (i < nk) ? G(i, 1 + j) : (terminal ? 0.0 : Aff(i - nk, j));
+    }
+    for (int e = w.tid; e < nr * nth; e += w.nthr) {
+      const int i = e / nth, j = e - i * nth;
+      out[fo.fth + e] = (i < nk) ? G(i, 1 + nx + j) : (terminal ? 0.0 : Yth(i - nk, j));
+    }
+    __syncthreads(); // symmetrisation visible before Vxx is stored
+    for (int e = w.tid; e < nx * nx; e += w.nthr)
+      out[fo.Vxx + e] = Vc.p[e];
+    for (int e = w.tid; e < nx; e += w.nthr)
+      out[fo.vx + e] = vc[e];
+    for (int e = w.tid; e < nx * nth; e += w.nthr)
+      out[fo.Vxt + e] = Vxtc.p[e];
+    for (int e = w.tid; e < nth * nth; e += w.nthr)
+      out[fo.Vtt + e] = Vttc.p[e];
+    for (int e = w.tid; e < nth; e += w.nthr)
+      out[fo.vt + e] = vtc[e];
+    cur ^= 1;
+    __syncthreads();
+  }
+
+  // value function of the leg's first stage now sits in buffer (cur ^ 1)
+  const int fin = cur ^ 1;
+  const gar_stage_meta m0 = P.meta[t_beg];
+  if (P.num_legs > 1) {
+    // leg-boundary tuple: Vxx | Vxt | Vtt | vx | vt, blocks of nxb
+    const int nxb = P.nxb;
+    double *tup = P.boundary + (long long)b * P.boundary_stride +
+                  (long long)(leg - P.leg_begin) * P.tuple_doubles;
+    const int nx = m0.nx, nth = m0.nth;
+    for (int e = w.tid; e < nxb * nxb; e += w.nthr) {
+      const int j = e / nxb, i = e - j * nxb;
+      tup[e] = (i < nx && j < nx) ? sm[L.V[fin] + j * nx + i] : 0.0;
+      tup[nxb * nxb + e] = (i < nx && j < nth) ? sm[L.Vxt[fin] + j * nx + i] : 0.0;
+      tup[2 * nxb * nxb + e] = (i < nth && j < nth) ? sm[L.Vtt[fin] + j * nth + i] : 0.0;
+    }
+    for (int e = w.tid; e < nxb; e += w.nthr) {
+      tup[3 * nxb * nxb + e] = (e < nx) ? sm[L.v[fin] + e] : 0.0;
+      tup[3 * nxb * nxb + nxb + e] = (e < nth) ? sm[L.vt[fin] + e] : 0.0;
+    }
+  } else {
+    // ---- initial stage (proximal-riccati.hxx:42-60) --------------------------
+    const int nx = m0.nx, nth = m0.nth, nc0 = P.nc0, n0 = nx + nc0;
+    const double *G0 = prob + P.G0_off, *g0 = prob + P.g0_off;
+    // move what we need out of the way of the kkt0 buffers (they alias H,F,P..)
+    // V[fin], v[fin], Vxt[fin], Vtt[fin], vt[fin] are outside the aliased range.
+    MatV K0 = colmajor(sm + L.k0mat, n0);
+    const int rld = 1 + nth;
+    MatV R0 = rowmajor(sm + L.k0rhs, rld); // [ff | fth]
+    MatV V0 = colmajor(sm + L.V[fin], nx), Vxt0 = colmajor(sm + L.Vxt[fin], nx);
+    for (int e = w.tid; e < n0 * n0; e += w.nthr) {
+      const int j = e / n0, i = e - j * n0;
+      double v = 0.0;
+      if (j < nx)
+        v = (i < nx) ? V0(i, j) : G0[j * nc0 + (i - nx)];
+      else if (i < nx)
+        v = G0[i * nc0 + (j - nx)];
+      K0(i, j) = v;
+    }
+    for (int e = w.tid; e < n0 * rld; e += w.nthr) {
+      const int i = e / rld, j = e - i * rld;
+      double v;
+      if (j == 0)
+        v = (i < nx) ? -sm[L.v[fin] + i] : -g0[i - nx];
+      else
+        v = (i < nx) ? -Vxt0(i, j - 1) : 0.0;
+      R0(i, j) = v;
+    }
+    __syncthreads();
+    int *piv0 = (int *)(sm + L.k0piv);
+    failed |= 2 * wg_bk_factor(w, n0, K0.p, n0, sm + L.k0sub, piv0, piv0 + 512);
+    wg_bk_solve(w, n0, K0.p, n0, sm + L.k0sub, piv0, R0.p, rld, 1, rld);
+    double *io = P.init + (long long)b * P.init_stride;
+    for (int e = w.tid; e < n0; e += w.nthr)
+      io[e] = R0(e, 0);
+    for (int e = w.tid; e < n0 * nth; e += w.nthr) {
+      const int i = e / nth, j = e - i * nth;
+      io[n0 + e] = R0(i, 1 + j);
+    }
+    // thGrad = vt + Vxt^T x0 ; thHess = Vtt + Vxt^T fth_x   (:56-59)
+    for (int i = w.tid; i < nth; i += w.nthr) {
+      double s = 0.0;
+      for (int k = 0; k < nx; ++k)
+        s += Vxt0(k, i) * R0(k, 0);
+      io[n0 + n0 * nth + i] = sm[L.vt[fin] + i] + s;
+    }
+    for (int e = w.tid; e < nth * nth; e += w.nthr) {
+      const int j = e / nth, i = e - j * nth;
+      double s = 0.0;
+      for (int k = 0; k < nx; ++k)
+        s += Vxt0(k, i) * R0(k, 1 + j);
+      io[n0 + n0 * nth + nth + e] = sm[L.Vtt[fin] + e] + s;
+    }
+  }
+  if (failed && w.tid == 0)
+    atomicOr(&P.status[b], failed);
+}
+
+// ---------------------------------------------------------------------------
+// forward: x0/lbd0 from kkt0 (serial) or the condensed solution (legs), then
+// the closed-loop roll-out.  LDS: x (nxM), xn (nxM), theta (nthM).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gar_forward_generic(GenericParams P) {
+  const WG w = wg_self();
+  double *sm = gar_smem;
+  const int leg = (int)blockIdx.x + P.leg_begin;
+  const int b = (int)blockIdx.y;
+  const double *fac = P.fac + (long long)b * P.fac_stride;
+  double *sol = P.sol + (long long)b * P.sol_stride;
+  int t_beg, t_end;
+  gar_get_work(P.horizon, leg, P.num_legs, &t_beg, &t_end);
+  const gar_stage_meta m0 = P.meta[t_beg];
+  double *x = sm + P.lds.fx;   // current state
+  double *xn = sm + P.lds.fxn; // next state
+  double *th = sm + P.lds.fth; // theta
+  bool have_theta = false;
+  int nth_used = 0;
+  if (P.num_legs == 1) { // computeInitial (riccati-kernel.hxx:195-207)
+    const int nx = m0.nx, nc0 = P.nc0, n0 = nx + nc0, nth = m0.nth;
+    const double *io = P.init + (long long)b * P.init_stride;
+    have_theta = (P.theta != nullptr) && nth > 0;
+    nth_used = nth;
+    if (have_theta)
+      for (int e = w.tid; e < nth; e += w.nthr)
+        th[e] = P.theta[(long long)b * nth + e];
+    __syncthreads();
+    for (int i = w.tid; i < n0; i += w.nthr) {
+      double s = io[i];
+      if (have_theta)
+        for (int k = 0; k < nth; ++k)
+          s += io[n0 + i * nth + k] * th[k];
+      if (i < nx) {
+        x[i] = s;
+        sol[m0.x_off + i] = s;
+      } else {
+        sol[m0.l_off + (i - nx)] = s;
+      }
+    }
+  } else { // scatter of the condensed solution (parallel-solver.hxx:215-220)
+    const int nxb = P.nxb;
+    const double *cs = P.csol + (long long)b * (2 * P.num_legs) * nxb;
+    const int nx = m0.nx;
+    const int nl0 = (leg == 0) ? P.nc0 : nx;
+    for (int i = w.tid; i < nl0; i += w.nthr)
+      sol[m0.l_off + i] = cs[(2 * leg) * nxb + i];
+    for (int i = w.tid; i < nx; i += w.nthr) {
+      const double s = cs[(2 * leg + 1) * nxb + i];
+      x[i] = s;
+      sol[m0.x_off + i] = s;
+    }
+    if (leg < P.num_legs - 1) { // theta = lbdas[end] (:234-236)
+      have_theta = true;
+      nth_used = m0.nth;
+      for (int e = w.tid; e < nth_used; e += w.nthr)
+        th[e] = cs[(2 * (leg + 1)) * nxb + e];
+    }
+  }
+  __syncthreads();
+
+  for (int t = t_beg; t < t_end; ++t) {
+    const gar_stage_meta m = P.meta[t];
+    const int nx = m.nx, nu = m.nu, nc = m.nc, nx2 = m.nx2, nth = m.nth;
+    const int nk = nu + nc, nr = nk + nx2;
+    const gar_factor_offsets fo = gar_factor_layout(nx, nu, nc, nx2, nth);
+    const double *rec = fac + m.fac_off;
+    const bool last = (t == t_end - 1);
+    const bool use_th = have_theta && nth > 0;
+    // u = kff + K x (+Kth th); v = zff + Z x (+Zth th); x' = yff + Aff x (+Yth th)
+    const int rows = last ? nk : nr;
+    for (int i = w.tid; i < rows; i += w.nthr) {
+      double s = rec[fo.ff + i];
+      const double *row = rec + fo.fb + (long long)i * nx;
+      double a = 0.0;
+      for (int k = 0; k < nx; ++k)
+        a += row[k] * x[k];
+      s += a;
+      if (use_th) {
+        const double *rt = rec + fo.fth + (long long)i * nth;
+        double a2 = 0.0;
+        for (int k = 0; k < nth; ++k)
+          a2 += rt[k] * th[k];
+        s += a2;
+      }
+      if (i < nu)
+        sol[m.u_off + i] = s;
+      else if (i < nk)
+        sol[m.v_off + (i - nu)] = s;
+      else
+        xn[i - nk] = s;
+    }
+    if (last)
+      break;
+    __syncthreads();
+    // lbd' = vx' + Vxx' x' (+ Vxt' th)  (:369-374)
+    const gar_stage_meta mn = P.meta[t + 1];
+    const gar_factor_offsets fn = gar_factor_layout(mn.nx, mn.nu, mn.nc, mn.nx2, mn.nth);
+    const double *recn = fac + mn.fac_off;
+    for (int i = w.tid; i < nx2; i += w.nthr) {
+      double s = recn[fn.vx + i];
+      double a = 0.0;
+      for (int k = 0; k < nx2; ++k)
+        a += recn[fn.Vxx + (long long)k * nx2 + i] * xn[k];
+      s += a;
+      if (use_th) {
+        double a2 = 0.0;
+        for (int k = 0; k < nth; ++k)
+          a2 += recn[fn.Vxt + (long long)k * nx2 + i] * th[k];
+        s += a2;
+      }
+      sol[mn.l_off + i] = s;
+      sol[mn.x_off + i] = xn[i];
+      x[i] = xn[i];
+    }
+    __syncthreads();
+  }
+}
+
+} // namespace gar
+
+namespace gar {
+
+// ---------------------------------------------------------------------------
+// condensed (leg-boundary) system: assemble, factor, solve, refine.
+// One workgroup per problem; every rank runs it redundantly on the gathered
+// boundary tuples, so no second collective is needed.
+// ---------------------------------------------------------------------------
+struct CondensedParams {
+  const double *ball;  // gathered tuples: [rank][problem][legs_per_rank][tuple]
+  const double *prob;  // packed problems (G0, g0)
+  double *scratch;     // per problem: see offsets below
+  double *csol;        // per problem: [2*num_legs][nxb]
+  int *status;
+  long long prob_stride, scratch_stride, G0_off, g0_off;
+  int batch, num_legs, legs_per_rank, tuple_doubles, nxb, nc0, nx0;
+  int max_refinement;
+  double threshold;
+  // scratch layout (doubles, per problem): nblk = 2*num_legs, bs = nxb*nxb
+  //   diag[nblk][bs] super[nblk][bs] facD[nblk][bs] U[nblk][bs]
+  //   fsub[nblk][nxb] rhs[nblk][nxb] err[nblk][nxb] fpiv[nblk][nxb] (ints in doubles)
+  //   info[2] : residual, refinement steps
+};
+
+__device__ __forceinline__ const double *cond_tuple(const CondensedParams &P, int b, int leg) {
+  const int rank = leg / P.legs_per_rank, ll = leg - rank * P.legs_per_rank;
+  return P.ball + (((long long)rank * P.batch + b) * P.legs_per_rank + ll) * P.tuple_doubles;
+}
+
+// LDS: blk[nxb*nxb] ublk[nxb*nxb] sub[nxb] piv/ctrl
+__global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) {
+  const WG w = wg_self();
+  double *sm = gar_smem;
+  const int b = (int)blockIdx.x;
+  const int nxb = P.nxb, bs = nxb * nxb, nblk = 2 * P.num_legs, N = nblk - 1;
+  double *S = P.scratch + (long long)b * P.scratch_stride;
+  double *diag = S, *super = diag + (long long)nblk * bs, *facD = super + (long long)nblk * bs;
+  double *U = facD + (long long)nblk * bs;
+  double *fsub = U + (long long)nblk * bs;
+  double *rhs = fsub + nblk * nxb, *err = rhs + nblk * nxb;
+  int *fpiv = (int *)(err + nblk * nxb);
+  double *info = err + 2 * nblk * nxb;
+  double *sol = P.csol + (long long)b * nblk * nxb;
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  double *blk = sm, *ublk = sm + bs, *lsub = sm + 2 * bs;
+  int *lpiv = (int *)(lsub + nxb + (nxb & 1));
+  int *ctrl = lpiv + nxb + 8;
+  // block i has dimension dim(i): nc0 for i == 0, else nxb  (rhsDims_, :68-73)
+#define DIM(i) ((i) == 0 ? P.nc0 : nxb)
+
+  // ---- assembleCondensedSystem (parallel-solver.hxx:85-129), blocks stored
+  // column-major with leading dimension DIM(row block)
+  for (int e = w.tid; e < nblk * bs; e += w.nthr) {
+    diag[e] = 0.0;
+    super[e] = 0.0;
+  }
+  __syncthreads();
+  {
+    const int nc0 = P.nc0, nx0 = P.nx0;
+    for (int e = w.tid; e < nc0 * nx0; e += w.nthr) // super[0] = G0 (nc0 x nx0)
+      super[e] = prob[P.G0_off + e];
+    for (int e = w.tid; e < nc0; e += w.nthr)
+      rhs[e] = -prob[P.g0_off + e];
+  }
+  for (int leg = 0; leg < P.num_legs; ++leg) {
+    const double *tup = cond_tuple(P, b, leg);
+    // diag[2 leg + 1] = Vxx(leg) ; rhs[2 leg + 1] = -vx(leg)
+    for (int e = w.tid; e < bs; e += w.nthr)
+      diag[(long long)(2 * leg + 1) * bs + e] = tup[e];
+    for (int e = w.tid; e < nxb; e += w.nthr)
+      rhs[(2 * leg + 1) * nxb + e] = -tup[3 * bs + e];
+    if (leg + 1 < P.num_legs) {
+      // super[2 leg + 1] = Vxt(leg); diag[2 leg + 2] = Vtt(leg); super[2 leg + 2] = -I
+      for (int e = w.tid; e < bs; e += w.nthr) {
+        super[(long long)(2 * leg + 1) * bs + e] = tup[bs + e];
+        diag[(long long)(2 * leg + 2) * bs + e] = tup[2 * bs + e];
+        const int j = e / nxb, i = e - j * nxb;
+        super[(long long)(2 * leg + 2) * bs + e] = (i == j) ? -1.0 : 0.0;
+      }
+      for (int e = w.tid; e < nxb; e += w.nthr)
+        rhs[(2 * leg + 2) * nxb + e] = -tup[3 * bs + nxb + e];
+    }
+  }
+  __syncthreads();
+  for (int e = w.tid; e < nblk * nxb; e += w.nthr)
+    sol[e] = rhs[e];
+  for (int e = w.tid; e < nblk * bs; e += w.nthr)
+    facD[e] = diag[e];
+  // U[i] = sub[i] = super[i]^T : DIM(i+1) x DIM(i)
+  for (int i = 0; i < N; ++i) {
+    const int r = DIM(i), c = DIM(i + 1);
+    for (int e = w.tid; e < r * c; e += w.nthr) {
+      const int bb = e / r, a = e - bb * r; // super(a, bb)
+      U[(long long)i * bs + a * c + bb] = super[(long long)i * bs + e];
+    }
+  }
+  __syncthreads();
+
+  int failed = 0;
+  // ---- symmetricBlockTridiagSolve, up-looking (block-tridiagonal.hpp:82-138)
+  for (int i = N - 1; i >= -1; --i) {
+    const int ib = i + 1, n = DIM(ib);
+    // factor facD[ib] in LDS
+    for (int e = w.tid; e < n * n; e += w.nthr)
+      blk[e] = facD[(long long)ib * bs + e];
+    __syncthreads();
+    failed |= wg_bk_factor(w, n, blk, n, lsub, lpiv, ctrl);
+    for (int e = w.tid; e < n * n; e += w.nthr)
+      facD[(long long)ib * bs + e] = blk[e];
+    for (int e = w.tid; e < n; e += w.nthr) {
+      fsub[ib * nxb + e] = lsub[e];
+      fpiv[ib * nxb + e] = lpiv[e];
+    }
+    wg_bk_solve(w, n, blk, n, lsub, lpiv, sol + ib * nxb, 1, 0, 1);
+    if (i < 0)
+      break;
+    const int r = DIM(i);
+    MatV Bi = colmajor(super + (long long)i * bs, r); // r x n
+    // rhs[i] -= B rhs[i+1]
+    wg_gemv(w, r, n, Bi, sol + ib * nxb, 1, sol + i * nxb, 1, sol + i * nxb, 1, -1.0);
+    // U[i] <- D^{-1} U[i]  (n x r), through LDS
+    for (int e = w.tid; e < n * r; e += w.nthr)
+      ublk[e] = U[(long long)i * bs + e];
+    __syncthreads();
+    wg_bk_solve(w, n, blk, n, lsub, lpiv, ublk, 1, n, r);
+    for (int e = w.tid; e < n * r; e += w.nthr)
+      U[(long long)i * bs + e] = ublk[e];
+    // facD[i] -= B U[i]
+    wg_gemm(w, r, r, n, Bi, colmajor(ublk, n), colmajor(facD + (long long)i * bs, r),
+            colmajor(facD + (long long)i * bs, r), -1.0);
+    __syncthreads();
+  }
+  for (int i = 0; i < N; ++i) { // :131-134
+    const int r = DIM(i), n = DIM(i + 1);
+    wg_gemv(w, n, r, colmajor(U + (long long)i * bs, n), sol + i * nxb, 1, sol + (i + 1) * nxb, 1,
+            sol + (i + 1) * nxb, 1, -1.0);
+    __syncthreads();
+  }
+
+  // ---- iterative refinement (parallel-solver.hxx:184-202, with the residual
+  // computed from the true right-hand side; see DESIGN.md "refinement")
+  int steps = 0;
+  double resdl = 0.0;
+  for (int it = 0; it < P.max_refinement; ++it) {
+    // err = rhs - A sol   (blockTridiagMatMul, :52-75)
+    for (int e = w.tid; e < nblk * nxb; e += w.nthr) {
+      const int i = e / nxb, a = e - i * nxb;
+      const int n = DIM(i);
+      double s = 0.0;
+      if (a < n) {
+        s = rhs[e];
+        const double *Dg = diag + (long long)i * bs;
+        for (int k = 0; k < n; ++k)
+          s -= Dg[k * n + a] * sol[i * nxb + k];
+        if (i > 0) { // sub[i-1] = super[i-1]^T
+          const int r = DIM(i - 1);
+          const double *Bp = super + (long long)(i - 1) * bs;
+          for (int k = 0; k < r; ++k)
+            s -= Bp[a * r + k] * sol[(i - 1) * nxb + k];
+        }
+        if (i < N) {
+          const int c = DIM(i + 1);
+          const double *Bn = super + (long long)i * bs;
+          for (int k = 0; k < c; ++k)
+            s -= Bn[k * n + a] * sol[(i + 1) * nxb + k];
+        }
+      }
+      err[e] = s;
+    }
+    __syncthreads();
+    // infinity norm (all threads redundantly; tiny)
+    double mx = 0.0;
+    for (int e = 0; e < nblk * nxb; ++e) {
+      const double v = fabs(err[e]);
+      mx = (v > mx || v != v) ? v : mx;
+    }
+    resdl = mx;
+    if (resdl <= P.threshold)
+      break;
+    // blockTridiagRefinementStep (:147-182) on err
+    for (int i = N - 1; i >= -1; --i) {
+      const int ib = i + 1, n = DIM(ib);
+      __syncthreads();
+      wg_bk_solve(w, n, facD + (long long)ib * bs, n, fsub + ib * nxb, fpiv + ib * nxb,
+                  err + ib * nxb, 1, 0, 1);
+      if (i < 0)
+        break;
+      const int r = DIM(i);
+      wg_gemv(w, r, n, colmajor(super + (long long)i * bs, r), err + ib * nxb, 1, err + i * nxb, 1,
+              err + i * nxb, 1, -1.0);
+    }
+    for (int i = 0; i < N; ++i) {
+      const int r = DIM(i), n = DIM(i + 1);
+      __syncthreads();
+      wg_gemv(w, n, r, colmajor(U + (long long)i * bs, n), err + i * nxb, 1, err + (i + 1) * nxb,
+              1, err + (i + 1) * nxb, 1, -1.0);
+    }
+    __syncthreads();
+    for (int e = w.tid; e < nblk * nxb; e += w.nthr)
+      sol[e] += err[e];
+    steps = it + 1;
+    __syncthreads();
+  }
+  if (w.tid == 0) {
+    info[0] = resdl;
+    info[1] = (double)steps;
+    if (failed)
+      atomicOr(&P.status[b], 4);
+  }
+#undef DIM
+}
+
+// collapseFeedback (parallel-solver.hpp:41-51): K0 -= Kth0 * Vxt(b0)^T on the
+// factor record of stage 0 (subdiagonal[1] holds the UNFACTORED Vxt(b0)^T after
+// backward()).
+__global__ void gar_collapse_feedback(const gar_stage_meta *meta, double *fac,
+                                      long long fac_stride, int batch) {
+  const int b = (int)blockIdx.x;
+  if (b >= batch)
+    return;
+  const gar_stage_meta m = meta[0];
+  const gar_factor_offsets fo = gar_factor_layout(m.nx, m.nu, m.nc, m.nx2, m.nth);
+  double *rec = fac + (long long)b * fac_stride + m.fac_off;
+  for (int e = (int)threadIdx.x; e < m.nu * m.nx; e += (int)blockDim.x) {
+    const int i = e / m.nx, j = e - i * m.nx;
+    double s = 0.0;
+    for (int k = 0; k < m.nth; ++k)
+      s += rec[fo.fth + i * m.nth + k] * rec[fo.Vxt + k * m.nx + j];
+    rec[fo.fb + e] -= s;
+  }
+}
+
+} // namespace gar

@@ -1,0 +1,894 @@
+// gar_hip.cpp -- C-ABI implementation (include/gar_hip.h) over the HIP kernels.
+// Host C++ only packs per-stage blocks into the contiguous device records,
+// launches kernels on a HIP stream and copies results back; all arithmetic of
+// the Riccati path runs in the kernels (gar_generic.hpp, gar_mfma.hpp).
+#include "../../include/gar_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gar_generic.hpp"
+#include "gar_layout.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(GAR_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+inline int align2(int x) { return (x + 1) & ~1; }
+
+} // namespace
+
+struct gar_hip_solver {
+  int device = 0, horizon = 0, nc0 = 0, batch = 0;
+  int num_legs = 1, leg_begin = 0, leg_end = 1;
+  std::vector<gar_stage_meta> meta;
+  std::vector<int32_t> dims5;
+  gar_stage_meta *d_meta = nullptr;
+  int64_t prob_doubles = 0, fac_doubles = 0, sol_doubles = 0, init_doubles = 0;
+  int64_t G0_off = 0, g0_off = 0;
+  int64_t sol_x = 0, sol_u = 0, sol_v = 0, sol_l = 0; // base offsets of xs/us/vs/lbdas
+  int nx0 = 0, nth0 = 0, n0 = 0;
+  double *d_prob = nullptr, *d_fac = nullptr, *d_sol = nullptr, *d_init = nullptr;
+  double *d_theta = nullptr;
+  int *d_status = nullptr;
+  // leg mode
+  int nxb = 0;
+  int64_t tuple_doubles = 0, cscratch_doubles = 0;
+  double *d_bound_local = nullptr, *d_bound_all = nullptr, *d_csol = nullptr,
+         *d_cscratch = nullptr;
+  bool bound_all_owned = false;
+  int legs_per_rank = 0;
+  double cond_threshold = 1e-10; // parallel-solver.hpp:92
+  int max_refinement = 5;        // parallel-solver.hpp:94
+  // host staging
+  double *h_prob = nullptr; // pinned, batch * prob_doubles (when small enough)
+  bool staged = false, dirty = false;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  gar::LdsPlan lds{};
+  int cond_lds_doubles = 0;
+  std::string kernel_name = "generic";
+  int last_failed = 0;
+};
+
+namespace {
+
+// ---- layout ---------------------------------------------------------------
+int build_layout(gar_hip_solver *s) {
+  const int N = s->horizon;
+  s->meta.assign(N + 1, gar_stage_meta{});
+  std::vector<int> leg_of(N + 1, 0), nth_eff(N + 1, 0), flags(N + 1, 0);
+  for (int t = 0; t <= N; ++t) {
+    const int32_t *d = &s->dims5[5 * t];
+    if (d[0] < 0 || d[1] < 0 || d[2] < 0 || d[3] < 0 || d[4] < 0 || d[0] == 0)
+      return fail(GAR_HIP_ERR_ARG, "negative or zero state dimension");
+    nth_eff[t] = d[4];
+    flags[t] = d[4] > 0 ? GAR_KNOT_HAS_PARAM : 0;
+  }
+  if (s->num_legs > 1) {
+    // ParallelRiccatiSolver::initialize (parallel-solver.hxx:51-82)
+    for (int i = 0; i < s->num_legs; ++i) {
+      int i0, i1;
+      gar_get_work(N, i, s->num_legs, &i0, &i1);
+      if (i1 <= i0)
+        return fail(GAR_HIP_ERR_ARG, "more legs than stages");
+      const bool last_leg = (i == s->num_legs - 1);
+      const int nth = s->dims5[5 * (i1 - 1) + 3]; // nx2 of the leg's last knot
+      for (int t = i0; t < i1; ++t) {
+        if (s->dims5[5 * t + 4] != 0)
+          return fail(GAR_HIP_ERR_UNSUPPORTED,
+                      "leg mode on a user-parameterised problem is not supported");
+        leg_of[t] = i;
+        nth_eff[t] = last_leg ? 0 : nth;
+        flags[t] = last_leg ? 0 : (t == i1 - 1 ? GAR_KNOT_LEG_END : GAR_KNOT_LEG_PARAM);
+      }
+    }
+  }
+  s->nx0 = s->dims5[0];
+  s->nth0 = nth_eff[0];
+  s->n0 = s->nx0 + s->nc0;
+  int64_t in = 0, fo = 0;
+  s->G0_off = in;
+  in += (int64_t)s->nc0 * s->nx0;
+  s->g0_off = in;
+  in += s->nc0;
+  in = (in + 1) & ~(int64_t)1;
+  int64_t x = 0, u = 0, v = 0, l = s->nc0;
+  for (int t = 0; t <= N; ++t) {
+    const int32_t *d = &s->dims5[5 * t];
+    gar_stage_meta &m = s->meta[t];
+    m.nx = d[0]; m.nu = d[1]; m.nc = d[2]; m.nx2 = d[3];
+    m.nth = nth_eff[t];
+    m.flags = flags[t];
+    m.leg = leg_of[t];
+    m.in_off = in;
+    in += gar_knot_doubles(d[0], d[1], d[2], d[3], (flags[t] & GAR_KNOT_HAS_PARAM) ? d[4] : 0);
+    in = (in + 1) & ~(int64_t)1; // keep records 16-byte aligned
+    m.fac_off = fo;
+    fo += gar_factor_doubles(d[0], d[1], d[2], d[3], nth_eff[t]);
+    fo = (fo + 1) & ~(int64_t)1;
+    m.x_off = (int32_t)x; x += d[0];
+    m.u_off = (int32_t)u; u += d[1];
+    m.v_off = (int32_t)v; v += d[2];
+    m.l_off = (int32_t)(t == 0 ? 0 : l);
+    if (t > 0)
+      l += s->dims5[5 * (t - 1) + 3];
+  }
+  // lbdas[t] (t>=1) has nx2 of stage t-1: recompute l offsets cleanly
+  {
+    int64_t lo = s->nc0;
+    s->meta[0].l_off = 0;
+    for (int t = 1; t <= N; ++t) {
+      s->meta[t].l_off = (int32_t)lo;
+      lo += s->dims5[5 * (t - 1) + 3];
+    }
+    l = lo;
+  }
+  s->prob_doubles = in;
+  s->fac_doubles = fo;
+  s->sol_x = 0;
+  s->sol_u = x;
+  s->sol_v = x + u;
+  s->sol_l = x + u + v;
+  for (int t = 0; t <= N; ++t) {
+    s->meta[t].u_off += (int32_t)s->sol_u;
+    s->meta[t].v_off += (int32_t)s->sol_v;
+    s->meta[t].l_off += (int32_t)s->sol_l;
+  }
+  s->sol_doubles = (x + u + v + l + 1) & ~(int64_t)1;
+  s->init_doubles = ((int64_t)s->n0 + (int64_t)s->n0 * s->nth0 + s->nth0 +
+                     (int64_t)s->nth0 * s->nth0 + 1) & ~(int64_t)1;
+  return GAR_HIP_OK;
+}
+
+int plan_lds(gar_hip_solver *s) {
+  int nxM = 0, nuM = 0, ncM = 0, nthM = 0, nwM = 0, nkM = 0;
+  for (const auto &m : s->meta) {
+    nxM = std::max(nxM, std::max(m.nx, m.nx2));
+    nuM = std::max(nuM, m.nu);
+    ncM = std::max(ncM, m.nc);
+    nthM = std::max(nthM, m.nth);
+    nwM = std::max(nwM, m.nx + m.nu);
+    nkM = std::max(nkM, m.nu + m.nc);
+  }
+  gar::LdsPlan &L = s->lds;
+  int p = 0;
+  auto take = [&](int n) { int o = p; p += align2(std::max(n, 0)); return o; };
+  for (int k = 0; k < 2; ++k) {
+    L.V[k] = take(nxM * nxM);
+    L.v[k] = take(nxM);
+    L.Vxt[k] = take(nxM * nthM);
+    L.Vtt[k] = take(nthM * nthM);
+    L.vt[k] = take(nthM);
+  }
+  const int stage_begin = p;
+  L.H = take(nwM * nwM);
+  L.h = take(nwM);
+  L.F = take(nxM * nwM);
+  L.fv = take(nxM);
+  L.P = take(std::max(nxM * nwM, nxM * nxM));
+  L.vp = take(nxM);
+  L.CD = take(ncM * nwM);
+  L.dd = take(ncM);
+  L.Gu = take(nuM * nthM);
+  L.Guh = take(nuM * nthM);
+  L.Gv = take(ncM * nthM);
+  L.M = take(nkM * nkM);
+  L.msub = take(nkM);
+  L.piv = take(264); // 512 pivots + 8 control ints
+  L.G = take(nkM * (1 + nxM + nthM));
+  L.Yth = take(nxM * nthM);
+  L.yff = take(nxM);
+  const int stage_end = p;
+  // initial-stage KKT aliases the per-stage buffers
+  p = stage_begin;
+  const int n0 = s->n0, nth0 = s->nth0;
+  L.k0mat = take(n0 * n0);
+  L.k0rhs = take(n0 * (1 + nth0));
+  L.k0sub = take(n0);
+  L.k0piv = take(264);
+  L.total = std::max(stage_end, p);
+  // forward kernel
+  p = 0;
+  L.fx = take(nxM);
+  L.fxn = take(nxM);
+  L.fth = take(nthM);
+  L.ftotal = p;
+  if (n0 > 512 || nkM > 512)
+    return fail(GAR_HIP_ERR_UNSUPPORTED, "KKT dimension above 512");
+  if ((int64_t)L.total * 8 > 160 * 1024)
+    return fail(GAR_HIP_ERR_UNSUPPORTED,
+                "stage dimensions need " + std::to_string((int64_t)L.total * 8) +
+                    " B of LDS (> 160 KiB per CU)");
+  return GAR_HIP_OK;
+}
+
+gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
+  gar::GenericParams P{};
+  P.meta = s->d_meta;
+  P.prob = s->d_prob;
+  P.fac = s->d_fac;
+  P.sol = s->d_sol;
+  P.init = s->d_init;
+  P.status = s->d_status;
+  P.boundary = s->d_bound_local;
+  P.csol = s->d_csol;
+  P.theta = nullptr;
+  P.prob_stride = s->prob_doubles;
+  P.fac_stride = s->fac_doubles;
+  P.sol_stride = s->sol_doubles;
+  P.init_stride = s->init_doubles;
+  P.boundary_stride = (long long)(s->leg_end - s->leg_begin) * s->tuple_doubles;
+  P.G0_off = s->G0_off;
+  P.g0_off = s->g0_off;
+  P.horizon = s->horizon;
+  P.nc0 = s->nc0;
+  P.nx0 = s->nx0;
+  P.nth0 = s->nth0;
+  P.num_legs = s->num_legs;
+  P.leg_begin = s->leg_begin;
+  P.local_legs = s->leg_end - s->leg_begin;
+  P.tuple_doubles = (int)s->tuple_doubles;
+  P.nxb = s->nxb;
+  P.mueq = mueq;
+  P.lds = s->lds;
+  return P;
+}
+
+int commit(gar_hip_solver *s) {
+  if (s->staged && s->dirty) {
+    HIP_TRY(hipMemcpyAsync(s->d_prob, s->h_prob,
+                           sizeof(double) * (size_t)s->prob_doubles * s->batch,
+                           hipMemcpyHostToDevice, s->stream));
+    s->dirty = false;
+  }
+  return GAR_HIP_OK;
+}
+
+int write_block(gar_hip_solver *s, int b, int64_t off, const double *src, int64_t n) {
+  if (n <= 0)
+    return GAR_HIP_OK;
+  if (s->staged) {
+    double *dst = s->h_prob + (int64_t)b * s->prob_doubles + off;
+    if (src)
+      std::memcpy(dst, src, sizeof(double) * (size_t)n);
+    else
+      std::memset(dst, 0, sizeof(double) * (size_t)n);
+    s->dirty = true;
+    return GAR_HIP_OK;
+  }
+  double *dst = s->d_prob + (int64_t)b * s->prob_doubles + off;
+  if (src)
+    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+  else
+    HIP_TRY(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)n, s->stream));
+  return GAR_HIP_OK;
+}
+
+int launch_backward(gar_hip_solver *s, double mueq) {
+  gar::GenericParams P = make_params(s, mueq);
+  const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
+  hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(256),
+                     (size_t)s->lds.total * sizeof(double), s->stream, P);
+  HIP_TRY(hipGetLastError());
+  return GAR_HIP_OK;
+}
+
+int launch_forward(gar_hip_solver *s, const double *theta_dev) {
+  gar::GenericParams P = make_params(s, 0.0);
+  P.theta = theta_dev;
+  const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
+  hipLaunchKernelGGL(gar::gar_forward_generic, grid, dim3(256),
+                     (size_t)s->lds.ftotal * sizeof(double), s->stream, P);
+  HIP_TRY(hipGetLastError());
+  return GAR_HIP_OK;
+}
+
+int launch_condensed(gar_hip_solver *s) {
+  gar::CondensedParams C{};
+  C.ball = s->d_bound_all;
+  C.prob = s->d_prob;
+  C.scratch = s->d_cscratch;
+  C.csol = s->d_csol;
+  C.status = s->d_status;
+  C.prob_stride = s->prob_doubles;
+  C.scratch_stride = s->cscratch_doubles;
+  C.G0_off = s->G0_off;
+  C.g0_off = s->g0_off;
+  C.batch = s->batch;
+  C.num_legs = s->num_legs;
+  C.legs_per_rank = s->legs_per_rank;
+  C.tuple_doubles = (int)s->tuple_doubles;
+  C.nxb = s->nxb;
+  C.nc0 = s->nc0;
+  C.nx0 = s->nx0;
+  C.max_refinement = s->max_refinement;
+  C.threshold = s->cond_threshold;
+  hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(256),
+                     (size_t)s->cond_lds_doubles * sizeof(double), s->stream, C);
+  HIP_TRY(hipGetLastError());
+  return GAR_HIP_OK;
+}
+
+int check_bt(const gar_hip_solver *s, int b, int t) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  if (b < 0 || b >= s->batch)
+    return fail(GAR_HIP_ERR_ARG, "problem index out of range");
+  if (t < 0 || t > s->horizon)
+    return fail(GAR_HIP_ERR_ARG, "stage index out of range");
+  return GAR_HIP_OK;
+}
+
+int d2h(gar_hip_solver *s, double *dst, const double *src, int64_t n) {
+  if (!dst || n <= 0)
+    return GAR_HIP_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+  return GAR_HIP_OK;
+}
+
+void free_device(gar_hip_solver *s) {
+  (void)hipFree(s->d_meta);
+  (void)hipFree(s->d_prob);
+  (void)hipFree(s->d_fac);
+  (void)hipFree(s->d_sol);
+  (void)hipFree(s->d_init);
+  (void)hipFree(s->d_theta);
+  (void)hipFree(s->d_status);
+  (void)hipFree(s->d_bound_local);
+  if (s->bound_all_owned)
+    (void)hipFree(s->d_bound_all);
+  (void)hipFree(s->d_csol);
+  (void)hipFree(s->d_cscratch);
+  if (s->h_prob)
+    (void)hipHostFree(s->h_prob);
+  s->d_meta = nullptr;
+  s->d_prob = s->d_fac = s->d_sol = s->d_init = s->d_theta = nullptr;
+  s->d_status = nullptr;
+  s->d_bound_local = s->d_bound_all = s->d_csol = s->d_cscratch = nullptr;
+  s->h_prob = nullptr;
+}
+
+int allocate(gar_hip_solver *s) {
+  const size_t B = (size_t)s->batch;
+  HIP_TRY(hipMalloc((void **)&s->d_meta, sizeof(gar_stage_meta) * s->meta.size()));
+  HIP_TRY(hipMemcpy(s->d_meta, s->meta.data(), sizeof(gar_stage_meta) * s->meta.size(),
+                    hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void **)&s->d_prob, sizeof(double) * (size_t)s->prob_doubles * B));
+  HIP_TRY(hipMemset(s->d_prob, 0, sizeof(double) * (size_t)s->prob_doubles * B));
+  HIP_TRY(hipMalloc((void **)&s->d_fac, sizeof(double) * (size_t)s->fac_doubles * B));
+  HIP_TRY(hipMemset(s->d_fac, 0, sizeof(double) * (size_t)s->fac_doubles * B));
+  HIP_TRY(hipMalloc((void **)&s->d_sol, sizeof(double) * (size_t)s->sol_doubles * B));
+  HIP_TRY(hipMemset(s->d_sol, 0, sizeof(double) * (size_t)s->sol_doubles * B));
+  HIP_TRY(hipMalloc((void **)&s->d_init, sizeof(double) * (size_t)s->init_doubles * B));
+  HIP_TRY(hipMemset(s->d_init, 0, sizeof(double) * (size_t)s->init_doubles * B));
+  HIP_TRY(hipMalloc((void **)&s->d_theta, sizeof(double) * (size_t)std::max(s->nth0, 1) * B));
+  HIP_TRY(hipMalloc((void **)&s->d_status, sizeof(int) * B));
+  HIP_TRY(hipMemset(s->d_status, 0, sizeof(int) * B));
+  if (s->num_legs > 1) {
+    const int local = s->leg_end - s->leg_begin;
+    const int nblk = 2 * s->num_legs;
+    const size_t bs = (size_t)s->nxb * s->nxb;
+    HIP_TRY(hipMalloc((void **)&s->d_bound_local, sizeof(double) * s->tuple_doubles * local * B));
+    if (local == s->num_legs) {
+      s->d_bound_all = s->d_bound_local;
+      s->bound_all_owned = false;
+    } else {
+      HIP_TRY(hipMalloc((void **)&s->d_bound_all,
+                        sizeof(double) * s->tuple_doubles * s->num_legs * B));
+      s->bound_all_owned = true;
+    }
+    HIP_TRY(hipMalloc((void **)&s->d_csol, sizeof(double) * (size_t)nblk * s->nxb * B));
+    s->cscratch_doubles = (int64_t)(4 * nblk * bs + 4 * (size_t)nblk * s->nxb + 4);
+    HIP_TRY(hipMalloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
+    s->cond_lds_doubles = (int)(2 * bs + s->nxb + 2 + (s->nxb + 16) / 2 + 2);
+  }
+  const size_t staging = sizeof(double) * (size_t)s->prob_doubles * B;
+  if (staging <= ((size_t)1 << 30)) {
+    HIP_TRY(hipHostMalloc((void **)&s->h_prob, staging, hipHostMallocDefault));
+    std::memset(s->h_prob, 0, staging);
+    s->staged = true;
+  }
+  // > 64 KiB of dynamic LDS needs the opt-in attribute
+  HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_backward_generic,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(s->lds.total * sizeof(double))));
+  if (s->num_legs > 1)
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_generic,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->cond_lds_doubles * sizeof(double))));
+  return GAR_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *gar_hip_version(void) { return "gar-hip 0.1 (gfx950)"; }
+const char *gar_hip_last_error(void) { return g_last_error.c_str(); }
+
+int gar_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int64_t gar_hip_knot_doubles(const int32_t d[5]) {
+  return gar_knot_doubles(d[0], d[1], d[2], d[3], d[4]);
+}
+int64_t gar_hip_factor_doubles(const int32_t d[5]) {
+  return gar_factor_doubles(d[0], d[1], d[2], d[3], d[4]);
+}
+
+gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon, const int32_t *dims5,
+                                              int nc0, int batch, int num_legs, int leg_begin,
+                                              int leg_end) {
+  if (horizon < 0 || !dims5 || nc0 < 0 || batch < 1 || num_legs < 1 || leg_begin < 0 ||
+      leg_end > num_legs || leg_begin >= leg_end) {
+    fail(GAR_HIP_ERR_ARG, "gar_hip_solver_create: bad argument");
+    return nullptr;
+  }
+  if (gar_hip_device_count() <= device) {
+    fail(GAR_HIP_ERR_DEVICE, "gar_hip_solver_create: no such HIP device (the HIP "
+                             "backend has no CPU fallback)");
+    return nullptr;
+  }
+  gar_hip_solver *s = new gar_hip_solver();
+  s->device = device;
+  s->horizon = horizon;
+  s->nc0 = nc0;
+  s->batch = batch;
+  s->num_legs = num_legs;
+  s->leg_begin = leg_begin;
+  s->leg_end = leg_end;
+  s->dims5.assign(dims5, dims5 + 5 * (horizon + 1));
+  if (hipSetDevice(device) != hipSuccess) {
+    fail(GAR_HIP_ERR_DEVICE, "hipSetDevice failed");
+    delete s;
+    return nullptr;
+  }
+  if (build_layout(s) != GAR_HIP_OK || plan_lds(s) != GAR_HIP_OK) {
+    delete s;
+    return nullptr;
+  }
+  if (num_legs > 1) {
+    const int local = leg_end - leg_begin;
+    if (num_legs % local != 0 || leg_begin % local != 0) {
+      fail(GAR_HIP_ERR_ARG, "legs must be split evenly over ranks");
+      delete s;
+      return nullptr;
+    }
+    s->legs_per_rank = local;
+    int nxb = 0;
+    for (const auto &m : s->meta)
+      nxb = std::max(nxb, std::max(m.nx, m.nx2));
+    if (nc0 > nxb) {
+      fail(GAR_HIP_ERR_UNSUPPORTED, "leg mode needs nc0 <= nx");
+      delete s;
+      return nullptr;
+    }
+    s->nxb = nxb;
+    s->tuple_doubles = 3 * (int64_t)nxb * nxb + 2 * nxb;
+  }
+  if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    fail(GAR_HIP_ERR_DEVICE, "hipStreamCreate failed");
+    delete s;
+    return nullptr;
+  }
+  s->stream = s->own_stream;
+  if (allocate(s) != GAR_HIP_OK) {
+    free_device(s);
+    (void)hipStreamDestroy(s->own_stream);
+    delete s;
+    return nullptr;
+  }
+  return s;
+}
+
+gar_hip_solver *gar_hip_solver_create(int device, int horizon, const int32_t *dims5, int nc0,
+                                      int batch, int num_legs) {
+  return gar_hip_solver_create_sharded(device, horizon, dims5, nc0, batch, num_legs, 0,
+                                       num_legs);
+}
+
+void gar_hip_solver_destroy(gar_hip_solver *s) {
+  if (!s)
+    return;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  free_device(s);
+  if (s->own_stream)
+    (void)hipStreamDestroy(s->own_stream);
+  delete s;
+}
+
+int gar_hip_set_stream(gar_hip_solver *s, void *hip_stream) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_sync(gar_hip_solver *s) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int64_t gar_hip_problem_doubles(const gar_hip_solver *s) { return s ? s->prob_doubles : 0; }
+int64_t gar_hip_factors_doubles(const gar_hip_solver *s) { return s ? s->fac_doubles : 0; }
+int64_t gar_hip_solution_doubles(const gar_hip_solver *s) { return s ? s->sol_doubles : 0; }
+int gar_hip_batch(const gar_hip_solver *s) { return s ? s->batch : 0; }
+int gar_hip_horizon(const gar_hip_solver *s) { return s ? s->horizon : -1; }
+const char *gar_hip_kernel_name(const gar_hip_solver *s) {
+  return s ? s->kernel_name.c_str() : "";
+}
+
+int gar_hip_stage_offsets(const gar_hip_solver *s, int t, int64_t out[6]) {
+  if (int rc = check_bt(s, 0, t))
+    return rc;
+  const gar_stage_meta &m = s->meta[t];
+  out[0] = m.in_off;
+  out[1] = m.fac_off;
+  out[2] = m.x_off;
+  out[3] = m.u_off;
+  out[4] = m.v_off;
+  out[5] = m.l_off;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_init_offsets(const gar_hip_solver *s, int64_t out[2]) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  out[0] = s->G0_off;
+  out[1] = s->g0_off;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const double *S,
+                         const double *R, const double *q, const double *r, const double *A,
+                         const double *B, const double *f, const double *C, const double *D,
+                         const double *d, const double *Gth, const double *Gx,
+                         const double *Gu, const double *Gv, const double *gamma) {
+  if (int rc = check_bt(s, b, t))
+    return rc;
+  const gar_stage_meta &m = s->meta[t];
+  const int nth_st = (m.flags & GAR_KNOT_HAS_PARAM) ? m.nth : 0;
+  const gar_knot_offsets o = gar_knot_layout(m.nx, m.nu, m.nc, m.nx2, nth_st);
+  const int64_t base = m.in_off;
+  const int nx = m.nx, nu = m.nu, nc = m.nc, nx2 = m.nx2;
+  if (!Q || !q || !A || !f || (nu > 0 && (!S || !R || !r || !B)))
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_stage: null block");
+  int rc = 0;
+  rc |= write_block(s, b, base + o.Q, Q, (int64_t)nx * nx);
+  rc |= write_block(s, b, base + o.S, S, (int64_t)nx * nu);
+  rc |= write_block(s, b, base + o.R, R, (int64_t)nu * nu);
+  rc |= write_block(s, b, base + o.q, q, nx);
+  rc |= write_block(s, b, base + o.r, r, nu);
+  rc |= write_block(s, b, base + o.A, A, (int64_t)nx2 * nx);
+  rc |= write_block(s, b, base + o.B, B, (int64_t)nx2 * nu);
+  rc |= write_block(s, b, base + o.f, f, nx2);
+  rc |= write_block(s, b, base + o.C, C, (int64_t)nc * nx);
+  rc |= write_block(s, b, base + o.D, D, (int64_t)nc * nu);
+  rc |= write_block(s, b, base + o.d, d, nc);
+  if (nth_st > 0) {
+    rc |= write_block(s, b, base + o.Gth, Gth, (int64_t)nth_st * nth_st);
+    rc |= write_block(s, b, base + o.Gx, Gx, (int64_t)nx * nth_st);
+    rc |= write_block(s, b, base + o.Gu, Gu, (int64_t)nu * nth_st);
+    rc |= write_block(s, b, base + o.Gv, Gv, (int64_t)nc * nth_st);
+    rc |= write_block(s, b, base + o.gamma, gamma, nth_st);
+  }
+  return rc ? GAR_HIP_ERR_DEVICE : GAR_HIP_OK;
+}
+
+int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g0) {
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  if (s->nc0 > 0 && (!G0 || !g0))
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_set_init: null block");
+  int rc = write_block(s, b, s->G0_off, G0, (int64_t)s->nc0 * s->nx0);
+  rc |= write_block(s, b, s->g0_off, g0, s->nc0);
+  return rc ? GAR_HIP_ERR_DEVICE : GAR_HIP_OK;
+}
+
+int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packed) {
+  if (!s || !packed || b0 < 0 || nb < 0 || b0 + nb > s->batch)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_packed: bad argument");
+  const size_t bytes = sizeof(double) * (size_t)s->prob_doubles * nb;
+  if (s->staged) {
+    std::memcpy(s->h_prob + (int64_t)b0 * s->prob_doubles, packed, bytes);
+    s->dirty = true;
+    return GAR_HIP_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(s->d_prob + (int64_t)b0 * s->prob_doubles, packed, bytes,
+                         hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int gar_hip_upload_packed_device(gar_hip_solver *s, int b0, int nb, const double *packed_dev) {
+  if (!s || !packed_dev || b0 < 0 || nb < 0 || b0 + nb > s->batch)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_packed_device: bad argument");
+  if (int rc = commit(s)) // staged host data first, then the device copy wins
+    return rc;
+  HIP_TRY(hipMemcpyAsync(s->d_prob + (int64_t)b0 * s->prob_doubles, packed_dev,
+                         sizeof(double) * (size_t)s->prob_doubles * nb, hipMemcpyDeviceToDevice,
+                         s->stream));
+  s->staged = false; // the device copy is now the source of truth
+  return GAR_HIP_OK;
+}
+
+int gar_hip_commit(gar_hip_solver *s) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  return commit(s);
+}
+
+double *gar_hip_device_problems(gar_hip_solver *s) { return s ? s->d_prob : nullptr; }
+double *gar_hip_device_factors(gar_hip_solver *s) { return s ? s->d_fac : nullptr; }
+double *gar_hip_device_solutions(gar_hip_solver *s) { return s ? s->d_sol : nullptr; }
+
+int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  if (int rc = commit(s))
+    return rc;
+  HIP_TRY(hipMemsetAsync(s->d_status, 0, sizeof(int) * (size_t)s->batch, s->stream));
+  return launch_backward(s, mueq);
+}
+
+int gar_hip_condensed_solve_async(gar_hip_solver *s) {
+  if (!s || s->num_legs < 2)
+    return fail(GAR_HIP_ERR_ARG, "condensed solve needs leg mode");
+  return launch_condensed(s);
+}
+
+int gar_hip_forward_legs_async(gar_hip_solver *s) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  return launch_forward(s, nullptr);
+}
+
+int gar_hip_backward_async(gar_hip_solver *s, double mueq) {
+  if (int rc = gar_hip_backward_legs_async(s, mueq))
+    return rc;
+  if (s->num_legs > 1) {
+    if (s->leg_end - s->leg_begin != s->num_legs)
+      return fail(GAR_HIP_ERR_ARG, "sharded solver: exchange boundaries, then call "
+                                   "gar_hip_condensed_solve_async");
+    return launch_condensed(s);
+  }
+  return GAR_HIP_OK;
+}
+
+int gar_hip_num_failed(gar_hip_solver *s) {
+  if (!s)
+    return 0;
+  std::vector<int> st((size_t)s->batch);
+  if (hipMemcpyAsync(st.data(), s->d_status, sizeof(int) * st.size(), hipMemcpyDeviceToHost,
+                     s->stream) != hipSuccess ||
+      hipStreamSynchronize(s->stream) != hipSuccess)
+    return -1;
+  int n = 0;
+  for (int v : st)
+    n += (v != 0);
+  s->last_failed = n;
+  return n;
+}
+
+int gar_hip_backward(gar_hip_solver *s, double mueq) {
+  if (int rc = gar_hip_backward_async(s, mueq))
+    return rc;
+  const int nf = gar_hip_num_failed(s);
+  if (nf < 0)
+    return fail(GAR_HIP_ERR_DEVICE, std::string("backward: ") +
+                                        hipGetErrorString(hipGetLastError()));
+  if (nf > 0)
+    return fail(GAR_HIP_ERR_FACTOR, "Failed stage LDL factorization (" + std::to_string(nf) +
+                                        " problem(s))");
+  return GAR_HIP_OK;
+}
+
+int gar_hip_forward_async(gar_hip_solver *s, const double *theta_device) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  return launch_forward(s, theta_device);
+}
+
+int gar_hip_forward(gar_hip_solver *s, const double *theta) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  const double *th = nullptr;
+  if (theta && s->nth0 > 0 && s->num_legs == 1) {
+    HIP_TRY(hipMemcpyAsync(s->d_theta, theta, sizeof(double) * (size_t)s->nth0 * s->batch,
+                           hipMemcpyHostToDevice, s->stream));
+    th = s->d_theta;
+  }
+  if (int rc = launch_forward(s, th))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int64_t gar_hip_boundary_doubles(const gar_hip_solver *s) { return s ? s->tuple_doubles : 0; }
+double *gar_hip_device_boundary_local(gar_hip_solver *s) { return s ? s->d_bound_local : nullptr; }
+double *gar_hip_device_boundary_all(gar_hip_solver *s) { return s ? s->d_bound_all : nullptr; }
+
+int gar_hip_set_refinement(gar_hip_solver *s, double thr, int max_steps) {
+  if (!s || max_steps < 0)
+    return fail(GAR_HIP_ERR_ARG, "bad refinement settings");
+  s->cond_threshold = thr;
+  s->max_refinement = max_steps;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, double *vs,
+                         double *lbdas) {
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  const double *base = s->d_sol + (int64_t)b * s->sol_doubles;
+  int rc = d2h(s, xs, base + s->sol_x, s->sol_u - s->sol_x);
+  rc |= d2h(s, us, base + s->sol_u, s->sol_v - s->sol_u);
+  rc |= d2h(s, vs, base + s->sol_v, s->sol_l - s->sol_v);
+  int64_t nl = s->nc0;
+  for (int t = 0; t < s->horizon; ++t)
+    nl += s->meta[t].nx2;
+  rc |= d2h(s, lbdas, base + s->sol_l, nl);
+  if (rc)
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, double *fth) {
+  if (int rc = check_bt(s, b, t))
+    return rc;
+  const gar_stage_meta &m = s->meta[t];
+  const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, m.nx2, m.nth);
+  const double *rec = s->d_fac + (int64_t)b * s->fac_doubles + m.fac_off;
+  const int64_t nr = (int64_t)m.nu + m.nc + m.nx2;
+  int rc = d2h(s, ff, rec + o.ff, nr);
+  rc |= d2h(s, fb, rec + o.fb, nr * m.nx);
+  rc |= d2h(s, fth, rec + o.fth, nr * m.nth);
+  if (rc)
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, double *Vxt,
+                      double *Vtt, double *vt) {
+  if (int rc = check_bt(s, b, t))
+    return rc;
+  const gar_stage_meta &m = s->meta[t];
+  const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, m.nx2, m.nth);
+  const double *rec = s->d_fac + (int64_t)b * s->fac_doubles + m.fac_off;
+  int rc = d2h(s, Vxx, rec + o.Vxx, (int64_t)m.nx * m.nx);
+  rc |= d2h(s, vx, rec + o.vx, m.nx);
+  rc |= d2h(s, Vxt, rec + o.Vxt, (int64_t)m.nx * m.nth);
+  rc |= d2h(s, Vtt, rec + o.Vtt, (int64_t)m.nth * m.nth);
+  rc |= d2h(s, vt, rec + o.vt, m.nth);
+  if (rc)
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff, double *kkt0_fth,
+                        double *thGrad, double *thHess) {
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  const double *io = s->d_init + (int64_t)b * s->init_doubles;
+  const int64_t n0 = s->n0, nth = s->nth0;
+  int rc = d2h(s, kkt0_ff, io, n0);
+  rc |= d2h(s, kkt0_fth, io + n0, n0 * nth);
+  rc |= d2h(s, thGrad, io + n0 + n0 * nth, nth);
+  rc |= d2h(s, thHess, io + n0 + n0 * nth + nth, nth * nth);
+  if (rc)
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_factors(gar_hip_solver *s, int b, double *out) {
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  if (int rc = d2h(s, out, s->d_fac + (int64_t)b * s->fac_doubles, s->fac_doubles))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int gar_hip_collapse_feedback(gar_hip_solver *s) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  if (s->num_legs < 2 || s->leg_begin != 0)
+    return GAR_HIP_OK; // no-op except Parallel (riccati-base.hpp:33)
+  hipLaunchKernelGGL(gar::gar_collapse_feedback, dim3((unsigned)s->batch), dim3(256), 0,
+                     s->stream, s->d_meta, s->d_fac, (long long)s->fac_doubles, s->batch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
+  if (!s || !d)
+    return fail(GAR_HIP_ERR_ARG, "bad argument");
+  const int N = s->horizon;
+  if (N < 1)
+    return GAR_HIP_OK;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  // new dims sequence: old[1..N-1], new knot, old[N]  (rotate_vec_left(datas,0,1) +
+  // re-created last-but-one factor, proximal-riccati.hxx:79-86)
+  std::vector<int32_t> nd(s->dims5.size());
+  for (int t = 0; t + 1 < N; ++t)
+    std::copy(&s->dims5[5 * (t + 1)], &s->dims5[5 * (t + 1)] + 5, &nd[5 * t]);
+  std::copy(d, d + 5, &nd[5 * (N - 1)]);
+  std::copy(&s->dims5[5 * N], &s->dims5[5 * N] + 5, &nd[5 * N]);
+  bool uniform = true;
+  for (int t = 0; t < N; ++t)
+    for (int k = 0; k < 5; ++k)
+      uniform &= (nd[5 * t + k] == d[k]) && (s->dims5[5 * t + k] == d[k]);
+  if (uniform && s->num_legs == 1) {
+    // device ring rotate: records of stages 1..N-1 slide to 0..N-2
+    const int64_t in0 = s->meta[0].in_off, in1 = s->meta[1].in_off, inL = s->meta[N].in_off;
+    const int64_t f0 = s->meta[0].fac_off, f1 = s->meta[1].fac_off, fL = s->meta[N].fac_off;
+    for (int b = 0; b < s->batch; ++b) {
+      double *pb = s->d_prob + (int64_t)b * s->prob_doubles;
+      double *fb = s->d_fac + (int64_t)b * s->fac_doubles;
+      // overlapping ranges: stage through the solution scratch is not possible in
+      // general, so slide record by record (front to back is overlap-safe per record)
+      for (int t = 0; t + 1 < N; ++t) {
+        HIP_TRY(hipMemcpyAsync(pb + in0 + (int64_t)t * (in1 - in0), pb + in1 + (int64_t)t * (in1 - in0),
+                               sizeof(double) * (size_t)(in1 - in0), hipMemcpyDeviceToDevice,
+                               s->stream));
+        HIP_TRY(hipMemcpyAsync(fb + f0 + (int64_t)t * (f1 - f0), fb + f1 + (int64_t)t * (f1 - f0),
+                               sizeof(double) * (size_t)(f1 - f0), hipMemcpyDeviceToDevice,
+                               s->stream));
+      }
+      HIP_TRY(hipMemsetAsync(pb + inL - (in1 - in0), 0, sizeof(double) * (size_t)(in1 - in0), s->stream));
+      HIP_TRY(hipMemsetAsync(fb + fL - (f1 - f0), 0, sizeof(double) * (size_t)(f1 - f0), s->stream));
+    }
+    if (s->staged) {
+      for (int b = 0; b < s->batch; ++b) {
+        double *pb = s->h_prob + (int64_t)b * s->prob_doubles;
+        std::memmove(pb + in0, pb + in1, sizeof(double) * (size_t)(inL - in1));
+        std::memset(pb + inL - (in1 - in0), 0, sizeof(double) * (size_t)(in1 - in0));
+      }
+    }
+    HIP_TRY(hipMemsetAsync(s->d_init, 0, sizeof(double) * (size_t)s->init_doubles * s->batch, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return GAR_HIP_OK;
+  }
+  // dimensions changed (or leg mode: "just reinitialise everything",
+  // parallel-solver.hxx:246-258): rebuild the layout and the buffers
+  s->dims5 = nd;
+  free_device(s);
+  s->staged = s->dirty = false;
+  if (int rc = build_layout(s))
+    return rc;
+  if (int rc = plan_lds(s))
+    return rc;
+  return allocate(s);
+}
+
+} // extern "C"

@@ -1,0 +1,472 @@
+"""Host-side mirror of the reference's ``aligator.gar`` solver surface on top of
+the C ABI (include/gar_hip.h).
+
+Same names, argument meaning and error behaviour as the reference:
+
+* ``RiccatiSolverBase``       <- gar::RiccatiSolverBase   (gar/riccati-base.hpp:13-37)
+* ``ProximalRiccatiSolver``   <- gar::ProximalRiccatiSolver (gar/proximal-riccati.hpp:17-47;
+  Python binding bindings/python/src/gar/expose-prox-riccati.cpp:14-54)
+* ``ParallelRiccatiSolver``   <- gar::ParallelRiccatiSolver (gar/parallel-solver.hpp:26-110;
+  bindings/python/src/gar/expose-parallel.cpp:16-24)
+* ``BatchedRiccatiSolver``    -- new: `batch` independent problems of identical
+  dimensions swept by one launch (the throughput axis).
+
+All arithmetic happens in the HIP kernels; this file only packs / unpacks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .lqr import (BLOCK_NAMES, LqrKnot, LqrProblem, block_shapes,
+                  lqrComputeKktError, lqrInitializeSolution, lqrNumRows)
+
+__all__ = ["LqrKnot", "LqrProblem", "RiccatiSolverBase", "ProximalRiccatiSolver",
+           "ParallelRiccatiSolver", "BatchedRiccatiSolver", "lqrInitializeSolution",
+           "lqrComputeKktError", "lqrNumRows", "get_work"]
+
+_PD = C.POINTER(C.c_double)
+GAR_HIP_ERR_FACTOR = -4
+
+
+def _ptr(a: Optional[np.ndarray]):
+    if a is None or a.size == 0:
+        return None
+    return a.ctypes.data_as(_PD)
+
+
+def _f64(a, order="F"):
+    return np.require(a, dtype=np.float64, requirements=[order])
+
+
+def get_work(horz: int, tid: int, num_threads: int):
+    """gar/parallel-solver.hxx:23-28."""
+    return (tid * (horz + 1) // num_threads, (tid + 1) * (horz + 1) // num_threads)
+
+
+class _ValueView:
+    """StageFactor::CostToGo (gar/riccati-kernel.hpp:33-39)."""
+    __slots__ = ("Vxx", "vx", "Vxt", "Vtt", "vt")
+
+
+class _FactorView:
+    """The surviving outputs of gar::StageFactor (riccati-kernel.hpp:88-101)."""
+    __slots__ = ("nx", "nu", "nc", "nx2", "nth", "ff", "fb", "fth", "vm")
+
+
+class _Kkt0View:
+    __slots__ = ("ff", "fth")
+
+
+class BatchedRiccatiSolver:
+    """`batch` LQ problems with the same per-stage dimensions on one GPU.
+
+    dims: (horizon+1) x (nx, nu, nc, nx2, nth).  num_legs = 1 is the serial
+    ProximalRiccatiSolver algorithm, >= 2 the ParallelRiccatiSolver one.
+    """
+
+    def __init__(self, dims, nc0: int, batch: int = 1, num_legs: int = 1, device: int = 0,
+                 leg_range=None, lib_path: Optional[str] = None):
+        self._L = _lib.load(lib_path)
+        self.dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int32).reshape(-1, 5))
+        self.horizon = self.dims.shape[0] - 1
+        self.nc0, self.batch, self.num_legs = int(nc0), int(batch), int(num_legs)
+        lb, le = leg_range if leg_range is not None else (0, self.num_legs)
+        self._h = self._L.gar_hip_solver_create_sharded(
+            int(device), self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
+            self.nc0, self.batch, self.num_legs, int(lb), int(le))
+        if not self._h:
+            raise RuntimeError(self._err())
+        self._refresh_layout()
+
+    # ---- plumbing ------------------------------------------------------------
+    def _err(self) -> str:
+        return self._L.gar_hip_last_error().decode()
+
+    def _check(self, rc: int):
+        if rc == GAR_HIP_ERR_FACTOR:
+            # the reference throws ALIGATOR_RUNTIME_ERROR (riccati-kernel.hxx:239-241)
+            raise RuntimeError(self._err())
+        if rc != 0:
+            raise RuntimeError(f"gar_hip error {rc}: {self._err()}")
+
+    def _refresh_layout(self):
+        L, h = self._L, self._h
+        self.problem_doubles = L.gar_hip_problem_doubles(h)
+        self.factors_doubles = L.gar_hip_factors_doubles(h)
+        self.solution_doubles = L.gar_hip_solution_doubles(h)
+        offs = np.zeros((self.horizon + 1, 6), dtype=np.int64)
+        for t in range(self.horizon + 1):
+            self._check(L.gar_hip_stage_offsets(h, t, offs[t].ctypes.data_as(C.POINTER(C.c_int64))))
+        self.stage_offsets = offs
+        io = np.zeros(2, dtype=np.int64)
+        self._check(L.gar_hip_init_offsets(h, io.ctypes.data_as(C.POINTER(C.c_int64))))
+        self.G0_off, self.g0_off = int(io[0]), int(io[1])
+        self.kernel_name = L.gar_hip_kernel_name(h).decode()
+        self._factors_cache = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gar_hip_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._L.gar_hip_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def sync(self):
+        self._check(self._L.gar_hip_sync(self._h))
+
+    # ---- packing ---------------------------------------------------------------
+    def effective_nth(self, t: int) -> int:
+        """nth the kernels use for stage t (leg mode re-parameterises, like
+        ParallelRiccatiSolver::initialize, parallel-solver.hxx:52-60)."""
+        if self.num_legs == 1:
+            return int(self.dims[t, 4])
+        for i in range(self.num_legs):
+            b, e = get_work(self.horizon, i, self.num_legs)
+            if b <= t < e:
+                return 0 if i == self.num_legs - 1 else int(self.dims[e - 1, 3])
+        raise IndexError(t)
+
+    def pack(self, problem: LqrProblem) -> np.ndarray:
+        """One problem as the contiguous device record (csrc/gar_layout.h)."""
+        buf = np.zeros(self.problem_doubles)
+        nx0 = int(self.dims[0, 0])
+        buf[self.G0_off:self.G0_off + self.nc0 * nx0] = _f64(problem.G0).ravel(order="F")
+        buf[self.g0_off:self.g0_off + self.nc0] = problem.g0
+        for t, k in enumerate(problem.stages):
+            nx, nu, nc, nx2, nth = (int(v) for v in self.dims[t])
+            if (k.nx, k.nu, k.nc, k.nx2) != (nx, nu, nc, nx2):
+                raise ValueError(f"knot {t}: dimensions differ from the solver's")
+            stored = nth if self.num_legs == 1 else 0
+            p = int(self.stage_offsets[t, 0])
+            for name, shp in block_shapes(nx, nu, nc, nx2, stored).items():
+                n = int(np.prod(shp))
+                if name in ("Gth", "Gx", "Gu", "Gv", "gamma") and stored == 0:
+                    continue
+                buf[p:p + n] = _f64(getattr(k, name)).ravel(order="F")
+                p += n
+        return buf
+
+    def unpack(self, buf: np.ndarray) -> LqrProblem:
+        """Inverse of pack(): a host LqrProblem from one packed device record."""
+        knots = []
+        for t in range(self.horizon + 1):
+            nx, nu, nc, nx2, nth = (int(v) for v in self.dims[t])
+            stored = nth if self.num_legs == 1 else 0
+            k = LqrKnot(nx, nu, nc, nx2, stored)
+            p = int(self.stage_offsets[t, 0])
+            for name, shp in block_shapes(nx, nu, nc, nx2, stored).items():
+                n = int(np.prod(shp))
+                getattr(k, name)[...] = buf[p:p + n].reshape(shp, order="F")
+                p += n
+            knots.append(k)
+        prob = LqrProblem(knots, self.nc0)
+        nx0 = int(self.dims[0, 0])
+        prob.G0[...] = buf[self.G0_off:self.G0_off + self.nc0 * nx0].reshape((self.nc0, nx0), order="F")
+        prob.g0[...] = buf[self.g0_off:self.g0_off + self.nc0]
+        return prob
+
+    def upload(self, problems: Sequence[LqrProblem], b0: int = 0):
+        packed = np.concatenate([self.pack(p) for p in problems])
+        self.upload_packed(packed, b0, len(problems))
+
+    def upload_packed(self, packed: np.ndarray, b0: int = 0, nb: Optional[int] = None):
+        packed = np.ascontiguousarray(packed, dtype=np.float64)
+        nb = packed.size // self.problem_doubles if nb is None else nb
+        self._check(self._L.gar_hip_upload_packed(self._h, b0, nb, _ptr(packed)))
+
+    def upload_packed_device(self, dev_ptr: int, b0: int = 0, nb: Optional[int] = None):
+        """`dev_ptr`: device address of nb packed problems (e.g. a torch tensor's data_ptr())."""
+        nb = self.batch - b0 if nb is None else nb
+        self._check(self._L.gar_hip_upload_packed_device(self._h, b0, nb, C.c_void_p(dev_ptr)))
+
+    def device_pointers(self):
+        """(problems, factors, solutions) device addresses for device-resident producers."""
+        L, h = self._L, self._h
+        return (L.gar_hip_device_problems(h), L.gar_hip_device_factors(h),
+                L.gar_hip_device_solutions(h))
+
+    def upload_knot(self, b: int, t: int, k: LqrKnot):
+        """gar_hip_upload_stage: the 16 separately allocated blocks of LqrKnotTpl."""
+        a = {n: _f64(getattr(k, n)) for n in BLOCK_NAMES}
+        self._check(self._L.gar_hip_upload_stage(self._h, b, t, *[_ptr(a[n]) for n in BLOCK_NAMES]))
+
+    def set_init(self, b: int, G0, g0):
+        G0, g0 = _f64(G0), _f64(g0)
+        self._check(self._L.gar_hip_set_init(self._h, b, _ptr(G0), _ptr(g0)))
+
+    # ---- the sweep ---------------------------------------------------------------
+    def backward(self, mueq: float) -> bool:
+        self._factors_cache = {}
+        self._check(self._L.gar_hip_backward(self._h, float(mueq)))
+        return True
+
+    def forward(self, theta: Optional[np.ndarray] = None) -> bool:
+        th = None
+        if theta is not None:
+            theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1)
+            th = _ptr(theta)
+        self._check(self._L.gar_hip_forward(self._h, th))
+        return True
+
+    def backward_async(self, mueq: float):
+        self._factors_cache = {}
+        self._check(self._L.gar_hip_backward_async(self._h, float(mueq)))
+
+    def forward_async(self, theta_device_ptr: int = 0):
+        self._check(self._L.gar_hip_forward_async(self._h, C.c_void_p(theta_device_ptr)))
+
+    def num_failed(self) -> int:
+        return self._L.gar_hip_num_failed(self._h)
+
+    def set_refinement(self, threshold: float, max_steps: int):
+        self._check(self._L.gar_hip_set_refinement(self._h, float(threshold), int(max_steps)))
+
+    def collapse_feedback(self):
+        self._factors_cache = {}
+        self._check(self._L.gar_hip_collapse_feedback(self._h))
+
+    # ---- results -------------------------------------------------------------------
+    def solution(self, b: int = 0):
+        """-> (xs, us, vs, lbdas) as lists of per-stage vectors
+        (the shape lqrInitializeSolution returns, gar/utils.hpp:114-142)."""
+        d = self.dims
+        N = self.horizon
+        X = np.zeros(int(d[:, 0].sum()))
+        U = np.zeros(int(d[:, 1].sum()))
+        V = np.zeros(int(d[:, 2].sum()))
+        Lb = np.zeros(self.nc0 + int(d[:N, 3].sum()))
+        self._check(self._L.gar_hip_get_solution(self._h, b, _ptr(X), _ptr(U), _ptr(V), _ptr(Lb)))
+        xs = list(np.split(X, np.cumsum(d[:, 0])[:-1]))
+        us = [u for u in np.split(U, np.cumsum(d[:, 1])[:-1])]
+        vs = list(np.split(V, np.cumsum(d[:, 2])[:-1]))
+        ldim = np.concatenate([[self.nc0], d[:N, 3]])
+        lbdas = list(np.split(Lb, np.cumsum(ldim)[:-1]))
+        if d[N, 1] == 0:
+            us.pop()
+        return xs, us, vs, lbdas
+
+    def factor(self, t: int, b: int = 0) -> _FactorView:
+        key = (b, t)
+        if key in self._factors_cache:
+            return self._factors_cache[key]
+        nx, nu, nc, nx2, _ = (int(v) for v in self.dims[t])
+        nth = self.effective_nth(t)
+        nr = nu + nc + nx2
+        f = _FactorView()
+        f.nx, f.nu, f.nc, f.nx2, f.nth = nx, nu, nc, nx2, nth
+        f.ff = np.zeros(nr)
+        f.fb = np.zeros((nr, nx))
+        f.fth = np.zeros((nr, nth))
+        self._check(self._L.gar_hip_get_gains(self._h, b, t, _ptr(f.ff), _ptr(f.fb), _ptr(f.fth)))
+        vm = _ValueView()
+        vm.Vxx = np.zeros((nx, nx), order="F")
+        vm.vx = np.zeros(nx)
+        vm.Vxt = np.zeros((nx, nth), order="F")
+        vm.Vtt = np.zeros((nth, nth), order="F")
+        vm.vt = np.zeros(nth)
+        self._check(self._L.gar_hip_get_value(self._h, b, t, _ptr(vm.Vxx), _ptr(vm.vx),
+                                              _ptr(vm.Vxt), _ptr(vm.Vtt), _ptr(vm.vt)))
+        f.vm = vm
+        self._factors_cache[key] = f
+        return f
+
+    def initial(self, b: int = 0):
+        """-> (kkt0.ff, kkt0.fth, thGrad, thHess) (proximal-riccati.hpp:40-43)."""
+        nx0 = int(self.dims[0, 0])
+        nth = self.effective_nth(0)
+        n0 = nx0 + self.nc0
+        ff, fth = np.zeros(n0), np.zeros((n0, nth))
+        g, H = np.zeros(nth), np.zeros((nth, nth), order="F")
+        self._check(self._L.gar_hip_get_initial(self._h, b, _ptr(ff), _ptr(fth), _ptr(g), _ptr(H)))
+        return ff, fth, g, H
+
+    def cycle_append(self, dims5):
+        d = np.ascontiguousarray(np.asarray(dims5, dtype=np.int32))
+        self._check(self._L.gar_hip_cycle_append(self._h, d.ctypes.data_as(C.POINTER(C.c_int32))))
+        N = self.horizon
+        if N >= 1:
+            nd = self.dims.copy()
+            nd[:N - 1] = self.dims[1:N]
+            nd[N - 1] = d
+            self.dims = nd
+        self._refresh_layout()
+
+
+class RiccatiSolverBase:
+    """gar::RiccatiSolverBase (gar/riccati-base.hpp:13-37)."""
+
+    def backward(self, mueq: float) -> bool:
+        raise NotImplementedError
+
+    def forward(self, xs, us, vs, lbdas, theta=None) -> bool:
+        raise NotImplementedError
+
+    def cycleAppend(self, knot: LqrKnot) -> None:
+        raise NotImplementedError
+
+    def collapseFeedback(self) -> None:
+        pass
+
+    def getFeedforward(self, i: int) -> np.ndarray:
+        raise NotImplementedError
+
+    def getFeedback(self, i: int) -> np.ndarray:
+        raise NotImplementedError
+
+
+class _HipSolver(RiccatiSolverBase):
+    def __init__(self, problem: LqrProblem, num_legs: int, device: int, lib_path):
+        self.problem_ = problem  # non-owning, re-read on every backward()
+        dims = [k.dims for k in problem.stages]
+        self._num_legs = num_legs
+        self._device, self._lib_path = device, lib_path
+        self._make(dims)
+
+    def _make(self, dims):
+        if self._num_legs > 1:
+            dims = [(nx, nu, nc, nx2, 0) for (nx, nu, nc, nx2, _) in dims]
+        self._impl = BatchedRiccatiSolver(dims, self.problem_.nc0, 1, self._num_legs,
+                                          self._device, lib_path=self._lib_path)
+
+    class _Datas:
+        def __init__(self, impl):
+            self._impl = impl
+
+        def __getitem__(self, t) -> _FactorView:
+            if t < 0:
+                t += self._impl.horizon + 1
+            return self._impl.factor(t)
+
+        def __len__(self):
+            return self._impl.horizon + 1
+
+    @property
+    def datas(self):
+        return _HipSolver._Datas(self._impl)
+
+    def _upload(self):
+        p = self.problem_
+        if p.horizon != self._impl.horizon:
+            raise ValueError("problem horizon changed; create a new solver")
+        for t, k in enumerate(p.stages):
+            self._impl.upload_knot(0, t, k)
+        self._impl.set_init(0, p.G0, p.g0)
+
+    def forward(self, xs, us, vs, lbdas, theta=None) -> bool:
+        self._impl.forward(theta)
+        X, U, V, Lb = self._impl.solution(0)
+        for dst, src in ((xs, X), (us, U), (vs, V), (lbdas, Lb)):
+            for i in range(min(len(dst), len(src))):
+                dst[i][...] = src[i]
+        return True
+
+    def getFeedforward(self, i: int) -> np.ndarray:
+        return self._impl.factor(i).ff
+
+    def getFeedback(self, i: int) -> np.ndarray:
+        return self._impl.factor(i).fb
+
+    @property
+    def kernel_name(self):
+        return self._impl.kernel_name
+
+
+class ProximalRiccatiSolver(_HipSolver):
+    """gar::ProximalRiccatiSolver on the MI355X backend (serial in time)."""
+
+    def __init__(self, problem: LqrProblem, device: int = 0, lib_path=None):
+        super().__init__(problem, 1, device, lib_path)
+
+    def backward(self, mueq: float) -> bool:
+        self._upload()
+        return self._impl.backward(mueq)
+
+    @property
+    def kkt0(self):
+        k = _Kkt0View()
+        k.ff, k.fth, _, _ = self._impl.initial(0)
+        return k
+
+    @property
+    def thGrad(self):
+        return self._impl.initial(0)[2]
+
+    @property
+    def thHess(self):
+        return self._impl.initial(0)[3]
+
+    def cycleAppend(self, knot: LqrKnot) -> None:
+        """proximal-riccati.hxx:79-86."""
+        self._impl.cycle_append(knot.dims)
+
+
+class ParallelRiccatiSolver(_HipSolver):
+    """gar::ParallelRiccatiSolver: `num_threads` legs, one workgroup per leg.
+
+    Like the reference, construction MUTATES the caller's problem: every knot of
+    a non-final leg is re-parameterised with nth = nx (parallel-solver.hxx:52-60)
+    and backward() rewrites Gx, Gu, Gth, gamma of each leg-end knot (:136-147).
+    The device records keep this parameterisation implicit.
+    """
+
+    def __init__(self, problem: LqrProblem, num_threads: int, device: int = 0, lib_path=None):
+        if num_threads < 2:
+            raise RuntimeError(f"(ParallelRiccatiSolver) numThreads ({num_threads}) should be "
+                               "greater than or equal to 2.")  # parallel-solver.hxx:42-46
+        self.numThreads_ = int(num_threads)
+        self.condensedThreshold = 1e-10   # parallel-solver.hpp:92
+        self.maxRefinementSteps = 5       # parallel-solver.hpp:94
+        self._parameterize(problem)
+        super().__init__(problem, self.numThreads_, device, lib_path)
+
+    def getNumThreads(self) -> int:
+        return self.numThreads_
+
+    def _parameterize(self, problem: LqrProblem):
+        N = problem.horizon
+        for i in range(self.numThreads_ - 1):
+            i0, i1 = get_work(N, i, self.numThreads_)
+            nth = problem.stages[i1 - 1].nx2
+            for t in range(i0, i1):
+                problem.stages[t].addParameterization(nth)
+
+    def backward(self, mueq: float) -> bool:
+        p = self.problem_
+        N = p.horizon
+        for i in range(self.numThreads_ - 1):  # configure_knot (:136-147)
+            _, end = get_work(N, i, self.numThreads_)
+            k = p.stages[end - 1]
+            k.Gx[...] = k.A.T
+            k.Gu[...] = k.B.T
+            k.Gth[...] = 0.0
+            k.gamma[...] = k.f
+        self._upload()
+        self._impl.set_refinement(self.condensedThreshold, self.maxRefinementSteps)
+        return self._impl.backward(mueq)
+
+    def forward(self, xs, us, vs, lbdas, theta=None) -> bool:
+        return super().forward(xs, us, vs, lbdas, None)  # theta ignored (:209-212)
+
+    def collapseFeedback(self) -> None:
+        self._impl.collapse_feedback()
+
+    def cycleAppend(self, knot: LqrKnot) -> None:
+        """parallel-solver.hxx:246-258: drop the parameterisation, re-initialise."""
+        self.problem_.addParameterization(0)
+        self._parameterize(self.problem_)
+        self._make([k.dims for k in self.problem_.stages])

@@ -1,0 +1,92 @@
+"""Device-side synthetic LQ problems (torch is plumbing here: RNG + batched
+matmul on the GPU, written straight into the packed device records).
+
+Same distributions as aligator_amd.synth (which restates
+tests/gar/test_util.cpp:14-76): generator "F" (faithful) or "W"
+(well-conditioned), every knot of every problem drawn independently, so the
+timed sweep streams distinct data from HBM (no cache-resident replicas).
+Only uniform-dimension problems (nc = nth = 0) are generated here.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .lqr import LqrProblem
+
+
+def _colmajor(m: torch.Tensor) -> torch.Tensor:
+    """[..., r, c] -> [..., r*c] in column-major order."""
+    return m.transpose(-1, -2).reshape(*m.shape[:-2], m.shape[-2] * m.shape[-1])
+
+
+def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = True,
+                  chunk: int = 64, keep=(0, -1)):
+    """Generate `solver.batch` problems on the GPU and load them into the solver.
+    Keeps host copies of the problems listed in `keep` (for oracle spot checks)."""
+    d = solver.dims
+    N = solver.horizon
+    nx, nu = int(d[0, 0]), int(d[0, 1])
+    assert N >= 1 and (d[:N] == d[0]).all() and d[0, 2] == 0 and d[0, 4] == 0 and d[N, 1] == 0
+    assert solver.nc0 == nx
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    f64 = torch.float64
+    rec = int(solver.stage_offsets[1, 0] - solver.stage_offsets[0, 0])
+    off0 = int(solver.stage_offsets[0, 0])
+    offN = int(solver.stage_offsets[N, 0])
+    P = solver.problem_doubles
+    nw = nx + nu
+    keep_idx = sorted({k % solver.batch for k in keep})
+    solver._host_samples = {}
+
+    def randn(*s):
+        return torch.randn(*s, generator=gen, device=dev, dtype=f64)
+
+    def randu(*s):
+        return torch.rand(*s, generator=gen, device=dev, dtype=f64) * 2.0 - 1.0
+
+    for b0 in range(0, solver.batch, chunk):
+        nb = min(chunk, solver.batch - b0)
+        buf = torch.zeros(nb, P, device=dev, dtype=f64)
+        # G0 = -I, g0 = x0 = 0   (tests/gar/test_util.cpp:72-74)
+        G0 = -torch.eye(nx, device=dev, dtype=f64)
+        buf[:, solver.G0_off:solver.G0_off + nx * nx] = _colmajor(G0)
+        root = randn(nb, N, nw, nw + 1)
+        qsr = root @ root.transpose(-1, -2) / max(nx, nu)
+        Q = qsr[..., :nx, :nx]
+        if singular:
+            r2 = randn(nb, N, nx, int(0.8 * nw))
+            Q = r2 @ r2.transpose(-1, -2)
+        S = qsr[..., :nx, nx:]
+        R = qsr[..., nx:, nx:].clone()
+        R.diagonal(dim1=-2, dim2=-1).mul_(1.0 + 1e-6)
+        if mode == "F":
+            A, B = randu(nb, N, nx, nx), randu(nb, N, nx, nu)
+        else:
+            A = torch.eye(nx, device=dev, dtype=f64) + 0.1 * randu(nb, N, nx, nx)
+            B = 0.5 * randu(nb, N, nx, nu)
+        stage = torch.cat([_colmajor(Q), _colmajor(S), _colmajor(R), randu(nb, N, nx),
+                           randu(nb, N, nu), _colmajor(A), _colmajor(B), randn(nb, N, nx)], dim=-1)
+        assert stage.shape[-1] <= rec
+        view = buf[:, off0:off0 + N * rec].view(nb, N, rec)
+        view[..., :stage.shape[-1]] = stage
+        # terminal knot: nu = 0, non-singular Q (test_util.cpp:69)
+        rt = randn(nb, nx, nx + 1)
+        Qt = rt @ rt.transpose(-1, -2) / nx
+        At = randu(nb, nx, nx) if mode == "F" else (torch.eye(nx, device=dev, dtype=f64) + 0.1 * randu(nb, nx, nx))
+        term = torch.cat([_colmajor(Qt), randu(nb, nx), _colmajor(At), randn(nb, nx)], dim=-1)
+        buf[:, offN:offN + term.shape[-1]] = term
+        solver.upload_packed_device(buf.data_ptr(), b0, nb)
+        for k in keep_idx:
+            if b0 <= k < b0 + nb:
+                solver._host_samples[k] = buf[k - b0].cpu().numpy()
+        torch.cuda.synchronize()
+        del buf, root, qsr, stage
+    solver.sync()
+
+
+def download_problem(solver, b: int) -> LqrProblem:
+    """Host LqrProblem of a sampled problem (kept by fill_problems)."""
+    return solver.unpack(solver._host_samples[b % solver.batch])

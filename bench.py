@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- batched Riccati sweeps/s on MI355X (BASELINE.json metric).
+
+One *step* = one pass of the hot path over one batch of synthetic LQ problems:
+``backward(mueq)`` + ``forward(xs,us,vs,lbdas)`` on every problem of the batch
+(the timed body of the reference's bench/gar-riccati.cpp:46-49), inputs already
+resident in HBM.  Workload = BASELINE.json configs[1]: N=256, nx=36, nu=12,
+nc=0, fp64, serial in time, `--batch` independent problems per GPU.
+
+N>1 GPUs: the batch axis shards with no data-path collective (weak scaling:
+`--batch` problems PER GPU); RCCL is used only for the timing barrier/max.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from aligator_amd import synth_device  # noqa: E402
+from aligator_amd.gar import BatchedRiccatiSolver  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; 6.29e12 measured copy)
+
+
+def algorithmic_bytes(N, nx, nu):
+    """per stage, nc = nth = 0, doubles."""
+    knot = 2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu          # 3684
+    fac = (nu + nx) * nx + (nu + nx) + nx * nx + nx                    # 3108
+    fwd_out = 2 * nx + nu                                              # 84
+    bwd = 8 * (knot + fac) * N
+    fwd = 8 * (fac + fwd_out) * N
+    return bwd, fwd
+
+
+def cpu_baseline(args, nx, nu, N, mueq):
+    """The oracle (restated reference, NOT the Eigen build) timed on this box's
+    host cores: OpenMP parallel-for over a bounded sample of the same workload."""
+    from aligator_amd import synth
+    from oracle import oracle as ora
+
+    cores = os.cpu_count() or 1
+    nprob = max(2 * cores, 8)
+    rng = np.random.default_rng(1234)
+    L = ora.lib(native=True)  # rebuilt with -march=native on THIS host
+    t0 = time.time()
+    probs = []
+    for i in range(nprob):
+        p = synth.generate_lq_problem(np.random.default_rng(1234 + i), np.zeros(nx), N, nx, nu,
+                                      mode=args.generator)
+        probs.append(ora.Problem.from_knots(p.stages, p.G0, p.g0, native=True))
+        if time.time() - t0 > 60:
+            break
+    bs = ora.BatchSweep(probs)
+    threads = bs.max_threads()
+    bs.sweep(mueq, threads)  # warm-up
+    reps, t_acc = 0, 0.0
+    while t_acc < args.cpu_seconds and reps < 50:
+        t1 = time.perf_counter()
+        fails = bs.sweep(mueq, threads)
+        t_acc += time.perf_counter() - t1
+        reps += 1
+        assert fails == 0
+    t1 = time.perf_counter()
+    ora.BatchSweep(probs[:1]).sweep(mueq, 1)
+    lat = time.perf_counter() - t1
+    del rng, L
+    return {"value": len(probs) * reps / t_acc, "unit": "sweeps/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{len(probs)} problems x {reps} reps, OpenMP parallel-for over problems, "
+                      f"oracle/gar_oracle.c -O3 -march=native (restated reference, not the Eigen "
+                      f"build); 1-thread latency {lat * 1e3:.2f} ms/sweep"}
+
+
+def parity_check(solver, args, mueq, nsample=2):
+    """Spot-check the timed data: pull a few problems back, solve with the oracle."""
+    from aligator_amd.gar import lqrComputeKktError
+    from oracle import oracle as ora
+
+    worst, worst_kkt = 0.0, 0.0
+    for b in np.linspace(0, solver.batch - 1, nsample).astype(int):
+        prob = synth_device.download_problem(solver, int(b))
+        sol = solver.solution(int(b))
+        op = ora.Problem.from_knots(prob.stages, prob.G0, prob.g0)
+        os_ = ora.ProximalRiccatiSolver(op)
+        os_.backward(mueq)
+        ref = op.initialize_solution()
+        os_.forward(*ref)
+        scale = max(1.0, max(float(np.abs(v).max()) for v in ref[3]))
+        for A, B in zip(sol, ref):
+            for a, c in zip(A, B):
+                if a.size:
+                    worst = max(worst, float(np.abs(a - c).max()) / scale)
+        worst_kkt = max(worst_kkt, max(lqrComputeKktError(prob, *sol, mueq=mueq)))
+    return worst, worst_kkt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--horizon", type=int, default=256)
+    ap.add_argument("--nx", type=int, default=36)
+    ap.add_argument("--nu", type=int, default=12)
+    ap.add_argument("--generator", default="W", choices=["W", "F"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N, nx, nu, mueq = args.horizon, args.nx, args.nu, 1e-14
+    dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
+    solver = BatchedRiccatiSolver(dims, nx, batch=args.batch, num_legs=1, device=local_rank)
+    stream = torch.cuda.current_stream()
+    solver.set_stream(stream.cuda_stream)
+    synth_device.fill_problems(solver, seed=1234 + 7919 * rank, mode=args.generator)
+    torch.cuda.synchronize()
+
+    def step():
+        solver.backward_async(mueq)
+        solver.forward_async()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if solver.num_failed() != 0:
+        raise SystemExit("a stage factorisation failed during warm-up")
+
+    # per-kernel durations with HIP events on the launch stream (torch's current stream)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        solver.backward_async(mueq)
+        ev[k][1].record(stream)
+        solver.forward_async()
+        ev[k][2].record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    bwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    fwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    failed = solver.num_failed()
+
+    err, kkt = parity_check(solver, args, mueq)
+    if rank == 0:
+        sweeps = args.batch * world * args.steps
+        bwd_b, fwd_b = algorithmic_bytes(N, nx, nu)
+        achieved = bwd_b * args.batch / (bwd_ms * 1e-3)
+        out = {
+            "metric": "Riccati sweeps/sec (bwd+fwd), N=256 nx=36 nu=12",
+            "value": sweeps / elapsed,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": f"synthetic (generator {args.generator}, generated on device)",
+            "config": {"workload": f"batched serial-in-time Riccati N={N} nx={nx} nu={nu} nc=0 fp64 "
+                                   f"(BASELINE.json configs[1])",
+                       "batch_per_gpu": args.batch, "kernel": solver.kernel_name,
+                       "parallelism": f"batch-sharded x{world} (no data-path collective)"},
+            "kernel_ms": {"backward": bwd_ms, "forward": fwd_ms},
+            "roofline": {"bound": "hbm", "kernel": "backward", "achieved": achieved / 1e9,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": bwd_b * args.batch,
+                         "forward_GBps": fwd_b * args.batch / (fwd_ms * 1e-3) / 1e9},
+            "parity": {"max_rel_err_vs_oracle": err, "max_kkt": kkt, "failed_factorisations": failed},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, nx, nu, N, mueq)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,183 @@
+/*
+ * gar_hip.h -- C ABI of the MI355X-native gar Riccati/LQR backend.
+ *
+ * This is the drop-in boundary: a plain C interface (extern "C", raw pointers
+ * and sizes, no C++/torch types, no exceptions across it) exporting exactly
+ * what a `gar::RiccatiSolverBase<double>` subclass needs to serve the six
+ * calls SolverProxDDP makes on `linear_solver_`
+ * (/root/reference/include/aligator/solvers/proxddp/solver-proxddp.hxx:208,
+ * 608-611, 619, 624-625, 631-632).  INTEGRATION.md shows the reference-side
+ * binding (a `HipRiccatiSolver : gar::RiccatiSolverBase<double>` of ~80 lines).
+ *
+ * Reference interface replaced, entry point by entry point:
+ *   gar_hip_solver_create        ProximalRiccatiSolver::ProximalRiccatiSolver
+ *                                (gar/proximal-riccati.hxx:13-31) and
+ *                                ParallelRiccatiSolver ctor + initialize()
+ *                                (gar/parallel-solver.hxx:32-82, 261-287)
+ *   gar_hip_upload_stage         reads of LqrKnotTpl blocks (gar/lqr-problem.hpp:45-56);
+ *                                the reference re-reads the caller's problem on every
+ *                                backward() (proximal-riccati.hxx:37)
+ *   gar_hip_set_init             LqrProblemTpl::G0, g0 (gar/lqr-problem.hpp:111-112)
+ *   gar_hip_backward             RiccatiSolverBase::backward (gar/riccati-base.hpp:20):
+ *                                ProximalRiccatiSolver::backward (proximal-riccati.hxx:34-62),
+ *                                ParallelRiccatiSolver::backward (parallel-solver.hxx:132-206)
+ *   gar_hip_forward              RiccatiSolverBase::forward (riccati-base.hpp:22-25):
+ *                                proximal-riccati.hxx:65-77, parallel-solver.hxx:209-243
+ *   gar_hip_collapse_feedback    RiccatiSolverBase::collapseFeedback (riccati-base.hpp:33,
+ *                                parallel-solver.hpp:41-51)
+ *   gar_hip_get_gains            getFeedforward / getFeedback (riccati-base.hpp:34-35)
+ *   gar_hip_get_value / _initial public StageFactor::vm, kkt0, thGrad, thHess
+ *                                (riccati-kernel.hpp:33-39,113-123; proximal-riccati.hpp:40-43)
+ *   gar_hip_cycle_append         RiccatiSolverBase::cycleAppend (riccati-base.hpp:28,
+ *                                proximal-riccati.hxx:79-86, parallel-solver.hxx:246-258)
+ *
+ * New relative to the reference (its own axis for reaching the HBM roofline,
+ * SURVEY.md section 2c): a solver owns `batch` independent problems of identical
+ * dimensions and sweeps them in one launch.
+ *
+ * Conventions: all host matrices are column-major float64 unless stated
+ * (fb / fth are ROW-major like StageFactor::fb, riccati-kernel.hpp:96-98).
+ * Return value: 0 = ok, <0 = error (gar_hip_last_error()).  Calls are
+ * synchronous on return unless suffixed _async.  One solver <-> one host
+ * thread at a time.  The library owns all device memory; the caller owns all
+ * host buffers.  No device allocation happens inside backward/forward (the
+ * reference's ALIGATOR_NOMALLOC_SCOPED contract, proximal-riccati.hxx:35).
+ */
+#ifndef GAR_HIP_H
+#define GAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gar_hip_solver gar_hip_solver;
+
+#define GAR_HIP_OK 0
+#define GAR_HIP_ERR_ARG (-1)     /* bad argument / index out of range         */
+#define GAR_HIP_ERR_DEVICE (-2)  /* HIP runtime error                          */
+#define GAR_HIP_ERR_UNSUPPORTED (-3) /* dims exceed what fits one CU's LDS     */
+#define GAR_HIP_ERR_FACTOR (-4)  /* a stage LDL^T hit an exactly-zero pivot
+                                    column (riccati-kernel.hxx:239-241)       */
+
+/* ---- library ------------------------------------------------------------ */
+const char *gar_hip_version(void);
+const char *gar_hip_last_error(void);
+int gar_hip_device_count(void);
+
+/* ---- layout queries (pure host arithmetic, no GPU needed) ---------------- */
+/* doubles in the packed record of one knot / one factor (csrc/gar_layout.h) */
+int64_t gar_hip_knot_doubles(const int32_t dims5[5]);
+int64_t gar_hip_factor_doubles(const int32_t dims5[5]);
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* dims5: (horizon+1) x {nx,nu,nc,nx2,nth} exactly as LqrKnotTpl's fields.
+ * num_legs = 1: serial-in-time ProximalRiccatiSolver semantics.
+ * num_legs >= 2: ParallelRiccatiSolver(problem, num_legs) semantics; like the
+ *   reference, every knot of a non-final leg is (implicitly) re-parameterised
+ *   with nth = nx2 of the leg's last knot.
+ * Horizon sharding over ranks: this solver owns legs [leg_begin, leg_end) of
+ *   num_legs; pass (0, num_legs) for a single-GPU solver. */
+gar_hip_solver *gar_hip_solver_create(int device, int horizon, const int32_t *dims5,
+                                      int nc0, int batch, int num_legs);
+gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon,
+                                              const int32_t *dims5, int nc0, int batch,
+                                              int num_legs, int leg_begin, int leg_end);
+void gar_hip_solver_destroy(gar_hip_solver *s);
+
+/* Launch every kernel of this solver on `hip_stream` (a hipStream_t); NULL
+ * selects the solver's own stream. */
+int gar_hip_set_stream(gar_hip_solver *s, void *hip_stream);
+int gar_hip_sync(gar_hip_solver *s);
+
+/* ---- sizes --------------------------------------------------------------- */
+int64_t gar_hip_problem_doubles(const gar_hip_solver *s);  /* one packed problem  */
+int64_t gar_hip_factors_doubles(const gar_hip_solver *s);  /* one problem's factors */
+int64_t gar_hip_solution_doubles(const gar_hip_solver *s); /* one problem's xs|us|vs|lbdas */
+int gar_hip_batch(const gar_hip_solver *s);
+int gar_hip_horizon(const gar_hip_solver *s);
+/* which kernel family serves this solver: "generic" or "mfma<NX,NU>" */
+const char *gar_hip_kernel_name(const gar_hip_solver *s);
+/* offsets (doubles) of stage t inside one packed problem / one solution record:
+ * out[0]=knot record, out[1]=factor record, out[2..5]= x,u,v,lbda offsets */
+int gar_hip_stage_offsets(const gar_hip_solver *s, int t, int64_t out[6]);
+/* offset (doubles) of G0 and g0 inside one packed problem */
+int gar_hip_init_offsets(const gar_hip_solver *s, int64_t out[2]);
+
+/* ---- problem upload (host -> HBM) ---------------------------------------- */
+/* One knot of problem b from LqrKnotTpl's separately allocated blocks.  Any of
+ * the parametric pointers may be NULL when nth == 0; C,D,d may be NULL when
+ * nc == 0. */
+int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q,
+                         const double *S, const double *R, const double *q,
+                         const double *r, const double *A, const double *B,
+                         const double *f, const double *C, const double *D,
+                         const double *d, const double *Gth, const double *Gx,
+                         const double *Gu, const double *Gv, const double *gamma);
+int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g0);
+/* nb already-packed problems (gar_hip_problem_doubles() each) starting at b0 */
+int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packed);
+/* same, but `packed_dev` is a DEVICE pointer (device-resident producers) */
+int gar_hip_upload_packed_device(gar_hip_solver *s, int b0, int nb, const double *packed_dev);
+/* Flush the pinned staging area filled by upload_stage/set_init to the GPU.
+ * backward() calls it implicitly when staging is dirty. */
+int gar_hip_commit(gar_hip_solver *s);
+/* Device pointer to the packed problems (batch x problem_doubles) so that
+ * device-resident producers (the updateLQSubproblem replacement, SURVEY 8f1, or
+ * a synthetic generator) can write knots in place. */
+double *gar_hip_device_problems(gar_hip_solver *s);
+double *gar_hip_device_factors(gar_hip_solver *s);
+double *gar_hip_device_solutions(gar_hip_solver *s);
+
+/* ---- the sweep ------------------------------------------------------------ */
+/* backward(mueq): returns 0, or GAR_HIP_ERR_FACTOR if any stage factorisation
+ * of any problem failed (the reference throws). */
+int gar_hip_backward(gar_hip_solver *s, double mueq);
+int gar_hip_backward_async(gar_hip_solver *s, double mueq);
+/* forward: theta (host, ntheta doubles per problem, batch-major) or NULL.
+ * Results stay in HBM; fetch with gar_hip_get_solution. */
+int gar_hip_forward(gar_hip_solver *s, const double *theta);
+int gar_hip_forward_async(gar_hip_solver *s, const double *theta_device);
+/* number of problems whose backward reported a failed factorisation */
+int gar_hip_num_failed(gar_hip_solver *s);
+
+/* ---- horizon sharding (leg mode, one rank per GPU) ------------------------ */
+/* doubles per leg in the boundary tuple (Vxx | Vxt | Vtt | vx | vt of the leg's
+ * first stage): 3 nx^2 + 2 nx */
+int64_t gar_hip_boundary_doubles(const gar_hip_solver *s);
+/* device buffer holding this rank's tuples: [batch][local legs][tuple] */
+double *gar_hip_device_boundary_local(gar_hip_solver *s);
+/* device buffer the condensed solve reads: [num_ranks chunks as gathered]; on a
+ * single-GPU solver it aliases the local buffer */
+double *gar_hip_device_boundary_all(gar_hip_solver *s);
+int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq);   /* parallel-solver.hxx:150-164 */
+int gar_hip_condensed_solve_async(gar_hip_solver *s);              /* :169-202 */
+int gar_hip_forward_legs_async(gar_hip_solver *s);                 /* :209-243 */
+/* refinement controls (parallel-solver.hpp:92-94) */
+int gar_hip_set_refinement(gar_hip_solver *s, double condensed_threshold, int max_steps);
+
+/* ---- results (HBM -> host) ------------------------------------------------ */
+/* packed solution of problem b: xs | us | vs | lbdas (per-stage offsets from
+ * gar_hip_stage_offsets); any pointer may be NULL */
+int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us,
+                         double *vs, double *lbdas);
+/* ff (nu+nc+nx2), fb ((nu+nc+nx2) x nx ROW-major), fth (.. x nth ROW-major) */
+int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb,
+                      double *fth);
+int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx,
+                      double *Vxt, double *Vtt, double *vt);
+/* kkt0.ff (nx0+nc0), kkt0.fth ((nx0+nc0) x nth ROW-major), thGrad, thHess */
+int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff,
+                        double *kkt0_fth, double *thGrad, double *thHess);
+/* all factor records of problem b in one copy (gar_hip_factors_doubles()) */
+int gar_hip_get_factors(gar_hip_solver *s, int b, double *out);
+int gar_hip_collapse_feedback(gar_hip_solver *s);
+/* MPC cycling: drop knot 0, shift left, last-but-one knot gets dims5_new */
+int gar_hip_cycle_append(gar_hip_solver *s, const int32_t dims5_new[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,125 @@
+// TEST-ONLY emulation of the slice of the HIP runtime and of the gfx950 wave64
+// intrinsics that aligator_amd/csrc uses.  It lets the *unmodified* kernel
+// sources run on host threads (one OS thread per lane, std::barrier for
+// __syncthreads and for the lock-step of cross-lane instructions) so that
+// index maps, LDS plans and barrier placement can be checked -- also under
+// ThreadSanitizer -- without spending GPU minutes.  It is never built into,
+// loaded by, or shipped with the product (aligator_amd/); the product has no
+// CPU path and fails loudly without a HIP device.
+#pragma once
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+typedef struct emu_stream_t *hipStream_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+constexpr unsigned hipStreamNonBlocking = 1, hipHostMallocDefault = 0;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+
+namespace emu {
+struct WaveCtx {
+  std::barrier<> bar{64};
+  double a[64], b[64];
+};
+struct BlockCtx {
+  std::barrier<> bar;
+  std::vector<std::unique_ptr<WaveCtx>> waves;
+  explicit BlockCtx(int nthr) : bar(nthr) {
+    for (int i = 0; i < (nthr + 63) / 64; ++i)
+      waves.emplace_back(new WaveCtx());
+  }
+};
+extern thread_local BlockCtx *block;
+extern int device_count; // tests flip this to check the "no GPU" error path
+} // namespace emu
+
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+inline void __syncthreads() { emu::block->bar.arrive_and_wait(); }
+
+typedef double emu_double4 __attribute__((ext_vector_type(4)));
+// v_mfma_f64_16x16x4_f64: A[i][k] in lane i+16k, B[k][j] in lane j+16k,
+// D[row=(l>>4)+4r][col=l&15] in lane l register r (cdna_hip_programming.md sec. 3)
+inline emu_double4 emu_mfma_f64_16x16x4(double a, double b, emu_double4 c, int, int, int) {
+  const int lane = threadIdx.x & 63;
+  emu::WaveCtx &W = *emu::block->waves[threadIdx.x >> 6];
+  W.a[lane] = a;
+  W.b[lane] = b;
+  W.bar.arrive_and_wait();
+  emu_double4 d;
+  const int col = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (lane >> 4) + 4 * r;
+    double acc = c[r];
+    for (int k = 0; k < 4; ++k)
+      acc = std::fma(W.a[row + 16 * k], W.b[col + 16 * k], acc);
+    d[r] = acc;
+  }
+  W.bar.arrive_and_wait();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64 emu_mfma_f64_16x16x4
+
+inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+
+// ---- runtime -------------------------------------------------------------------
+inline hipError_t hipGetDeviceCount(int *n) { *n = emu::device_count; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return 0; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
+
+template <class Kernel, class... Args>
+void hipLaunchKernelGGL(Kernel kernel, dim3 grid, dim3 block, size_t /*lds*/, hipStream_t,
+                        Args... args) {
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        emu::BlockCtx ctx((int)block.x);
+        std::vector<std::thread> thr;
+        thr.reserve(block.x);
+        for (unsigned t = 0; t < block.x; ++t)
+          thr.emplace_back([&, t]() {
+            emu::block = &ctx;
+            threadIdx = dim3(t, 0, 0);
+            blockIdx = dim3(bx, by, bz);
+            blockDim = block;
+            gridDim = grid;
+            kernel(args...);
+          });
+        for (auto &th : thr)
+          th.join();
+      }
+}

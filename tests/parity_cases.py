@@ -1,0 +1,127 @@
+"""Parity checks shared by the emulator tests (CPU, small sizes) and the GPU
+tests (real library, reference sizes).  Each check mirrors a test of the
+reference (tests/gar/riccati.cpp, tests/gar/parallel.cpp) and compares the HIP
+path (through the C ABI) with the CPU oracle on the same seeded input.
+
+Stated fp64 tolerances: relative 1e-9 on the
+well-conditioned generator "W", 1e-6 on the reference-faithful generator "F"
+(the reference's own bar at nx=36, tests/gar/riccati.cpp:138), relative to the
+largest multiplier / value-function entry of the oracle solution.
+"""
+import numpy as np
+
+from aligator_amd import synth
+from aligator_amd.gar import (BatchedRiccatiSolver, ParallelRiccatiSolver,
+                              ProximalRiccatiSolver, lqrComputeKktError,
+                              lqrInitializeSolution)
+from oracle import oracle as ora
+
+TOL = {"W": 1e-9, "F": 1e-6}
+
+
+def to_oracle(prob):
+    return ora.Problem.from_knots(prob.stages, prob.G0, prob.g0)
+
+
+def maxdiff(A, B):
+    return max([0.0] + [float(np.max(np.abs(a - b))) for a, b in zip(A, B) if a.size])
+
+
+def scale_of(sol):
+    return max(1.0, max(float(np.abs(v).max()) for part in sol for v in part if v.size))
+
+
+def oracle_serial(prob, mueq, theta=None):
+    op = to_oracle(prob)
+    s = ora.ProximalRiccatiSolver(op)
+    assert s.backward(mueq)
+    sol = lqrInitializeSolution(prob)
+    s.forward(*sol, theta)
+    return op, s, sol
+
+
+def compare_factors(hip_datas, ora_solver, N, tol, names=("ff", "fb", "fth"),
+                    vnames=("Vxx", "vx", "Vxt", "Vtt", "vt")):
+    """Gains and value function of every stage, relative to each block's scale."""
+    for t in range(N + 1):
+        f, o = hip_datas[t], ora_solver.datas(t)
+        for nm in names:
+            a, b = getattr(f, nm), getattr(o, nm)
+            if a.size:
+                assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (t, nm)
+        for nm in vnames:
+            a, b = getattr(f.vm, nm), getattr(o, nm)
+            if a.size:
+                assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (t, nm)
+
+
+def check_serial(prob, mueq, tol, lib_path=None, theta=None, kkt_tol=None, factors=True):
+    solver = ProximalRiccatiSolver(prob, lib_path=lib_path)
+    assert solver.backward(mueq)
+    sol = lqrInitializeSolution(prob)
+    assert solver.forward(*sol, theta)
+    _, osol, ref = oracle_serial(prob, mueq, theta)
+    sc = scale_of(ref)
+    for A, B in zip(sol, ref):
+        assert maxdiff(A, B) <= tol * sc
+    if kkt_tol is not None:
+        assert max(lqrComputeKktError(prob, *sol, mueq=mueq, theta=theta)) <= kkt_tol
+    if factors:
+        compare_factors(solver.datas, osol, prob.horizon, tol)
+        ff, fth, g, H = solver._impl.initial(0)
+        for a, b in ((ff, osol.kkt0_ff), (fth, osol.kkt0_fth), (g, osol.thGrad), (H, osol.thHess)):
+            if a.size:
+                assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+    return solver, sol, ref
+
+
+def check_parallel(prob, mueq, nthreads, tol, lib_path=None, max_refine=10, rounds=0, rng=None):
+    """tests/gar/parallel.cpp:185-245 (parallel_solver_class)."""
+    _, _, ref = oracle_serial(prob, mueq)
+    pprob = prob.copy()
+    par = ParallelRiccatiSolver(pprob, nthreads, lib_path=lib_path)
+    par.maxRefinementSteps = max_refine
+    sol = lqrInitializeSolution(pprob)
+    assert par.backward(mueq)
+    assert par.forward(*sol)
+    sc = scale_of(ref)
+    assert max(lqrComputeKktError(pprob, *sol, mueq=mueq)) <= tol * sc   # parallel.cpp:221
+    assert maxdiff(sol[0], ref[0]) <= tol * sc                           # :234
+    assert maxdiff(sol[3], ref[3]) <= tol * sc                           # :235
+    # the knots were re-parameterised in place like the reference does
+    b0, e0 = 0, (prob.horizon + 1) // nthreads
+    assert pprob.stages[b0].nth == prob.stages[e0 - 1].nx2
+    assert np.array_equal(pprob.stages[e0 - 1].Gx, pprob.stages[e0 - 1].A.T)
+    # per-stage factors against the oracle's own leg-parallel solver
+    op = to_oracle(prob)
+    opar = ora.ParallelRiccatiSolver(op, nthreads)
+    opar.maxRefinementSteps = max_refine
+    opar.backward(mueq)
+    compare_factors(par.datas, opar, prob.horizon, max(tol, 1e-8))
+    par.collapseFeedback()
+    opar.collapseFeedback()
+    K0, K0o = par.getFeedback(0), opar.datas(0).fb
+    assert np.abs(K0 - K0o).max() <= max(tol, 1e-8) * max(1.0, np.abs(K0o).max())
+    for _ in range(rounds):                                              # :238-244
+        synth.randomly_modify_problem(rng, pprob)
+        par.backward(mueq)
+        par.forward(*sol)
+        assert max(lqrComputeKktError(pprob, *sol, mueq=mueq)) <= tol * sc
+    return par
+
+
+def check_batched(probs, mueq, tol, lib_path=None, num_legs=1):
+    """The batch axis: each problem of a batch equals its own serial oracle solve."""
+    p0 = probs[0]
+    dims = [k.dims for k in p0.stages]
+    s = BatchedRiccatiSolver(dims, p0.nc0, batch=len(probs), num_legs=num_legs, lib_path=lib_path)
+    s.upload(probs)
+    assert s.backward(mueq)
+    assert s.forward()
+    for b, prob in enumerate(probs):
+        _, _, ref = oracle_serial(prob, mueq)
+        sol = s.solution(b)
+        sc = scale_of(ref)
+        for A, B in zip(sol, ref):
+            assert maxdiff(A, B) <= tol * sc, b
+    return s

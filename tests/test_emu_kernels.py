@@ -1,0 +1,122 @@
+"""Kernel-logic tests on the wave emulator (tests/emu): the UNMODIFIED kernel
+and C-ABI sources of aligator_amd/csrc run on host threads (one per lane), so
+index maps, LDS plans and barrier placement are checked on CPU.  This is test
+infrastructure only: the product never loads the emulator build, and these
+tests prove nothing about GPU execution (tests/test_gpu_parity.py does)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from aligator_amd import synth
+import parity_cases as pc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu", "_build", "libgar_hip_emu.so")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def build_emu():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu")], check=True)
+
+
+@pytest.mark.parametrize("horz", [4, 8, 16])
+def test_riccati_short_horz_pb(horz):                         # tests/gar/riccati.cpp:26-85
+    pc.check_serial(synth.short_horizon_problem(horz), 1e-14, 1e-9, EMU, kkt_tol=1e-9)
+
+
+def test_riccati_one_knot_prob():                             # riccati.cpp:87-105
+    prob = synth.generate_lq_problem(1, np.zeros(2), 0, 2, 2)
+    pc.check_serial(prob, 1e-13, 1e-10, EMU, kkt_tol=1e-10)
+
+
+@pytest.mark.parametrize("mode", ["F", "W"])
+def test_riccati_random_large_problem(mode):                  # riccati.cpp:107-139 (short horizon)
+    nx, nu = 36, 12
+    prob = synth.generate_lq_problem(42, np.zeros(nx), 6, nx, nu, mode=mode)
+    pc.check_serial(prob, 1e-14, pc.TOL[mode], EMU, kkt_tol=1e-6 if mode == "F" else 1e-9)
+
+
+def test_riccati_parametric():                                # riccati.cpp:157-192
+    rng = np.random.default_rng(9)
+    nx, nu, nth = 10, 4, 1
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 12, nx, nu, nth=nth)
+    theta = rng.uniform(-1, 1, nth)
+    solver, sol, _ = pc.check_serial(prob, 1e-12, 1e-9, EMU, theta=theta, kkt_tol=1e-9)
+    for arr in (solver.kkt0.ff, solver.kkt0.fth, solver.thGrad, solver.thHess,
+                solver.datas[0].vm.vt, solver.datas[0].vm.Vxt, solver.datas[0].vm.Vtt):
+        assert np.isfinite(arr).all()
+
+
+def test_constrained_stages_and_2x2_pivots():
+    """nc > 0 at every stage, tiny mu: the reduced KKT is indefinite and the
+    device Bunch-Kaufman takes 2x2 pivots (riccati-kernel.hxx:232-241)."""
+    rng = np.random.default_rng(5)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(6), 5, 6, 3, nc=4, mode="W")
+    pc.check_serial(prob, 1e-9, 1e-9, EMU)
+
+
+def test_parametric_and_constrained():
+    rng = np.random.default_rng(6)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(6), 4, 6, 2, nth=3, nc=3, mode="F")
+    pc.check_serial(prob, 1e-9, 1e-8, EMU, theta=rng.uniform(-1, 1, 3))
+
+
+def test_heterogeneous_dimensions():
+    """nx, nu vary along the horizon (A is nx2 x nx, lqr-problem.hxx:28-72)."""
+    from aligator_amd.lqr import LqrProblem
+    rng = np.random.default_rng(8)
+    shapes = [(3, 2, 4), (4, 1, 5), (5, 3, 2), (2, 2, 2)]     # (nx, nu, nx2)
+    knots = [synth.generate_knot(rng, nx, nu, nx2=nx2, mode="W") for nx, nu, nx2 in shapes]
+    knots.append(synth.generate_knot(rng, 2, 0, mode="W"))
+    prob = LqrProblem(knots, 3)
+    prob.G0[...] = -np.eye(3)
+    prob.g0[...] = rng.standard_normal(3)
+    pc.check_serial(prob, 1e-10, 1e-9, EMU, kkt_tol=1e-9)
+
+
+@pytest.mark.parametrize("nthreads,horz,nx,nu", [(2, 11, 4, 2), (4, 17, 6, 3), (3, 20, 12, 6)])
+def test_parallel_solver_class(nthreads, horz, nx, nu):       # tests/gar/parallel.cpp:185-245
+    rng = np.random.default_rng(17)
+    prob = synth.generate_lq_problem(rng, np.zeros(nx), horz, nx, nu)
+    pc.check_parallel(prob, 1e-9, nthreads, 1e-7, EMU, rounds=1, rng=rng)
+
+
+def test_parallel_rejects_single_thread():                    # parallel-solver.hxx:42-46
+    from aligator_amd.gar import ParallelRiccatiSolver
+    prob = synth.generate_lq_problem(1, np.zeros(2), 4, 2, 2)
+    with pytest.raises(RuntimeError):
+        ParallelRiccatiSolver(prob, 1, lib_path=EMU)
+
+
+def test_batched_problems():
+    probs = [synth.generate_lq_problem(100 + i, np.zeros(5), 6, 5, 2, mode="W") for i in range(3)]
+    pc.check_batched(probs, 1e-10, 1e-9, EMU)
+    pc.check_batched(probs, 1e-10, 1e-8, EMU, num_legs=2)
+
+
+def test_failed_factorisation_raises():
+    """An exactly-zero pivot column makes BunchKaufman report NumericalIssue; the
+    reference throws (riccati-kernel.hxx:239-241), so does the host mirror."""
+    from aligator_amd.gar import ProximalRiccatiSolver
+    prob = synth.generate_lq_problem(3, np.zeros(3), 3, 3, 2, mode="W")
+    for k in prob.stages[:-1]:
+        k.R[...] = 0.0
+        k.S[...] = 0.0
+        k.B[...] = 0.0
+    with pytest.raises(RuntimeError, match="LDL"):
+        ProximalRiccatiSolver(prob, lib_path=EMU).backward(1e-10)
+
+
+def test_cycle_append_rotates_factors():                      # proximal-riccati.hxx:79-86
+    from aligator_amd.gar import ProximalRiccatiSolver
+    prob = synth.generate_lq_problem(21, np.zeros(4), 6, 4, 2, mode="W")
+    s = ProximalRiccatiSolver(prob, lib_path=EMU)
+    s.backward(1e-10)
+    before = [s.getFeedback(t).copy() for t in range(7)]
+    s.cycleAppend(prob.stages[5])
+    for t in range(5):
+        assert np.array_equal(s.getFeedback(t), before[t + 1])
+    assert np.array_equal(s.getFeedback(5), np.zeros_like(before[5]))   # re-created factor
+    assert np.array_equal(s.getFeedback(6), before[6])                  # terminal factor kept

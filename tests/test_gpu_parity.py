@@ -1,0 +1,122 @@
+"""Parity of the HIP path (through the C ABI, on a real MI355X) against the CPU
+oracle, at the reference's own test sizes, plus size-independent properties at
+BASELINE.json's full sizes.  Run with ``pytest -m gpu``."""
+import numpy as np
+import pytest
+
+from aligator_amd import synth
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("horz", [4, 8, 16])
+def test_riccati_short_horz_pb(horz):                         # tests/gar/riccati.cpp:26-85
+    pc.check_serial(synth.short_horizon_problem(horz), 1e-14, 1e-9, kkt_tol=1e-9)
+
+
+def test_riccati_one_knot_prob():                             # riccati.cpp:87-105
+    prob = synth.generate_lq_problem(1, np.zeros(2), 0, 2, 2)
+    pc.check_serial(prob, 1e-13, 1e-10, kkt_tol=1e-10)
+
+
+@pytest.mark.parametrize("horz", [20, 100])
+@pytest.mark.parametrize("mode", ["F", "W"])
+def test_riccati_random_large_problem(horz, mode):            # riccati.cpp:107-139
+    nx, nu = 36, 12
+    prob = synth.generate_lq_problem(42, np.zeros(nx), horz, nx, nu, mode=mode)
+    pc.check_serial(prob, 1e-14, pc.TOL[mode], kkt_tol=1e-6 if mode == "F" else 1e-9)
+
+
+def test_riccati_parametric():                                # riccati.cpp:157-192
+    rng = np.random.default_rng(9)
+    nx, nu, nth = 10, 4, 1
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 100, nx, nu, nth=nth)
+    theta = rng.uniform(-1, 1, nth)
+    solver, _, _ = pc.check_serial(prob, 1e-12, 1e-9, theta=theta, kkt_tol=1e-9)
+    for arr in (solver.kkt0.ff, solver.kkt0.fth, solver.thGrad, solver.thHess,
+                solver.datas[0].vm.vt, solver.datas[100].vm.Vtt):
+        assert np.isfinite(arr).all()
+
+
+def test_constrained_bench_shape():
+    """bench/gar-riccati.cpp:19-22: nc=32, mu=1e-11 (multipliers O(1/mu))."""
+    nx, nu, nc = 36, 12, 32
+    rng = np.random.default_rng(5)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 16, nx, nu, nc=nc, mode="W")
+    pc.check_serial(prob, 1e-11, 1e-7, factors=False)
+
+
+def test_constrained_small_with_2x2_pivots():
+    rng = np.random.default_rng(5)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(6), 5, 6, 3, nc=4, mode="W")
+    pc.check_serial(prob, 1e-9, 1e-9)
+
+
+def test_north_star_config_single_problem():
+    """BASELINE.json configs[1]: N=256, nx=36, nu=12, fp64, serial in time."""
+    nx, nu = 36, 12
+    prob = synth.generate_lq_problem(7, np.zeros(nx), 256, nx, nu, mode="W")
+    pc.check_serial(prob, 1e-14, 1e-9, kkt_tol=1e-9)
+
+
+@pytest.mark.parametrize("nthreads", [2, 6])
+def test_parallel_solver_class(nthreads):                     # tests/gar/parallel.cpp:185-245
+    rng = np.random.default_rng(17)
+    nx, nu, horizon = 32, 12, 50
+    prob = synth.generate_lq_problem(rng, np.zeros(nx), horizon, nx, nu)
+    pc.check_parallel(prob, 1e-9, nthreads, 1e-7, rounds=3, rng=rng)
+
+
+def test_parallel_config3():
+    """BASELINE.json configs[2]: N=1024, nx=12, nu=6, legs on one GPU."""
+    rng = np.random.default_rng(3)
+    prob = synth.generate_lq_problem(rng, np.zeros(12), 1024, 12, 6, mode="W")
+    for legs in (8, 64):
+        pc.check_parallel(prob, 1e-9, legs, 1e-7)
+
+
+def test_batched_problems_and_legs():
+    probs = [synth.generate_lq_problem(100 + i, np.zeros(36), 32, 36, 12, mode="W") for i in range(5)]
+    pc.check_batched(probs, 1e-12, 1e-9)
+    pc.check_batched(probs, 1e-12, 1e-8, num_legs=4)
+
+
+def test_failed_factorisation_raises():
+    from aligator_amd.gar import ProximalRiccatiSolver
+    prob = synth.generate_lq_problem(3, np.zeros(3), 3, 3, 2, mode="W")
+    for k in prob.stages[:-1]:
+        k.R[...] = 0.0
+        k.S[...] = 0.0
+        k.B[...] = 0.0
+    with pytest.raises(RuntimeError, match="LDL"):
+        ProximalRiccatiSolver(prob).backward(1e-10)
+
+
+def test_full_size_batch_properties():
+    """Size-independent properties at the bench's full sizes (device-generated
+    batch): KKT residual of sampled problems, idempotence of a repeated sweep,
+    and agreement with the oracle on the sampled problems."""
+    import torch
+    from aligator_amd import synth_device
+    from aligator_amd.gar import BatchedRiccatiSolver, lqrComputeKktError
+    nx, nu, N, B = 36, 12, 256, 64
+    dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
+    s = BatchedRiccatiSolver(dims, nx, batch=B)
+    synth_device.fill_problems(s, seed=99, mode="W", keep=(0, 31, -1))
+    s.backward(1e-14)
+    s.forward()
+    first = [s.solution(b) for b in (0, 31, B - 1)]
+    s.backward(1e-14)
+    s.forward()
+    for (b, sol) in zip((0, 31, B - 1), first):
+        again = s.solution(b)
+        for A, C in zip(sol, again):
+            assert pc.maxdiff(A, C) == 0.0                     # deterministic / idempotent
+        prob = synth_device.download_problem(s, b)
+        assert max(lqrComputeKktError(prob, *sol, mueq=1e-14)) <= 1e-9
+        _, _, ref = pc.oracle_serial(prob, 1e-14)
+        for A, C in zip(sol, ref):
+            assert pc.maxdiff(A, C) <= 1e-9 * pc.scale_of(ref)
+    assert s.num_failed() == 0
+    del torch
