@@ -75,6 +75,20 @@ class GarLibraryError(RuntimeError):
 _cache = {}
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64
+    (SONAME libamdhip64.so.7, same as /opt/rocm's); if torch initialises after a
+    different copy is already mapped, the process ends up with two runtimes and
+    the second one sees no GPU.  Importing torch first makes the backend bind
+    (by SONAME) to the copy torch uses, so torch tensors, streams and RCCL
+    buffers are valid in our kernels' address space."""
+    try:
+        import torch  # noqa: F401  (plumbing: device memory, streams, RCCL)
+    except ImportError:
+        pass  # plain C/C++ consumers use the system runtime
+
+
+
 def load(path: str | None = None):
     """dlopen the backend and bind every entry point of include/gar_hip.h."""
     path = os.path.abspath(path or DEFAULT_PATH)
@@ -85,6 +99,7 @@ def load(path: str | None = None):
             f"{path} not found: build the HIP backend first "
             "(python -c 'import __graft_entry__ as g; g.build()' or "
             "make -C aligator_amd/csrc). There is no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

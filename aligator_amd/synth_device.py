@@ -78,7 +78,9 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
         At = randu(nb, nx, nx) if mode == "F" else (torch.eye(nx, device=dev, dtype=f64) + 0.1 * randu(nb, nx, nx))
         term = torch.cat([_colmajor(Qt), randu(nb, nx), _colmajor(At), randn(nb, nx)], dim=-1)
         buf[:, offN:offN + term.shape[-1]] = term
+        torch.cuda.synchronize()  # generation done before the solver's stream copies it
         solver.upload_packed_device(buf.data_ptr(), b0, nb)
+        solver.sync()
         for k in keep_idx:
             if b0 <= k < b0 + nb:
                 solver._host_samples[k] = buf[k - b0].cpu().numpy()

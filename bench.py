@@ -132,7 +132,10 @@ def main():
     N, nx, nu, mueq = args.horizon, args.nx, args.nu, 1e-14
     dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
     solver = BatchedRiccatiSolver(dims, nx, batch=args.batch, num_legs=1, device=local_rank)
-    stream = torch.cuda.current_stream()
+    # a dedicated (non-null) stream: the kernels, the HIP events and the timing all
+    # live on it (gar_hip_set_stream(NULL) would select the solver's private stream)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     solver.set_stream(stream.cuda_stream)
     synth_device.fill_problems(solver, seed=1234 + 7919 * rank, mode=args.generator)
     torch.cuda.synchronize()
