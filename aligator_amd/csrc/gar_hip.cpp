@@ -8,12 +8,14 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "gar_generic.hpp"
 #include "gar_layout.h"
+#include "gar_mfma.hpp"
 
 namespace {
 
@@ -65,6 +67,9 @@ struct gar_hip_solver {
   int cond_lds_doubles = 0;
   std::string kernel_name = "generic";
   int last_failed = 0;
+  // specialised backward kernel (gar_mfma.hpp), null = generic
+  void (*mfma_kernel)(gar::MfmaParams) = nullptr;
+  int mfma_lds_doubles = 0;
 };
 
 namespace {
@@ -219,6 +224,42 @@ int plan_lds(gar_hip_solver *s) {
   return GAR_HIP_OK;
 }
 
+// ---- specialised kernel dispatch ---------------------------------------------
+template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
+  s->mfma_kernel = gar::gar_backward_mfma<NX, NU>;
+  s->mfma_lds_doubles = gar::MfmaCfg<NX, NU>::total;
+  s->kernel_name = "mfma<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+}
+
+void select_kernel(gar_hip_solver *s) {
+  s->mfma_kernel = nullptr;
+  s->kernel_name = "generic";
+  const char *force = std::getenv("GAR_HIP_FORCE_GENERIC");
+  if (force && force[0] == '1')
+    return;
+  const int N = s->horizon;
+  if (s->num_legs != 1 || N < 1)
+    return;
+  const gar_stage_meta &m0 = s->meta[0];
+  if (m0.nc != 0 || m0.nth != 0 || m0.nx2 != m0.nx)
+    return;
+  for (int t = 1; t < N; ++t) {
+    const gar_stage_meta &m = s->meta[t];
+    if (m.nx != m0.nx || m.nu != m0.nu || m.nc != 0 || m.nth != 0 || m.nx2 != m0.nx ||
+        m.in_off - s->meta[t - 1].in_off != s->meta[1 < N ? 1 : 0].in_off - m0.in_off)
+      return;
+  }
+  const gar_stage_meta &mt = s->meta[N];
+  if (mt.nx != m0.nx || mt.nu != 0 || mt.nc != 0 || mt.nth != 0)
+    return;
+  const int nx = m0.nx, nu = m0.nu;
+  if (nx == 36 && nu == 12) bind_mfma<36, 12>(s);
+  else if (nx == 32 && nu == 12) bind_mfma<32, 12>(s);
+  else if (nx == 16 && nu == 8) bind_mfma<16, 8>(s);
+  else if (nx == 12 && nu == 4) bind_mfma<12, 4>(s);
+  else if (nx == 8 && nu == 4) bind_mfma<8, 4>(s);
+}
+
 gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
   gar::GenericParams P{};
   P.meta = s->d_meta;
@@ -283,6 +324,28 @@ int write_block(gar_hip_solver *s, int b, int64_t off, const double *src, int64_
 
 int launch_backward(gar_hip_solver *s, double mueq) {
   gar::GenericParams P = make_params(s, mueq);
+  if (s->mfma_kernel) {
+    gar::MfmaParams M{};
+    M.prob = s->d_prob;
+    M.fac = s->d_fac;
+    M.status = s->d_status;
+    M.prob_stride = s->prob_doubles;
+    M.fac_stride = s->fac_doubles;
+    const int N = s->horizon;
+    M.in_off0 = s->meta[0].in_off;
+    M.in_rec = N > 1 ? s->meta[1].in_off - s->meta[0].in_off : s->meta[N].in_off - s->meta[0].in_off;
+    M.in_offN = s->meta[N].in_off;
+    M.fac_rec = N > 1 ? s->meta[1].fac_off - s->meta[0].fac_off : s->meta[N].fac_off;
+    M.fac_offN = s->meta[N].fac_off;
+    M.horizon = N;
+    hipLaunchKernelGGL(s->mfma_kernel, dim3((unsigned)s->batch), dim3(256),
+                       (size_t)s->mfma_lds_doubles * sizeof(double), s->stream, M);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(gar::gar_initial_generic, dim3((unsigned)s->batch), dim3(256),
+                       (size_t)s->lds.total * sizeof(double), s->stream, P);
+    HIP_TRY(hipGetLastError());
+    return GAR_HIP_OK;
+  }
   const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
   hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(256),
                      (size_t)s->lds.total * sizeof(double), s->stream, P);
@@ -405,6 +468,14 @@ int allocate(gar_hip_solver *s) {
     std::memset(s->h_prob, 0, staging);
     s->staged = true;
   }
+  select_kernel(s);
+  if (s->mfma_kernel)
+    HIP_TRY(hipFuncSetAttribute((const void *)s->mfma_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->mfma_lds_doubles * sizeof(double))));
+  HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_initial_generic,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(s->lds.total * sizeof(double))));
   // > 64 KiB of dynamic LDS needs the opt-in attribute
   HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_backward_generic,
                               hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1,0 +1,501 @@
+// gar_mfma.hpp -- the specialised backward sweep for uniform, unconstrained,
+// unparameterised problems (nc = nth = 0, every stage NX x NU, terminal knot
+// nu = 0): the BASELINE.json north-star path (N=256, nx=36, nu=12, fp64).
+//
+// Same arithmetic as ProximalRiccatiKernel::stageKernelSolve
+// (gar/riccati-kernel.hxx:209-277) but laid out for CDNA4:
+//
+//  * one 256-thread workgroup per problem; waves 0..2 are "column-tile workers",
+//    wave 3 streams the next knot HBM -> LDS and does the vector recursions
+//    (vplus, qhat, rhat, kff, yff, vx);
+//  * P = V'[A B] and H = [Q S;S^T R] + [A B]^T P are v_mfma_f64_16x16x4 chains in
+//    which the D registers of P are fed straight back as the B operand of H
+//    (the f64 C/D map row=(l>>4)+4r, col=l&15 IS the B map k=l>>4, j=l&15), so
+//    P and H never touch LDS and there is no barrier between the two products;
+//  * only the lower tiles of H / Vxx are computed; Vxx is mirrored when it is
+//    stored -- exactly the reference's `selfadjointView<Lower>` (:216);
+//  * Rhat (NU x NU) is factorised redundantly by every wave in registers
+//    (lane = row) as an unpivoted LDL^T while evaluating the Bunch-Kaufman
+//    pivot rule (core/bunchkaufman.hpp:46-83) at every column; if the rule would
+//    ever interchange (or hit a zero column) the stage falls back, uniformly
+//    for the workgroup, to the generic device Bunch-Kaufman -- so pivot
+//    decisions are always the reference's;
+//  * 2 barriers per stage; LDS ~50 KB -> 3 workgroups per CU.
+#pragma once
+#include "gar_device.hpp"
+#include "gar_layout.h"
+
+namespace gar {
+
+struct MfmaParams {
+  const double *prob;
+  double *fac;
+  int *status;
+  long long prob_stride, fac_stride;
+  long long in_off0, in_rec, in_offN; // knot record of stage t < N at in_off0 + t*in_rec
+  long long fac_rec, fac_offN;        // factor record of stage t < N at t*fac_rec
+  int horizon;
+};
+
+template <int NX, int NU> struct MfmaCfg {
+  static_assert(NX % 4 == 0 && NU % 4 == 0, "NX, NU must be multiples of 4");
+  static_assert(NU >= 4 && NU <= 16 && NX >= NU, "4 <= NU <= 16 <= NX");
+  static constexpr int NW = NX + NU;
+  static constexpr int TX = (NX + 15) / 16; // tiles over the state index
+  static constexpr int TW = (NW + 15) / 16; // tiles over [x; u]
+  static constexpr int KS = NX / 4;         // k-steps over the next-state index
+  static constexpr int KU = NU / 4;         // k-steps over the control index
+  static_assert(TW <= 3, "one column tile per worker wave (3 workers)");
+  // pitch of the k-fast buffers: p = 2 mod 4 makes "16 lanes stride p, 4 lane
+  // groups +1" conflict-free for ds_read_b64 (bank = dword address mod 64)
+  static constexpr int PK = NX + 2;
+  static constexpr int FROWS = TW * 16;
+  // pitch of G = [-rhat | -Shat^T]: 16 mod 32 -> "16 lanes +1, 4 groups stride p" conflict-free
+  static constexpr int PG = ((NX + 1 + 15) / 32) * 32 + 16;
+  static constexpr int NL = NU * (NU - 1) / 2; // packed strictly-lower L
+  // LDS carve (doubles); +16 slack after buffers read with padded tile indices
+  static constexpr int oV = 0;
+  static constexpr int oFt0 = oV + NX * PK + 16;
+  static constexpr int oFt1 = oFt0 + FROWS * PK + 16;
+  static constexpr int oG = oFt1 + FROWS * PK + 16;
+  static constexpr int oM = oG + NU * PG + 16;
+  static constexpr int oL = oM + NU * NU;      // 4 per-wave packed L copies + dinv
+  static constexpr int oVec = oL + 4 * (NL + NU + (NL + NU) % 2);
+  // vectors: vn[NX] fv[2][NX] qr[2][NW] vp[NX]
+  static constexpr int oVn = oVec, oFv = oVn + NX, oQr = oFv + 2 * NX, oVp = oQr + 2 * NW;
+  // Bunch-Kaufman fallback scratch: G2 (NU*PG+16), sub (16), piv+ctrl (16 doubles)
+  static constexpr int oFb = (oVp + NX + 1) & ~1;
+  static constexpr int total = oFb + NU * PG + 16 + 16 + 16;
+  // record offsets (uniform stage / terminal knot)
+  static constexpr int kQ = 0, kS = NX * NX, kR = kS + NX * NU, kq = kR + NU * NU, kr = kq + NX,
+                       kA = kr + NU, kB = kA + NX * NX, kf = kB + NX * NU;
+  static constexpr int tQ = 0, tq = NX * NX; // terminal: Q, q, A, f (nu = 0)
+  static constexpr int fFF = 0, fFB = NW, fVxx = fFB + NW * NX, fvx = fVxx + NX * NX;
+  static constexpr int tVxx = NX + NX * NX, tvx = tVxx + NX * NX; // terminal factor record
+};
+
+__device__ __forceinline__ double lane_bcast(double v, int src /*wave-uniform*/) {
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Element (a, b), a >= b, of the stage Hessian [Q S; S^T R] read from the knot
+// record through its LOWER triangle (the reference's products only ever feed the
+// lower triangle of Vxx forward, riccati-kernel.hxx:216).
+template <int NX, int NU>
+__device__ __forceinline__ double w_lower(const double *rec, int row, int col) {
+  using C = MfmaCfg<NX, NU>;
+  const int a = row >= col ? row : col, b = row >= col ? col : row;
+  if (a >= C::NW)
+    return 0.0;
+  if (a < NX)
+    return rec[C::kQ + b * NX + a];
+  if (b < NX)
+    return rec[C::kS + (a - NX) * NX + b];
+  return rec[C::kR + (b - NX) * NU + (a - NX)];
+}
+
+// Unpivoted LDL^T of the NU x NU matrix M (LDS, column-major, lower valid) in
+// registers, lane i < NU owning row i, with the Bunch-Kaufman rule evaluated at
+// every column.  On return a[j] (j < row) = L(row, j), dinv[k] = 1/d_k
+// (wave-uniform).  Returns 0 if BK would have taken the 1x1 pivot kp = k at every
+// column (then BK == this factorisation, operation for operation,
+// bunchkaufman.hpp:104-121), 1 if it would interchange, 2 on a zero column.
+template <int NU>
+__device__ __forceinline__ int wave_ldl_bk_rule(const double *M, int lane, double (&a)[NU],
+                                                double (&dinv)[NU]) {
+  const double alpha = (1.0 + 4.123105625617661) / 8.0;
+  const int row = lane < NU ? lane : NU - 1;
+#pragma unroll
+  for (int j = 0; j < NU; ++j)
+    a[j] = (j <= row) ? M[j * NU + row] : 0.0;
+  int verdict = 0;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const double akk = lane_bcast(a[k], k);
+    double xs[NU];
+    double colmax = 0.0;
+    int imax = k + 1;
+#pragma unroll
+    for (int j = k + 1; j < NU; ++j) {
+      xs[j] = lane_bcast(a[k], j); // a(j,k), lower triangle
+      const double v = fabs(xs[j]);
+      if (v > colmax) {
+        colmax = v;
+        imax = j;
+      }
+    }
+    const double abs_akk = fabs(akk);
+    if (fmax(abs_akk, colmax) == 0.0) {
+      verdict |= 2;
+    } else if (!(abs_akk >= colmax * alpha)) {
+      // rowmax over row imax of the trailing matrix (bunchkaufman.hpp:63-73)
+      double t = 0.0; // own a[imax]
+#pragma unroll
+      for (int c = 0; c < NU; ++c)
+        t = (c == imax) ? a[c] : t;
+      double rowmax = 0.0;
+#pragma unroll
+      for (int j = k; j < NU; ++j) {
+        const double e1 = lane_bcast(a[j], imax); // a(imax, j), valid for j < imax
+        const double e2 = lane_bcast(t, j);       // a(j, imax), valid for j > imax
+        if (j < imax)
+          rowmax = fmax(rowmax, fabs(e1));
+        else if (j > imax)
+          rowmax = fmax(rowmax, fabs(e2));
+      }
+      if (!(abs_akk >= (alpha * colmax) * (colmax / rowmax)))
+        verdict |= 1;
+    }
+    const double d11 = 1.0 / akk;
+#pragma unroll
+    for (int j = k + 1; j < NU; ++j) {
+      const double d11xj = xs[j] * d11;
+      if (lane >= j)
+        a[j] -= d11xj * a[k];
+    }
+    if (lane > k)
+      a[k] *= d11;
+    dinv[k] = d11;
+  }
+  return verdict;
+}
+
+// x <- (L D L^T)^{-1} x with L packed strictly-lower row-wise in LDS (pl[i*(i-1)/2 + j])
+template <int NU>
+__device__ __forceinline__ void ldl_solve_regs(const double *pl, const double (&dinv)[NU],
+                                               double (&x)[NU]) {
+#pragma unroll
+  for (int i = 1; i < NU; ++i) {
+    double s = x[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+      s -= pl[i * (i - 1) / 2 + j] * x[j];
+    x[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < NU; ++i)
+    x[i] *= dinv[i];
+  asm volatile("" ::: "memory"); // re-read L for the transposed solve (register pressure)
+#pragma unroll
+  for (int j = NU - 2; j >= 0; --j) {
+    double s = x[j];
+#pragma unroll
+    for (int i = j + 1; i < NU; ++i)
+      s -= pl[i * (i - 1) / 2 + j] * x[i];
+    x[j] = s;
+  }
+}
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
+  using C = MfmaCfg<NX, NU>;
+  constexpr int NW = C::NW, PK = C::PK, PG = C::PG;
+  const WG w = wg_self();
+  double *sm = gar_smem;
+  const int lane = w.lane, wave = w.wave;
+  const int li = lane & 15, lk = lane >> 4;
+  const int b = (int)blockIdx.x;
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  double *fac = P.fac + (long long)b * P.fac_stride;
+  const int N = P.horizon;
+  double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM;
+  double *vn = sm + C::oVn, *vp = sm + C::oVp;
+  double *Lw = sm + C::oL + wave * (C::NL + NU + (C::NL + NU) % 2);
+  int failed = 0;
+
+  // ---- terminal knot (terminalSolve, nu = 0, nc = 0, :175-178): Vxx = Q, vx = q
+  {
+    const double *rec = prob + P.in_offN;
+    double *out = fac + P.fac_offN;
+    for (int e = w.tid; e < NX * NX; e += 256) {
+      const int j = e / NX, i = e - j * NX; // column-major element (i, j)
+      const double v = (i >= j) ? rec[C::tQ + e] : rec[C::tQ + i * NX + j];
+      V[i * PK + j] = v;                 // symmetrised from lower, as the consumer does (:216)
+      out[C::tVxx + e] = v;
+    }
+    for (int e = w.tid; e < NX; e += 256) {
+      const double v = rec[C::tq + e];
+      vn[e] = v;
+      out[C::tvx + e] = v;
+    }
+    // prologue: knot N-1 -> Ft[(N-1)&1]
+    if (N >= 1) {
+      const double *r1 = prob + P.in_off0 + (long long)(N - 1) * P.in_rec;
+      double *Ft = sm + (((N - 1) & 1) ? C::oFt1 : C::oFt0);
+      for (int e = w.tid; e < NX * NW; e += 256) {
+        const int j = e / NX, k = e - j * NX;
+        Ft[j * PK + k] = r1[C::kA + e]; // [A B] column-major == F^T rows with pitch PK
+      }
+      for (int e = w.tid; e < NX; e += 256)
+        sm[C::oFv + ((N - 1) & 1) * NX + e] = r1[C::kf + e];
+      for (int e = w.tid; e < NW; e += 256)
+        sm[C::oQr + ((N - 1) & 1) * NW + e] = r1[C::kq + e];
+    }
+  }
+  __syncthreads();
+
+  for (int t = N - 1; t >= 0; --t) {
+    const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
+    double *out = fac + (long long)t * P.fac_rec;
+    const int cur = t & 1;
+    const double *Ft = sm + (cur ? C::oFt1 : C::oFt0);
+    double *Ftn = sm + (cur ? C::oFt0 : C::oFt1);
+    const double *fv = sm + C::oFv + cur * NX;
+    const double *qr = sm + C::oQr + cur * NW;
+
+    double4_t Hc[C::TW];  // H tiles (ti, tj=wave), ti >= tj
+    double x[NU];         // this lane's solve column (K column / kff)
+    double a_row[NU], dinv[NU];
+    double qhat = 0.0;    // wave 3, lane i < NX
+    // wave 3: prefetch registers for knot t-1
+    constexpr int PFN = (NX * NW + 63) / 64;  // doubles per lane of [A B]
+    constexpr int PFC = (PFN + 2) / 3;        // ... moved in 3 chunks (register pressure)
+    double pf[PFC];
+    double pf_f = 0.0, pf_qr = 0.0;
+    const double *rn = rec - P.in_rec;        // knot t-1 (valid when t > 0)
+#define GAR_PF_LOAD(ch)                                                        \
+  if (t > 0) {                                                                 \
+    _Pragma("unroll") for (int q = 0; q < PFC; ++q) {                          \
+      const int e = lane + 64 * ((ch) * PFC + q);                              \
+      pf[q] = (e < NX * NW) ? rn[C::kA + e] : 0.0;                             \
+    }                                                                          \
+  }
+#define GAR_PF_STORE(ch)                                                       \
+  if (t > 0) {                                                                 \
+    _Pragma("unroll") for (int q = 0; q < PFC; ++q) {                          \
+      const int e = lane + 64 * ((ch) * PFC + q);                              \
+      if (e < NX * NW) {                                                       \
+        const int j = e / NX, k = e - j * NX;                                  \
+        Ftn[j * PK + k] = pf[q];                                               \
+      }                                                                        \
+    }                                                                          \
+  }
+
+    if (wave < 3) {
+      const int tj = wave;
+      if (tj < C::TW) {
+        // C-init of H tiles from the knot record (lower elements), issued early
+#pragma unroll
+        for (int ti = 0; ti < C::TW; ++ti)
+          if (ti >= tj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              Hc[ti][r] = w_lower<NX, NU>(rec, 16 * ti + lk + 4 * r, 16 * tj + li);
+          }
+        // S1: P(:, tj) = V' F(:, tj)            (:216-221, AtV/BtV fused)
+        double4_t Pt[C::TX];
+#pragma unroll
+        for (int tm = 0; tm < C::TX; ++tm)
+          Pt[tm] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+          const double bq = Ft[(16 * tj + li) * PK + 4 * s + lk];
+#pragma unroll
+          for (int tm = 0; tm < C::TX; ++tm) {
+            const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
+            const double aq = V[ic * PK + 4 * s + lk];
+            Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, Pt[tm], 0, 0, 0);
+          }
+        }
+        // S2: H(ti, tj) += F(:, ti)^T P(:, tj); B operand = P's D registers (:224-228)
+#pragma unroll
+        for (int ti = 0; ti < C::TW; ++ti)
+          if (ti >= tj) {
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+              const double aq = Ft[(16 * ti + li) * PK + 4 * s + lk];
+              Hc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Pt[s >> 2][s & 3], Hc[ti], 0, 0, 0);
+            }
+          }
+        // export the control rows: G(u, 1+j) = -Shat^T(u, j), M = Rhat (lower)
+#pragma unroll
+        for (int ti = 0; ti < C::TW; ++ti)
+          if (ti >= tj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+              if (row >= NX && row < NW) {
+                if (col < NX)
+                  G[(row - NX) * PG + 1 + col] = -Hc[ti][r];
+                else if (col <= row)
+                  Mm[(col - NX) * NU + (row - NX)] = Hc[ti][r];
+              }
+            }
+          }
+      }
+    } else {
+      // ---- wave 3: prefetch knot t-1, vector recursions ----------------------
+      GAR_PF_LOAD(0)
+      if (t > 0) {
+        pf_f = (lane < NX) ? rn[C::kf + lane] : 0.0;
+        pf_qr = (lane < NW) ? rn[C::kq + lane] : 0.0;
+      }
+      // vplus = vx' + V' f (:217-218), lane i < NX
+      {
+        const int ic = lane < NX ? lane : NX - 1;
+        double s = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < NX; ++k)
+          s += V[ic * PK + k] * fv[k];
+        if (lane < NX)
+          vp[lane] = vn[lane] + s;
+      }
+      wave_sync();
+      // [qhat; rhat] = [q; r] + F^T vplus (:227-228), lane j < NW
+      {
+        const int jc = lane < NW ? lane : NW - 1;
+        double s = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < NX; ++k)
+          s += Ft[jc * PK + k] * vp[k];
+        const double hj = qr[jc] + s;
+        qhat = hj;
+        if (lane >= NX && lane < NW)
+          G[(lane - NX) * PG] = -hj; // kff right-hand side (:248)
+      }
+      GAR_PF_STORE(0)
+      GAR_PF_LOAD(1)
+    }
+    __syncthreads(); // #1: G, M complete
+
+    // ---- factor Rhat (every wave, redundantly, in registers) -------------------
+    const int verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
+    int col = 0; // G column this lane solves: 0 = kff (wave 3), 1 + x-index for workers
+    if (wave < 3) {
+      const int c = 16 * wave + li;
+      col = 1 + (c < NX ? c : NX - 1);
+    }
+    if (verdict == 0) {
+      // publish L (packed strictly lower) to this wave's LDS slot, then solve
+      if (lane < NU) {
+#pragma unroll
+        for (int j = 0; j < NU - 1; ++j)
+          if (j < lane)
+            Lw[lane * (lane - 1) / 2 + j] = a_row[j];
+      }
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < NU; ++k)
+        x[k] = G[k * PG + col];
+      ldl_solve_regs<NU>(Lw, dinv, x);
+    } else {
+      // Bunch-Kaufman would interchange here: do what the reference does, with the
+      // generic device BK (uniform for the workgroup: every wave saw the same M).
+      double *G2 = sm + C::oFb;
+      double *sub = G2 + NU * PG + 16;
+      int *piv = (int *)(sub + 16);
+      for (int e = w.tid; e < NU * PG; e += 256)
+        G2[e] = G[e];
+      __syncthreads();
+      failed |= wg_bk_factor(w, NU, Mm, NU, sub, piv, piv + 16);
+      wg_bk_solve(w, NU, Mm, NU, sub, piv, G2, PG, 1, NX + 1);
+#pragma unroll
+      for (int k = 0; k < NU; ++k)
+        x[k] = G2[k * PG + col];
+    }
+
+    if (wave < 3) {
+      const int tj = wave;
+      if (tj < C::TX) {
+        const int c = 16 * tj + li;
+        // K -> fb rows 0..NU-1 (row-major NU x NX), one lane group stores
+        if (lk == 0 && c < NX) {
+#pragma unroll
+          for (int k = 0; k < NU; ++k)
+            out[C::fFB + k * NX + c] = x[k];
+        }
+        double Kb[C::KU]; // B operand K[u = 4s + lk][j = c]
+#pragma unroll
+        for (int s = 0; s < C::KU; ++s)
+          Kb[s] = lk == 0 ? x[4 * s] : (lk == 1 ? x[4 * s + 1] : (lk == 2 ? x[4 * s + 2] : x[4 * s + 3]));
+        // Aff(ti, tj) = A + B K (:267) -> fb rows NU.. (row-major)
+#pragma unroll
+        for (int ti = 0; ti < C::TX; ++ti) {
+          double4_t acc;
+          const int jc = c < NX ? c : NX - 1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + lk + 4 * r;
+            acc[r] = Ft[jc * PK + (i < NX ? i : NX - 1)]; // A(i, j) = F^T(j, i)
+          }
+#pragma unroll
+          for (int s = 0; s < C::KU; ++s) {
+            const double aq = Ft[(NX + 4 * s + lk) * PK + 16 * ti + li]; // B(i, u)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[s], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + lk + 4 * r;
+            if (i < NX && c < NX)
+              out[C::fFB + (NU + i) * NX + c] = acc[r];
+          }
+        }
+        // Vxx(ti, tj), ti >= tj: Qhat + Shat K (:272-273); lower tiles only, mirrored
+#pragma unroll
+        for (int ti = 0; ti < C::TX; ++ti)
+          if (ti >= tj) {
+            double4_t acc = Hc[ti];
+#pragma unroll
+            for (int s = 0; s < C::KU; ++s) {
+              const double aq = -G[(4 * s + lk) * PG + 1 + 16 * ti + li]; // Shat(i, u)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * ti + lk + 4 * r;
+              if (i < NX && c < NX && i >= c) {
+                V[i * PK + c] = acc[r];
+                V[c * PK + i] = acc[r];
+              }
+            }
+          }
+      }
+    } else {
+      // wave 3: x = kff (uniform).  yff = f + B kff (:266), vx = qhat + Shat kff (:275-276)
+      GAR_PF_STORE(1)
+      GAR_PF_LOAD(2)
+      const int ic = lane < NX ? lane : NX - 1;
+      double yf = fv[ic], vxv = qhat;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        yf += Ft[(NX + u) * PK + ic] * x[u];
+        vxv -= G[u * PG + 1 + ic] * x[u];
+      }
+      double ku = 0.0;
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+        ku = (lane == u) ? x[u] : ku;
+      if (lane < NU)
+        out[C::fFF + lane] = ku;
+      if (lane < NX) {
+        out[C::fFF + NU + lane] = yf;
+        out[C::fvx + lane] = vxv;
+        vn[lane] = vxv;
+      }
+      GAR_PF_STORE(2)
+      if (t > 0) { // prefetched f, q, r of knot t-1 -> LDS
+        if (lane < NX)
+          sm[C::oFv + (cur ^ 1) * NX + lane] = pf_f;
+        if (lane < NW)
+          sm[C::oQr + (cur ^ 1) * NW + lane] = pf_qr;
+      }
+    }
+    __syncthreads(); // #2: V, vn, Ft[next] complete
+    for (int e = w.tid; e < NX * NX; e += 256) { // Vxx -> HBM (column-major, symmetric)
+      const int j = e / NX, i = e - j * NX;
+      out[C::fVxx + e] = V[i * PK + j];
+    }
+#undef GAR_PF_LOAD
+#undef GAR_PF_STORE
+  }
+  if (failed && w.tid == 0)
+    atomicOr(&P.status[b], failed);
+}
+
+} // namespace gar

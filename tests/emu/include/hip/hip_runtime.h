@@ -80,6 +80,53 @@ inline emu_double4 emu_mfma_f64_16x16x4(double a, double b, emu_double4 c, int, 
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64 emu_mfma_f64_16x16x4
 
+// ---- wave-level exchange (lock-step via the wave barrier) ----------------------
+namespace emu {
+inline WaveCtx &wave() { return *block->waves[threadIdx.x >> 6]; }
+} // namespace emu
+inline double __shfl(double v, int src) {
+  emu::WaveCtx &W = emu::wave();
+  const int lane = threadIdx.x & 63;
+  W.a[lane] = v;
+  W.bar.arrive_and_wait();
+  const double r = W.a[src & 63];
+  W.bar.arrive_and_wait();
+  return r;
+}
+inline double __shfl_xor(double v, int mask) { return __shfl(v, (int)((threadIdx.x & 63) ^ mask)); }
+inline int __builtin_amdgcn_readlane(int v, int src) {
+  emu::WaveCtx &W = emu::wave();
+  const int lane = threadIdx.x & 63;
+  W.b[lane] = (double)v; // exact for 32-bit ints
+  W.bar.arrive_and_wait();
+  const int r = (int)W.b[src & 63];
+  W.bar.arrive_and_wait();
+  return r;
+}
+inline unsigned long long __ballot(int pred) {
+  emu::WaveCtx &W = emu::wave();
+  const int lane = threadIdx.x & 63;
+  W.a[lane] = pred ? 1.0 : 0.0;
+  W.bar.arrive_and_wait();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if (W.a[l] != 0.0)
+      m |= 1ull << l;
+  W.bar.arrive_and_wait();
+  return m;
+}
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
+inline double __hiloint2double(int hi, int lo) {
+  long long b = ((long long)hi << 32) | (unsigned int)lo;
+  double d; std::memcpy(&d, &b, 8); return d;
+}
+inline void __builtin_amdgcn_wave_barrier() {
+  emu::wave().bar.arrive_and_wait();
+}
+#define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
+
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 

@@ -120,3 +120,61 @@ def test_cycle_append_rotates_factors():                      # proximal-riccati
         assert np.array_equal(s.getFeedback(t), before[t + 1])
     assert np.array_equal(s.getFeedback(5), np.zeros_like(before[5]))   # re-created factor
     assert np.array_equal(s.getFeedback(6), before[6])                  # terminal factor kept
+
+
+# ---- the specialised MFMA backward kernel (csrc/gar_mfma.hpp) -----------------
+@pytest.mark.parametrize("nx,nu,horz,mode", [(8, 4, 3, "W"), (12, 4, 5, "W"), (16, 8, 4, "F"),
+                                             (36, 12, 4, "W"), (36, 12, 3, "F"), (32, 12, 3, "W")])
+def test_mfma_kernel_matches_oracle(nx, nu, horz, mode):
+    prob = synth.generate_lq_problem(7, np.zeros(nx), horz, nx, nu, mode=mode)
+    solver, _, _ = pc.check_serial(prob, 1e-12, pc.TOL[mode], EMU,
+                                   kkt_tol=1e-6 if mode == "F" else 1e-9)
+    assert solver.kernel_name == f"mfma<{nx},{nu}>"
+
+
+def test_mfma_kernel_bunch_kaufman_fallback():
+    """A stage whose Rhat makes Bunch-Kaufman interchange (rule at
+    bunchkaufman.hpp:61-83) must take the generic device BK, uniformly for the
+    workgroup, and still match the oracle."""
+    from oracle import oracle as ora
+    nx, nu = 8, 4
+    prob = synth.generate_lq_problem(11, np.zeros(nx), 4, nx, nu, mode="W")
+    for k in prob.stages[:-1]:
+        k.R[...] = np.array([[1e-3, 2.0, 0.1, 0.0], [2.0, 1e-3, 0.0, 0.1],
+                             [0.1, 0.0, 3.0, 0.2], [0.0, 0.1, 0.2, 4.0]])
+        k.B[...] *= 1e-2
+    op, osol, _ = pc.oracle_serial(prob, 1e-12)
+    pivots = [ora.BunchKaufman(osol.datas(t).Rhat).pivots for t in range(4)]
+    assert any(not np.array_equal(p, np.arange(nu)) for p in pivots), "test must force a pivot"
+    solver, _, _ = pc.check_serial(prob, 1e-12, 1e-9, EMU)
+    assert solver.kernel_name == "mfma<8,4>"
+
+
+def test_mfma_kernel_failed_factorisation_raises():
+    from aligator_amd.gar import ProximalRiccatiSolver
+    prob = synth.generate_lq_problem(3, np.zeros(8), 3, 8, 4, mode="W")
+    for k in prob.stages[:-1]:
+        k.R[...] = 0.0
+        k.S[...] = 0.0
+        k.B[...] = 0.0
+    s = ProximalRiccatiSolver(prob, lib_path=EMU)
+    assert s.kernel_name == "mfma<8,4>"
+    with pytest.raises(RuntimeError, match="LDL"):
+        s.backward(1e-10)
+
+
+def test_mfma_and_generic_kernels_agree(monkeypatch):
+    prob = synth.generate_lq_problem(5, np.zeros(12), 6, 12, 4, mode="W")
+    from aligator_amd.gar import ProximalRiccatiSolver, lqrInitializeSolution
+    a = ProximalRiccatiSolver(prob, lib_path=EMU)
+    a.backward(1e-12)
+    sa = lqrInitializeSolution(prob)
+    a.forward(*sa)
+    monkeypatch.setenv("GAR_HIP_FORCE_GENERIC", "1")
+    g = ProximalRiccatiSolver(prob, lib_path=EMU)
+    assert g.kernel_name == "generic" and a.kernel_name == "mfma<12,4>"
+    g.backward(1e-12)
+    sg = lqrInitializeSolution(prob)
+    g.forward(*sg)
+    for A, B in zip(sa, sg):
+        assert pc.maxdiff(A, B) <= 1e-11
