@@ -33,9 +33,21 @@ struct MatV {
 __device__ __forceinline__ MatV colmajor(double *p, int ld) { return MatV{p, 1, ld}; }
 __device__ __forceinline__ MatV rowmajor(double *p, int ld) { return MatV{p, ld, 1}; }
 
-struct WG { // who am I inside the workgroup
+struct WG { // who am I inside the cooperating group (a workgroup, or one wave)
   int tid, nthr, lane, wave, nwaves;
+  int wave_scope; // 1: the group is a single wave (tid = lane, nthr = 64)
 };
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// barrier of the cooperating group
+__device__ __forceinline__ void wg_bar(const WG &w) {
+  if (w.wave_scope)
+    wave_sync();
+  else
+    __syncthreads();
+}
 __device__ __forceinline__ WG wg_self() {
   WG w;
   w.tid = (int)threadIdx.x;
@@ -43,6 +55,17 @@ __device__ __forceinline__ WG wg_self() {
   w.lane = w.tid & 63;
   w.wave = w.tid >> 6;
   w.nwaves = w.nthr >> 6;
+  w.wave_scope = 0;
+  return w;
+}
+__device__ __forceinline__ WG wave_self() { // this wave as its own group
+  WG w;
+  w.lane = (int)threadIdx.x & 63;
+  w.tid = w.lane;
+  w.nthr = 64;
+  w.wave = 0;
+  w.nwaves = 1;
+  w.wave_scope = 1;
   return w;
 }
 
@@ -140,22 +163,22 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
   if (n == 0)
     return 0;
   if (n == 1) { // :36-43
-    __syncthreads();
+    wg_bar(w);
     int bad = (fabs(GA(0, 0)) == 0.0);
-    __syncthreads();
+    wg_bar(w);
     if (w.tid == 0) {
       if (!bad)
         GA(0, 0) = 1.0 / GA(0, 0);
       piv[0] = 0;
       subdiag[0] = 0.0;
     }
-    __syncthreads();
+    wg_bar(w);
     return bad;
   }
   int k = 0;
   int info = 0;
   while (k < n) {
-    __syncthreads();
+    wg_bar(w);
     if (w.tid == 0) { // pivot search, :46-83
       int k_step = 1, kp, fail = 0;
       const double abs_akk = fabs(GA(k, k));
@@ -195,7 +218,7 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       ctrl[1] = kp;
       ctrl[2] = fail;
     }
-    __syncthreads();
+    wg_bar(w);
     const int k_step = ctrl[0], kp = ctrl[1];
     if (ctrl[2]) { // NumericalIssue: keep the remaining pivots in range and stop
       for (int i = k + w.tid; i < n; i += w.nthr)
@@ -226,7 +249,7 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
           GA(kp, k) = t2;
         }
       }
-      __syncthreads();
+      wg_bar(w);
     }
     if (k_step == 1) { // :104-121
       const int m = n - k - 1;
@@ -238,7 +261,7 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
           GA(k + 1 + i, k + 1 + j) -= d11xj * GA(k + 1 + i, k);
         }
       }
-      __syncthreads();
+      wg_bar(w);
       for (int i = w.tid; i < m; i += w.nthr)
         GA(k + 1 + i, k) *= d11;
       if (w.tid == 0) {
@@ -272,7 +295,7 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
           wkp1_r[q] = ((GA(j, k + 1) * d22) - (GA(j, k) * d21)) * d;
         }
       }
-      __syncthreads();
+      wg_bar(w);
       for (int q = 0; q < 2; ++q) {
         const int j = k + 2 + w.tid + q * w.nthr;
         if (j < n) {
@@ -290,7 +313,7 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
     }
     k += k_step;
   }
-  __syncthreads();
+  wg_bar(w);
   // subdiag extraction (:393-404) and row interchanges of the L part (:406-417).
   // Thread c applies the interchange sequence to column c of L.
   for (int c = w.tid; c < n; c += w.nthr) {
@@ -314,10 +337,10 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       kq += step;
     }
   }
-  __syncthreads();
+  wg_bar(w);
   for (int kq = w.tid; kq < n; kq += w.nthr)
     subdiag[kq] = 0.0;
-  __syncthreads();
+  wg_bar(w);
   if (w.tid == 0) { // pairs are rare; serial pass keeps the pairing unambiguous
     int kq = 0;
     while (kq < n) {
@@ -331,7 +354,7 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       }
     }
   }
-  __syncthreads();
+  wg_bar(w);
   return info;
 #undef GA
 }
@@ -407,7 +430,7 @@ __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
       }
     }
   }
-  __syncthreads();
+  wg_bar(w);
 #undef GA
 #undef GX
 }

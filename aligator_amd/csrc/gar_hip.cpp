@@ -70,6 +70,7 @@ struct gar_hip_solver {
   // specialised backward kernel (gar_mfma.hpp), null = generic
   void (*mfma_kernel)(gar::MfmaParams) = nullptr;
   int mfma_lds_doubles = 0;
+  long long *d_trace = nullptr; // 64 cycle stamps (debug)
 };
 
 namespace {
@@ -338,6 +339,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.fac_rec = N > 1 ? s->meta[1].fac_off - s->meta[0].fac_off : s->meta[N].fac_off;
     M.fac_offN = s->meta[N].fac_off;
     M.horizon = N;
+    M.trace = s->d_trace;
     hipLaunchKernelGGL(s->mfma_kernel, dim3((unsigned)s->batch), dim3(256),
                        (size_t)s->mfma_lds_doubles * sizeof(double), s->stream, M);
     HIP_TRY(hipGetLastError());
@@ -419,6 +421,8 @@ void free_device(gar_hip_solver *s) {
     (void)hipFree(s->d_bound_all);
   (void)hipFree(s->d_csol);
   (void)hipFree(s->d_cscratch);
+  (void)hipFree(s->d_trace);
+  s->d_trace = nullptr;
   if (s->h_prob)
     (void)hipHostFree(s->h_prob);
   s->d_meta = nullptr;
@@ -886,6 +890,23 @@ int gar_hip_get_factors(gar_hip_solver *s, int b, double *out) {
   if (int rc = d2h(s, out, s->d_fac + (int64_t)b * s->fac_doubles, s->fac_doubles))
     return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (enable && !s->d_trace) {
+    HIP_TRY(hipMalloc((void **)&s->d_trace, sizeof(long long) * 64));
+    HIP_TRY(hipMemset(s->d_trace, 0, sizeof(long long) * 64));
+  }
+  if (out && s->d_trace)
+    HIP_TRY(hipMemcpy(out, s->d_trace, sizeof(long long) * 64, hipMemcpyDeviceToHost));
+  if (!enable && s->d_trace) {
+    (void)hipFree(s->d_trace);
+    s->d_trace = nullptr;
+  }
   return GAR_HIP_OK;
 }
 

@@ -35,6 +35,7 @@ struct MfmaParams {
   long long in_off0, in_rec, in_offN; // knot record of stage t < N at in_off0 + t*in_rec
   long long fac_rec, fac_offN;        // factor record of stage t < N at t*fac_rec
   int horizon;
+  long long *trace; // debug: per-wave cycle stamps of one stage of problem 0 (or null)
 };
 
 template <int NX, int NU> struct MfmaCfg {
@@ -59,13 +60,15 @@ template <int NX, int NU> struct MfmaCfg {
   static constexpr int oFt1 = oFt0 + FROWS * PK + 16;
   static constexpr int oG = oFt1 + FROWS * PK + 16;
   static constexpr int oM = oG + NU * PG + 16;
-  static constexpr int oL = oM + NU * NU;      // 4 per-wave packed L copies + dinv
-  static constexpr int oVec = oL + 4 * (NL + NU + (NL + NU) % 2);
+  static constexpr int oL = oM + NU * NU;      // packed strictly-lower L
+  static constexpr int oVec = oL + NL + (NL % 2);
   // vectors: vn[NX] fv[2][NX] qr[2][NW] vp[NX]
   static constexpr int oVn = oVec, oFv = oVn + NX, oQr = oFv + 2 * NX, oVp = oQr + 2 * NW;
-  // Bunch-Kaufman fallback scratch: G2 (NU*PG+16), sub (16), piv+ctrl (16 doubles)
-  static constexpr int oFb = (oVp + NX + 1) & ~1;
-  static constexpr int total = oFb + NU * PG + 16 + 16 + 16;
+  // G2 = solution [kff | K] in the layout of G (pitch PG); the Bunch-Kaufman
+  // fallback solves in place there; sub (16) and piv+ctrl (16 doubles) follow
+  static constexpr int oG2 = (oVp + NX + 1) & ~1;
+  static constexpr int oBk = oG2 + NU * PG + 16;
+  static constexpr int total = oBk + 16 + 16;
   // record offsets (uniform stage / terminal knot)
   static constexpr int kQ = 0, kS = NX * NX, kR = kS + NX * NU, kq = kR + NU * NU, kr = kq + NX,
                        kA = kr + NU, kB = kA + NX * NX, kf = kB + NX * NU;
@@ -79,10 +82,6 @@ __device__ __forceinline__ double lane_bcast(double v, int src /*wave-uniform*/)
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // Element (a, b), a >= b, of the stage Hessian [Q S; S^T R] read from the knot
 // record through its LOWER triangle (the reference's products only ever feed the
@@ -90,14 +89,15 @@ __device__ __forceinline__ void wave_sync() {
 template <int NX, int NU>
 __device__ __forceinline__ double w_lower(const double *rec, int row, int col) {
   using C = MfmaCfg<NX, NU>;
-  const int a = row >= col ? row : col, b = row >= col ? col : row;
-  if (a >= C::NW)
-    return 0.0;
-  if (a < NX)
-    return rec[C::kQ + b * NX + a];
-  if (b < NX)
-    return rec[C::kS + (a - NX) * NX + b];
-  return rec[C::kR + (b - NX) * NU + (a - NX)];
+  int a = row >= col ? row : col, b = row >= col ? col : row;
+  a = a < C::NW ? a : C::NW - 1; // padded tile rows: any valid element (result unused)
+  b = b < C::NW ? b : C::NW - 1;
+  // one address, one load (no divergent branches around the HBM loads)
+  const int iq = C::kQ + b * NX + a;
+  const int is = C::kS + (a - NX) * NX + b;
+  const int ir = C::kR + (b - NX) * NU + (a - NX);
+  const int idx = a < NX ? iq : (b < NX ? is : ir);
+  return rec[idx];
 }
 
 // Unpivoted LDL^T of the NU x NU matrix M (LDS, column-major, lower valid) in
@@ -196,106 +196,80 @@ template <int NX, int NU>
 __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
   using C = MfmaCfg<NX, NU>;
   constexpr int NW = C::NW, PK = C::PK, PG = C::PG;
-  const WG w = wg_self();
   double *sm = gar_smem;
-  const int lane = w.lane, wave = w.wave;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int b = (int)blockIdx.x;
   const double *prob = P.prob + (long long)b * P.prob_stride;
   double *fac = P.fac + (long long)b * P.fac_stride;
   const int N = P.horizon;
-  double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM;
-  double *vn = sm + C::oVn, *vp = sm + C::oVp;
-  double *Lw = sm + C::oL + wave * (C::NL + NU + (C::NL + NU) % 2);
-  int failed = 0;
+  double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM, *G2 = sm + C::oG2;
+  double *vn = sm + C::oVn, *vp = sm + C::oVp, *Lp = sm + C::oL;
+  const bool tracing = P.trace != nullptr && b == 0 && lane == 0;
+#define GAR_MARK(id)                                                           \
+  if (tracing && t == (N >> 1))                                                \
+    P.trace[wave * 16 + (id)] = (long long)clock64();
 
   // ---- terminal knot (terminalSolve, nu = 0, nc = 0, :175-178): Vxx = Q, vx = q
   {
     const double *rec = prob + P.in_offN;
     double *out = fac + P.fac_offN;
-    for (int e = w.tid; e < NX * NX; e += 256) {
+    for (int e = tid; e < NX * NX; e += 256) {
       const int j = e / NX, i = e - j * NX; // column-major element (i, j)
       const double v = (i >= j) ? rec[C::tQ + e] : rec[C::tQ + i * NX + j];
-      V[i * PK + j] = v;                 // symmetrised from lower, as the consumer does (:216)
+      V[i * PK + j] = v; // symmetrised from lower, as the consumer stage does (:216)
       out[C::tVxx + e] = v;
     }
-    for (int e = w.tid; e < NX; e += 256) {
+    for (int e = tid; e < NX; e += 256) {
       const double v = rec[C::tq + e];
       vn[e] = v;
       out[C::tvx + e] = v;
     }
-    // prologue: knot N-1 -> Ft[(N-1)&1]
-    if (N >= 1) {
+    if (N >= 1) { // prologue: knot N-1 -> Ft[(N-1)&1]
       const double *r1 = prob + P.in_off0 + (long long)(N - 1) * P.in_rec;
       double *Ft = sm + (((N - 1) & 1) ? C::oFt1 : C::oFt0);
-      for (int e = w.tid; e < NX * NW; e += 256) {
+      for (int e = tid; e < NX * NW; e += 256) {
         const int j = e / NX, k = e - j * NX;
         Ft[j * PK + k] = r1[C::kA + e]; // [A B] column-major == F^T rows with pitch PK
       }
-      for (int e = w.tid; e < NX; e += 256)
+      for (int e = tid; e < NX; e += 256)
         sm[C::oFv + ((N - 1) & 1) * NX + e] = r1[C::kf + e];
-      for (int e = w.tid; e < NW; e += 256)
+      for (int e = tid; e < NW; e += 256)
         sm[C::oQr + ((N - 1) & 1) * NW + e] = r1[C::kq + e];
     }
   }
   __syncthreads();
 
-  for (int t = N - 1; t >= 0; --t) {
-    const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
-    double *out = fac + (long long)t * P.fac_rec;
-    const int cur = t & 1;
-    const double *Ft = sm + (cur ? C::oFt1 : C::oFt0);
-    double *Ftn = sm + (cur ? C::oFt0 : C::oFt1);
-    const double *fv = sm + C::oFv + cur * NX;
-    const double *qr = sm + C::oQr + cur * NW;
-
-    double4_t Hc[C::TW];  // H tiles (ti, tj=wave), ti >= tj
-    double x[NU];         // this lane's solve column (K column / kff)
-    double a_row[NU], dinv[NU];
-    double qhat = 0.0;    // wave 3, lane i < NX
-    // wave 3: prefetch registers for knot t-1
-    constexpr int PFN = (NX * NW + 63) / 64;  // doubles per lane of [A B]
-    constexpr int PFC = (PFN + 2) / 3;        // ... moved in 3 chunks (register pressure)
-    double pf[PFC];
-    double pf_f = 0.0, pf_qr = 0.0;
-    const double *rn = rec - P.in_rec;        // knot t-1 (valid when t > 0)
-#define GAR_PF_LOAD(ch)                                                        \
-  if (t > 0) {                                                                 \
-    _Pragma("unroll") for (int q = 0; q < PFC; ++q) {                          \
-      const int e = lane + 64 * ((ch) * PFC + q);                              \
-      pf[q] = (e < NX * NW) ? rn[C::kA + e] : 0.0;                             \
-    }                                                                          \
-  }
-#define GAR_PF_STORE(ch)                                                       \
-  if (t > 0) {                                                                 \
-    _Pragma("unroll") for (int q = 0; q < PFC; ++q) {                          \
-      const int e = lane + 64 * ((ch) * PFC + q);                              \
-      if (e < NX * NW) {                                                       \
-        const int j = e / NX, k = e - j * NX;                                  \
-        Ftn[j * PK + k] = pf[q];                                               \
-      }                                                                        \
-    }                                                                          \
-  }
-
-    if (wave < 3) {
-      const int tj = wave;
+  if (wave < 3) {
+    // =====================================================================
+    // column-tile workers: the matrix recursions on MFMA
+    // =====================================================================
+    const int tj = wave;
+    const int c = 16 * tj + li;               // this lane's column in tile tj
+    const int cc = c < NX ? c : NX - 1;
+    for (int t = N - 1; t >= 0; --t) {
+      GAR_MARK(0)
+      const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
+      double *out = fac + (long long)t * P.fac_rec;
+      const double *Ft = sm + ((t & 1) ? C::oFt1 : C::oFt0);
+      double4_t Hc[C::TW]; // H tiles (ti, tj), ti >= tj
       if (tj < C::TW) {
-        // C-init of H tiles from the knot record (lower elements), issued early
+        // C-init of H from the knot record (lower elements); the HBM latency hides under S1
 #pragma unroll
         for (int ti = 0; ti < C::TW; ++ti)
           if (ti >= tj) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              Hc[ti][r] = w_lower<NX, NU>(rec, 16 * ti + lk + 4 * r, 16 * tj + li);
+              Hc[ti][r] = w_lower<NX, NU>(rec, 16 * ti + lk + 4 * r, c);
           }
-        // S1: P(:, tj) = V' F(:, tj)            (:216-221, AtV/BtV fused)
+        // S1: P(:, tj) = V' F(:, tj)            (:216-221, AtV / BtV fused)
         double4_t Pt[C::TX];
 #pragma unroll
         for (int tm = 0; tm < C::TX; ++tm)
           Pt[tm] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
-          const double bq = Ft[(16 * tj + li) * PK + 4 * s + lk];
+          const double bq = Ft[c * PK + 4 * s + lk];
 #pragma unroll
           for (int tm = 0; tm < C::TX; ++tm) {
             const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
@@ -303,6 +277,7 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
             Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, Pt[tm], 0, 0, 0);
           }
         }
+        GAR_MARK(1)
         // S2: H(ti, tj) += F(:, ti)^T P(:, tj); B operand = P's D registers (:224-228)
 #pragma unroll
         for (int ti = 0; ti < C::TW; ++ti)
@@ -313,116 +288,41 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
               Hc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Pt[s >> 2][s & 3], Hc[ti], 0, 0, 0);
             }
           }
+        GAR_MARK(2)
         // export the control rows: G(u, 1+j) = -Shat^T(u, j), M = Rhat (lower)
 #pragma unroll
         for (int ti = 0; ti < C::TW; ++ti)
           if (ti >= tj) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+              const int row = 16 * ti + lk + 4 * r;
               if (row >= NX && row < NW) {
-                if (col < NX)
-                  G[(row - NX) * PG + 1 + col] = -Hc[ti][r];
-                else if (col <= row)
-                  Mm[(col - NX) * NU + (row - NX)] = Hc[ti][r];
+                if (c < NX)
+                  G[(row - NX) * PG + 1 + c] = -Hc[ti][r];
+                else if (c <= row)
+                  Mm[(c - NX) * NU + (row - NX)] = Hc[ti][r];
               }
             }
           }
       }
-    } else {
-      // ---- wave 3: prefetch knot t-1, vector recursions ----------------------
-      GAR_PF_LOAD(0)
-      if (t > 0) {
-        pf_f = (lane < NX) ? rn[C::kf + lane] : 0.0;
-        pf_qr = (lane < NW) ? rn[C::kq + lane] : 0.0;
-      }
-      // vplus = vx' + V' f (:217-218), lane i < NX
-      {
-        const int ic = lane < NX ? lane : NX - 1;
-        double s = 0.0;
-#pragma unroll 4
-        for (int k = 0; k < NX; ++k)
-          s += V[ic * PK + k] * fv[k];
-        if (lane < NX)
-          vp[lane] = vn[lane] + s;
-      }
-      wave_sync();
-      // [qhat; rhat] = [q; r] + F^T vplus (:227-228), lane j < NW
-      {
-        const int jc = lane < NW ? lane : NW - 1;
-        double s = 0.0;
-#pragma unroll 4
-        for (int k = 0; k < NX; ++k)
-          s += Ft[jc * PK + k] * vp[k];
-        const double hj = qr[jc] + s;
-        qhat = hj;
-        if (lane >= NX && lane < NW)
-          G[(lane - NX) * PG] = -hj; // kff right-hand side (:248)
-      }
-      GAR_PF_STORE(0)
-      GAR_PF_LOAD(1)
-    }
-    __syncthreads(); // #1: G, M complete
-
-    // ---- factor Rhat (every wave, redundantly, in registers) -------------------
-    const int verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
-    int col = 0; // G column this lane solves: 0 = kff (wave 3), 1 + x-index for workers
-    if (wave < 3) {
-      const int c = 16 * wave + li;
-      col = 1 + (c < NX ? c : NX - 1);
-    }
-    if (verdict == 0) {
-      // publish L (packed strictly lower) to this wave's LDS slot, then solve
-      if (lane < NU) {
-#pragma unroll
-        for (int j = 0; j < NU - 1; ++j)
-          if (j < lane)
-            Lw[lane * (lane - 1) / 2 + j] = a_row[j];
-      }
-      wave_sync();
-#pragma unroll
-      for (int k = 0; k < NU; ++k)
-        x[k] = G[k * PG + col];
-      ldl_solve_regs<NU>(Lw, dinv, x);
-    } else {
-      // Bunch-Kaufman would interchange here: do what the reference does, with the
-      // generic device BK (uniform for the workgroup: every wave saw the same M).
-      double *G2 = sm + C::oFb;
-      double *sub = G2 + NU * PG + 16;
-      int *piv = (int *)(sub + 16);
-      for (int e = w.tid; e < NU * PG; e += 256)
-        G2[e] = G[e];
-      __syncthreads();
-      failed |= wg_bk_factor(w, NU, Mm, NU, sub, piv, piv + 16);
-      wg_bk_solve(w, NU, Mm, NU, sub, piv, G2, PG, 1, NX + 1);
-#pragma unroll
-      for (int k = 0; k < NU; ++k)
-        x[k] = G2[k * PG + col];
-    }
-
-    if (wave < 3) {
-      const int tj = wave;
+      GAR_MARK(3)
+      __syncthreads(); // A: G, M complete -> wave 3 factors and solves
+      GAR_MARK(4)
+      __syncthreads(); // B: [kff | K] in G2
+      GAR_MARK(5)
       if (tj < C::TX) {
-        const int c = 16 * tj + li;
-        // K -> fb rows 0..NU-1 (row-major NU x NX), one lane group stores
-        if (lk == 0 && c < NX) {
-#pragma unroll
-          for (int k = 0; k < NU; ++k)
-            out[C::fFB + k * NX + c] = x[k];
-        }
         double Kb[C::KU]; // B operand K[u = 4s + lk][j = c]
 #pragma unroll
         for (int s = 0; s < C::KU; ++s)
-          Kb[s] = lk == 0 ? x[4 * s] : (lk == 1 ? x[4 * s + 1] : (lk == 2 ? x[4 * s + 2] : x[4 * s + 3]));
+          Kb[s] = G2[(4 * s + lk) * PG + 1 + cc];
         // Aff(ti, tj) = A + B K (:267) -> fb rows NU.. (row-major)
 #pragma unroll
         for (int ti = 0; ti < C::TX; ++ti) {
           double4_t acc;
-          const int jc = c < NX ? c : NX - 1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = 16 * ti + lk + 4 * r;
-            acc[r] = Ft[jc * PK + (i < NX ? i : NX - 1)]; // A(i, j) = F^T(j, i)
+            acc[r] = Ft[cc * PK + (i < NX ? i : NX - 1)]; // A(i, j) = F^T(j, i)
           }
 #pragma unroll
           for (int s = 0; s < C::KU; ++s) {
@@ -436,6 +336,7 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
               out[C::fFB + (NU + i) * NX + c] = acc[r];
           }
         }
+        GAR_MARK(6)
         // Vxx(ti, tj), ti >= tj: Qhat + Shat K (:272-273); lower tiles only, mirrored
 #pragma unroll
         for (int ti = 0; ti < C::TX; ++ti)
@@ -456,46 +357,168 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
             }
           }
       }
-    } else {
-      // wave 3: x = kff (uniform).  yff = f + B kff (:266), vx = qhat + Shat kff (:275-276)
+      GAR_MARK(7)
+      __syncthreads(); // C: V, vn, Ft[next] complete
+      GAR_MARK(8)
+      for (int e = tid; e < NX * NX; e += 192) { // Vxx -> HBM (column-major, symmetric)
+        const int j = e / NX, i = e - j * NX;
+        out[C::fVxx + e] = V[i * PK + j];
+      }
+      GAR_MARK(9)
+    }
+  } else {
+    // =====================================================================
+    // wave 3: streams knot t-1 into LDS, runs the vector recursions, factors
+    // Rhat and solves for [kff | K]
+    // =====================================================================
+    const WG w1 = wave_self();
+    int failed = 0;
+    for (int t = N - 1; t >= 0; --t) {
+      GAR_MARK(0)
+      const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
+      double *out = fac + (long long)t * P.fac_rec;
+      const int cur = t & 1;
+      const double *Ft = sm + (cur ? C::oFt1 : C::oFt0);
+      double *Ftn = sm + (cur ? C::oFt0 : C::oFt1);
+      const double *fv = sm + C::oFv + cur * NX;
+      const double *qr = sm + C::oQr + cur * NW;
+      const double *rn = rec - (t > 0 ? P.in_rec : 0); // knot t-1 (t = 0: harmless re-read)
+      // [A B] of knot t-1 moves HBM -> registers -> LDS in 3 chunks interleaved with
+      // the arithmetic below; indices are clamped, never predicated, so the loads
+      // stay in flight together
+      constexpr int PFN = (NX * NW + 63) / 64, PFC = (PFN + 2) / 3;
+      double pf[PFC];
+#define GAR_PF_LOAD(ch)                                                        \
+  _Pragma("unroll") for (int q = 0; q < PFC; ++q) {                            \
+    const int e = lane + 64 * ((ch) * PFC + q);                                \
+    pf[q] = rn[C::kA + (e < NX * NW ? e : NX * NW - 1)];                       \
+  }
+#define GAR_PF_STORE(ch)                                                       \
+  _Pragma("unroll") for (int q = 0; q < PFC; ++q) {                            \
+    const int e = lane + 64 * ((ch) * PFC + q);                                \
+    const int ec = e < NX * NW ? e : NX * NW - 1;                              \
+    const int j = ec / NX, k = ec - j * NX;                                    \
+    Ftn[j * PK + k] = pf[q];                                                   \
+  }
+      GAR_PF_LOAD(0)
+      const double pf_f = rn[C::kf + (lane < NX ? lane : NX - 1)];
+      const double pf_qr = rn[C::kq + (lane < NW ? lane : NW - 1)];
+      double qhat;
+      // vplus = vx' + V' f (:217-218), lane i < NX
+      {
+        const int ic = lane < NX ? lane : NX - 1;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; k += 2) {
+          s0 += V[ic * PK + k] * fv[k];
+          s1 += V[ic * PK + k + 1] * fv[k + 1];
+        }
+        if (lane < NX)
+          vp[lane] = vn[lane] + (s0 + s1);
+      }
+      wave_sync();
+      GAR_MARK(1)
+      // [qhat; rhat] = [q; r] + F^T vplus (:227-228), lane j < NW
+      {
+        const int jc = lane < NW ? lane : NW - 1;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; k += 2) {
+          s0 += Ft[jc * PK + k] * vp[k];
+          s1 += Ft[jc * PK + k + 1] * vp[k + 1];
+        }
+        qhat = qr[jc] + (s0 + s1);
+        if (lane >= NX && lane < NW)
+          G[(lane - NX) * PG] = -qhat; // kff right-hand side (:248)
+      }
+      GAR_MARK(2)
+      GAR_PF_STORE(0)
+      GAR_PF_LOAD(1)
+      GAR_MARK(3)
+      __syncthreads(); // A
+      GAR_MARK(4)
+      // ---- factor Rhat in registers (lane = row) under the Bunch-Kaufman rule ----
+      double a_row[NU], dinv[NU], x[NU];
+      const int verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
+      GAR_MARK(5)
+      const int col = lane <= NX ? lane : NX; // G column: 0 = kff, 1 + j = K(:, j)
+      if (verdict == 0) {
+        if (lane < NU) {
+#pragma unroll
+          for (int j = 0; j < NU - 1; ++j)
+            if (j < lane)
+              Lp[lane * (lane - 1) / 2 + j] = a_row[j];
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+          x[k] = G[k * PG + col];
+        ldl_solve_regs<NU>(Lp, dinv, x);
+        if (lane <= NX) {
+#pragma unroll
+          for (int k = 0; k < NU; ++k)
+            G2[k * PG + col] = x[k];
+        }
+      } else {
+        // Bunch-Kaufman would interchange (or met a zero column): do exactly what the
+        // reference does, with the generic device BK run by this wave alone
+        for (int e = lane; e < NU * PG; e += 64)
+          G2[e] = G[e];
+        double *sub = sm + C::oBk;
+        int *piv = (int *)(sub + 16);
+        wave_sync();
+        failed |= wg_bk_factor(w1, NU, Mm, NU, sub, piv, piv + 16);
+        wg_bk_solve(w1, NU, Mm, NU, sub, piv, G2, PG, 1, NX + 1);
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+          x[k] = G2[k * PG + col];
+      }
+      GAR_MARK(6)
+      __syncthreads(); // B: workers pick K up from G2
+      GAR_MARK(7)
       GAR_PF_STORE(1)
       GAR_PF_LOAD(2)
-      const int ic = lane < NX ? lane : NX - 1;
-      double yf = fv[ic], vxv = qhat;
+      // K -> fb rows 0..NU-1 (row-major NU x NX): lane = column, coalesced rows
+      if (lane >= 1 && lane <= NX) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        yf += Ft[(NX + u) * PK + ic] * x[u];
-        vxv -= G[u * PG + 1 + ic] * x[u];
+        for (int k = 0; k < NU; ++k)
+          out[C::fFB + k * NX + (lane - 1)] = x[k];
       }
-      double ku = 0.0;
+      // kff = G2(:, 0); yff = f + B kff (:266), vx = qhat + Shat kff (:275-276)
+      {
+        const int ic = lane < NX ? lane : NX - 1;
+        double yf = fv[ic], vxv = qhat;
 #pragma unroll
-      for (int u = 0; u < NU; ++u)
-        ku = (lane == u) ? x[u] : ku;
-      if (lane < NU)
-        out[C::fFF + lane] = ku;
-      if (lane < NX) {
-        out[C::fFF + NU + lane] = yf;
-        out[C::fvx + lane] = vxv;
-        vn[lane] = vxv;
+        for (int u = 0; u < NU; ++u) {
+          const double ku = G2[u * PG];
+          yf += Ft[(NX + u) * PK + ic] * ku;
+          vxv -= G[u * PG + 1 + ic] * ku;
+        }
+        if (lane < NU)
+          out[C::fFF + lane] = G2[lane * PG];
+        if (lane < NX) {
+          out[C::fFF + NU + lane] = yf;
+          out[C::fvx + lane] = vxv;
+          vn[lane] = vxv;
+        }
       }
       GAR_PF_STORE(2)
-      if (t > 0) { // prefetched f, q, r of knot t-1 -> LDS
+      if (t > 0) { // f, q, r of knot t-1 -> LDS
         if (lane < NX)
           sm[C::oFv + (cur ^ 1) * NX + lane] = pf_f;
         if (lane < NW)
           sm[C::oQr + (cur ^ 1) * NW + lane] = pf_qr;
       }
-    }
-    __syncthreads(); // #2: V, vn, Ft[next] complete
-    for (int e = w.tid; e < NX * NX; e += 256) { // Vxx -> HBM (column-major, symmetric)
-      const int j = e / NX, i = e - j * NX;
-      out[C::fVxx + e] = V[i * PK + j];
-    }
+      GAR_MARK(8)
+      __syncthreads(); // C
+      GAR_MARK(9)
 #undef GAR_PF_LOAD
 #undef GAR_PF_STORE
+    }
+    if (failed && lane == 0)
+      atomicOr(&P.status[b], failed);
   }
-  if (failed && w.tid == 0)
-    atomicOr(&P.status[b], failed);
+#undef GAR_MARK
 }
 
 } // namespace gar

@@ -174,6 +174,10 @@ int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff,
 /* all factor records of problem b in one copy (gar_hip_factors_doubles()) */
 int gar_hip_get_factors(gar_hip_solver *s, int b, double *out);
 int gar_hip_collapse_feedback(gar_hip_solver *s);
+/* Debug aid (no reference counterpart): with enable != 0 the specialised backward
+ * kernel stamps s_memtime at its phase boundaries for one stage of problem 0,
+ * 16 marks per wave; `out` (may be NULL) receives the last 4 x 16 stamps. */
+int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
 /* MPC cycling: drop knot 0, shift left, last-but-one knot gets dims5_new */
 int gar_hip_cycle_append(gar_hip_solver *s, const int32_t dims5_new[5]);
 
