@@ -62,7 +62,6 @@ SIGNATURES = {
     "gar_hip_get_gains": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _PD, _PD, _PD]),
     "gar_hip_get_value": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _PD, _PD, _PD, _PD, _PD]),
     "gar_hip_get_initial": (C.c_int, [C.c_void_p, C.c_int, _PD, _PD, _PD, _PD]),
-    "gar_hip_get_factors": (C.c_int, [C.c_void_p, C.c_int, _PD]),
     "gar_hip_collapse_feedback": (C.c_int, [C.c_void_p]),
     "gar_hip_debug_trace": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),
     "gar_hip_cycle_append": (C.c_int, [C.c_void_p, _PI32]),

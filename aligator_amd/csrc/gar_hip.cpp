@@ -69,6 +69,7 @@ struct gar_hip_solver {
   int last_failed = 0;
   // specialised backward kernel (gar_mfma.hpp), null = generic
   void (*mfma_kernel)(gar::MfmaParams) = nullptr;
+  void (*mfma_fwd_kernel)(gar::MfmaFwdParams) = nullptr;
   int mfma_lds_doubles = 0;
   long long *d_trace = nullptr; // 64 cycle stamps (debug)
 };
@@ -228,12 +229,14 @@ int plan_lds(gar_hip_solver *s) {
 // ---- specialised kernel dispatch ---------------------------------------------
 template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   s->mfma_kernel = gar::gar_backward_mfma<NX, NU>;
+  s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU>;
   s->mfma_lds_doubles = gar::MfmaCfg<NX, NU>::total;
   s->kernel_name = "mfma<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
 }
 
 void select_kernel(gar_hip_solver *s) {
   s->mfma_kernel = nullptr;
+  s->mfma_fwd_kernel = nullptr;
   s->kernel_name = "generic";
   const char *force = std::getenv("GAR_HIP_FORCE_GENERIC");
   if (force && force[0] == '1')
@@ -356,6 +359,25 @@ int launch_backward(gar_hip_solver *s, double mueq) {
 }
 
 int launch_forward(gar_hip_solver *s, const double *theta_dev) {
+  if (s->mfma_fwd_kernel) {
+    gar::MfmaFwdParams F{};
+    const int N = s->horizon;
+    F.fac = s->d_fac;
+    F.init = s->d_init;
+    F.sol = s->d_sol;
+    F.fac_stride = s->fac_doubles;
+    F.init_stride = s->init_doubles;
+    F.sol_stride = s->sol_doubles;
+    F.fac_rec = N > 1 ? s->meta[1].fac_off - s->meta[0].fac_off : s->meta[N].fac_off;
+    F.fac_offN = s->meta[N].fac_off;
+    F.horizon = N;
+    F.nc0 = s->nc0;
+    F.sol_u = (int)s->sol_u;
+    F.sol_l = (int)s->sol_l;
+    hipLaunchKernelGGL(s->mfma_fwd_kernel, dim3((unsigned)s->batch), dim3(64), 0, s->stream, F);
+    HIP_TRY(hipGetLastError());
+    return GAR_HIP_OK;
+  }
   gar::GenericParams P = make_params(s, 0.0);
   P.theta = theta_dev;
   const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
@@ -842,11 +864,24 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
   const double *rec = s->d_fac + (int64_t)b * s->fac_doubles + m.fac_off;
   const int64_t nr = (int64_t)m.nu + m.nc + m.nx2;
   int rc = d2h(s, ff, rec + o.ff, nr);
-  rc |= d2h(s, fb, rec + o.fb, nr * m.nx);
+  std::vector<double> tmp;
+  const bool fbt2 = s->mfma_kernel && t < s->horizon && fb; // device keeps fb in fbT2 layout
+  if (fbt2) {
+    tmp.resize((size_t)(nr * m.nx));
+    rc |= d2h(s, tmp.data(), rec + o.fb, nr * m.nx);
+  } else {
+    rc |= d2h(s, fb, rec + o.fb, nr * m.nx);
+  }
   rc |= d2h(s, fth, rec + o.fth, nr * m.nth);
   if (rc)
     return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (fbt2) { // back to StageFactor's row-major [K; Z; Aff] (riccati-kernel.hpp:96-97)
+    const int NW = (int)nr, NX = m.nx;
+    for (int r = 0; r < NW; ++r)
+      for (int j = 0; j < NX; ++j)
+        fb[(size_t)r * NX + j] = tmp[(size_t)(j >> 1) * (2 * NW) + 2 * r + (j & 1)];
+  }
   return GAR_HIP_OK;
 }
 
@@ -879,15 +914,6 @@ int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff, double *kkt0_
   rc |= d2h(s, thGrad, io + n0 + n0 * nth, nth);
   rc |= d2h(s, thHess, io + n0 + n0 * nth + nth, nth * nth);
   if (rc)
-    return rc;
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  return GAR_HIP_OK;
-}
-
-int gar_hip_get_factors(gar_hip_solver *s, int b, double *out) {
-  if (int rc = check_bt(s, b, 0))
-    return rc;
-  if (int rc = d2h(s, out, s->d_fac + (int64_t)b * s->fac_doubles, s->fac_doubles))
     return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   return GAR_HIP_OK;

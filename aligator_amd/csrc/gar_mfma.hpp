@@ -74,6 +74,13 @@ template <int NX, int NU> struct MfmaCfg {
                        kA = kr + NU, kB = kA + NX * NX, kf = kB + NX * NU;
   static constexpr int tQ = 0, tq = NX * NX; // terminal: Q, q, A, f (nu = 0)
   static constexpr int fFF = 0, fFB = NW, fVxx = fFB + NW * NX, fvx = fVxx + NX * NX;
+  // Device layout of fb = [K; Aff] in this kernel family ("fbT2"): element (r, j),
+  // r in [0, NW), j in [0, NX), lives at (j/2)*(2 NW) + 2 r + (j & 1): the forward
+  // sweep reads 16 B per lane with lane = row r, consecutive lanes consecutive
+  // addresses.  gar_hip_get_gains converts back to StageFactor's row-major fb.
+  __host__ __device__ static constexpr int fbT2(int r, int j) {
+    return (j >> 1) * (2 * NW) + 2 * r + (j & 1);
+  }
   static constexpr int tVxx = NX + NX * NX, tvx = tVxx + NX * NX; // terminal factor record
 };
 
@@ -166,6 +173,75 @@ __device__ __forceinline__ int wave_ldl_bk_rule(const double *M, int lane, doubl
   return verdict;
 }
 
+// 1/a to <= 1 ulp: v_rcp_f64 + two Newton steps (the IEEE division sequence is
+// ~4x longer and sits on the pivot-to-pivot critical path of the factorisation)
+__device__ __forceinline__ double fast_rcp(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+  double e = __builtin_fma(-a, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-a, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
+// Lean variant of wave_ldl_bk_rule: same elimination, but only the first test of
+// the Bunch-Kaufman rule (|a_kk| >= alpha * colmax, bunchkaufman.hpp:61) is
+// evaluated.  Returns 0 when that test held at every column (so BK takes kp = k
+// everywhere and the factorisation below IS Bunch-Kaufman's); otherwise the
+// caller re-runs the full rule.  No lane predication: entries above the diagonal
+// hold garbage and are never read.
+template <int NU>
+__device__ __forceinline__ int wave_ldl_lean(const double *M, int lane, double (&a)[NU],
+                                             double (&dinv)[NU]) {
+  const double alpha = (1.0 + 4.123105625617661) / 8.0;
+  const int row = lane < NU ? lane : NU - 1;
+#pragma unroll
+  for (int j = 0; j < NU; ++j)
+    a[j] = M[j * NU + (j <= row ? row : j)]; // lower triangle (clamped address above it)
+  int verdict = 0;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const double akk = lane_bcast(a[k], k);
+    double xs[NU];
+    double colmax = 0.0;
+#pragma unroll
+    for (int j = k + 1; j < NU; ++j) {
+      xs[j] = lane_bcast(a[k], j);
+      colmax = fmax(colmax, fabs(xs[j]));
+    }
+    verdict |= !(fabs(akk) >= colmax * alpha) || (akk == 0.0);
+    const double d = fast_rcp(akk);
+#pragma unroll
+    for (int j = k + 1; j < NU; ++j)
+      a[j] = __builtin_fma(-(xs[j] * d), a[k], a[j]);
+    a[k] *= d;
+    dinv[k] = d;
+  }
+  return verdict;
+}
+
+// x <- (L D L^T)^{-1} x, lane = right-hand-side column, L(i, j) broadcast from lane
+// i's register j (no LDS, no waits)
+template <int NU>
+__device__ __forceinline__ void ldl_solve_bcast(const double (&a)[NU], const double (&dinv)[NU],
+                                                double (&x)[NU]) {
+#pragma unroll
+  for (int i = 1; i < NU; ++i) {
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+      x[i] = __builtin_fma(-lane_bcast(a[j], i), x[j], x[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NU; ++i)
+    x[i] *= dinv[i];
+#pragma unroll
+  for (int j = NU - 2; j >= 0; --j) {
+#pragma unroll
+    for (int i = j + 1; i < NU; ++i)
+      x[j] = __builtin_fma(-lane_bcast(a[j], i), x[i], x[j]);
+  }
+}
+
 // x <- (L D L^T)^{-1} x with L packed strictly-lower row-wise in LDS (pl[i*(i-1)/2 + j])
 template <int NU>
 __device__ __forceinline__ void ldl_solve_regs(const double *pl, const double (&dinv)[NU],
@@ -204,7 +280,7 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
   double *fac = P.fac + (long long)b * P.fac_stride;
   const int N = P.horizon;
   double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM, *G2 = sm + C::oG2;
-  double *vn = sm + C::oVn, *vp = sm + C::oVp, *Lp = sm + C::oL;
+  double *vn = sm + C::oVn, *vp = sm + C::oVp;
   const bool tracing = P.trace != nullptr && b == 0 && lane == 0;
 #define GAR_MARK(id)                                                           \
   if (tracing && t == (N >> 1))                                                \
@@ -315,25 +391,27 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
 #pragma unroll
         for (int s = 0; s < C::KU; ++s)
           Kb[s] = G2[(4 * s + lk) * PG + 1 + cc];
-        // Aff(ti, tj) = A + B K (:267) -> fb rows NU.. (row-major)
+        // Aff^T(tj, ti) = A^T + K^T B^T (:267), i.e. Aff with the column index j on the
+        // tile rows, so that every lane group stores 16 consecutive i (fbT2 layout)
 #pragma unroll
         for (int ti = 0; ti < C::TX; ++ti) {
           double4_t acc;
+          const int i = 16 * ti + li, icl = i < NX ? i : NX - 1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int i = 16 * ti + lk + 4 * r;
-            acc[r] = Ft[cc * PK + (i < NX ? i : NX - 1)]; // A(i, j) = F^T(j, i)
+            const int j = 16 * tj + lk + 4 * r;
+            acc[r] = Ft[(j < NX ? j : NX - 1) * PK + icl]; // A(i, j) = F^T(j, i)
           }
 #pragma unroll
           for (int s = 0; s < C::KU; ++s) {
-            const double aq = Ft[(NX + 4 * s + lk) * PK + 16 * ti + li]; // B(i, u)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[s], acc, 0, 0, 0);
+            const double bq = Ft[(NX + 4 * s + lk) * PK + icl]; // B^T(u, i)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Kb[s], bq, acc, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int i = 16 * ti + lk + 4 * r;
-            if (i < NX && c < NX)
-              out[C::fFB + (NU + i) * NX + c] = acc[r];
+            const int j = 16 * tj + lk + 4 * r;
+            if (i < NX && j < NX)
+              out[C::fFB + C::fbT2(NU + i, j)] = acc[r];
           }
         }
         GAR_MARK(6)
@@ -439,21 +517,16 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       GAR_MARK(4)
       // ---- factor Rhat in registers (lane = row) under the Bunch-Kaufman rule ----
       double a_row[NU], dinv[NU], x[NU];
-      const int verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
+      int verdict = wave_ldl_lean<NU>(Mm, lane, a_row, dinv);
+      if (verdict != 0) // rare: evaluate the complete Bunch-Kaufman rule
+        verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
       GAR_MARK(5)
       const int col = lane <= NX ? lane : NX; // G column: 0 = kff, 1 + j = K(:, j)
       if (verdict == 0) {
-        if (lane < NU) {
-#pragma unroll
-          for (int j = 0; j < NU - 1; ++j)
-            if (j < lane)
-              Lp[lane * (lane - 1) / 2 + j] = a_row[j];
-        }
-        wave_sync();
 #pragma unroll
         for (int k = 0; k < NU; ++k)
           x[k] = G[k * PG + col];
-        ldl_solve_regs<NU>(Lp, dinv, x);
+        ldl_solve_bcast<NU>(a_row, dinv, x);
         if (lane <= NX) {
 #pragma unroll
           for (int k = 0; k < NU; ++k)
@@ -478,11 +551,11 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       GAR_MARK(7)
       GAR_PF_STORE(1)
       GAR_PF_LOAD(2)
-      // K -> fb rows 0..NU-1 (row-major NU x NX): lane = column, coalesced rows
+      // K -> fb rows 0..NU-1 (fbT2 layout), lane = column
       if (lane >= 1 && lane <= NX) {
 #pragma unroll
         for (int k = 0; k < NU; ++k)
-          out[C::fFB + k * NX + (lane - 1)] = x[k];
+          out[C::fFB + C::fbT2(k, lane - 1)] = x[k];
       }
       // kff = G2(:, 0); yff = f + B kff (:266), vx = qhat + Shat kff (:275-276)
       {
@@ -519,6 +592,80 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       atomicOr(&P.status[b], failed);
   }
 #undef GAR_MARK
+}
+
+// ---------------------------------------------------------------------------
+// Forward sweep for the same problem family (computeInitial + forwardImpl,
+// riccati-kernel.hxx:195-207, 314-377, nc = nth = 0).  One wave per problem, no
+// LDS: lane r < NW owns row r of [K; Aff], lane i < NX row i of Vxx'; the state
+// is broadcast lane -> wave with v_readlane; every knot's gains are streamed
+// once, 16 B per lane, straight into registers.  Latency is hidden by
+// occupancy (many independent waves per CU), not by software pipelining.
+// ---------------------------------------------------------------------------
+struct MfmaFwdParams {
+  const double *fac;  // factor records (fbT2 layout)
+  const double *init; // kkt0.ff per problem: [x0; lbd0]
+  double *sol;        // xs | us | vs | lbdas
+  long long fac_stride, init_stride, sol_stride;
+  long long fac_rec, fac_offN;
+  int horizon, nc0;
+  int sol_u, sol_l; // base offsets of us / lbdas inside a solution record
+};
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(64) gar_forward_mfma(MfmaFwdParams P) {
+  using C = MfmaCfg<NX, NU>;
+  constexpr int NW = C::NW;
+  const int lane = (int)threadIdx.x;
+  const int b = (int)blockIdx.x;
+  const double *fac = P.fac + (long long)b * P.fac_stride;
+  double *sol = P.sol + (long long)b * P.sol_stride;
+  const double *io = P.init + (long long)b * P.init_stride;
+  const int N = P.horizon;
+  const int r = lane < NW ? lane : NW - 1;  // row of [K; Aff]
+  const int iv = lane < NX ? lane : NX - 1; // row of Vxx'
+  // the state lives in lanes NU .. NW-1 (where x' = yff + Aff x is produced)
+  const int ix = (lane >= NU && lane < NW) ? lane - NU : 0;
+  double xs = io[ix]; // x0 from the initial-stage solve (kkt0.ff)
+  if (lane >= NU && lane < NW)
+    sol[ix] = xs;
+  for (int e = lane; e < P.nc0; e += 64)
+    sol[P.sol_l + e] = io[NX + e]; // lbd0
+  for (int t = 0; t < N; ++t) {
+    const double *rec = fac + (long long)t * P.fac_rec;
+    const double *recn = (t + 1 < N) ? rec + P.fac_rec : fac + P.fac_offN;
+    const int oVn = (t + 1 < N) ? C::fVxx : C::tVxx, ovn = (t + 1 < N) ? C::fvx : C::tvx;
+    // all loads of the stage first: [K; Aff] rows (16 B per lane), Vxx' rows, ff, vx'
+    double2_t g[NX / 2];
+#pragma unroll
+    for (int m = 0; m < NX / 2; ++m)
+      g[m] = *reinterpret_cast<const double2_t *>(rec + C::fFB + m * 2 * NW + 2 * r);
+    double vrow[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      vrow[j] = recn[oVn + j * NX + iv]; // Vxx' symmetric: column j, row iv
+    double acc = rec[C::fFF + r];
+    double lam = recn[ovn + iv];
+    // u = kff + K x ; x' = yff + Aff x   (:334-336, :360-361)
+#pragma unroll
+    for (int m = 0; m < NX / 2; ++m) {
+      acc = __builtin_fma(g[m].x, lane_bcast(xs, NU + 2 * m), acc);
+      acc = __builtin_fma(g[m].y, lane_bcast(xs, NU + 2 * m + 1), acc);
+    }
+    if (lane < NU)
+      sol[P.sol_u + t * NU + lane] = acc;
+    else if (lane < NW)
+      sol[(t + 1) * NX + (lane - NU)] = acc;
+    xs = acc;
+    // lbd' = vx' + Vxx' x'  (:369-371); x'_j sits in lane NU + j
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      lam = __builtin_fma(vrow[j], lane_bcast(xs, NU + j), lam);
+    if (lane < NX)
+      sol[P.sol_l + P.nc0 + t * NX + lane] = lam;
+  }
 }
 
 } // namespace gar

@@ -171,8 +171,6 @@ int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx,
 /* kkt0.ff (nx0+nc0), kkt0.fth ((nx0+nc0) x nth ROW-major), thGrad, thHess */
 int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff,
                         double *kkt0_fth, double *thGrad, double *thHess);
-/* all factor records of problem b in one copy (gar_hip_factors_doubles()) */
-int gar_hip_get_factors(gar_hip_solver *s, int b, double *out);
 int gar_hip_collapse_feedback(gar_hip_solver *s);
 /* Debug aid (no reference counterpart): with enable != 0 the specialised backward
  * kernel stamps s_memtime at its phase boundaries for one stage of problem 0,

@@ -128,6 +128,7 @@ inline void __builtin_amdgcn_wave_barrier() {
 #define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
 
 inline long long clock64() { return 0; }
+inline double __builtin_amdgcn_rcp(double a) { return 1.0 / a; }
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 
