@@ -179,12 +179,53 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
   int info = 0;
   while (k < n) {
     wg_bar(w);
-    if (w.tid == 0) { // pivot search, :46-83
+    // pivot search, :46-83.  The column maximum (first row attaining it, as the reference's
+    // strict ">" scan) is found by the whole group when the column is long: every thread scans
+    // its rows, waves reduce with xor-shuffles, thread 0 combines the per-wave results that
+    // were parked in `subdiag` (free until the end of the factorisation).
+    const bool par_search = (n - k - 1) >= 16 && n >= 2 * w.nwaves;
+    if (par_search) {
+      double bv = -1.0;
+      int bi = 0x7fffffff;
+      for (int i = k + 1 + w.tid; i < n; i += w.nthr) {
+        const double v = fabs(GA(i, k));
+        if (v > bv) {
+          bv = v;
+          bi = i;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) {
+          bv = ov;
+          bi = oi;
+        }
+      }
+      if (w.lane == 0) {
+        subdiag[2 * w.wave] = bv;
+        subdiag[2 * w.wave + 1] = (double)bi;
+      }
+      wg_bar(w);
+    }
+    if (w.tid == 0) {
       int k_step = 1, kp, fail = 0;
       const double abs_akk = fabs(GA(k, k));
       int imax = k + 1;
       double colmax = 0.0;
-      if (k + 1 < n) {
+      if (par_search) {
+        colmax = subdiag[0];
+        imax = (int)subdiag[1];
+        for (int q = 1; q < w.nwaves; ++q) {
+          const double v = subdiag[2 * q];
+          const int iq = (int)subdiag[2 * q + 1];
+          if (v > colmax || (v == colmax && iq < imax)) {
+            colmax = v;
+            imax = iq;
+          }
+        }
+      } else if (k + 1 < n) {
         colmax = fabs(GA(k + 1, k));
         for (int i = k + 2; i < n; ++i) {
           const double v = fabs(GA(i, k));
@@ -254,13 +295,18 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
     if (k_step == 1) { // :104-121
       const int m = n - k - 1;
       const double d11 = 1.0 / GA(k, k);
-      for (int e = w.tid; e < m * m; e += w.nthr) {
-        const int j = e / m, i = e - j * m;
-        if (i >= j) {
-          const double d11xj = GA(k + 1 + j, k) * d11;
-          GA(k + 1 + i, k + 1 + j) -= d11xj * GA(k + 1 + i, k);
+      // one thread per trailing row i: a(i,j) -= (a(j,k) d11) a(i,k) for j <= i.  For a fixed j
+      // the threads touch consecutive i (conflict-free), a(j,k) is a broadcast read, and there
+      // is no integer division in the loop
+      for (int i = k + 1 + w.tid; i < n; i += w.nthr) {
+        const double aik = GA(i, k);
+#pragma unroll 4
+        for (int j = k + 1; j <= i; ++j) {
+          const double d11xj = GA(j, k) * d11;
+          GA(i, j) -= d11xj * aik;
         }
       }
+      (void)m;
       wg_bar(w);
       for (int i = w.tid; i < m; i += w.nthr)
         GA(k + 1 + i, k) *= d11;
@@ -276,14 +322,12 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       const double t = 1.0 / ((d11 * d22) - 1.0);
       const double d = t * d21_inv;
       const double d21 = GA(k + 1, k) * d21_inv;
-      const int m = n - k - 2;
-      for (int e = w.tid; e < m * m; e += w.nthr) {
-        const int jj = e / m, ii = e - jj * m;
-        if (ii >= jj) {
-          const int j = k + 2 + jj, i = k + 2 + ii;
+      for (int i = k + 2 + w.tid; i < n; i += w.nthr) {
+        const double aik = GA(i, k), aik1 = GA(i, k + 1);
+        for (int j = k + 2; j <= i; ++j) {
           const double wk = ((GA(j, k) * d11) - (GA(j, k + 1) * d21)) * d;
           const double wkp1 = ((GA(j, k + 1) * d22) - (GA(j, k) * d21)) * d;
-          GA(i, j) -= GA(i, k) * wk + GA(i, k + 1) * wkp1;
+          GA(i, j) -= aik * wk + aik1 * wkp1;
         }
       }
       double wk_r[2] = {0.0, 0.0}, wkp1_r[2] = {0.0, 0.0};
@@ -362,9 +406,100 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
 // In-place solve of (L D L^T with interchanges) X = X for an n x ncols block X
 // with strides (xrs, xcs); bunchkaufman.hpp:451-518.  One thread per column of
 // X (columns are independent); ends with a barrier.
+// Few right-hand sides (ncols < 16, e.g. the single column of the initial-stage KKT): one
+// thread per column would leave the whole group idle behind a serial n^2 substitution, so the
+// group works on ONE column at a time, column-oriented: x_j is final, every thread updates
+// its rows i > j (i < j for the transposed solve).  Same operations as the per-column path,
+// summed in the same order per row.
+__device__ inline void wg_bk_solve_few(const WG &w, int n, const double *a, int lda,
+                                       const double *subdiag, const int *piv, double *x, int xrs,
+                                       int xcs, int ncols) {
+#define GA(i, j) a[(j) * lda + (i)]
+#define GX(i) xc[(i) * xrs]
+  for (int c = 0; c < ncols; ++c) {
+    double *xc = x + c * xcs;
+    wg_bar(w);
+    if (w.tid == 0) { // forward interchanges (:458-468)
+      int k = 0;
+      while (k < n) {
+        int p = piv[k];
+        int row = k;
+        if (p < 0) {
+          p = -1 - p;
+          row = k + 1;
+          k += 2;
+        } else {
+          k += 1;
+        }
+        if (row != p) {
+          const double t = GX(row);
+          GX(row) = GX(p);
+          GX(p) = t;
+        }
+      }
+    }
+    for (int j = 0; j + 1 < n; ++j) { // unit-lower solve (:472), axpy form
+      wg_bar(w);
+      const double xj = GX(j);
+      for (int i = j + 1 + w.tid; i < n; i += w.nthr)
+        GX(i) -= GA(i, j) * xj;
+    }
+    wg_bar(w);
+    if (w.tid == 0) { // inverse-D multiply (:474-502)
+      int k = 0;
+      while (k < n) {
+        if (piv[k] < 0) {
+          const double akp1k = subdiag[k], ak = GA(k, k), akp1 = GA(k + 1, k + 1);
+          const double xk = GX(k), xkp1 = GX(k + 1);
+          GX(k) = xk * ak + xkp1 * akp1k;
+          GX(k + 1) = xkp1 * akp1 + xk * akp1k;
+          k += 2;
+        } else {
+          GX(k) *= GA(k, k);
+          k += 1;
+        }
+      }
+    }
+    for (int i = n - 1; i >= 1; --i) { // unit-upper (L^T) solve (:504), axpy form
+      wg_bar(w);
+      const double xi = GX(i);
+      for (int j = w.tid; j < i; j += w.nthr)
+        GX(j) -= GA(i, j) * xi;
+    }
+    wg_bar(w);
+    if (w.tid == 0) { // reverse interchanges (:506-517)
+      int k = n;
+      while (k > 0) {
+        k -= 1;
+        int p = piv[k];
+        if (p < 0) {
+          p = -1 - p;
+          if (k != p) {
+            const double t = GX(k);
+            GX(k) = GX(p);
+            GX(p) = t;
+          }
+          k -= 1;
+        } else if (k != p) {
+          const double t = GX(k);
+          GX(k) = GX(p);
+          GX(p) = t;
+        }
+      }
+    }
+  }
+  wg_bar(w);
+#undef GA
+#undef GX
+}
+
 __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
                                    const double *subdiag, const int *piv, double *x, int xrs,
                                    int xcs, int ncols) {
+  if (ncols < 16 && n >= 16) {
+    wg_bk_solve_few(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
+    return;
+  }
 #define GA(i, j) a[(j) * lda + (i)]
 #define GX(i) xc[(i) * xrs]
   for (int c = w.tid; c < ncols; c += w.nthr) {

@@ -60,65 +60,70 @@ extern __shared__ double gar_smem[];
 // Vxx0 is not symmetrised first), kkt0.ff = -[vx0; g0], kkt0.fth = -[Vxt0; 0],
 // thGrad, thHess.  The value function of stage 0 sits in LDS buffer `fin`.
 // ---------------------------------------------------------------------------
+__device__ inline int initial_stage_ptr(const WG &w, const GenericParams &P, int b, int nx, int nth,
+                                        const double *V0p, const double *v0, const double *Vxt0p,
+                                        const double *Vtt0, const double *vt0, double *k0mat,
+                                        double *k0rhs, double *k0sub, int *piv0, int *ctrl0) {
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  int failed = 0;
+  const int nc0 = P.nc0, n0 = nx + nc0;
+  const double *G0 = prob + P.G0_off, *g0 = prob + P.g0_off;
+  MatV K0 = colmajor(k0mat, n0);
+  const int rld = 1 + nth;
+  MatV R0 = rowmajor(k0rhs, rld); // [ff | fth]
+  for (int e = w.tid; e < n0 * n0; e += w.nthr) {
+    const int j = e / n0, i = e - j * n0;
+    double v = 0.0;
+    if (j < nx)
+      v = (i < nx) ? V0p[j * nx + i] : G0[j * nc0 + (i - nx)];
+    else if (i < nx)
+      v = G0[i * nc0 + (j - nx)];
+    K0(i, j) = v;
+  }
+  for (int e = w.tid; e < n0 * rld; e += w.nthr) {
+    const int i = e / rld, j = e - i * rld;
+    double v;
+    if (j == 0)
+      v = (i < nx) ? -v0[i] : -g0[i - nx];
+    else
+      v = (i < nx) ? -Vxt0p[(j - 1) * nx + i] : 0.0;
+    R0(i, j) = v;
+  }
+  wg_bar(w);
+  failed |= 2 * wg_bk_factor(w, n0, K0.p, n0, k0sub, piv0, ctrl0);
+  wg_bk_solve(w, n0, K0.p, n0, k0sub, piv0, R0.p, rld, 1, rld);
+  double *io = P.init + (long long)b * P.init_stride;
+  for (int e = w.tid; e < n0; e += w.nthr)
+    io[e] = R0(e, 0);
+  for (int e = w.tid; e < n0 * nth; e += w.nthr) {
+    const int i = e / nth, j = e - i * nth;
+    io[n0 + e] = R0(i, 1 + j);
+  }
+  // thGrad = vt + Vxt^T x0 ; thHess = Vtt + Vxt^T fth_x   (:56-59)
+  for (int i = w.tid; i < nth; i += w.nthr) {
+    double s = 0.0;
+    for (int k = 0; k < nx; ++k)
+      s += Vxt0p[i * nx + k] * R0(k, 0);
+    io[n0 + n0 * nth + i] = vt0[i] + s;
+  }
+  for (int e = w.tid; e < nth * nth; e += w.nthr) {
+    const int j = e / nth, i = e - j * nth;
+    double s = 0.0;
+    for (int k = 0; k < nx; ++k)
+      s += Vxt0p[i * nx + k] * R0(k, 1 + j);
+    io[n0 + n0 * nth + nth + e] = Vtt0[e] + s;
+  }
+  return failed;
+}
+
 __device__ inline int initial_stage(const WG &w, const GenericParams &P, int b, double *sm,
                                     int fin, const gar_stage_meta &m0) {
   const LdsPlan &L = P.lds;
-  const double *prob = P.prob + (long long)b * P.prob_stride;
-  int failed = 0;
-  {
-    const int nx = m0.nx, nth = m0.nth, nc0 = P.nc0, n0 = nx + nc0;
-    const double *G0 = prob + P.G0_off, *g0 = prob + P.g0_off;
-    // move what we need out of the way of the kkt0 buffers (they alias H,F,P..)
-    // V[fin], v[fin], Vxt[fin], Vtt[fin], vt[fin] are outside the aliased range.
-    MatV K0 = colmajor(sm + L.k0mat, n0);
-    const int rld = 1 + nth;
-    MatV R0 = rowmajor(sm + L.k0rhs, rld); // [ff | fth]
-    MatV V0 = colmajor(sm + L.V[fin], nx), Vxt0 = colmajor(sm + L.Vxt[fin], nx);
-    for (int e = w.tid; e < n0 * n0; e += w.nthr) {
-      const int j = e / n0, i = e - j * n0;
-      double v = 0.0;
-      if (j < nx)
-        v = (i < nx) ? V0(i, j) : G0[j * nc0 + (i - nx)];
-      else if (i < nx)
-        v = G0[i * nc0 + (j - nx)];
-      K0(i, j) = v;
-    }
-    for (int e = w.tid; e < n0 * rld; e += w.nthr) {
-      const int i = e / rld, j = e - i * rld;
-      double v;
-      if (j == 0)
-        v = (i < nx) ? -sm[L.v[fin] + i] : -g0[i - nx];
-      else
-        v = (i < nx) ? -Vxt0(i, j - 1) : 0.0;
-      R0(i, j) = v;
-    }
-    __syncthreads();
-    int *piv0 = (int *)(sm + L.k0piv);
-    failed |= 2 * wg_bk_factor(w, n0, K0.p, n0, sm + L.k0sub, piv0, piv0 + 512);
-    wg_bk_solve(w, n0, K0.p, n0, sm + L.k0sub, piv0, R0.p, rld, 1, rld);
-    double *io = P.init + (long long)b * P.init_stride;
-    for (int e = w.tid; e < n0; e += w.nthr)
-      io[e] = R0(e, 0);
-    for (int e = w.tid; e < n0 * nth; e += w.nthr) {
-      const int i = e / nth, j = e - i * nth;
-      io[n0 + e] = R0(i, 1 + j);
-    }
-    // thGrad = vt + Vxt^T x0 ; thHess = Vtt + Vxt^T fth_x   (:56-59)
-    for (int i = w.tid; i < nth; i += w.nthr) {
-      double s = 0.0;
-      for (int k = 0; k < nx; ++k)
-        s += Vxt0(k, i) * R0(k, 0);
-      io[n0 + n0 * nth + i] = sm[L.vt[fin] + i] + s;
-    }
-    for (int e = w.tid; e < nth * nth; e += w.nthr) {
-      const int j = e / nth, i = e - j * nth;
-      double s = 0.0;
-      for (int k = 0; k < nx; ++k)
-        s += Vxt0(k, i) * R0(k, 1 + j);
-      io[n0 + n0 * nth + nth + e] = sm[L.Vtt[fin] + e] + s;
-    }
-  }
-  return failed;
+  // V[fin], v[fin], Vxt[fin], Vtt[fin], vt[fin] are outside the range the kkt0 buffers alias
+  int *piv0 = (int *)(sm + L.k0piv);
+  return initial_stage_ptr(w, P, b, m0.nx, m0.nth, sm + L.V[fin], sm + L.v[fin], sm + L.Vxt[fin],
+                           sm + L.Vtt[fin], sm + L.vt[fin], sm + L.k0mat, sm + L.k0rhs,
+                           sm + L.k0sub, piv0, piv0 + 512);
 }
 
 // ---------------------------------------------------------------------------
@@ -426,6 +431,30 @@ __global__ void __launch_bounds__(256) gar_initial_generic(GenericParams P) {
     sm[L.vt[0] + e] = rec[fo.vt + e];
   __syncthreads();
   const int failed = initial_stage(w, P, b, sm, 0, m0);
+  if (failed && w.tid == 0)
+    atomicOr(&P.status[b], failed);
+}
+
+// The same initial stage run by ONE wave per problem, reading the stage-0 value function
+// straight from the factor record: only the kkt0 buffers live in LDS ((nx+nc0)^2 + ...), so
+// several problems share a CU, and the Bunch-Kaufman steps synchronise with wave barriers
+// instead of workgroup barriers.  Dynamic LDS: gar_initial_wave_lds_doubles(n0, nth).
+__host__ __device__ inline int gar_initial_wave_lds_doubles(int n0, int nth) {
+  return n0 * n0 + n0 * (1 + nth) + n0 + (n0 & 1) + (n0 + 16 + 1) / 2 * 1 + 8;
+}
+__global__ void __launch_bounds__(64) gar_initial_wave(GenericParams P) {
+  const WG w = wave_self();
+  double *sm = gar_smem;
+  const int b = (int)blockIdx.x;
+  const gar_stage_meta m0 = P.meta[0];
+  const gar_factor_offsets fo = gar_factor_layout(m0.nx, m0.nu, m0.nc, m0.nx2, m0.nth);
+  const double *rec = P.fac + (long long)b * P.fac_stride + m0.fac_off;
+  const int n0 = m0.nx + P.nc0, nth = m0.nth;
+  double *k0mat = sm, *k0rhs = k0mat + n0 * n0, *k0sub = k0rhs + n0 * (1 + nth);
+  int *piv0 = (int *)(k0sub + n0 + (n0 & 1));
+  const int failed = initial_stage_ptr(w, P, b, m0.nx, nth, rec + fo.Vxx, rec + fo.vx, rec + fo.Vxt,
+                                       rec + fo.Vtt, rec + fo.vt, k0mat, k0rhs, k0sub, piv0,
+                                       piv0 + n0);
   if (failed && w.tid == 0)
     atomicOr(&P.status[b], failed);
 }

@@ -16,6 +16,7 @@
 #include "gar_generic.hpp"
 #include "gar_layout.h"
 #include "gar_mfma.hpp"
+#include "gar_wave.hpp"
 
 namespace {
 
@@ -71,6 +72,9 @@ struct gar_hip_solver {
   void (*mfma_kernel)(gar::MfmaParams) = nullptr;
   void (*mfma_fwd_kernel)(gar::MfmaFwdParams) = nullptr;
   int mfma_lds_doubles = 0;
+  // one-wave-per-problem backward kernel (gar_wave.hpp), preferred when bound
+  void (*wave_kernel)(gar::MfmaParams, int) = nullptr;
+  int wave_lds_doubles = 0, waves_per_block = 1;
   long long *d_trace = nullptr; // 64 cycle stamps (debug)
 };
 
@@ -232,11 +236,19 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU>;
   s->mfma_lds_doubles = gar::MfmaCfg<NX, NU>::total;
   s->kernel_name = "mfma<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+  const char *bw = std::getenv("GAR_HIP_BACKWARD"); // "wg4": the 4-wave workgroup kernel
+  if (!(bw && std::string(bw) == "wg4")) {
+    s->wave_kernel = gar::gar_backward_wave<NX, NU>;
+    s->wave_lds_doubles = gar::WaveCfg<NX, NU>::total;
+    s->waves_per_block = 1; // one 64-thread workgroup per problem (constant LDS base)
+    s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+  }
 }
 
 void select_kernel(gar_hip_solver *s) {
   s->mfma_kernel = nullptr;
   s->mfma_fwd_kernel = nullptr;
+  s->wave_kernel = nullptr;
   s->kernel_name = "generic";
   const char *force = std::getenv("GAR_HIP_FORCE_GENERIC");
   if (force && force[0] == '1')
@@ -343,11 +355,24 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.fac_offN = s->meta[N].fac_off;
     M.horizon = N;
     M.trace = s->d_trace;
-    hipLaunchKernelGGL(s->mfma_kernel, dim3((unsigned)s->batch), dim3(256),
-                       (size_t)s->mfma_lds_doubles * sizeof(double), s->stream, M);
+    if (s->wave_kernel) {
+      const int wpb = s->waves_per_block;
+      hipLaunchKernelGGL(s->wave_kernel, dim3((unsigned)((s->batch + wpb - 1) / wpb)),
+                         dim3(64 * wpb), (size_t)s->wave_lds_doubles * wpb * sizeof(double),
+                         s->stream, M, s->batch);
+    } else {
+      hipLaunchKernelGGL(s->mfma_kernel, dim3((unsigned)s->batch), dim3(256),
+                         (size_t)s->mfma_lds_doubles * sizeof(double), s->stream, M);
+    }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(gar::gar_initial_generic, dim3((unsigned)s->batch), dim3(256),
-                       (size_t)s->lds.total * sizeof(double), s->stream, P);
+    if (s->n0 <= 128) { // one wave per problem (wave-scope Bunch-Kaufman handles n <= 128)
+      hipLaunchKernelGGL(gar::gar_initial_wave, dim3((unsigned)s->batch), dim3(64),
+                         (size_t)gar::gar_initial_wave_lds_doubles(s->n0, s->nth0) * sizeof(double),
+                         s->stream, P);
+    } else {
+      hipLaunchKernelGGL(gar::gar_initial_generic, dim3((unsigned)s->batch), dim3(256),
+                         (size_t)s->lds.total * sizeof(double), s->stream, P);
+    }
     HIP_TRY(hipGetLastError());
     return GAR_HIP_OK;
   }
@@ -499,9 +524,17 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipFuncSetAttribute((const void *)s->mfma_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->mfma_lds_doubles * sizeof(double))));
+  if (s->wave_kernel)
+    HIP_TRY(hipFuncSetAttribute((const void *)s->wave_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->wave_lds_doubles * s->waves_per_block * sizeof(double))));
   HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_initial_generic,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(s->lds.total * sizeof(double))));
+  if (s->n0 <= 128)
+    HIP_TRY(hipFuncSetAttribute(
+        (const void *)gar::gar_initial_wave, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (int)(gar::gar_initial_wave_lds_doubles(s->n0, s->nth0) * sizeof(double))));
   // > 64 KiB of dynamic LDS needs the opt-in attribute
   HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_backward_generic,
                               hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1,0 +1,683 @@
+// gar_wave.hpp -- ONE WAVE PER PROBLEM backward sweep for uniform, unconstrained,
+// unparameterised problems (nc = nth = 0, every stage NX x NU, terminal knot
+// nu = 0): the BASELINE.json north-star path (N=256, nx=36, nu=12, fp64).
+//
+// Same arithmetic as ProximalRiccatiKernel::stageKernelSolve
+// (gar/riccati-kernel.hxx:209-277); what changes against gar_mfma.hpp is the
+// mapping onto the machine, driven by two measurements on MI355X
+// (scripts/ubench/ubench_f64.cpp, profiles/r01_ubench_f64.log):
+//   * v_mfma_f64_16x16x4_f64 issues once per 64 cycles per SIMD, and while a wave
+//     streams them NO other VALU instruction of ANY wave on that SIMD issues
+//     (fp64 MFMA runs on the vector ALU's DP lanes): a SIMD's time is the plain sum
+//     of its MFMA time (64 cyc each) and of every VALU instruction it executes;
+//   * so a workgroup whose waves wait on each other at barriers wastes exactly the
+//     SIMD time the HBM roofline needs (the 4-wave kernel of gar_mfma.hpp spends
+//     ~2/3 of each stage with 3 of its 4 waves parked).
+// Here a problem lives in ONE wave: no barriers, no inter-wave hand-offs, every
+// SIMD runs its own independent problem(s), and the non-MFMA work is kept off
+// the VALU wherever an LDS-port or memory-port instruction can do it:
+//   * F = [A B] goes HBM -> registers directly in MFMA operand layout (lane
+//     (li,lk) holds F[4s+lk][16t+li]); the same registers are the B operand of
+//     P = V'F, the A operand of H = W + F^T P and -- because the operand rows
+//     4s+lk ARE the C/D rows lk+4r of tile s>>2 -- the accumulator init of
+//     Aff = A + B K, which is computed in place on top of them;
+//   * P's D registers are the B operand of H (as in gar_mfma.hpp); the Shat^T rows
+//     of H's D registers are the A operand of Vxx = Qhat + Shat K;
+//   * V' lives in LDS (symmetric, k-fast) as the A operand of P = V'F;
+//   * the next knot is loaded into the SAME registers as soon as the current one has
+//     been consumed (F after Aff, the Hessian tiles after Vxx), so the working set
+//     stays below 256 registers and two waves fit a SIMD: the partner wave covers
+//     what is left of the HBM / LDS latencies.
+// Measured on the (32,12) shape, whose working set fits 256 registers: a second wave per SIMD
+// buys ~5 % (MFMA and VALU of the two waves exclude each other), so the kernel is built for
+// ONE wave per SIMD (all 512 registers), and hides its latencies with instruction-level
+// parallelism instead.  LDS: 19 KB per wave.
+#pragma once
+#include "gar_mfma.hpp"
+
+namespace gar {
+
+template <int NX, int NU> struct WaveCfg {
+  using M = MfmaCfg<NX, NU>;
+  static constexpr int NW = NX + NU, TX = M::TX, TW = M::TW, KS = M::KS, KU = M::KU;
+  static constexpr int KSF = KS / 4, KST = KS % 4; // full double4 groups of k-steps, tail steps
+  // V is kept unpadded (pitch NX): it then IS the column-major Vxx record, so the copy to HBM is
+  // linear; the 2-way bank conflicts this costs the operand reads are invisible beside 64-cycle MFMAs
+  static constexpr int PK = NX, PG = M::PG;
+  // tile row / register of H holding Shat^T row u = 4s' + lk (rows NX + u)
+  __host__ __device__ static constexpr int shTile(int s) { return (NX + 4 * s) >> 4; }
+  __host__ __device__ static constexpr int shReg(int s) { return ((NX + 4 * s) & 15) >> 2; }
+  // LDS carve (doubles), one slice per wave
+  static constexpr int oV = 0;
+  static constexpr int oG = oV + NX * PK + 16;    // [rhat | Shat^T], NU x PG
+  static constexpr int oG2 = oG;                  // [kff | K]: the solve runs in place
+  static constexpr int oM = oG + NU * PG + 16;    // Rhat, column-major lower
+  static constexpr int oVn = oM + NU * NU;        // vx' (NX)
+  static constexpr int oFv = oVn + NX;            // f (NX)
+  static constexpr int oVp = oFv + NX;            // vplus (NX)
+  static constexpr int oLr = (oVp + NX + 1) & ~1; // L of Rhat = L D L^T, row-major (forward solve)
+  static constexpr int oLc = oLr;                 // (the transposed solve reads L strided)
+  static constexpr int oDi = oLr + NU * NU;       // -1/d_k
+  static constexpr int oBk = (oDi + NU + 1) & ~1; // Bunch-Kaufman fallback: sub(16) | piv, ctrl
+  static constexpr int total = (oBk + 32 + 1) & ~1;
+};
+
+// base + cst (doubles, compile-time: goes to the scalar base / the instruction's immediate) +
+// a loop-invariant per-lane byte offset: one VGPR per access PATTERN, not per access
+__device__ __forceinline__ double ldg_b(const double *base, int cst, unsigned lane_bytes) {
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base + cst) + lane_bytes);
+}
+__device__ __forceinline__ void stg_b(double *base, int cst, unsigned lane_bytes, double v) {
+  *reinterpret_cast<double *>(reinterpret_cast<char *>(base + cst) + lane_bytes) = v;
+}
+
+// one knot's data in registers, in the layouts the stage body consumes
+template <int NX, int NU> struct WaveStage {
+  using C = WaveCfg<NX, NU>;
+  // F[4s+lk][16t+li]: k-steps s = 4g+e < 4*KSF in Fo[t][g][e], the tail steps in FoT[t][s-4*KSF]
+  double4_t Fo[C::TW][C::KSF > 0 ? C::KSF : 1];
+  double FoT[C::TW][C::KST > 0 ? C::KST : 1];
+  double4_t Hc[C::TW][C::TW];    // lower tiles of [Q S;S^T R], D layout (init of H)
+  double fi, qri;                // f[lane], [q;r][lane]
+  __device__ __forceinline__ double fo(int t, int s) const {
+    return s < 4 * C::KSF ? Fo[t][s >> 2][s & 3] : FoT[t][s - 4 * C::KSF];
+  }
+};
+
+// loop-invariant per-lane byte offsets into a knot record.  A column/row tile that lies
+// entirely inside its block shares ONE lane offset with the other interior tiles (the tile
+// origin is a compile-time constant that goes to the scalar base / the immediate); only a tile
+// that straddles a block boundary or overhangs the matrix needs its own (clamped) offsets.
+template <int NX, int NU> struct WaveLane {
+  using C = WaveCfg<NX, NU>;
+  unsigned fo0, foX;             // F operand F[lk][li] ; overhanging last column tile
+  // element (16ti+lk+4r, 16tj+li) of [Q S;S^T R] at its NATURAL position (no mirroring:
+  // the strictly-upper part of a diagonal tile only feeds results that are never used)
+  unsigned hcx0, hcxX[C::TW];    // rows < NX: Q[lk][li] ; column tiles reaching past NX
+  unsigned hcu0, hcuX[C::TW][C::KU]; // rows NX+4s'+lk: S^T[lk][li] ; tiles reaching past NX
+  unsigned bop0, bopX;           // B[li][lk] ; overhanging last row tile
+  unsigned fi, qri;
+  unsigned fbl;                  // fbT2 lane part: (li>>1)*2NW + 2lk + (li&1)
+  __host__ __device__ static constexpr bool fo_in(int t) { return 16 * t + 15 < C::NW; }
+  __host__ __device__ static constexpr bool x_in(int t) { return 16 * t + 15 < NX; }
+};
+
+template <int NX, int NU>
+__device__ __forceinline__ void wave_lane_init(WaveLane<NX, NU> &L, int lane) {
+  using C = WaveCfg<NX, NU>;
+  using M = MfmaCfg<NX, NU>;
+  const int li = lane & 15, lk = lane >> 4;
+  L.fo0 = 8u * (unsigned)(M::kA + li * NX + lk);
+  {
+    const int t = C::TW - 1, col = (16 * t + li) < C::NW ? (16 * t + li) : C::NW - 1;
+    L.foX = 8u * (unsigned)(M::kA + col * NX + lk);
+  }
+  L.hcx0 = 8u * (unsigned)(M::kQ + li * NX + lk);
+  L.hcu0 = 8u * (unsigned)(M::kS + lk * NX + li);
+#pragma unroll
+  for (int tj = 0; tj < C::TW; ++tj) {
+    const int col = (16 * tj + li) < C::NW ? (16 * tj + li) : C::NW - 1;
+    // x rows (row = lk + const): Q(row, col) = kQ + col*NX + row ; S(row, col-NX) = kS + (col-NX)*NX + row
+    L.hcxX[tj] = 8u * (unsigned)((col < NX ? M::kQ + col * NX : M::kS + (col - NX) * NX) + lk);
+    // u rows (row = NX + u, u = 4s' + lk): S^T(u, col) = kS + u*NX + col ; R(u, col-NX) = kR + (col-NX)*NU + u
+#pragma unroll
+    for (int sp = 0; sp < C::KU; ++sp) {
+      const int u = 4 * sp + lk;
+      L.hcuX[tj][sp] = 8u * (unsigned)(col < NX ? M::kS + u * NX + col : M::kR + (col - NX) * NU + u);
+    }
+  }
+  L.bop0 = 8u * (unsigned)(M::kB + lk * NX + li);
+  {
+    const int ti = C::TX - 1, row = (16 * ti + li) < NX ? (16 * ti + li) : NX - 1;
+    L.bopX = 8u * (unsigned)(M::kB + lk * NX + row);
+  }
+  const int ir = lane < NX ? lane : NX - 1, iw = lane < C::NW ? lane : C::NW - 1;
+  L.fbl = 8u * (unsigned)((li >> 1) * 2 * C::NW + 2 * lk + (li & 1));
+  L.fi = 8u * (unsigned)(M::kf + ir);
+  L.qri = 8u * (unsigned)(M::kq + iw);
+}
+
+// part A of a knot: the F operands and the vectors (needed from the start of the stage)
+template <int NX, int NU>
+__device__ __forceinline__ void wave_load_a(const double *rec, const WaveLane<NX, NU> &L,
+                                            WaveStage<NX, NU> &S) {
+  using C = WaveCfg<NX, NU>;
+#pragma unroll
+  for (int t = 0; t < C::TW; ++t)
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+      const double v = WaveLane<NX, NU>::fo_in(t) ? ldg_b(rec, 16 * t * NX + 4 * s, L.fo0)
+                                                  : ldg_b(rec, 4 * s, L.foX);
+      if (s < 4 * C::KSF)
+        S.Fo[t][s >> 2][s & 3] = v;
+      else
+        S.FoT[t][s - 4 * C::KSF] = v;
+    }
+  S.fi = ldg_b(rec, 0, L.fi);
+  S.qri = ldg_b(rec, 0, L.qri);
+}
+// part B: the Hessian tiles (first needed by H's accumulation) and B as the A operand of Aff
+template <int NX, int NU>
+__device__ __forceinline__ void wave_load_b(const double *rec, const WaveLane<NX, NU> &L,
+                                            WaveStage<NX, NU> &S) {
+  using C = WaveCfg<NX, NU>;
+#pragma unroll
+  for (int ti = 0; ti < C::TW; ++ti)
+#pragma unroll
+    for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row0 = 16 * ti + 4 * r; // + lk
+        if (row0 + 3 < NX)
+          S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, 16 * tj * NX + row0, L.hcx0)
+                                                       : ldg_b(rec, row0, L.hcxX[tj]);
+        else if (row0 >= NX && row0 + 3 < C::NW)
+          S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj)
+                                ? ldg_b(rec, (row0 - NX) * NX + 16 * tj, L.hcu0)
+                                : ldg_b(rec, 0, L.hcuX[tj][(row0 - NX) >> 2]);
+        else
+          S.Hc[ti][tj][r] = 0.0; // rows past NW (padding)
+      }
+}
+
+// x <- -(L D L^T)^{-1} x, lane = right-hand-side column; L and -1/d are read from LDS with
+// wave-uniform addresses (LDS port, broadcast) instead of v_readlane pairs (VALU port)
+// A zero-instruction scheduling fence: makes `p` (an LDS pointer) depend on `after`, so loads
+// through `p` cannot be hoisted above the instruction that produces `after`.  Without it the
+// scheduler issues ALL the reads of an unrolled phase first and spills what they return.
+__device__ __forceinline__ const double *lds_after(const double *p, double after) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(p) : "v"(after));
+#else
+  (void)after;
+#endif
+  return p;
+}
+
+template <int NU>
+__device__ __forceinline__ void ldl_solve_lds(const double *Lr, const double *ndi, double (&x)[NU]) {
+  // column-oriented substitutions: the FMAs of one column are independent of each other;
+  // L is read one column (forward) / one row (transposed) at a time with wave-uniform
+  // addresses (LDS port, broadcast), one column ahead of the FMAs that consume it
+#pragma unroll
+  for (int j = 0; j < NU - 1; ++j) {
+    const double *Lp = lds_after(Lr, x[j > 0 ? j - 1 : 0]);
+    double lc[NU];
+#pragma unroll
+    for (int i = j + 1; i < NU; ++i)
+      lc[i] = Lp[i * NU + j];
+#pragma unroll
+    for (int i = j + 1; i < NU; ++i)
+      x[i] = __builtin_fma(-lc[i], x[j], x[i]);
+  }
+  {
+    const double *dp = lds_after(ndi, x[NU - 2]);
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+      x[i] *= dp[i];
+  }
+#pragma unroll
+  for (int i = NU - 1; i >= 1; --i) {
+    const double *Lp = lds_after(Lr, x[i < NU - 1 ? i + 1 : i]);
+    double lr[NU];
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+      lr[j] = Lp[i * NU + j];
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+      x[j] = __builtin_fma(-lr[j], x[i], x[j]);
+  }
+}
+
+// Unpivoted LDL^T of the NU x NU matrix M (LDS, column-major, lower valid), lane i < NU owning
+// row i, checking at every column the first test of the Bunch-Kaufman rule
+// (|a_kk| >= alpha * colmax, bunchkaufman.hpp:61) lane-parallel (one compare + ballot).  When
+// the test holds everywhere BK takes kp = k at every column and its elimination
+// (bunchkaufman.hpp:104-121: d11xj = a(j,k) d11; a(i,j) -= d11xj a(i,k)) is what runs here,
+// product for product.  Writes L row-major / column-major and -1/d to LDS; returns 0 if the
+// test held at every column (and no pivot was zero).
+template <int NU>
+__device__ __forceinline__ int wave_ldl_fast(const double *M, int lane, double *Lr, double *ndi) {
+  const double alpha = (1.0 + 4.123105625617661) / 8.0;
+  const int row = lane < NU ? lane : NU - 1;
+  double a[NU];
+#pragma unroll
+  for (int j = 0; j < NU; ++j)
+    a[j] = M[j * NU + row]; // row i of Rhat; entries above the diagonal are stale LDS, never used
+  unsigned long long bad = 0ull;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const double akk = lane_bcast(a[k], k);
+    // lanes i > k hold a(i,k): the column below the pivot
+    // rows i >= k: |a_kk| >= alpha |a(i,k)| (lane k itself: a non-zero pivot)
+    const unsigned long long nok = __ballot(!(fabs(akk) >= alpha * fabs(a[k])) || akk == 0.0);
+    const unsigned long long from_k = ((1ull << NU) - 1ull) & ~((1ull << k) - 1ull);
+    bad |= nok & from_k;
+    const double d = fast_rcp(akk);
+    const double lik = a[k] * d; // L(i,k) = a(i,k) d11  (== the reference's d11xj for row i)
+#pragma unroll
+    for (int j = k + 1; j < NU; ++j)
+      a[j] = __builtin_fma(-lane_bcast(lik, j), a[k], a[j]); // a(i,j) -= d11xj * a(i,k)
+    a[k] = lik;
+    if (lane == 0)
+      ndi[k] = -d;
+  }
+  if (lane < NU) {
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      Lr[lane * NU + j] = a[j];
+    }
+  }
+  return bad != 0ull;
+}
+
+// Rare path, kept out of line so that its registers do not weigh on the sweep: the first
+// Bunch-Kaufman test failed somewhere (or a pivot was zero).  Evaluate the complete rule;
+// if BK still takes kp = k everywhere redo the unpivoted factorisation, else run the generic
+// device Bunch-Kaufman exactly as the reference would (interchanges, 2x2 pivots), solving
+// [kff | K] into G2.  Returns 1 if the factorisation failed (zero pivot column).
+template <int NX, int NU>
+__device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int lane) {
+  using C = WaveCfg<NX, NU>;
+  constexpr int PG = C::PG;
+  double *G = sm + C::oG, *G2 = sm + C::oG2, *Mm = sm + C::oM;
+  double *Lr = sm + C::oLr, *ndi = sm + C::oDi;
+  int failed = 0;
+  int verdict;
+  {
+    double a_row[NU], dinv[NU];
+    verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
+    if (verdict == 0) {
+      if (lane < NU) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          Lr[lane * NU + j] = a_row[j];
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+          ndi[j] = -dinv[j];
+      }
+    }
+  }
+  wave_sync();
+  const int col = lane <= NX ? lane : NX;
+  if (verdict == 0) {
+    double x[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+      x[k] = G[k * PG + col];
+    ldl_solve_lds<NU>(Lr, ndi, x);
+    if (lane <= NX) {
+#pragma unroll
+      for (int k = 0; k < NU; ++k)
+        G2[k * PG + col] = x[k];
+    }
+  } else {
+    for (int e = lane; e < NU * PG; e += 64)
+      G2[e] = -G[e]; // in place (G2 aliases G)
+    double *sub = sm + C::oBk;
+    int *piv = (int *)(sub + 16);
+    const WG w1 = wave_self();
+    wave_sync();
+    failed |= wg_bk_factor(w1, NU, Mm, NU, sub, piv, piv + 16);
+    wg_bk_solve(w1, NU, Mm, NU, sub, piv, G2, PG, 1, NX + 1);
+  }
+  wave_sync();
+  return failed;
+}
+
+// One stage t of the backward sweep, entirely inside one wave.  On entry S holds knot t
+// (F operands, vectors, Hessian tiles); on exit it holds knot t-1.
+template <int NX, int NU>
+__device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, const double *prob,
+                                           double *fac, int t, int lane,
+                                           const WaveLane<NX, NU> &L, WaveStage<NX, NU> &S,
+                                           int &failed, const bool tracing) {
+  using C = WaveCfg<NX, NU>;
+  using M = MfmaCfg<NX, NU>;
+  constexpr int NW = C::NW, PK = C::PK, PG = C::PG, TX = C::TX, TW = C::TW, KS = C::KS,
+                KU = C::KU;
+  const int li = lane & 15, lk = lane >> 4;
+  double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM;
+  double *vn = sm + C::oVn, *fv = sm + C::oFv, *vp = sm + C::oVp;
+  double *Lr = sm + C::oLr, *ndi = sm + C::oDi;
+  double *out = fac + (long long)t * P.fac_rec;
+  const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
+  const double *recn = rec - (t > 0 ? P.in_rec : 0); // knot t-1 (t = 0: harmless re-read)
+#define GAR_WMARK(id)                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  if (tracing && t == (P.horizon >> 1))                                        \
+    P.trace[(id)] = (long long)clock64();                                      \
+  __builtin_amdgcn_sched_barrier(0);
+  GAR_WMARK(0)
+  // ---- vplus = vx' + V' f (:217-218), lane i < NX ------------------------------
+  const int ir = lane < NX ? lane : NX - 1;
+  if (lane < NX)
+    fv[lane] = S.fi;
+  wave_sync();
+  {
+    double s0 = 0.0, s1 = 0.0;
+    double s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; k += 4) {
+      s0 = __builtin_fma(V[ir * PK + k], fv[k], s0);
+      s1 = __builtin_fma(V[ir * PK + k + 1], fv[k + 1], s1);
+      s2 = __builtin_fma(V[ir * PK + k + 2], fv[k + 2], s2);
+      s3 = __builtin_fma(V[ir * PK + k + 3], fv[k + 3], s3);
+    }
+    s0 += s2;
+    s1 += s3;
+    if (lane < NX)
+      vp[lane] = vn[lane] + (s0 + s1);
+  }
+  wave_sync();
+  GAR_WMARK(1)
+  // ---- [qhat; rhat] = [q; r] + F^T vplus (:227-228) from the operand registers:
+  // lane (li,lk) sums its rows 4s+lk, the four lk groups are added by two xor-shuffles
+  double hq; // lane j < NW: [qhat; rhat][j]
+  const double fi = S.fi;
+  {
+    double vps[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      vps[s] = vp[4 * s + lk];
+    double part[TW];
+#pragma unroll
+    for (int tt = 0; tt < TW; ++tt) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s & 1)
+          a1 = __builtin_fma(S.fo(tt, s), vps[s], a1);
+        else
+          a0 = __builtin_fma(S.fo(tt, s), vps[s], a0);
+      }
+      double a = a0 + a1;
+      a += __shfl_xor(a, 16);
+      a += __shfl_xor(a, 32);
+      part[tt] = a; // column 16 tt + li, replicated over lk
+    }
+    double sel = part[0];
+#pragma unroll
+    for (int tt = 1; tt < TW; ++tt)
+      sel = (lk == tt) ? part[tt] : sel; // lane 16 tt + li picks its own column
+    hq = S.qri + sel;
+    if (lane >= NX && lane < NW)
+      G[(lane - NX) * PG] = hq; // rhat: right-hand side of kff (:248), sign applied in the solve
+  }
+  GAR_WMARK(2)
+  // ---- P = V' F, H = W + F^T P (:216-228), column tile by column tile ----------
+#pragma unroll
+  for (int tj = 0; tj < TW; ++tj) {
+    double4_t Pt[TX];
+#pragma unroll
+    for (int tm = 0; tm < TX; ++tm)
+      Pt[tm] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const double bq = S.fo(tj, s);
+#pragma unroll
+      for (int tm = 0; tm < TX; ++tm) {
+        const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
+        const double aq = V[ic * PK + 4 * s + lk];
+        Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, Pt[tm], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ti = tj; ti < TW; ++ti) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.fo(ti, s), Pt[s >> 2][s & 3],
+                                                           S.Hc[ti][tj], 0, 0, 0);
+    }
+  }
+  GAR_WMARK(3)
+  // ---- export the control rows: G(u, 1+j) = Shat^T(u, j), M = Rhat (lower) -----
+#pragma unroll
+  for (int ti = 0; ti < TW; ++ti)
+#pragma unroll
+    for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + lk + 4 * r, c = 16 * tj + li;
+        if (16 * ti + 4 * r >= NX && 16 * ti + 4 * r < NW) { // compile-time: control rows
+          if (c < NX)
+            G[(row - NX) * PG + 1 + c] = S.Hc[ti][tj][r];
+          else if (c <= row)
+            Mm[(c - NX) * NU + (row - NX)] = S.Hc[ti][tj][r];
+        }
+      }
+  wave_sync();
+  // B of this knot as the A operand of Aff = A + B K: needed a factorisation from now
+  double Bop[TX][KU]; // B[16ti+li][4s'+lk]
+#pragma unroll
+  for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      Bop[ti][s] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * s * NX + 16 * ti, L.bop0)
+                                              : ldg_b(rec, 4 * s * NX, L.bopX);
+  GAR_WMARK(4)
+  // ---- factor Rhat (lane = row) under the Bunch-Kaufman rule; solve [kff | K] ---
+  {
+    const int verdict = wave_ldl_fast<NU>(Mm, lane, Lr, ndi);
+    wave_sync();
+    GAR_WMARK(5)
+    if (verdict == 0) {
+      const int col = lane <= NX ? lane : NX; // G column: 0 = kff, 1 + j = K(:, j)
+      double x[NU];
+#pragma unroll
+      for (int k = 0; k < NU; ++k)
+        x[k] = G[k * PG + col];
+      ldl_solve_lds<NU>(Lr, ndi, x); // [kff | K] = -Rhat^{-1} [rhat | Shat^T]  (:248-262)
+      if (lane <= NX) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+          G[k * PG + col] = x[k]; // in place: G now holds [kff | K]
+      }
+      wave_sync();
+    } else {
+      failed |= wave_slow_factor_solve<NX, NU>(sm, lane);
+    }
+  }
+  GAR_WMARK(6)
+  // ---- K as the B operand of Aff and Vxx: Kb[tj][s'] = K[4s'+lk][16tj+li] --------
+  double Kb[TX][KU];
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj) {
+    const int cc = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
+#pragma unroll
+    for (int s = 0; s < KU; ++s) {
+      Kb[tj][s] = G[(4 * s + lk) * PG + 1 + cc];
+      if (16 * tj + li < NX) // fbT2(4s+lk, 16tj+li) = 8tj*2NW + 8s + [(li>>1)*2NW + 2lk + (li&1)]
+        stg_b(out, M::fFB + 8 * tj * 2 * NW + 8 * s, L.fbl, Kb[tj][s]);
+    }
+  }
+  // ---- kff; yff = f + B kff (:266); vx = qhat + Shat kff (:275-276) ----------------
+  // B and Shat are read from the operand registers (rows on li, u = 4s'+lk): partial sums
+  // over this lane's u, the four lk groups added by two xor-shuffles
+  {
+    double kf[KU]; // kff[4s'+lk]
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      kf[s] = G[(4 * s + lk) * PG];
+    double py[TX], pv[TX];
+#pragma unroll
+    for (int ti = 0; ti < TX; ++ti) {
+      double a = 0.0, c = 0.0;
+#pragma unroll
+      for (int s = 0; s < KU; ++s) {
+        a = __builtin_fma(Bop[ti][s], kf[s], a);
+        c = __builtin_fma(S.Hc[C::shTile(s)][ti][C::shReg(s)], kf[s], c); // Shat(16ti+li, 4s+lk)
+      }
+      a += __shfl_xor(a, 16);
+      c += __shfl_xor(c, 16);
+      a += __shfl_xor(a, 32);
+      c += __shfl_xor(c, 32);
+      py[ti] = a; // (B kff)[16 ti + li]
+      pv[ti] = c; // (Shat kff)[16 ti + li]
+    }
+    double sy = py[0], sv = pv[0];
+#pragma unroll
+    for (int ti = 1; ti < TX; ++ti) {
+      sy = (lk == ti) ? py[ti] : sy;
+      sv = (lk == ti) ? pv[ti] : sv;
+    }
+    const double yf = fi + sy, vxv = hq + sv;
+    if (lane < NU)
+      out[M::fFF + lane] = G[lane * PG];
+    if (lane < NX) {
+      out[M::fFF + NU + lane] = yf;
+      out[M::fvx + lane] = vxv;
+      vn[lane] = vxv;
+    }
+  }
+  GAR_WMARK(7)
+  // ---- Aff = A + B K (:267), in place on the F operand registers ------------------
+  // A[16ti+lk+4r][16tj+li] IS the F operand F[4s+lk][16tj+li] with s = 4ti + r.  The MFMAs of
+  // one k-step go round all the tiles (independent accumulators, back-to-back issue); the
+  // stores follow when every tile is done.
+  double4_t accT[TX]; // the tile row made of the tail k-steps (rows 16*KSF ..)
+  if (C::KST > 0) {
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        accT[tj][r] = (r < C::KST) ? S.FoT[tj][r] : 0.0;
+  }
+#pragma unroll
+  for (int s = 0; s < KU; ++s)
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < TX; ++ti) {
+        if (ti < C::KSF)
+          S.Fo[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], S.Fo[tj][ti], 0, 0, 0);
+        else
+          accT[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], accT[tj], 0, 0, 0);
+      }
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
+        if (16 * ti + 4 * r < NX) { // compile-time
+          if (i < NX && j < NX) // fbT2(NU+i, j), i = 16ti+4r+lk
+            stg_b(out, M::fFB + 8 * tj * 2 * NW + 2 * (NU + 16 * ti + 4 * r), L.fbl,
+                  ti < C::KSF ? S.Fo[tj][ti][r] : accT[tj][r]);
+        }
+      }
+  // ---- knot t-1: the F operands and vectors go into the registers Aff just released
+  wave_load_a<NX, NU>(recn, L, S);
+  GAR_WMARK(8)
+  // ---- Vxx = Qhat + Shat K (:272-273), lower tiles, mirrored into LDS --------------
+  // Shat(16ti+li, 4s'+lk) is register shReg(s') of H tile (shTile(s'), ti).  Tiles of those
+  // tile rows accumulate in copies (their other registers are still operands); every other
+  // tile accumulates in place.  One k-step goes round all the tiles.
+  constexpr int shLo = C::shTile(0);
+  double4_t accS[TX][TX];
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+    for (int ti = tj; ti < TX; ++ti)
+      if (ti >= shLo)
+        accS[ti][tj] = S.Hc[ti][tj];
+#pragma unroll
+  for (int s = 0; s < KU; ++s)
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+      for (int ti = tj; ti < TX; ++ti) {
+        const double aq = S.Hc[C::shTile(s)][ti][C::shReg(s)];
+        if (ti >= shLo)
+          accS[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], accS[ti][tj], 0, 0, 0);
+        else
+          S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], S.Hc[ti][tj], 0, 0, 0);
+      }
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+    for (int ti = tj; ti < TX; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + lk + 4 * r, c = 16 * tj + li;
+        if (16 * ti + 4 * r < NX) { // compile-time
+          if (i < NX && c < NX && i >= c) {
+            const double v = ti >= shLo ? accS[ti][tj][r] : S.Hc[ti][tj][r];
+            V[i * PK + c] = v;
+            V[c * PK + i] = v;
+          }
+        }
+      }
+  wave_sync();
+  // ---- knot t-1: its Hessian tiles replace H
+  wave_load_b<NX, NU>(recn, L, S);
+  GAR_WMARK(9)
+  // ---- Vxx -> HBM (column-major, symmetric), 16 B per lane -----------------------
+  static_assert(PK == NX, "V is stored exactly as the Vxx record");
+#pragma unroll
+  for (int e0 = 0; e0 < NX * NX / 2; e0 += 64) {
+    const int e = e0 + lane;
+    if (e0 + 64 <= NX * NX / 2 || e < NX * NX / 2) {
+      const double2_t v = *reinterpret_cast<const double2_t *>(&V[2 * e]);
+      *reinterpret_cast<double2_t *>(&out[M::fVxx + 2 * e]) = v;
+    }
+  }
+  GAR_WMARK(10)
+#undef GAR_WMARK
+}
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int batch) {
+  using C = WaveCfg<NX, NU>;
+  using M = MfmaCfg<NX, NU>;
+  constexpr int PK = C::PK;
+  const int lane = (int)threadIdx.x & 63;
+  // wave-uniform by construction; readfirstlane tells the compiler, so that every global
+  // access is "scalar base + 32-bit lane offset + immediate" (no 64-bit VALU address math)
+  // one 64-thread workgroup per problem: the LDS slice starts at the (link-time constant) base
+  // of the dynamic LDS, so every ds address is "lane pattern + immediate"
+  const int b = (int)blockIdx.x;
+  if (b >= batch)
+    return;
+  double *sm = gar_smem;
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  double *fac = P.fac + (long long)b * P.fac_stride;
+  const int N = P.horizon;
+  double *V = sm + C::oV, *vn = sm + C::oVn;
+  const bool tracing = P.trace != nullptr && b == 0 && lane == 0;
+
+  WaveLane<NX, NU> L;
+  wave_lane_init<NX, NU>(L, lane);
+  WaveStage<NX, NU> S;
+  wave_load_a<NX, NU>(prob + P.in_off0 + (long long)(N - 1) * P.in_rec, L, S);
+  wave_load_b<NX, NU>(prob + P.in_off0 + (long long)(N - 1) * P.in_rec, L, S);
+
+  // ---- terminal knot (terminalSolve, nu = 0, nc = 0, :175-178): Vxx = Q, vx = q
+  {
+    const double *rec = prob + P.in_offN;
+    double *out = fac + P.fac_offN;
+    for (int e = lane; e < NX * NX; e += 64) {
+      const int j = e / NX, i = e - j * NX; // column-major element (i, j)
+      const double v = (i >= j) ? rec[M::tQ + e] : rec[M::tQ + i * NX + j];
+      V[i * PK + j] = v; // symmetrised from lower, as the consumer stage does (:216)
+      out[M::tVxx + e] = v;
+    }
+    if (lane < NX) {
+      const double v = rec[M::tq + lane];
+      vn[lane] = v;
+      out[M::tvx + lane] = v;
+    }
+  }
+  wave_sync();
+  int failed = 0;
+  for (int t = N - 1; t >= 0; --t)
+    wave_stage<NX, NU>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+  if (failed && lane == 0)
+    atomicOr(&P.status[b], failed);
+}
+
+} // namespace gar

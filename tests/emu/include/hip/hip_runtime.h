@@ -94,6 +94,7 @@ inline double __shfl(double v, int src) {
   return r;
 }
 inline double __shfl_xor(double v, int mask) { return __shfl(v, (int)((threadIdx.x & 63) ^ mask)); }
+inline int __shfl_xor(int v, int mask) { return (int)__shfl((double)v, (int)((threadIdx.x & 63) ^ mask)); }
 inline int __builtin_amdgcn_readlane(int v, int src) {
   emu::WaveCtx &W = emu::wave();
   const int lane = threadIdx.x & 63;
@@ -102,6 +103,9 @@ inline int __builtin_amdgcn_readlane(int v, int src) {
   const int r = (int)W.b[src & 63];
   W.bar.arrive_and_wait();
   return r;
+}
+inline int __builtin_amdgcn_readfirstlane(int v) { // exec is full wherever the kernels call it
+  return __builtin_amdgcn_readlane(v, 0);
 }
 inline unsigned long long __ballot(int pred) {
   emu::WaveCtx &W = emu::wave();
@@ -128,6 +132,7 @@ inline void __builtin_amdgcn_wave_barrier() {
 #define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
 
 inline long long clock64() { return 0; }
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 inline double __builtin_amdgcn_rcp(double a) { return 1.0 / a; }
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

@@ -122,17 +122,37 @@ def test_cycle_append_rotates_factors():                      # proximal-riccati
     assert np.array_equal(s.getFeedback(6), before[6])                  # terminal factor kept
 
 
-# ---- the specialised MFMA backward kernel (csrc/gar_mfma.hpp) -----------------
+# ---- the specialised backward kernels: one wave per problem (csrc/gar_wave.hpp,
+# the default) and the 4-wave workgroup kernel (csrc/gar_mfma.hpp, GAR_HIP_BACKWARD=wg4)
+FAMILIES = [("wave", "wave"), ("wg4", "mfma")]
+
+
+@pytest.fixture(params=FAMILIES, ids=[f[0] for f in FAMILIES])
+def family(request, monkeypatch):
+    monkeypatch.setenv("GAR_HIP_BACKWARD", request.param[0])
+    return request.param[1]
+
+
 @pytest.mark.parametrize("nx,nu,horz,mode", [(8, 4, 3, "W"), (12, 4, 5, "W"), (16, 8, 4, "F"),
                                              (36, 12, 4, "W"), (36, 12, 3, "F"), (32, 12, 3, "W")])
-def test_mfma_kernel_matches_oracle(nx, nu, horz, mode):
+def test_mfma_kernel_matches_oracle(nx, nu, horz, mode, family):
     prob = synth.generate_lq_problem(7, np.zeros(nx), horz, nx, nu, mode=mode)
     solver, _, _ = pc.check_serial(prob, 1e-12, pc.TOL[mode], EMU,
                                    kkt_tol=1e-6 if mode == "F" else 1e-9)
-    assert solver.kernel_name == f"mfma<{nx},{nu}>"
+    assert solver.kernel_name == f"{family}<{nx},{nu}>"
 
 
-def test_mfma_kernel_bunch_kaufman_fallback():
+def test_wave_kernel_odd_and_even_horizons(monkeypatch):
+    """The stage body is instantiated twice (register ping-pong): both parities of the
+    horizon, and horizon 1, must take the right tail."""
+    monkeypatch.setenv("GAR_HIP_BACKWARD", "wave")
+    for horz in (1, 2, 5):
+        prob = synth.generate_lq_problem(70 + horz, np.zeros(12), horz, 12, 4, mode="W")
+        solver, _, _ = pc.check_serial(prob, 1e-12, 1e-9, EMU, kkt_tol=1e-9)
+        assert solver.kernel_name == "wave<12,4>"
+
+
+def test_mfma_kernel_bunch_kaufman_fallback(family):
     """A stage whose Rhat makes Bunch-Kaufman interchange (rule at
     bunchkaufman.hpp:61-83) must take the generic device BK, uniformly for the
     workgroup, and still match the oracle."""
@@ -147,10 +167,10 @@ def test_mfma_kernel_bunch_kaufman_fallback():
     pivots = [ora.BunchKaufman(osol.datas(t).Rhat).pivots for t in range(4)]
     assert any(not np.array_equal(p, np.arange(nu)) for p in pivots), "test must force a pivot"
     solver, _, _ = pc.check_serial(prob, 1e-12, 1e-9, EMU)
-    assert solver.kernel_name == "mfma<8,4>"
+    assert solver.kernel_name == f"{family}<8,4>"
 
 
-def test_mfma_kernel_failed_factorisation_raises():
+def test_mfma_kernel_failed_factorisation_raises(family):
     from aligator_amd.gar import ProximalRiccatiSolver
     prob = synth.generate_lq_problem(3, np.zeros(8), 3, 8, 4, mode="W")
     for k in prob.stages[:-1]:
@@ -158,12 +178,12 @@ def test_mfma_kernel_failed_factorisation_raises():
         k.S[...] = 0.0
         k.B[...] = 0.0
     s = ProximalRiccatiSolver(prob, lib_path=EMU)
-    assert s.kernel_name == "mfma<8,4>"
+    assert s.kernel_name == f"{family}<8,4>"
     with pytest.raises(RuntimeError, match="LDL"):
         s.backward(1e-10)
 
 
-def test_mfma_and_generic_kernels_agree(monkeypatch):
+def test_mfma_and_generic_kernels_agree(monkeypatch, family):
     prob = synth.generate_lq_problem(5, np.zeros(12), 6, 12, 4, mode="W")
     from aligator_amd.gar import ProximalRiccatiSolver, lqrInitializeSolution
     a = ProximalRiccatiSolver(prob, lib_path=EMU)
@@ -172,7 +192,7 @@ def test_mfma_and_generic_kernels_agree(monkeypatch):
     a.forward(*sa)
     monkeypatch.setenv("GAR_HIP_FORCE_GENERIC", "1")
     g = ProximalRiccatiSolver(prob, lib_path=EMU)
-    assert g.kernel_name == "generic" and a.kernel_name == "mfma<12,4>"
+    assert g.kernel_name == "generic" and a.kernel_name == f"{family}<12,4>"
     g.backward(1e-12)
     sg = lqrInitializeSolution(prob)
     g.forward(*sg)
