@@ -76,6 +76,11 @@ struct gar_hip_solver {
   void (*wave_kernel)(gar::MfmaParams, int) = nullptr;
   int wave_lds_doubles = 0, waves_per_block = 1;
   long long *d_trace = nullptr; // 64 cycle stamps (debug)
+  // optional per-kernel timing of the sweep (bench.py's roofline figure): HIP events recorded on
+  // the launch stream around the backward sweep kernel, the initial-stage kernel and the forward
+  // sweep kernel of the LAST backward/forward calls
+  bool timing = false;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -355,6 +360,8 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.fac_offN = s->meta[N].fac_off;
     M.horizon = N;
     M.trace = s->d_trace;
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->wave_kernel) {
       const int wpb = s->waves_per_block;
       hipLaunchKernelGGL(s->wave_kernel, dim3((unsigned)((s->batch + wpb - 1) / wpb)),
@@ -365,6 +372,8 @@ int launch_backward(gar_hip_solver *s, double mueq) {
                          (size_t)s->mfma_lds_doubles * sizeof(double), s->stream, M);
     }
     HIP_TRY(hipGetLastError());
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     if (s->n0 <= 128) { // one wave per problem (wave-scope Bunch-Kaufman handles n <= 128)
       hipLaunchKernelGGL(gar::gar_initial_wave, dim3((unsigned)s->batch), dim3(64),
                          (size_t)gar::gar_initial_wave_lds_doubles(s->n0, s->nth0) * sizeof(double),
@@ -374,6 +383,8 @@ int launch_backward(gar_hip_solver *s, double mueq) {
                          (size_t)s->lds.total * sizeof(double), s->stream, P);
     }
     HIP_TRY(hipGetLastError());
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     return GAR_HIP_OK;
   }
   const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
@@ -399,8 +410,12 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
     F.nc0 = s->nc0;
     F.sol_u = (int)s->sol_u;
     F.sol_l = (int)s->sol_l;
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[3], s->stream));
     hipLaunchKernelGGL(s->mfma_fwd_kernel, dim3((unsigned)s->batch), dim3(64), 0, s->stream, F);
     HIP_TRY(hipGetLastError());
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[4], s->stream));
     return GAR_HIP_OK;
   }
   gar::GenericParams P = make_params(s, 0.0);
@@ -646,6 +661,9 @@ void gar_hip_solver_destroy(gar_hip_solver *s) {
   free_device(s);
   if (s->own_stream)
     (void)hipStreamDestroy(s->own_stream);
+  for (auto &e : s->ev)
+    if (e)
+      (void)hipEventDestroy(e);
   delete s;
 }
 
@@ -966,6 +984,34 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]) {
     (void)hipFree(s->d_trace);
     s->d_trace = nullptr;
   }
+  return GAR_HIP_OK;
+}
+
+int gar_hip_set_timing(gar_hip_solver *s, int enable) {
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (enable && !s->ev[0])
+    for (auto &e : s->ev)
+      HIP_TRY(hipEventCreate(&e));
+  s->timing = enable != 0;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]) {
+  if (!s || !out)
+    return fail(GAR_HIP_ERR_ARG, "bad argument");
+  if (!s->timing || !s->mfma_kernel)
+    return fail(GAR_HIP_ERR_UNSUPPORTED, "per-kernel timing is recorded for the specialised "
+                                         "kernel family after gar_hip_set_timing(s, 1)");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+  out[0] = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
+  out[1] = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev[3], s->ev[4]));
+  out[2] = ms;
   return GAR_HIP_OK;
 }
 

@@ -1,0 +1,136 @@
+"""Horizon sharding of ONE LQ problem (or one batch of them) over the ranks of a
+``torch.distributed`` process group: one process per GPU, RCCL over xGMI.
+
+This is the multi-GPU form of gar::ParallelRiccatiSolver
+(gar/parallel-solver.hxx:132-243).  In the reference the legs are OpenMP threads
+of one process and the "boundary exchange" is the implicit barrier that closes
+the parallel region (:150-164 -> assembleCondensedSystem at :169).  Here rank r
+owns legs [r*L, (r+1)*L) of `num_legs` (L = num_legs / world):
+
+  1. per-rank leg-parallel backward          gar_hip_backward_legs_async
+  2. ONE all-gather of the per-leg boundary tuples (Vxx | Vxt | Vtt | vx | vt of
+     the leg's first stage: 3 nx^2 + 2 nx doubles, 31.7 KB at nx = 36)
+  3. the small condensed block-tridiagonal system is solved redundantly on every
+     rank (no broadcast)                      gar_hip_condensed_solve_async
+  4. per-rank leg-parallel forward            gar_hip_forward_legs_async
+
+xGMI is point-to-point and the payload is tens of KB, so the exchange is
+latency-bound: a single fused collective per sweep, no O(log J) rounds.
+
+torch.distributed is plumbing here (process group + the collective on the
+library's own device buffers); all arithmetic stays in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .gar import BatchedRiccatiSolver, get_work
+
+__all__ = ["ShardedRiccatiSolver"]
+
+
+class _DevArray:
+    """A raw device pointer as a __cuda_array_interface__ object (float64, 1-D)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+def _view(ptr: int, n: int, on_device: bool) -> torch.Tensor:
+    """A torch tensor ALIASING n doubles at `ptr` (no copy)."""
+    if on_device:
+        return torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", torch.cuda.current_device()))
+    buf = (C.c_double * n).from_address(ptr)  # host memory (the CPU test build of the library)
+    return torch.from_numpy(np.ctypeslib.as_array(buf))
+
+
+class ShardedRiccatiSolver:
+    """`batch` problems of identical dimensions, horizon split into `num_legs` legs,
+    the legs split evenly over the ranks of `group`."""
+
+    def __init__(self, dims, nc0: int, num_legs: int, batch: int = 1, device: int = 0,
+                 group: Optional[dist.ProcessGroup] = None, lib_path: Optional[str] = None,
+                 on_device: Optional[bool] = None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if num_legs % self.world != 0 or num_legs < 2:
+            raise ValueError("num_legs must be >= 2 and a multiple of the number of ranks")
+        self.legs_per_rank = num_legs // self.world
+        self.num_legs = num_legs
+        lo = self.rank * self.legs_per_rank
+        self.impl = BatchedRiccatiSolver(dims, nc0, batch=batch, num_legs=num_legs, device=device,
+                                         leg_range=(lo, lo + self.legs_per_rank), lib_path=lib_path)
+        self.on_device = torch.cuda.is_available() if on_device is None else on_device
+        L, h = self.impl._L, self.impl.handle
+        tup = int(L.gar_hip_boundary_doubles(h))
+        n_local = batch * self.legs_per_rank * tup
+        self._local = _view(L.gar_hip_device_boundary_local(h), n_local, self.on_device)
+        self._all = _view(L.gar_hip_device_boundary_all(h), n_local * self.world, self.on_device)
+        self.stage_range = (get_work(self.impl.horizon, lo, num_legs)[0],
+                            get_work(self.impl.horizon, lo + self.legs_per_rank - 1, num_legs)[1])
+
+    # ---- the sweep -----------------------------------------------------------------
+    def backward(self, mueq: float) -> bool:
+        L, h = self.impl._L, self.impl.handle
+        self.impl._check(L.gar_hip_backward_legs_async(h, float(mueq)))   # parallel-solver.hxx:150-164
+        self.impl.sync()
+        # the boundary exchange: one all-gather, rank-major == the layout the condensed solve reads
+        dist.all_gather_into_tensor(self._all, self._local, group=self.group)
+        if self.on_device:
+            torch.cuda.synchronize()
+        self.impl._check(L.gar_hip_condensed_solve_async(h))             # :169-202, redundant per rank
+        self.impl.sync()
+        if self.impl.num_failed() != 0:
+            raise RuntimeError("Failed stage LDL factorization")
+        return True
+
+    def forward(self) -> bool:
+        L, h = self.impl._L, self.impl.handle
+        self.impl._check(L.gar_hip_forward_legs_async(h))                # :209-243
+        self.impl.sync()
+        return True
+
+    # ---- results ---------------------------------------------------------------------
+    def local_solution(self, b: int = 0):
+        """(xs, us, vs, lbdas) of problem b; only this rank's stages
+        [stage_range[0], stage_range[1]) carry results."""
+        return self.impl.solution(b)
+
+    def gather_solution(self, b: int = 0):
+        """Every rank's stages merged (an all_gather of the per-stage vectors; test/diagnostic
+        helper, not part of the timed path)."""
+        sol = self.impl.solution(b)
+        flat = torch.from_numpy(np.concatenate([np.concatenate([np.ravel(v) for v in part])
+                                                if part else np.zeros(0) for part in sol]))
+        if self.on_device:
+            flat = flat.cuda()
+        parts = [torch.empty_like(flat) for _ in range(self.world)]
+        dist.all_gather(parts, flat, group=self.group)
+        parts = [p.cpu().numpy() for p in parts]
+        N = self.impl.horizon
+        owner = np.zeros(N + 1, dtype=int)
+        for r in range(self.world):
+            s0 = get_work(N, r * self.legs_per_rank, self.num_legs)[0]
+            s1 = get_work(N, (r + 1) * self.legs_per_rank - 1, self.num_legs)[1]
+            owner[s0:s1] = r
+        out = []
+        pos = 0
+        for pi, part in enumerate(sol):
+            merged = []
+            for t, v in enumerate(part):
+                # xs[t], us[t], vs[t] belong to stage t; lbdas[t] (t >= 1) is produced with
+                # x_t by the leg holding stage t-1 ... except at a leg start, where it comes
+                # from the condensed solution every rank holds (parallel-solver.hxx:215-220)
+                st = min(t, N)
+                r = owner[st] if pi != 3 or t == 0 else owner[st]
+                merged.append(parts[r][pos:pos + v.size].reshape(v.shape).copy())
+                pos += v.size
+            out.append(merged)
+        return tuple(out)

@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -30,6 +31,22 @@ from aligator_amd import synth_device  # noqa: E402
 from aligator_amd.gar import BatchedRiccatiSolver  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; 6.29e12 measured copy)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # scripts/collect_pmc.sh (rocprofv3 --pmc)
+
+
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes, with the
+    factors calibrated on a known-size copy in the same run); None if not collected for this batch."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        e = d["kernels"][kernel]
+        if int(e["batch"]) != int(batch):
+            return None
+        return float(e["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def algorithmic_bytes(N, nx, nu):
@@ -150,18 +167,13 @@ def main():
     if solver.num_failed() != 0:
         raise SystemExit("a stage factorisation failed during warm-up")
 
-    # per-kernel durations with HIP events on the launch stream (torch's current stream)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
         solver.backward_async(mueq)
-        ev[k][1].record(stream)
         solver.forward_async()
-        ev[k][2].record(stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -170,8 +182,19 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    bwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    fwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    # per-kernel durations: HIP events the library recorded on the launch stream around the
+    # backward sweep kernel, the initial-stage kernel and the forward sweep kernel, averaged
+    # over a few extra (untimed) steps
+    solver._check(solver._L.gar_hip_set_timing(solver.handle, 1))
+    kms = np.zeros(3)
+    reps = max(3, min(args.steps, 10))
+    for _ in range(reps):
+        step()
+        out3 = (C.c_double * 3)()
+        solver._check(solver._L.gar_hip_last_kernel_ms(solver.handle, out3))
+        kms += np.array(list(out3))
+    kms /= reps
+    bwd_ms, init_ms, fwd_ms = (float(v) for v in kms)
     failed = solver.num_failed()
 
     err, kkt = parity_check(solver, args, mueq)
@@ -196,12 +219,14 @@ def main():
                                    f"(BASELINE.json configs[1])",
                        "batch_per_gpu": args.batch, "kernel": solver.kernel_name,
                        "parallelism": f"batch-sharded x{world} (no data-path collective)"},
-            "kernel_ms": {"backward": bwd_ms, "forward": fwd_ms},
-            "roofline": {"bound": "hbm", "kernel": "backward", "achieved": achieved / 1e9,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "traffic": None,
+            "kernel_ms": {"backward_sweep": bwd_ms, "initial_stage": init_ms, "forward_sweep": fwd_ms},
+            "roofline": {"bound": "hbm", "kernel": f"gar_backward_{solver.kernel_name}",
+                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK,
+                         "traffic": pmc_traffic("backward", args.batch),
                          "algorithmic_bytes_per_launch": bwd_b * args.batch,
-                         "forward_GBps": fwd_b * args.batch / (fwd_ms * 1e-3) / 1e9},
+                         "forward_GBps": fwd_b * args.batch / (fwd_ms * 1e-3) / 1e9,
+                         "sweep_frac_of_hbm_roofline": (sweeps / elapsed) * (bwd_b + fwd_b) / HBM_PEAK},
             "parity": {"max_rel_err_vs_oracle": err, "max_kkt": kkt, "failed_factorisations": failed},
         }
         if world == 1 and not args.no_cpu:

@@ -176,6 +176,12 @@ int gar_hip_collapse_feedback(gar_hip_solver *s);
  * kernel stamps s_memtime at its phase boundaries for one stage of problem 0,
  * 16 marks per wave; `out` (may be NULL) receives the last 4 x 16 stamps. */
 int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
+/* Measurement aid (no reference counterpart): with enable != 0 the library brackets the
+ * backward sweep kernel, the initial-stage kernel and the forward sweep kernel with HIP events
+ * on the launch stream; gar_hip_last_kernel_ms returns the durations (ms) of the last
+ * backward/forward pair as out[0..2].  Specialised kernel family only. */
+int gar_hip_set_timing(gar_hip_solver *s, int enable);
+int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]);
 /* MPC cycling: drop knot 0, shift left, last-but-one knot gets dims5_new */
 int gar_hip_cycle_append(gar_hip_solver *s, const int32_t dims5_new[5]);
 

@@ -6,7 +6,7 @@ echo "== pytest gpu (wave) =="; timeout 900 python -m pytest tests -m gpu -x -q 
 for B in ${BATCHES:-1024 2048}; do
   echo "== bench wave batch $B =="; timeout 600 python bench.py --steps 5 --warmup 2 --batch $B --no-cpu 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print(d['config']['kernel'], 'batch', d['config']['batch_per_gpu'], 'sweeps/s %.0f'%d['value'], 'bwd %.3f ms fwd %.3f ms'%(d['kernel_ms']['backward'], d['kernel_ms']['forward']), 'frac %.3f'%d['roofline']['frac'], 'err', d['parity'])" | tee gpurun_out/bench_wave_b$B.log
+d=json.loads(sys.stdin.read()); print(d['config']['kernel'], 'batch', d['config']['batch_per_gpu'], 'sweeps/s %.0f'%d['value'], 'bwd %.3f init %.3f fwd %.3f ms'%(d['kernel_ms']['backward_sweep'], d['kernel_ms']['initial_stage'], d['kernel_ms']['forward_sweep']), 'frac %.3f'%d['roofline']['frac'], 'err', d['parity'])" | tee gpurun_out/bench_wave_b$B.log
 done
 echo "== trace =="; for B in ${TRACEB:-1 1024 2048}; do timeout 300 python scripts/trace_wave.py $B 2>&1 | tail -2 | tee gpurun_out/trace_wave_b$B.log; done
 if [ "${PROF:-0}" = "1" ]; then

@@ -152,6 +152,11 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = null
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
+typedef struct emu_event_t *hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)std::malloc(1); return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 

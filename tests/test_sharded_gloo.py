@@ -1,0 +1,91 @@
+"""The N > 1 path on CPU: world_size = 2, backend gloo, 127.0.0.1.
+
+Two processes run the REAL sharded flow of aligator_amd.sharded
+(gar_hip_solver_create_sharded -> backward_legs -> all_gather of the boundary
+tuples -> condensed solve -> forward_legs) with the kernel sources executing on
+the wave emulator (tests/emu: test-only build, host memory), and bench.py's batch
+sharding (independent problems per rank, no data-path collective).  Results are
+checked against the serial CPU oracle and the golden fixture.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU = os.path.join(HERE, "emu", "_build", "libgar_hip_emu.so")
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+emu, mode = sys.argv[2], sys.argv[3]
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+from aligator_amd import synth
+from aligator_amd.gar import BatchedRiccatiSolver
+from aligator_amd.lqr import lqrComputeKktError
+import parity_cases as pc
+if mode == "horizon":
+    from aligator_amd.sharded import ShardedRiccatiSolver
+    from test_golden import load_fixture, assert_matches
+    prob, mueq, _, gold = load_fixture(os.path.join(sys.argv[1], "tests", "golden", "parallel_shape_nx8_N17.npz"))
+    for legs in (2, 4, 6):
+        s = ShardedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, legs, batch=1,
+                                 lib_path=emu, on_device=False)
+        s.impl.upload([prob])
+        s.backward(mueq)
+        s.forward()
+        sol = s.gather_solution(0)
+        assert_matches(sol, gold, 1e-8)
+        assert max(lqrComputeKktError(prob, *sol, mueq=mueq)) <= 1e-8
+        # this rank really only computed its own stages
+        lo, hi = s.stage_range
+        assert (lo, hi) == ((0, 9) if rank == 0 else (9, 18)), (lo, hi)
+    print(f"rank {rank}: horizon sharding ok")
+else:
+    # batch sharding (bench.py --gpus N): each rank sweeps its own problems; the only
+    # collective is the reduction of a scalar summary
+    nx, nu, N, B = 8, 4, 6, 3
+    probs = [synth.generate_lq_problem(1000 + 17 * rank + i, np.zeros(nx), N, nx, nu, mode="W") for i in range(B)]
+    s = pc.check_batched(probs, 1e-12, 1e-9, lib_path=emu)
+    assert s.kernel_name == "wave<8,4>"
+    t = torch.tensor([float(B)], dtype=torch.float64)
+    dist.all_reduce(t)
+    assert t.item() == B * world
+    print(f"rank {rank}: batch sharding ok")
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def build_emu():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu")], check=True)
+
+
+@pytest.mark.parametrize("mode", ["horizon", "batch"])
+def test_two_ranks_gloo(tmp_path, mode):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, EMU, mode], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+        assert "ok" in out
