@@ -149,6 +149,49 @@ __device__ inline void wg_fill(const WG &w, double *dst, int n, double v) {
     dst[e] = v;
 }
 
+// Storage of the symmetric matrix handed to the Bunch-Kaufman routines: every access they make
+// is to the lower triangle (i >= j), so besides plain column-major (leading dimension lda) the
+// lower triangle may be PACKED by columns (lda = n): half the LDS.
+enum { GAR_COLMAJOR = 0, GAR_PACKED_LOWER = 1 };
+template <int MODE> __device__ __forceinline__ int bk_idx(int i, int j, int lda) {
+  return MODE == GAR_PACKED_LOWER ? j * lda - ((j * (j - 1)) >> 1) + (i - j) : j * lda + i;
+}
+
+// Row i of the 1x1 elimination step k (bunchkaufman.hpp:104-121): a(i,j) -= (a(j,k) d11) a(i,k)
+// for j = k+1 .. i.  Loads are issued eight at a time before the stores that follow them (the
+// compiler cannot prove that a(i,j+1) does not alias the store to a(i,j), and would otherwise
+// serialise one LDS round trip per element); indices advance incrementally.
+template <int MODE>
+__device__ __forceinline__ void bk_update_row(double *a, int lda, int i, int k, double aik,
+                                              double d11) {
+  int pij = bk_idx<MODE>(i, k + 1, lda), pjk = bk_idx<MODE>(k + 1, k, lda);
+  int j = k + 1;
+  for (; j + 8 <= i + 1; j += 8) {
+    double wv[8], v[8];
+    int pp[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      wv[q] = a[pjk + q];
+      pp[q] = pij;
+      v[q] = a[pij];
+      pij += (MODE == GAR_PACKED_LOWER) ? lda - (j + q) - 1 : lda;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      v[q] -= (wv[q] * d11) * aik;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      a[pp[q]] = v[q];
+    pjk += 8;
+  }
+  for (; j <= i; ++j) {
+    const double d11xj = a[pjk] * d11;
+    a[pij] -= d11xj * aik;
+    pij += (MODE == GAR_PACKED_LOWER) ? lda - j - 1 : lda;
+    pjk += 1;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Bunch-Kaufman, whole workgroup, matrix `a` (n x n, lower triangle used,
 // column-major with leading dimension lda) factorised in place.
@@ -156,9 +199,10 @@ __device__ inline void wg_fill(const WG &w, double *dst, int n, double v) {
 //   piv[k] = piv[k+1] = -1-p : 2x2 pivot, row k+1 interchanged with p
 // ctrl: >= 4 ints of scratch.  Returns 0 on success, 1 on an exactly-zero
 // pivot column (NumericalIssue, bunchkaufman.hpp:58-59).  Ends with a barrier.
+template <int MODE = GAR_COLMAJOR>
 __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, double *subdiag,
                                    int *piv, int *ctrl) {
-#define GA(i, j) a[(j) * lda + (i)]
+#define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
   const double alpha = (1.0 + 4.123105625617661) / 8.0; // (1+sqrt(17))/8, :29
   if (n == 0)
     return 0;
@@ -179,6 +223,35 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
   int info = 0;
   while (k < n) {
     wg_bar(w);
+    if (w.wave_scope && n <= 128) {
+      // Common case inside one wave, decided without a reduction or a round trip through
+      // thread 0: the first test of the rule, |a_kk| >= alpha * colmax (:61), holds iff
+      // |a_kk| >= alpha |a(i,k)| for every row below -- one compare per lane and a ballot.
+      // Then kp = k, a 1x1 pivot (:104-121), eliminated from registers.
+      const double akk = GA(k, k);
+      const int i0 = k + 1 + w.lane, i1 = i0 + 64;
+      const double a0 = i0 < n ? GA(i0, k) : 0.0, a1 = i1 < n ? GA(i1, k) : 0.0;
+      const double abs_akk = fabs(akk);
+      const bool bad = !(abs_akk >= fabs(a0) * alpha) || !(abs_akk >= fabs(a1) * alpha);
+      if (__ballot(bad) == 0ull && akk != 0.0) {
+        const double d11 = 1.0 / akk;
+        if (i0 < n)
+          bk_update_row<MODE>(a, lda, i0, k, a0, d11);
+        if (i1 < n)
+          bk_update_row<MODE>(a, lda, i1, k, a1, d11);
+        wg_bar(w); // every row has read column k: now scale it (:118-120)
+        if (i0 < n)
+          GA(i0, k) = a0 * d11;
+        if (i1 < n)
+          GA(i1, k) = a1 * d11;
+        if (w.tid == 0) {
+          GA(k, k) = d11;
+          piv[k] = k;
+        }
+        k += 1;
+        continue;
+      }
+    }
     // pivot search, :46-83.  The column maximum (first row attaining it, as the reference's
     // strict ">" scan) is found by the whole group when the column is long: every thread scans
     // its rows, waves reduce with xor-shuffles, thread 0 combines the per-wave results that
@@ -298,14 +371,9 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       // one thread per trailing row i: a(i,j) -= (a(j,k) d11) a(i,k) for j <= i.  For a fixed j
       // the threads touch consecutive i (conflict-free), a(j,k) is a broadcast read, and there
       // is no integer division in the loop
-      for (int i = k + 1 + w.tid; i < n; i += w.nthr) {
-        const double aik = GA(i, k);
-#pragma unroll 4
-        for (int j = k + 1; j <= i; ++j) {
-          const double d11xj = GA(j, k) * d11;
-          GA(i, j) -= d11xj * aik;
-        }
-      }
+      // (incremental indices: element (i, j+1) is lda [- j - 1 when packed] past (i, j))
+      for (int i = k + 1 + w.tid; i < n; i += w.nthr)
+        bk_update_row<MODE>(a, lda, i, k, GA(i, k), d11);
       (void)m;
       wg_bar(w);
       for (int i = w.tid; i < m; i += w.nthr)
@@ -411,11 +479,88 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
 // group works on ONE column at a time, column-oriented: x_j is final, every thread updates
 // its rows i > j (i < j for the transposed solve).  Same operations as the per-column path,
 // summed in the same order per row.
+__device__ __forceinline__ double bk_bcast(double v, int src /*wave-uniform*/) {
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// One wave, n <= 128, no 2x2 pivots: x lives in REGISTERS (lane l owns x_l and x_{l+64}); the
+// pivot entry is broadcast with v_readlane (the column index is wave-uniform), so a substitution
+// step is one conflict-free LDS read and one FMA per lane, with no barrier and no LDS round trip
+// for x.  Same operations, same order per row, as wg_bk_solve_few.
+template <int MODE>
+__device__ inline void wave_bk_solve_regs(const WG &w, int n, const double *a, int lda,
+                                          const int *piv, double *xc, int xrs) {
+#define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
+#define GX(i) xc[(i) * xrs]
+  const int i0 = w.lane, i1 = w.lane + 64;
+  wg_bar(w);
+  if (w.tid == 0) { // forward interchanges (:458-468); 1x1 pivots only
+    for (int k = 0; k < n; ++k) {
+      const int p = piv[k];
+      if (k != p) {
+        const double t = GX(k);
+        GX(k) = GX(p);
+        GX(p) = t;
+      }
+    }
+  }
+  wg_bar(w);
+  double x0 = i0 < n ? GX(i0) : 0.0, x1 = i1 < n ? GX(i1) : 0.0;
+  for (int j = 0; j + 1 < n; ++j) { // unit-lower solve (:472), axpy form
+    const double xj = j < 64 ? bk_bcast(x0, j) : bk_bcast(x1, j - 64);
+    if (i0 > j && i0 < n)
+      x0 -= GA(i0, j) * xj;
+    if (i1 > j && i1 < n)
+      x1 -= GA(i1, j) * xj;
+  }
+  if (i0 < n) // inverse-D multiply (:474-502), 1x1 blocks: D^{-1} is stored on the diagonal
+    x0 *= GA(i0, i0);
+  if (i1 < n)
+    x1 *= GA(i1, i1);
+  for (int i = n - 1; i >= 1; --i) { // unit-upper (L^T) solve (:504), axpy form
+    const double xi = i < 64 ? bk_bcast(x0, i) : bk_bcast(x1, i - 64);
+    if (i0 < i)
+      x0 -= GA(i, i0) * xi;
+    if (i1 < i)
+      x1 -= GA(i, i1) * xi;
+  }
+  if (i0 < n)
+    GX(i0) = x0;
+  if (i1 < n)
+    GX(i1) = x1;
+  wg_bar(w);
+  if (w.tid == 0) { // reverse interchanges (:506-517)
+    for (int k = n - 1; k >= 0; --k) {
+      const int p = piv[k];
+      if (k != p) {
+        const double t = GX(k);
+        GX(k) = GX(p);
+        GX(p) = t;
+      }
+    }
+  }
+  wg_bar(w);
+#undef GA
+#undef GX
+}
+
+template <int MODE = GAR_COLMAJOR>
 __device__ inline void wg_bk_solve_few(const WG &w, int n, const double *a, int lda,
                                        const double *subdiag, const int *piv, double *x, int xrs,
                                        int xcs, int ncols) {
-#define GA(i, j) a[(j) * lda + (i)]
+#define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
 #define GX(i) xc[(i) * xrs]
+  if (w.wave_scope && n <= 128) {
+    // any 2x2 pivot (negative entry)?  lane-parallel scan + ballot
+    const bool neg = (w.lane < n && piv[w.lane] < 0) || (w.lane + 64 < n && piv[w.lane + 64] < 0);
+    if (__ballot(neg) == 0ull) {
+      for (int c = 0; c < ncols; ++c)
+        wave_bk_solve_regs<MODE>(w, n, a, lda, piv, x + c * xcs, xrs);
+      return;
+    }
+  }
   for (int c = 0; c < ncols; ++c) {
     double *xc = x + c * xcs;
     wg_bar(w);
@@ -493,14 +638,15 @@ __device__ inline void wg_bk_solve_few(const WG &w, int n, const double *a, int 
 #undef GX
 }
 
+template <int MODE = GAR_COLMAJOR>
 __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
                                    const double *subdiag, const int *piv, double *x, int xrs,
                                    int xcs, int ncols) {
   if (ncols < 16 && n >= 16) {
-    wg_bk_solve_few(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
+    wg_bk_solve_few<MODE>(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
     return;
   }
-#define GA(i, j) a[(j) * lda + (i)]
+#define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
 #define GX(i) xc[(i) * xrs]
   for (int c = w.tid; c < ncols; c += w.nthr) {
     double *xc = x + c * xcs;

@@ -75,6 +75,7 @@ struct gar_hip_solver {
   // one-wave-per-problem backward kernel (gar_wave.hpp), preferred when bound
   void (*wave_kernel)(gar::MfmaParams, int) = nullptr;
   int wave_lds_doubles = 0, waves_per_block = 1;
+  bool wave_fused_init = false;
   long long *d_trace = nullptr; // 64 cycle stamps (debug)
   // optional per-kernel timing of the sweep (bench.py's roofline figure): HIP events recorded on
   // the launch stream around the backward sweep kernel, the initial-stage kernel and the forward
@@ -244,7 +245,11 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   const char *bw = std::getenv("GAR_HIP_BACKWARD"); // "wg4": the 4-wave workgroup kernel
   if (!(bw && std::string(bw) == "wg4")) {
     s->wave_kernel = gar::gar_backward_wave<NX, NU>;
-    s->wave_lds_doubles = gar::WaveCfg<NX, NU>::total;
+    // the initial stage is fused into the sweep when its packed kkt0 fits beside V in a
+    // quarter of the CU's LDS (four waves per CU)
+    const int with_init = gar::WaveCfg<NX, NU>::total_with_init(s->nc0);
+    s->wave_fused_init = (size_t)with_init * sizeof(double) <= 40 * 1024 && s->nth0 == 0;
+    s->wave_lds_doubles = s->wave_fused_init ? with_init : gar::WaveCfg<NX, NU>::total;
     s->waves_per_block = 1; // one 64-thread workgroup per problem (constant LDS base)
     s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
   }
@@ -254,6 +259,7 @@ void select_kernel(gar_hip_solver *s) {
   s->mfma_kernel = nullptr;
   s->mfma_fwd_kernel = nullptr;
   s->wave_kernel = nullptr;
+  s->wave_fused_init = false;
   s->kernel_name = "generic";
   const char *force = std::getenv("GAR_HIP_FORCE_GENERIC");
   if (force && force[0] == '1')
@@ -360,6 +366,12 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.fac_offN = s->meta[N].fac_off;
     M.horizon = N;
     M.trace = s->d_trace;
+    const bool fused = s->wave_kernel && s->wave_fused_init;
+    M.init = fused ? s->d_init : nullptr;
+    M.init_stride = s->init_doubles;
+    M.G0_off = s->G0_off;
+    M.g0_off = s->g0_off;
+    M.nc0 = s->nc0;
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->wave_kernel) {
@@ -374,7 +386,9 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     HIP_TRY(hipGetLastError());
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-    if (s->n0 <= 128) { // one wave per problem (wave-scope Bunch-Kaufman handles n <= 128)
+    if (fused) {
+      // nothing to launch: gar_backward_wave already produced kkt0.ff
+    } else if (s->n0 <= 128) { // one wave per problem (wave-scope Bunch-Kaufman handles n <= 128)
       hipLaunchKernelGGL(gar::gar_initial_wave, dim3((unsigned)s->batch), dim3(64),
                          (size_t)gar::gar_initial_wave_lds_doubles(s->n0, s->nth0) * sizeof(double),
                          s->stream, P);

@@ -36,6 +36,11 @@ struct MfmaParams {
   long long fac_rec, fac_offN;        // factor record of stage t < N at t*fac_rec
   int horizon;
   long long *trace; // debug: per-wave cycle stamps of one stage of problem 0 (or null)
+  // initial stage fused into the one-wave-per-problem sweep (gar_wave.hpp); init == null: the
+  // host launches the separate initial-stage kernel instead
+  double *init;
+  long long init_stride, G0_off, g0_off;
+  int nc0;
 };
 
 template <int NX, int NU> struct MfmaCfg {

@@ -59,7 +59,17 @@ template <int NX, int NU> struct WaveCfg {
   static constexpr int oLc = oLr;                 // (the transposed solve reads L strided)
   static constexpr int oDi = oLr + NU * NU;       // -1/d_k
   static constexpr int oBk = (oDi + NU + 1) & ~1; // Bunch-Kaufman fallback: sub(16) | piv, ctrl
-  static constexpr int total = (oBk + 32 + 1) & ~1;
+  static constexpr int oDump = (oBk + 32 + 1) & ~1; // 2 doubles: target of masked-out LDS writes
+  static constexpr int total = oDump + 2;
+  // fused initial stage (after the sweep): the packed lower triangle of kkt0 = [Vxx0 G0^T; G0 0]
+  // and its right-hand side overlay everything but V
+  static constexpr int oK0 = oG;
+  __host__ __device__ static constexpr int k0_doubles(int n0) {
+    return n0 * (n0 + 1) / 2 + 2 * n0 + (n0 + 24) / 2 + 4; // matrix | rhs | sub | piv, ctrl
+  }
+  __host__ __device__ static constexpr int total_with_init(int nc0) {
+    return (oK0 + k0_doubles(NX + nc0)) > total ? (oK0 + k0_doubles(NX + nc0)) : total;
+  }
 };
 
 // base + cst (doubles, compile-time: goes to the scalar base / the instruction's immediate) +
@@ -182,26 +192,28 @@ __device__ __forceinline__ void wave_load_b(const double *rec, const WaveLane<NX
 
 // x <- -(L D L^T)^{-1} x, lane = right-hand-side column; L and -1/d are read from LDS with
 // wave-uniform addresses (LDS port, broadcast) instead of v_readlane pairs (VALU port)
-// A zero-instruction scheduling fence: makes `p` (an LDS pointer) depend on `after`, so loads
-// through `p` cannot be hoisted above the instruction that produces `after`.  Without it the
-// scheduler issues ALL the reads of an unrolled phase first and spills what they return.
-__device__ __forceinline__ const double *lds_after(const double *p, double after) {
+// A zero-instruction scheduling fence: returns 0 in a register the compiler believes to depend
+// on `after`, so loads at `base + fence0(after)` cannot be hoisted above the instruction that
+// produces `after` -- without it the scheduler issues ALL the reads of an unrolled phase first.
+// (An offset, not the pointer, goes through the asm: the pointer keeps its LDS address space.)
+__device__ __forceinline__ int fence0(double after) {
+  int z = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(p) : "v"(after));
+  asm volatile("" : "+v"(z) : "v"(after));
 #else
   (void)after;
 #endif
-  return p;
+  return z;
 }
 
 template <int NU>
 __device__ __forceinline__ void ldl_solve_lds(const double *Lr, const double *ndi, double (&x)[NU]) {
   // column-oriented substitutions: the FMAs of one column are independent of each other;
   // L is read one column (forward) / one row (transposed) at a time with wave-uniform
-  // addresses (LDS port, broadcast), one column ahead of the FMAs that consume it
+  // addresses (LDS port, broadcast)
 #pragma unroll
   for (int j = 0; j < NU - 1; ++j) {
-    const double *Lp = lds_after(Lr, x[j > 0 ? j - 1 : 0]);
+    const double *Lp = Lr + fence0(x[j > 2 ? j - 3 : 0]);
     double lc[NU];
 #pragma unroll
     for (int i = j + 1; i < NU; ++i)
@@ -211,20 +223,20 @@ __device__ __forceinline__ void ldl_solve_lds(const double *Lr, const double *nd
       x[i] = __builtin_fma(-lc[i], x[j], x[i]);
   }
   {
-    const double *dp = lds_after(ndi, x[NU - 2]);
+    const double *dp = ndi + fence0(x[NU - 2]);
 #pragma unroll
     for (int i = 0; i < NU; ++i)
       x[i] *= dp[i];
   }
 #pragma unroll
   for (int i = NU - 1; i >= 1; --i) {
-    const double *Lp = lds_after(Lr, x[i < NU - 1 ? i + 1 : i]);
+    const double *Lp = Lr + fence0(x[i < NU - 3 ? i + 3 : NU - 1]);
     double lr[NU];
 #pragma unroll
     for (int j = 0; j < i; ++j)
       lr[j] = Lp[i * NU + j];
 #pragma unroll
-    for (int j = 0; j < i; ++j)
+    for (int j = i - 1; j >= 0; --j) // x[i-1], the next pivot, first
       x[j] = __builtin_fma(-lr[j], x[i], x[j]);
   }
 }
@@ -470,7 +482,9 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
 #pragma unroll
       for (int k = 0; k < NU; ++k)
         x[k] = G[k * PG + col];
+      GAR_WMARK(11)
       ldl_solve_lds<NU>(Lr, ndi, x); // [kff | K] = -Rhat^{-1} [rhat | Shat^T]  (:248-262)
+      GAR_WMARK(12)
       if (lane <= NX) {
 #pragma unroll
         for (int k = 0; k < NU; ++k)
@@ -597,6 +611,8 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         else
           S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], S.Hc[ti][tj], 0, 0, 0);
       }
+  // branch-free: a lane whose element is outside the lower triangle writes to a dump slot
+  // (its address is a loop-invariant select), so the whole phase is one scheduling region
 #pragma unroll
   for (int tj = 0; tj < TX; ++tj)
 #pragma unroll
@@ -605,10 +621,14 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * ti + lk + 4 * r, c = 16 * tj + li;
         if (16 * ti + 4 * r < NX) { // compile-time
-          if (i < NX && c < NX && i >= c) {
-            const double v = ti >= shLo ? accS[ti][tj][r] : S.Hc[ti][tj][r];
+          const bool ok = (i < NX && c < NX && i >= c);
+          const double v = ti >= shLo ? accS[ti][tj][r] : S.Hc[ti][tj][r];
+          if (ti > tj && 16 * ti + 4 * r + 3 < NX && 16 * tj + 15 < NX) { // compile-time: all lanes valid
             V[i * PK + c] = v;
             V[c * PK + i] = v;
+          } else {
+            V[ok ? i * PK + c : C::oDump] = v;
+            V[ok ? c * PK + i : C::oDump + 1] = v;
           }
         }
       }
@@ -618,12 +638,20 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   GAR_WMARK(9)
   // ---- Vxx -> HBM (column-major, symmetric), 16 B per lane -----------------------
   static_assert(PK == NX, "V is stored exactly as the Vxx record");
+  {
+    constexpr int NCH = (NX * NX / 2 + 63) / 64;
+    double2_t vbuf[NCH];
 #pragma unroll
-  for (int e0 = 0; e0 < NX * NX / 2; e0 += 64) {
-    const int e = e0 + lane;
-    if (e0 + 64 <= NX * NX / 2 || e < NX * NX / 2) {
-      const double2_t v = *reinterpret_cast<const double2_t *>(&V[2 * e]);
-      *reinterpret_cast<double2_t *>(&out[M::fVxx + 2 * e]) = v;
+    for (int q = 0; q < NCH; ++q) { // all the LDS reads first (one latency), then the stores
+      const int e = 64 * q + lane;
+      const int ec = (64 * q + 63 < NX * NX / 2) ? e : (e < NX * NX / 2 ? e : NX * NX / 2 - 1);
+      vbuf[q] = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int e = 64 * q + lane;
+      if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
+        *reinterpret_cast<double2_t *>(&out[M::fVxx + 2 * e]) = vbuf[q];
     }
   }
   GAR_WMARK(10)
@@ -676,6 +704,41 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   int failed = 0;
   for (int t = N - 1; t >= 0; --t)
     wave_stage<NX, NU>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+  // ---- initial stage (proximal-riccati.hxx:42-60), fused: kkt0 = [Vxx0 G0^T; G0 0] is
+  // Bunch-Kaufman-factorised by this wave right away (packed lower triangle in LDS, read from
+  // the V and vx this wave still holds) and solved for kkt0.ff = -kkt0^{-1} [vx0; g0]
+  if (P.init != nullptr) {
+    const int nc0 = P.nc0, n0 = NX + nc0;
+    const double vx0 = vn[lane < NX ? lane : NX - 1];
+    wave_sync();
+    double *k0 = sm + C::oK0, *rhs = k0 + n0 * (n0 + 1) / 2, *sub = rhs + n0;
+    int *piv0 = (int *)(sub + n0);
+    const double *G0 = prob + P.G0_off, *g0 = prob + P.g0_off;
+    for (int j = 0; j < n0; ++j) // lower triangle, by columns
+      for (int i = j + lane; i < n0; i += 64) {
+        double v = 0.0;
+        if (j < NX)
+          v = (i < NX) ? V[i * PK + j] : G0[j * nc0 + (i - NX)];
+        k0[bk_idx<GAR_PACKED_LOWER>(i, j, n0)] = v;
+      }
+    if (lane < NX)
+      rhs[lane] = -vx0;
+    for (int e = lane; e < nc0; e += 64)
+      rhs[NX + e] = -g0[e];
+    const WG w1 = wave_self();
+    wave_sync();
+    if (tracing)
+      P.trace[13] = (long long)clock64();
+    failed |= 2 * wg_bk_factor<GAR_PACKED_LOWER>(w1, n0, k0, n0, sub, piv0, piv0 + n0);
+    if (tracing)
+      P.trace[14] = (long long)clock64();
+    wg_bk_solve<GAR_PACKED_LOWER>(w1, n0, k0, n0, sub, piv0, rhs, 1, 0, 1);
+    if (tracing)
+      P.trace[15] = (long long)clock64();
+    double *io = P.init + (long long)b * P.init_stride;
+    for (int e = lane; e < n0; e += 64)
+      io[e] = rhs[e];
+  }
   if (failed && lane == 0)
     atomicOr(&P.status[b], failed);
 }

@@ -15,7 +15,7 @@ out = (C.c_longlong * 64)()
 s._L.gar_hip_debug_trace(s.handle, 1, None)
 s.backward(1e-14)
 s._L.gar_hip_debug_trace(s.handle, 0, out)
-t = np.array(list(out))[:11]
+tt = np.array(list(out)); t = tt[:11]; print("init: factor", tt[14]-tt[13], "solve", tt[15]-tt[14]); print("solve sub-marks: G-read", tt[11]-tt[5], "subst", tt[12]-tt[11], "write+sync", tt[6]-tt[12])
 names = ["start", "vplus", "qhat", "S1S2", "export", "factor", "solve", "Kb+vec", "Aff", "Vxx", "store"]
 print(f"{s.kernel_name} batch {B}: cycles per phase (s_memtime ticks), total {t[10]-t[0]}")
 print(" ".join(f"{names[i]}={t[i]-t[i-1]}" for i in range(1, 11)))
