@@ -619,6 +619,66 @@ struct MfmaFwdParams {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// one stage's gains in registers: [K; Aff] row r (fbT2: 16 B per lane), Vxx' row iv, ff, vx'
+template <int NX> struct FwdStage {
+  double2_t g[NX / 2];
+  double vrow[NX];
+  double ff, vxn;
+};
+
+template <int NX, int NU>
+__device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *fac, int t, int r,
+                                         int iv, FwdStage<NX> &S) {
+  using C = MfmaCfg<NX, NU>;
+  constexpr int NW = C::NW;
+  const int N = P.horizon;
+  const int tc = t < N ? t : N - 1; // past the end: harmless re-read of the last stage
+  const double *rec = fac + (long long)tc * P.fac_rec;
+  const double *recn = (tc + 1 < N) ? rec + P.fac_rec : fac + P.fac_offN;
+  const int oVn = (tc + 1 < N) ? C::fVxx : C::tVxx, ovn = (tc + 1 < N) ? C::fvx : C::tvx;
+#pragma unroll
+  for (int m = 0; m < NX / 2; ++m)
+    S.g[m] = *reinterpret_cast<const double2_t *>(rec + C::fFB + m * 2 * NW + 2 * r);
+#pragma unroll
+  for (int j = 0; j < NX; ++j)
+    S.vrow[j] = recn[oVn + j * NX + iv]; // Vxx' symmetric: column j, row iv
+  S.ff = rec[C::fFF + r];
+  S.vxn = recn[ovn + iv];
+}
+
+template <int NX, int NU>
+__device__ __forceinline__ double fwd_step(const MfmaFwdParams &P, double *sol, int t, int lane,
+                                           double xs, const FwdStage<NX> &S) {
+  using C = MfmaCfg<NX, NU>;
+  constexpr int NW = C::NW;
+  // u = kff + K x ; x' = yff + Aff x   (:334-336, :360-361); two accumulators
+  double acc = S.ff, acc1 = 0.0;
+#pragma unroll
+  for (int m = 0; m < NX / 2; ++m) {
+    acc = __builtin_fma(S.g[m].x, lane_bcast(xs, NU + 2 * m), acc);
+    acc1 = __builtin_fma(S.g[m].y, lane_bcast(xs, NU + 2 * m + 1), acc1);
+  }
+  acc += acc1;
+  if (lane < NU)
+    sol[P.sol_u + t * NU + lane] = acc;
+  else if (lane < NW)
+    sol[(t + 1) * NX + (lane - NU)] = acc;
+  // lbd' = vx' + Vxx' x'  (:369-371); x'_j sits in lane NU + j
+  double lam = S.vxn, lam1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < NX; j += 2) {
+    lam = __builtin_fma(S.vrow[j], lane_bcast(acc, NU + j), lam);
+    lam1 = __builtin_fma(S.vrow[j + 1], lane_bcast(acc, NU + j + 1), lam1);
+  }
+  lam += lam1;
+  if (lane < NX)
+    sol[P.sol_l + P.nc0 + t * NX + lane] = lam;
+  return acc;
+}
+
+// The gains of stage t+1 are requested BEFORE stage t is evaluated (two register sets, the loop
+// body instantiated twice): with one wave per SIMD -- all a 1 024-problem batch gives a 1 024-SIMD
+// chip -- nothing else would cover the HBM latency of the next 25 KB.
 template <int NX, int NU>
 __global__ void __launch_bounds__(64) gar_forward_mfma(MfmaFwdParams P) {
   using C = MfmaCfg<NX, NU>;
@@ -633,44 +693,22 @@ __global__ void __launch_bounds__(64) gar_forward_mfma(MfmaFwdParams P) {
   const int iv = lane < NX ? lane : NX - 1; // row of Vxx'
   // the state lives in lanes NU .. NW-1 (where x' = yff + Aff x is produced)
   const int ix = (lane >= NU && lane < NW) ? lane - NU : 0;
+  FwdStage<NX> SA, SB;
+  fwd_load<NX, NU>(P, fac, 0, r, iv, SA);
   double xs = io[ix]; // x0 from the initial-stage solve (kkt0.ff)
   if (lane >= NU && lane < NW)
     sol[ix] = xs;
   for (int e = lane; e < P.nc0; e += 64)
     sol[P.sol_l + e] = io[NX + e]; // lbd0
-  for (int t = 0; t < N; ++t) {
-    const double *rec = fac + (long long)t * P.fac_rec;
-    const double *recn = (t + 1 < N) ? rec + P.fac_rec : fac + P.fac_offN;
-    const int oVn = (t + 1 < N) ? C::fVxx : C::tVxx, ovn = (t + 1 < N) ? C::fvx : C::tvx;
-    // all loads of the stage first: [K; Aff] rows (16 B per lane), Vxx' rows, ff, vx'
-    double2_t g[NX / 2];
-#pragma unroll
-    for (int m = 0; m < NX / 2; ++m)
-      g[m] = *reinterpret_cast<const double2_t *>(rec + C::fFB + m * 2 * NW + 2 * r);
-    double vrow[NX];
-#pragma unroll
-    for (int j = 0; j < NX; ++j)
-      vrow[j] = recn[oVn + j * NX + iv]; // Vxx' symmetric: column j, row iv
-    double acc = rec[C::fFF + r];
-    double lam = recn[ovn + iv];
-    // u = kff + K x ; x' = yff + Aff x   (:334-336, :360-361)
-#pragma unroll
-    for (int m = 0; m < NX / 2; ++m) {
-      acc = __builtin_fma(g[m].x, lane_bcast(xs, NU + 2 * m), acc);
-      acc = __builtin_fma(g[m].y, lane_bcast(xs, NU + 2 * m + 1), acc);
-    }
-    if (lane < NU)
-      sol[P.sol_u + t * NU + lane] = acc;
-    else if (lane < NW)
-      sol[(t + 1) * NX + (lane - NU)] = acc;
-    xs = acc;
-    // lbd' = vx' + Vxx' x'  (:369-371); x'_j sits in lane NU + j
-#pragma unroll
-    for (int j = 0; j < NX; ++j)
-      lam = __builtin_fma(vrow[j], lane_bcast(xs, NU + j), lam);
-    if (lane < NX)
-      sol[P.sol_l + P.nc0 + t * NX + lane] = lam;
+  int t = 0;
+  for (; t + 1 < N; t += 2) {
+    fwd_load<NX, NU>(P, fac, t + 1, r, iv, SB);
+    xs = fwd_step<NX, NU>(P, sol, t, lane, xs, SA);
+    fwd_load<NX, NU>(P, fac, t + 2, r, iv, SA);
+    xs = fwd_step<NX, NU>(P, sol, t + 1, lane, xs, SB);
   }
+  if (t < N)
+    xs = fwd_step<NX, NU>(P, sol, t, lane, xs, SA);
 }
 
 } // namespace gar

@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU (59 GB of the 288 GB at the default)")
     ap.add_argument("--horizon", type=int, default=256)
     ap.add_argument("--nx", type=int, default=36)
     ap.add_argument("--nu", type=int, default=12)
