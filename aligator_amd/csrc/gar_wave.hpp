@@ -249,10 +249,10 @@ __device__ __forceinline__ void ldl_solve_lds(const double *Lr, const double *nd
 // product for product.  Writes L row-major / column-major and -1/d to LDS; returns 0 if the
 // test held at every column (and no pivot was zero).
 template <int NU>
-__device__ __forceinline__ int wave_ldl_fast(const double *M, int lane, double *Lr, double *ndi) {
+__device__ __forceinline__ int wave_ldl_fast(const double *M, int lane, double (&a)[NU],
+                                             double (&nd)[NU]) {
   const double alpha = (1.0 + 4.123105625617661) / 8.0;
   const int row = lane < NU ? lane : NU - 1;
-  double a[NU];
 #pragma unroll
   for (int j = 0; j < NU; ++j)
     a[j] = M[j * NU + row]; // row i of Rhat; entries above the diagonal are stale LDS, never used
@@ -271,16 +271,31 @@ __device__ __forceinline__ int wave_ldl_fast(const double *M, int lane, double *
     for (int j = k + 1; j < NU; ++j)
       a[j] = __builtin_fma(-lane_bcast(lik, j), a[k], a[j]); // a(i,j) -= d11xj * a(i,k)
     a[k] = lik;
-    if (lane == 0)
-      ndi[k] = -d;
-  }
-  if (lane < NU) {
-#pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      Lr[lane * NU + j] = a[j];
-    }
+    nd[k] = -d; // wave-uniform
   }
   return bad != 0ull;
+}
+
+// x <- -(L D L^T)^{-1} x, lane = right-hand-side column; L(i,j) is broadcast from lane i's
+// register j with v_readlane (no LDS round trip on the way from the factorisation to the solve)
+template <int NU>
+__device__ __forceinline__ void ldl_solve_regs_bcast(const double (&a)[NU], const double (&nd)[NU],
+                                                     double (&x)[NU]) {
+#pragma unroll
+  for (int j = 0; j < NU - 1; ++j) {
+#pragma unroll
+    for (int i = j + 1; i < NU; ++i)
+      x[i] = __builtin_fma(-lane_bcast(a[j], i), x[j], x[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NU; ++i)
+    x[i] *= nd[i];
+#pragma unroll
+  for (int i = NU - 1; i >= 1; --i) {
+#pragma unroll
+    for (int j = i - 1; j >= 0; --j)
+      x[j] = __builtin_fma(-lane_bcast(a[j], i), x[i], x[j]);
+  }
 }
 
 // Rare path, kept out of line so that its registers do not weigh on the sweep: the first
@@ -358,6 +373,8 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   double *out = fac + (long long)t * P.fac_rec;
   const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
   const double *recn = rec - (t > 0 ? P.in_rec : 0); // knot t-1 (t = 0: harmless re-read)
+// phase boundaries are pinned (sched_barrier) so that the per-phase cycle stamps of
+// scripts/trace_wave.py mean what they say; measured: un-pinning them changes nothing
 #define GAR_WMARK(id)                                                          \
   __builtin_amdgcn_sched_barrier(0);                                           \
   if (tracing && t == (P.horizon >> 1))                                        \
@@ -366,18 +383,17 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   GAR_WMARK(0)
   // ---- vplus = vx' + V' f (:217-218), lane i < NX ------------------------------
   const int ir = lane < NX ? lane : NX - 1;
-  if (lane < NX)
-    fv[lane] = S.fi;
-  wave_sync();
   {
+    // f[k] is broadcast from lane k's register (v_readlane: measured 2.5x cheaper here than
+    // wave-uniform LDS reads), V's row from LDS
     double s0 = 0.0, s1 = 0.0;
     double s2 = 0.0, s3 = 0.0;
 #pragma unroll
     for (int k = 0; k < NX; k += 4) {
-      s0 = __builtin_fma(V[ir * PK + k], fv[k], s0);
-      s1 = __builtin_fma(V[ir * PK + k + 1], fv[k + 1], s1);
-      s2 = __builtin_fma(V[ir * PK + k + 2], fv[k + 2], s2);
-      s3 = __builtin_fma(V[ir * PK + k + 3], fv[k + 3], s3);
+      s0 = __builtin_fma(V[ir * PK + k], lane_bcast(S.fi, k), s0);
+      s1 = __builtin_fma(V[ir * PK + k + 1], lane_bcast(S.fi, k + 1), s1);
+      s2 = __builtin_fma(V[ir * PK + k + 2], lane_bcast(S.fi, k + 2), s2);
+      s3 = __builtin_fma(V[ir * PK + k + 3], lane_bcast(S.fi, k + 3), s3);
     }
     s0 += s2;
     s1 += s3;
@@ -473,8 +489,8 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   GAR_WMARK(4)
   // ---- factor Rhat (lane = row) under the Bunch-Kaufman rule; solve [kff | K] ---
   {
-    const int verdict = wave_ldl_fast<NU>(Mm, lane, Lr, ndi);
-    wave_sync();
+    double a_row[NU], nd[NU];
+    const int verdict = wave_ldl_fast<NU>(Mm, lane, a_row, nd);
     GAR_WMARK(5)
     if (verdict == 0) {
       const int col = lane <= NX ? lane : NX; // G column: 0 = kff, 1 + j = K(:, j)
@@ -483,7 +499,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       for (int k = 0; k < NU; ++k)
         x[k] = G[k * PG + col];
       GAR_WMARK(11)
-      ldl_solve_lds<NU>(Lr, ndi, x); // [kff | K] = -Rhat^{-1} [rhat | Shat^T]  (:248-262)
+      ldl_solve_regs_bcast<NU>(a_row, nd, x); // [kff | K] = -Rhat^{-1} [rhat | Shat^T]  (:248-262)
       GAR_WMARK(12)
       if (lane <= NX) {
 #pragma unroll
