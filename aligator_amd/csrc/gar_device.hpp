@@ -638,12 +638,127 @@ __device__ inline void wg_bk_solve_few(const WG &w, int n, const double *a, int 
 #undef GX
 }
 
+// Many right-hand sides, whole workgroup: threads are laid out (column c, row group g); at
+// substitution step j every thread updates its rows i > j of its column -- all (n-j-1) x ncols
+// elements move per barrier, instead of one thread grinding through a whole column alone.
+// Same operations, same order per element, as the one-thread-per-column path.
+template <int MODE>
+__device__ inline void wg_bk_solve_block(const WG &w, int n, const double *a, int lda,
+                                         const double *subdiag, const int *piv, double *x,
+                                         int xrs, int xcs, int ncols) {
+#define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
+#define GXC(i, c) x[(c) * xcs + (i) * xrs]
+  const int ngrp = w.nthr / ncols > 0 ? w.nthr / ncols : 1; // row groups per column
+  const int c0 = w.tid % ncols, g0 = w.tid / ncols;
+  const bool active = g0 < ngrp && w.tid < ngrp * ncols;
+  wg_bar(w);
+  for (int c = w.tid; c < ncols; c += w.nthr) { // forward interchanges (:458-468)
+    int k = 0;
+    while (k < n) {
+      int p = piv[k];
+      int row = k;
+      if (p < 0) {
+        p = -1 - p;
+        row = k + 1;
+        k += 2;
+      } else {
+        k += 1;
+      }
+      if (row != p) {
+        const double t = GXC(row, c);
+        GXC(row, c) = GXC(p, c);
+        GXC(p, c) = t;
+      }
+    }
+  }
+  for (int j = 0; j + 1 < n; ++j) { // unit-lower solve (:472)
+    wg_bar(w);
+    if (active) {
+      const double xj = GXC(j, c0);
+      for (int i = j + 1 + g0; i < n; i += ngrp)
+        GXC(i, c0) -= GA(i, j) * xj;
+    }
+  }
+  wg_bar(w);
+  for (int c = w.tid; c < ncols; c += w.nthr) { // inverse-D multiply (:474-502)
+    int k = 0;
+    while (k < n) {
+      if (piv[k] < 0) {
+        const double akp1k = subdiag[k], ak = GA(k, k), akp1 = GA(k + 1, k + 1);
+        const double xk = GXC(k, c), xkp1 = GXC(k + 1, c);
+        GXC(k, c) = xk * ak + xkp1 * akp1k;
+        GXC(k + 1, c) = xkp1 * akp1 + xk * akp1k;
+        k += 2;
+      } else {
+        GXC(k, c) *= GA(k, k);
+        k += 1;
+      }
+    }
+  }
+  for (int i = n - 1; i >= 1; --i) { // unit-upper (L^T) solve (:504)
+    wg_bar(w);
+    if (active) {
+      const double xi = GXC(i, c0);
+      for (int j = g0; j < i; j += ngrp)
+        GXC(j, c0) -= GA(i, j) * xi;
+    }
+  }
+  wg_bar(w);
+  for (int c = w.tid; c < ncols; c += w.nthr) { // reverse interchanges (:506-517)
+    int k = n;
+    while (k > 0) {
+      k -= 1;
+      int p = piv[k];
+      if (p < 0) {
+        p = -1 - p;
+        if (k != p) {
+          const double t = GXC(k, c);
+          GXC(k, c) = GXC(p, c);
+          GXC(p, c) = t;
+        }
+        k -= 1;
+      } else if (k != p) {
+        const double t = GXC(k, c);
+        GXC(k, c) = GXC(p, c);
+        GXC(p, c) = t;
+      }
+    }
+  }
+  wg_bar(w);
+#undef GA
+#undef GXC
+}
+
 template <int MODE = GAR_COLMAJOR>
 __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
                                    const double *subdiag, const int *piv, double *x, int xrs,
                                    int xcs, int ncols) {
   if (ncols < 16 && n >= 16) {
+    if (!w.wave_scope && n <= 128) {
+      // a workgroup with few columns: if there are no 2x2 pivots, wave 0 alone runs the
+      // register-resident substitution (no workgroup barrier per step); every wave
+      // evaluates the same ballot, so the choice is uniform
+      const bool neg = (w.lane < n && piv[w.lane] < 0) || (w.lane + 64 < n && piv[w.lane + 64] < 0);
+      if (__ballot(neg) == 0ull) {
+        wg_bar(w);
+        if (w.wave == 0) {
+          WG w0 = w;
+          w0.tid = w.lane;
+          w0.nthr = 64;
+          w0.nwaves = 1;
+          w0.wave_scope = 1;
+          for (int c = 0; c < ncols; ++c)
+            wave_bk_solve_regs<MODE>(w0, n, a, lda, piv, x + c * xcs, xrs);
+        }
+        wg_bar(w);
+        return;
+      }
+    }
     wg_bk_solve_few<MODE>(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
+    return;
+  }
+  if (!w.wave_scope && ncols >= 16 && ncols <= w.nthr) {
+    wg_bk_solve_block<MODE>(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
     return;
   }
 #define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]

@@ -25,9 +25,13 @@
 //     of H's D registers are the A operand of Vxx = Qhat + Shat K;
 //   * V' lives in LDS (symmetric, k-fast) as the A operand of P = V'F;
 //   * the next knot is loaded into the SAME registers as soon as the current one has
-//     been consumed (F after Aff, the Hessian tiles after Vxx), so the working set
-//     stays below 256 registers and two waves fit a SIMD: the partner wave covers
-//     what is left of the HBM / LDS latencies.
+//     been consumed (F after Aff, the Hessian tiles after Vxx), most of a stage ahead of
+//     its first use;
+//   * wave-uniform operands of the VALU phases (the pivot column of the LDL^T, L in the
+//     triangular solves, f in vplus) are broadcast with v_readlane from the register that
+//     already holds them: measured 2.5x cheaper than wave-uniform LDS reads;
+//   * the initial-stage KKT solve (proximal-riccati.hxx:42-60) runs at the end of the same
+//     wave (packed lower triangle of kkt0 in the LDS the sweep no longer needs).
 // Measured on the (32,12) shape, whose working set fits 256 registers: a second wave per SIMD
 // buys ~5 % (MFMA and VALU of the two waves exclude each other), so the kernel is built for
 // ONE wave per SIMD (all 512 registers), and hides its latencies with instruction-level
@@ -53,8 +57,7 @@ template <int NX, int NU> struct WaveCfg {
   static constexpr int oG2 = oG;                  // [kff | K]: the solve runs in place
   static constexpr int oM = oG + NU * PG + 16;    // Rhat, column-major lower
   static constexpr int oVn = oM + NU * NU;        // vx' (NX)
-  static constexpr int oFv = oVn + NX;            // f (NX)
-  static constexpr int oVp = oFv + NX;            // vplus (NX)
+  static constexpr int oVp = oVn + NX;            // vplus (NX)
   static constexpr int oLr = (oVp + NX + 1) & ~1; // L of Rhat = L D L^T, row-major (forward solve)
   static constexpr int oLc = oLr;                 // (the transposed solve reads L strided)
   static constexpr int oDi = oLr + NU * NU;       // -1/d_k
@@ -368,7 +371,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
                 KU = C::KU;
   const int li = lane & 15, lk = lane >> 4;
   double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM;
-  double *vn = sm + C::oVn, *fv = sm + C::oFv, *vp = sm + C::oVp;
+  double *vn = sm + C::oVn, *vp = sm + C::oVp;
   double *Lr = sm + C::oLr, *ndi = sm + C::oDi;
   double *out = fac + (long long)t * P.fac_rec;
   const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;

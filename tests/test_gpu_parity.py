@@ -120,3 +120,42 @@ def test_full_size_batch_properties():
             assert pc.maxdiff(A, C) <= 1e-9 * pc.scale_of(ref)
     assert s.num_failed() == 0
     del torch
+
+
+def test_config4_shape_legs_on_one_gpu():
+    """BASELINE.json configs[3] shape (N=2048, nx=36, nu=12) with the 8-way leg partition
+    the 8-GPU run uses, all legs on this GPU: same condensed system, same forward."""
+    prob = synth.generate_lq_problem(31, np.zeros(36), 2048, 36, 12, mode="W")
+    pc.check_parallel(prob, 1e-9, 8, 1e-7)
+
+
+def test_sharded_solver_single_rank_rccl():
+    """aligator_amd.sharded on the real device path: torch views of the library's device
+    buffers, all_gather_into_tensor over RCCL (world_size 1 is all a 1-GPU box offers; the
+    2-rank flow is covered on CPU by tests/test_sharded_gloo.py)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from aligator_amd.sharded import ShardedRiccatiSolver
+    from aligator_amd.gar import lqrComputeKktError
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+                            device_id=torch.device("cuda", 0))
+    try:
+        prob = synth.generate_lq_problem(32, np.zeros(12), 255, 12, 6, mode="W")
+        _, _, ref = pc.oracle_serial(prob, 1e-9)
+        for legs in (2, 8):
+            s = ShardedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, legs, batch=1)
+            s.impl.upload([prob])
+            s.backward(1e-9)
+            s.forward()
+            sol = s.gather_solution(0)
+            sc = pc.scale_of(ref)
+            for A, B in zip(sol, ref):
+                assert pc.maxdiff(A, B) <= 1e-7 * sc
+            assert max(lqrComputeKktError(prob, *sol, mueq=1e-9)) <= 1e-7 * sc
+    finally:
+        dist.destroy_process_group()
