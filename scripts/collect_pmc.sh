@@ -12,3 +12,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc/bench_$C -o bench -- python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu > $R/gpurun_out/pmc/bench_$C.log 2>&1
 done
 cd $R && python scripts/pmc_reduce.py gpurun_out/pmc $B | tee gpurun_out/pmc_traffic.json
+# the raw per-dispatch CSVs are large (gpurun_out is capped at 64 MiB): keep the reductions only
+find $R/gpurun_out/pmc $R/gpurun_out/sq -name "*.csv" -size +200k -delete 2>/dev/null

@@ -24,3 +24,5 @@ for d in ("gpurun_out/sq/p1", "gpurun_out/sq/p2"):
         for n, v in sorted(c.items()):
             print(f"   {n:34s} {sum(v)/len(v):16.0f}  (n={len(v)})")
 PY
+# the raw per-dispatch CSVs are large (gpurun_out is capped at 64 MiB): keep the reductions only
+find $R/gpurun_out/pmc $R/gpurun_out/sq -name "*.csv" -size +200k -delete 2>/dev/null
