@@ -45,6 +45,17 @@ template <int NX, int NU> struct WaveCfg {
   using M = MfmaCfg<NX, NU>;
   static constexpr int NW = NX + NU, TX = M::TX, TW = M::TW, KS = M::KS, KU = M::KU;
   static constexpr int KSF = KS / 4, KST = KS % 4; // full double4 groups of k-steps, tail steps
+  // NX = 16 (TX-1) + 4: the last row tile of P, Aff and Vxx holds FOUR valid rows.  Those tiles
+  // run on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks, 16 cycles) instead of
+  // wasting 3/4 of a 64-cycle 16x16x4: with A_b[i][k] in lane 16k+4b+i, B_b[k][j] in lane
+  // 16k+4b+j and D_b[i][j] in lane 16i+4b+j (measured, scripts/ubench/mfma4x4_probe.cpp) the B
+  // operand and the result have exactly the 16x16x4 B-operand layout (column on lane&15, k or
+  // row on lane>>4), so they drop into the same registers.
+#ifdef GAR_NO_REM4
+  static constexpr bool REM4 = false;
+#else
+  static constexpr bool REM4 = (NX % 16 == 4) && (KST == 1);
+#endif
   // V is kept unpadded (pitch NX): it then IS the column-major Vxx record, so the copy to HBM is
   // linear; the 2-way bank conflicts this costs the operand reads are invisible beside 64-cycle MFMAs
   static constexpr int PK = NX, PG = M::PG;
@@ -109,6 +120,7 @@ template <int NX, int NU> struct WaveLane {
   unsigned hcx0, hcxX[C::TW];    // rows < NX: Q[lk][li] ; column tiles reaching past NX
   unsigned hcu0, hcuX[C::TW][C::KU]; // rows NX+4s'+lk: S^T[lk][li] ; tiles reaching past NX
   unsigned bop0, bopX;           // B[li][lk] ; overhanging last row tile
+  unsigned bop4;                 // B[NX-4+(lane&3)][lane>>4]: A operand of the 4x4x4 blocks
   unsigned fi, qri;
   unsigned fbl;                  // fbT2 lane part: (li>>1)*2NW + 2lk + (li&1)
   __host__ __device__ static constexpr bool fo_in(int t) { return 16 * t + 15 < C::NW; }
@@ -144,6 +156,7 @@ __device__ __forceinline__ void wave_lane_init(WaveLane<NX, NU> &L, int lane) {
     const int ti = C::TX - 1, row = (16 * ti + li) < NX ? (16 * ti + li) : NX - 1;
     L.bopX = 8u * (unsigned)(M::kB + lk * NX + row);
   }
+  L.bop4 = 8u * (unsigned)(M::kB + (lane >> 4) * NX + NX - 4 + (lane & 3));
   const int ir = lane < NX ? lane : NX - 1, iw = lane < C::NW ? lane : C::NW - 1;
   L.fbl = 8u * (unsigned)((li >> 1) * 2 * C::NW + 2 * lk + (li & 1));
   L.fi = 8u * (unsigned)(M::kf + ir);
@@ -440,9 +453,12 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   }
   GAR_WMARK(2)
   // ---- P = V' F, H = W + F^T P (:216-228), column tile by column tile ----------
+  constexpr int TXF = C::REM4 ? TX - 1 : TX; // row tiles of P on the 16x16x4 instruction
+  const int i4 = lane & 3, k4 = lane >> 4;   // 4x4x4 A operand: row i4 of the block, k = k4
 #pragma unroll
   for (int tj = 0; tj < TW; ++tj) {
     double4_t Pt[TX];
+    double p4 = 0.0; // REM4: P[NX-4+lk][16tj+li], the rows of the last (4-row) tile
 #pragma unroll
     for (int tm = 0; tm < TX; ++tm)
       Pt[tm] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -450,18 +466,21 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
     for (int s = 0; s < KS; ++s) {
       const double bq = S.fo(tj, s);
 #pragma unroll
-      for (int tm = 0; tm < TX; ++tm) {
+      for (int tm = 0; tm < TXF; ++tm) {
         const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
         const double aq = V[ic * PK + 4 * s + lk];
         Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, Pt[tm], 0, 0, 0);
       }
+      if (C::REM4)
+        p4 = __builtin_amdgcn_mfma_f64_4x4x4f64(V[(NX - 4 + i4) * PK + 4 * s + k4], bq, p4, 0, 0, 0);
     }
 #pragma unroll
     for (int ti = tj; ti < TW; ++ti) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-        S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.fo(ti, s), Pt[s >> 2][s & 3],
-                                                           S.Hc[ti][tj], 0, 0, 0);
+      for (int s = 0; s < KS; ++s) {
+        const double pq = (C::REM4 && (s >> 2) == TX - 1) ? p4 : Pt[s >> 2][s & 3];
+        S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.fo(ti, s), pq, S.Hc[ti][tj], 0, 0, 0);
+      }
     }
   }
   GAR_WMARK(3)
@@ -483,12 +502,18 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   wave_sync();
   // B of this knot as the A operand of Aff = A + B K: needed a factorisation from now
   double Bop[TX][KU]; // B[16ti+li][4s'+lk]
+  double Bop4[KU];    // REM4: B[NX-4+i4][4s'+k4], the A operand of the 4x4x4 blocks
 #pragma unroll
   for (int ti = 0; ti < TX; ++ti)
 #pragma unroll
     for (int s = 0; s < KU; ++s)
       Bop[ti][s] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * s * NX + 16 * ti, L.bop0)
                                               : ldg_b(rec, 4 * s * NX, L.bopX);
+  if (C::REM4) {
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      Bop4[s] = ldg_b(rec, 4 * s * NX, L.bop4);
+  }
   GAR_WMARK(4)
   // ---- factor Rhat (lane = row) under the Bunch-Kaufman rule; solve [kff | K] ---
   {
@@ -572,7 +597,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   // one k-step go round all the tiles (independent accumulators, back-to-back issue); the
   // stores follow when every tile is done.
   double4_t accT[TX]; // the tile row made of the tail k-steps (rows 16*KSF ..)
-  if (C::KST > 0) {
+  if (C::KST > 0 && !C::REM4) {
 #pragma unroll
     for (int tj = 0; tj < TX; ++tj)
 #pragma unroll
@@ -587,6 +612,8 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       for (int ti = 0; ti < TX; ++ti) {
         if (ti < C::KSF)
           S.Fo[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], S.Fo[tj][ti], 0, 0, 0);
+        else if (C::REM4) // rows NX-4 .. NX-1: four 4x4x4 blocks, in place on the tail operand
+          S.FoT[tj][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(Bop4[s], Kb[tj][s], S.FoT[tj][0], 0, 0, 0);
         else
           accT[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], accT[tj], 0, 0, 0);
       }
@@ -600,7 +627,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         if (16 * ti + 4 * r < NX) { // compile-time
           if (i < NX && j < NX) // fbT2(NU+i, j), i = 16ti+4r+lk
             stg_b(out, M::fFB + 8 * tj * 2 * NW + 2 * (NU + 16 * ti + 4 * r), L.fbl,
-                  ti < C::KSF ? S.Fo[tj][ti][r] : accT[tj][r]);
+                  ti < C::KSF ? S.Fo[tj][ti][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r]));
         }
       }
   // ---- knot t-1: the F operands and vectors go into the registers Aff just released
@@ -612,12 +639,23 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   // tile accumulates in place.  One k-step goes round all the tiles.
   constexpr int shLo = C::shTile(0);
   double4_t accS[TX][TX];
+  double acc4[TX]; // REM4: rows NX-4 .. NX-1 of Vxx (row on lane>>4, column 16tj + lane&15)
+  double sh4[KU];  // REM4: Shat(NX-4+i4, 4s'+k4) = H(NX+4s'+k4, NX-4+i4), from lane 16 k4 + (NX-4)%16 + i4
 #pragma unroll
   for (int tj = 0; tj < TX; ++tj)
 #pragma unroll
     for (int ti = tj; ti < TX; ++ti)
-      if (ti >= shLo)
-        accS[ti][tj] = S.Hc[ti][tj];
+      if (ti >= shLo) {
+        if (C::REM4 && ti == TX - 1)
+          acc4[tj] = S.Hc[ti][tj][0];
+        else
+          accS[ti][tj] = S.Hc[ti][tj];
+      }
+  if (C::REM4) {
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      sh4[s] = __shfl(S.Hc[C::shTile(s)][TX - 1][C::shReg(s)], (lane & 48) | ((NX - 4) & 15) | (lane & 3));
+  }
 #pragma unroll
   for (int s = 0; s < KU; ++s)
 #pragma unroll
@@ -625,7 +663,9 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
 #pragma unroll
       for (int ti = tj; ti < TX; ++ti) {
         const double aq = S.Hc[C::shTile(s)][ti][C::shReg(s)];
-        if (ti >= shLo)
+        if (C::REM4 && ti == TX - 1)
+          acc4[tj] = __builtin_amdgcn_mfma_f64_4x4x4f64(sh4[s], Kb[tj][s], acc4[tj], 0, 0, 0);
+        else if (ti >= shLo)
           accS[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], accS[ti][tj], 0, 0, 0);
         else
           S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], S.Hc[ti][tj], 0, 0, 0);
@@ -641,7 +681,8 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         const int i = 16 * ti + lk + 4 * r, c = 16 * tj + li;
         if (16 * ti + 4 * r < NX) { // compile-time
           const bool ok = (i < NX && c < NX && i >= c);
-          const double v = ti >= shLo ? accS[ti][tj][r] : S.Hc[ti][tj][r];
+          const double v = (C::REM4 && ti == TX - 1) ? acc4[tj]
+                                                     : (ti >= shLo ? accS[ti][tj][r] : S.Hc[ti][tj][r]);
           if (ti > tj && 16 * ti + 4 * r + 3 < NX && 16 * tj + 15 < NX) { // compile-time: all lanes valid
             V[i * PK + c] = v;
             V[c * PK + i] = v;

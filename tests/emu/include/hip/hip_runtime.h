@@ -79,6 +79,23 @@ inline emu_double4 emu_mfma_f64_16x16x4(double a, double b, emu_double4 c, int, 
   return d;
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64 emu_mfma_f64_16x16x4
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products (blocks b).  Lane maps measured on
+// MI355X (scripts/ubench/mfma4x4_probe.cpp): A_b[i][k] in lane 16k+4b+i, B_b[k][j] in lane
+// 16k+4b+j, D_b[i][j] in lane 16i+4b+j (one double per lane).
+inline double emu_mfma_f64_4x4x4(double a, double b, double c, int, int, int) {
+  const int lane = threadIdx.x & 63;
+  emu::WaveCtx &W = *emu::block->waves[threadIdx.x >> 6];
+  W.a[lane] = a;
+  W.b[lane] = b;
+  W.bar.arrive_and_wait();
+  const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+  double acc = c;
+  for (int k = 0; k < 4; ++k)
+    acc = std::fma(W.a[16 * k + 4 * blk + i], W.b[16 * k + 4 * blk + j], acc);
+  W.bar.arrive_and_wait();
+  return acc;
+}
+#define __builtin_amdgcn_mfma_f64_4x4x4f64 emu_mfma_f64_4x4x4
 
 // ---- wave-level exchange (lock-step via the wave barrier) ----------------------
 namespace emu {
