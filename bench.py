@@ -133,6 +133,10 @@ def main():
     ap.add_argument("--generator", default="W", choices=["W", "F"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the timing barrier (gloo + --same-device lets two "
+                         "ranks share one GPU to exercise the N>1 path on a 1-GPU box)")
+    ap.add_argument("--same-device", action="store_true", help="testing: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,11 +144,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the backend has no CPU path")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     N, nx, nu, mueq = args.horizon, args.nx, args.nu, 1e-14
     dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
@@ -179,7 +188,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # per-kernel durations: HIP events the library recorded on the launch stream around the
