@@ -242,8 +242,15 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU>;
   s->mfma_lds_doubles = gar::MfmaCfg<NX, NU>::total;
   s->kernel_name = "mfma<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
-  const char *bw = std::getenv("GAR_HIP_BACKWARD"); // "wg4": the 4-wave workgroup kernel
-  if (!(bw && std::string(bw) == "wg4")) {
+  // Two backward kernels: one wave per problem (throughput: every SIMD runs its own problem) and
+  // one 4-wave workgroup per problem (latency: a problem gets a whole CU; measured 2.2 ms vs
+  // 3.0 ms per sweep while there are no more problems than CUs).  GAR_HIP_BACKWARD=wave|wg4
+  // overrides the choice.
+  const char *bw = std::getenv("GAR_HIP_BACKWARD");
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
+  const bool want_wave = bw ? std::string(bw) != "wg4" : s->batch > cus;
+  if (want_wave) {
     s->wave_kernel = gar::gar_backward_wave<NX, NU>;
     // the initial stage is fused into the sweep when its packed kkt0 fits beside V in a
     // quarter of the CU's LDS (four waves per CU)

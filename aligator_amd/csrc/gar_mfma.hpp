@@ -203,26 +203,24 @@ __device__ __forceinline__ int wave_ldl_lean(const double *M, int lane, double (
 #pragma unroll
   for (int j = 0; j < NU; ++j)
     a[j] = M[j * NU + (j <= row ? row : j)]; // lower triangle (clamped address above it)
-  int verdict = 0;
+  unsigned long long bad = 0ull;
 #pragma unroll
   for (int k = 0; k < NU; ++k) {
     const double akk = lane_bcast(a[k], k);
-    double xs[NU];
-    double colmax = 0.0;
-#pragma unroll
-    for (int j = k + 1; j < NU; ++j) {
-      xs[j] = lane_bcast(a[k], j);
-      colmax = fmax(colmax, fabs(xs[j]));
-    }
-    verdict |= !(fabs(akk) >= colmax * alpha) || (akk == 0.0);
+    // the first test, |a_kk| >= alpha * colmax, holds iff it holds against every row below:
+    // one compare per lane and a ballot instead of a max-reduction over broadcast entries
+    const unsigned long long nok = __ballot(!(fabs(akk) >= alpha * fabs(a[k])) || akk == 0.0);
+    const unsigned long long from_k = ((1ull << NU) - 1ull) & ~((1ull << k) - 1ull);
+    bad |= nok & from_k;
     const double d = fast_rcp(akk);
+    const double lik = a[k] * d; // L(i,k) = a(i,k) d11: for row j this IS the reference's d11xj
 #pragma unroll
     for (int j = k + 1; j < NU; ++j)
-      a[j] = __builtin_fma(-(xs[j] * d), a[k], a[j]);
-    a[k] *= d;
+      a[j] = __builtin_fma(-lane_bcast(lik, j), a[k], a[j]); // a(i,j) -= d11xj * a(i,k)
+    a[k] = lik;
     dinv[k] = d;
   }
-  return verdict;
+  return bad != 0ull;
 }
 
 // x <- (L D L^T)^{-1} x, lane = right-hand-side column, L(i, j) broadcast from lane

@@ -157,6 +157,8 @@ inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_S
 // ---- runtime -------------------------------------------------------------------
 inline hipError_t hipGetDeviceCount(int *n) { *n = emu::device_count; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 0; return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
