@@ -198,3 +198,58 @@ def test_mfma_and_generic_kernels_agree(monkeypatch, family):
     g.forward(*sg)
     for A, B in zip(sa, sg):
         assert pc.maxdiff(A, B) <= 1e-11
+
+
+# ---- edge cases of the boundary -------------------------------------------------
+@pytest.mark.parametrize("nc0", [0, 2])
+def test_partial_or_no_initial_constraint(nc0):
+    """G0 with fewer rows than nx (or none): kkt0 = [Vxx0 G0^T; G0 0] is (nx+nc0)-dimensional
+    (proximal-riccati.hxx:42-60)."""
+    from aligator_amd.lqr import LqrProblem
+    rng = np.random.default_rng(40 + nc0)
+    nx, nu = 4, 2
+    knots = [synth.generate_knot(rng, nx, nu, mode="W") for _ in range(5)]
+    knots.append(synth.generate_knot(rng, nx, 0, mode="W"))
+    prob = LqrProblem(knots, nc0)
+    if nc0:
+        prob.G0[...] = rng.standard_normal((nc0, nx))
+        prob.g0[...] = rng.standard_normal(nc0)
+    pc.check_serial(prob, 1e-10, 1e-9, EMU, kkt_tol=1e-9)
+
+
+def test_dimensions_beyond_one_cu_are_refused():
+    """A stage whose working set exceeds a CU's 160 KiB of LDS is refused at creation with
+    GAR_HIP_ERR_UNSUPPORTED (no silent fallback)."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    dims = [(160, 40, 0, 160, 0)] * 2 + [(160, 0, 0, 160, 0)]
+    with pytest.raises(RuntimeError, match="LDS"):
+        BatchedRiccatiSolver(dims, 160, batch=1, lib_path=EMU)
+
+
+def test_bad_arguments_are_rejected():
+    from aligator_amd.gar import BatchedRiccatiSolver
+    with pytest.raises(RuntimeError):
+        BatchedRiccatiSolver([(4, 2, 0, 4, 0), (4, 0, 0, 4, 0)], 4, batch=0, lib_path=EMU)
+    s = BatchedRiccatiSolver([(4, 2, 0, 4, 0), (4, 0, 0, 4, 0)], 4, batch=2, lib_path=EMU)
+    with pytest.raises(RuntimeError, match="out of range"):
+        s._check(s._L.gar_hip_get_gains(s.handle, 0, 5, None, None, None))
+    with pytest.raises(RuntimeError, match="out of range"):
+        s._check(s._L.gar_hip_get_gains(s.handle, 7, 0, None, None, None))
+
+
+def test_batch_of_identical_and_distinct_problems_agree_with_singles():
+    """Batch axis: problem b of a batch equals the same problem solved alone (bitwise)."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    probs = [synth.generate_lq_problem(300 + i, np.zeros(8), 5, 8, 4, mode="W") for i in range(3)]
+    dims = [k.dims for k in probs[0].stages]
+    sb = BatchedRiccatiSolver(dims, 8, batch=3, lib_path=EMU)
+    sb.upload(probs)
+    sb.backward(1e-12)
+    sb.forward()
+    for b, p in enumerate(probs):
+        s1 = BatchedRiccatiSolver(dims, 8, batch=1, lib_path=EMU)
+        s1.upload([p])
+        s1.backward(1e-12)
+        s1.forward()
+        for A, B in zip(sb.solution(b), s1.solution(0)):
+            assert pc.maxdiff(A, B) == 0.0
