@@ -159,3 +159,37 @@ def test_sharded_solver_single_rank_rccl():
             assert max(lqrComputeKktError(prob, *sol, mueq=1e-9)) <= 1e-7 * sc
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("family,name", [("wave", "wave"), ("wg4", "mfma")])
+@pytest.mark.parametrize("nx,nu,horz,mode", [(36, 12, 33, "W"), (36, 12, 20, "F"), (32, 12, 17, "W"),
+                                             (16, 8, 12, "F"), (12, 4, 9, "W"), (8, 4, 5, "W")])
+def test_both_backward_families(monkeypatch, family, name, nx, nu, horz, mode):
+    """The throughput kernel (one wave per problem) and the latency kernel (one workgroup per
+    problem) are selected by batch size; force each and check every specialised shape."""
+    monkeypatch.setenv("GAR_HIP_BACKWARD", family)
+    prob = synth.generate_lq_problem(700 + nx + horz, np.zeros(nx), horz, nx, nu, mode=mode)
+    solver, _, _ = pc.check_serial(prob, 1e-12, pc.TOL[mode], kkt_tol=1e-6 if mode == "F" else 1e-9)
+    assert solver.kernel_name == f"{name}<{nx},{nu}>"
+
+
+def test_wave_family_bunch_kaufman_fallback_and_failure(monkeypatch):
+    """Stages where Bunch-Kaufman pivots (out-of-line exact path) and a zero pivot column
+    (the reference throws, riccati-kernel.hxx:239-241) on the throughput kernel."""
+    from aligator_amd.gar import ProximalRiccatiSolver
+    monkeypatch.setenv("GAR_HIP_BACKWARD", "wave")
+    nx, nu = 8, 4
+    prob = synth.generate_lq_problem(11, np.zeros(nx), 4, nx, nu, mode="W")
+    for k in prob.stages[:-1]:
+        k.R[...] = np.array([[1e-3, 2.0, 0.1, 0.0], [2.0, 1e-3, 0.0, 0.1],
+                             [0.1, 0.0, 3.0, 0.2], [0.0, 0.1, 0.2, 4.0]])
+        k.B[...] *= 1e-2
+    solver, _, _ = pc.check_serial(prob, 1e-12, 1e-9)
+    assert solver.kernel_name == "wave<8,4>"
+    bad = synth.generate_lq_problem(3, np.zeros(8), 3, 8, 4, mode="W")
+    for k in bad.stages[:-1]:
+        k.R[...] = 0.0
+        k.S[...] = 0.0
+        k.B[...] = 0.0
+    with pytest.raises(RuntimeError, match="LDL"):
+        ProximalRiccatiSolver(bad).backward(1e-10)
