@@ -460,6 +460,82 @@ __global__ void __launch_bounds__(64) gar_initial_wave(GenericParams P) {
 }
 
 // ---------------------------------------------------------------------------
+// Device-resident SolverProxDDPTpl::updateLQSubproblem (solver-proxddp.hxx:734-805): one
+// workgroup per (stage, problem) turns the stage's derivative record (gar_layout.h) into its
+// knot record -- Q = Lxx + preg I [+ Hxx], S = Lxu [+ Hxu], R = Luu + preg I [+ Huu],
+// q = Lx + lx_corr, r = Lu + lu_corr, A = Jx, B = Ju, f = slack, C, D, d copied; the terminal
+// knot takes Q, q, C, d only (:787-797); G0 = init Jx, g0 = init value, and stage 0's Q gets the
+// initial condition's Hessian (:799-804).  Same order of additions as the reference.  HBM-bound:
+// one read and one write of a knot record per stage.
+// ---------------------------------------------------------------------------
+struct UpdateParams {
+  const gar_stage_meta *meta;
+  const double *deriv; // [problem][header: G0 | g0 | init Hxx][stage records]
+  double *prob;
+  long long deriv_stride, prob_stride, G0_off, g0_off;
+  const long long *deriv_off; // horizon+1 stage-record offsets inside one derivative buffer
+  long long d_G0, d_g0, d_iH;
+  int horizon, nc0, nx0, hess_exact;
+  double preg;
+};
+
+__global__ void __launch_bounds__(256) gar_update_lq(UpdateParams P) {
+  const int t = (int)blockIdx.x, b = (int)blockIdx.y, tid = (int)threadIdx.x;
+  const gar_stage_meta m = P.meta[t];
+  const int nx = m.nx, nu = m.nu, nc = m.nc, nx2 = m.nx2;
+  const gar_knot_offsets ko = gar_knot_layout(nx, nu, nc, nx2, 0);
+  const gar_deriv_offsets dof = gar_deriv_layout(nx, nu, nc, nx2);
+  const double *dv = P.deriv + (long long)b * P.deriv_stride;
+  const double *d = dv + P.deriv_off[t];
+  double *k = P.prob + (long long)b * P.prob_stride + m.in_off;
+  const bool term = (t == P.horizon);
+  const bool exact = P.hess_exact && !term;
+  for (int e = tid; e < nx * nx; e += 256) { // Q (:763, :768, :773, :804)
+    const int j = e / nx, i = e - j * nx;
+    double v = d[ko.Q + e];
+    if (i == j)
+      v += P.preg;
+    if (exact)
+      v += d[dof.Hxx + e];
+    if (t == 0)
+      v += dv[P.d_iH + e];
+    k[ko.Q + e] = v;
+  }
+  for (int e = tid; e < nx; e += 256) // q (:766, :783)
+    k[ko.q + e] = d[ko.q + e] + d[dof.lxc + e];
+  for (int e = tid; e < nc * nx; e += 256) // C
+    k[ko.C + e] = d[ko.C + e];
+  for (int e = tid; e < nc; e += 256) // d
+    k[ko.d + e] = d[ko.d + e];
+  if (!term) {
+    for (int e = tid; e < nx * nu; e += 256) // S (:764, :774)
+      k[ko.S + e] = exact ? d[ko.S + e] + d[dof.Hxu + e] : d[ko.S + e];
+    for (int e = tid; e < nu * nu; e += 256) { // R (:765, :769, :775)
+      const int j = e / nu, i = e - j * nu;
+      double v = d[ko.R + e];
+      if (i == j)
+        v += P.preg;
+      if (exact)
+        v += d[dof.Huu + e];
+      k[ko.R + e] = v;
+    }
+    for (int e = tid; e < nu; e += 256) // r (:767, :784)
+      k[ko.r + e] = d[ko.r + e] + d[dof.luc + e];
+    for (int e = tid; e < nx2 * (nx + nu) + nx2; e += 256) // A, B, f contiguous (:759-761)
+      k[ko.A + e] = d[ko.A + e];
+    for (int e = tid; e < nc * nu; e += 256) // D
+      k[ko.D + e] = d[ko.D + e];
+  }
+  if (t == 0) { // G0, g0 (:800-801)
+    double *pb = P.prob + (long long)b * P.prob_stride;
+    for (int e = tid; e < P.nc0 * P.nx0; e += 256)
+      pb[P.G0_off + e] = dv[P.d_G0 + e];
+    for (int e = tid; e < P.nc0; e += 256)
+      pb[P.g0_off + e] = dv[P.d_g0 + e];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // forward: x0/lbd0 from kkt0 (serial) or the condensed solution (legs), then
 // the closed-loop roll-out.  LDS: x (nxM), xn (nxM), theta (nthM).
 // ---------------------------------------------------------------------------

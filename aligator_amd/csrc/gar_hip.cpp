@@ -80,6 +80,10 @@ struct gar_hip_solver {
   // optional per-kernel timing of the sweep (bench.py's roofline figure): HIP events recorded on
   // the launch stream around the backward sweep kernel, the initial-stage kernel and the forward
   // sweep kernel of the LAST backward/forward calls
+  // device-resident updateLQSubproblem: layout of one problem's derivative buffer
+  std::vector<long long> deriv_off; // per stage
+  long long deriv_doubles = 0, d_G0 = 0, d_g0 = 0, d_iH = 0;
+  long long *d_deriv_off = nullptr;
   bool timing = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -169,6 +173,21 @@ int build_layout(gar_hip_solver *s) {
     s->meta[t].l_off += (int32_t)s->sol_l;
   }
   s->sol_doubles = (x + u + v + l + 1) & ~(int64_t)1;
+  { // derivative buffer: header G0 | g0 | init Hxx, then one record per stage (even offsets)
+    long long p = 0;
+    s->d_G0 = p; p += (long long)s->nc0 * s->nx0;
+    s->d_g0 = p; p += s->nc0;
+    s->d_iH = p; p += (long long)s->nx0 * s->nx0;
+    p = (p + 1) & ~1ll;
+    s->deriv_off.assign(N + 1, 0);
+    for (int t = 0; t <= N; ++t) {
+      const int32_t *d = &s->dims5[5 * t];
+      s->deriv_off[t] = p;
+      p += gar_deriv_layout(d[0], d[1], d[2], d[3]).total;
+      p = (p + 1) & ~1ll;
+    }
+    s->deriv_doubles = p;
+  }
   s->init_doubles = ((int64_t)s->n0 + (int64_t)s->n0 * s->nth0 + s->nth0 +
                      (int64_t)s->nth0 * s->nth0 + 1) & ~(int64_t)1;
   return GAR_HIP_OK;
@@ -506,6 +525,8 @@ void free_device(gar_hip_solver *s) {
   (void)hipFree(s->d_cscratch);
   (void)hipFree(s->d_trace);
   s->d_trace = nullptr;
+  (void)hipFree(s->d_deriv_off);
+  s->d_deriv_off = nullptr;
   if (s->h_prob)
     (void)hipHostFree(s->h_prob);
   s->d_meta = nullptr;
@@ -1005,6 +1026,65 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]) {
     (void)hipFree(s->d_trace);
     s->d_trace = nullptr;
   }
+  return GAR_HIP_OK;
+}
+
+int64_t gar_hip_deriv_doubles(const gar_hip_solver *s) { return s ? s->deriv_doubles : 0; }
+
+int gar_hip_deriv_offsets(const gar_hip_solver *s, int t, int64_t out[4]) {
+  if (int rc = check_bt(s, 0, t))
+    return rc;
+  out[0] = s->deriv_off[t];
+  out[1] = s->d_G0;
+  out[2] = s->d_g0;
+  out[3] = s->d_iH;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_dev, double preg,
+                                        int hess_exact) {
+  if (!s || !deriv_dev)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_update_lq_subproblem_device: bad argument");
+  if (int rc = commit(s)) // pending host staging first; from now on the device copy is the truth
+    return rc;
+  s->staged = false;
+  if (!s->d_deriv_off) {
+    HIP_TRY(hipMalloc((void **)&s->d_deriv_off, sizeof(long long) * s->deriv_off.size()));
+    HIP_TRY(hipMemcpy(s->d_deriv_off, s->deriv_off.data(), sizeof(long long) * s->deriv_off.size(),
+                      hipMemcpyHostToDevice));
+  }
+  gar::UpdateParams U{};
+  U.meta = s->d_meta;
+  U.deriv = deriv_dev;
+  U.prob = s->d_prob;
+  U.deriv_stride = s->deriv_doubles;
+  U.prob_stride = s->prob_doubles;
+  U.G0_off = s->G0_off;
+  U.g0_off = s->g0_off;
+  U.deriv_off = s->d_deriv_off;
+  U.d_G0 = s->d_G0;
+  U.d_g0 = s->d_g0;
+  U.d_iH = s->d_iH;
+  U.horizon = s->horizon;
+  U.nc0 = s->nc0;
+  U.nx0 = s->nx0;
+  U.hess_exact = hess_exact;
+  U.preg = preg;
+  hipLaunchKernelGGL(gar::gar_update_lq, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch),
+                     dim3(256), 0, s->stream, U);
+  HIP_TRY(hipGetLastError());
+  return GAR_HIP_OK;
+}
+
+int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed) {
+  if (!s || !packed || b0 < 0 || nb < 0 || b0 + nb > s->batch)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_download_packed: bad argument");
+  if (int rc = commit(s))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(packed, s->d_prob + (int64_t)b0 * s->prob_doubles,
+                         sizeof(double) * (size_t)s->prob_doubles * nb, hipMemcpyDeviceToHost,
+                         s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return GAR_HIP_OK;
 }
 

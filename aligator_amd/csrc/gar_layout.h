@@ -117,6 +117,27 @@ GAR_HD static inline gar_factor_offsets gar_factor_layout(int nx, int nu, int nc
   return o;
 }
 
+// ---- derivative record (input of the device-resident updateLQSubproblem) -------------------
+// What SolverProxDDPTpl::updateLQSubproblem reads for stage t (solver-proxddp.hxx:746-785),
+// packed in the knot record's own order so that assembling the LQ problem is a fused copy:
+//   Lxx Lxu Luu Lx Lu | Jx Ju slack | Cx Cu Lv      <- same shapes/order as Q S R q r A B f C D d
+//   Hxx Hxu Huu  (dynamics Hessians, used when hess_exact)  | lx_corr lu_corr
+typedef struct gar_deriv_offsets {
+  int32_t Hxx, Hxu, Huu, lxc, luc, total; // the knot-shaped part starts at 0
+} gar_deriv_offsets;
+
+GAR_HD static inline gar_deriv_offsets gar_deriv_layout(int nx, int nu, int nc, int nx2) {
+  gar_deriv_offsets o;
+  int32_t p = (int32_t)gar_knot_doubles(nx, nu, nc, nx2, 0);
+  o.Hxx = p; p += nx * nx;
+  o.Hxu = p; p += nx * nu;
+  o.Huu = p; p += nu * nu;
+  o.lxc = p; p += nx;
+  o.luc = p; p += nu;
+  o.total = p;
+  return o;
+}
+
 // get_work (parallel-solver.hxx:23-28): leg i of J owns [beg, end)
 GAR_HD static inline void gar_get_work(int horz, int leg, int nlegs, int *beg, int *end) {
   *beg = (int)((int64_t)leg * (horz + 1) / nlegs);

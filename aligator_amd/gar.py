@@ -200,6 +200,53 @@ class BatchedRiccatiSolver:
         return (L.gar_hip_device_problems(h), L.gar_hip_device_factors(h),
                 L.gar_hip_device_solutions(h))
 
+    def download_packed(self, b0: int = 0, nb: Optional[int] = None) -> np.ndarray:
+        """nb packed problems back from HBM (diagnostics / tests)."""
+        nb = self.batch - b0 if nb is None else nb
+        out = np.zeros(nb * self.problem_doubles)
+        self._check(self._L.gar_hip_download_packed(self._h, b0, nb, _ptr(out)))
+        return out
+
+    # ---- device-resident LQ assembly (updateLQSubproblem, solver-proxddp.hxx:734-805) ----
+    DERIV_BLOCKS = ("Lxx", "Lxu", "Luu", "Lx", "Lu", "Jx", "Ju", "slack", "Cx", "Cu", "Lv",
+                    "Hxx", "Hxu", "Huu", "lx_corr", "lu_corr")
+
+    @staticmethod
+    def deriv_shapes(nx, nu, nc, nx2):
+        return dict(Lxx=(nx, nx), Lxu=(nx, nu), Luu=(nu, nu), Lx=(nx,), Lu=(nu,), Jx=(nx2, nx),
+                    Ju=(nx2, nu), slack=(nx2,), Cx=(nc, nx), Cu=(nc, nu), Lv=(nc,), Hxx=(nx, nx),
+                    Hxu=(nx, nu), Huu=(nu, nu), lx_corr=(nx,), lu_corr=(nu,))
+
+    @property
+    def deriv_doubles(self) -> int:
+        return int(self._L.gar_hip_deriv_doubles(self._h))
+
+    def pack_derivs(self, derivs, init) -> np.ndarray:
+        """One problem's derivative buffer (csrc/gar_layout.h, gar_deriv_layout): header
+        G0 | g0 | init Hxx, then one record per stage in DERIV_BLOCKS order."""
+        buf = np.zeros(self.deriv_doubles)
+        off = np.zeros(4, dtype=np.int64)
+        for t, d in enumerate(derivs):
+            self._check(self._L.gar_hip_deriv_offsets(self._h, t, off.ctypes.data_as(C.POINTER(C.c_int64))))
+            p = int(off[0])
+            nx, nu, nc, nx2, _ = (int(v) for v in self.dims[t])
+            for name, shp in self.deriv_shapes(nx, nu, nc, nx2).items():
+                n = int(np.prod(shp))
+                buf[p:p + n] = _f64(np.asarray(d[name]).reshape(shp)).ravel(order="F")
+                p += n
+        nx0 = int(self.dims[0, 0])
+        buf[int(off[1]):int(off[1]) + self.nc0 * nx0] = _f64(init["Jx"]).ravel(order="F")
+        buf[int(off[2]):int(off[2]) + self.nc0] = init["value"]
+        buf[int(off[3]):int(off[3]) + nx0 * nx0] = _f64(init["Hxx"]).ravel(order="F")
+        return buf
+
+    def update_lq_subproblem_device(self, deriv_device_ptr: int, preg: float, hess_exact: bool):
+        """The knots of every problem are rebuilt ON THE DEVICE from a device-resident
+        derivative buffer (batch x deriv_doubles); asynchronous on the solver's stream."""
+        self._factors_cache = {}
+        self._check(self._L.gar_hip_update_lq_subproblem_device(
+            self._h, C.c_void_p(deriv_device_ptr), float(preg), int(bool(hess_exact))))
+
     def upload_knot(self, b: int, t: int, k: LqrKnot):
         """gar_hip_upload_stage: the 16 separately allocated blocks of LqrKnotTpl."""
         a = {n: _f64(getattr(k, n)) for n in BLOCK_NAMES}

@@ -131,6 +131,23 @@ double *gar_hip_device_problems(gar_hip_solver *s);
 double *gar_hip_device_factors(gar_hip_solver *s);
 double *gar_hip_device_solutions(gar_hip_solver *s);
 
+/* nb packed problems (gar_hip_problem_doubles() each) back to the host (diagnostics, tests) */
+int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed);
+
+/* ---- device-resident LQ assembly (next row either side of the path) ----------- */
+/* Replaces SolverProxDDPTpl::updateLQSubproblem (solvers/proxddp/solver-proxddp.hxx:734-805):
+ * `deriv_dev` is a DEVICE buffer of batch x gar_hip_deriv_doubles() doubles holding, per problem,
+ * the header G0 | g0 | init Hxx and one derivative record per stage (csrc/gar_layout.h:
+ * Lxx Lxu Luu Lx Lu Jx Ju slack Cx Cu Lv | Hxx Hxu Huu | lx_corr lu_corr); the kernel writes the
+ * knot records in place (Q,R get `preg` on the diagonal, the dynamics Hessians are added when
+ * hess_exact != 0, stage 0 gets the initial condition's Hessian).  Asynchronous on the solver's
+ * stream: follow with gar_hip_backward_async.  out[0] of gar_hip_deriv_offsets = offset of stage
+ * t's record, out[1..3] = offsets of G0, g0, init Hxx inside one problem's derivative buffer. */
+int64_t gar_hip_deriv_doubles(const gar_hip_solver *s);
+int gar_hip_deriv_offsets(const gar_hip_solver *s, int t, int64_t out[4]);
+int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_dev, double preg,
+                                        int hess_exact);
+
 /* ---- the sweep ------------------------------------------------------------ */
 /* backward(mueq): returns 0, or GAR_HIP_ERR_FACTOR if any stage factorisation
  * of any problem failed (the reference throws). */
