@@ -58,6 +58,7 @@ SIGNATURES = {
     "gar_hip_condensed_solve_async": (C.c_int, [C.c_void_p]),
     "gar_hip_forward_legs_async": (C.c_int, [C.c_void_p]),
     "gar_hip_set_refinement": (C.c_int, [C.c_void_p, C.c_double, C.c_int]),
+    "gar_hip_condensed_info": (C.c_int, [C.c_void_p, C.c_int, _PD]),
     "gar_hip_get_solution": (C.c_int, [C.c_void_p, C.c_int, _PD, _PD, _PD, _PD]),
     "gar_hip_get_gains": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _PD, _PD, _PD]),
     "gar_hip_get_value": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _PD, _PD, _PD, _PD, _PD]),

@@ -17,6 +17,7 @@
 #include "gar_layout.h"
 #include "gar_mfma.hpp"
 #include "gar_wave.hpp"
+#include "gar_wave_leg.hpp"
 
 namespace {
 
@@ -76,6 +77,15 @@ struct gar_hip_solver {
   void (*wave_kernel)(gar::MfmaParams, int) = nullptr;
   int wave_lds_doubles = 0, waves_per_block = 1;
   bool wave_fused_init = false;
+  // one-wave-per-(problem, leg) kernels (gar_wave_leg.hpp), bound for uniform leg-mode problems
+  void (*leg_bwd_kernel)(gar::LegParams) = nullptr;
+  void (*leg_tuple_kernel)(gar::LegParams) = nullptr;
+  void (*leg_fwd_param_kernel)(gar::LegParams) = nullptr;
+  void (*leg_fwd_final_kernel)(gar::LegParams) = nullptr;
+  void (*leg_collapse_kernel)(const gar_stage_meta *, double *, long long, int) = nullptr;
+  int leg_lds_doubles = 0;
+  void (*cond_wave_kernel)(gar::CondensedParams) = nullptr;
+  int cond_wave_lds_doubles = 0;
   long long *d_trace = nullptr; // 64 cycle stamps (debug)
   // optional per-kernel timing of the sweep (bench.py's roofline figure): HIP events recorded on
   // the launch stream around the backward sweep kernel, the initial-stage kernel and the forward
@@ -281,7 +291,58 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   }
 }
 
+template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
+  s->leg_bwd_kernel = gar::gar_backward_wave_leg<NX, NU>;
+  s->leg_tuple_kernel = gar::gar_leg_tuples<NX, NU>;
+  s->leg_fwd_param_kernel = gar::gar_forward_wave_leg<NX, NU, true>;
+  s->leg_fwd_final_kernel = gar::gar_forward_wave_leg<NX, NU, false>;
+  s->leg_collapse_kernel = gar::gar_collapse_feedback_t2<NX, NU>;
+  s->leg_lds_doubles = gar::WaveCfg<NX, NU>::leg_total;
+  const char *ck = std::getenv("GAR_HIP_CONDENSED");
+  if (!(ck && std::string(ck) == "generic")) {
+    const int lds = 4 * NX * NX + NX + (NX & 1) + (NX + 16) / 2 + 2 + 2 * (2 * s->num_legs) * NX + 2;
+    if ((size_t)lds * sizeof(double) <= 160 * 1024) {
+      s->cond_wave_kernel = gar::gar_condensed_wave<NX>;
+      s->cond_wave_lds_doubles = lds;
+    }
+  }
+  s->kernel_name = "wave_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+}
+
+// leg mode: uniform unconstrained problem whose every leg holds at least two knots
+void select_leg_kernel(gar_hip_solver *s) {
+  const int N = s->horizon;
+  const char *lk = std::getenv("GAR_HIP_LEGS");
+  if (lk && std::string(lk) == "generic")
+    return;
+  if (N < 1 || s->nxb != s->dims5[0])
+    return;
+  const int nx = s->dims5[0], nu = s->dims5[1];
+  for (int t = 0; t <= N; ++t) {
+    const int32_t *d = &s->dims5[5 * t];
+    if (d[0] != nx || d[1] != (t < N ? nu : 0) || d[2] != 0 || d[3] != nx || d[4] != 0)
+      return;
+  }
+  for (int i = 0; i < s->num_legs; ++i) {
+    int i0, i1;
+    gar_get_work(N, i, s->num_legs, &i0, &i1);
+    if (i1 - i0 < (i + 1 < s->num_legs ? 2 : 1))
+      return;
+  }
+  if (nx == 36 && nu == 12) bind_leg<36, 12>(s);
+  else if (nx == 32 && nu == 12) bind_leg<32, 12>(s);
+  else if (nx == 16 && nu == 8) bind_leg<16, 8>(s);
+  else if (nx == 12 && nu == 4) bind_leg<12, 4>(s);
+  else if (nx == 8 && nu == 4) bind_leg<8, 4>(s);
+}
+
 void select_kernel(gar_hip_solver *s) {
+  s->leg_bwd_kernel = nullptr;
+  s->leg_tuple_kernel = nullptr;
+  s->leg_fwd_param_kernel = nullptr;
+  s->leg_fwd_final_kernel = nullptr;
+  s->leg_collapse_kernel = nullptr;
+  s->cond_wave_kernel = nullptr;
   s->mfma_kernel = nullptr;
   s->mfma_fwd_kernel = nullptr;
   s->wave_kernel = nullptr;
@@ -291,7 +352,11 @@ void select_kernel(gar_hip_solver *s) {
   if (force && force[0] == '1')
     return;
   const int N = s->horizon;
-  if (s->num_legs != 1 || N < 1)
+  if (s->num_legs > 1) {
+    select_leg_kernel(s);
+    return;
+  }
+  if (N < 1)
     return;
   const gar_stage_meta &m0 = s->meta[0];
   if (m0.nc != 0 || m0.nth != 0 || m0.nx2 != m0.nx)
@@ -375,7 +440,48 @@ int write_block(gar_hip_solver *s, int b, int64_t off, const double *src, int64_
   return GAR_HIP_OK;
 }
 
+gar::LegParams make_leg_params(gar_hip_solver *s) {
+  gar::LegParams Q{};
+  const int N = s->horizon;
+  Q.M.prob = s->d_prob;
+  Q.M.fac = s->d_fac;
+  Q.M.status = s->d_status;
+  Q.M.prob_stride = s->prob_doubles;
+  Q.M.fac_stride = s->fac_doubles;
+  Q.M.in_off0 = s->meta[0].in_off;
+  Q.M.in_rec = N > 1 ? s->meta[1].in_off - s->meta[0].in_off : s->meta[N].in_off - s->meta[0].in_off;
+  Q.M.in_offN = s->meta[N].in_off;
+  Q.M.horizon = N;
+  Q.M.trace = nullptr;
+  Q.meta = s->d_meta;
+  Q.num_legs = s->num_legs;
+  Q.leg_begin = s->leg_begin;
+  Q.csol = s->d_csol;
+  Q.sol = s->d_sol;
+  Q.sol_stride = s->sol_doubles;
+  Q.sol_u = (int)s->sol_u;
+  Q.sol_l = (int)s->sol_l;
+  Q.nc0 = s->nc0;
+  Q.boundary = s->d_bound_local;
+  Q.boundary_stride = (long long)(s->leg_end - s->leg_begin) * s->tuple_doubles;
+  Q.tuple_doubles = (int)s->tuple_doubles;
+  return Q;
+}
+
 int launch_backward(gar_hip_solver *s, double mueq) {
+  if (s->leg_bwd_kernel) {
+    gar::LegParams Q = make_leg_params(s);
+    const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+    hipLaunchKernelGGL(s->leg_bwd_kernel, grid, dim3(64),
+                       (size_t)s->leg_lds_doubles * sizeof(double), s->stream, Q);
+    hipLaunchKernelGGL(s->leg_tuple_kernel, grid, dim3(256), 0, s->stream, Q);
+    HIP_TRY(hipGetLastError());
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+    return GAR_HIP_OK;
+  }
   gar::GenericParams P = make_params(s, mueq);
   if (s->mfma_kernel) {
     gar::MfmaParams M{};
@@ -435,6 +541,24 @@ int launch_backward(gar_hip_solver *s, double mueq) {
 }
 
 int launch_forward(gar_hip_solver *s, const double *theta_dev) {
+  if (s->leg_fwd_param_kernel) {
+    gar::LegParams Q = make_leg_params(s);
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[3], s->stream));
+    // the non-final local legs, then (if this rank owns it) the final leg
+    const int last = s->num_legs - 1;
+    const int nparam = std::min(s->leg_end, last) - s->leg_begin;
+    if (nparam > 0)
+      hipLaunchKernelGGL(s->leg_fwd_param_kernel, dim3((unsigned)nparam, (unsigned)s->batch),
+                         dim3(64), 0, s->stream, Q);
+    if (s->leg_end == s->num_legs)
+      hipLaunchKernelGGL(s->leg_fwd_final_kernel, dim3(1u, (unsigned)s->batch), dim3(64), 0,
+                         s->stream, Q);
+    HIP_TRY(hipGetLastError());
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[4], s->stream));
+    return GAR_HIP_OK;
+  }
   if (s->mfma_fwd_kernel) {
     gar::MfmaFwdParams F{};
     const int N = s->horizon;
@@ -487,9 +611,15 @@ int launch_condensed(gar_hip_solver *s) {
   C.nx0 = s->nx0;
   C.max_refinement = s->max_refinement;
   C.threshold = s->cond_threshold;
-  hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(256),
-                     (size_t)s->cond_lds_doubles * sizeof(double), s->stream, C);
+  if (s->cond_wave_kernel)
+    hipLaunchKernelGGL(s->cond_wave_kernel, dim3((unsigned)s->batch), dim3(64),
+                       (size_t)s->cond_wave_lds_doubles * sizeof(double), s->stream, C);
+  else
+    hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(256),
+                       (size_t)s->cond_lds_doubles * sizeof(double), s->stream, C);
   HIP_TRY(hipGetLastError());
+  if (s->timing) // leg mode: the "initial stage" slot of the timing API is the condensed solve
+    HIP_TRY(hipEventRecord(s->ev[2], s->stream));
   return GAR_HIP_OK;
 }
 
@@ -581,6 +711,14 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipFuncSetAttribute((const void *)s->mfma_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->mfma_lds_doubles * sizeof(double))));
+  if (s->cond_wave_kernel)
+    HIP_TRY(hipFuncSetAttribute((const void *)s->cond_wave_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->cond_wave_lds_doubles * sizeof(double))));
+  if (s->leg_bwd_kernel)
+    HIP_TRY(hipFuncSetAttribute((const void *)s->leg_bwd_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->leg_lds_doubles * sizeof(double))));
   if (s->wave_kernel)
     HIP_TRY(hipFuncSetAttribute((const void *)s->wave_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -931,6 +1069,20 @@ int gar_hip_set_refinement(gar_hip_solver *s, double thr, int max_steps) {
   return GAR_HIP_OK;
 }
 
+int gar_hip_condensed_info(gar_hip_solver *s, int b, double out[2]) {
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  if (s->num_legs < 2 || !out)
+    return fail(GAR_HIP_ERR_ARG, "condensed info needs leg mode");
+  const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
+  const double *info = s->d_cscratch + (int64_t)b * s->cscratch_doubles + 4 * nblk * bs +
+                       4 * nblk * s->nxb;
+  if (int rc = d2h(s, out, info, 2))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
 int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, double *vs,
                          double *lbdas) {
   if (int rc = check_bt(s, b, 0))
@@ -958,17 +1110,32 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
   const int64_t nr = (int64_t)m.nu + m.nc + m.nx2;
   int rc = d2h(s, ff, rec + o.ff, nr);
   std::vector<double> tmp;
-  const bool fbt2 = s->mfma_kernel && t < s->horizon && fb; // device keeps fb in fbT2 layout
+  // the specialised kernel families keep fb (and fth) in the fbT2 device order
+  const bool t2 = (s->mfma_kernel || s->leg_bwd_kernel) && t < s->horizon;
+  const bool fbt2 = t2 && fb;
+  const bool ftht2 = t2 && fth && m.nth > 0;
+  std::vector<double> tmpth;
   if (fbt2) {
     tmp.resize((size_t)(nr * m.nx));
     rc |= d2h(s, tmp.data(), rec + o.fb, nr * m.nx);
   } else {
     rc |= d2h(s, fb, rec + o.fb, nr * m.nx);
   }
-  rc |= d2h(s, fth, rec + o.fth, nr * m.nth);
+  if (ftht2) {
+    tmpth.resize((size_t)(nr * m.nth));
+    rc |= d2h(s, tmpth.data(), rec + o.fth, nr * m.nth);
+  } else {
+    rc |= d2h(s, fth, rec + o.fth, nr * m.nth);
+  }
   if (rc)
     return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (ftht2) {
+    const int NW = (int)nr, NT = m.nth;
+    for (int r = 0; r < NW; ++r)
+      for (int j = 0; j < NT; ++j)
+        fth[(size_t)r * NT + j] = tmpth[(size_t)(j >> 1) * (2 * NW) + 2 * r + (j & 1)];
+  }
   if (fbt2) { // back to StageFactor's row-major [K; Z; Aff] (riccati-kernel.hpp:96-97)
     const int NW = (int)nr, NX = m.nx;
     for (int r = 0; r < NW; ++r)
@@ -1102,7 +1269,7 @@ int gar_hip_set_timing(gar_hip_solver *s, int enable) {
 int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]) {
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
-  if (!s->timing || !s->mfma_kernel)
+  if (!s->timing || !(s->mfma_kernel || s->leg_bwd_kernel))
     return fail(GAR_HIP_ERR_UNSUPPORTED, "per-kernel timing is recorded for the specialised "
                                          "kernel family after gar_hip_set_timing(s, 1)");
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1121,8 +1288,9 @@ int gar_hip_collapse_feedback(gar_hip_solver *s) {
     return fail(GAR_HIP_ERR_ARG, "null solver");
   if (s->num_legs < 2 || s->leg_begin != 0)
     return GAR_HIP_OK; // no-op except Parallel (riccati-base.hpp:33)
-  hipLaunchKernelGGL(gar::gar_collapse_feedback, dim3((unsigned)s->batch), dim3(256), 0,
-                     s->stream, s->d_meta, s->d_fac, (long long)s->fac_doubles, s->batch);
+  hipLaunchKernelGGL(s->leg_collapse_kernel ? s->leg_collapse_kernel : gar::gar_collapse_feedback,
+                     dim3((unsigned)s->batch), dim3(256), 0, s->stream, s->d_meta, s->d_fac,
+                     (long long)s->fac_doubles, s->batch);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
   return GAR_HIP_OK;

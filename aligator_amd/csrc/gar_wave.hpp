@@ -84,6 +84,22 @@ template <int NX, int NU> struct WaveCfg {
   __host__ __device__ static constexpr int total_with_init(int nc0) {
     return (oK0 + k0_doubles(NX + nc0)) > total ? (oK0 + k0_doubles(NX + nc0)) : total;
   }
+  // ---- parameterised legs (gar_wave_leg.hpp; nth = NX): the extra state of the recursion
+  // (riccati-kernel.hxx:278-311) lives in LDS in LANE-PRIVATE layouts, slot (s, tj) at
+  // ((s*TX + tj)*64 + lane):
+  //   Xt : Vxt'[4s+lk][16tj+li]  -- the MFMA B operand of k-step s (== register s&3 of D tile s>>2)
+  //   Tt : Vtt'^T accumulators, D-tile register (s&3) of tile (s>>2, tj)
+  static constexpr int oXt = (total + 1) & ~1;
+  static constexpr int oTt = oXt + KS * TX * 64;
+  static constexpr int oGt = oTt + KS * TX * 64;   // [Ghat_u] then [Kth], NU x PG (solved in place)
+  static constexpr int oVt = oGt + NU * PG + 16;   // vt (NX)
+  static constexpr int oYf = oVt + NX;             // yff (NX)
+  static constexpr int leg_total = (oYf + NX + 1) & ~1;
+  // factor record of a parameterised stage (gar_factor_layout(NX,NU,0,NX,NX)); fb and fth in the
+  // fbT2 device order
+  static constexpr int pFTH = NW + NW * NX, pVxx = pFTH + NW * NX, pvx = pVxx + NX * NX,
+                       pVxt = pvx + NX, pVtt = pVxt + NX * NX, pvt = pVtt + NX * NX,
+                       prec = pvt + NX;
 };
 
 // base + cst (doubles, compile-time: goes to the scalar base / the instruction's immediate) +
@@ -314,16 +330,47 @@ __device__ __forceinline__ void ldl_solve_regs_bcast(const double (&a)[NU], cons
   }
 }
 
+// two right-hand-side sets per lane (the gains and the parameter gains, :262 and :291) behind ONE
+// set of broadcasts
+template <int NU>
+__device__ __forceinline__ void ldl_solve_regs_bcast2(const double (&a)[NU], const double (&nd)[NU],
+                                                      double (&x)[NU], double (&y)[NU]) {
+#pragma unroll
+  for (int j = 0; j < NU - 1; ++j) {
+#pragma unroll
+    for (int i = j + 1; i < NU; ++i) {
+      const double l = lane_bcast(a[j], i);
+      x[i] = __builtin_fma(-l, x[j], x[i]);
+      y[i] = __builtin_fma(-l, y[j], y[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    x[i] *= nd[i];
+    y[i] *= nd[i];
+  }
+#pragma unroll
+  for (int i = NU - 1; i >= 1; --i) {
+#pragma unroll
+    for (int j = i - 1; j >= 0; --j) {
+      const double l = lane_bcast(a[j], i);
+      x[j] = __builtin_fma(-l, x[i], x[j]);
+      y[j] = __builtin_fma(-l, y[i], y[j]);
+    }
+  }
+}
+
 // Rare path, kept out of line so that its registers do not weigh on the sweep: the first
 // Bunch-Kaufman test failed somewhere (or a pivot was zero).  Evaluate the complete rule;
 // if BK still takes kp = k everywhere redo the unpivoted factorisation, else run the generic
 // device Bunch-Kaufman exactly as the reference would (interchanges, 2x2 pivots), solving
 // [kff | K] into G2.  Returns 1 if the factorisation failed (zero pivot column).
-template <int NX, int NU>
+template <int NX, int NU, bool PARAM = false>
 __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int lane) {
   using C = WaveCfg<NX, NU>;
   constexpr int PG = C::PG;
   double *G = sm + C::oG, *G2 = sm + C::oG2, *Mm = sm + C::oM;
+  double *Gt = sm + C::oGt; // PARAM: [Ghat_u] -> [Kth], NX columns
   double *Lr = sm + C::oLr, *ndi = sm + C::oDi;
   int failed = 0;
   int verdict;
@@ -357,15 +404,32 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
       for (int k = 0; k < NU; ++k)
         G2[k * PG + col] = x[k];
     }
+    if (PARAM) {
+      const int ct = lane < NX ? lane : NX - 1;
+#pragma unroll
+      for (int k = 0; k < NU; ++k)
+        x[k] = Gt[k * PG + ct];
+      ldl_solve_lds<NU>(Lr, ndi, x);
+      if (lane < NX) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+          Gt[k * PG + ct] = x[k];
+      }
+    }
   } else {
     for (int e = lane; e < NU * PG; e += 64)
       G2[e] = -G[e]; // in place (G2 aliases G)
+    if (PARAM)
+      for (int e = lane; e < NU * PG; e += 64)
+        Gt[e] = -Gt[e];
     double *sub = sm + C::oBk;
     int *piv = (int *)(sub + 16);
     const WG w1 = wave_self();
     wave_sync();
     failed |= wg_bk_factor(w1, NU, Mm, NU, sub, piv, piv + 16);
     wg_bk_solve(w1, NU, Mm, NU, sub, piv, G2, PG, 1, NX + 1);
+    if (PARAM)
+      wg_bk_solve(w1, NU, Mm, NU, sub, piv, Gt, PG, 1, NX);
   }
   wave_sync();
   return failed;
@@ -373,7 +437,16 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
 
 // One stage t of the backward sweep, entirely inside one wave.  On entry S holds knot t
 // (F operands, vectors, Hessian tiles); on exit it holds knot t-1.
-template <int NX, int NU>
+// MODE 0: the plain stage (stageKernelSolve, :209-277).
+// MODE 1: a stage of a parameterised leg (ParallelRiccatiSolver, nth = NX, implicit
+//         Gx = Gu = Gth = gamma = 0): the plain stage plus :278-311 --
+//           Ghat_u = B^T Vxt' ; Kth = -Rhat^{-1} Ghat_u ; Yth = B Kth ; vt = vt' + Vxt'^T yff ;
+//           Vxt = Aff^T Vxt' ; Vtt = Vtt' + Ghat_u^T Kth (== Vxt'^T Yth, :310, in NU instead of
+//           NX products per entry).
+// MODE 2: the leg-end knot (terminalSolve with nu > 0, :146-192, under configure_knot's
+//         Gx = A^T, Gu = B^T, Gth = 0, gamma = f, parallel-solver.hxx:136-141): no V', so
+//         H = W; Kth = -R^{-1} B^T ; Vxt = A^T + K^T B^T ; Vtt = B Kth ; vt = f + B kff.
+template <int NX, int NU, int MODE = 0>
 __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, const double *prob,
                                            double *fac, int t, int lane,
                                            const WaveLane<NX, NU> &L, WaveStage<NX, NU> &S,
@@ -386,6 +459,10 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM;
   double *vn = sm + C::oVn, *vp = sm + C::oVp;
   double *Lr = sm + C::oLr, *ndi = sm + C::oDi;
+  double *Xt = sm + C::oXt + lane, *Tt = sm + C::oTt + lane; // lane-private slots, stride 64
+  double *Gt = sm + C::oGt, *vtl = sm + C::oVt, *yfl = sm + C::oYf;
+  constexpr int oVxx = MODE ? C::pVxx : M::fVxx, ovx = MODE ? C::pvx : M::fvx;
+  const unsigned lkx = 8u * (unsigned)(lk * NX + li); // element (lk, li) of a pitch-NX block
   double *out = fac + (long long)t * P.fac_rec;
   const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
   const double *recn = rec - (t > 0 ? P.in_rec : 0); // knot t-1 (t = 0: harmless re-read)
@@ -399,7 +476,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   GAR_WMARK(0)
   // ---- vplus = vx' + V' f (:217-218), lane i < NX ------------------------------
   const int ir = lane < NX ? lane : NX - 1;
-  {
+  if (MODE != 2) {
     // f[k] is broadcast from lane k's register (v_readlane: measured 2.5x cheaper here than
     // wave-uniform LDS reads), V's row from LDS
     double s0 = 0.0, s1 = 0.0;
@@ -422,7 +499,11 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   // lane (li,lk) sums its rows 4s+lk, the four lk groups are added by two xor-shuffles
   double hq; // lane j < NW: [qhat; rhat][j]
   const double fi = S.fi;
-  {
+  if (MODE == 2) { // no next knot inside the leg: qhat = q, rhat = r
+    hq = S.qri;
+    if (lane >= NX && lane < NW)
+      G[(lane - NX) * PG] = hq;
+  } else {
     double vps[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -455,8 +536,25 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   // ---- P = V' F, H = W + F^T P (:216-228), column tile by column tile ----------
   constexpr int TXF = C::REM4 ? TX - 1 : TX; // row tiles of P on the 16x16x4 instruction
   const int i4 = lane & 3, k4 = lane >> 4;   // 4x4x4 A operand: row i4 of the block, k = k4
+  // MODE 1: Ghat_u = B^T Vxt' (:286-287).  The rows u of F^T Vxt' are rows NX+u of the tile rows
+  // shTile(0..KU-1) -- the same (tile, register) as the Shat^T rows of H; A operand = the F
+  // operand registers of those column tiles, B operand = Vxt' (LDS, lane-private)
+  constexpr int shLoT = C::shTile(0), shHiT = C::shTile(KU - 1);
+  double4_t Gh[shHiT - shLoT + 1][TX];
+  if (MODE == 1) {
 #pragma unroll
-  for (int tj = 0; tj < TW; ++tj) {
+    for (int tu = shLoT; tu <= shHiT; ++tu)
+#pragma unroll
+      for (int tj = 0; tj < TX; ++tj) {
+        double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S.fo(tu, s), Xt[(s * TX + tj) * 64], acc, 0, 0, 0);
+        Gh[tu - shLoT][tj] = acc;
+      }
+  }
+#pragma unroll
+  for (int tj = 0; tj < (MODE == 2 ? 0 : TW); ++tj) {
     double4_t Pt[TX];
     double p4 = 0.0; // REM4: P[NX-4+lk][16tj+li], the rows of the last (4-row) tile
 #pragma unroll
@@ -499,6 +597,14 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
             Mm[(c - NX) * NU + (row - NX)] = S.Hc[ti][tj][r];
         }
       }
+  if (MODE == 1) { // Gt(u, c) = Ghat_u(u, c): the right-hand sides of Kth
+#pragma unroll
+    for (int sp = 0; sp < KU; ++sp)
+#pragma unroll
+      for (int tj = 0; tj < TX; ++tj)
+        if (16 * tj + 15 < NX || 16 * tj + li < NX)
+          Gt[(4 * sp + lk) * PG + 16 * tj + li] = Gh[C::shTile(sp) - shLoT][tj][C::shReg(sp)];
+  }
   wave_sync();
   // B of this knot as the A operand of Aff = A + B K: needed a factorisation from now
   double Bop[TX][KU]; // B[16ti+li][4s'+lk]
@@ -514,6 +620,15 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
     for (int s = 0; s < KU; ++s)
       Bop4[s] = ldg_b(rec, 4 * s * NX, L.bop4);
   }
+  if (MODE == 2) { // Gu = B^T: Gt(u, c) = B(c, u)
+#pragma unroll
+    for (int sp = 0; sp < KU; ++sp)
+#pragma unroll
+      for (int tj = 0; tj < TX; ++tj)
+        if (16 * tj + 15 < NX || 16 * tj + li < NX)
+          Gt[(4 * sp + lk) * PG + 16 * tj + li] = Bop[tj][sp];
+    wave_sync();
+  }
   GAR_WMARK(4)
   // ---- factor Rhat (lane = row) under the Bunch-Kaufman rule; solve [kff | K] ---
   {
@@ -527,7 +642,21 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       for (int k = 0; k < NU; ++k)
         x[k] = G[k * PG + col];
       GAR_WMARK(11)
-      ldl_solve_regs_bcast<NU>(a_row, nd, x); // [kff | K] = -Rhat^{-1} [rhat | Shat^T]  (:248-262)
+      if (MODE == 0) {
+        ldl_solve_regs_bcast<NU>(a_row, nd, x); // [kff | K] = -Rhat^{-1} [rhat | Shat^T]  (:248-262)
+      } else {
+        const int ct = lane < NX ? lane : NX - 1; // Kth = -Rhat^{-1} Ghat_u (:288-291)
+        double y[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+          y[k] = Gt[k * PG + ct];
+        ldl_solve_regs_bcast2<NU>(a_row, nd, x, y);
+        if (lane < NX) {
+#pragma unroll
+          for (int k = 0; k < NU; ++k)
+            Gt[k * PG + ct] = y[k];
+        }
+      }
       GAR_WMARK(12)
       if (lane <= NX) {
 #pragma unroll
@@ -536,7 +665,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       }
       wave_sync();
     } else {
-      failed |= wave_slow_factor_solve<NX, NU>(sm, lane);
+      failed |= wave_slow_factor_solve<NX, NU, MODE != 0>(sm, lane);
     }
   }
   GAR_WMARK(6)
@@ -550,6 +679,19 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       Kb[tj][s] = G[(4 * s + lk) * PG + 1 + cc];
       if (16 * tj + li < NX) // fbT2(4s+lk, 16tj+li) = 8tj*2NW + 8s + [(li>>1)*2NW + 2lk + (li&1)]
         stg_b(out, M::fFB + 8 * tj * 2 * NW + 8 * s, L.fbl, Kb[tj][s]);
+    }
+  }
+  double Kthb[TX][KU]; // MODE != 0: Kth[4s'+lk][16tj+li], fth rows 0..NU-1 (same device order as fb)
+  if (MODE != 0) {
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+      const int cc = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
+#pragma unroll
+      for (int s = 0; s < KU; ++s) {
+        Kthb[tj][s] = Gt[(4 * s + lk) * PG + cc];
+        if (16 * tj + li < NX)
+          stg_b(out, C::pFTH + 8 * tj * 2 * NW + 8 * s, L.fbl, Kthb[tj][s]);
+      }
     }
   }
   // ---- kff; yff = f + B kff (:266); vx = qhat + Shat kff (:275-276) ----------------
@@ -586,9 +728,49 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
     if (lane < NU)
       out[M::fFF + lane] = G[lane * PG];
     if (lane < NX) {
-      out[M::fFF + NU + lane] = yf;
-      out[M::fvx + lane] = vxv;
+      out[M::fFF + NU + lane] = (MODE == 2) ? 0.0 : yf; // terminalSolve leaves yff untouched (zero)
+      out[ovx + lane] = vxv;
       vn[lane] = vxv;
+    }
+    if (MODE == 2) { // vt = gamma + Gu^T kff = f + B kff (:189-190)
+      if (lane < NX) {
+        vtl[lane] = yf;
+        out[C::pvt + lane] = yf;
+      }
+    }
+    if (MODE == 1) { // vt = vt' + Vxt'^T yff (:298-301): Vxt' from the operand slots, yff via LDS
+      if (lane < NX)
+        yfl[lane] = yf;
+      wave_sync();
+      double ys[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        ys[s] = yfl[4 * s + lk];
+      double pt[TX];
+#pragma unroll
+      for (int tj = 0; tj < TX; ++tj) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          if (s & 1)
+            a1 = __builtin_fma(Xt[(s * TX + tj) * 64], ys[s], a1);
+          else
+            a0 = __builtin_fma(Xt[(s * TX + tj) * 64], ys[s], a0);
+        }
+        double a = a0 + a1;
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        pt[tj] = a; // (Vxt'^T yff)[16 tj + li]
+      }
+      double st = pt[0];
+#pragma unroll
+      for (int tj = 1; tj < TX; ++tj)
+        st = (lk == tj) ? pt[tj] : st;
+      if (lane < NX) {
+        const double v = vtl[lane] + st;
+        vtl[lane] = v;
+        out[C::pvt + lane] = v;
+      }
     }
   }
   GAR_WMARK(7)
@@ -605,7 +787,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         accT[tj][r] = (r < C::KST) ? S.FoT[tj][r] : 0.0;
   }
 #pragma unroll
-  for (int s = 0; s < KU; ++s)
+  for (int s = 0; s < (MODE == 2 ? 0 : KU); ++s)
 #pragma unroll
     for (int tj = 0; tj < TX; ++tj)
 #pragma unroll
@@ -627,9 +809,101 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         if (16 * ti + 4 * r < NX) { // compile-time
           if (i < NX && j < NX) // fbT2(NU+i, j), i = 16ti+4r+lk
             stg_b(out, M::fFB + 8 * tj * 2 * NW + 2 * (NU + 16 * ti + 4 * r), L.fbl,
-                  ti < C::KSF ? S.Fo[tj][ti][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r]));
+                  MODE == 2 ? 0.0 // terminalSolve leaves the Aff rows untouched (zero)
+                            : (ti < C::KSF ? S.Fo[tj][ti][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r])));
         }
       }
+  if (MODE != 0) {
+    // ---- Yth = B Kth (:295), fth rows NU.. (MODE 2: those rows stay zero) ------------------
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < TX; ++ti) {
+        double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+        if (MODE == 1) {
+#pragma unroll
+          for (int s = 0; s < KU; ++s)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kthb[tj][s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
+          if (16 * ti + 4 * r < NX) {
+            if (i < NX && j < NX)
+              stg_b(out, C::pFTH + 8 * tj * 2 * NW + 2 * (NU + 16 * ti + 4 * r), L.fbl, acc[r]);
+          }
+        }
+      }
+    // ---- Vxt (NX x nth), one parameter column tile at a time; the new tile column replaces
+    // the old one in the lane-private operand slots once all its row tiles are done
+    //   MODE 1: Vxt = Aff^T Vxt' (:304-306): A operand = the Aff registers (operand layout of
+    //           the F they were computed on), B operand = Vxt'
+    //   MODE 2: Vxt = A^T + K^T B^T (:185-186): A operand = K as loaded for Aff, B operand = B
+    //           as loaded for Aff, accumulator initialised with A^T from the knot record
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+      double4_t nv[TX];
+#pragma unroll
+      for (int ti = 0; ti < TX; ++ti) {
+        double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+        if (MODE == 1) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            // Aff(4s+lk, 16ti+li): in place on the F operand, except the tail k-steps of a
+            // shape without the 4-row remainder tile, which sit in accT
+            const double aq = (s < 4 * C::KSF || C::REM4) ? S.fo(ti, s) : accT[ti][s - 4 * C::KSF];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Xt[(s * TX + tj) * 64], acc, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) // A^T(16ti+lk+4r, 16tj+li) = A(16tj+li, 16ti+4r+lk)
+            if (16 * ti + 4 * r < NX)
+              acc[r] = ldg_b(rec, M::kA + (16 * ti + 4 * r) * NX + (16 * tj + 15 < NX ? 16 * tj : 0),
+                             16 * tj + 15 < NX ? lkx : 8u * (unsigned)(lk * NX + ((16 * tj + li) < NX ? 16 * tj + li : NX - 1)));
+#pragma unroll
+          for (int s = 0; s < KU; ++s)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Kb[ti][s], Bop[tj][s], acc, 0, 0, 0);
+        }
+        nv[ti] = acc;
+      }
+#pragma unroll
+      for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * ti + 4 * r < NX) { // rows 16ti+4r+lk < NX: k-step 4ti+r of the next stage
+            Xt[((4 * ti + r) * TX + tj) * 64] = nv[ti][r];
+            if (16 * tj + 15 < NX || 16 * tj + li < NX) // column-major (x, theta)
+              stg_b(out, C::pVxt + 16 * tj * NX + 16 * ti + 4 * r, 8u * (unsigned)(li * NX + lk), nv[ti][r]);
+          }
+    }
+    // ---- Vtt = Gth + Vtt' + Gu^T Kth + Vxt'^T Yth (:308-310) as Vtt' + Ghat_u^T Kth; computed
+    // transposed (D' = Kth^T Ghat_u), so that the accumulator row index runs along the lanes that
+    // are contiguous in the column-major record
+#pragma unroll
+    for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TX; ++tj) {
+        double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+        if (MODE == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * ti + 4 * r < NX)
+              acc[r] = Tt[((4 * ti + r) * TX + tj) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < KU; ++s)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(
+              Kthb[ti][s], MODE == 1 ? Gh[C::shTile(s) - shLoT][tj][C::shReg(s)] : Bop[tj][s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * ti + 4 * r < NX) {
+            Tt[((4 * ti + r) * TX + tj) * 64] = acc[r];
+            // D'(i, j) = Vtt(j, i): column-major element (j, i) at i*NX + j
+            if (16 * tj + 15 < NX || 16 * tj + li < NX)
+              stg_b(out, C::pVtt + (16 * ti + 4 * r) * NX + 16 * tj, lkx, acc[r]);
+          }
+      }
+  }
   // ---- knot t-1: the F operands and vectors go into the registers Aff just released
   wave_load_a<NX, NU>(recn, L, S);
   GAR_WMARK(8)
@@ -711,7 +985,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
     for (int q = 0; q < NCH; ++q) {
       const int e = 64 * q + lane;
       if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
-        *reinterpret_cast<double2_t *>(&out[M::fVxx + 2 * e]) = vbuf[q];
+        *reinterpret_cast<double2_t *>(&out[oVxx + 2 * e]) = vbuf[q];
     }
   }
   GAR_WMARK(10)

@@ -1,0 +1,575 @@
+// gar_wave_leg.hpp -- the parallel-in-time (leg) sweeps of ParallelRiccatiSolver
+// (gar/parallel-solver.hxx:131-240) for uniform unconstrained problems, at the speed of
+// the one-wave-per-problem kernels of gar_wave.hpp: ONE WAVE PER (problem, leg).
+//
+//   backward: non-final legs run the parameterised recursion (nth = NX, the costate of the next
+//             leg's first state is the parameter): the leg-end knot through wave_stage<2>
+//             (terminalSolve under configure_knot), every other stage through wave_stage<1>
+//             (stageKernelSolve + :278-311); the final leg is the plain recursion
+//             (wave_stage<0>) down from the true terminal knot.  Parallelism comes from the legs:
+//             a single long-horizon problem occupies num_legs SIMDs instead of one.
+//   tuples  : (Vxx, Vxt, Vtt, vx, vt) of every leg's first stage -> the boundary buffer that the
+//             all-gather / condensed solve consume.
+//   forward : the closed-loop roll-out of a leg from the condensed solution; theta (constant
+//             along the leg) is held in scalar registers, so its terms (Kth theta, Yth theta,
+//             Vxt' theta) are independent FMAs beside the state recursion, not extra latency.
+#pragma once
+#include "gar_generic.hpp"
+#include "gar_wave.hpp"
+
+namespace gar {
+
+struct LegParams {
+  MfmaParams M;            // prob, fac, status, strides, in_off0/in_rec/in_offN, horizon
+  const gar_stage_meta *meta;
+  int num_legs, leg_begin; // this launch covers legs leg_begin + blockIdx.x
+  // forward
+  const double *csol;      // condensed solution [problem][2*num_legs][NX]
+  double *sol;
+  long long sol_stride;
+  int sol_u, sol_l, nc0;
+  // tuples
+  double *boundary;        // [problem][local leg][tuple]
+  long long boundary_stride;
+  int tuple_doubles;
+};
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(64, 1) gar_backward_wave_leg(LegParams Q) {
+  using C = WaveCfg<NX, NU>;
+  using M = MfmaCfg<NX, NU>;
+  constexpr int PK = C::PK;
+  const int lane = (int)threadIdx.x & 63;
+  const int leg = (int)blockIdx.x + Q.leg_begin;
+  const int b = (int)blockIdx.y;
+  double *sm = gar_smem;
+  MfmaParams P = Q.M;
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  const int N = P.horizon;
+  int t_beg, t_end;
+  gar_get_work(N, leg, Q.num_legs, &t_beg, &t_end);
+  const bool last_leg = (leg == Q.num_legs - 1);
+  // factor records are uniform inside a leg: stage t at fac0 + t * fac_rec
+  P.fac_rec = last_leg ? (long long)(M::fvx + NX) : (long long)C::prec;
+  P.fac_rec = (P.fac_rec + 1) & ~1ll;
+  double *fac = P.fac + (long long)b * P.fac_stride + Q.meta[t_beg].fac_off - (long long)t_beg * P.fac_rec;
+  double *V = sm + C::oV, *vn = sm + C::oVn;
+  const bool tracing = false;
+  WaveLane<NX, NU> L;
+  wave_lane_init<NX, NU>(L, lane);
+  WaveStage<NX, NU> S;
+  int failed = 0;
+  if (last_leg) {
+    // ---- true terminal knot (terminalSolve, nu = 0, nc = 0, :175-178): Vxx = Q, vx = q
+    const int t1 = N - 1 >= t_beg ? N - 1 : t_beg;
+    if (N - 1 >= t_beg) {
+      wave_load_a<NX, NU>(prob + P.in_off0 + (long long)t1 * P.in_rec, L, S);
+      wave_load_b<NX, NU>(prob + P.in_off0 + (long long)t1 * P.in_rec, L, S);
+    }
+    {
+      const double *rec = prob + P.in_offN;
+      double *out = P.fac + (long long)b * P.fac_stride + Q.meta[N].fac_off;
+      for (int e = lane; e < NX * NX; e += 64) {
+        const int j = e / NX, i = e - j * NX;
+        const double v = (i >= j) ? rec[M::tQ + e] : rec[M::tQ + i * NX + j];
+        V[i * PK + j] = v;
+        out[M::tVxx + e] = v;
+      }
+      if (lane < NX) {
+        const double v = rec[M::tq + lane];
+        vn[lane] = v;
+        out[M::tvx + lane] = v;
+      }
+    }
+    wave_sync();
+    for (int t = N - 1; t >= t_beg; --t)
+      wave_stage<NX, NU, 0>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+  } else {
+    const int te = t_end - 1;
+    wave_load_a<NX, NU>(prob + P.in_off0 + (long long)te * P.in_rec, L, S);
+    wave_load_b<NX, NU>(prob + P.in_off0 + (long long)te * P.in_rec, L, S);
+    wave_stage<NX, NU, 2>(P, sm, prob, fac, te, lane, L, S, failed, tracing);
+    for (int t = te - 1; t >= t_beg; --t)
+      wave_stage<NX, NU, 1>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+  }
+  if (failed && lane == 0)
+    atomicOr(&P.status[b], failed);
+}
+
+// (Vxx | Vxt | Vtt | vx | vt) of each local leg's first stage, blocks of NX
+template <int NX, int NU>
+__global__ void __launch_bounds__(256) gar_leg_tuples(LegParams Q) {
+  using C = WaveCfg<NX, NU>;
+  using M = MfmaCfg<NX, NU>;
+  const int leg = (int)blockIdx.x + Q.leg_begin;
+  const int b = (int)blockIdx.y;
+  int t_beg, t_end;
+  gar_get_work(Q.M.horizon, leg, Q.num_legs, &t_beg, &t_end);
+  const bool last_leg = (leg == Q.num_legs - 1);
+  const double *rec = Q.M.fac + (long long)b * Q.M.fac_stride + Q.meta[t_beg].fac_off;
+  double *tup = Q.boundary + (long long)b * Q.boundary_stride + (long long)blockIdx.x * Q.tuple_doubles;
+  const bool term = (t_beg == Q.M.horizon); // a leg made of the terminal knot alone
+  const int oVxx = last_leg ? (term ? M::tVxx : M::fVxx) : C::pVxx;
+  const int ovx = last_leg ? (term ? M::tvx : M::fvx) : C::pvx;
+  constexpr int bs = NX * NX;
+  for (int e = (int)threadIdx.x; e < bs; e += (int)blockDim.x) {
+    tup[e] = rec[oVxx + e];
+    tup[bs + e] = last_leg ? 0.0 : rec[C::pVxt + e];
+    tup[2 * bs + e] = last_leg ? 0.0 : rec[C::pVtt + e];
+  }
+  for (int e = (int)threadIdx.x; e < NX; e += (int)blockDim.x) {
+    tup[3 * bs + e] = rec[ovx + e];
+    tup[3 * bs + NX + e] = last_leg ? 0.0 : rec[C::pvt + e];
+  }
+}
+
+// collapseFeedback (parallel-solver.hpp:41-51) on the device order of this kernel family:
+// K0 -= Kth0 * Vxt(0)^T on the factor record of stage 0
+template <int NX, int NU>
+__global__ void gar_collapse_feedback_t2(const gar_stage_meta *meta, double *fac,
+                                         long long fac_stride, int batch) {
+  using C = WaveCfg<NX, NU>;
+  using M = MfmaCfg<NX, NU>;
+  const int b = (int)blockIdx.x;
+  if (b >= batch || meta[0].nth == 0)
+    return;
+  double *rec = fac + (long long)b * fac_stride + meta[0].fac_off;
+  for (int e = (int)threadIdx.x; e < NU * NX; e += (int)blockDim.x) {
+    const int i = e / NX, j = e - i * NX;
+    double s = 0.0;
+    for (int k = 0; k < NX; ++k)
+      s += rec[C::pFTH + M::fbT2(i, k)] * rec[C::pVxt + k * NX + j];
+    rec[M::fFB + M::fbT2(i, j)] -= s;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Condensed (leg-boundary) system, one WAVE per problem, blocks of NX resident in LDS.
+// Same elimination as gar_condensed_generic / the reference (assembleCondensedSystem,
+// parallel-solver.hxx:85-129; symmetricBlockTridiagSolve, block-tridiagonal.hpp:82-138):
+// up-looking from the last block, D_i <- D_i - B_i D_{i+1}^{-1} B_i^T, then the down sweep.
+// What changes is how a block step runs:
+//   * D is factorised in registers (lane = row; unpivoted LDL^T while the first Bunch-Kaufman
+//     test holds at every column -- then it IS Bunch-Kaufman's factorisation; otherwise the
+//     generic device Bunch-Kaufman takes over for that block) and W = D^{-1} is formed once
+//     (lane = column of the identity); every later use of the factorisation -- the right-hand
+//     side, U = D^{-1} B^T, the refinement sweeps -- is a product with W;
+//   * the coupling blocks that are -I by construction (super[2k+2], parallel-solver.hxx:105)
+//     are not multiplied: U = -W and D_i <- D_i - W, which is what the products evaluate to;
+//   * U = W B^T and D_i -= B U run on v_mfma_f64_16x16x4 tiles straight from LDS.
+// The chain is serial in the block index (2*num_legs steps); everything inside a step is
+// wave-parallel.  LDS: 4 blocks + the solution vector.
+// ---------------------------------------------------------------------------------------------
+template <int NX>
+__global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
+  constexpr int bs = NX * NX;
+  const int lane = (int)threadIdx.x & 63;
+  const int b = (int)blockIdx.x;
+  const WG w1 = wave_self();
+  double *sm = gar_smem;
+  const int nblk = 2 * P.num_legs, N = nblk - 1;
+  double *Dm = sm, *Wm = sm + bs, *Bm = sm + 2 * bs, *Um = sm + 3 * bs;
+  double *bsub = sm + 4 * bs;                 // Bunch-Kaufman fallback: sub | piv, ctrl
+  int *bpiv = (int *)(bsub + NX + (NX & 1));
+  double *solv = bsub + NX + (NX & 1) + (NX + 16) / 2 + 2; // [nblk][NX]
+  double *errv = solv + nblk * NX;                         // [nblk][NX]
+  double *S = P.scratch + (long long)b * P.scratch_stride;
+  double *Wall = S + 2ll * nblk * bs, *Uall = S + 3ll * nblk * bs; // the facD / U slots
+  double *info = S + 4ll * nblk * bs + 4ll * nblk * NX;
+  double *sol = P.csol + (long long)b * nblk * NX;
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  const int nc0 = P.nc0;
+  const int row = lane < NX ? lane : NX - 1;
+  int failed = 0;
+
+  // right-hand side (assembleCondensedSystem, :118-128); block 0 padded to NX with zeros
+  for (int e = lane; e < NX; e += 64)
+    solv[e] = e < nc0 ? -prob[P.g0_off + e] : 0.0;
+  for (int leg = 0; leg < P.num_legs; ++leg) {
+    const double *tup = cond_tuple(P, b, leg);
+    if (lane < NX) {
+      solv[(2 * leg + 1) * NX + lane] = -tup[3 * bs + lane];
+      if (leg + 1 < P.num_legs)
+        solv[(2 * leg + 2) * NX + lane] = -tup[3 * bs + NX + lane];
+    }
+  }
+  // D of the last block: Vxx of the last leg
+  {
+    const double *tup = cond_tuple(P, b, P.num_legs - 1);
+    for (int e = lane; e < bs; e += 64)
+      Dm[e] = tup[e];
+  }
+  wave_sync();
+
+  // one pass of "x_ib <- W_ib x_ib ; x_i -= B_i x_ib" uses these two helpers (lane = row)
+  auto matvec = [&](const double *Mcol, double x) { // sum_k M(row, k) x_k, M column-major
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; k += 2) {
+      s0 = __builtin_fma(Mcol[k * NX + row], lane_bcast(x, k), s0);
+      s1 = __builtin_fma(Mcol[(k + 1) * NX + row], lane_bcast(x, k + 1), s1);
+    }
+    return s0 + s1;
+  };
+  auto matvecT = [&](const double *Mcol, double x) { // sum_k M(k, row) x_k
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; k += 2) {
+      s0 = __builtin_fma(Mcol[row * NX + k], lane_bcast(x, k), s0);
+      s1 = __builtin_fma(Mcol[row * NX + k + 1], lane_bcast(x, k + 1), s1);
+    }
+    return s0 + s1;
+  };
+  // the coupling block B_i = super[i] (rows: block i, columns: block i+1) into Bm, column-major,
+  // zero-padded; returns 1 if it is -I (nothing loaded)
+  auto load_coupling = [&](int i) -> int {
+    if (i >= 2 && (i & 1) == 0)
+      return 1;
+    if (i == 0) { // G0: nc0 x NX
+      for (int e = lane; e < bs; e += 64) {
+        const int j = e / NX, r = e - j * NX;
+        Bm[e] = r < nc0 ? prob[P.G0_off + j * nc0 + r] : 0.0;
+      }
+    } else { // Vxt of leg (i-1)/2
+      const double *tup = cond_tuple(P, b, (i - 1) >> 1);
+      for (int e = lane; e < bs; e += 64)
+        Bm[e] = tup[bs + e];
+    }
+    return 0;
+  };
+
+  // ---- up-looking elimination -------------------------------------------------------------
+  for (int ib = N; ib >= 0; --ib) {
+    const int n = ib == 0 ? nc0 : NX;
+    if (ib == 0) { // pad the nc0 x nc0 block with an identity
+      for (int e = lane; e < bs; e += 64) {
+        const int j = e / NX, r = e - j * NX;
+        if (r >= n || j >= n)
+          Dm[e] = (r == j) ? 1.0 : 0.0;
+      }
+      wave_sync();
+    }
+    {
+      double a_row[NX], nd[NX];
+      const int verdict = wave_ldl_fast<NX>(Dm, lane, a_row, nd);
+      if (verdict == 0) {
+        double x[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+          x[k] = (k == lane) ? 1.0 : 0.0;
+        ldl_solve_regs_bcast<NX>(a_row, nd, x); // -D^{-1} e_lane
+        if (lane < NX) {
+#pragma unroll
+          for (int k = 0; k < NX; ++k)
+            Wm[lane * NX + k] = -x[k];
+        }
+      } else {
+        for (int e = lane; e < bs; e += 64) {
+          const int j = e / NX, r = e - j * NX;
+          Wm[e] = (r == j) ? 1.0 : 0.0;
+        }
+        wave_sync();
+        failed |= wg_bk_factor(w1, NX, Dm, NX, bsub, bpiv, bpiv + NX + 8);
+        wg_bk_solve(w1, NX, Dm, NX, bsub, bpiv, Wm, 1, NX, NX);
+      }
+    }
+    wave_sync();
+    for (int e = lane; e < bs; e += 64)
+      Wall[(long long)ib * bs + e] = Wm[e];
+    // x_ib <- D^{-1} x_ib
+    const double xb = matvec(Wm, solv[ib * NX + row]);
+    if (lane < NX)
+      solv[ib * NX + lane] = xb;
+    if (ib == 0)
+      break;
+    const int i = ib - 1;
+    const int negI = load_coupling(i);
+    // D_i of the next step: the original diagonal block ...
+    if (i == 0) {
+      for (int e = lane; e < bs; e += 64)
+        Dm[e] = 0.0; // -mudyn I with mudyn = 0 (:93-94, :165)
+    } else {
+      const double *tup = cond_tuple(P, b, (i - 1) >> 1);
+      const int off = (i & 1) ? 0 : 2 * bs; // odd: Vxx(leg) ; even: Vtt(leg)
+      for (int e = lane; e < bs; e += 64)
+        Dm[e] = tup[off + e];
+    }
+    wave_sync();
+    if (negI) {
+      // x_i -= (-I) x_ib ; U_i = -W ; D_i -= (-I)(-W)
+      if (lane < NX)
+        solv[i * NX + lane] += xb;
+      for (int e = lane; e < bs; e += 64) {
+        const double wv = Wm[e];
+        Uall[(long long)i * bs + e] = -wv;
+        Dm[e] -= wv;
+      }
+    } else {
+      const double xi = solv[i * NX + row] - matvec(Bm, xb);
+      if (lane < NX)
+        solv[i * NX + lane] = xi;
+      // U_i = W B^T (NX x NX; columns >= dim(i) are zero) ; D_i -= B U_i
+      wg_gemm(w1, NX, NX, NX, colmajor(Wm, NX), colmajor(Bm, NX).T(), MatV{nullptr, 0, 0},
+              colmajor(Um, NX), 1.0);
+      wave_sync();
+      wg_gemm(w1, NX, NX, NX, colmajor(Bm, NX), colmajor(Um, NX), colmajor(Dm, NX),
+              colmajor(Dm, NX), -1.0);
+      for (int e = lane; e < bs; e += 64)
+        Uall[(long long)i * bs + e] = Um[e];
+    }
+    wave_sync();
+  }
+  // ---- down sweep: x_{i+1} -= U_i x_i  (:131-134) -----------------------------------------------
+  __threadfence_block();
+  for (int i = 0; i < N; ++i) {
+    const double xi = solv[i * NX + row];
+    double s0 = 0.0, s1 = 0.0;
+    const double *Ug = Uall + (long long)i * bs;
+#pragma unroll
+    for (int k = 0; k < NX; k += 2) {
+      s0 = __builtin_fma(Ug[k * NX + row], lane_bcast(xi, k), s0);
+      s1 = __builtin_fma(Ug[(k + 1) * NX + row], lane_bcast(xi, k + 1), s1);
+    }
+    if (lane < NX)
+      solv[(i + 1) * NX + lane] -= s0 + s1;
+    wave_sync();
+  }
+
+  // ---- iterative refinement (parallel-solver.hxx:184-202; residual against the true
+  // right-hand side, as gar_condensed_generic) ----------------------------------------------------
+  int steps = 0;
+  double resdl = 0.0;
+  for (int it = 0; it < P.max_refinement; ++it) {
+    // err = rhs - A sol, block row by block row (blockTridiagMatMul, :52-75)
+    double mx = 0.0;
+    for (int i = 0; i <= N; ++i) {
+      const double xi = solv[i * NX + row];
+      double r;
+      if (i == 0) {
+        r = row < nc0 ? -prob[P.g0_off + row] : 0.0; // D_0 = 0
+      } else {
+        const double *tup = cond_tuple(P, b, (i - 1) >> 1);
+        const int off = (i & 1) ? 0 : 2 * bs;
+        r = -tup[3 * bs + ((i & 1) ? 0 : NX) + row] - matvec(tup + off, xi);
+      }
+      if (i > 0) { // sub[i-1] = super[i-1]^T applied to x_{i-1}
+        const double xp = solv[(i - 1) * NX + row];
+        if (i - 1 == 0) {
+          double s = 0.0;
+          for (int k = 0; k < nc0; ++k)
+            s += prob[P.G0_off + row * nc0 + k] * lane_bcast(xp, k);
+          r -= s;
+        } else if (((i - 1) & 1) == 0) {
+          r += xp;
+        } else {
+          r -= matvecT(cond_tuple(P, b, (i - 2) >> 1) + bs, xp);
+        }
+      }
+      if (i < N) { // super[i] applied to x_{i+1}
+        const double xn = solv[(i + 1) * NX + row];
+        if (i == 0) {
+          double s = 0.0;
+          for (int k = 0; k < NX; ++k)
+            s += (row < nc0 ? prob[P.G0_off + k * nc0 + row] : 0.0) * lane_bcast(xn, k);
+          r -= s;
+        } else if ((i & 1) == 0) {
+          r += xn;
+        } else {
+          r -= matvec(cond_tuple(P, b, (i - 1) >> 1) + bs, xn);
+        }
+      }
+      if (lane >= NX || (i == 0 && lane >= nc0))
+        r = 0.0;
+      if (lane < NX)
+        errv[i * NX + lane] = r;
+      const double av = fabs(r);
+      mx = (av > mx || av != av) ? av : mx;
+    }
+    // infinity norm over the wave
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const double other = __shfl_xor(mx, o);
+      mx = (other > mx || other != other) ? other : mx;
+    }
+    resdl = mx;
+    wave_sync();
+    if (resdl <= P.threshold)
+      break;
+    // blockTridiagRefinementStep (:147-182) with the stored W and U
+    for (int ib = N; ib >= 0; --ib) {
+      const double eb = matvec(Wall + (long long)ib * bs, errv[ib * NX + row]);
+      if (lane < NX)
+        errv[ib * NX + lane] = eb;
+      if (ib == 0)
+        break;
+      const int i = ib - 1;
+      double ei = errv[i * NX + row];
+      if (i >= 2 && (i & 1) == 0) {
+        ei += eb;
+      } else if (i == 0) {
+        double s = 0.0;
+        for (int k = 0; k < NX; ++k)
+          s += (row < nc0 ? prob[P.G0_off + k * nc0 + row] : 0.0) * lane_bcast(eb, k);
+        ei -= s;
+      } else {
+        ei -= matvec(cond_tuple(P, b, (i - 1) >> 1) + bs, eb);
+      }
+      if (lane < NX)
+        errv[i * NX + lane] = ei;
+      wave_sync();
+    }
+    for (int i = 0; i < N; ++i) {
+      const double s = matvec(Uall + (long long)i * bs, errv[i * NX + row]);
+      if (lane < NX)
+        errv[(i + 1) * NX + lane] -= s;
+      wave_sync();
+    }
+    for (int e = lane; e < nblk * NX; e += 64)
+      solv[e] += errv[e];
+    steps = it + 1;
+    wave_sync();
+  }
+  for (int e = lane; e < nblk * NX; e += 64)
+    sol[e] = solv[e];
+  if (lane == 0) {
+    info[0] = resdl;
+    info[1] = (double)steps;
+    if (failed)
+      atomicOr(&P.status[b], 4);
+  }
+}
+
+// ---- forward roll-out of one leg (parallel-solver.hxx:215-240 around forwardImpl,
+// riccati-kernel.hxx:314-377) ---------------------------------------------------------------
+template <int NX> struct LegFwdStage {
+  double2_t g[NX / 2];  // [K; Aff] row r
+  double2_t gt[NX / 2]; // [Kth; Yth] row r
+  double vrow[NX];      // Vxx' row iv
+  double trow[NX];      // Vxt' row iv
+  double ff, vxn;
+};
+
+template <int NX, int NU, bool PARAM>
+__device__ __forceinline__ void leg_fwd_load(const double *rec, const double *recn, int oVn, int ovn,
+                                             int r, int iv, bool with_next, LegFwdStage<NX> &S) {
+  using C = WaveCfg<NX, NU>;
+  using M = MfmaCfg<NX, NU>;
+  constexpr int NW = C::NW;
+#pragma unroll
+  for (int m = 0; m < NX / 2; ++m) {
+    S.g[m] = *reinterpret_cast<const double2_t *>(rec + M::fFB + m * 2 * NW + 2 * r);
+    if (PARAM)
+      S.gt[m] = *reinterpret_cast<const double2_t *>(rec + C::pFTH + m * 2 * NW + 2 * r);
+  }
+  S.ff = rec[M::fFF + r];
+  if (with_next) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      S.vrow[j] = recn[oVn + j * NX + iv]; // symmetric: column j, row iv
+      if (PARAM)
+        S.trow[j] = recn[C::pVxt + j * NX + iv];
+    }
+    S.vxn = recn[ovn + iv];
+  }
+}
+
+template <int NX, int NU, bool PARAM>
+__global__ void __launch_bounds__(64) gar_forward_wave_leg(LegParams Q) {
+  using C = WaveCfg<NX, NU>;
+  using M = MfmaCfg<NX, NU>;
+  constexpr int NW = C::NW;
+  const int lane = (int)threadIdx.x;
+  // PARAM kernels cover the non-final legs, the other instantiation the final leg
+  const int leg = PARAM ? (int)blockIdx.x + Q.leg_begin : Q.num_legs - 1;
+  const int b = (int)blockIdx.y;
+  const int N = Q.M.horizon;
+  int t_beg, t_end;
+  gar_get_work(N, leg, Q.num_legs, &t_beg, &t_end);
+  if (PARAM && leg >= Q.num_legs - 1)
+    return;
+  const double *facb = Q.M.fac + (long long)b * Q.M.fac_stride;
+  double *sol = Q.sol + (long long)b * Q.sol_stride;
+  const double *cs = Q.csol + (long long)b * (2 * Q.num_legs) * NX;
+  const long long frec = ((PARAM ? (long long)C::prec : (long long)(M::fvx + NX)) + 1) & ~1ll;
+  const double *fac = facb + Q.meta[t_beg].fac_off - (long long)t_beg * frec;
+  const int r = lane < NW ? lane : NW - 1;
+  const int iv = lane < NX ? lane : NX - 1;
+  const int ix = (lane >= NU && lane < NW) ? lane - NU : 0;
+  // scatter of the condensed solution (:215-220): lbdas[t_beg], xs[t_beg]
+  double xs = cs[(2 * leg + 1) * NX + ix];
+  if (lane >= NU && lane < NW)
+    sol[(long long)t_beg * NX + ix] = xs;
+  {
+    const int nl0 = (leg == 0) ? Q.nc0 : NX;
+    const long long lo = (leg == 0) ? Q.sol_l : Q.sol_l + Q.nc0 + (long long)(t_beg - 1) * NX;
+    for (int e = lane; e < nl0; e += 64)
+      sol[lo + e] = cs[(2 * leg) * NX + e];
+  }
+  // theta = lbdas[t_end] = the next leg's first costate (:234-236), kept wave-uniform
+  double th[NX];
+  if (PARAM) {
+    const double tv = cs[(2 * (leg + 1)) * NX + iv];
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+      th[k] = lane_bcast(tv, k);
+  }
+  const int oVxx = PARAM ? C::pVxx : M::fVxx, ovx = PARAM ? C::pvx : M::fvx;
+  for (int t = t_beg; t < t_end; ++t) {
+    const bool last = (t == t_end - 1);
+    if (!PARAM && t == N)
+      break; // the terminal knot has no controls
+    const double *rec = fac + (long long)t * frec;
+    // the knot after t inside this leg (the final leg ends on the terminal knot's record)
+    const bool next_is_term = (!PARAM && t + 1 == N);
+    const double *recn = next_is_term ? facb + Q.meta[N].fac_off : rec + frec;
+    LegFwdStage<NX> S;
+    leg_fwd_load<NX, NU, PARAM>(rec, recn, next_is_term ? M::tVxx : oVxx, next_is_term ? M::tvx : ovx,
+                                r, iv, !last, S);
+    // u = kff + K x + Kth theta ; x' = yff + Aff x + Yth theta  (:334-336, :360-361)
+    double acc = S.ff, acc1 = 0.0;
+#pragma unroll
+    for (int m = 0; m < NX / 2; ++m) {
+      acc = __builtin_fma(S.g[m].x, lane_bcast(xs, NU + 2 * m), acc);
+      acc1 = __builtin_fma(S.g[m].y, lane_bcast(xs, NU + 2 * m + 1), acc1);
+    }
+    if (PARAM) {
+      double a2 = 0.0, a3 = 0.0;
+#pragma unroll
+      for (int m = 0; m < NX / 2; ++m) {
+        a2 = __builtin_fma(S.gt[m].x, th[2 * m], a2);
+        a3 = __builtin_fma(S.gt[m].y, th[2 * m + 1], a3);
+      }
+      acc1 += a2 + a3;
+    }
+    acc += acc1;
+    if (lane < NU)
+      sol[Q.sol_u + (long long)t * NU + lane] = acc;
+    if (last)
+      break;
+    if (lane >= NU && lane < NW)
+      sol[(long long)(t + 1) * NX + (lane - NU)] = acc;
+    // lbd' = vx' + Vxx' x' + Vxt' theta  (:369-374)
+    double lam = S.vxn, lam1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; j += 2) {
+      lam = __builtin_fma(S.vrow[j], lane_bcast(acc, NU + j), lam);
+      lam1 = __builtin_fma(S.vrow[j + 1], lane_bcast(acc, NU + j + 1), lam1);
+    }
+    if (PARAM) {
+      double l2 = 0.0, l3 = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; j += 2) {
+        l2 = __builtin_fma(S.trow[j], th[j], l2);
+        l3 = __builtin_fma(S.trow[j + 1], th[j + 1], l3);
+      }
+      lam1 += l2 + l3;
+    }
+    lam += lam1;
+    if (lane < NX)
+      sol[Q.sol_l + Q.nc0 + (long long)t * NX + lane] = lam;
+    xs = acc;
+  }
+}
+
+} // namespace gar

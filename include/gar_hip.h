@@ -174,6 +174,9 @@ int gar_hip_condensed_solve_async(gar_hip_solver *s);              /* :169-202 *
 int gar_hip_forward_legs_async(gar_hip_solver *s);                 /* :209-243 */
 /* refinement controls (parallel-solver.hpp:92-94) */
 int gar_hip_set_refinement(gar_hip_solver *s, double condensed_threshold, int max_steps);
+/* outcome of the last condensed solve of problem b: out[0] = infinity norm of the last residual
+ * evaluated (the quantity parallel-solver.hxx:191 tests), out[1] = refinement steps taken */
+int gar_hip_condensed_info(gar_hip_solver *s, int b, double out[2]);
 
 /* ---- results (HBM -> host) ------------------------------------------------ */
 /* packed solution of problem b: xs | us | vs | lbdas (per-stage offsets from

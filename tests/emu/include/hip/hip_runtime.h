@@ -147,6 +147,7 @@ inline void __builtin_amdgcn_wave_barrier() {
   emu::wave().bar.arrive_and_wait();
 }
 #define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
+inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 inline long long clock64() { return 0; }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)

@@ -83,6 +83,23 @@ def test_parallel_solver_class(nthreads, horz, nx, nu):       # tests/gar/parall
     pc.check_parallel(prob, 1e-9, nthreads, 1e-7, EMU, rounds=1, rng=rng)
 
 
+@pytest.mark.parametrize("nthreads,horz,nx,nu", [(3, 11, 8, 4), (2, 7, 12, 4), (4, 9, 16, 8)])
+def test_parallel_wave_leg_kernels(nthreads, horz, nx, nu):
+    """Uniform unconstrained shapes in leg mode run the one-wave-per-(problem, leg) kernels
+    (csrc/gar_wave_leg.hpp): parameterised recursion, leg-end knot, tuples, leg roll-out."""
+    from aligator_amd.gar import ParallelRiccatiSolver
+    rng = np.random.default_rng(23)
+    prob = synth.generate_lq_problem(rng, np.zeros(nx), horz, nx, nu, mode="W")
+    par = pc.check_parallel(prob, 1e-10, nthreads, 1e-9, EMU, rounds=1, rng=rng)
+    assert par._impl.kernel_name.startswith("wave_leg<")
+
+
+def test_parallel_wave_leg_batched():
+    probs = [synth.generate_lq_problem(300 + i, np.zeros(8), 9, 8, 4, mode="W") for i in range(3)]
+    s = pc.check_batched(probs, 1e-10, 1e-9, EMU, num_legs=3)
+    assert s.kernel_name.startswith("wave_leg<")
+
+
 def test_parallel_rejects_single_thread():                    # parallel-solver.hxx:42-46
     from aligator_amd.gar import ParallelRiccatiSolver
     prob = synth.generate_lq_problem(1, np.zeros(2), 4, 2, 2)
