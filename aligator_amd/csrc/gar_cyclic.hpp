@@ -1,0 +1,557 @@
+// gar_cyclic.hpp -- the condensed (leg-boundary) system of ParallelRiccatiSolver solved by
+// BLOCK CYCLIC REDUCTION: O(log J) dependent steps instead of the 2J-step elimination chain of
+// symmetricBlockTridiagSolve (gar/block-tridiagonal.hpp:82-138), so that the number of legs (and
+// with it the parallelism of the leg sweeps) is no longer paid for in the condensed solve.
+//
+// The system (assembleCondensedSystem, parallel-solver.hxx:85-129), unknowns (lambda_k, x_k) per
+// leg k = 0..J-1 (lambda_0: multiplier of the initial condition):
+//     lambda_0 row :  G0 x_0                                              = -g0
+//     x_k row      :  E_k^T lambda_k + Vxx_k x_k + Vxt_k lambda_{k+1}    = -vx_k    (E_0 = G0, else -I)
+//     lambda_{k+1} :  Vxt_k^T x_k + Vtt_k lambda_{k+1} - x_{k+1}         = -vt_k
+//  1. setup (one wave per leg, all legs at once): Vxx_k is positive definite, so every x_k is
+//     eliminated first.  With P = Vxx^{-1}, Q = P Vxt, p = P vx this leaves a block-tridiagonal
+//     system in the multipliers alone,
+//         S_0 = -G0 P_0 G0^T                         S_{k+1} = Vtt_k - Vxt_k^T Q_k - P_{k+1}
+//         C_0 = -G0 Q_0  (row 0, column 1)           C_k     = Q_k                    (k >= 1)
+//         r_0 = -g0 + G0 p_0                         r_{k+1} = -vt_k + Vxt_k^T p_k - p_{k+1}
+//     whose diagonal blocks are negative definite (-P_{k+1} < 0, the rest <= 0), as are all their
+//     Schur complements: any elimination order is safe.
+//  2. reduce, level h = 1, 2, 4, ...: the blocks at odd multiples of h are eliminated; every
+//     survivor i (multiple of 2h) folds in its two eliminated neighbours,
+//         S_i -= C_i W_{i+h} C_i^T + C_{i-h}^T W_{i-h} C_{i-h}         (W_j = S_j^{-1})
+//         C_i <- -C_i W_{i+h} C_{i+h}     r_i -= C_i W_{i+h} r_{i+h} + C_{i-h}^T W_{i-h} r_{i-h}
+//     one wave per survivor, ONE launch per level, no wave writes what another reads in the
+//     same level (a survivor inverts both neighbours itself).
+//  3. back-substitution + recovery of the states (one workgroup per problem):
+//         z_0 = S_0^{-1} r_0 ;  z_j = W_j (r_j - Cl_j^T z_{j-h} - C_j z_{j+h})  level by level;
+//         x_k = -p_k - P_k E_k^T lambda_k - Q_k lambda_{k+1};
+//     then the residual of the ORIGINAL system (the quantity parallel-solver.hxx:191 tests); if
+//     it exceeds the threshold the problem is flagged and the elimination-chain kernel
+//     (gar_condensed_wave, with the reference's iterative refinement) re-solves it.
+// Arithmetic differs from the reference's elimination order; parity is to the stated fp64
+// tolerance, checked by the same residual the reference checks.
+#pragma once
+#include "gar_wave_leg.hpp"
+
+namespace gar {
+
+struct CyclicParams {
+  CondensedParams C; // tuples, problems, scratch, csol, status, dims
+  int h;             // reduction level stride
+  int *flag;         // per problem: 1 = residual above threshold, re-solve with the chain kernel
+};
+
+// scratch carve (doubles, per problem), J = num_legs, bs = NX*NX; fits in the 8*J*bs + ... of the
+// elimination-chain kernel's scratch
+template <int NX> struct CyclicScratch {
+  static constexpr int bs = NX * NX;
+  double *P, *Q, *S, *C, *W, *Cl, *r, *z, *p, *info;
+  __device__ CyclicScratch(double *base, int J) {
+    P = base;
+    Q = P + (long long)J * bs;
+    S = Q + (long long)J * bs;
+    C = S + (long long)J * bs;
+    W = C + (long long)J * bs;
+    Cl = W + (long long)J * bs;
+    r = Cl + (long long)J * bs;
+    z = r + (long long)J * NX;
+    p = z + (long long)J * NX;
+    info = base + 8ll * J * bs + 8ll * J * NX; // same slot as the chain kernel's
+  }
+};
+
+template <int NX> __device__ __forceinline__ double cyc_matvec(const double *Mc, double x, int row) {
+  double s0 = 0.0, s1 = 0.0; // sum_k M(row, k) x_k, M column-major pitch NX
+#pragma unroll
+  for (int k = 0; k < NX; k += 2) {
+    s0 = __builtin_fma(Mc[k * NX + row], lane_bcast(x, k), s0);
+    s1 = __builtin_fma(Mc[(k + 1) * NX + row], lane_bcast(x, k + 1), s1);
+  }
+  return s0 + s1;
+}
+template <int NX> __device__ __forceinline__ double cyc_matvecT(const double *Mc, double x, int row) {
+  double s0 = 0.0, s1 = 0.0; // sum_k M(k, row) x_k
+#pragma unroll
+  for (int k = 0; k < NX; k += 2) {
+    s0 = __builtin_fma(Mc[row * NX + k], lane_bcast(x, k), s0);
+    s1 = __builtin_fma(Mc[row * NX + k + 1], lane_bcast(x, k + 1), s1);
+  }
+  return s0 + s1;
+}
+
+// LDS plan of the setup / reduce kernels (one wave)
+template <int NX> struct CyclicLds {
+  static constexpr int bs = NX * NX;
+  static constexpr int oD = 0, oW = bs, oB = 2 * bs, oM = 3 * bs, oD2 = 4 * bs, oT = 5 * bs,
+                       oDl = oT + 16 * NX, oSub = oDl + NX, oPiv = oSub + NX + (NX & 1),
+                       total = oPiv + (NX + 16) / 2 + 4;
+};
+
+// W = D^{-1} of the symmetric block in Dm (lower triangle read): register LDL^T + blocked inverse
+// while the first Bunch-Kaufman test holds at every column, the generic device Bunch-Kaufman
+// otherwise.  Returns 1 on an exactly singular block.
+template <int NX>
+__device__ __forceinline__ int cyc_inverse(double *sm, int lane) {
+  using L = CyclicLds<NX>;
+  constexpr int bs = NX * NX;
+  double *Dm = sm + L::oD, *Wm = sm + L::oW, *Mm = sm + L::oM, *Tm = sm + L::oT, *Dl = sm + L::oDl;
+  int failed = 0;
+  double a_row[NX], nd[NX];
+  const int verdict = wave_ldl_fast<NX>(Dm, lane, a_row, nd);
+  if (verdict == 0) {
+    cond_inverse<NX>(a_row, nd, Wm, Mm, Wm, Tm, Dl, lane);
+  } else {
+    double *bsub = sm + L::oSub;
+    int *bpiv = (int *)(sm + L::oPiv);
+    for (int e = lane; e < bs; e += 64) {
+      const int j = e / NX, r = e - j * NX;
+      Wm[e] = (r == j) ? 1.0 : 0.0;
+    }
+    wave_sync();
+    const WG w1 = wave_self();
+    failed = wg_bk_factor(w1, NX, Dm, NX, bsub, bpiv, bpiv + NX + 8);
+    wg_bk_solve(w1, NX, Dm, NX, bsub, bpiv, Wm, 1, NX, NX);
+  }
+  wave_sync();
+  return failed;
+}
+
+// U = W op(B)^T (kept in accumulator registers) and Dd -= op(B) U (lower tiles), W, B, Dd
+// column-major pitch-NX blocks in LDS; op(B) = B or B^T.  U's accumulator registers are the B
+// operand of the second product (D -> B identity of the f64 MFMA).
+template <int NX, bool TRANSB>
+__device__ __forceinline__ void cyc_update(const double *Wm, const double *Bm, double *Dd,
+                                           double4_t (&Ut)[CondCfg<NX>::TX][CondCfg<NX>::TX],
+                                           int lane) {
+  using K = CondCfg<NX>;
+  constexpr int TX = K::TX, KS = K::KS;
+  const int li = lane & 15, lk = lane >> 4;
+  double opW[TX][KS], opB[TX][KS];
+#pragma unroll
+  for (int t = 0; t < TX; ++t) {
+    const int c = (16 * t + li) < NX ? (16 * t + li) : NX - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      opW[t][s] = Wm[(4 * s + lk) * NX + c];                                // W(16t+li, 4s+lk)
+      opB[t][s] = TRANSB ? Bm[c * NX + 4 * s + lk] : Bm[(4 * s + lk) * NX + c]; // op(B)(16t+li, 4s+lk)
+    }
+  }
+#pragma unroll
+  for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < TX; ++tb) {
+      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opW[ta][s], opB[tb][s], acc, 0, 0, 0);
+      Ut[ta][tb] = acc;
+    }
+#pragma unroll
+  for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+    for (int tb = 0; tb <= ta; ++tb) {
+      double4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = 16 * ta + lk + 4 * r, jj = 16 * tb + li;
+        acc[r] = (16 * ta + 4 * r < NX) ? Dd[(jj < NX ? jj : NX - 1) * NX + (ii < NX ? ii : NX - 1)] : 0.0;
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-opB[ta][s], Ut[s >> 2][tb][s & 3], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * ta + 4 * r < NX) {
+          const int ii = 16 * ta + lk + 4 * r, jj = 16 * tb + li;
+          if (ii < NX && jj < NX)
+            Dd[jj * NX + ii] = acc[r];
+        }
+    }
+}
+
+// Out = sgn * U^T Cm, U in accumulator registers (element (4s+lk, 16ta+li) of U is register s&3 of
+// tile (s>>2, ta): the A operand of the transposed product), Cm a column-major block in LDS;
+// the result goes to a column-major block in global memory
+template <int NX>
+__device__ __forceinline__ void cyc_ut_times(const double4_t (&Ut)[CondCfg<NX>::TX][CondCfg<NX>::TX],
+                                             const double *Cm, double *out, double sgn, int lane) {
+  using K = CondCfg<NX>;
+  constexpr int TX = K::TX, KS = K::KS;
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int tb = 0; tb < TX; ++tb) {
+    const int c = (16 * tb + li) < NX ? (16 * tb + li) : NX - 1;
+    double opC[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      opC[s] = Cm[c * NX + 4 * s + lk]; // C(4s+lk, 16tb+li)
+#pragma unroll
+    for (int ta = 0; ta < TX; ++ta) {
+      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ut[s >> 2][ta][s & 3], opC[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * ta + 4 * r < NX) {
+          if (16 * tb + 15 < NX || 16 * tb + li < NX)
+            out[(16 * tb + li) * NX + 16 * ta + 4 * r + lk] = sgn * acc[r];
+        }
+    }
+  }
+}
+
+// accumulator tiles -> column-major block in global memory
+template <int NX>
+__device__ __forceinline__ void cyc_store_tiles(const double4_t (&Ut)[CondCfg<NX>::TX][CondCfg<NX>::TX],
+                                                double *out, int lane) {
+  constexpr int TX = CondCfg<NX>::TX;
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < TX; ++tb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * ta + 4 * r < NX) {
+          if (16 * tb + 15 < NX || 16 * tb + li < NX)
+            out[(16 * tb + li) * NX + 16 * ta + 4 * r + lk] = Ut[ta][tb][r];
+        }
+}
+
+// LDS block -> global block (all reads first)
+template <int NX>
+__device__ __forceinline__ void cyc_store_block(double *dst, const double *src_lds, int lane) {
+  constexpr int bs = NX * NX, NCH = (bs + 63) / 64;
+  double tmp[NCH];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    tmp[q] = src_lds[(64 * q + 63 < bs || e < bs) ? e : bs - 1];
+  }
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    if (64 * q + 63 < bs || e < bs)
+      dst[e] = tmp[q];
+  }
+}
+// dst(LDS) = a - b, two global blocks
+template <int NX>
+__device__ __forceinline__ void cyc_load_diff(double *dst, const double *a, const double *b, bool sub,
+                                              int lane) {
+  constexpr int bs = NX * NX, NCH = (bs + 63) / 64;
+  double ta[NCH], tb[NCH];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    const int ec = (64 * q + 63 < bs || e < bs) ? e : bs - 1;
+    ta[q] = a[ec];
+    tb[q] = sub ? b[ec] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    if (64 * q + 63 < bs || e < bs)
+      dst[e] = ta[q] - tb[q];
+  }
+}
+
+// ---- 1. setup: eliminate the states, one wave per leg -----------------------------------------
+template <int NX>
+__global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
+  using L = CyclicLds<NX>;
+  using K = CondCfg<NX>;
+  constexpr int bs = NX * NX, TX = K::TX;
+  const CondensedParams &P = Y.C;
+  const int lane = (int)threadIdx.x & 63;
+  const int k = (int)blockIdx.x, b = (int)blockIdx.y, J = P.num_legs;
+  double *sm = gar_smem;
+  double *Dm = sm + L::oD, *Wm = sm + L::oW, *Bm = sm + L::oB, *Mm = sm + L::oM, *D2 = sm + L::oD2;
+  CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  const double *tup = cond_tuple(P, b, k);
+  const int row = lane < NX ? lane : NX - 1;
+  const int nc0 = P.nc0;
+  const bool has_next = (k + 1 < J);
+  if (k == 0 && lane == 0)
+    Y.flag[b] = 0;
+  cond_copy_block<NX>(Dm, tup, lane); // Vxx_k
+  wave_sync();
+  int failed = cyc_inverse<NX>(sm, lane); // Wm = P_k
+  cyc_store_block<NX>(X.P + (long long)k * bs, Wm, lane);
+  const double pk = cyc_matvec<NX>(Wm, tup[3 * bs + row], row); // p_k = P vx
+  if (lane < NX)
+    X.p[k * NX + lane] = pk;
+  double4_t Qt[TX][TX];
+  if (has_next) {
+    cond_copy_block<NX>(Bm, tup + bs, lane);     // Vxt_k
+    cond_copy_block<NX>(D2, tup + 2 * bs, lane); // Vtt_k
+    wave_sync();
+    // Q = P Vxt = W (Vxt^T)^T ; D2 = Vtt - Vxt^T Q  -> the part of S_{k+1} this leg owns
+    cyc_update<NX, true>(Wm, Bm, D2, Qt, lane);
+    cyc_store_tiles<NX>(Qt, X.Q + (long long)k * bs, lane);
+    if (k >= 1)
+      cyc_store_tiles<NX>(Qt, X.C + (long long)k * bs, lane); // C_k = Q_k
+    wave_sync();
+    cyc_store_block<NX>(X.S + (long long)(k + 1) * bs, D2, lane);
+    // r_{k+1} (this leg's part) = -vt_k + Vxt^T p_k
+    const double rk = -tup[3 * bs + NX + row] + cyc_matvecT<NX>(Bm, pk, row);
+    if (lane < NX)
+      X.r[(k + 1) * NX + lane] = rk;
+  }
+  if (k == 0) {
+    // S_0 = -G0 P_0 G0^T (padded with -I), C_0 = -G0 Q_0, r_0 = -g0 + G0 p_0
+    for (int e = lane; e < bs; e += 64) {
+      const int j = e / NX, r = e - j * NX;
+      Mm[e] = r < nc0 ? prob[P.G0_off + j * nc0 + r] : 0.0; // G0 padded to NX rows
+      D2[e] = (r == j && r >= nc0) ? -1.0 : 0.0;
+    }
+    wave_sync();
+    double4_t Zt[TX][TX];
+    cyc_update<NX, false>(Wm, Mm, D2, Zt, lane); // Z = P G0^T ; D2 -= G0 Z
+    wave_sync();
+    cyc_store_block<NX>(X.S, D2, lane);
+    double r0 = cyc_matvec<NX>(Mm, pk, row);
+    r0 += (row < nc0) ? -prob[P.g0_off + row] : 0.0;
+    if (lane < NX)
+      X.r[lane] = r0;
+    if (has_next) {
+      // C_0 = -G0 Q_0 = -(G0^T)^T Q_0: the tiles of Z^T... computed as (G0^T)^T Q with G0^T's
+      // accumulator-layout copy: G0^T = Mm^T, so use U := G0^T in tile registers
+      double4_t Gt[TX][TX];
+      const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+      for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TX; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { // U(16ta+lk+4r, 16tb+li) = G0^T(.,.) = G0(16tb+li, 16ta+lk+4r)
+            const int ii = 16 * ta + lk + 4 * r, jj = 16 * tb + li;
+            Gt[ta][tb][r] = (ii < NX && jj < NX) ? Mm[ii * NX + jj] : 0.0;
+          }
+      // Q_0 as a column-major LDS block: write the tiles to D2 (S_0 already stored)
+      wave_sync();
+#pragma unroll
+      for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TX; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ii = 16 * ta + lk + 4 * r, jj = 16 * tb + li;
+            if (16 * ta + 4 * r < NX) {
+              if (ii < NX && jj < NX)
+                D2[jj * NX + ii] = Qt[ta][tb][r];
+            }
+          }
+      wave_sync();
+      cyc_ut_times<NX>(Gt, D2, X.C, -1.0, lane); // C_0 = -(G0^T)^T Q_0
+    }
+  }
+  if (failed && lane == 0)
+    atomicOr(&P.status[b], 4);
+}
+
+// ---- 2. one reduction level -------------------------------------------------------------------
+template <int NX>
+__global__ void __launch_bounds__(64, 1) gar_cyclic_reduce(CyclicParams Y) {
+  using L = CyclicLds<NX>;
+  using K = CondCfg<NX>;
+  constexpr int bs = NX * NX, TX = K::TX;
+  const CondensedParams &P = Y.C;
+  const int lane = (int)threadIdx.x & 63;
+  const int h = Y.h, J = P.num_legs;
+  const int i = 2 * h * (int)blockIdx.x, b = (int)blockIdx.y;
+  if (i >= J)
+    return;
+  const bool first = (h == 1); // the -P_j / -p_j halves of S_j, r_j are still separate
+  double *sm = gar_smem;
+  double *Dm = sm + L::oD, *Wm = sm + L::oW, *Bm = sm + L::oB, *D2 = sm + L::oD2;
+  CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
+  const int row = lane < NX ? lane : NX - 1;
+  int failed = 0;
+  auto S_of = [&](int j) { return X.S + (long long)j * bs; };
+  auto load_S = [&](double *dst, int j) {
+    cyc_load_diff<NX>(dst, S_of(j), X.P + (long long)j * bs, first && j >= 1, lane);
+  };
+  auto r_of = [&](int j) {
+    double v = X.r[j * NX + row];
+    if (first && j >= 1)
+      v -= X.p[j * NX + row];
+    return v;
+  };
+  load_S(D2, i); // own block
+  double ri = r_of(i);
+  if (i + h < J) { // right eliminated neighbour j = i + h
+    const int j = i + h;
+    load_S(Dm, j);
+    cond_copy_block<NX>(Bm, X.C + (long long)i * bs, lane); // C_i (row i, column j)
+    wave_sync();
+    failed |= cyc_inverse<NX>(sm, lane); // Wm = W_j
+    cyc_store_block<NX>(X.W + (long long)j * bs, Wm, lane);
+    cyc_store_block<NX>(X.Cl + (long long)j * bs, Bm, lane); // the coupling j had to its left
+    double4_t Ut[TX][TX];
+    cyc_update<NX, false>(Wm, Bm, D2, Ut, lane); // U = W_j C_i^T ; S_i -= C_i U
+    const double y = cyc_matvec<NX>(Wm, r_of(j), row);
+    ri -= cyc_matvec<NX>(Bm, y, row);
+    if (j + h < J) { // new coupling (i, i + 2h) = -C_i W_j C_j = -U^T C_j
+      wave_sync();
+      cond_copy_block<NX>(Dm, X.C + (long long)j * bs, lane); // C_j into the dead S_j buffer
+      wave_sync();
+      cyc_ut_times<NX>(Ut, Dm, X.C + (long long)i * bs, -1.0, lane);
+    }
+    wave_sync();
+  }
+  if (i - h >= 0) { // left eliminated neighbour j = i - h
+    const int j = i - h;
+    load_S(Dm, j);
+    cond_copy_block<NX>(Bm, X.C + (long long)j * bs, lane); // C_j (row j, column i)
+    wave_sync();
+    failed |= cyc_inverse<NX>(sm, lane);
+    double4_t Ut[TX][TX];
+    cyc_update<NX, true>(Wm, Bm, D2, Ut, lane); // U = W_j C_j ; S_i -= C_j^T U
+    const double y = cyc_matvec<NX>(Wm, r_of(j), row);
+    ri -= cyc_matvecT<NX>(Bm, y, row);
+    wave_sync();
+  }
+  // first level: the stored S_i / r_i become the complete ones (S slot was missing -P_i)
+  cyc_store_block<NX>(S_of(i), D2, lane);
+  if (lane < NX)
+    X.r[i * NX + lane] = ri;
+  if (failed && lane == 0)
+    atomicOr(&P.status[b], 4);
+}
+
+// ---- 3. back-substitution, recovery of the states, residual ----------------------------------
+template <int NX>
+__global__ void __launch_bounds__(256) gar_cyclic_backsub(CyclicParams Y) {
+  using L = CyclicLds<NX>;
+  constexpr int bs = NX * NX;
+  const CondensedParams &P = Y.C;
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+  const int b = (int)blockIdx.x, J = P.num_legs, nblk = 2 * J;
+  double *sm = gar_smem;
+  CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  double *sol = P.csol + (long long)b * nblk * NX;
+  const int row = lane < NX ? lane : NX - 1;
+  const int nc0 = P.nc0;
+  int hmax = 1;
+  while (2 * hmax < J)
+    hmax *= 2;
+  // z_0 = S_0^{-1} r_0 (the only block never eliminated)
+  if (wave == 0) {
+    cond_copy_block<NX>(sm + L::oD, X.S, lane);
+    wave_sync();
+    const int failed = cyc_inverse<NX>(sm, lane);
+    const double z0 = cyc_matvec<NX>(sm + L::oW, X.r[row], row);
+    if (lane < NX)
+      X.z[lane] = z0;
+    if (failed && lane == 0)
+      atomicOr(&P.status[b], 4);
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int h = hmax; h >= 1; h >>= 1) {
+    const bool first = (h == 1);
+    // eliminated at this level: j = h, 3h, 5h, ... < J
+    for (int q = wave; (2 * q + 1) * h < J; q += nw) {
+      const int j = (2 * q + 1) * h;
+      double v = X.r[j * NX + row];
+      if (first)
+        v -= X.p[j * NX + row];
+      v -= cyc_matvecT<NX>(X.Cl + (long long)j * bs, X.z[(j - h) * NX + row], row);
+      if (j + h < J)
+        v -= cyc_matvec<NX>(X.C + (long long)j * bs, X.z[(j + h) * NX + row], row);
+      const double zj = cyc_matvec<NX>(X.W + (long long)j * bs, v, row);
+      if (lane < NX)
+        X.z[j * NX + lane] = zj;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // lambda_k = z_k ; x_k = -p_k - P_k E_k^T lambda_k - Q_k lambda_{k+1}
+  for (int k = wave; k < J; k += nw) {
+    const double lam = X.z[k * NX + row];
+    double x = -X.p[k * NX + row];
+    if (k == 0) { // E_0 = G0 (nc0 x NX): (G0^T lambda)(row) then P_0 times it
+      double g = 0.0;
+      for (int c = 0; c < nc0; ++c)
+        g += prob[P.G0_off + row * nc0 + c] * lane_bcast(lam, c);
+      x -= cyc_matvec<NX>(X.P, g, row);
+    } else {
+      x += cyc_matvec<NX>(X.P + (long long)k * bs, lam, row);
+    }
+    if (k + 1 < J)
+      x -= cyc_matvec<NX>(X.Q + (long long)k * bs, X.z[(k + 1) * NX + row], row);
+    if (lane < NX) {
+      sol[(2 * k) * NX + lane] = (k == 0 && lane >= nc0) ? 0.0 : lam;
+      sol[(2 * k + 1) * NX + lane] = x;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // residual of the original system (blockTridiagMatMul, block-tridiagonal.hpp:52-75), block rows
+  // spread over the waves; infinity norm through LDS
+  double mx = 0.0;
+  for (int i = wave; i < nblk; i += nw) {
+    const double xi = sol[i * NX + row];
+    double r;
+    if (i == 0) {
+      r = row < nc0 ? -prob[P.g0_off + row] : 0.0;
+    } else {
+      const double *tup = cond_tuple(P, b, (i - 1) >> 1);
+      const int off = (i & 1) ? 0 : 2 * bs;
+      r = -tup[3 * bs + ((i & 1) ? 0 : NX) + row] - cyc_matvec<NX>(tup + off, xi, row);
+    }
+    if (i > 0) {
+      const double xp = sol[(i - 1) * NX + row];
+      if (i - 1 == 0) {
+        double s = 0.0;
+        for (int c = 0; c < nc0; ++c)
+          s += prob[P.G0_off + row * nc0 + c] * lane_bcast(xp, c);
+        r -= s;
+      } else if (((i - 1) & 1) == 0) {
+        r += xp;
+      } else {
+        r -= cyc_matvecT<NX>(cond_tuple(P, b, (i - 2) >> 1) + bs, xp, row);
+      }
+    }
+    if (i < nblk - 1) {
+      const double xn = sol[(i + 1) * NX + row];
+      if (i == 0) {
+        double s = 0.0;
+        for (int c = 0; c < NX; ++c)
+          s += (row < nc0 ? prob[P.G0_off + c * nc0 + row] : 0.0) * lane_bcast(xn, c);
+        r -= s;
+      } else if ((i & 1) == 0) {
+        r += xn;
+      } else {
+        r -= cyc_matvec<NX>(cond_tuple(P, b, (i - 1) >> 1) + bs, xn, row);
+      }
+    }
+    if (lane >= NX || (i == 0 && lane >= nc0))
+      r = 0.0;
+    const double av = fabs(r);
+    mx = (av > mx || av != av) ? av : mx;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double other = __shfl_xor(mx, o);
+    mx = (other > mx || other != other) ? other : mx;
+  }
+  double *red = sm; // LDS is free again
+  if (lane == 0)
+    red[wave] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = 0.0;
+    for (int w = 0; w < nw; ++w)
+      m = (red[w] > m || red[w] != red[w]) ? red[w] : m;
+    X.info[0] = m;
+    X.info[1] = 0.0;
+    Y.flag[b] = !(m <= P.threshold) && P.max_refinement > 0;
+  }
+}
+
+} // namespace gar

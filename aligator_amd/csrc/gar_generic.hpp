@@ -673,6 +673,8 @@ struct CondensedParams {
   int batch, num_legs, legs_per_rank, tuple_doubles, nxb, nc0, nx0;
   int max_refinement;
   double threshold;
+  long long *trace; // debug: cycle stamps of two elimination steps of problem 0 (or null)
+  const int *gate;  // if non-null: only the problems with gate[b] != 0 are solved
   // scratch layout (doubles, per problem): nblk = 2*num_legs, bs = nxb*nxb
   //   diag[nblk][bs] super[nblk][bs] facD[nblk][bs] U[nblk][bs]
   //   fsub[nblk][nxb] rhs[nblk][nxb] err[nblk][nxb] fpiv[nblk][nxb] (ints in doubles)

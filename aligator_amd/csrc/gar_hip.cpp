@@ -18,6 +18,7 @@
 #include "gar_mfma.hpp"
 #include "gar_wave.hpp"
 #include "gar_wave_leg.hpp"
+#include "gar_cyclic.hpp"
 
 namespace {
 
@@ -86,6 +87,12 @@ struct gar_hip_solver {
   int leg_lds_doubles = 0;
   void (*cond_wave_kernel)(gar::CondensedParams) = nullptr;
   int cond_wave_lds_doubles = 0;
+  // block cyclic reduction of the condensed system (gar_cyclic.hpp), preferred when bound
+  void (*cyc_setup_kernel)(gar::CyclicParams) = nullptr;
+  void (*cyc_reduce_kernel)(gar::CyclicParams) = nullptr;
+  void (*cyc_backsub_kernel)(gar::CyclicParams) = nullptr;
+  int cyc_lds_doubles = 0;
+  int *d_cyc_flag = nullptr;
   long long *d_trace = nullptr; // 64 cycle stamps (debug)
   // optional per-kernel timing of the sweep (bench.py's roofline figure): HIP events recorded on
   // the launch stream around the backward sweep kernel, the initial-stage kernel and the forward
@@ -300,10 +307,17 @@ template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
   s->leg_lds_doubles = gar::WaveCfg<NX, NU>::leg_total;
   const char *ck = std::getenv("GAR_HIP_CONDENSED");
   if (!(ck && std::string(ck) == "generic")) {
-    const int lds = 4 * NX * NX + NX + (NX & 1) + (NX + 16) / 2 + 2 + 2 * (2 * s->num_legs) * NX + 2;
+    const int lds = 4 * NX * NX + 16 * NX + NX + NX + (NX & 1) + (NX + 16) / 2 + 2 +
+                    2 * (2 * s->num_legs) * NX + 2;
     if ((size_t)lds * sizeof(double) <= 160 * 1024) {
       s->cond_wave_kernel = gar::gar_condensed_wave<NX>;
       s->cond_wave_lds_doubles = lds;
+      if (!(ck && std::string(ck) == "chain")) {
+        s->cyc_setup_kernel = gar::gar_cyclic_setup<NX>;
+        s->cyc_reduce_kernel = gar::gar_cyclic_reduce<NX>;
+        s->cyc_backsub_kernel = gar::gar_cyclic_backsub<NX>;
+        s->cyc_lds_doubles = gar::CyclicLds<NX>::total;
+      }
     }
   }
   s->kernel_name = "wave_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
@@ -343,6 +357,9 @@ void select_kernel(gar_hip_solver *s) {
   s->leg_fwd_final_kernel = nullptr;
   s->leg_collapse_kernel = nullptr;
   s->cond_wave_kernel = nullptr;
+  s->cyc_setup_kernel = nullptr;
+  s->cyc_reduce_kernel = nullptr;
+  s->cyc_backsub_kernel = nullptr;
   s->mfma_kernel = nullptr;
   s->mfma_fwd_kernel = nullptr;
   s->wave_kernel = nullptr;
@@ -611,6 +628,27 @@ int launch_condensed(gar_hip_solver *s) {
   C.nx0 = s->nx0;
   C.max_refinement = s->max_refinement;
   C.threshold = s->cond_threshold;
+  C.trace = s->d_trace;
+  C.gate = nullptr;
+  if (s->cyc_setup_kernel) {
+    gar::CyclicParams Y{};
+    Y.C = C;
+    Y.h = 0;
+    Y.flag = s->d_cyc_flag;
+    const int J = s->num_legs;
+    const size_t lds = (size_t)s->cyc_lds_doubles * sizeof(double);
+    hipLaunchKernelGGL(s->cyc_setup_kernel, dim3((unsigned)J, (unsigned)s->batch), dim3(64), lds,
+                       s->stream, Y);
+    for (int h = 1; h < J; h *= 2) {
+      Y.h = h;
+      hipLaunchKernelGGL(s->cyc_reduce_kernel,
+                         dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch), dim3(64),
+                         lds, s->stream, Y);
+    }
+    hipLaunchKernelGGL(s->cyc_backsub_kernel, dim3((unsigned)s->batch), dim3(256), lds, s->stream, Y);
+    HIP_TRY(hipGetLastError());
+    C.gate = s->d_cyc_flag; // the chain kernel (with refinement) re-solves only flagged problems
+  }
   if (s->cond_wave_kernel)
     hipLaunchKernelGGL(s->cond_wave_kernel, dim3((unsigned)s->batch), dim3(64),
                        (size_t)s->cond_wave_lds_doubles * sizeof(double), s->stream, C);
@@ -653,6 +691,8 @@ void free_device(gar_hip_solver *s) {
     (void)hipFree(s->d_bound_all);
   (void)hipFree(s->d_csol);
   (void)hipFree(s->d_cscratch);
+  (void)hipFree(s->d_cyc_flag);
+  s->d_cyc_flag = nullptr;
   (void)hipFree(s->d_trace);
   s->d_trace = nullptr;
   (void)hipFree(s->d_deriv_off);
@@ -699,6 +739,8 @@ int allocate(gar_hip_solver *s) {
     s->cscratch_doubles = (int64_t)(4 * nblk * bs + 4 * (size_t)nblk * s->nxb + 4);
     HIP_TRY(hipMalloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
     s->cond_lds_doubles = (int)(2 * bs + s->nxb + 2 + (s->nxb + 16) / 2 + 2);
+    HIP_TRY(hipMalloc((void **)&s->d_cyc_flag, sizeof(int) * B));
+    HIP_TRY(hipMemset(s->d_cyc_flag, 0, sizeof(int) * B));
   }
   const size_t staging = sizeof(double) * (size_t)s->prob_doubles * B;
   if (staging <= ((size_t)1 << 30)) {
@@ -711,6 +753,15 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipFuncSetAttribute((const void *)s->mfma_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->mfma_lds_doubles * sizeof(double))));
+  if (s->cyc_setup_kernel) {
+    const int lds = (int)(s->cyc_lds_doubles * sizeof(double));
+    HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_setup_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_reduce_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_backsub_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
   if (s->cond_wave_kernel)
     HIP_TRY(hipFuncSetAttribute((const void *)s->cond_wave_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,

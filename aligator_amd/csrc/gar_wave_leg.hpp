@@ -161,16 +161,190 @@ __global__ void gar_collapse_feedback_t2(const gar_stage_meta *meta, double *fac
 // The chain is serial in the block index (2*num_legs steps); everything inside a step is
 // wave-parallel.  LDS: 4 blocks + the solution vector.
 // ---------------------------------------------------------------------------------------------
+template <int NX> struct CondCfg {
+  // diagonal blocks of the blocked triangular inverse
+  static constexpr int BS = (NX % 12 == 0) ? 12 : ((NX % 16 == 0) ? 16 : NX);
+  static constexpr int NB = NX / BS, KB = BS / 4;
+  static constexpr int TX = (NX + 15) / 16, KS = NX / 4;
+  static_assert(NX % 4 == 0 && BS <= 16 && NB >= 1 && NB <= 3, "unsupported block size");
+};
+
+// one 16x16 accumulator tile += A[r0 + li][c0 + 4s + lk] * B[c0b + 4s + lk][j0 + li], s < KB:
+// a BS x BS x BS product of sub-blocks of two column-major pitch-NX matrices in LDS (rows and
+// columns past BS are clamped: they only feed accumulator entries that are never stored)
+template <int NX>
+__device__ __forceinline__ double4_t cond_blk_gemm(const double *A, int ar0, int ac0, const double *B,
+                                                   int br0, int bc0, double4_t acc, int li, int lk) {
+  using K = CondCfg<NX>;
+  const int lc = li < K::BS ? li : K::BS - 1;
+#pragma unroll
+  for (int s = 0; s < K::KB; ++s) {
+    const double aq = A[(ac0 + 4 * s + lk) * NX + ar0 + lc];
+    const double bq = B[(bc0 + lc) * NX + br0 + 4 * s + lk];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// store the valid BS x BS part of a tile into a column-major pitch-NX matrix at (r0, c0)
+template <int NX>
+__device__ __forceinline__ void cond_blk_store(double *Mx, int r0, int c0, double4_t acc, double sgn,
+                                               int li, int lk) {
+  using K = CondCfg<NX>;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (4 * r < K::BS) { // compile-time
+      if (lk + 4 * r < K::BS && li < K::BS)
+        Mx[(c0 + li) * NX + r0 + lk + 4 * r] = sgn * acc[r];
+    }
+}
+
+// W = D^{-1} from the unpivoted factorisation D = L Dd L^T held lane = row (a_row[j] = L(row, j),
+// nd[k] = -1/d_k): L goes to LDS, its inverse M is formed block-wise (diagonal blocks by lane-
+// parallel substitution -- lane = (block, column) --, off-diagonal blocks as small MFMA products),
+// then W = M^T Dd^{-1} M on MFMA tiles, skipping the k-steps where the triangular M is zero.
+// Lm may alias Wm.
+template <int NX>
+__device__ __forceinline__ void cond_inverse(const double (&a_row)[NX], const double (&nd)[NX],
+                                             double *Lm, double *Mm, double *Wm, double *Tm,
+                                             double *Dl, int lane) {
+  using K = CondCfg<NX>;
+  constexpr int BS = K::BS, NB = K::NB, TX = K::TX, KS = K::KS;
+  const int li = lane & 15, lk = lane >> 4;
+  // clean unit-lower L, column-major; 1/d_k to lane k
+  if (lane < NX) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      Lm[j * NX + lane] = (j < lane) ? a_row[j] : (j == lane ? 1.0 : 0.0);
+  }
+  {
+    double dl = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+      dl = (lane == k) ? -nd[k] : dl;
+    if (lane < NX)
+      Dl[lane] = dl;
+  }
+  for (int e = lane; e < NX * NX; e += 64)
+    Mm[e] = 0.0;
+  wave_sync();
+  { // diagonal blocks: M_bb = L_bb^{-1}, lane = (block, column)
+    const int lc = lane < NX ? lane : NX - 1;
+    const int bb = lc / BS, c = lc - bb * BS;
+    const double *Lb = Lm + bb * BS * (NX + 1);
+    double y[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+      y[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < BS - 1; ++j)
+#pragma unroll
+      for (int i = j + 1; i < BS; ++i)
+        y[i] = __builtin_fma(-Lb[j * NX + i], y[j], y[i]);
+    if (lane < NX) {
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+        Mm[lc * NX + bb * BS + i] = y[i];
+    }
+  }
+  wave_sync();
+  const double4_t z4 = double4_t{0.0, 0.0, 0.0, 0.0};
+  if (NB >= 2) {
+    // T1 = L10 M00 ; T2 = L21 M11
+    double4_t t1 = cond_blk_gemm<NX>(Lm, BS, 0, Mm, 0, 0, z4, li, lk);
+    cond_blk_store<NX>(Tm, 0, 0, t1, 1.0, li, lk); // T1 at rows 0.., columns 0..
+    if (NB >= 3) {
+      double4_t t2 = cond_blk_gemm<NX>(Lm, 2 * BS, BS, Mm, BS, BS, z4, li, lk);
+      cond_blk_store<NX>(Tm, BS, 0, t2, 1.0, li, lk); // T2 below T1
+    }
+    wave_sync();
+    // M10 = -M11 T1 ; M21 = -M22 T2
+    double4_t m10 = cond_blk_gemm<NX>(Mm, BS, BS, Tm, 0, 0, z4, li, lk);
+    cond_blk_store<NX>(Mm, BS, 0, m10, -1.0, li, lk);
+    if (NB >= 3) {
+      double4_t m21 = cond_blk_gemm<NX>(Mm, 2 * BS, 2 * BS, Tm, BS, 0, z4, li, lk);
+      cond_blk_store<NX>(Mm, 2 * BS, BS, m21, -1.0, li, lk);
+    }
+    wave_sync();
+    if (NB >= 3) {
+      // T3 = L20 M00 + L21 M10 ; M20 = -M22 T3
+      double4_t t3 = cond_blk_gemm<NX>(Lm, 2 * BS, 0, Mm, 0, 0, z4, li, lk);
+      t3 = cond_blk_gemm<NX>(Lm, 2 * BS, BS, Mm, BS, 0, t3, li, lk);
+      cond_blk_store<NX>(Tm, 0, 0, t3, 1.0, li, lk);
+      wave_sync();
+      double4_t m20 = cond_blk_gemm<NX>(Mm, 2 * BS, 2 * BS, Tm, 0, 0, z4, li, lk);
+      cond_blk_store<NX>(Mm, 2 * BS, 0, m20, -1.0, li, lk);
+      wave_sync();
+    }
+  }
+  // W = M^T Dd^{-1} M, lower tiles, mirrored; M(k, a) = 0 for k < a
+  double op[TX][KS], dsc[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    dsc[s] = Dl[4 * s + lk];
+#pragma unroll
+  for (int t = 0; t < TX; ++t) {
+    const int c = (16 * t + li) < NX ? (16 * t + li) : NX - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      op[t][s] = (4 * s + 3 >= 16 * t) ? Mm[c * NX + 4 * s + lk] : 0.0;
+  }
+  wave_sync(); // Lm (which may alias Wm) is dead from here
+#pragma unroll
+  for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+    for (int tb = 0; tb <= ta; ++tb) {
+      double4_t acc = z4;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        if (4 * s + 3 >= 16 * ta) // compile-time: rows k >= 16 ta of M's column tile ta
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ta][s] * dsc[s], op[tb][s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * ta + 4 * r < NX) {
+          const int i = 16 * ta + lk + 4 * r, j = 16 * tb + li;
+          if (i < NX && j < NX && (ta != tb || i >= j)) { // the lower entry, to both places
+            Wm[j * NX + i] = acc[r];
+            Wm[i * NX + j] = acc[r];
+          }
+        }
+    }
+}
+
+// a pitch-NX block HBM -> LDS: every load is issued before the first LDS write
+template <int NX>
+__device__ __forceinline__ void cond_copy_block(double *dst, const double *src, int lane) {
+  constexpr int bs = NX * NX, NCH = (bs + 63) / 64;
+  double tmp[NCH];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    tmp[q] = src[(64 * q + 63 < bs || e < bs) ? e : bs - 1];
+  }
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    if (64 * q + 63 < bs || e < bs)
+      dst[e] = tmp[q];
+  }
+}
+
 template <int NX>
 __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
   constexpr int bs = NX * NX;
   const int lane = (int)threadIdx.x & 63;
   const int b = (int)blockIdx.x;
+  if (P.gate != nullptr && P.gate[b] == 0)
+    return; // the cyclic-reduction solve of this problem met the residual threshold
   const WG w1 = wave_self();
   double *sm = gar_smem;
   const int nblk = 2 * P.num_legs, N = nblk - 1;
-  double *Dm = sm, *Wm = sm + bs, *Bm = sm + 2 * bs, *Um = sm + 3 * bs;
-  double *bsub = sm + 4 * bs;                 // Bunch-Kaufman fallback: sub | piv, ctrl
+  using K = CondCfg<NX>;
+  constexpr int TX = K::TX, KS = K::KS;
+  const int li = lane & 15, lk = lane >> 4;
+  double *Dm = sm, *Wm = sm + bs, *Bm = sm + 2 * bs, *Mm = sm + 3 * bs;
+  double *Tm = sm + 4 * bs;                   // NX x 16 scratch of the blocked inverse
+  double *Dl = Tm + 16 * NX;                  // 1/d_k
+  double *bsub = Dl + NX;                     // Bunch-Kaufman fallback: sub | piv, ctrl
   int *bpiv = (int *)(bsub + NX + (NX & 1));
   double *solv = bsub + NX + (NX & 1) + (NX + 16) / 2 + 2; // [nblk][NX]
   double *errv = solv + nblk * NX;                         // [nblk][NX]
@@ -197,7 +371,7 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
   // D of the last block: Vxx of the last leg
   {
     const double *tup = cond_tuple(P, b, P.num_legs - 1);
-    for (int e = lane; e < bs; e += 64)
+    _Pragma("unroll") for (int e = lane; e < bs; e += 64)
       Dm[e] = tup[e];
   }
   wave_sync();
@@ -227,23 +401,28 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
     if (i >= 2 && (i & 1) == 0)
       return 1;
     if (i == 0) { // G0: nc0 x NX
-      for (int e = lane; e < bs; e += 64) {
+      _Pragma("unroll") for (int e = lane; e < bs; e += 64) {
         const int j = e / NX, r = e - j * NX;
         Bm[e] = r < nc0 ? prob[P.G0_off + j * nc0 + r] : 0.0;
       }
     } else { // Vxt of leg (i-1)/2
-      const double *tup = cond_tuple(P, b, (i - 1) >> 1);
-      for (int e = lane; e < bs; e += 64)
-        Bm[e] = tup[bs + e];
+      cond_copy_block<NX>(Bm, cond_tuple(P, b, (i - 1) >> 1) + bs, lane);
     }
     return 0;
   };
 
   // ---- up-looking elimination -------------------------------------------------------------
+  const bool tracing = P.trace != nullptr && b == 0 && lane == 0;
+#define GAR_CMARK(id)                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  if (tracing && (ib == N - 2 || ib == N - 3))                                 \
+    P.trace[(id) + 16 * (N - 2 - ib)] = (long long)clock64();                  \
+  __builtin_amdgcn_sched_barrier(0);
   for (int ib = N; ib >= 0; --ib) {
     const int n = ib == 0 ? nc0 : NX;
+    GAR_CMARK(0)
     if (ib == 0) { // pad the nc0 x nc0 block with an identity
-      for (int e = lane; e < bs; e += 64) {
+      _Pragma("unroll") for (int e = lane; e < bs; e += 64) {
         const int j = e / NX, r = e - j * NX;
         if (r >= n || j >= n)
           Dm[e] = (r == j) ? 1.0 : 0.0;
@@ -253,19 +432,11 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
     {
       double a_row[NX], nd[NX];
       const int verdict = wave_ldl_fast<NX>(Dm, lane, a_row, nd);
+      GAR_CMARK(1)
       if (verdict == 0) {
-        double x[NX];
-#pragma unroll
-        for (int k = 0; k < NX; ++k)
-          x[k] = (k == lane) ? 1.0 : 0.0;
-        ldl_solve_regs_bcast<NX>(a_row, nd, x); // -D^{-1} e_lane
-        if (lane < NX) {
-#pragma unroll
-          for (int k = 0; k < NX; ++k)
-            Wm[lane * NX + k] = -x[k];
-        }
+        cond_inverse<NX>(a_row, nd, Wm, Mm, Wm, Tm, Dl, lane);
       } else {
-        for (int e = lane; e < bs; e += 64) {
+        _Pragma("unroll") for (int e = lane; e < bs; e += 64) {
           const int j = e / NX, r = e - j * NX;
           Wm[e] = (r == j) ? 1.0 : 0.0;
         }
@@ -275,7 +446,8 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
       }
     }
     wave_sync();
-    for (int e = lane; e < bs; e += 64)
+    GAR_CMARK(2)
+    _Pragma("unroll") for (int e = lane; e < bs; e += 64)
       Wall[(long long)ib * bs + e] = Wm[e];
     // x_ib <- D^{-1} x_ib
     const double xb = matvec(Wm, solv[ib * NX + row]);
@@ -283,24 +455,25 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
       solv[ib * NX + lane] = xb;
     if (ib == 0)
       break;
+    GAR_CMARK(3)
     const int i = ib - 1;
     const int negI = load_coupling(i);
     // D_i of the next step: the original diagonal block ...
     if (i == 0) {
-      for (int e = lane; e < bs; e += 64)
+      _Pragma("unroll") for (int e = lane; e < bs; e += 64)
         Dm[e] = 0.0; // -mudyn I with mudyn = 0 (:93-94, :165)
     } else {
       const double *tup = cond_tuple(P, b, (i - 1) >> 1);
       const int off = (i & 1) ? 0 : 2 * bs; // odd: Vxx(leg) ; even: Vtt(leg)
-      for (int e = lane; e < bs; e += 64)
-        Dm[e] = tup[off + e];
+      cond_copy_block<NX>(Dm, tup + off, lane);
     }
     wave_sync();
+    GAR_CMARK(4)
     if (negI) {
       // x_i -= (-I) x_ib ; U_i = -W ; D_i -= (-I)(-W)
       if (lane < NX)
         solv[i * NX + lane] += xb;
-      for (int e = lane; e < bs; e += 64) {
+      _Pragma("unroll") for (int e = lane; e < bs; e += 64) {
         const double wv = Wm[e];
         Uall[(long long)i * bs + e] = -wv;
         Dm[e] -= wv;
@@ -309,17 +482,68 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
       const double xi = solv[i * NX + row] - matvec(Bm, xb);
       if (lane < NX)
         solv[i * NX + lane] = xi;
-      // U_i = W B^T (NX x NX; columns >= dim(i) are zero) ; D_i -= B U_i
-      wg_gemm(w1, NX, NX, NX, colmajor(Wm, NX), colmajor(Bm, NX).T(), MatV{nullptr, 0, 0},
-              colmajor(Um, NX), 1.0);
-      wave_sync();
-      wg_gemm(w1, NX, NX, NX, colmajor(Bm, NX), colmajor(Um, NX), colmajor(Dm, NX),
-              colmajor(Dm, NX), -1.0);
-      for (int e = lane; e < bs; e += 64)
-        Uall[(long long)i * bs + e] = Um[e];
+      // U_i = W B^T (NX x NX; columns >= dim(i) are zero) ; D_i -= B U_i (lower tiles).
+      // W(16t+li, 4s+lk) and B(16t+li, 4s+lk) share one operand pattern; U's accumulator
+      // registers ARE the B operand of the second product (D -> B identity of the f64 MFMA)
+      double opW[TX][KS], opB[TX][KS];
+#pragma unroll
+      for (int t = 0; t < TX; ++t) {
+        const int c = (16 * t + li) < NX ? (16 * t + li) : NX - 1;
+#pragma unroll
+        for (int sk = 0; sk < KS; ++sk) {
+          opW[t][sk] = Wm[(4 * sk + lk) * NX + c];
+          opB[t][sk] = Bm[(4 * sk + lk) * NX + c];
+        }
+      }
+      double4_t Ut[TX][TX];
+#pragma unroll
+      for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TX; ++tb) {
+          double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int sk = 0; sk < KS; ++sk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opW[ta][sk], opB[tb][sk], acc, 0, 0, 0);
+          Ut[ta][tb] = acc;
+        }
+      GAR_CMARK(5)
+      double *Ug = Uall + (long long)i * bs;
+#pragma unroll
+      for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TX; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * ta + 4 * r < NX) {
+              if (16 * tb + 15 < NX || 16 * tb + li < NX)
+                Ug[(16 * tb + li) * NX + 16 * ta + 4 * r + lk] = Ut[ta][tb][r];
+            }
+#pragma unroll
+      for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+        for (int tb = 0; tb <= ta; ++tb) {
+          double4_t acc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ii = 16 * ta + lk + 4 * r, jj = 16 * tb + li;
+            acc[r] = (16 * ta + 4 * r < NX) ? Dm[(jj < NX ? jj : NX - 1) * NX + (ii < NX ? ii : NX - 1)] : 0.0;
+          }
+#pragma unroll
+          for (int sk = 0; sk < KS; ++sk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-opB[ta][sk], Ut[sk >> 2][tb][sk & 3], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * ta + 4 * r < NX) {
+              const int ii = 16 * ta + lk + 4 * r, jj = 16 * tb + li;
+              if (ii < NX && jj < NX)
+                Dm[jj * NX + ii] = acc[r];
+            }
+        }
     }
     wave_sync();
+    GAR_CMARK(6)
   }
+#undef GAR_CMARK
   // ---- down sweep: x_{i+1} -= U_i x_i  (:131-134) -----------------------------------------------
   __threadfence_block();
   for (int i = 0; i < N; ++i) {

@@ -9,13 +9,15 @@ from aligator_amd.gar import BatchedRiccatiSolver
 
 nx, nu, mueq = 36, 12, 1e-12
 batch = int(os.environ.get("BATCH", "1"))
-cases = [(256, (1, 4, 8, 16, 32)), (2048, (1, 8, 16, 32, 64, 128))]
+cases = [(256, (1, 8, 16, 32)), (2048, (1, 32, 64, 128, 256))]
 for N, legs_list in cases:
     prob = synth.generate_lq_problem(5, np.zeros(nx), N, nx, nu, mode="W")
     dims = [k.dims for k in prob.stages]
     ref = None
     for legs in legs_list:
         s = BatchedRiccatiSolver(dims, nx, batch=batch, num_legs=legs)
+        if legs > 1 and os.environ.get("REFINE") is not None:
+            s._check(s._L.gar_hip_set_refinement(s.handle, 1e-10, int(os.environ["REFINE"])))
         s.upload([prob] * batch)
         s.backward(mueq); s.forward(); s.sync()
         sol = s.solution(0)

@@ -1,0 +1,23 @@
+"""Cycle stamps of two consecutive elimination steps of the condensed solver (problem 0)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aligator_amd import synth
+from aligator_amd.gar import BatchedRiccatiSolver
+nx, nu, N, legs = 36, 12, 256, 8
+prob = synth.generate_lq_problem(5, np.zeros(nx), N, nx, nu, mode="W")
+s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs)
+s.upload([prob]); s.backward(1e-12); s.forward()
+s._L.gar_hip_debug_trace(s.handle, 1, None)
+s.backward(1e-12)
+out = (C.c_longlong * 64)()
+s._L.gar_hip_debug_trace(s.handle, 0, out)
+names = ["factor", "W=D^-1 (36 rhs)", "store W + matvec", "load B, D_i", "x_i, U=WB^T | -I: all", "D_i -= B U", "next"]
+for st in range(2):
+    t = [out[16 * st + k] for k in range(7)]
+    print(f"step {st} ({'B = Vxt' if t[5] else 'B = -I'}):", end=" ")
+    prev = t[0]
+    for k in range(1, 7):
+        if t[k]:
+            print(f"{names[k-1]} {t[k]-prev}", end=" | "); prev = t[k]
+    print(f"total {prev - t[0]} (100 MHz ticks: x24 = shader cycles)")
