@@ -22,12 +22,12 @@
 //         C_i <- -C_i W_{i+h} C_{i+h}     r_i -= C_i W_{i+h} r_{i+h} + C_{i-h}^T W_{i-h} r_{i-h}
 //     one wave per survivor, ONE launch per level, no wave writes what another reads in the
 //     same level (a survivor inverts both neighbours itself).
-//  3. back-substitution + recovery of the states (one workgroup per problem):
-//         z_0 = S_0^{-1} r_0 ;  z_j = W_j (r_j - Cl_j^T z_{j-h} - C_j z_{j+h})  level by level;
-//         x_k = -p_k - P_k E_k^T lambda_k - Q_k lambda_{k+1};
-//     then the residual of the ORIGINAL system (the quantity parallel-solver.hxx:191 tests); if
-//     it exceeds the threshold the problem is flagged and the elimination-chain kernel
-//     (gar_condensed_wave, with the reference's iterative refinement) re-solves it.
+//  3. back-substitution, z_0 = S_0^{-1} r_0 ;  z_j = W_j (r_j - Cl_j^T z_{j-h} - C_j z_{j+h})  level
+//     by level: the top levels (a handful of blocks) in one workgroup, the wide ones a launch each;
+//  4. recovery of the states, x_k = -p_k - P_k E_k^T lambda_k - Q_k lambda_{k+1}, and the residual
+//     of the ORIGINAL system (the quantity parallel-solver.hxx:191 tests), one wave per leg; if it
+//     exceeds the threshold the elimination-chain kernel (gar_condensed_wave, with the reference's
+//     iterative refinement) re-solves the problem.
 // Arithmetic differs from the reference's elimination order; parity is to the stated fp64
 // tolerance, checked by the same residual the reference checks.
 #pragma once
@@ -37,8 +37,7 @@ namespace gar {
 
 struct CyclicParams {
   CondensedParams C; // tuples, problems, scratch, csol, status, dims
-  int h;             // reduction level stride
-  int *flag;         // per problem: 1 = residual above threshold, re-solve with the chain kernel
+  int h;             // reduce / back-substitution level stride (top kernel: the last level it runs)
 };
 
 // scratch carve (doubles, per problem), J = num_legs, bs = NX*NX; fits in the 8*J*bs + ... of the
@@ -274,8 +273,10 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
   const int row = lane < NX ? lane : NX - 1;
   const int nc0 = P.nc0;
   const bool has_next = (k + 1 < J);
-  if (k == 0 && lane == 0)
-    Y.flag[b] = 0;
+  if (k == 0 && lane == 0) {
+    X.info[0] = 0.0; // the residual norm is accumulated with atomicMax by gar_cyclic_recover
+    X.info[1] = 0.0;
+  }
   cond_copy_block<NX>(Dm, tup, lane); // Vxx_k
   wave_sync();
   int failed = cyc_inverse<NX>(sm, lane); // Wm = P_k
@@ -422,24 +423,38 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_reduce(CyclicParams Y) {
     atomicOr(&P.status[b], 4);
 }
 
-// ---- 3. back-substitution, recovery of the states, residual ----------------------------------
+// ---- 3. back-substitution ---------------------------------------------------------------------
+// z_j = W_j (r_j - Cl_j^T z_{j-h} - C_j z_{j+h}) for one block eliminated at level h
 template <int NX>
-__global__ void __launch_bounds__(256) gar_cyclic_backsub(CyclicParams Y) {
-  using L = CyclicLds<NX>;
+__device__ __forceinline__ void cyc_backsolve_block(const CyclicScratch<NX> &X, int j, int h, int J,
+                                                    int lane) {
   constexpr int bs = NX * NX;
+  const int row = lane < NX ? lane : NX - 1;
+  double v = X.r[j * NX + row];
+  if (h == 1)
+    v -= X.p[j * NX + row];
+  v -= cyc_matvecT<NX>(X.Cl + (long long)j * bs, X.z[(j - h) * NX + row], row);
+  if (j + h < J)
+    v -= cyc_matvec<NX>(X.C + (long long)j * bs, X.z[(j + h) * NX + row], row);
+  const double zj = cyc_matvec<NX>(X.W + (long long)j * bs, v, row);
+  if (lane < NX)
+    X.z[j * NX + lane] = zj;
+}
+
+// the top of the tree in one workgroup: z_0 = S_0^{-1} r_0 (the only block never eliminated), then
+// the levels hmax .. Y.h, which hold a handful of blocks each
+template <int NX>
+__global__ void __launch_bounds__(256) gar_cyclic_top(CyclicParams Y) {
+  using L = CyclicLds<NX>;
   const CondensedParams &P = Y.C;
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-  const int b = (int)blockIdx.x, J = P.num_legs, nblk = 2 * J;
+  const int b = (int)blockIdx.x, J = P.num_legs;
   double *sm = gar_smem;
   CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
-  const double *prob = P.prob + (long long)b * P.prob_stride;
-  double *sol = P.csol + (long long)b * nblk * NX;
   const int row = lane < NX ? lane : NX - 1;
-  const int nc0 = P.nc0;
   int hmax = 1;
   while (2 * hmax < J)
     hmax *= 2;
-  // z_0 = S_0^{-1} r_0 (the only block never eliminated)
   if (wave == 0) {
     cond_copy_block<NX>(sm + L::oD, X.S, lane);
     wave_sync();
@@ -452,106 +467,106 @@ __global__ void __launch_bounds__(256) gar_cyclic_backsub(CyclicParams Y) {
   }
   __threadfence_block();
   __syncthreads();
-  for (int h = hmax; h >= 1; h >>= 1) {
-    const bool first = (h == 1);
-    // eliminated at this level: j = h, 3h, 5h, ... < J
-    for (int q = wave; (2 * q + 1) * h < J; q += nw) {
-      const int j = (2 * q + 1) * h;
-      double v = X.r[j * NX + row];
-      if (first)
-        v -= X.p[j * NX + row];
-      v -= cyc_matvecT<NX>(X.Cl + (long long)j * bs, X.z[(j - h) * NX + row], row);
-      if (j + h < J)
-        v -= cyc_matvec<NX>(X.C + (long long)j * bs, X.z[(j + h) * NX + row], row);
-      const double zj = cyc_matvec<NX>(X.W + (long long)j * bs, v, row);
-      if (lane < NX)
-        X.z[j * NX + lane] = zj;
-    }
+  for (int h = hmax; h >= Y.h; h >>= 1) {
+    for (int q = wave; (2 * q + 1) * h < J; q += nw)
+      cyc_backsolve_block<NX>(X, (2 * q + 1) * h, h, J, lane);
     __threadfence_block();
     __syncthreads();
   }
-  // lambda_k = z_k ; x_k = -p_k - P_k E_k^T lambda_k - Q_k lambda_{k+1}
-  for (int k = wave; k < J; k += nw) {
-    const double lam = X.z[k * NX + row];
-    double x = -X.p[k * NX + row];
-    if (k == 0) { // E_0 = G0 (nc0 x NX): (G0^T lambda)(row) then P_0 times it
-      double g = 0.0;
-      for (int c = 0; c < nc0; ++c)
-        g += prob[P.G0_off + row * nc0 + c] * lane_bcast(lam, c);
-      x -= cyc_matvec<NX>(X.P, g, row);
-    } else {
-      x += cyc_matvec<NX>(X.P + (long long)k * bs, lam, row);
-    }
-    if (k + 1 < J)
-      x -= cyc_matvec<NX>(X.Q + (long long)k * bs, X.z[(k + 1) * NX + row], row);
-    if (lane < NX) {
-      sol[(2 * k) * NX + lane] = (k == 0 && lane >= nc0) ? 0.0 : lam;
-      sol[(2 * k + 1) * NX + lane] = x;
-    }
+}
+
+// one lower level: a wave per eliminated block
+template <int NX>
+__global__ void __launch_bounds__(64) gar_cyclic_backlevel(CyclicParams Y) {
+  const CondensedParams &P = Y.C;
+  const int lane = (int)threadIdx.x & 63;
+  const int b = (int)blockIdx.y, J = P.num_legs, h = Y.h;
+  const int j = (2 * (int)blockIdx.x + 1) * h;
+  if (j >= J)
+    return;
+  CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
+  cyc_backsolve_block<NX>(X, j, h, J, lane);
+}
+
+// ---- 4. recovery of the states and the residual of the ORIGINAL system, a wave per leg --------
+//   lambda_k = z_k ;  x_k = -p_k - P_k E_k^T lambda_k - Q_k lambda_{k+1}
+//   rows 2k (lambda_k row) and 2k+1 (x_k row) of rhs - A sol (blockTridiagMatMul,
+//   block-tridiagonal.hpp:52-75); x_{k-1} is recomputed locally so that one launch suffices;
+//   the infinity norm is accumulated with atomicMax on the bit pattern (non-negative doubles
+//   order like their bits, NaN above everything)
+template <int NX>
+__global__ void __launch_bounds__(64) gar_cyclic_recover(CyclicParams Y) {
+  constexpr int bs = NX * NX;
+  const CondensedParams &P = Y.C;
+  const int lane = (int)threadIdx.x & 63;
+  const int k = (int)blockIdx.x, b = (int)blockIdx.y, J = P.num_legs, nblk = 2 * J;
+  CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  double *sol = P.csol + (long long)b * nblk * NX;
+  const int row = lane < NX ? lane : NX - 1;
+  const int nc0 = P.nc0;
+  auto G0T = [&](double lam) { // (G0^T lam)(row)
+    double g = 0.0;
+    for (int c = 0; c < nc0; ++c)
+      g += prob[P.G0_off + row * nc0 + c] * lane_bcast(lam, c);
+    return g;
+  };
+  auto state = [&](int kk, double lam, double lamn) {
+    double x = -X.p[kk * NX + row];
+    if (kk == 0)
+      x -= cyc_matvec<NX>(X.P, G0T(lam), row);
+    else
+      x += cyc_matvec<NX>(X.P + (long long)kk * bs, lam, row);
+    if (kk + 1 < J)
+      x -= cyc_matvec<NX>(X.Q + (long long)kk * bs, lamn, row);
+    return x;
+  };
+  double lam = X.z[k * NX + row];
+  if (k == 0 && lane >= nc0)
+    lam = 0.0;
+  const double lamn = (k + 1 < J) ? X.z[(k + 1) * NX + row] : 0.0;
+  const double x = state(k, lam, lamn);
+  if (lane < NX) {
+    sol[(2 * k) * NX + lane] = lam;
+    sol[(2 * k + 1) * NX + lane] = x;
   }
-  __threadfence_block();
-  __syncthreads();
-  // residual of the original system (blockTridiagMatMul, block-tridiagonal.hpp:52-75), block rows
-  // spread over the waves; infinity norm through LDS
-  double mx = 0.0;
-  for (int i = wave; i < nblk; i += nw) {
-    const double xi = sol[i * NX + row];
-    double r;
-    if (i == 0) {
-      r = row < nc0 ? -prob[P.g0_off + row] : 0.0;
-    } else {
-      const double *tup = cond_tuple(P, b, (i - 1) >> 1);
-      const int off = (i & 1) ? 0 : 2 * bs;
-      r = -tup[3 * bs + ((i & 1) ? 0 : NX) + row] - cyc_matvec<NX>(tup + off, xi, row);
-    }
-    if (i > 0) {
-      const double xp = sol[(i - 1) * NX + row];
-      if (i - 1 == 0) {
-        double s = 0.0;
-        for (int c = 0; c < nc0; ++c)
-          s += prob[P.G0_off + row * nc0 + c] * lane_bcast(xp, c);
-        r -= s;
-      } else if (((i - 1) & 1) == 0) {
-        r += xp;
-      } else {
-        r -= cyc_matvecT<NX>(cond_tuple(P, b, (i - 2) >> 1) + bs, xp, row);
-      }
-    }
-    if (i < nblk - 1) {
-      const double xn = sol[(i + 1) * NX + row];
-      if (i == 0) {
-        double s = 0.0;
-        for (int c = 0; c < NX; ++c)
-          s += (row < nc0 ? prob[P.G0_off + c * nc0 + row] : 0.0) * lane_bcast(xn, c);
-        r -= s;
-      } else if ((i & 1) == 0) {
-        r += xn;
-      } else {
-        r -= cyc_matvec<NX>(cond_tuple(P, b, (i - 1) >> 1) + bs, xn, row);
-      }
-    }
-    if (lane >= NX || (i == 0 && lane >= nc0))
-      r = 0.0;
-    const double av = fabs(r);
-    mx = (av > mx || av != av) ? av : mx;
+  const double *tup = cond_tuple(P, b, k);
+  // x_k row: -vx_k - Vxx_k x_k - E_k^T lambda_k - Vxt_k lambda_{k+1}
+  double rx = -tup[3 * bs + row] - cyc_matvec<NX>(tup, x, row);
+  rx -= (k == 0) ? G0T(lam) : -lam;
+  if (k + 1 < J)
+    rx -= cyc_matvec<NX>(tup + bs, lamn, row);
+  // lambda_k row
+  double rl;
+  if (k == 0) { // -g0 - G0 x_0
+    double s = 0.0;
+    for (int c = 0; c < NX; ++c)
+      s += (row < nc0 ? prob[P.G0_off + c * nc0 + row] : 0.0) * lane_bcast(x, c);
+    rl = (row < nc0 ? -prob[P.g0_off + row] : 0.0) - s;
+    if (lane >= nc0)
+      rl = 0.0;
+  } else { // -vt_{k-1} - Vxt_{k-1}^T x_{k-1} - Vtt_{k-1} lambda_k + x_k
+    double lamp = X.z[(k - 1) * NX + row];
+    if (k - 1 == 0 && lane >= nc0)
+      lamp = 0.0;
+    const double xp = state(k - 1, lamp, lam);
+    const double *tp = cond_tuple(P, b, k - 1);
+    rl = -tp[3 * bs + NX + row] - cyc_matvecT<NX>(tp + bs, xp, row) -
+         cyc_matvec<NX>(tp + 2 * bs, lam, row) + x;
   }
+  double mx = fmax(fabs(rx), fabs(rl));
+  if (rx != rx || rl != rl)
+    mx = rx + rl; // NaN
+  if (lane >= NX)
+    mx = 0.0;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const double other = __shfl_xor(mx, o);
     mx = (other > mx || other != other) ? other : mx;
   }
-  double *red = sm; // LDS is free again
   if (lane == 0)
-    red[wave] = mx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double m = 0.0;
-    for (int w = 0; w < nw; ++w)
-      m = (red[w] > m || red[w] != red[w]) ? red[w] : m;
-    X.info[0] = m;
-    X.info[1] = 0.0;
-    Y.flag[b] = !(m <= P.threshold) && P.max_refinement > 0;
-  }
+    atomicMax(reinterpret_cast<unsigned long long *>(&X.info[0]),
+              (unsigned long long)__double_as_longlong(fabs(mx)));
 }
 
 } // namespace gar

@@ -674,7 +674,7 @@ struct CondensedParams {
   int max_refinement;
   double threshold;
   long long *trace; // debug: cycle stamps of two elimination steps of problem 0 (or null)
-  const int *gate;  // if non-null: only the problems with gate[b] != 0 are solved
+  int gated;        // 1: skip the problems whose cyclic-reduction residual (scratch info[0]) met the threshold
   // scratch layout (doubles, per problem): nblk = 2*num_legs, bs = nxb*nxb
   //   diag[nblk][bs] super[nblk][bs] facD[nblk][bs] U[nblk][bs]
   //   fsub[nblk][nxb] rhs[nblk][nxb] err[nblk][nxb] fpiv[nblk][nxb] (ints in doubles)
@@ -692,6 +692,11 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
   double *sm = gar_smem;
   const int b = (int)blockIdx.x;
   const int nxb = P.nxb, bs = nxb * nxb, nblk = 2 * P.num_legs, N = nblk - 1;
+  if (P.gated) { // already solved to the residual threshold by the cyclic-reduction kernels?
+    const double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * bs + 4ll * nblk * nxb;
+    if (inf[0] <= P.threshold || P.max_refinement == 0)
+      return;
+  }
   double *S = P.scratch + (long long)b * P.scratch_stride;
   double *diag = S, *super = diag + (long long)nblk * bs, *facD = super + (long long)nblk * bs;
   double *U = facD + (long long)nblk * bs;

@@ -81,8 +81,7 @@ struct gar_hip_solver {
   // one-wave-per-(problem, leg) kernels (gar_wave_leg.hpp), bound for uniform leg-mode problems
   void (*leg_bwd_kernel)(gar::LegParams) = nullptr;
   void (*leg_tuple_kernel)(gar::LegParams) = nullptr;
-  void (*leg_fwd_param_kernel)(gar::LegParams) = nullptr;
-  void (*leg_fwd_final_kernel)(gar::LegParams) = nullptr;
+  void (*leg_fwd_kernel)(gar::LegParams) = nullptr;
   void (*leg_collapse_kernel)(const gar_stage_meta *, double *, long long, int) = nullptr;
   int leg_lds_doubles = 0;
   void (*cond_wave_kernel)(gar::CondensedParams) = nullptr;
@@ -90,9 +89,10 @@ struct gar_hip_solver {
   // block cyclic reduction of the condensed system (gar_cyclic.hpp), preferred when bound
   void (*cyc_setup_kernel)(gar::CyclicParams) = nullptr;
   void (*cyc_reduce_kernel)(gar::CyclicParams) = nullptr;
-  void (*cyc_backsub_kernel)(gar::CyclicParams) = nullptr;
+  void (*cyc_top_kernel)(gar::CyclicParams) = nullptr;
+  void (*cyc_backlevel_kernel)(gar::CyclicParams) = nullptr;
+  void (*cyc_recover_kernel)(gar::CyclicParams) = nullptr;
   int cyc_lds_doubles = 0;
-  int *d_cyc_flag = nullptr;
   long long *d_trace = nullptr; // 64 cycle stamps (debug)
   // optional per-kernel timing of the sweep (bench.py's roofline figure): HIP events recorded on
   // the launch stream around the backward sweep kernel, the initial-stage kernel and the forward
@@ -301,8 +301,7 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
 template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
   s->leg_bwd_kernel = gar::gar_backward_wave_leg<NX, NU>;
   s->leg_tuple_kernel = gar::gar_leg_tuples<NX, NU>;
-  s->leg_fwd_param_kernel = gar::gar_forward_wave_leg<NX, NU, true>;
-  s->leg_fwd_final_kernel = gar::gar_forward_wave_leg<NX, NU, false>;
+  s->leg_fwd_kernel = gar::gar_forward_wave_leg<NX, NU>;
   s->leg_collapse_kernel = gar::gar_collapse_feedback_t2<NX, NU>;
   s->leg_lds_doubles = gar::WaveCfg<NX, NU>::leg_total;
   const char *ck = std::getenv("GAR_HIP_CONDENSED");
@@ -312,12 +311,14 @@ template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
     if ((size_t)lds * sizeof(double) <= 160 * 1024) {
       s->cond_wave_kernel = gar::gar_condensed_wave<NX>;
       s->cond_wave_lds_doubles = lds;
-      if (!(ck && std::string(ck) == "chain")) {
-        s->cyc_setup_kernel = gar::gar_cyclic_setup<NX>;
-        s->cyc_reduce_kernel = gar::gar_cyclic_reduce<NX>;
-        s->cyc_backsub_kernel = gar::gar_cyclic_backsub<NX>;
-        s->cyc_lds_doubles = gar::CyclicLds<NX>::total;
-      }
+    }
+    if (!(ck && std::string(ck) == "chain")) {
+      s->cyc_setup_kernel = gar::gar_cyclic_setup<NX>;
+      s->cyc_reduce_kernel = gar::gar_cyclic_reduce<NX>;
+      s->cyc_top_kernel = gar::gar_cyclic_top<NX>;
+      s->cyc_backlevel_kernel = gar::gar_cyclic_backlevel<NX>;
+      s->cyc_recover_kernel = gar::gar_cyclic_recover<NX>;
+      s->cyc_lds_doubles = gar::CyclicLds<NX>::total;
     }
   }
   s->kernel_name = "wave_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
@@ -353,13 +354,14 @@ void select_leg_kernel(gar_hip_solver *s) {
 void select_kernel(gar_hip_solver *s) {
   s->leg_bwd_kernel = nullptr;
   s->leg_tuple_kernel = nullptr;
-  s->leg_fwd_param_kernel = nullptr;
-  s->leg_fwd_final_kernel = nullptr;
+  s->leg_fwd_kernel = nullptr;
   s->leg_collapse_kernel = nullptr;
   s->cond_wave_kernel = nullptr;
   s->cyc_setup_kernel = nullptr;
   s->cyc_reduce_kernel = nullptr;
-  s->cyc_backsub_kernel = nullptr;
+  s->cyc_top_kernel = nullptr;
+  s->cyc_backlevel_kernel = nullptr;
+  s->cyc_recover_kernel = nullptr;
   s->mfma_kernel = nullptr;
   s->mfma_fwd_kernel = nullptr;
   s->wave_kernel = nullptr;
@@ -558,19 +560,12 @@ int launch_backward(gar_hip_solver *s, double mueq) {
 }
 
 int launch_forward(gar_hip_solver *s, const double *theta_dev) {
-  if (s->leg_fwd_param_kernel) {
+  if (s->leg_fwd_kernel) {
     gar::LegParams Q = make_leg_params(s);
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[3], s->stream));
-    // the non-final local legs, then (if this rank owns it) the final leg
-    const int last = s->num_legs - 1;
-    const int nparam = std::min(s->leg_end, last) - s->leg_begin;
-    if (nparam > 0)
-      hipLaunchKernelGGL(s->leg_fwd_param_kernel, dim3((unsigned)nparam, (unsigned)s->batch),
-                         dim3(64), 0, s->stream, Q);
-    if (s->leg_end == s->num_legs)
-      hipLaunchKernelGGL(s->leg_fwd_final_kernel, dim3(1u, (unsigned)s->batch), dim3(64), 0,
-                         s->stream, Q);
+    hipLaunchKernelGGL(s->leg_fwd_kernel, dim3((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch),
+                       dim3(64), 0, s->stream, Q);
     HIP_TRY(hipGetLastError());
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[4], s->stream));
@@ -629,12 +624,11 @@ int launch_condensed(gar_hip_solver *s) {
   C.max_refinement = s->max_refinement;
   C.threshold = s->cond_threshold;
   C.trace = s->d_trace;
-  C.gate = nullptr;
+  C.gated = 0;
   if (s->cyc_setup_kernel) {
     gar::CyclicParams Y{};
     Y.C = C;
     Y.h = 0;
-    Y.flag = s->d_cyc_flag;
     const int J = s->num_legs;
     const size_t lds = (size_t)s->cyc_lds_doubles * sizeof(double);
     hipLaunchKernelGGL(s->cyc_setup_kernel, dim3((unsigned)J, (unsigned)s->batch), dim3(64), lds,
@@ -645,9 +639,26 @@ int launch_condensed(gar_hip_solver *s) {
                          dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch), dim3(64),
                          lds, s->stream, Y);
     }
-    hipLaunchKernelGGL(s->cyc_backsub_kernel, dim3((unsigned)s->batch), dim3(256), lds, s->stream, Y);
+    // back-substitution: the levels holding at most 4 blocks in one workgroup, the wider ones a
+    // launch each; then the states and the residual, a wave per leg
+    int hmax = 1;
+    while (2 * hmax < J)
+      hmax *= 2;
+    int htop = hmax;
+    while (htop > 1 && (J / (htop / 2) + 1) / 2 <= 4)
+      htop /= 2;
+    Y.h = htop;
+    hipLaunchKernelGGL(s->cyc_top_kernel, dim3((unsigned)s->batch), dim3(256), lds, s->stream, Y);
+    for (int h = htop / 2; h >= 1; h /= 2) {
+      Y.h = h;
+      hipLaunchKernelGGL(s->cyc_backlevel_kernel,
+                         dim3((unsigned)((J / h + 1) / 2), (unsigned)s->batch), dim3(64), 0,
+                         s->stream, Y);
+    }
+    hipLaunchKernelGGL(s->cyc_recover_kernel, dim3((unsigned)J, (unsigned)s->batch), dim3(64), 0,
+                       s->stream, Y);
     HIP_TRY(hipGetLastError());
-    C.gate = s->d_cyc_flag; // the chain kernel (with refinement) re-solves only flagged problems
+    C.gated = 1; // the chain kernel (with refinement) re-solves only what missed the threshold
   }
   if (s->cond_wave_kernel)
     hipLaunchKernelGGL(s->cond_wave_kernel, dim3((unsigned)s->batch), dim3(64),
@@ -691,8 +702,7 @@ void free_device(gar_hip_solver *s) {
     (void)hipFree(s->d_bound_all);
   (void)hipFree(s->d_csol);
   (void)hipFree(s->d_cscratch);
-  (void)hipFree(s->d_cyc_flag);
-  s->d_cyc_flag = nullptr;
+
   (void)hipFree(s->d_trace);
   s->d_trace = nullptr;
   (void)hipFree(s->d_deriv_off);
@@ -739,8 +749,6 @@ int allocate(gar_hip_solver *s) {
     s->cscratch_doubles = (int64_t)(4 * nblk * bs + 4 * (size_t)nblk * s->nxb + 4);
     HIP_TRY(hipMalloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
     s->cond_lds_doubles = (int)(2 * bs + s->nxb + 2 + (s->nxb + 16) / 2 + 2);
-    HIP_TRY(hipMalloc((void **)&s->d_cyc_flag, sizeof(int) * B));
-    HIP_TRY(hipMemset(s->d_cyc_flag, 0, sizeof(int) * B));
   }
   const size_t staging = sizeof(double) * (size_t)s->prob_doubles * B;
   if (staging <= ((size_t)1 << 30)) {
@@ -759,7 +767,7 @@ int allocate(gar_hip_solver *s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_reduce_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_backsub_kernel,
+    HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_top_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   if (s->cond_wave_kernel)

@@ -333,11 +333,14 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
   constexpr int bs = NX * NX;
   const int lane = (int)threadIdx.x & 63;
   const int b = (int)blockIdx.x;
-  if (P.gate != nullptr && P.gate[b] == 0)
-    return; // the cyclic-reduction solve of this problem met the residual threshold
+  const int nblk = 2 * P.num_legs, N = nblk - 1;
+  if (P.gated) { // the cyclic-reduction solve of this problem met the residual threshold?
+    const double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * NX * NX + 4ll * nblk * NX;
+    if (inf[0] <= P.threshold || P.max_refinement == 0)
+      return;
+  }
   const WG w1 = wave_self();
   double *sm = gar_smem;
-  const int nblk = 2 * P.num_legs, N = nblk - 1;
   using K = CondCfg<NX>;
   constexpr int TX = K::TX, KS = K::KS;
   const int li = lane & 15, lk = lane >> 4;
@@ -699,19 +702,13 @@ __device__ __forceinline__ void leg_fwd_load(const double *rec, const double *re
 }
 
 template <int NX, int NU, bool PARAM>
-__global__ void __launch_bounds__(64) gar_forward_wave_leg(LegParams Q) {
+__device__ __forceinline__ void leg_forward_body(const LegParams &Q, int leg, int b, int lane) {
   using C = WaveCfg<NX, NU>;
   using M = MfmaCfg<NX, NU>;
   constexpr int NW = C::NW;
-  const int lane = (int)threadIdx.x;
-  // PARAM kernels cover the non-final legs, the other instantiation the final leg
-  const int leg = PARAM ? (int)blockIdx.x + Q.leg_begin : Q.num_legs - 1;
-  const int b = (int)blockIdx.y;
   const int N = Q.M.horizon;
   int t_beg, t_end;
   gar_get_work(N, leg, Q.num_legs, &t_beg, &t_end);
-  if (PARAM && leg >= Q.num_legs - 1)
-    return;
   const double *facb = Q.M.fac + (long long)b * Q.M.fac_stride;
   double *sol = Q.sol + (long long)b * Q.sol_stride;
   const double *cs = Q.csol + (long long)b * (2 * Q.num_legs) * NX;
@@ -794,6 +791,19 @@ __global__ void __launch_bounds__(64) gar_forward_wave_leg(LegParams Q) {
       sol[Q.sol_l + Q.nc0 + (long long)t * NX + lane] = lam;
     xs = acc;
   }
+}
+
+// one launch for all local legs: the parameterised roll-out for the non-final legs, the plain one
+// for the final leg
+template <int NX, int NU>
+__global__ void __launch_bounds__(64) gar_forward_wave_leg(LegParams Q) {
+  const int lane = (int)threadIdx.x;
+  const int leg = (int)blockIdx.x + Q.leg_begin;
+  const int b = (int)blockIdx.y;
+  if (leg < Q.num_legs - 1)
+    leg_forward_body<NX, NU, true>(Q, leg, b, lane);
+  else
+    leg_forward_body<NX, NU, false>(Q, leg, b, lane);
 }
 
 } // namespace gar

@@ -137,6 +137,7 @@ inline unsigned long long __ballot(int pred) {
   return m;
 }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline long long __double_as_longlong(double d) { long long b; std::memcpy(&b, &d, 8); return b; }
 inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
 inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 inline double __hiloint2double(int hi, int lo) {
@@ -153,6 +154,7 @@ inline long long clock64() { return 0; }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 inline double __builtin_amdgcn_rcp(double a) { return 1.0 / a; }
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return o; }
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 
 // ---- runtime -------------------------------------------------------------------
