@@ -354,19 +354,22 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
 }
 
 // ---- 2. one reduction level -------------------------------------------------------------------
+// Two waves per survivor: wave 0 folds in the right neighbour, wave 1 the left one (each inverts
+// its neighbour in its own LDS slice); wave 0 then adds wave 1's contribution and stores.
 template <int NX>
-__global__ void __launch_bounds__(64, 1) gar_cyclic_reduce(CyclicParams Y) {
+__global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
   using L = CyclicLds<NX>;
   using K = CondCfg<NX>;
   constexpr int bs = NX * NX, TX = K::TX;
   const CondensedParams &P = Y.C;
-  const int lane = (int)threadIdx.x & 63;
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
   const int h = Y.h, J = P.num_legs;
   const int i = 2 * h * (int)blockIdx.x, b = (int)blockIdx.y;
   if (i >= J)
     return;
   const bool first = (h == 1); // the -P_j / -p_j halves of S_j, r_j are still separate
-  double *sm = gar_smem;
+  double *sm = gar_smem + wave * L::total;
+  double *xch = gar_smem + 2 * L::total; // r_i contribution of wave 1
   double *Dm = sm + L::oD, *Wm = sm + L::oW, *Bm = sm + L::oB, *D2 = sm + L::oD2;
   CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
   const int row = lane < NX ? lane : NX - 1;
@@ -381,9 +384,15 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_reduce(CyclicParams Y) {
       v -= X.p[j * NX + row];
     return v;
   };
-  load_S(D2, i); // own block
-  double ri = r_of(i);
-  if (i + h < J) { // right eliminated neighbour j = i + h
+  double ri = 0.0;
+  if (wave == 0) {
+    load_S(D2, i); // own block
+    ri = r_of(i);
+  } else {
+    for (int e = lane; e < bs; e += 64)
+      D2[e] = 0.0;
+  }
+  if (wave == 0 && i + h < J) { // right eliminated neighbour j = i + h
     const int j = i + h;
     load_S(Dm, j);
     cond_copy_block<NX>(Bm, X.C + (long long)i * bs, lane); // C_i (row i, column j)
@@ -403,7 +412,7 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_reduce(CyclicParams Y) {
     }
     wave_sync();
   }
-  if (i - h >= 0) { // left eliminated neighbour j = i - h
+  if (wave == 1 && i - h >= 0) { // left eliminated neighbour j = i - h
     const int j = i - h;
     load_S(Dm, j);
     cond_copy_block<NX>(Bm, X.C + (long long)j * bs, lane); // C_j (row j, column i)
@@ -415,10 +424,23 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_reduce(CyclicParams Y) {
     ri -= cyc_matvecT<NX>(Bm, y, row);
     wave_sync();
   }
-  // first level: the stored S_i / r_i become the complete ones (S slot was missing -P_i)
-  cyc_store_block<NX>(S_of(i), D2, lane);
-  if (lane < NX)
-    X.r[i * NX + lane] = ri;
+  if (wave == 1 && lane < NX)
+    xch[lane] = ri;
+  __syncthreads();
+  if (wave == 0) {
+    const double *D2b = gar_smem + L::total + L::oD2;
+    if (i - h >= 0) {
+#pragma unroll
+      for (int e = lane; e < bs; e += 64)
+        D2[e] += D2b[e];
+      ri += xch[row];
+      wave_sync();
+    }
+    // first level: the stored S_i / r_i become the complete ones (S slot was missing -P_i)
+    cyc_store_block<NX>(S_of(i), D2, lane);
+    if (lane < NX)
+      X.r[i * NX + lane] = ri;
+  }
   if (failed && lane == 0)
     atomicOr(&P.status[b], 4);
 }

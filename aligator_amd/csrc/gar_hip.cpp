@@ -636,8 +636,8 @@ int launch_condensed(gar_hip_solver *s) {
     for (int h = 1; h < J; h *= 2) {
       Y.h = h;
       hipLaunchKernelGGL(s->cyc_reduce_kernel,
-                         dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch), dim3(64),
-                         lds, s->stream, Y);
+                         dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch), dim3(128),
+                         2 * lds + 64 * sizeof(double), s->stream, Y);
     }
     // back-substitution: the levels holding at most 4 blocks in one workgroup, the wider ones a
     // launch each; then the states and the residual, a wave per leg
@@ -766,7 +766,7 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_setup_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_reduce_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds + 512));
     HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_top_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }

@@ -283,6 +283,12 @@ class BatchedRiccatiSolver:
     def set_refinement(self, threshold: float, max_steps: int):
         self._check(self._L.gar_hip_set_refinement(self._h, float(threshold), int(max_steps)))
 
+    def condensed_info(self, b: int = 0):
+        """(infinity norm of the last condensed residual evaluated, refinement steps taken)."""
+        out = (C.c_double * 2)()
+        self._check(self._L.gar_hip_condensed_info(self._h, int(b), out))
+        return float(out[0]), int(out[1])
+
     def collapse_feedback(self):
         self._factors_cache = {}
         self._check(self._L.gar_hip_collapse_feedback(self._h))

@@ -100,6 +100,73 @@ def test_parallel_wave_leg_batched():
     assert s.kernel_name.startswith("wave_leg<")
 
 
+def _leg_solution(probs, legs, mueq, refine=None, threshold=1e-10):
+    from aligator_amd.gar import BatchedRiccatiSolver
+    dims = [k.dims for k in probs[0].stages]
+    s = BatchedRiccatiSolver(dims, probs[0].nc0, batch=len(probs), num_legs=legs, lib_path=EMU)
+    if refine is not None:
+        s.set_refinement(threshold, refine)
+    s.upload(probs)
+    assert s.backward(mueq) and s.forward()
+    return s, [s.solution(b) for b in range(len(probs))]
+
+
+@pytest.mark.parametrize("legs,horz,nx,nu", [(9, 28, 8, 4), (5, 16, 12, 4)])
+def test_condensed_cyclic_reduction_vs_chain_vs_generic(monkeypatch, legs, horz, nx, nu):
+    """Three solvers of the leg-boundary system -- block cyclic reduction (csrc/gar_cyclic.hpp, the
+    default, here WITHOUT its fallback: refinement off), the wave-scope elimination chain and the
+    generic workgroup kernel that follows the reference's block-tridiagonal routine line by line --
+    agree with each other and with the serial oracle."""
+    probs = [synth.generate_lq_problem(900 + i, np.random.default_rng(i).standard_normal(nx), horz,
+                                       nx, nu, mode="W") for i in range(1)]
+    s, cyc = _leg_solution(probs, legs, 1e-10, refine=0)
+    assert s.kernel_name.startswith("wave_leg<")
+    resid, steps = s.condensed_info(0)
+    assert resid < 1e-9 and steps == 0
+    monkeypatch.setenv("GAR_HIP_CONDENSED", "chain")
+    _, chain = _leg_solution(probs, legs, 1e-10)
+    monkeypatch.setenv("GAR_HIP_CONDENSED", "generic")
+    _, gen = _leg_solution(probs, legs, 1e-10)
+    monkeypatch.delenv("GAR_HIP_CONDENSED")
+    monkeypatch.setenv("GAR_HIP_LEGS", "generic")
+    s4, allgen = _leg_solution(probs, legs, 1e-10)
+    assert s4.kernel_name == "generic"
+    for b, prob in enumerate(probs):
+        _, _, ref = pc.oracle_serial(prob, 1e-10)
+        sc = pc.scale_of(ref)
+        for sol in (cyc[b], chain[b], gen[b], allgen[b]):
+            for A, B in zip(sol, ref):
+                assert pc.maxdiff(A, B) <= 1e-9 * sc
+
+
+def test_condensed_cyclic_fallback_to_chain():
+    """A threshold the cyclic-reduction residual cannot meet gates the elimination-chain kernel
+    in: it re-solves with the reference's iterative refinement and reports its steps."""
+    probs = [synth.generate_lq_problem(950, np.ones(8), 21, 8, 4, mode="W")]
+    s, sol = _leg_solution(probs, 4, 1e-10, refine=3, threshold=1e-300)
+    resid, steps = s.condensed_info(0)
+    assert steps == 3                       # the chain kernel ran (cyclic reduction reports 0 steps)
+    _, _, ref = pc.oracle_serial(probs[0], 1e-10)
+    for A, B in zip(sol[0], ref):
+        assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
+
+
+@pytest.mark.parametrize("nc0", [0, 3])
+def test_leg_kernels_partial_initial_constraint(nc0):
+    """G0 with fewer rows than states (nc0 < nx): block 0 of the condensed system is padded."""
+    from aligator_amd.lqr import LqrProblem
+    rng = np.random.default_rng(5)
+    p0 = synth.generate_lq_problem(rng, rng.standard_normal(8), 13, 8, 4, mode="W")
+    prob = LqrProblem(p0.stages, nc0)
+    prob.G0[...] = rng.standard_normal((nc0, 8))
+    prob.g0[...] = rng.standard_normal(nc0)
+    s, sol = _leg_solution([prob], 4, 1e-10, refine=0)
+    assert s.kernel_name.startswith("wave_leg<")
+    _, _, ref = pc.oracle_serial(prob, 1e-10)
+    for A, B in zip(sol[0], ref):
+        assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
+
+
 def test_parallel_rejects_single_thread():                    # parallel-solver.hxx:42-46
     from aligator_amd.gar import ParallelRiccatiSolver
     prob = synth.generate_lq_problem(1, np.zeros(2), 4, 2, 2)

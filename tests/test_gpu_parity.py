@@ -129,6 +129,53 @@ def test_config4_shape_legs_on_one_gpu():
     pc.check_parallel(prob, 1e-9, 8, 1e-7)
 
 
+@pytest.mark.parametrize("nx,nu,horz,legs", [(36, 12, 256, 32), (36, 12, 257, 7), (32, 12, 64, 8),
+                                              (16, 8, 100, 16), (12, 4, 60, 5), (8, 4, 40, 12)])
+def test_wave_leg_kernels_and_cyclic_reduction(nx, nu, horz, legs):
+    """Parallel-in-time at kernel speed (csrc/gar_wave_leg.hpp, csrc/gar_cyclic.hpp): per-stage
+    factors against the oracle's own leg-parallel solver, solution against the serial oracle,
+    collapseFeedback, a re-solve after the problem changed (tests/gar/parallel.cpp:185-245)."""
+    rng = np.random.default_rng(4000 + nx + legs)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+    par = pc.check_parallel(prob, 1e-10, legs, 1e-9, rounds=1, rng=rng)
+    assert par._impl.kernel_name == f"wave_leg<{nx},{nu}>"
+
+
+def test_condensed_solvers_agree_on_gpu(monkeypatch):
+    """Block cyclic reduction (no fallback: refinement off), the elimination chain and the generic
+    kernel on the north-star shape, 64 legs, a batch of problems; and the gated fallback."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    nx, nu, N, legs = 36, 12, 512, 64
+    probs = [synth.generate_lq_problem(4100 + i, np.full(nx, 0.1 * i), N, nx, nu, mode="W") for i in range(3)]
+    dims = [k.dims for k in probs[0].stages]
+
+    def solve(refine=None, thr=1e-10):
+        s = BatchedRiccatiSolver(dims, nx, batch=len(probs), num_legs=legs)
+        if refine is not None:
+            s.set_refinement(thr, refine)
+        s.upload(probs)
+        assert s.backward(1e-10) and s.forward()
+        return s, [s.solution(b) for b in range(len(probs))]
+
+    s, cyc = solve(refine=0)
+    assert s.kernel_name == "wave_leg<36,12>"
+    for b in range(len(probs)):
+        resid, steps = s.condensed_info(b)
+        assert resid < 1e-9 and steps == 0
+    s2, gated = solve(refine=2, thr=1e-300)
+    assert s2.condensed_info(0)[1] == 2          # the chain kernel (with refinement) took over
+    monkeypatch.setenv("GAR_HIP_CONDENSED", "chain")
+    _, chain = solve()
+    monkeypatch.setenv("GAR_HIP_CONDENSED", "generic")
+    _, gen = solve()
+    for b, prob in enumerate(probs):
+        _, _, ref = pc.oracle_serial(prob, 1e-10)
+        sc = pc.scale_of(ref)
+        for sol in (cyc[b], gated[b], chain[b], gen[b]):
+            for A, B in zip(sol, ref):
+                assert pc.maxdiff(A, B) <= 1e-9 * sc
+
+
 def test_sharded_solver_single_rank_rccl():
     """aligator_amd.sharded on the real device path: torch views of the library's device
     buffers, all_gather_into_tensor over RCCL (world_size 1 is all a 1-GPU box offers; the
@@ -145,18 +192,19 @@ def test_sharded_solver_single_rank_rccl():
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
                             device_id=torch.device("cuda", 0))
     try:
-        prob = synth.generate_lq_problem(32, np.zeros(12), 255, 12, 6, mode="W")
-        _, _, ref = pc.oracle_serial(prob, 1e-9)
-        for legs in (2, 8):
-            s = ShardedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, legs, batch=1)
-            s.impl.upload([prob])
-            s.backward(1e-9)
-            s.forward()
-            sol = s.gather_solution(0)
-            sc = pc.scale_of(ref)
-            for A, B in zip(sol, ref):
-                assert pc.maxdiff(A, B) <= 1e-7 * sc
-            assert max(lqrComputeKktError(prob, *sol, mueq=1e-9)) <= 1e-7 * sc
+        for (nx, nu) in ((12, 6), (36, 12)):  # generic leg kernels ; wave-leg kernels + cyclic reduction
+            prob = synth.generate_lq_problem(32, np.zeros(nx), 255, nx, nu, mode="W")
+            _, _, ref = pc.oracle_serial(prob, 1e-9)
+            for legs in (2, 8):
+                s = ShardedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, legs, batch=1)
+                s.impl.upload([prob])
+                s.backward(1e-9)
+                s.forward()
+                sol = s.gather_solution(0)
+                sc = pc.scale_of(ref)
+                for A, B in zip(sol, ref):
+                    assert pc.maxdiff(A, B) <= 1e-7 * sc
+                assert max(lqrComputeKktError(prob, *sol, mueq=1e-9)) <= 1e-7 * sc
     finally:
         dist.destroy_process_group()
 
