@@ -471,7 +471,7 @@ gar::LegParams make_leg_params(gar_hip_solver *s) {
   Q.M.in_rec = N > 1 ? s->meta[1].in_off - s->meta[0].in_off : s->meta[N].in_off - s->meta[0].in_off;
   Q.M.in_offN = s->meta[N].in_off;
   Q.M.horizon = N;
-  Q.M.trace = nullptr;
+  Q.M.trace = s->d_trace;
   Q.meta = s->d_meta;
   Q.num_legs = s->num_legs;
   Q.leg_begin = s->leg_begin;
