@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B two builds of the library in the same visit (same box, alternating), backward sweep ms
 for rep in 1 2 3; do
-  for lib in aligator_amd/libgar_hip.so aligator_amd/libgar_hip_norem4.so; do
+  for lib in aligator_amd/libgar_hip.so ${AB_LIB:-aligator_amd/libgar_hip_norem4.so}; do
     cp $lib /tmp/lib_ab.so
     python - <<PY
 import json, subprocess, sys, os
