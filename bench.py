@@ -98,6 +98,41 @@ def cpu_baseline(args, nx, nu, N, mueq):
                       f"build); 1-thread latency {lat * 1e3:.2f} ms/sweep"}
 
 
+def parallel_in_time(args, device, stream, nx, nu, mueq, N=2048, legs=128, reps=10):
+    """Secondary figure (not `value`): ONE problem of the configs[3] shape swept serially and
+    parallel in time (one wave per (problem, leg), leg-boundary system by block cyclic reduction)
+    on this GPU; the two solutions are compared."""
+    dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
+    out, ref = {}, None
+    for J in (1, legs):
+        s = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=J, device=device)
+        s.set_stream(stream.cuda_stream)
+        synth_device.fill_problems(s, seed=4242, mode=args.generator, keep=())
+        for _ in range(2):
+            s.backward_async(mueq)
+            s.forward_async()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s.backward_async(mueq)
+            s.forward_async()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        sol = s.solution(0)
+        if J == 1:
+            ref, out["serial_ms_per_sweep"], out["serial_kernel"] = sol, ms, s.kernel_name
+        else:
+            scale = max(1.0, max(float(np.abs(v).max()) for v in ref[3]))
+            diff = max(float(np.abs(a - c).max()) for A, B in zip(sol, ref) for a, c in zip(A, B) if a.size)
+            resid, steps = s.condensed_info(0)
+            out.update({"legs": J, "ms_per_sweep": ms, "kernel": s.kernel_name,
+                        "speedup_vs_serial": out["serial_ms_per_sweep"] / ms,
+                        "max_rel_diff_vs_serial": diff / scale,
+                        "condensed_residual": resid, "refinement_steps": steps})
+    out["workload"] = f"one problem, N={N} nx={nx} nu={nu} fp64 (BASELINE.json configs[3] shape), one GPU"
+    return out
+
+
 def parity_check(solver, args, mueq, nsample=2):
     """Spot-check the timed data: pull a few problems back, solve with the oracle."""
     from aligator_amd.gar import lqrComputeKktError
@@ -133,6 +168,7 @@ def main():
     ap.add_argument("--generator", default="W", choices=["W", "F"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary parallel-in-time figure")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the timing barrier (gloo + --same-device lets two "
                          "ranks share one GPU to exercise the N>1 path on a 1-GPU box)")
@@ -207,6 +243,9 @@ def main():
     failed = solver.num_failed()
 
     err, kkt = parity_check(solver, args, mueq)
+    pit = None
+    if world == 1 and not args.no_legs and (nx, nu) == (36, 12):
+        pit = parallel_in_time(args, local_rank, stream, nx, nu, mueq)
     if rank == 0:
         sweeps = args.batch * world * args.steps
         bwd_b, fwd_b = algorithmic_bytes(N, nx, nu)
@@ -238,6 +277,8 @@ def main():
                          "sweep_frac_of_hbm_roofline": (sweeps / elapsed) * (bwd_b + fwd_b) / HBM_PEAK},
             "parity": {"max_rel_err_vs_oracle": err, "max_kkt": kkt, "failed_factorisations": failed},
         }
+        if pit is not None:
+            out["parallel_in_time"] = pit
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, nx, nu, N, mueq)
         print(json.dumps(out))
