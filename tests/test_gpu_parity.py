@@ -141,6 +141,15 @@ def test_wave_leg_kernels_and_cyclic_reduction(nx, nu, horz, legs):
     assert par._impl.kernel_name == f"wave_leg<{nx},{nu}>"
 
 
+def test_wave_leg_kernels_reference_faithful_generator():
+    """The reference's own random generator (tests/gar/test_util.cpp: dense random A, B -- value
+    functions grow along the horizon) at its own bar for nx = 36 (tests/gar/riccati.cpp:138)."""
+    rng = np.random.default_rng(4300)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(36), 40, 36, 12, mode="F")
+    par = pc.check_parallel(prob, 1e-9, 5, pc.TOL["F"], rounds=1, rng=rng)
+    assert par._impl.kernel_name == "wave_leg<36,12>"
+
+
 def test_condensed_solvers_agree_on_gpu(monkeypatch):
     """Block cyclic reduction (no fallback: refinement off), the elimination chain and the generic
     kernel on the north-star shape, 64 legs, a batch of problems; and the gated fallback."""
