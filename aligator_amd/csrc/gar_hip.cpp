@@ -347,6 +347,7 @@ void select_leg_kernel(gar_hip_solver *s) {
   if (nx == 36 && nu == 12) bind_leg<36, 12>(s);
   else if (nx == 32 && nu == 12) bind_leg<32, 12>(s);
   else if (nx == 16 && nu == 8) bind_leg<16, 8>(s);
+  else if (nx == 12 && nu == 8) bind_leg<12, 8>(s);
   else if (nx == 12 && nu == 4) bind_leg<12, 4>(s);
   else if (nx == 8 && nu == 4) bind_leg<8, 4>(s);
 }
@@ -393,6 +394,7 @@ void select_kernel(gar_hip_solver *s) {
   if (nx == 36 && nu == 12) bind_mfma<36, 12>(s);
   else if (nx == 32 && nu == 12) bind_mfma<32, 12>(s);
   else if (nx == 16 && nu == 8) bind_mfma<16, 8>(s);
+  else if (nx == 12 && nu == 8) bind_mfma<12, 8>(s);
   else if (nx == 12 && nu == 4) bind_mfma<12, 4>(s);
   else if (nx == 8 && nu == 4) bind_mfma<8, 4>(s);
 }

@@ -61,17 +61,76 @@ class _Kkt0View:
     __slots__ = ("ff", "fth")
 
 
+# (nx, nu) shapes with specialised kernels (csrc/gar_hip.cpp: bind_mfma / bind_leg)
+SPECIALISED_SHAPES = {(36, 12), (32, 12), (16, 8), (12, 8), (12, 4), (8, 4)}
+
+
+def _padded_controls(dims: np.ndarray) -> int:
+    """Control padding: a uniform unconstrained problem whose nu is not a multiple of 4 is run on
+    the specialised kernels of (nx, 4*ceil(nu/4)) with DUMMY controls (R = I, S = 0, B = 0,
+    r = 0 on the padding: they solve to exactly zero and decouple).  Returns the padded nu, or 0
+    when padding does not apply."""
+    N = dims.shape[0] - 1
+    if N < 1:
+        return 0
+    nx, nu = int(dims[0, 0]), int(dims[0, 1])
+    if nu % 4 == 0 or nu == 0:
+        return 0
+    if not ((dims[:N] == (nx, nu, 0, nx, 0)).all() and tuple(dims[N]) == (nx, 0, 0, nx, 0)):
+        return 0
+    nup = 4 * ((nu + 3) // 4)
+    return nup if (nx, nup) in SPECIALISED_SHAPES else 0
+
+
+def _pad_knot(k: LqrKnot, nup: int) -> LqrKnot:
+    if k.nu == 0 or k.nu == nup:
+        return k
+    p = LqrKnot(k.nx, nup, k.nc, k.nx2, k.nth)
+    nu = k.nu
+    for name in ("Q", "q", "A", "f", "C", "d", "Gth", "Gx", "Gv", "gamma"):
+        getattr(p, name)[...] = getattr(k, name)
+    p.S[:, :nu] = k.S
+    p.R[:nu, :nu] = k.R
+    p.R[np.arange(nu, nup), np.arange(nu, nup)] = 1.0
+    p.r[:nu] = k.r
+    p.B[:, :nu] = k.B
+    p.D[:, :nu] = k.D
+    p.Gu[:nu] = k.Gu
+    return p
+
+
+def _unpad_knot(p: LqrKnot, nu: int) -> LqrKnot:
+    if p.nu == 0 or p.nu == nu:
+        return p
+    k = LqrKnot(p.nx, nu, p.nc, p.nx2, p.nth)
+    for name in ("Q", "q", "A", "f", "C", "d", "Gth", "Gx", "Gv", "gamma"):
+        getattr(k, name)[...] = getattr(p, name)
+    k.S[...] = p.S[:, :nu]
+    k.R[...] = p.R[:nu, :nu]
+    k.r[...] = p.r[:nu]
+    k.B[...] = p.B[:, :nu]
+    k.D[...] = p.D[:, :nu]
+    k.Gu[...] = p.Gu[:nu]
+    return k
+
+
 class BatchedRiccatiSolver:
     """`batch` LQ problems with the same per-stage dimensions on one GPU.
 
     dims: (horizon+1) x (nx, nu, nc, nx2, nth).  num_legs = 1 is the serial
     ProximalRiccatiSolver algorithm, >= 2 the ParallelRiccatiSolver one.
+    `dims` (attribute) are the dimensions of the device records; `user_dims` those of the caller's
+    problem (they differ only under control padding, see _padded_controls).
     """
 
     def __init__(self, dims, nc0: int, batch: int = 1, num_legs: int = 1, device: int = 0,
-                 leg_range=None, lib_path: Optional[str] = None):
+                 leg_range=None, lib_path: Optional[str] = None, pad_controls: bool = True):
         self._L = _lib.load(lib_path)
-        self.dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int32).reshape(-1, 5))
+        self.user_dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int32).reshape(-1, 5))
+        self.dims = self.user_dims.copy()
+        self._nup = _padded_controls(self.user_dims) if pad_controls else 0
+        if self._nup:
+            self.dims[:-1, 1] = self._nup
         self.horizon = self.dims.shape[0] - 1
         self.nc0, self.batch, self.num_legs = int(nc0), int(batch), int(num_legs)
         lb, le = leg_range if leg_range is not None else (0, self.num_legs)
@@ -149,8 +208,10 @@ class BatchedRiccatiSolver:
         buf[self.g0_off:self.g0_off + self.nc0] = problem.g0
         for t, k in enumerate(problem.stages):
             nx, nu, nc, nx2, nth = (int(v) for v in self.dims[t])
-            if (k.nx, k.nu, k.nc, k.nx2) != (nx, nu, nc, nx2):
+            if (k.nx, k.nu, k.nc, k.nx2) != tuple(int(v) for v in self.user_dims[t, :4]):
                 raise ValueError(f"knot {t}: dimensions differ from the solver's")
+            if self._nup:
+                k = _pad_knot(k, self._nup)
             stored = nth if self.num_legs == 1 else 0
             p = int(self.stage_offsets[t, 0])
             for name, shp in block_shapes(nx, nu, nc, nx2, stored).items():
@@ -173,7 +234,7 @@ class BatchedRiccatiSolver:
                 n = int(np.prod(shp))
                 getattr(k, name)[...] = buf[p:p + n].reshape(shp, order="F")
                 p += n
-            knots.append(k)
+            knots.append(_unpad_knot(k, int(self.user_dims[t, 1])) if self._nup else k)
         prob = LqrProblem(knots, self.nc0)
         nx0 = int(self.dims[0, 0])
         prob.G0[...] = buf[self.G0_off:self.G0_off + self.nc0 * nx0].reshape((self.nc0, nx0), order="F")
@@ -224,6 +285,8 @@ class BatchedRiccatiSolver:
     def pack_derivs(self, derivs, init) -> np.ndarray:
         """One problem's derivative buffer (csrc/gar_layout.h, gar_deriv_layout): header
         G0 | g0 | init Hxx, then one record per stage in DERIV_BLOCKS order."""
+        if self._nup:
+            raise NotImplementedError("derivative records of a control-padded solver")
         buf = np.zeros(self.deriv_doubles)
         off = np.zeros(4, dtype=np.int64)
         for t, d in enumerate(derivs):
@@ -249,6 +312,8 @@ class BatchedRiccatiSolver:
 
     def upload_knot(self, b: int, t: int, k: LqrKnot):
         """gar_hip_upload_stage: the 16 separately allocated blocks of LqrKnotTpl."""
+        if self._nup:
+            k = _pad_knot(k, self._nup)
         a = {n: _f64(getattr(k, n)) for n in BLOCK_NAMES}
         self._check(self._L.gar_hip_upload_stage(self._h, b, t, *[_ptr(a[n]) for n in BLOCK_NAMES]))
 
@@ -311,6 +376,8 @@ class BatchedRiccatiSolver:
         lbdas = list(np.split(Lb, np.cumsum(ldim)[:-1]))
         if d[N, 1] == 0:
             us.pop()
+        if self._nup:
+            us = [u[:int(self.user_dims[t, 1])] for t, u in enumerate(us)]
         return xs, us, vs, lbdas
 
     def factor(self, t: int, b: int = 0) -> _FactorView:
@@ -326,6 +393,10 @@ class BatchedRiccatiSolver:
         f.fb = np.zeros((nr, nx))
         f.fth = np.zeros((nr, nth))
         self._check(self._L.gar_hip_get_gains(self._h, b, t, _ptr(f.ff), _ptr(f.fb), _ptr(f.fth)))
+        if self._nup and nu > 0: # drop the rows of the dummy controls (exactly zero)
+            unu = int(self.user_dims[t, 1])
+            keep = np.r_[0:unu, nu:nr]
+            f.nu, f.ff, f.fb, f.fth = unu, f.ff[keep], np.ascontiguousarray(f.fb[keep]), np.ascontiguousarray(f.fth[keep])
         vm = _ValueView()
         vm.Vxx = np.zeros((nx, nx), order="F")
         vm.vx = np.zeros(nx)
@@ -350,6 +421,16 @@ class BatchedRiccatiSolver:
 
     def cycle_append(self, dims5):
         d = np.ascontiguousarray(np.asarray(dims5, dtype=np.int32))
+        if self.horizon >= 1:
+            ud = self.user_dims.copy()
+            ud[:self.horizon - 1] = self.user_dims[1:self.horizon]
+            ud[self.horizon - 1] = d
+            self.user_dims = ud
+        if self._nup:
+            if tuple(d) != tuple(self.user_dims[0]):
+                raise ValueError("cycle_append on a control-padded solver needs a knot of the same dimensions")
+            d = d.copy()
+            d[1] = self._nup
         self._check(self._L.gar_hip_cycle_append(self._h, d.ctypes.data_as(C.POINTER(C.c_int32))))
         N = self.horizon
         if N >= 1:

@@ -7,9 +7,11 @@ import torch
 from aligator_amd import synth
 from aligator_amd.gar import BatchedRiccatiSolver
 
-nx, nu, mueq = 36, 12, 1e-12
+nx, nu, mueq = int(os.environ.get("NX", "36")), int(os.environ.get("NU", "12")), 1e-12
 batch = int(os.environ.get("BATCH", "1"))
 cases = [(256, (1, 8, 16, 32)), (2048, (1, 32, 64, 128, 256))]
+if os.environ.get("CASES"):
+    cases = eval(os.environ["CASES"])
 for N, legs_list in cases:
     prob = synth.generate_lq_problem(5, np.zeros(nx), N, nx, nu, mode="W")
     dims = [k.dims for k in prob.stages]
@@ -32,14 +34,17 @@ for N, legs_list in cases:
             s.backward_async(mueq); s.forward_async()
         s.sync()
         dt = (time.perf_counter() - t0) / reps
-        s._check(s._L.gar_hip_set_timing(s.handle, 1))
         k = np.zeros(3)
-        for _ in range(5):
-            s.backward_async(mueq); s.forward_async()
-            o = (C.c_double * 3)()
-            s._check(s._L.gar_hip_last_kernel_ms(s.handle, o))
-            k += np.array(list(o))
-        k /= 5
+        try:
+            s._check(s._L.gar_hip_set_timing(s.handle, 1))
+            for _ in range(5):
+                s.backward_async(mueq); s.forward_async()
+                o = (C.c_double * 3)()
+                s._check(s._L.gar_hip_last_kernel_ms(s.handle, o))
+                k += np.array(list(o))
+            k /= 5
+        except RuntimeError:
+            k[:] = float("nan")  # the generic kernels carry no per-kernel events
         inf = "-"
         if legs > 1:
             o2 = (C.c_double * 2)()
