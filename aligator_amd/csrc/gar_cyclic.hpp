@@ -256,6 +256,37 @@ __device__ __forceinline__ void cyc_load_diff(double *dst, const double *a, cons
   }
 }
 
+// a block in flight: global loads issued now, written to LDS later (the latency hides behind
+// whatever runs in between)
+template <int NX> struct BlockRegs {
+  static constexpr int bs = NX * NX, NCH = (bs + 63) / 64;
+  double v[NCH];
+  __device__ __forceinline__ void issue(const double *a, int lane) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int e = 64 * q + lane;
+      v[q] = a[(64 * q + 63 < bs || e < bs) ? e : bs - 1];
+    }
+  }
+  __device__ __forceinline__ void issue_diff(const double *a, const double *b, bool sub, int lane) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int e = 64 * q + lane;
+      const int ec = (64 * q + 63 < bs || e < bs) ? e : bs - 1;
+      const double x = a[ec], y = sub ? b[ec] : 0.0;
+      v[q] = x - y;
+    }
+  }
+  __device__ __forceinline__ void commit(double *dst_lds, int lane) const {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int e = 64 * q + lane;
+      if (64 * q + 63 < bs || e < bs)
+        dst_lds[e] = v[q];
+    }
+  }
+};
+
 // ---- 1. setup: eliminate the states, one wave per leg -----------------------------------------
 template <int NX>
 __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
@@ -375,18 +406,24 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
   const int row = lane < NX ? lane : NX - 1;
   int failed = 0;
   auto S_of = [&](int j) { return X.S + (long long)j * bs; };
-  auto load_S = [&](double *dst, int j) {
-    cyc_load_diff<NX>(dst, S_of(j), X.P + (long long)j * bs, first && j >= 1, lane);
-  };
   auto r_of = [&](int j) {
     double v = X.r[j * NX + row];
     if (first && j >= 1)
       v -= X.p[j * NX + row];
     return v;
   };
+  // debug: cycle stamps of wave 0 of the second survivor of the first level
+  const bool tracing = P.trace != nullptr && b == 0 && h == 1 && blockIdx.x == 1 && threadIdx.x == 0;
+#define GAR_YMARK(id)                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  if (tracing)                                                                 \
+    P.trace[32 + (id)] = (long long)clock64();                                 \
+  __builtin_amdgcn_sched_barrier(0);
+  GAR_YMARK(0)
   double ri = 0.0;
+  BlockRegs<NX> own; // S_i: in flight while the neighbour is inverted
   if (wave == 0) {
-    load_S(D2, i); // own block
+    own.issue_diff(S_of(i), X.P + (long long)i * bs, first && i >= 1, lane);
     ri = r_of(i);
   } else {
     for (int e = lane; e < bs; e += 64)
@@ -394,28 +431,48 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
   }
   if (wave == 0 && i + h < J) { // right eliminated neighbour j = i + h
     const int j = i + h;
-    load_S(Dm, j);
-    cond_copy_block<NX>(Bm, X.C + (long long)i * bs, lane); // C_i (row i, column j)
+    BlockRegs<NX> rs, rc, rcj;
+    rs.issue_diff(S_of(j), X.P + (long long)j * bs, first && j >= 1, lane);
+    rc.issue(X.C + (long long)i * bs, lane); // C_i (row i, column j)
+    if (j + h < J)
+      rcj.issue(X.C + (long long)j * bs, lane); // C_j, for the new coupling
+    rs.commit(Dm, lane);
+    rc.commit(Bm, lane);
     wave_sync();
+    GAR_YMARK(1)
     failed |= cyc_inverse<NX>(sm, lane); // Wm = W_j
+    own.commit(D2, lane);
+    wave_sync();
+    GAR_YMARK(2)
     cyc_store_block<NX>(X.W + (long long)j * bs, Wm, lane);
     cyc_store_block<NX>(X.Cl + (long long)j * bs, Bm, lane); // the coupling j had to its left
+    GAR_YMARK(3)
     double4_t Ut[TX][TX];
     cyc_update<NX, false>(Wm, Bm, D2, Ut, lane); // U = W_j C_i^T ; S_i -= C_i U
+    GAR_YMARK(4)
     const double y = cyc_matvec<NX>(Wm, r_of(j), row);
     ri -= cyc_matvec<NX>(Bm, y, row);
+    GAR_YMARK(5)
     if (j + h < J) { // new coupling (i, i + 2h) = -C_i W_j C_j = -U^T C_j
       wave_sync();
-      cond_copy_block<NX>(Dm, X.C + (long long)j * bs, lane); // C_j into the dead S_j buffer
+      rcj.commit(Dm, lane); // C_j into the dead S_j buffer
       wave_sync();
+      GAR_YMARK(6)
       cyc_ut_times<NX>(Ut, Dm, X.C + (long long)i * bs, -1.0, lane);
     }
+    wave_sync();
+    GAR_YMARK(7)
+  } else if (wave == 0) {
+    own.commit(D2, lane);
     wave_sync();
   }
   if (wave == 1 && i - h >= 0) { // left eliminated neighbour j = i - h
     const int j = i - h;
-    load_S(Dm, j);
-    cond_copy_block<NX>(Bm, X.C + (long long)j * bs, lane); // C_j (row j, column i)
+    BlockRegs<NX> rs, rc;
+    rs.issue_diff(S_of(j), X.P + (long long)j * bs, first && j >= 1, lane);
+    rc.issue(X.C + (long long)j * bs, lane); // C_j (row j, column i)
+    rs.commit(Dm, lane);
+    rc.commit(Bm, lane);
     wave_sync();
     failed |= cyc_inverse<NX>(sm, lane);
     double4_t Ut[TX][TX];
@@ -427,6 +484,7 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
   if (wave == 1 && lane < NX)
     xch[lane] = ri;
   __syncthreads();
+  GAR_YMARK(8)
   if (wave == 0) {
     const double *D2b = gar_smem + L::total + L::oD2;
     if (i - h >= 0) {
@@ -441,6 +499,8 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
     if (lane < NX)
       X.r[i * NX + lane] = ri;
   }
+  GAR_YMARK(9)
+#undef GAR_YMARK
   if (failed && lane == 0)
     atomicOr(&P.status[b], 4);
 }

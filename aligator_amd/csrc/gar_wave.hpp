@@ -834,7 +834,6 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
           }
         }
       }
-    GAR_WMARK(16)
     // ---- Vxt (NX x nth), one parameter column tile at a time; the new tile column replaces
     // the old one in the lane-private operand slots once all its row tiles are done
     //   MODE 1: Vxt = Aff^T Vxt' (:304-306): A operand = the Aff registers (operand layout of
@@ -877,7 +876,6 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
               stg_b(out, C::pVxt + 16 * tj * NX + 16 * ti + 4 * r, 8u * (unsigned)(li * NX + lk), nv[ti][r]);
           }
     }
-    GAR_WMARK(17)
     // ---- Vtt = Gth + Vtt' + Gu^T Kth + Vxt'^T Yth (:308-310) as Vtt' + Ghat_u^T Kth; computed
     // transposed (D' = Kth^T Ghat_u), so that the accumulator row index runs along the lanes that
     // are contiguous in the column-major record
@@ -905,7 +903,6 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
               stg_b(out, C::pVtt + (16 * ti + 4 * r) * NX + 16 * tj, lkx, acc[r]);
           }
       }
-    GAR_WMARK(18)
   }
   // ---- knot t-1: the F operands and vectors go into the registers Aff just released
   wave_load_a<NX, NU>(recn, L, S);
@@ -1013,7 +1010,13 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   double *fac = P.fac + (long long)b * P.fac_stride;
   const int N = P.horizon;
   double *V = sm + C::oV, *vn = sm + C::oVn;
+  // cycle stamps (scripts/trace_wave.py) only in the debug build (make trace, -DGAR_TRACE): the
+  // run-time test alone costs 1 % of the sweep
+#ifdef GAR_TRACE
   const bool tracing = P.trace != nullptr && b == 0 && lane == 0;
+#else
+  const bool tracing = false;
+#endif
 
   WaveLane<NX, NU> L;
   wave_lane_init<NX, NU>(L, lane);

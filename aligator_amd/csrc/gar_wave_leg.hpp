@@ -54,10 +54,16 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave_leg(LegParams Q) {
   P.fac_rec = (P.fac_rec + 1) & ~1ll;
   double *fac = P.fac + (long long)b * P.fac_stride + Q.meta[t_beg].fac_off - (long long)t_beg * P.fac_rec;
   double *V = sm + C::oV, *vn = sm + C::oVn;
-  // debug: cycle stamps of the second stage of leg 0 (wave_stage stamps stage horizon/2)
+  // debug build (make trace, -DGAR_TRACE; scripts/trace_leg.py): cycle stamps of the second stage of leg 0
+  // (wave_stage stamps stage horizon/2); compiled out otherwise -- the run-time test alone costs
+  // 3 % of the leg sweep
+#ifdef GAR_TRACE
   const bool tracing = P.trace != nullptr && b == 0 && leg == 0 && lane == 0;
   if (P.trace != nullptr)
     P.horizon = 2 * (t_beg + 1);
+#else
+  const bool tracing = false;
+#endif
   WaveLane<NX, NU> L;
   wave_lane_init<NX, NU>(L, lane);
   WaveStage<NX, NU> S;

@@ -21,3 +21,12 @@ for st in range(2):
         if t[k]:
             print(f"{names[k-1]} {t[k]-prev}", end=" | "); prev = t[k]
     print(f"total {prev - t[0]} (100 MHz ticks: x24 = shader cycles)")
+
+print("cyclic reduction, first level, survivor 2, wave 0 (shader cycles):")
+y = [out[32 + k] for k in range(10)]
+nm = ["loads S_i,S_j,C_i", "inverse (factor+W)", "store W, Cl", "U=W C^T, S -= C U", "matvecs", "load C_j", "new coupling -U^T C_j",
+      "wait wave 1", "combine + store S_i"]
+for k in range(1, 10):
+    if y[k] and y[k-1]:
+        print(f"  {nm[k-1]:28s} {y[k]-y[k-1]:7d}")
+print("  total", y[9] - y[0])

@@ -5,10 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aligator_amd import synth_device
 from aligator_amd.gar import BatchedRiccatiSolver
+TRACE_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aligator_amd", "libgar_hip_trace.so")  # make -C aligator_amd/csrc trace
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nx, nu, N = 36, 12, 256
 dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
-s = BatchedRiccatiSolver(dims, nx, batch=B)
+s = BatchedRiccatiSolver(dims, nx, batch=B, lib_path=TRACE_LIB)
 synth_device.fill_problems(s, seed=1, mode="W")
 s.backward(1e-14)
 out = (C.c_longlong * 64)()
