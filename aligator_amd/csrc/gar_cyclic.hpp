@@ -488,7 +488,6 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
   if (wave == 0) {
     const double *D2b = gar_smem + L::total + L::oD2;
     if (i - h >= 0) {
-#pragma unroll
       for (int e = lane; e < bs; e += 64)
         D2[e] += D2b[e];
       ri += xch[row];

@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) gar_backward_generic(GenericParams P) {
 
     // ---- S5: closed loop + value function  (:266-277) ----------------------
     MatV K = G.sub(0, 1), Z = G.sub(nu, 1);
-    MatV Kth = G.sub(0, 1 + nx), Zth = G.sub(nu, 1 + nx);
+    MatV Kth = G.sub(0, 1 + nx);
     if (!terminal) {
       // yff = f + B kff ; Aff = A + B K
       wg_gemv(w, nx2, nu, F.sub(0, nx), G.p, gld, fv, 1, yff, 1, 1.0);

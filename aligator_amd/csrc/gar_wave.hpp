@@ -458,7 +458,6 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   const int li = lane & 15, lk = lane >> 4;
   double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM;
   double *vn = sm + C::oVn, *vp = sm + C::oVp;
-  double *Lr = sm + C::oLr, *ndi = sm + C::oDi;
   double *Xt = sm + C::oXt + lane, *Tt = sm + C::oTt + lane; // lane-private slots, stride 64
   double *Gt = sm + C::oGt, *vtl = sm + C::oVt, *yfl = sm + C::oYf;
   constexpr int oVxx = MODE ? C::pVxx : M::fVxx, ovx = MODE ? C::pvx : M::fvx;

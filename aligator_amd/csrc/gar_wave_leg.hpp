@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
   // D of the last block: Vxx of the last leg
   {
     const double *tup = cond_tuple(P, b, P.num_legs - 1);
-    _Pragma("unroll") for (int e = lane; e < bs; e += 64)
+    for (int e = lane; e < bs; e += 64)
       Dm[e] = tup[e];
   }
   wave_sync();
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
     if (i >= 2 && (i & 1) == 0)
       return 1;
     if (i == 0) { // G0: nc0 x NX
-      _Pragma("unroll") for (int e = lane; e < bs; e += 64) {
+      for (int e = lane; e < bs; e += 64) {
         const int j = e / NX, r = e - j * NX;
         Bm[e] = r < nc0 ? prob[P.G0_off + j * nc0 + r] : 0.0;
       }
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
     const int n = ib == 0 ? nc0 : NX;
     GAR_CMARK(0)
     if (ib == 0) { // pad the nc0 x nc0 block with an identity
-      _Pragma("unroll") for (int e = lane; e < bs; e += 64) {
+      for (int e = lane; e < bs; e += 64) {
         const int j = e / NX, r = e - j * NX;
         if (r >= n || j >= n)
           Dm[e] = (r == j) ? 1.0 : 0.0;
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
       if (verdict == 0) {
         cond_inverse<NX>(a_row, nd, Wm, Mm, Wm, Tm, Dl, lane);
       } else {
-        _Pragma("unroll") for (int e = lane; e < bs; e += 64) {
+        for (int e = lane; e < bs; e += 64) {
           const int j = e / NX, r = e - j * NX;
           Wm[e] = (r == j) ? 1.0 : 0.0;
         }
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
     }
     wave_sync();
     GAR_CMARK(2)
-    _Pragma("unroll") for (int e = lane; e < bs; e += 64)
+    for (int e = lane; e < bs; e += 64)
       Wall[(long long)ib * bs + e] = Wm[e];
     // x_ib <- D^{-1} x_ib
     const double xb = matvec(Wm, solv[ib * NX + row]);
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
     const int negI = load_coupling(i);
     // D_i of the next step: the original diagonal block ...
     if (i == 0) {
-      _Pragma("unroll") for (int e = lane; e < bs; e += 64)
+      for (int e = lane; e < bs; e += 64)
         Dm[e] = 0.0; // -mudyn I with mudyn = 0 (:93-94, :165)
     } else {
       const double *tup = cond_tuple(P, b, (i - 1) >> 1);
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
       // x_i -= (-I) x_ib ; U_i = -W ; D_i -= (-I)(-W)
       if (lane < NX)
         solv[i * NX + lane] += xb;
-      _Pragma("unroll") for (int e = lane; e < bs; e += 64) {
+      for (int e = lane; e < bs; e += 64) {
         const double wv = Wm[e];
         Uall[(long long)i * bs + e] = -wv;
         Dm[e] -= wv;
