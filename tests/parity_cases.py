@@ -125,3 +125,45 @@ def check_batched(probs, mueq, tol, lib_path=None, num_legs=1):
         for A, B in zip(sol, ref):
             assert maxdiff(A, B) <= tol * sc, b
     return s
+
+
+def _leg_solution(probs, legs, mueq, lib_path=None, refine=None, threshold=1e-10):
+    dims = [k.dims for k in probs[0].stages]
+    s = BatchedRiccatiSolver(dims, probs[0].nc0, batch=len(probs), num_legs=legs, lib_path=lib_path)
+    if refine is not None:
+        s.set_refinement(threshold, refine)
+    s.upload(probs)
+    assert s.backward(mueq) and s.forward()
+    return s, [s.solution(b) for b in range(len(probs))]
+
+
+def check_condensed_block_inverse_fallback(lib_path=None):
+    """A leg-start value function whose unpivoted LDL^T fails the first Bunch-Kaufman test
+    (|a_kk| < alpha * max|a_ik|): the block inverse of the condensed solve hands that block to the
+    generic device Bunch-Kaufman (interchanges / 2x2 pivots), like the reference would."""
+    nx, nu, N, legs = 8, 4, 11, 3
+    prob = synth.generate_lq_problem(77, np.ones(nx), N, nx, nu, mode="W")
+    t0 = 8                                     # first stage of the final leg
+    M = np.diag(np.r_[1.0, 100.0, np.full(nx - 2, 10.0)])
+    M[0, 1] = M[1, 0] = 5.0                    # SPD, |a_00| = 1 < 0.64 * 5
+    prob.stages[t0].Q[...] = 1e4 * M
+    osol = ora.ProximalRiccatiSolver(to_oracle(prob))
+    osol.backward(1e-10)
+    V = osol.datas(t0).Vxx
+    alpha = (1 + np.sqrt(17)) / 8
+    assert abs(V[0, 0]) < alpha * np.abs(V[1:, 0]).max()      # the premise of this test
+    for refine in (0, 3):
+        s, sol = _leg_solution([prob], legs, 1e-10, lib_path, refine=refine)
+        assert s.kernel_name.startswith("wave_leg<") and s.num_failed() == 0
+        _, _, ref = oracle_serial(prob, 1e-10)
+        for A, B in zip(sol[0], ref):
+            assert maxdiff(A, B) <= 1e-9 * scale_of(ref)
+    # and through the elimination-chain kernel, whose last block is the same Vxx
+    import os
+    os.environ["GAR_HIP_CONDENSED"] = "chain"
+    try:
+        s, sol = _leg_solution([prob], legs, 1e-10, lib_path)
+    finally:
+        del os.environ["GAR_HIP_CONDENSED"]
+    for A, B in zip(sol[0], ref):
+        assert maxdiff(A, B) <= 1e-9 * scale_of(ref)

@@ -151,6 +151,10 @@ def test_condensed_cyclic_fallback_to_chain():
         assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
 
 
+def test_condensed_block_inverse_bunch_kaufman_fallback():
+    pc.check_condensed_block_inverse_fallback(EMU)
+
+
 @pytest.mark.parametrize("nc0", [0, 3])
 def test_leg_kernels_partial_initial_constraint(nc0):
     """G0 with fewer rows than states (nc0 < nx): block 0 of the condensed system is padded."""

@@ -185,6 +185,10 @@ def test_condensed_solvers_agree_on_gpu(monkeypatch):
                 assert pc.maxdiff(A, B) <= 1e-9 * sc
 
 
+def test_condensed_block_inverse_bunch_kaufman_fallback():
+    pc.check_condensed_block_inverse_fallback()
+
+
 def test_sharded_solver_single_rank_rccl():
     """aligator_amd.sharded on the real device path: torch views of the library's device
     buffers, all_gather_into_tensor over RCCL (world_size 1 is all a 1-GPU box offers; the
