@@ -82,37 +82,27 @@ template <int NX> __device__ __forceinline__ double cyc_matvecT(const double *Mc
 template <int NX> struct CyclicLds {
   static constexpr int bs = NX * NX;
   static constexpr int oD = 0, oW = bs, oB = 2 * bs, oM = 3 * bs, oD2 = 4 * bs, oT = 5 * bs,
-                       oDl = oT + 16 * NX, oSub = oDl + NX, oPiv = oSub + NX + (NX & 1),
-                       total = oPiv + (NX + 16) / 2 + 4;
+                       oDl = oT + 16 * NX, total = (oDl + NX + 1) & ~1;
 };
 
-// W = D^{-1} of the symmetric block in Dm (lower triangle read): register LDL^T + blocked inverse
-// while the first Bunch-Kaufman test holds at every column, the generic device Bunch-Kaufman
-// otherwise.  Returns 1 on an exactly singular block.
+// W = D^{-1} of the symmetric DEFINITE block in Dm (lower triangle read): unpivoted register
+// LDL^T (every block this solver inverts is definite -- Vxx_k > 0, S_j < 0 and its Schur
+// complements -- so no pivoting is needed for stability) + blocked inverse.  Returns 1 on a zero or
+// non-finite pivot: the caller then poisons the residual, which hands the problem to the
+// elimination-chain kernel (Bunch-Kaufman pivoting, refinement).
 template <int NX>
 __device__ __forceinline__ int cyc_inverse(double *sm, int lane) {
   using L = CyclicLds<NX>;
-  constexpr int bs = NX * NX;
   double *Dm = sm + L::oD, *Wm = sm + L::oW, *Mm = sm + L::oM, *Tm = sm + L::oT, *Dl = sm + L::oDl;
-  int failed = 0;
   double a_row[NX], nd[NX];
-  const int verdict = wave_ldl_fast<NX>(Dm, lane, a_row, nd);
-  if (verdict == 0) {
-    cond_inverse<NX>(a_row, nd, Wm, Mm, Wm, Tm, Dl, lane);
-  } else {
-    double *bsub = sm + L::oSub;
-    int *bpiv = (int *)(sm + L::oPiv);
-    for (int e = lane; e < bs; e += 64) {
-      const int j = e / NX, r = e - j * NX;
-      Wm[e] = (r == j) ? 1.0 : 0.0;
-    }
-    wave_sync();
-    const WG w1 = wave_self();
-    failed = wg_bk_factor(w1, NX, Dm, NX, bsub, bpiv, bpiv + NX + 8);
-    wg_bk_solve(w1, NX, Dm, NX, bsub, bpiv, Wm, 1, NX, NX);
-  }
+  const int failed = wave_ldl_fast<NX, true>(Dm, lane, a_row, nd);
+  cond_inverse<NX>(a_row, nd, Wm, Mm, Wm, Tm, Dl, lane);
   wave_sync();
   return failed;
+}
+// a failed block inverse: the residual slot is set to +inf (atomicMax on the bit pattern)
+__device__ __forceinline__ void cyc_poison(double *info) {
+  atomicMax(reinterpret_cast<unsigned long long *>(info), 0x7ff0000000000000ull);
 }
 
 // U = W op(B)^T (kept in accumulator registers) and Dd -= op(B) U (lower tiles), W, B, Dd
@@ -304,10 +294,6 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
   const int row = lane < NX ? lane : NX - 1;
   const int nc0 = P.nc0;
   const bool has_next = (k + 1 < J);
-  if (k == 0 && lane == 0) {
-    X.info[0] = 0.0; // the residual norm is accumulated with atomicMax by gar_cyclic_recover
-    X.info[1] = 0.0;
-  }
   cond_copy_block<NX>(Dm, tup, lane); // Vxx_k
   wave_sync();
   int failed = cyc_inverse<NX>(sm, lane); // Wm = P_k
@@ -381,7 +367,7 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
     }
   }
   if (failed && lane == 0)
-    atomicOr(&P.status[b], 4);
+    cyc_poison(X.info);
 }
 
 // ---- 2. one reduction level -------------------------------------------------------------------
@@ -501,7 +487,7 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
   GAR_YMARK(9)
 #undef GAR_YMARK
   if (failed && lane == 0)
-    atomicOr(&P.status[b], 4);
+    cyc_poison(X.info);
 }
 
 // ---- 3. back-substitution ---------------------------------------------------------------------
@@ -544,7 +530,7 @@ __global__ void __launch_bounds__(256) gar_cyclic_top(CyclicParams Y) {
     if (lane < NX)
       X.z[lane] = z0;
     if (failed && lane == 0)
-      atomicOr(&P.status[b], 4);
+      cyc_poison(X.info);
   }
   __threadfence_block();
   __syncthreads();

@@ -694,7 +694,9 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
   const int nxb = P.nxb, bs = nxb * nxb, nblk = 2 * P.num_legs, N = nblk - 1;
   if (P.gated) { // already solved to the residual threshold by the cyclic-reduction kernels?
     const double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * bs + 4ll * nblk * nxb;
-    if (inf[0] <= P.threshold || P.max_refinement == 0)
+    // (refinement disabled: the cyclic-reduction result stands -- unless a block inverse failed
+    // outright, which poisons the residual with +inf)
+    if (inf[0] <= P.threshold || (P.max_refinement == 0 && inf[0] <= 1.79e308))
       return;
   }
   double *S = P.scratch + (long long)b * P.scratch_stride;

@@ -486,6 +486,11 @@ gar::LegParams make_leg_params(gar_hip_solver *s) {
   Q.boundary = s->d_bound_local;
   Q.boundary_stride = (long long)(s->leg_end - s->leg_begin) * s->tuple_doubles;
   Q.tuple_doubles = (int)s->tuple_doubles;
+  {
+    const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
+    Q.cinfo = s->d_cscratch ? s->d_cscratch + 4 * nblk * bs + 4 * nblk * s->nxb : nullptr;
+    Q.cinfo_stride = s->cscratch_doubles;
+  }
   return Q;
 }
 

@@ -280,7 +280,9 @@ __device__ __forceinline__ void ldl_solve_lds(const double *Lr, const double *nd
 // (bunchkaufman.hpp:104-121: d11xj = a(j,k) d11; a(i,j) -= d11xj a(i,k)) is what runs here,
 // product for product.  Writes L row-major / column-major and -1/d to LDS; returns 0 if the
 // test held at every column (and no pivot was zero).
-template <int NU>
+// DEFINITE = true: the caller knows the matrix is definite (any diagonal pivot order is then
+// stable); only an exactly-zero or non-finite pivot is reported.
+template <int NU, bool DEFINITE = false>
 __device__ __forceinline__ int wave_ldl_fast(const double *M, int lane, double (&a)[NU],
                                              double (&nd)[NU]) {
   const double alpha = (1.0 + 4.123105625617661) / 8.0;
@@ -294,9 +296,13 @@ __device__ __forceinline__ int wave_ldl_fast(const double *M, int lane, double (
     const double akk = lane_bcast(a[k], k);
     // lanes i > k hold a(i,k): the column below the pivot
     // rows i >= k: |a_kk| >= alpha |a(i,k)| (lane k itself: a non-zero pivot)
-    const unsigned long long nok = __ballot(!(fabs(akk) >= alpha * fabs(a[k])) || akk == 0.0);
-    const unsigned long long from_k = ((1ull << NU) - 1ull) & ~((1ull << k) - 1ull);
-    bad |= nok & from_k;
+    if (DEFINITE) {
+      bad |= (akk == 0.0 || !(fabs(akk) <= 1.79e308)) ? 1ull : 0ull; // wave-uniform
+    } else {
+      const unsigned long long nok = __ballot(!(fabs(akk) >= alpha * fabs(a[k])) || akk == 0.0);
+      const unsigned long long from_k = ((1ull << NU) - 1ull) & ~((1ull << k) - 1ull);
+      bad |= nok & from_k;
+    }
     const double d = fast_rcp(akk);
     const double lik = a[k] * d; // L(i,k) = a(i,k) d11  (== the reference's d11xj for row i)
 #pragma unroll

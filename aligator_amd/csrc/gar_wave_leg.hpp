@@ -32,6 +32,8 @@ struct LegParams {
   double *boundary;        // [problem][local leg][tuple]
   long long boundary_stride;
   int tuple_doubles;
+  double *cinfo;           // condensed-solve scratch: info slot of problem 0 (residual, steps)
+  long long cinfo_stride;
 };
 
 template <int NX, int NU>
@@ -117,6 +119,11 @@ __global__ void __launch_bounds__(256) gar_leg_tuples(LegParams Q) {
   const bool last_leg = (leg == Q.num_legs - 1);
   const double *rec = Q.M.fac + (long long)b * Q.M.fac_stride + Q.meta[t_beg].fac_off;
   double *tup = Q.boundary + (long long)b * Q.boundary_stride + (long long)blockIdx.x * Q.tuple_doubles;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && Q.cinfo != nullptr) {
+    // the cyclic-reduction kernels accumulate the residual norm with atomicMax
+    Q.cinfo[(long long)b * Q.cinfo_stride] = 0.0;
+    Q.cinfo[(long long)b * Q.cinfo_stride + 1] = 0.0;
+  }
   const bool term = (t_beg == Q.M.horizon); // a leg made of the terminal knot alone
   const int oVxx = last_leg ? (term ? M::tVxx : M::fVxx) : C::pVxx;
   const int ovx = last_leg ? (term ? M::tvx : M::fvx) : C::pvx;
@@ -345,7 +352,9 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
   const int nblk = 2 * P.num_legs, N = nblk - 1;
   if (P.gated) { // the cyclic-reduction solve of this problem met the residual threshold?
     const double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * NX * NX + 4ll * nblk * NX;
-    if (inf[0] <= P.threshold || P.max_refinement == 0)
+    // (refinement disabled: the cyclic-reduction result stands -- unless a block inverse failed
+    // outright, which poisons the residual with +inf)
+    if (inf[0] <= P.threshold || (P.max_refinement == 0 && inf[0] <= 1.79e308))
       return;
   }
   const WG w1 = wave_self();

@@ -139,8 +139,9 @@ def _leg_solution(probs, legs, mueq, lib_path=None, refine=None, threshold=1e-10
 
 def check_condensed_block_inverse_fallback(lib_path=None):
     """A leg-start value function whose unpivoted LDL^T fails the first Bunch-Kaufman test
-    (|a_kk| < alpha * max|a_ik|): the block inverse of the condensed solve hands that block to the
-    generic device Bunch-Kaufman (interchanges / 2x2 pivots), like the reference would."""
+    (|a_kk| < alpha * max|a_ik|).  Cyclic reduction only ever inverts definite blocks and does not
+    pivot; the elimination-chain kernel follows the reference and hands that block to the generic
+    device Bunch-Kaufman (interchanges / 2x2 pivots).  Both must agree with the oracle."""
     nx, nu, N, legs = 8, 4, 11, 3
     prob = synth.generate_lq_problem(77, np.ones(nx), N, nx, nu, mode="W")
     t0 = 8                                     # first stage of the final leg
