@@ -98,7 +98,7 @@ def cpu_baseline(args, nx, nu, N, mueq):
                       f"build); 1-thread latency {lat * 1e3:.2f} ms/sweep"}
 
 
-def parallel_in_time(args, device, stream, nx, nu, mueq, N=2048, legs=128, reps=10):
+def parallel_in_time(args, device, stream, nx, nu, mueq, N=2048, legs=256, reps=10):
     """Secondary figure (not `value`): ONE problem of the configs[3] shape swept serially and
     parallel in time (one wave per (problem, leg), leg-boundary system by block cyclic reduction)
     on this GPU; the two solutions are compared."""
