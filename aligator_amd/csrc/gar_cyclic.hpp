@@ -399,12 +399,18 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
     return v;
   };
   // debug: cycle stamps of wave 0 of the second survivor of the first level
+#ifdef GAR_TRACE
   const bool tracing = P.trace != nullptr && b == 0 && h == 1 && blockIdx.x == 1 && threadIdx.x == 0;
+#endif
+#ifdef GAR_TRACE
 #define GAR_YMARK(id)                                                          \
   __builtin_amdgcn_sched_barrier(0);                                           \
   if (tracing)                                                                 \
     P.trace[32 + (id)] = (long long)clock64();                                 \
   __builtin_amdgcn_sched_barrier(0);
+#else
+#define GAR_YMARK(id)
+#endif
   GAR_YMARK(0)
   double ri = 0.0;
   BlockRegs<NX> own; // S_i: in flight while the neighbour is inverted

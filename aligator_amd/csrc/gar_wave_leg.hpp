@@ -433,12 +433,16 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
   };
 
   // ---- up-looking elimination -------------------------------------------------------------
+#ifdef GAR_TRACE
   const bool tracing = P.trace != nullptr && b == 0 && lane == 0;
 #define GAR_CMARK(id)                                                          \
   __builtin_amdgcn_sched_barrier(0);                                           \
   if (tracing && (ib == N - 2 || ib == N - 3))                                 \
     P.trace[(id) + 16 * (N - 2 - ib)] = (long long)clock64();                  \
   __builtin_amdgcn_sched_barrier(0);
+#else
+#define GAR_CMARK(id)
+#endif
   for (int ib = N; ib >= 0; --ib) {
     const int n = ib == 0 ? nc0 : NX;
     GAR_CMARK(0)

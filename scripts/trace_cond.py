@@ -6,7 +6,8 @@ from aligator_amd import synth
 from aligator_amd.gar import BatchedRiccatiSolver
 nx, nu, N, legs = 36, 12, 256, 8
 prob = synth.generate_lq_problem(5, np.zeros(nx), N, nx, nu, mode="W")
-s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs)
+TRACE_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aligator_amd", "libgar_hip_trace.so")  # make -C aligator_amd/csrc trace
+s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs, lib_path=TRACE_LIB)
 s.upload([prob]); s.backward(1e-12); s.forward()
 s._L.gar_hip_debug_trace(s.handle, 1, None)
 s.backward(1e-12)
