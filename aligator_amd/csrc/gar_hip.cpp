@@ -83,7 +83,7 @@ struct gar_hip_solver {
   void (*leg_tuple_kernel)(gar::LegParams) = nullptr;
   void (*leg_fwd_kernel)(gar::LegParams) = nullptr;
   void (*leg_collapse_kernel)(const gar_stage_meta *, double *, long long, int) = nullptr;
-  int leg_lds_doubles = 0;
+  int leg_lds_doubles = 0, leg_waves = 1;
   void (*cond_wave_kernel)(gar::CondensedParams) = nullptr;
   int cond_wave_lds_doubles = 0;
   // block cyclic reduction of the condensed system (gar_cyclic.hpp), preferred when bound
@@ -299,11 +299,14 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
 }
 
 template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
-  s->leg_bwd_kernel = gar::gar_backward_wave_leg<NX, NU>;
+  // two waves per leg (plain part / parameter part) unless GAR_HIP_LEG_WAVES=1
+  const char *lw = std::getenv("GAR_HIP_LEG_WAVES");
+  s->leg_waves = (lw && std::string(lw) == "1") ? 1 : 2;
+  s->leg_bwd_kernel = s->leg_waves == 2 ? gar::gar_backward_wave_leg2<NX, NU> : gar::gar_backward_wave_leg<NX, NU>;
   s->leg_tuple_kernel = gar::gar_leg_tuples<NX, NU>;
   s->leg_fwd_kernel = gar::gar_forward_wave_leg<NX, NU>;
   s->leg_collapse_kernel = gar::gar_collapse_feedback_t2<NX, NU>;
-  s->leg_lds_doubles = gar::WaveCfg<NX, NU>::leg_total;
+  s->leg_lds_doubles = s->leg_waves == 2 ? gar::WaveCfg<NX, NU>::leg2_total : gar::WaveCfg<NX, NU>::leg_total;
   const char *ck = std::getenv("GAR_HIP_CONDENSED");
   if (!(ck && std::string(ck) == "generic")) {
     const int lds = 4 * NX * NX + 16 * NX + NX + NX + (NX & 1) + (NX + 16) / 2 + 2 +
@@ -500,7 +503,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    hipLaunchKernelGGL(s->leg_bwd_kernel, grid, dim3(64),
+    hipLaunchKernelGGL(s->leg_bwd_kernel, grid, dim3(64 * s->leg_waves),
                        (size_t)s->leg_lds_doubles * sizeof(double), s->stream, Q);
     hipLaunchKernelGGL(s->leg_tuple_kernel, grid, dim3(256), 0, s->stream, Q);
     HIP_TRY(hipGetLastError());

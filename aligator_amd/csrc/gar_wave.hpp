@@ -74,7 +74,8 @@ template <int NX, int NU> struct WaveCfg {
   static constexpr int oDi = oLr + NU * NU;       // -1/d_k
   static constexpr int oBk = (oDi + NU + 1) & ~1; // Bunch-Kaufman fallback: sub(16) | piv, ctrl
   static constexpr int oDump = (oBk + 32 + 1) & ~1; // 2 doubles: target of masked-out LDS writes
-  static constexpr int total = oDump + 2;
+  static constexpr int oFlag = oDump + 2;           // MODE 3: verdict of the factorisation (as a double)
+  static constexpr int total = oDump + 4;
   // fused initial stage (after the sweep): the packed lower triangle of kkt0 = [Vxx0 G0^T; G0 0]
   // and its right-hand side overlay everything but V
   static constexpr int oK0 = oG;
@@ -95,6 +96,13 @@ template <int NX, int NU> struct WaveCfg {
   static constexpr int oVt = oGt + NU * PG + 16;   // vt (NX)
   static constexpr int oYf = oVt + NX;             // yff (NX)
   static constexpr int leg_total = (oYf + NX + 1) & ~1;
+  // two waves per leg (gar_backward_wave_leg2): wave A publishes, per stage, [kff | K], Rhat, L,
+  // 1/d, the verdict and yff for wave B; the block [oG, total) and yff exist twice (stage parity),
+  // so that one workgroup barrier per stage suffices
+  static constexpr int oPub1 = leg_total;
+  static constexpr int pub_shift = oPub1 - oG;
+  static constexpr int oYf1 = oPub1 + (total - oG);
+  static constexpr int leg2_total = (oYf1 + NX + 1) & ~1;
   // factor record of a parameterised stage (gar_factor_layout(NX,NU,0,NX,NX)); fb and fth in the
   // fbT2 device order
   static constexpr int pFTH = NW + NW * NX, pVxx = pFTH + NW * NX, pvx = pVxx + NX * NX,
@@ -397,6 +405,8 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
       }
     }
   }
+  if (lane == 0) // which factorisation the block holds: 0 = L, 1/d (unpivoted) ; 2 = Bunch-Kaufman
+    sm[C::oFlag] = verdict == 0 ? 0.0 : 2.0;
   wave_sync();
   const int col = lane <= NX ? lane : NX;
   if (verdict == 0) {
@@ -452,7 +462,11 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
 // MODE 2: the leg-end knot (terminalSolve with nu > 0, :146-192, under configure_knot's
 //         Gx = A^T, Gu = B^T, Gth = 0, gamma = f, parallel-solver.hxx:136-141): no V', so
 //         H = W; Kth = -R^{-1} B^T ; Vxt = A^T + K^T B^T ; Vtt = B Kth ; vt = f + B kff.
-template <int NX, int NU, int MODE = 0>
+// MODE 3: MODE 0's arithmetic for wave A of a two-wave leg (gar_backward_wave_leg2): record
+//         layout of a parameterised stage, the per-stage LDS block selected by the stage parity
+//         PAR, [kff | K], Rhat, L, 1/d, the verdict and yff published for wave B, which does the
+//         parameter part (wave_param_stage) after the workgroup barrier that ends the publication.
+template <int NX, int NU, int MODE = 0, int PAR = 0>
 __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, const double *prob,
                                            double *fac, int t, int lane,
                                            const WaveLane<NX, NU> &L, WaveStage<NX, NU> &S,
@@ -462,10 +476,14 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   constexpr int NW = C::NW, PK = C::PK, PG = C::PG, TX = C::TX, TW = C::TW, KS = C::KS,
                 KU = C::KU;
   const int li = lane & 15, lk = lane >> 4;
-  double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM;
-  double *vn = sm + C::oVn, *vp = sm + C::oVp;
+  constexpr bool PRM = (MODE == 1 || MODE == 2); // this wave does the parameter part itself
+  double *sb = sm + (MODE == 3 ? PAR * C::pub_shift : 0); // this stage's block [oG, total)
+  double *V = sm + C::oV, *G = sb + C::oG, *Mm = sb + C::oM;
+  double *vn = sb + C::oVn, *vp = sb + C::oVp;
+  // vx' was written by the previous stage: into the other block when the blocks alternate
+  const double *vnr = sm + (MODE == 3 ? (1 - PAR) * C::pub_shift : 0) + C::oVn;
   double *Xt = sm + C::oXt + lane, *Tt = sm + C::oTt + lane; // lane-private slots, stride 64
-  double *Gt = sm + C::oGt, *vtl = sm + C::oVt, *yfl = sm + C::oYf;
+  double *Gt = sm + C::oGt, *vtl = sm + C::oVt, *yfl = sm + (MODE == 3 && PAR ? C::oYf1 : C::oYf);
   constexpr int oVxx = MODE ? C::pVxx : M::fVxx, ovx = MODE ? C::pvx : M::fvx;
   const unsigned lkx = 8u * (unsigned)(lk * NX + li); // element (lk, li) of a pitch-NX block
   double *out = fac + (long long)t * P.fac_rec;
@@ -496,7 +514,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
     s0 += s2;
     s1 += s3;
     if (lane < NX)
-      vp[lane] = vn[lane] + (s0 + s1);
+      vp[lane] = vnr[lane] + (s0 + s1);
   }
   wave_sync();
   GAR_WMARK(1)
@@ -647,7 +665,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       for (int k = 0; k < NU; ++k)
         x[k] = G[k * PG + col];
       GAR_WMARK(11)
-      if (MODE == 0) {
+      if (!PRM) {
         ldl_solve_regs_bcast<NU>(a_row, nd, x); // [kff | K] = -Rhat^{-1} [rhat | Shat^T]  (:248-262)
       } else {
         const int ct = lane < NX ? lane : NX - 1; // Kth = -Rhat^{-1} Ghat_u (:288-291)
@@ -668,9 +686,23 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         for (int k = 0; k < NU; ++k)
           G[k * PG + col] = x[k]; // in place: G now holds [kff | K]
       }
+      if (MODE == 3) { // the factorisation, for wave B's Kth
+        double *Lr = sb + C::oLr, *ndi = sb + C::oDi;
+        if (lane < NU) {
+#pragma unroll
+          for (int j = 0; j < NU; ++j)
+            Lr[lane * NU + j] = a_row[j];
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int j = 0; j < NU; ++j)
+            ndi[j] = nd[j];
+          sb[C::oFlag] = 0.0;
+        }
+      }
       wave_sync();
     } else {
-      failed |= wave_slow_factor_solve<NX, NU, MODE != 0>(sm, lane);
+      failed |= wave_slow_factor_solve<NX, NU, PRM>(sb, lane);
     }
   }
   GAR_WMARK(6)
@@ -686,8 +718,8 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         stg_b(out, M::fFB + 8 * tj * 2 * NW + 8 * s, L.fbl, Kb[tj][s]);
     }
   }
-  double Kthb[TX][KU]; // MODE != 0: Kth[4s'+lk][16tj+li], fth rows 0..NU-1 (same device order as fb)
-  if (MODE != 0) {
+  double Kthb[TX][KU]; // PRM: Kth[4s'+lk][16tj+li], fth rows 0..NU-1 (same device order as fb)
+  if (PRM) {
 #pragma unroll
     for (int tj = 0; tj < TX; ++tj) {
       const int cc = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
@@ -743,6 +775,10 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         out[C::pvt + lane] = yf;
       }
     }
+    if (MODE == 3) { // published for wave B's vt = vt' + Vxt'^T yff
+      if (lane < NX)
+        yfl[lane] = yf;
+    }
     if (MODE == 1) { // vt = vt' + Vxt'^T yff (:298-301): Vxt' from the operand slots, yff via LDS
       if (lane < NX)
         yfl[lane] = yf;
@@ -778,6 +814,8 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       }
     }
   }
+  if (MODE == 3)
+    __syncthreads(); // [kff | K], the factorisation and yff are published: wave B goes on
   GAR_WMARK(7)
   // ---- Aff = A + B K (:267), in place on the F operand registers ------------------
   // A[16ti+lk+4r][16tj+li] IS the F operand F[4s+lk][16tj+li] with s = 4ti + r.  The MFMAs of
@@ -818,7 +856,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
                             : (ti < C::KSF ? S.Fo[tj][ti][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r])));
         }
       }
-  if (MODE != 0) {
+  if (PRM) {
     // ---- Yth = B Kth (:295), fth rows NU.. (MODE 2: those rows stay zero) ------------------
 #pragma unroll
     for (int tj = 0; tj < TX; ++tj)

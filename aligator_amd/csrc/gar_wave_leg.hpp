@@ -107,6 +107,311 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave_leg(LegParams Q) {
     atomicOr(&P.status[b], failed);
 }
 
+// ---- two waves per leg -----------------------------------------------------------------------
+// The parameter part of a leg stage (riccati-kernel.hxx:278-311) needs from the plain part only
+// K, the factorisation of Rhat and yff.  Wave A runs the plain recursion (wave_stage<.., 3, PAR>)
+// and publishes those in LDS; wave B (this function) runs one stage behind the publication:
+//   before the barrier of stage t : F operands of knot t, Ghat_u = B^T Vxt'
+//   after it                      : Kth = -Rhat^{-1} Ghat_u, Aff = A + B K (recomputed: 27 MFMAs
+//                                   are cheaper than moving Aff between waves), Yth, vt, Vxt, Vtt
+// The critical path of a stage is wave A's plain stage (the parameter part is shorter), instead
+// of the sum of both.  Published blocks alternate with the stage parity, so one workgroup barrier
+// per stage orders everything.
+template <int NX, int NU, int PAR>
+__device__ __forceinline__ void wave_param_stage(const MfmaParams &P, double *sm, const double *prob,
+                                                 double *fac, int t, int lane,
+                                                 const WaveLane<NX, NU> &L, WaveStage<NX, NU> &S,
+                                                 int &failed) {
+  using C = WaveCfg<NX, NU>;
+  constexpr int NW = C::NW, PG = C::PG, TX = C::TX, KS = C::KS, KU = C::KU;
+  const int li = lane & 15, lk = lane >> 4;
+  const double *sb = sm + PAR * C::pub_shift; // what wave A publishes for this stage
+  const double *Gp = sb + C::oG, *Lr = sb + C::oLr, *ndi = sb + C::oDi;
+  const double *yfp = sm + (PAR ? C::oYf1 : C::oYf);
+  double *Xt = sm + C::oXt + lane, *Tt = sm + C::oTt + lane;
+  double *Gt = sm + C::oGt, *vtl = sm + C::oVt;
+  const unsigned lkx = 8u * (unsigned)(lk * NX + li);
+  double *out = fac + (long long)t * P.fac_rec;
+  const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
+  const double *recn = rec - (t > 0 ? P.in_rec : 0);
+  // ---- before the barrier: B of this knot, Ghat_u = B^T Vxt' (:286-287) ----------------------
+  double Bop[TX][KU], Bop4[KU];
+#pragma unroll
+  for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      Bop[ti][s] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * s * NX + 16 * ti, L.bop0)
+                                              : ldg_b(rec, 4 * s * NX, L.bopX);
+  if (C::REM4) {
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      Bop4[s] = ldg_b(rec, 4 * s * NX, L.bop4);
+  }
+  constexpr int shLoT = C::shTile(0), shHiT = C::shTile(KU - 1);
+  double4_t Gh[shHiT - shLoT + 1][TX];
+#pragma unroll
+  for (int tu = shLoT; tu <= shHiT; ++tu)
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S.fo(tu, s), Xt[(s * TX + tj) * 64], acc, 0, 0, 0);
+      Gh[tu - shLoT][tj] = acc;
+    }
+#pragma unroll
+  for (int sp = 0; sp < KU; ++sp)
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj)
+      if (16 * tj + 15 < NX || 16 * tj + li < NX)
+        Gt[(4 * sp + lk) * PG + 16 * tj + li] = Gh[C::shTile(sp) - shLoT][tj][C::shReg(sp)];
+  __syncthreads(); // wave A has published stage t
+  // ---- Kth = -Rhat^{-1} Ghat_u (:288-291) with wave A's factorisation ---------------------------
+  if (sb[C::oFlag] == 0.0) {
+    const int rowu = lane < NU ? lane : NU - 1;
+    double a_row[NU], nd[NU], y[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      a_row[j] = Lr[rowu * NU + j];
+      nd[j] = ndi[j];
+    }
+    const int ct = lane < NX ? lane : NX - 1;
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+      y[k] = Gt[k * PG + ct];
+    ldl_solve_regs_bcast<NU>(a_row, nd, y);
+    if (lane < NX) {
+#pragma unroll
+      for (int k = 0; k < NU; ++k)
+        Gt[k * PG + ct] = y[k];
+    }
+  } else { // Bunch-Kaufman factors (interchanges / 2x2 pivots) in the published block
+    for (int e = lane; e < NU * PG; e += 64)
+      Gt[e] = -Gt[e];
+    const double *sub = sb + C::oBk;
+    const int *piv = (const int *)(sub + 16);
+    const WG w1 = wave_self();
+    wave_sync();
+    wg_bk_solve(w1, NU, sb + C::oM, NU, sub, piv, Gt, PG, 1, NX);
+  }
+  wave_sync();
+  double Kb[TX][KU], Kthb[TX][KU];
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj) {
+    const int cc = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
+#pragma unroll
+    for (int s = 0; s < KU; ++s) {
+      Kb[tj][s] = Gp[(4 * s + lk) * PG + 1 + cc];
+      Kthb[tj][s] = Gt[(4 * s + lk) * PG + cc];
+      if (16 * tj + li < NX)
+        stg_b(out, C::pFTH + 8 * tj * 2 * NW + 8 * s, L.fbl, Kthb[tj][s]);
+    }
+  }
+  // ---- vt = vt' + Vxt'^T yff (:298-301), before Vxt' is replaced ---------------------------------
+  {
+    double ys[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      ys[s] = yfp[4 * s + lk];
+    double pt[TX];
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s & 1)
+          a1 = __builtin_fma(Xt[(s * TX + tj) * 64], ys[s], a1);
+        else
+          a0 = __builtin_fma(Xt[(s * TX + tj) * 64], ys[s], a0);
+      }
+      double a = a0 + a1;
+      a += __shfl_xor(a, 16);
+      a += __shfl_xor(a, 32);
+      pt[tj] = a;
+    }
+    double st = pt[0];
+#pragma unroll
+    for (int tj = 1; tj < TX; ++tj)
+      st = (lk == tj) ? pt[tj] : st;
+    if (lane < NX) {
+      const double v = vtl[lane] + st;
+      vtl[lane] = v;
+      out[C::pvt + lane] = v;
+    }
+  }
+  // ---- Aff = A + B K in place on the F operand registers (as wave A does) -------------------------
+  double4_t accT[TX];
+  if (C::KST > 0 && !C::REM4) {
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        accT[tj][r] = (r < C::KST) ? S.FoT[tj][r] : 0.0;
+  }
+#pragma unroll
+  for (int s = 0; s < KU; ++s)
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < TX; ++ti) {
+        if (ti < C::KSF)
+          S.Fo[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], S.Fo[tj][ti], 0, 0, 0);
+        else if (C::REM4)
+          S.FoT[tj][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(Bop4[s], Kb[tj][s], S.FoT[tj][0], 0, 0, 0);
+        else
+          accT[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], accT[tj], 0, 0, 0);
+      }
+  // ---- Yth = B Kth (:295), fth rows NU.. -----------------------------------------------------------
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < TX; ++ti) {
+      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KU; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kthb[tj][s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
+        if (16 * ti + 4 * r < NX) {
+          if (i < NX && j < NX)
+            stg_b(out, C::pFTH + 8 * tj * 2 * NW + 2 * (NU + 16 * ti + 4 * r), L.fbl, acc[r]);
+        }
+      }
+    }
+  // ---- Vxt = Aff^T Vxt' (:304-306), one parameter column tile at a time ---------------------------
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj) {
+    double4_t nv[TX];
+#pragma unroll
+    for (int ti = 0; ti < TX; ++ti) {
+      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const double aq = (s < 4 * C::KSF || C::REM4) ? S.fo(ti, s) : accT[ti][s - 4 * C::KSF];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Xt[(s * TX + tj) * 64], acc, 0, 0, 0);
+      }
+      nv[ti] = acc;
+    }
+#pragma unroll
+    for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * ti + 4 * r < NX) {
+          Xt[((4 * ti + r) * TX + tj) * 64] = nv[ti][r];
+          if (16 * tj + 15 < NX || 16 * tj + li < NX)
+            stg_b(out, C::pVxt + 16 * tj * NX + 16 * ti + 4 * r, 8u * (unsigned)(li * NX + lk), nv[ti][r]);
+        }
+  }
+  // ---- Vtt = Vtt' + Ghat_u^T Kth, computed transposed (see wave_stage) ----------------------------
+#pragma unroll
+  for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * ti + 4 * r < NX)
+          acc[r] = Tt[((4 * ti + r) * TX + tj) * 64];
+#pragma unroll
+      for (int s = 0; s < KU; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Kthb[ti][s], Gh[C::shTile(s) - shLoT][tj][C::shReg(s)],
+                                                   acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * ti + 4 * r < NX) {
+          Tt[((4 * ti + r) * TX + tj) * 64] = acc[r];
+          if (16 * tj + 15 < NX || 16 * tj + li < NX)
+            stg_b(out, C::pVtt + (16 * ti + 4 * r) * NX + 16 * tj, lkx, acc[r]);
+        }
+    }
+  // ---- knot t-1: its F operands replace Aff
+  wave_load_a<NX, NU>(recn, L, S);
+  (void)failed;
+}
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(128, 1) gar_backward_wave_leg2(LegParams Q) {
+  using C = WaveCfg<NX, NU>;
+  using M = MfmaCfg<NX, NU>;
+  constexpr int PK = C::PK;
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  const int leg = (int)blockIdx.x + Q.leg_begin;
+  const int b = (int)blockIdx.y;
+  double *sm = gar_smem;
+  MfmaParams P = Q.M;
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  const int N = P.horizon;
+  int t_beg, t_end;
+  gar_get_work(N, leg, Q.num_legs, &t_beg, &t_end);
+  const bool last_leg = (leg == Q.num_legs - 1);
+  P.fac_rec = last_leg ? (long long)(M::fvx + NX) : (long long)C::prec;
+  P.fac_rec = (P.fac_rec + 1) & ~1ll;
+  double *fac = P.fac + (long long)b * P.fac_stride + Q.meta[t_beg].fac_off - (long long)t_beg * P.fac_rec;
+  double *V = sm + C::oV, *vn = sm + C::oVn;
+  const bool tracing = false;
+  WaveLane<NX, NU> L;
+  wave_lane_init<NX, NU>(L, lane);
+  WaveStage<NX, NU> S;
+  int failed = 0;
+  if (last_leg) { // the plain recursion: one wave
+    if (wave != 0)
+      return;
+    const int t1 = N - 1 >= t_beg ? N - 1 : t_beg;
+    if (N - 1 >= t_beg) {
+      wave_load_a<NX, NU>(prob + P.in_off0 + (long long)t1 * P.in_rec, L, S);
+      wave_load_b<NX, NU>(prob + P.in_off0 + (long long)t1 * P.in_rec, L, S);
+    }
+    {
+      const double *rec = prob + P.in_offN;
+      double *out = P.fac + (long long)b * P.fac_stride + Q.meta[N].fac_off;
+      for (int e = lane; e < NX * NX; e += 64) {
+        const int j = e / NX, i = e - j * NX;
+        const double v = (i >= j) ? rec[M::tQ + e] : rec[M::tQ + i * NX + j];
+        V[i * PK + j] = v;
+        out[M::tVxx + e] = v;
+      }
+      if (lane < NX) {
+        const double v = rec[M::tq + lane];
+        vn[lane] = v;
+        out[M::tvx + lane] = v;
+      }
+    }
+    wave_sync();
+    for (int t = N - 1; t >= t_beg; --t)
+      wave_stage<NX, NU, 0>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+  } else {
+    const int te = t_end - 1;
+    if (wave == 0) {
+      wave_load_a<NX, NU>(prob + P.in_off0 + (long long)te * P.in_rec, L, S);
+      wave_load_b<NX, NU>(prob + P.in_off0 + (long long)te * P.in_rec, L, S);
+      wave_stage<NX, NU, 2>(P, sm, prob, fac, te, lane, L, S, failed, tracing); // writes Xt, Tt, vt
+      __syncthreads();
+      // the first alternating stage reads vx' where the leg-end stage left it (block 0): PAR = 1
+      int t = te - 1;
+      for (; t - 1 >= t_beg; t -= 2) {
+        wave_stage<NX, NU, 3, 1>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+        wave_stage<NX, NU, 3, 0>(P, sm, prob, fac, t - 1, lane, L, S, failed, tracing);
+      }
+      if (t >= t_beg)
+        wave_stage<NX, NU, 3, 1>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+    } else {
+      if (te - 1 >= t_beg)
+        wave_load_a<NX, NU>(prob + P.in_off0 + (long long)(te - 1) * P.in_rec, L, S);
+      __syncthreads();
+      int t = te - 1;
+      for (; t - 1 >= t_beg; t -= 2) {
+        wave_param_stage<NX, NU, 1>(P, sm, prob, fac, t, lane, L, S, failed);
+        wave_param_stage<NX, NU, 0>(P, sm, prob, fac, t - 1, lane, L, S, failed);
+      }
+      if (t >= t_beg)
+        wave_param_stage<NX, NU, 1>(P, sm, prob, fac, t, lane, L, S, failed);
+    }
+  }
+  if (failed && lane == 0)
+    atomicOr(&P.status[b], failed);
+}
+
 // (Vxx | Vxt | Vtt | vx | vt) of each local leg's first stage, blocks of NX
 template <int NX, int NU>
 __global__ void __launch_bounds__(256) gar_leg_tuples(LegParams Q) {
