@@ -168,3 +168,32 @@ def check_condensed_block_inverse_fallback(lib_path=None):
         del os.environ["GAR_HIP_CONDENSED"]
     for A, B in zip(sol[0], ref):
         assert maxdiff(A, B) <= 1e-9 * scale_of(ref)
+
+
+def check_leg_kernels_bunch_kaufman_fallback(lib_path=None, nthreads=3, horz=11):
+    """Stages whose Rhat makes Bunch-Kaufman interchange (bunchkaufman.hpp:61-83), in leg mode:
+    the plain part takes the generic device Bunch-Kaufman and the parameter part (the second
+    right-hand-side set; wave B of the two-wave kernel) solves Kth with those pivoted factors.
+    A failing factorisation must be reported (riccati-kernel.hxx:239-241)."""
+    import pytest
+    nx, nu = 8, 4
+    prob = synth.generate_lq_problem(11, np.zeros(nx), horz, nx, nu, mode="W")
+    for k in prob.stages[:-1]:
+        k.R[...] = np.array([[1e-3, 2.0, 0.1, 0.0], [2.0, 1e-3, 0.0, 0.1],
+                             [0.1, 0.0, 3.0, 0.2], [0.0, 0.1, 0.2, 4.0]])
+        k.B[...] *= 1e-2
+    op = to_oracle(prob)
+    opar = ora.ParallelRiccatiSolver(op, nthreads)
+    opar.backward(1e-12)
+    pivots = [ora.BunchKaufman(opar.datas(t).Rhat).pivots for t in range(horz)]
+    assert any(not np.array_equal(p, np.arange(nu)) for p in pivots), "test must force a pivot"
+    par = check_parallel(prob, 1e-12, nthreads, 1e-9, lib_path)
+    assert par._impl.kernel_name == "wave_leg<8,4>"
+    bad = synth.generate_lq_problem(3, np.zeros(nx), horz, nx, nu, mode="W")
+    for k in bad.stages[:-1]:
+        k.R[...] = 0.0
+        k.S[...] = 0.0
+        k.B[...] = 0.0
+    with pytest.raises(RuntimeError, match="LDL"):
+        ParallelRiccatiSolver(bad, nthreads, lib_path=lib_path).backward(1e-10)
+

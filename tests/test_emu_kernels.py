@@ -155,6 +155,12 @@ def test_condensed_block_inverse_bunch_kaufman_fallback():
     pc.check_condensed_block_inverse_fallback(EMU)
 
 
+@pytest.mark.parametrize("leg_waves", ["2", "1"])
+def test_leg_kernels_bunch_kaufman_fallback_and_failure(monkeypatch, leg_waves):
+    monkeypatch.setenv("GAR_HIP_LEG_WAVES", leg_waves)
+    pc.check_leg_kernels_bunch_kaufman_fallback(EMU)
+
+
 @pytest.mark.parametrize("nc0", [0, 3])
 def test_leg_kernels_partial_initial_constraint(nc0):
     """G0 with fewer rows than states (nc0 < nx): block 0 of the condensed system is padded."""

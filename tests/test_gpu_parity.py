@@ -189,6 +189,16 @@ def test_condensed_block_inverse_bunch_kaufman_fallback():
     pc.check_condensed_block_inverse_fallback()
 
 
+@pytest.mark.parametrize("leg_waves", ["2", "1"])
+def test_leg_kernels_bunch_kaufman_fallback_and_failure(monkeypatch, leg_waves):
+    monkeypatch.setenv("GAR_HIP_LEG_WAVES", leg_waves)
+    pc.check_leg_kernels_bunch_kaufman_fallback()
+    # and the one-wave-per-leg kernel against the two-wave default on the north-star shape
+    prob = synth.generate_lq_problem(4400, np.ones(36), 64, 36, 12, mode="W")
+    par = pc.check_parallel(prob, 1e-10, 8, 1e-9)
+    assert par._impl.kernel_name == "wave_leg<36,12>"
+
+
 def test_sharded_solver_single_rank_rccl():
     """aligator_amd.sharded on the real device path: torch views of the library's device
     buffers, all_gather_into_tensor over RCCL (world_size 1 is all a 1-GPU box offers; the
