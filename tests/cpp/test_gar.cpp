@@ -1,0 +1,231 @@
+// C++ parity tests of the HIP gar backend through include/gar_hip.hpp, written the way the
+// reference's own tests are (tests/gar/riccati.cpp, tests/gar/parallel.cpp): build a problem,
+// `solver.backward(mu)`, `lqrInitializeSolution`, `solver.forward(...)`, check the KKT residual
+// against the reference's thresholds.  No test framework (Catch2 is not in this image): a failed
+// REQUIRE prints the line and makes the program exit 1.  Exit code 77 = no HIP device (the
+// backend has no CPU path; the product must fail loudly, and it does: the constructor throws).
+#include <gar_hip.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+using namespace aligator_hip::gar;
+
+static int g_failed = 0;
+// GAR_TEST_SMALL=1: the sizes the CPU emulator build (tests/emu) gets through in seconds
+static const bool g_small = std::getenv("GAR_TEST_SMALL") != nullptr;
+#define REQUIRE(cond)                                                          \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      std::printf("  REQUIRE failed at line %d: %s\n", __LINE__, #cond);       \
+      ++g_failed;                                                              \
+    }                                                                          \
+  } while (0)
+
+// a well-conditioned random knot (same distributions as aligator_amd/synth.py, generator "W",
+// which restates tests/gar/test_util.cpp:14-76 with contractive dynamics)
+static LqrKnot generate_knot(std::mt19937 &rng, uint nx, uint nu, uint nc = 0) {
+  std::normal_distribution<double> n01(0.0, 1.0);
+  std::uniform_real_distribution<double> u11(-1.0, 1.0);
+  LqrKnot k(nx, nu, nc);
+  const uint nw = nx + nu;
+  Matrix root((int)nw, (int)nw + 1);
+  for (double &v : root.v)
+    v = n01(rng);
+  auto W = [&](uint i, uint j) {
+    double s = 0;
+    for (uint c = 0; c <= nw; ++c)
+      s += root((int)i, (int)c) * root((int)j, (int)c);
+    return s / std::max(nx, std::max(nu, 1u));
+  };
+  for (uint i = 0; i < nx; ++i)
+    for (uint j = 0; j < nx; ++j)
+      k.Q((int)i, (int)j) = W(i, j);
+  for (uint i = 0; i < nx; ++i)
+    for (uint j = 0; j < nu; ++j)
+      k.S((int)i, (int)j) = W(i, nx + j);
+  for (uint i = 0; i < nu; ++i)
+    for (uint j = 0; j < nu; ++j)
+      k.R((int)i, (int)j) = W(nx + i, nx + j) * (i == j ? 1.0 + 1e-6 : 1.0);
+  for (double &v : k.q) v = u11(rng);
+  for (double &v : k.r) v = u11(rng);
+  k.A.setIdentity();
+  for (double &v : k.A.v) v += 0.1 * u11(rng);
+  for (double &v : k.B.v) v = 0.5 * u11(rng);
+  for (double &v : k.f) v = n01(rng);
+  for (double &v : k.C.v) v = u11(rng);
+  for (double &v : k.D.v) v = u11(rng);
+  for (double &v : k.d) v = u11(rng);
+  return k;
+}
+
+static LqrProblem generate_problem(std::mt19937 &rng, const VectorXs &x0, uint horz, uint nx, uint nu) {
+  LqrProblem::KnotVector knots;
+  for (uint t = 0; t < horz; ++t)
+    knots.push_back(generate_knot(rng, nx, nu));
+  knots.push_back(generate_knot(rng, nx, 0)); // terminal knot: no controls
+  LqrProblem prob(std::move(knots), nx);
+  prob.G0.setIdentity();
+  for (double &v : prob.G0.v) v = -v;
+  prob.g0 = x0; // G0 x0 + g0 = 0
+  return prob;
+}
+
+static double maxdiff(const VectorOfVectors &a, const VectorOfVectors &b) {
+  double m = 0;
+  for (size_t t = 0; t < a.size(); ++t)
+    for (size_t i = 0; i < a[t].size(); ++i)
+      m = std::max(m, std::fabs(a[t][i] - b[t][i]));
+  return m;
+}
+
+// tests/gar/riccati.cpp:24-86
+static void riccati_short_horz_pb(uint horz) {
+  std::printf("riccati_short_horz_pb horz=%u\n", horz);
+  const double mueq = 1e-14;
+  const uint nx = 2, nu = 2;
+  std::mt19937 rng(42);
+  std::uniform_real_distribution<double> u11(-1.0, 1.0);
+  auto init_knot = [&](uint nc) {
+    LqrKnot knot(nx, nu, nc);
+    knot.A(0, 0) = 0.1; knot.A(0, 1) = 0.0; knot.A(1, 0) = -0.1; knot.A(1, 1) = 0.01;
+    for (double &v : knot.B.v) v = u11(rng);
+    for (double &v : knot.f) v = u11(rng);
+    knot.Q.setIdentity();
+    for (double &v : knot.Q.v) v *= 0.01;
+    knot.R.setIdentity();
+    for (double &v : knot.R.v) v *= 0.1;
+    return knot;
+  };
+  LqrKnot base_knot = init_knot(0u);
+  LqrKnot knot1 = base_knot;
+  knot1.Q.setIdentity();
+  knot1.q = {1.0, 1.0}; // -x1, x1 = -ones
+  LqrProblem::KnotVector knots(horz + 1, base_knot);
+  knots[4] = init_knot(nu);
+  knots[4].D.setIdentity();
+  knots[4].d.assign(nu, 0.1);
+  knots[horz] = knot1;
+  LqrProblem prob(std::move(knots), nx);
+  prob.g0 = {-1.0, -1.0};
+  prob.G0.setIdentity();
+  ProximalRiccatiSolver solver{prob};
+  REQUIRE(solver.backward(mueq));
+  auto [xs, us, vs, lbdas] = lqrInitializeSolution(prob);
+  REQUIRE(xs.size() == size_t(prob.horizon()) + 1);
+  REQUIRE(vs.size() == size_t(prob.horizon()) + 1);
+  REQUIRE(lbdas.size() == size_t(prob.horizon()) + 1);
+  REQUIRE(solver.forward(xs, us, vs, lbdas));
+  KktError err = lqrComputeKktError(prob, xs, us, vs, lbdas);
+  std::printf("  kkt: dyn %.2e cstr %.2e dual %.2e\n", err.dyn, err.cstr, err.dual);
+  REQUIRE(err.max <= 1e-9);
+}
+
+// tests/gar/riccati.cpp:88-105
+static void riccati_one_knot_prob() {
+  std::printf("riccati_one_knot_prob\n");
+  std::mt19937 rng(7);
+  auto problem = generate_problem(rng, VectorXs(2, 0.0), 0, 2, 2);
+  ProximalRiccatiSolver solver(problem);
+  auto [xs, us, vs, lbdas] = lqrInitializeSolution(problem);
+  REQUIRE(xs.size() == 1);
+  REQUIRE(us.size() == 0);
+  REQUIRE(lbdas.size() == 1);
+  solver.backward(1e-13);
+  solver.forward(xs, us, vs, lbdas);
+  REQUIRE(lqrComputeKktError(problem, xs, us, vs, lbdas).max <= 1e-10);
+}
+
+// tests/gar/riccati.cpp:107-139 (nx = 36, nu = 12)
+static void riccati_random_large_problem() {
+  std::printf("riccati_random_large_problem\n");
+  std::mt19937 rng(11);
+  const uint nx = 36, nu = 12, horz = g_small ? 6 : 100;
+  VectorXs x0(nx, 1.0);
+  auto prob = generate_problem(rng, x0, horz, nx, nu);
+  ProximalRiccatiSolver solver{prob};
+  const double mu = 1e-14;
+  solver.backward(mu);
+  auto [xs, us, vs, lbdas] = lqrInitializeSolution(prob);
+  solver.forward(xs, us, vs, lbdas);
+  KktError err = lqrComputeKktError(prob, xs, us, vs, lbdas, mu);
+  std::printf("  kernel %s  kkt: dyn %.2e cstr %.2e dual %.2e\n", solver.kernelName(), err.dyn,
+              err.cstr, err.dual);
+  REQUIRE(err.max <= 1e-9);
+  REQUIRE(solver.getFeedback(0).rows == (int)(nu + nx));
+  REQUIRE(solver.getFeedforward(0).size() == nu + nx);
+}
+
+// tests/gar/parallel.cpp:185-245
+static void parallel_solver_class(uint num_threads) {
+  std::printf("parallel_solver_class threads=%u\n", num_threads);
+  std::mt19937 rng(13);
+  const uint nx = g_small ? 8 : 36, nu = g_small ? 4 : 12, horz = g_small ? 23 : 96;
+  VectorXs x0(nx, 0.5);
+  auto problem = generate_problem(rng, x0, horz, nx, nu);
+  const double mu = 1e-12;
+  ProximalRiccatiSolver refSolver{problem};
+  refSolver.backward(mu);
+  auto [xs_ref, us_ref, vs_ref, lbdas_ref] = lqrInitializeSolution(problem);
+  refSolver.forward(xs_ref, us_ref, vs_ref, lbdas_ref);
+
+  ParallelRiccatiSolver parSolver(problem, num_threads);
+  parSolver.backward(mu);
+  auto [xs, us, vs, lbdas] = lqrInitializeSolution(problem);
+  parSolver.forward(xs, us, vs, lbdas);
+  KktError err = lqrComputeKktError(problem, xs, us, vs, lbdas, mu);
+  std::printf("  kernel %s  kkt max %.2e  |x - x_ref| %.2e  |lbda - lbda_ref| %.2e\n",
+              parSolver.kernelName(), err.max, maxdiff(xs, xs_ref), maxdiff(lbdas, lbdas_ref));
+  REQUIRE(err.max <= 1e-9);
+  REQUIRE(maxdiff(xs, xs_ref) <= 1e-9);
+  REQUIRE(maxdiff(lbdas, lbdas_ref) <= 1e-7);
+  parSolver.collapseFeedback();
+}
+
+static void error_behaviour() {
+  std::printf("error_behaviour\n");
+  std::mt19937 rng(3);
+  auto prob = generate_problem(rng, VectorXs(8, 0.0), 3, 8, 4);
+  for (int t = 0; t < prob.horizon(); ++t) {
+    prob.stages[t].R.setZero();
+    prob.stages[t].S.setZero();
+    prob.stages[t].B.setZero();
+  }
+  bool threw = false;
+  try {
+    ProximalRiccatiSolver s{prob};
+    s.backward(1e-10);
+  } catch (const std::runtime_error &e) { // riccati-kernel.hxx:239-241
+    threw = std::string(e.what()).find("LDL") != std::string::npos;
+  }
+  REQUIRE(threw);
+  threw = false;
+  try {
+    ParallelRiccatiSolver s(prob, 1); // parallel-solver.hxx:42-46
+  } catch (const std::runtime_error &) {
+    threw = true;
+  }
+  REQUIRE(threw);
+}
+
+int main() {
+  std::printf("%s, %d HIP device(s)\n", gar_hip_version(), gar_hip_device_count());
+  try {
+    for (uint horz : {4u, 8u, 16u})
+      riccati_short_horz_pb(horz);
+  } catch (const std::runtime_error &e) {
+    if (gar_hip_device_count() == 0) {
+      std::printf("no HIP device: %s\n", e.what());
+      return 77;
+    }
+    throw;
+  }
+  riccati_one_knot_prob();
+  riccati_random_large_problem();
+  for (uint th : {2u, 4u, 8u})
+    parallel_solver_class(th);
+  error_behaviour();
+  std::printf(g_failed ? "%d REQUIRE(s) FAILED\n" : "all passed\n", g_failed);
+  return g_failed ? 1 : 0;
+}
