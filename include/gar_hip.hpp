@@ -199,6 +199,30 @@ public:
 
 namespace detail {
 
+// Control padding (same rule as aligator_amd/gar.py::_padded_controls): a uniform unconstrained
+// problem whose nu is not a multiple of 4 runs on the specialised kernels of (nx, 4*ceil(nu/4))
+// with DUMMY controls (R = I, S = 0, B = 0, r = 0 on the padding): they solve to exactly zero,
+// decouple, and are stripped from the gains and the solution.  Returns the padded nu, or 0.
+inline uint padded_controls(const LqrProblem &p) {
+  const int N = p.horizon();
+  if (N < 1)
+    return 0;
+  const uint nx = p.stages[0].nx, nu = p.stages[0].nu;
+  if (nu == 0 || nu % 4 == 0)
+    return 0;
+  for (int t = 0; t <= N; ++t) {
+    const LqrKnot &k = p.stages[t];
+    if (k.nx != nx || k.nx2 != nx || k.nc != 0 || k.nth != 0 || k.nu != (t < N ? nu : 0u))
+      return 0;
+  }
+  const uint nup = 4 * ((nu + 3) / 4);
+  const uint shapes[][2] = {{36, 12}, {32, 12}, {16, 8}, {12, 8}, {12, 4}, {8, 4}};
+  for (auto &sh : shapes)
+    if (sh[0] == nx && sh[1] == nup)
+      return nup;
+  return 0;
+}
+
 // the six virtuals over the C ABI, shared by the two solvers
 class HipSolver : public RiccatiSolverBase {
 public:
@@ -220,43 +244,58 @@ public:
       if (t < N)
         nls += k.nx2;
     }
+    if (nup_)
+      nus = (size_t)nup_ * (size_t)N;
     VectorXs X(nxs), U(nus + 1), V(nvs + 1), L(nls + 1);
     check(gar_hip_get_solution(h_, 0, X.data(), U.data(), V.data(), L.data()));
     scatter(X, xs);
-    scatter(U, us);
+    if (nup_) { // the device solution carries the dummy controls (exactly zero): drop them
+      for (size_t t = 0; t < us.size(); ++t)
+        std::copy(U.begin() + (long)(t * nup_), U.begin() + (long)(t * nup_ + us[t].size()),
+                  us[t].begin());
+    } else {
+      scatter(U, us);
+    }
     scatter(V, vs);
     scatter(L, lbdas);
     return true;
   }
   void cycleAppend(const LqrKnot &knot) override {
-    const int32_t d[5] = {(int)knot.nx, (int)knot.nu, (int)knot.nc, (int)knot.nx2, (int)knot.nth};
+    const int32_t d[5] = {(int)knot.nx, (int)(nup_ && knot.nu ? nup_ : knot.nu), (int)knot.nc,
+                          (int)knot.nx2, (int)knot.nth};
     check(gar_hip_cycle_append(h_, d));
   }
   VectorXs getFeedforward(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
-    VectorXs ff(k.nu + k.nc + k.nx2);
+    const uint nud = dev_nu(k);
+    VectorXs ff(nud + k.nc + k.nx2);
     check(gar_hip_get_gains(h_, 0, (int)i, ff.data(), nullptr, nullptr));
+    ff.erase(ff.begin() + k.nu, ff.begin() + nud); // rows of the dummy controls
     return ff;
   }
   Matrix getFeedback(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
-    const int nr = (int)(k.nu + k.nc + k.nx2);
-    std::vector<double> rm((size_t)nr * k.nx);
+    const uint nud = dev_nu(k);
+    const int nrd = (int)(nud + k.nc + k.nx2), nr = (int)(k.nu + k.nc + k.nx2);
+    std::vector<double> rm((size_t)nrd * k.nx);
     check(gar_hip_get_gains(h_, 0, (int)i, nullptr, rm.data(), nullptr));
     Matrix fb(nr, (int)k.nx);
-    for (int r = 0; r < nr; ++r)
+    for (int r = 0; r < nr; ++r) {
+      const int rd = r < (int)k.nu ? r : r + (int)(nud - k.nu);
       for (uint j = 0; j < k.nx; ++j)
-        fb(r, (int)j) = rm[(size_t)r * k.nx + j];
+        fb(r, (int)j) = rm[(size_t)rd * k.nx + j];
+    }
     return fb;
   }
   const char *kernelName() const { return gar_hip_kernel_name(h_); }
 
 protected:
-  HipSolver(LqrProblem &problem, int num_legs, int device) : problem_(&problem) {
+  HipSolver(LqrProblem &problem, int num_legs, int device)
+      : problem_(&problem), nup_(padded_controls(problem)) {
     const int N = problem.horizon();
     std::vector<int32_t> dims5;
     for (const LqrKnot &k : problem.stages) {
-      const int32_t d[5] = {(int)k.nx, (int)k.nu, (int)k.nc, (int)k.nx2,
+      const int32_t d[5] = {(int)k.nx, (int)dev_nu(k), (int)k.nc, (int)k.nx2,
                             num_legs > 1 ? 0 : (int)k.nth};
       dims5.insert(dims5.end(), d, d + 5);
     }
@@ -268,6 +307,14 @@ protected:
   void upload() const {
     const auto &st = problem_->stages;
     for (int t = 0; t < (int)st.size(); ++t) {
+      if (nup_ && st[t].nu > 0) {
+        const LqrKnot k = pad(st[t]);
+        check(gar_hip_upload_stage(h_, 0, t, k.Q.data(), k.S.data(), k.R.data(), k.q.data(),
+                                   k.r.data(), k.A.data(), k.B.data(), k.f.data(), k.C.data(),
+                                   k.D.data(), k.d.data(), k.Gth.data(), k.Gx.data(), k.Gu.data(),
+                                   k.Gv.data(), k.gamma.data()));
+        continue;
+      }
       const LqrKnot &k = st[t];
       check(gar_hip_upload_stage(h_, 0, t, k.Q.data(), k.S.data(), k.R.data(), k.q.data(),
                                  k.r.data(), k.A.data(), k.B.data(), k.f.data(), k.C.data(),
@@ -287,7 +334,25 @@ protected:
       p += v.size();
     }
   }
+  uint dev_nu(const LqrKnot &k) const { return (nup_ && k.nu > 0) ? nup_ : k.nu; }
+  LqrKnot pad(const LqrKnot &k) const {
+    LqrKnot p(k.nx, nup_, k.nc, k.nx2, k.nth);
+    p.Q = k.Q; p.q = k.q; p.A = k.A; p.f = k.f; p.C = k.C; p.d = k.d;
+    for (uint j = 0; j < k.nu; ++j) {
+      for (uint i = 0; i < k.nx; ++i)
+        p.S((int)i, (int)j) = k.S((int)i, (int)j);
+      for (uint i = 0; i < k.nx2; ++i)
+        p.B((int)i, (int)j) = k.B((int)i, (int)j);
+      for (uint i = 0; i < k.nu; ++i)
+        p.R((int)i, (int)j) = k.R((int)i, (int)j);
+      p.r[j] = k.r[j];
+    }
+    for (uint j = k.nu; j < nup_; ++j)
+      p.R((int)j, (int)j) = 1.0;
+    return p;
+  }
   LqrProblem *problem_;
+  uint nup_ = 0; // padded control dimension on the device (0: no padding)
   gar_hip_solver *h_ = nullptr;
 };
 

@@ -183,6 +183,30 @@ static void parallel_solver_class(uint num_threads) {
   parSolver.collapseFeedback();
 }
 
+// BASELINE.json configs[2] shape (nx = 12, nu = 6): runs on the (12, 8) kernels with two dummy
+// controls, which must not show in the gains or the solution
+static void padded_controls_shape() {
+  std::printf("padded_controls_shape (nx=12, nu=6)\n");
+  std::mt19937 rng(17);
+  const uint nx = 12, nu = 6, horz = g_small ? 9 : 64;
+  auto problem = generate_problem(rng, VectorXs(nx, 0.3), horz, nx, nu);
+  ProximalRiccatiSolver solver{problem};
+  solver.backward(1e-12);
+  auto [xs, us, vs, lbdas] = lqrInitializeSolution(problem);
+  solver.forward(xs, us, vs, lbdas);
+  REQUIRE(us[0].size() == nu);
+  REQUIRE(lqrComputeKktError(problem, xs, us, vs, lbdas, 1e-12).max <= 1e-9);
+  REQUIRE(solver.getFeedback(0).rows == (int)(nu + nx));
+  ParallelRiccatiSolver par(problem, 3);
+  par.backward(1e-12);
+  auto [xp, up, vp, lp] = lqrInitializeSolution(problem);
+  par.forward(xp, up, vp, lp);
+  std::printf("  kernels %s / %s  |x_par - x_serial| %.2e\n", solver.kernelName(), par.kernelName(),
+              maxdiff(xp, xs));
+  REQUIRE(maxdiff(xp, xs) <= 1e-9);
+  REQUIRE(maxdiff(up, us) <= 1e-9);
+}
+
 static void error_behaviour() {
   std::printf("error_behaviour\n");
   std::mt19937 rng(3);
@@ -225,6 +249,7 @@ int main() {
   riccati_random_large_problem();
   for (uint th : {2u, 4u, 8u})
     parallel_solver_class(th);
+  padded_controls_shape();
   error_behaviour();
   std::printf(g_failed ? "%d REQUIRE(s) FAILED\n" : "all passed\n", g_failed);
   return g_failed ? 1 : 0;
