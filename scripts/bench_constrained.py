@@ -1,0 +1,25 @@
+"""The reference's own benchmark shape (bench/gar-riccati.cpp: nx=36, nu=12, nc=32 on every knot,
+N = 2^e) on the generic kernels: batched sweeps/s (secondary figure; BASELINE.json's metric is the
+unconstrained north star)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aligator_amd import synth
+from aligator_amd.gar import BatchedRiccatiSolver, lqrComputeKktError
+
+nx, nu, nc, N, mueq = 36, 12, 32, int(os.environ.get("HORIZON", "256")), 1e-11
+probs = [synth.generate_lq_problem(100 + i, np.zeros(nx), N, nx, nu, nc=nc, mode="W") for i in range(2)]
+dims = [k.dims for k in probs[0].stages]
+for B in (64, 256, 1024):
+    s = BatchedRiccatiSolver(dims, nx, batch=B)
+    packed = np.concatenate([s.pack(p) for p in probs])
+    for b0 in range(0, B, 2):
+        s.upload_packed(packed, b0, 2)
+    s.backward(mueq); s.forward(); s.sync()
+    kkt = max(lqrComputeKktError(probs[1], *s.solution(B - 1), mueq=mueq))
+    t0 = time.perf_counter(); R = 3
+    for _ in range(R):
+        s.backward_async(mueq); s.forward_async()
+    s.sync()
+    dt = (time.perf_counter() - t0) / R
+    print(f"nc={nc} N={N} batch={B:5d} {s.kernel_name:10s} {dt*1e3:9.2f} ms/step {B/dt:9.0f} sweeps/s  kkt {kkt:.1e}", flush=True)
