@@ -34,6 +34,10 @@ for N, legs_list in cases:
             s.backward_async(mueq); s.forward_async()
         s.sync()
         dt = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):   # one sweep at a time: launch + sync latency included
+            s.backward_async(mueq); s.forward_async(); s.sync()
+        dts = (time.perf_counter() - t0) / reps
         k = np.zeros(3)
         try:
             s._check(s._L.gar_hip_set_timing(s.handle, 1))
@@ -50,5 +54,5 @@ for N, legs_list in cases:
             o2 = (C.c_double * 2)()
             s._check(s._L.gar_hip_condensed_info(s.handle, 0, o2))
             inf = f"resid {o2[0]:.1e} after {int(o2[1])} refinement steps"
-        print(f"N={N:5d} batch={batch} legs={legs:3d} {s.kernel_name:16s} sweep {dt*1e3:8.3f} ms | "
+        print(f"N={N:5d} batch={batch} legs={legs:3d} {s.kernel_name:16s} sweep {dt*1e3:8.3f} ms (synced each: {dts*1e3:6.3f}) | "
               f"bwd {k[0]:7.3f} cond/init {k[1]:7.3f} fwd {k[2]:7.3f} ms | rel.diff vs serial {err/sc:.1e} | {inf}", flush=True)
