@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI, on a real MI355X) against the CPU
 oracle, at the reference's own test sizes, plus size-independent properties at
 BASELINE.json's full sizes.  Run with ``pytest -m gpu``."""
+import os
 import numpy as np
 import pytest
 
@@ -264,3 +265,47 @@ def test_wave_family_bunch_kaufman_fallback_and_failure(monkeypatch):
         k.B[...] = 0.0
     with pytest.raises(RuntimeError, match="LDL"):
         ProximalRiccatiSolver(bad).backward(1e-10)
+
+
+def _bench_line(cmd):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable] + cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout            # ONE JSON line on rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_gpu():
+    """bench.py's JSON line: the driver's contract fields, the roofline and cpu_baseline objects."""
+    d = _bench_line(["bench.py", "--batch", "128", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "sweeps/s"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["scaling"] == "weak"
+    assert "workload" in d["config"] and d["value"] > 0
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert d["parity"]["max_rel_err_vs_oracle"] < 1e-9 and d["parity"]["failed_factorisations"] == 0
+    assert d["parallel_in_time"]["max_rel_diff_vs_serial"] < 1e-9
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 launch line of the driver (torch.distributed.run, one rank per GPU) with two ranks
+    sharing this box's only GPU (gloo barrier): whole-job value = all ranks' sweeps / max time."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                     "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                     "--steps", "2", "--warmup", "1", "--batch", "128", "--backend", "gloo", "--same-device"])
+    assert d["n_gpus"] == 2 and "cpu_baseline" not in d and "parallel_in_time" not in d
+    assert abs(d["value"] - 2 * 128 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
