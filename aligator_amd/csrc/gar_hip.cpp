@@ -355,6 +355,18 @@ void select_leg_kernel(gar_hip_solver *s) {
   else if (nx == 8 && nu == 4) bind_leg<8, 4>(s);
 }
 
+// uniform problems with NC constraints on every knot: the one-wave-per-problem kernels with the
+// reduced KKT system factorised by the wave-scope Bunch-Kaufman (gar_wave.hpp, NC > 0)
+template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
+  s->wave_kernel = gar::gar_backward_wave<NX, NU, NC>;
+  s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU, NC>;
+  const int with_init = gar::WaveCfg<NX, NU, NC>::total_with_init(s->nc0);
+  s->wave_fused_init = (size_t)with_init * sizeof(double) <= 64 * 1024 && s->nth0 == 0;
+  s->wave_lds_doubles = s->wave_fused_init ? with_init : gar::WaveCfg<NX, NU, NC>::total;
+  s->waves_per_block = 1;
+  s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + "," + std::to_string(NC) + ">";
+}
+
 void select_kernel(gar_hip_solver *s) {
   s->leg_bwd_kernel = nullptr;
   s->leg_tuple_kernel = nullptr;
@@ -382,18 +394,25 @@ void select_kernel(gar_hip_solver *s) {
   if (N < 1)
     return;
   const gar_stage_meta &m0 = s->meta[0];
-  if (m0.nc != 0 || m0.nth != 0 || m0.nx2 != m0.nx)
+  if (m0.nth != 0 || m0.nx2 != m0.nx)
     return;
   for (int t = 1; t < N; ++t) {
     const gar_stage_meta &m = s->meta[t];
-    if (m.nx != m0.nx || m.nu != m0.nu || m.nc != 0 || m.nth != 0 || m.nx2 != m0.nx ||
+    if (m.nx != m0.nx || m.nu != m0.nu || m.nc != m0.nc || m.nth != 0 || m.nx2 != m0.nx ||
         m.in_off - s->meta[t - 1].in_off != s->meta[1 < N ? 1 : 0].in_off - m0.in_off)
       return;
   }
   const gar_stage_meta &mt = s->meta[N];
-  if (mt.nx != m0.nx || mt.nu != 0 || mt.nc != 0 || mt.nth != 0)
+  if (mt.nx != m0.nx || mt.nu != 0 || mt.nc != m0.nc || mt.nth != 0)
     return;
   const int nx = m0.nx, nu = m0.nu;
+  if (m0.nc != 0) { // every knot constrained (the reference's bench/gar-riccati.cpp shape)
+    const int nc = m0.nc;
+    if (nx == 36 && nu == 12 && nc == 32) bind_cstr<36, 12, 32>(s);
+    else if (nx == 16 && nu == 8 && nc == 8) bind_cstr<16, 8, 8>(s);
+    else if (nx == 8 && nu == 4 && nc == 4) bind_cstr<8, 4, 4>(s);
+    return;
+  }
   if (nx == 36 && nu == 12) bind_mfma<36, 12>(s);
   else if (nx == 32 && nu == 12) bind_mfma<32, 12>(s);
   else if (nx == 16 && nu == 8) bind_mfma<16, 8>(s);
@@ -512,7 +531,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     return GAR_HIP_OK;
   }
   gar::GenericParams P = make_params(s, mueq);
-  if (s->mfma_kernel) {
+  if (s->mfma_kernel || s->wave_kernel) {
     gar::MfmaParams M{};
     M.prob = s->d_prob;
     M.fac = s->d_fac;
@@ -533,6 +552,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.G0_off = s->G0_off;
     M.g0_off = s->g0_off;
     M.nc0 = s->nc0;
+    M.mueq = mueq;
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->wave_kernel) {
@@ -596,6 +616,7 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
     F.nc0 = s->nc0;
     F.sol_u = (int)s->sol_u;
     F.sol_l = (int)s->sol_l;
+    F.sol_v = (int)s->sol_v;
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[3], s->stream));
     hipLaunchKernelGGL(s->mfma_fwd_kernel, dim3((unsigned)s->batch), dim3(64), 0, s->stream, F);
@@ -1180,7 +1201,7 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
   int rc = d2h(s, ff, rec + o.ff, nr);
   std::vector<double> tmp;
   // the specialised kernel families keep fb (and fth) in the fbT2 device order
-  const bool t2 = (s->mfma_kernel || s->leg_bwd_kernel) && t < s->horizon;
+  const bool t2 = (s->mfma_kernel || s->wave_kernel || s->leg_bwd_kernel) && t < s->horizon;
   const bool fbt2 = t2 && fb;
   const bool ftht2 = t2 && fth && m.nth > 0;
   std::vector<double> tmpth;
@@ -1338,7 +1359,7 @@ int gar_hip_set_timing(gar_hip_solver *s, int enable) {
 int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]) {
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
-  if (!s->timing || !(s->mfma_kernel || s->leg_bwd_kernel))
+  if (!s->timing || !(s->mfma_kernel || s->wave_kernel || s->leg_bwd_kernel))
     return fail(GAR_HIP_ERR_UNSUPPORTED, "per-kernel timing is recorded for the specialised "
                                          "kernel family after gar_hip_set_timing(s, 1)");
   HIP_TRY(hipStreamSynchronize(s->stream));

@@ -41,12 +41,17 @@ struct MfmaParams {
   double *init;
   long long init_stride, G0_off, g0_off;
   int nc0;
+  double mueq; // constrained stages: the proximal weight of [Rhat D^T; D -mu I]
 };
 
-template <int NX, int NU> struct MfmaCfg {
-  static_assert(NX % 4 == 0 && NU % 4 == 0, "NX, NU must be multiples of 4");
+// NC > 0: every knot carries NC equality constraints C x + D u + d = mu v (the one-wave-per-problem
+// backward sweep and the forward sweep; the 4-wave backward kernel is unconstrained only)
+template <int NX, int NU, int NC = 0> struct MfmaCfg {
+  static_assert(NX % 4 == 0 && NU % 4 == 0 && NC % 4 == 0, "NX, NU, NC must be multiples of 4");
   static_assert(NU >= 4 && NU <= 16 && NX >= NU, "4 <= NU <= 16 <= NX");
   static constexpr int NW = NX + NU;
+  static constexpr int NK = NU + NC; // rows of the reduced KKT system [Rhat D^T; D -mu I]
+  static constexpr int NR = NK + NX; // rows of ff / fb: [kff; zff; yff], [K; Z; Aff]
   static constexpr int TX = (NX + 15) / 16; // tiles over the state index
   static constexpr int TW = (NW + 15) / 16; // tiles over [x; u]
   static constexpr int KS = NX / 4;         // k-steps over the next-state index
@@ -77,16 +82,19 @@ template <int NX, int NU> struct MfmaCfg {
   // record offsets (uniform stage / terminal knot)
   static constexpr int kQ = 0, kS = NX * NX, kR = kS + NX * NU, kq = kR + NU * NU, kr = kq + NX,
                        kA = kr + NU, kB = kA + NX * NX, kf = kB + NX * NU;
+  static constexpr int kC = kf + NX, kD = kC + NC * NX, kd = kD + NC * NU; // C, D, d follow f
   static constexpr int tQ = 0, tq = NX * NX; // terminal: Q, q, A, f (nu = 0)
-  static constexpr int fFF = 0, fFB = NW, fVxx = fFB + NW * NX, fvx = fVxx + NX * NX;
-  // Device layout of fb = [K; Aff] in this kernel family ("fbT2"): element (r, j),
-  // r in [0, NW), j in [0, NX), lives at (j/2)*(2 NW) + 2 r + (j & 1): the forward
+  static constexpr int tC = tq + NX + NX * NX + NX, td = tC + NC * NX; // ... then C, d
+  static constexpr int fFF = 0, fFB = NR, fVxx = fFB + NR * NX, fvx = fVxx + NX * NX;
+  // Device layout of fb = [K; Z; Aff] in this kernel family ("fbT2"): element (r, j),
+  // r in [0, NR), j in [0, NX), lives at (j/2)*(2 NR) + 2 r + (j & 1): the forward
   // sweep reads 16 B per lane with lane = row r, consecutive lanes consecutive
   // addresses.  gar_hip_get_gains converts back to StageFactor's row-major fb.
   __host__ __device__ static constexpr int fbT2(int r, int j) {
-    return (j >> 1) * (2 * NW) + 2 * r + (j & 1);
+    return (j >> 1) * (2 * NR) + 2 * r + (j & 1);
   }
-  static constexpr int tVxx = NX + NX * NX, tvx = tVxx + NX * NX; // terminal factor record
+  // terminal factor record: ff (NC + NX), fb ((NC + NX) x NX, ROW-major: the generic layout), Vxx, vx
+  static constexpr int tVxx = (NC + NX) + (NC + NX) * NX, tvx = tVxx + NX * NX;
 };
 
 __device__ __forceinline__ double lane_bcast(double v, int src /*wave-uniform*/) {
@@ -613,22 +621,26 @@ struct MfmaFwdParams {
   long long fac_rec, fac_offN;
   int horizon, nc0;
   int sol_u, sol_l; // base offsets of us / lbdas inside a solution record
+  int sol_v;        // ... and of vs (constrained stages)
 };
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// one stage's gains in registers: [K; Aff] row r (fbT2: 16 B per lane), Vxx' row iv, ff, vx'
-template <int NX> struct FwdStage {
+// one stage's gains in registers: [K; Aff] row r (fbT2: 16 B per lane), Vxx' row iv, ff, vx';
+// constrained stages: row NU + lane of [K; Z; Aff] (a Z row) in a second slot
+template <int NX, int NC = 0> struct FwdStage {
   double2_t g[NX / 2];
+  double2_t gz[NC > 0 ? NX / 2 : 1];
   double vrow[NX];
-  double ff, vxn;
+  double ff, vxn, ffz;
 };
 
-template <int NX, int NU>
+// r: row of [K; Z; Aff] this lane owns in the first slot (a control row or a next-state row)
+template <int NX, int NU, int NC = 0>
 __device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *fac, int t, int r,
-                                         int iv, FwdStage<NX> &S) {
-  using C = MfmaCfg<NX, NU>;
-  constexpr int NW = C::NW;
+                                         int iv, int lane, FwdStage<NX, NC> &S) {
+  using C = MfmaCfg<NX, NU, NC>;
+  constexpr int NW = C::NR;
   const int N = P.horizon;
   const int tc = t < N ? t : N - 1; // past the end: harmless re-read of the last stage
   const double *rec = fac + (long long)tc * P.fac_rec;
@@ -637,6 +649,13 @@ __device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *f
 #pragma unroll
   for (int m = 0; m < NX / 2; ++m)
     S.g[m] = *reinterpret_cast<const double2_t *>(rec + C::fFB + m * 2 * NW + 2 * r);
+  if (NC > 0) {
+    const int rz = NU + (lane < NC ? lane : NC - 1);
+#pragma unroll
+    for (int m = 0; m < NX / 2; ++m)
+      S.gz[m] = *reinterpret_cast<const double2_t *>(rec + C::fFB + m * 2 * NW + 2 * rz);
+    S.ffz = rec[C::fFF + rz];
+  }
 #pragma unroll
   for (int j = 0; j < NX; ++j)
     S.vrow[j] = recn[oVn + j * NX + iv]; // Vxx' symmetric: column j, row iv
@@ -644,10 +663,10 @@ __device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *f
   S.vxn = recn[ovn + iv];
 }
 
-template <int NX, int NU>
+template <int NX, int NU, int NC = 0>
 __device__ __forceinline__ double fwd_step(const MfmaFwdParams &P, double *sol, int t, int lane,
-                                           double xs, const FwdStage<NX> &S) {
-  using C = MfmaCfg<NX, NU>;
+                                           double xs, const FwdStage<NX, NC> &S) {
+  using C = MfmaCfg<NX, NU, NC>;
   constexpr int NW = C::NW;
   // u = kff + K x ; x' = yff + Aff x   (:334-336, :360-361); two accumulators
   double acc = S.ff, acc1 = 0.0;
@@ -661,6 +680,16 @@ __device__ __forceinline__ double fwd_step(const MfmaFwdParams &P, double *sol, 
     sol[P.sol_u + t * NU + lane] = acc;
   else if (lane < NW)
     sol[(t + 1) * NX + (lane - NU)] = acc;
+  if (NC > 0) { // v = zff + Z x  (:338-340), off the state recursion's critical path
+    double az = S.ffz, az1 = 0.0;
+#pragma unroll
+    for (int m = 0; m < NX / 2; ++m) {
+      az = __builtin_fma(S.gz[m].x, lane_bcast(xs, NU + 2 * m), az);
+      az1 = __builtin_fma(S.gz[m].y, lane_bcast(xs, NU + 2 * m + 1), az1);
+    }
+    if (lane < NC)
+      sol[P.sol_v + t * NC + lane] = az + az1;
+  }
   // lbd' = vx' + Vxx' x'  (:369-371); x'_j sits in lane NU + j
   double lam = S.vxn, lam1 = 0.0;
 #pragma unroll
@@ -677,9 +706,9 @@ __device__ __forceinline__ double fwd_step(const MfmaFwdParams &P, double *sol, 
 // The gains of stage t+1 are requested BEFORE stage t is evaluated (two register sets, the loop
 // body instantiated twice): with one wave per SIMD -- all a 1 024-problem batch gives a 1 024-SIMD
 // chip -- nothing else would cover the HBM latency of the next 25 KB.
-template <int NX, int NU>
+template <int NX, int NU, int NC = 0>
 __global__ void __launch_bounds__(64) gar_forward_mfma(MfmaFwdParams P) {
-  using C = MfmaCfg<NX, NU>;
+  using C = MfmaCfg<NX, NU, NC>;
   constexpr int NW = C::NW;
   const int lane = (int)threadIdx.x;
   const int b = (int)blockIdx.x;
@@ -687,12 +716,13 @@ __global__ void __launch_bounds__(64) gar_forward_mfma(MfmaFwdParams P) {
   double *sol = P.sol + (long long)b * P.sol_stride;
   const double *io = P.init + (long long)b * P.init_stride;
   const int N = P.horizon;
-  const int r = lane < NW ? lane : NW - 1;  // row of [K; Aff]
+  // row of [K; Z; Aff] in the first slot: a control row or a next-state row (Z rows: second slot)
+  const int r = lane < NU ? lane : (lane < NW ? lane + NC : C::NR - 1);
   const int iv = lane < NX ? lane : NX - 1; // row of Vxx'
   // the state lives in lanes NU .. NW-1 (where x' = yff + Aff x is produced)
   const int ix = (lane >= NU && lane < NW) ? lane - NU : 0;
-  FwdStage<NX> SA, SB;
-  fwd_load<NX, NU>(P, fac, 0, r, iv, SA);
+  FwdStage<NX, NC> SA, SB;
+  fwd_load<NX, NU, NC>(P, fac, 0, r, iv, lane, SA);
   double xs = io[ix]; // x0 from the initial-stage solve (kkt0.ff)
   if (lane >= NU && lane < NW)
     sol[ix] = xs;
@@ -700,13 +730,23 @@ __global__ void __launch_bounds__(64) gar_forward_mfma(MfmaFwdParams P) {
     sol[P.sol_l + e] = io[NX + e]; // lbd0
   int t = 0;
   for (; t + 1 < N; t += 2) {
-    fwd_load<NX, NU>(P, fac, t + 1, r, iv, SB);
-    xs = fwd_step<NX, NU>(P, sol, t, lane, xs, SA);
-    fwd_load<NX, NU>(P, fac, t + 2, r, iv, SA);
-    xs = fwd_step<NX, NU>(P, sol, t + 1, lane, xs, SB);
+    fwd_load<NX, NU, NC>(P, fac, t + 1, r, iv, lane, SB);
+    xs = fwd_step<NX, NU, NC>(P, sol, t, lane, xs, SA);
+    fwd_load<NX, NU, NC>(P, fac, t + 2, r, iv, lane, SA);
+    xs = fwd_step<NX, NU, NC>(P, sol, t + 1, lane, xs, SB);
   }
   if (t < N)
-    xs = fwd_step<NX, NU>(P, sol, t, lane, xs, SA);
+    xs = fwd_step<NX, NU, NC>(P, sol, t, lane, xs, SA);
+  if (NC > 0) { // terminal knot: v_N = zff + Z x_N (its record keeps the generic row-major layout)
+    const double *recN = fac + P.fac_offN;
+    const int i = lane < NC ? lane : NC - 1;
+    double az = recN[i];
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      az = __builtin_fma(recN[(NC + NX) + i * NX + j], lane_bcast(xs, NU + j), az);
+    if (lane < NC)
+      sol[P.sol_v + N * NC + lane] = az;
+  }
 }
 
 } // namespace gar

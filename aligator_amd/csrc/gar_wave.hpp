@@ -41,9 +41,10 @@
 
 namespace gar {
 
-template <int NX, int NU> struct WaveCfg {
-  using M = MfmaCfg<NX, NU>;
+template <int NX, int NU, int NC = 0> struct WaveCfg {
+  using M = MfmaCfg<NX, NU, NC>;
   static constexpr int NW = NX + NU, TX = M::TX, TW = M::TW, KS = M::KS, KU = M::KU;
+  static constexpr int NK = M::NK, NR = M::NR, KC = NC / 4; // KKT rows ; fb rows ; k-steps over constraints
   static constexpr int KSF = KS / 4, KST = KS % 4; // full double4 groups of k-steps, tail steps
   // NX = 16 (TX-1) + 4: the last row tile of P, Aff and Vxx holds FOUR valid rows.  Those tiles
   // run on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks, 16 cycles) instead of
@@ -64,16 +65,17 @@ template <int NX, int NU> struct WaveCfg {
   __host__ __device__ static constexpr int shReg(int s) { return ((NX + 4 * s) & 15) >> 2; }
   // LDS carve (doubles), one slice per wave
   static constexpr int oV = 0;
-  static constexpr int oG = oV + NX * PK + 16;    // [rhat | Shat^T], NU x PG
-  static constexpr int oG2 = oG;                  // [kff | K]: the solve runs in place
-  static constexpr int oM = oG + NU * PG + 16;    // Rhat, column-major lower
-  static constexpr int oVn = oM + NU * NU;        // vx' (NX)
+  static constexpr int oG = oV + NX * PK + 16;    // [rhat | Shat^T ; d | C], NK x PG
+  static constexpr int oG2 = oG;                  // [kff | K ; zff | Z]: the solve runs in place
+  static constexpr int oM = oG + NK * PG + 16;    // Rhat (NC > 0: [Rhat D^T; D -mu I]), column-major lower
+  static constexpr int oVn = oM + NK * NK;        // vx' (NX)
   static constexpr int oVp = oVn + NX;            // vplus (NX)
   static constexpr int oLr = (oVp + NX + 1) & ~1; // L of Rhat = L D L^T, row-major (forward solve)
   static constexpr int oLc = oLr;                 // (the transposed solve reads L strided)
   static constexpr int oDi = oLr + NU * NU;       // -1/d_k
-  static constexpr int oBk = (oDi + NU + 1) & ~1; // Bunch-Kaufman fallback: sub(16) | piv, ctrl
-  static constexpr int oDump = (oBk + 32 + 1) & ~1; // 2 doubles: target of masked-out LDS writes
+  static constexpr int oBk = (oDi + NU + 1) & ~1; // Bunch-Kaufman: sub(BKS) | piv, ctrl (BKS ints each)
+  static constexpr int BKS = NC > 0 ? ((NK + 15) & ~15) : 16;
+  static constexpr int oDump = (oBk + 2 * BKS + 1) & ~1; // 2 doubles: target of masked-out LDS writes
   static constexpr int oFlag = oDump + 2;           // MODE 3: verdict of the factorisation (as a double)
   static constexpr int total = oDump + 4;
   // fused initial stage (after the sweep): the packed lower triangle of kkt0 = [Vxx0 G0^T; G0 0]
@@ -136,8 +138,8 @@ template <int NX, int NU> struct WaveStage {
 // entirely inside its block shares ONE lane offset with the other interior tiles (the tile
 // origin is a compile-time constant that goes to the scalar base / the immediate); only a tile
 // that straddles a block boundary or overhangs the matrix needs its own (clamped) offsets.
-template <int NX, int NU> struct WaveLane {
-  using C = WaveCfg<NX, NU>;
+template <int NX, int NU, int NC = 0> struct WaveLane {
+  using C = WaveCfg<NX, NU, NC>;
   unsigned fo0, foX;             // F operand F[lk][li] ; overhanging last column tile
   // element (16ti+lk+4r, 16tj+li) of [Q S;S^T R] at its NATURAL position (no mirroring:
   // the strictly-upper part of a diagonal tile only feeds results that are never used)
@@ -146,15 +148,15 @@ template <int NX, int NU> struct WaveLane {
   unsigned bop0, bopX;           // B[li][lk] ; overhanging last row tile
   unsigned bop4;                 // B[NX-4+(lane&3)][lane>>4]: A operand of the 4x4x4 blocks
   unsigned fi, qri;
-  unsigned fbl;                  // fbT2 lane part: (li>>1)*2NW + 2lk + (li&1)
+  unsigned fbl;                  // fbT2 lane part: (li>>1)*2NR + 2lk + (li&1)
   __host__ __device__ static constexpr bool fo_in(int t) { return 16 * t + 15 < C::NW; }
   __host__ __device__ static constexpr bool x_in(int t) { return 16 * t + 15 < NX; }
 };
 
-template <int NX, int NU>
-__device__ __forceinline__ void wave_lane_init(WaveLane<NX, NU> &L, int lane) {
-  using C = WaveCfg<NX, NU>;
-  using M = MfmaCfg<NX, NU>;
+template <int NX, int NU, int NC>
+__device__ __forceinline__ void wave_lane_init(WaveLane<NX, NU, NC> &L, int lane) {
+  using C = WaveCfg<NX, NU, NC>;
+  using M = MfmaCfg<NX, NU, NC>;
   const int li = lane & 15, lk = lane >> 4;
   L.fo0 = 8u * (unsigned)(M::kA + li * NX + lk);
   {
@@ -182,15 +184,14 @@ __device__ __forceinline__ void wave_lane_init(WaveLane<NX, NU> &L, int lane) {
   }
   L.bop4 = 8u * (unsigned)(M::kB + (lane >> 4) * NX + NX - 4 + (lane & 3));
   const int ir = lane < NX ? lane : NX - 1, iw = lane < C::NW ? lane : C::NW - 1;
-  L.fbl = 8u * (unsigned)((li >> 1) * 2 * C::NW + 2 * lk + (li & 1));
+  L.fbl = 8u * (unsigned)((li >> 1) * 2 * C::NR + 2 * lk + (li & 1));
   L.fi = 8u * (unsigned)(M::kf + ir);
   L.qri = 8u * (unsigned)(M::kq + iw);
 }
 
 // part A of a knot: the F operands and the vectors (needed from the start of the stage)
-template <int NX, int NU>
-__device__ __forceinline__ void wave_load_a(const double *rec, const WaveLane<NX, NU> &L,
-                                            WaveStage<NX, NU> &S) {
+template <int NX, int NU, class LANE>
+__device__ __forceinline__ void wave_load_a(const double *rec, const LANE &L, WaveStage<NX, NU> &S) {
   using C = WaveCfg<NX, NU>;
 #pragma unroll
   for (int t = 0; t < C::TW; ++t)
@@ -207,9 +208,8 @@ __device__ __forceinline__ void wave_load_a(const double *rec, const WaveLane<NX
   S.qri = ldg_b(rec, 0, L.qri);
 }
 // part B: the Hessian tiles (first needed by H's accumulation) and B as the A operand of Aff
-template <int NX, int NU>
-__device__ __forceinline__ void wave_load_b(const double *rec, const WaveLane<NX, NU> &L,
-                                            WaveStage<NX, NU> &S) {
+template <int NX, int NU, class LANE>
+__device__ __forceinline__ void wave_load_b(const double *rec, const LANE &L, WaveStage<NX, NU> &S) {
   using C = WaveCfg<NX, NU>;
 #pragma unroll
   for (int ti = 0; ti < C::TW; ++ti)
@@ -466,13 +466,19 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
 //         layout of a parameterised stage, the per-stage LDS block selected by the stage parity
 //         PAR, [kff | K], Rhat, L, 1/d, the verdict and yff published for wave B, which does the
 //         parameter part (wave_param_stage) after the workgroup barrier that ends the publication.
-template <int NX, int NU, int MODE = 0, int PAR = 0>
+// NC > 0 (MODE 0 only): the constrained stage (:232-262, :272-276 with C, D, d): the reduced KKT
+//         system [Rhat D^T; D -mu I] [K; Z] = -[Shat^T; C] is assembled in LDS and factorised by the
+//         wave-scope Bunch-Kaufman (it is indefinite: there is no unpivoted fast path);
+//         Vxx += C^T Z, vx += C^T zff; ff = [kff; zff; yff], fb = [K; Z; Aff].
+template <int NX, int NU, int MODE = 0, int PAR = 0, int NC = 0>
 __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, const double *prob,
                                            double *fac, int t, int lane,
-                                           const WaveLane<NX, NU> &L, WaveStage<NX, NU> &S,
+                                           const WaveLane<NX, NU, NC> &L, WaveStage<NX, NU> &S,
                                            int &failed, const bool tracing) {
-  using C = WaveCfg<NX, NU>;
-  using M = MfmaCfg<NX, NU>;
+  static_assert(NC == 0 || MODE == 0, "constrained stages: plain recursion only");
+  using C = WaveCfg<NX, NU, NC>;
+  using M = MfmaCfg<NX, NU, NC>;
+  constexpr int NK = C::NK, NR = C::NR, KC = C::KC;
   constexpr int NW = C::NW, PK = C::PK, PG = C::PG, TX = C::TX, TW = C::TW, KS = C::KS,
                 KU = C::KU;
   const int li = lane & 15, lk = lane >> 4;
@@ -617,9 +623,29 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
           if (c < NX)
             G[(row - NX) * PG + 1 + c] = S.Hc[ti][tj][r];
           else if (c <= row)
-            Mm[(c - NX) * NU + (row - NX)] = S.Hc[ti][tj][r];
+            Mm[(c - NX) * NK + (row - NX)] = S.Hc[ti][tj][r];
         }
       }
+  if (NC > 0) {
+    // rows NU.. of G: [d | C]; the KKT matrix [Rhat D^T; D -mu I] (lower, column-major pitch NK):
+    // Rhat was placed above with pitch NU -- re-place it, add D and the -mu diagonal
+    const double *recC = rec;
+    for (int e = lane; e < NC * NX; e += 64) {
+      const int c = e / NC, i = e - c * NC;
+      G[(NU + i) * PG + 1 + c] = recC[M::kC + e];
+    }
+    if (lane < NC)
+      G[(NU + lane) * PG] = recC[M::kd + lane];
+    for (int e = lane; e < NC * NU; e += 64) { // D (NC x NU), column-major
+      const int j = e / NC, i = e - j * NC;
+      Mm[j * NK + NU + i] = recC[M::kD + e];
+    }
+    for (int e = lane; e < NC * NC; e += 64) { // -mu I (lower part; BunchKaufman reads Lower)
+      const int j = e / NC, i = e - j * NC;
+      if (i >= j)
+        Mm[(NU + j) * NK + NU + i] = (i == j) ? -P.mueq : 0.0;
+    }
+  }
   if (MODE == 1) { // Gt(u, c) = Ghat_u(u, c): the right-hand sides of Kth
 #pragma unroll
     for (int sp = 0; sp < KU; ++sp)
@@ -654,7 +680,19 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   }
   GAR_WMARK(4)
   // ---- factor Rhat (lane = row) under the Bunch-Kaufman rule; solve [kff | K] ---
-  {
+  if (NC > 0) {
+    // [kff K; zff Z] = -KKT^{-1} [rhat Shat^T; d C]  (:232-262): Bunch-Kaufman with interchanges and
+    // 2x2 pivots, exactly the reference's kktChol on the same matrix
+    for (int e = lane; e < NK * PG; e += 64)
+      G[e] = -G[e];
+    double *sub = sb + C::oBk;
+    int *piv = (int *)(sub + C::BKS);
+    const WG w1 = wave_self();
+    wave_sync();
+    failed |= wg_bk_factor(w1, NK, Mm, NK, sub, piv, piv + C::BKS);
+    wg_bk_solve(w1, NK, Mm, NK, sub, piv, G, PG, 1, NX + 1);
+    wave_sync();
+  } else {
     double a_row[NU], nd[NU];
     const int verdict = wave_ldl_fast<NU>(Mm, lane, a_row, nd);
     GAR_WMARK(5)
@@ -715,7 +753,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
     for (int s = 0; s < KU; ++s) {
       Kb[tj][s] = G[(4 * s + lk) * PG + 1 + cc];
       if (16 * tj + li < NX) // fbT2(4s+lk, 16tj+li) = 8tj*2NW + 8s + [(li>>1)*2NW + 2lk + (li&1)]
-        stg_b(out, M::fFB + 8 * tj * 2 * NW + 8 * s, L.fbl, Kb[tj][s]);
+        stg_b(out, M::fFB + 8 * tj * 2 * NR + 8 * s, L.fbl, Kb[tj][s]);
     }
   }
   double Kthb[TX][KU]; // PRM: Kth[4s'+lk][16tj+li], fth rows 0..NU-1 (same device order as fb)
@@ -761,11 +799,29 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       sy = (lk == ti) ? py[ti] : sy;
       sv = (lk == ti) ? pv[ti] : sv;
     }
-    const double yf = fi + sy, vxv = hq + sv;
+    double cz = 0.0; // NC > 0: (C^T zff)[lane]  (:275-276)
+    if (NC > 0) {
+      const int xc = lane < NX ? lane : NX - 1;
+      double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NC; i += 2) {
+        c0 = __builtin_fma(rec[M::kC + xc * NC + i], G[(NU + i) * PG], c0);
+        c1 = __builtin_fma(rec[M::kC + xc * NC + i + 1], G[(NU + i + 1) * PG], c1);
+      }
+      cz = c0 + c1;
+      if (lane < NC)
+        out[M::fFF + NU + lane] = G[(NU + lane) * PG]; // zff
+      // Z rows of fb (device order fbT2)
+      for (int e = lane; e < NC * NX; e += 64) {
+        const int j = e / NC, i = e - j * NC;
+        out[M::fFB + M::fbT2(NU + i, j)] = G[(NU + i) * PG + 1 + j];
+      }
+    }
+    const double yf = fi + sy, vxv = hq + sv + cz;
     if (lane < NU)
       out[M::fFF + lane] = G[lane * PG];
     if (lane < NX) {
-      out[M::fFF + NU + lane] = (MODE == 2) ? 0.0 : yf; // terminalSolve leaves yff untouched (zero)
+      out[M::fFF + NK + lane] = (MODE == 2) ? 0.0 : yf; // terminalSolve leaves yff untouched (zero)
       out[ovx + lane] = vxv;
       vn[lane] = vxv;
     }
@@ -851,7 +907,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
         if (16 * ti + 4 * r < NX) { // compile-time
           if (i < NX && j < NX) // fbT2(NU+i, j), i = 16ti+4r+lk
-            stg_b(out, M::fFB + 8 * tj * 2 * NW + 2 * (NU + 16 * ti + 4 * r), L.fbl,
+            stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NK + 16 * ti + 4 * r), L.fbl,
                   MODE == 2 ? 0.0 // terminalSolve leaves the Aff rows untouched (zero)
                             : (ti < C::KSF ? S.Fo[tj][ti][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r])));
         }
@@ -987,6 +1043,31 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         else
           S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], S.Hc[ti][tj], 0, 0, 0);
       }
+  if (NC > 0) { // Vxx += C^T Z (:272-274): A operand C^T from the knot record, B operand Z from G
+#pragma unroll
+    for (int sc = 0; sc < KC; ++sc) {
+      double Zb[TX], Cop[TX], Cop4 = 0.0;
+#pragma unroll
+      for (int tj = 0; tj < TX; ++tj) {
+        const int cc = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
+        Zb[tj] = G[(NU + 4 * sc + lk) * PG + 1 + cc];   // Z(4sc+lk, 16tj+li)
+        Cop[tj] = rec[M::kC + cc * NC + 4 * sc + lk];   // C(4sc+lk, 16tj+li) = C^T(16tj+li, 4sc+lk)
+      }
+      if (C::REM4)
+        Cop4 = rec[M::kC + (NX - 4 + i4) * NC + 4 * sc + k4];
+#pragma unroll
+      for (int tj = 0; tj < TX; ++tj)
+#pragma unroll
+        for (int ti = tj; ti < TX; ++ti) {
+          if (C::REM4 && ti == TX - 1)
+            acc4[tj] = __builtin_amdgcn_mfma_f64_4x4x4f64(Cop4, Zb[tj], acc4[tj], 0, 0, 0);
+          else if (ti >= shLo)
+            accS[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cop[ti], Zb[tj], accS[ti][tj], 0, 0, 0);
+          else
+            S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cop[ti], Zb[tj], S.Hc[ti][tj], 0, 0, 0);
+        }
+    }
+  }
   // branch-free: a lane whose element is outside the lower triangle writes to a dump slot
   // (its address is a loop-invariant select), so the whole phase is one scheduling region
 #pragma unroll
@@ -1035,10 +1116,10 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
 #undef GAR_WMARK
 }
 
-template <int NX, int NU>
+template <int NX, int NU, int NC = 0>
 __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int batch) {
-  using C = WaveCfg<NX, NU>;
-  using M = MfmaCfg<NX, NU>;
+  using C = WaveCfg<NX, NU, NC>;
+  using M = MfmaCfg<NX, NU, NC>;
   constexpr int PK = C::PK;
   const int lane = (int)threadIdx.x & 63;
   // wave-uniform by construction; readfirstlane tells the compiler, so that every global
@@ -1061,32 +1142,45 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   const bool tracing = false;
 #endif
 
-  WaveLane<NX, NU> L;
+  WaveLane<NX, NU, NC> L;
   wave_lane_init<NX, NU>(L, lane);
   WaveStage<NX, NU> S;
   wave_load_a<NX, NU>(prob + P.in_off0 + (long long)(N - 1) * P.in_rec, L, S);
   wave_load_b<NX, NU>(prob + P.in_off0 + (long long)(N - 1) * P.in_rec, L, S);
 
-  // ---- terminal knot (terminalSolve, nu = 0, nc = 0, :175-178): Vxx = Q, vx = q
+  // ---- terminal knot (terminalSolve, nu = 0, :146-149, :175-178): Z = C/mu, zff = d/mu,
+  // Vxx = Q + C^T Z, vx = q + C^T zff (nc = 0: Vxx = Q, vx = q)
   {
     const double *rec = prob + P.in_offN;
     double *out = fac + P.fac_offN;
     for (int e = lane; e < NX * NX; e += 64) {
       const int j = e / NX, i = e - j * NX; // column-major element (i, j)
-      const double v = (i >= j) ? rec[M::tQ + e] : rec[M::tQ + i * NX + j];
+      double v = (i >= j) ? rec[M::tQ + e] : rec[M::tQ + i * NX + j];
+      for (int k = 0; k < NC; ++k) // (C^T Z)(i, j), Z = C / mu
+        v = __builtin_fma(rec[M::tC + i * NC + k], rec[M::tC + j * NC + k] / P.mueq, v);
       V[i * PK + j] = v; // symmetrised from lower, as the consumer stage does (:216)
       out[M::tVxx + e] = v;
     }
     if (lane < NX) {
-      const double v = rec[M::tq + lane];
+      double v = rec[M::tq + lane];
+      for (int k = 0; k < NC; ++k)
+        v = __builtin_fma(rec[M::tC + lane * NC + k], rec[M::td + k] / P.mueq, v);
       vn[lane] = v;
       out[M::tvx + lane] = v;
+    }
+    if (NC > 0) { // ff = [zff; 0], fb = [Z; 0] (row-major: the terminal record keeps the generic layout)
+      for (int e = lane; e < NC + NX; e += 64)
+        out[e] = e < NC ? rec[M::td + e] / P.mueq : 0.0;
+      for (int e = lane; e < (NC + NX) * NX; e += 64) {
+        const int i = e / NX, j = e - i * NX;
+        out[(NC + NX) + e] = i < NC ? rec[M::tC + j * NC + i] / P.mueq : 0.0;
+      }
     }
   }
   wave_sync();
   int failed = 0;
   for (int t = N - 1; t >= 0; --t)
-    wave_stage<NX, NU>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+    wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
   // ---- initial stage (proximal-riccati.hxx:42-60), fused: kkt0 = [Vxx0 G0^T; G0 0] is
   // Bunch-Kaufman-factorised by this wave right away (packed lower triangle in LDS, read from
   // the V and vx this wave still holds) and solved for kkt0.ff = -kkt0^{-1} [vx0; g0]
