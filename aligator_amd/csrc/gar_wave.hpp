@@ -68,7 +68,8 @@ template <int NX, int NU, int NC = 0> struct WaveCfg {
   static constexpr int oG = oV + NX * PK + 16;    // [rhat | Shat^T ; d | C], NK x PG
   static constexpr int oG2 = oG;                  // [kff | K ; zff | Z]: the solve runs in place
   static constexpr int oM = oG + NK * PG + 16;    // Rhat (NC > 0: [Rhat D^T; D -mu I]), column-major lower
-  static constexpr int oVn = oM + NK * NK;        // vx' (NX)
+  // (NC > 0: the KKT matrix is kept as a packed lower triangle, GAR_PACKED_LOWER)
+  static constexpr int oVn = oM + (NC > 0 ? NK * (NK + 1) / 2 : NK * NK); // vx' (NX)
   static constexpr int oVp = oVn + NX;            // vplus (NX)
   static constexpr int oLr = (oVp + NX + 1) & ~1; // L of Rhat = L D L^T, row-major (forward solve)
   static constexpr int oLc = oLr;                 // (the transposed solve reads L strided)
@@ -451,6 +452,22 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
   return failed;
 }
 
+// Constrained stages: Bunch-Kaufman factorisation of the reduced KKT matrix (packed lower triangle in
+// LDS) and the solve of its right-hand sides, out of line (the stage keeps ~400 registers live).
+// (A fully unrolled variant with the column in registers was 1.8x SLOWER than the LDS-resident
+// column loop of wg_bk_solve: 1 900 hoisted LDS reads spill.)
+template <int NK, int BKS, int PG>
+__device__ __attribute__((noinline)) int wave_kkt_factor_solve(double *Mm, double *sub, double *G,
+                                                               int ncols, int lane) {
+  int *piv = (int *)(sub + BKS);
+  const WG w1 = wave_self();
+  const int failed = wg_bk_factor<GAR_PACKED_LOWER>(w1, NK, Mm, NK, sub, piv, piv + BKS);
+  wg_bk_solve<GAR_PACKED_LOWER>(w1, NK, Mm, NK, sub, piv, G, PG, 1, ncols);
+  wave_sync();
+  (void)lane;
+  return failed;
+}
+
 // One stage t of the backward sweep, entirely inside one wave.  On entry S holds knot t
 // (F operands, vectors, Hessian tiles); on exit it holds knot t-1.
 // MODE 0: the plain stage (stageKernelSolve, :209-277).
@@ -623,27 +640,49 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
           if (c < NX)
             G[(row - NX) * PG + 1 + c] = S.Hc[ti][tj][r];
           else if (c <= row)
-            Mm[(c - NX) * NK + (row - NX)] = S.Hc[ti][tj][r];
+            Mm[NC > 0 ? bk_idx<GAR_PACKED_LOWER>(row - NX, c - NX, NK) : (c - NX) * NK + (row - NX)] =
+                S.Hc[ti][tj][r];
         }
       }
   if (NC > 0) {
     // rows NU.. of G: [d | C]; the KKT matrix [Rhat D^T; D -mu I] (lower, column-major pitch NK):
     // Rhat was placed above with pitch NU -- re-place it, add D and the -mu diagonal
-    const double *recC = rec;
-    for (int e = lane; e < NC * NX; e += 64) {
-      const int c = e / NC, i = e - c * NC;
-      G[(NU + i) * PG + 1 + c] = recC[M::kC + e];
+    // (all the loads first, then the LDS writes: the compiler cannot prove that the two do not
+    // alias and would otherwise serialise one round trip per element)
+    constexpr int NCC = NC > 0 ? (NC * NX + 63) / 64 : 1, NCD = NC > 0 ? (NC * NU + 63) / 64 : 1;
+    constexpr int NC1 = NC > 0 ? NC : 1; // (this block is compiled, never run, for NC = 0)
+    double tc[NCC], td[NCD];
+#pragma unroll
+    for (int q = 0; q < NCC; ++q) {
+      const int e = 64 * q + lane;
+      tc[q] = rec[M::kC + ((64 * q + 63 < NC * NX || e < NC * NX) ? e : NC * NX - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < NCD; ++q) {
+      const int e = 64 * q + lane;
+      td[q] = rec[M::kD + ((64 * q + 63 < NC * NU || e < NC * NU) ? e : NC * NU - 1)];
+    }
+    const double dv = rec[M::kd + (lane < NC ? lane : NC - 1)];
+#pragma unroll
+    for (int q = 0; q < NCC; ++q) { // C (NC x NX), column-major
+      const int e = 64 * q + lane;
+      const int c = e / NC1, i = e - c * NC1;
+      if (64 * q + 63 < NC * NX || e < NC * NX)
+        G[(NU + i) * PG + 1 + c] = tc[q];
     }
     if (lane < NC)
-      G[(NU + lane) * PG] = recC[M::kd + lane];
-    for (int e = lane; e < NC * NU; e += 64) { // D (NC x NU), column-major
-      const int j = e / NC, i = e - j * NC;
-      Mm[j * NK + NU + i] = recC[M::kD + e];
+      G[(NU + lane) * PG] = dv;
+#pragma unroll
+    for (int q = 0; q < NCD; ++q) { // D (NC x NU), column-major
+      const int e = 64 * q + lane;
+      const int j = e / NC1, i = e - j * NC1;
+      if (64 * q + 63 < NC * NU || e < NC * NU)
+        Mm[bk_idx<GAR_PACKED_LOWER>(NU + i, j, NK)] = td[q];
     }
     for (int e = lane; e < NC * NC; e += 64) { // -mu I (lower part; BunchKaufman reads Lower)
-      const int j = e / NC, i = e - j * NC;
+      const int j = e / NC1, i = e - j * NC1;
       if (i >= j)
-        Mm[(NU + j) * NK + NU + i] = (i == j) ? -P.mueq : 0.0;
+        Mm[bk_idx<GAR_PACKED_LOWER>(NU + i, NU + j, NK)] = (i == j) ? -P.mueq : 0.0;
     }
   }
   if (MODE == 1) { // Gt(u, c) = Ghat_u(u, c): the right-hand sides of Kth
@@ -685,13 +724,8 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
     // 2x2 pivots, exactly the reference's kktChol on the same matrix
     for (int e = lane; e < NK * PG; e += 64)
       G[e] = -G[e];
-    double *sub = sb + C::oBk;
-    int *piv = (int *)(sub + C::BKS);
-    const WG w1 = wave_self();
     wave_sync();
-    failed |= wg_bk_factor(w1, NK, Mm, NK, sub, piv, piv + C::BKS);
-    wg_bk_solve(w1, NK, Mm, NK, sub, piv, G, PG, 1, NX + 1);
-    wave_sync();
+    failed |= wave_kkt_factor_solve<NK, C::BKS, PG>(Mm, sb + C::oBk, G, NX + 1, lane);
   } else {
     double a_row[NU], nd[NU];
     const int verdict = wave_ldl_fast<NU>(Mm, lane, a_row, nd);

@@ -347,3 +347,17 @@ def test_batch_of_identical_and_distinct_problems_agree_with_singles():
         s1.forward()
         for A, B in zip(sb.solution(b), s1.solution(0)):
             assert pc.maxdiff(A, B) == 0.0
+
+
+# ---- constrained stages on the wave kernels (csrc/gar_wave.hpp, NC > 0) ---------------------------
+@pytest.mark.parametrize("nx,nu,nc,horz,mu", [(8, 4, 4, 7, 1e-6), (16, 8, 8, 4, 1e-9), (8, 4, 4, 1, 1e-3)])
+def test_constrained_wave_kernels(nx, nu, nc, horz, mu):
+    """Uniform problems with nc constraints on every knot (the reference's bench/gar-riccati.cpp
+    structure): reduced KKT system by wave-scope Bunch-Kaufman, Vxx += C^T Z, vs in the forward
+    sweep.  Factors (ff = [kff; zff; yff], fb = [K; Z; Aff]), value functions, kkt0 and the
+    solution against the oracle."""
+    rng = np.random.default_rng(300 + nx + nc)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nc=nc, mode="W")
+    solver, sol, ref = pc.check_serial(prob, mu, 1e-8, EMU)
+    assert solver.kernel_name == f"wave<{nx},{nu},{nc}>"
+    assert len(sol[2]) == horz + 1 and sol[2][horz].size == nc   # vs on every knot, terminal included

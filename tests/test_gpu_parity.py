@@ -45,7 +45,29 @@ def test_constrained_bench_shape():
     nx, nu, nc = 36, 12, 32
     rng = np.random.default_rng(5)
     prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 16, nx, nu, nc=nc, mode="W")
-    pc.check_serial(prob, 1e-11, 1e-7, factors=False)
+    solver, _, _ = pc.check_serial(prob, 1e-11, 1e-7, factors=False)
+    assert solver.kernel_name == "wave<36,12,32>"     # the constrained wave kernels, not the generic ones
+
+
+@pytest.mark.parametrize("nx,nu,nc,horz,mu", [(36, 12, 32, 40, 1e-6), (16, 8, 8, 30, 1e-8), (8, 4, 4, 25, 1e-5)])
+def test_constrained_wave_kernels_factors(monkeypatch, nx, nu, nc, horz, mu):
+    """Constrained stages on the wave kernels: every factor block (ff = [kff; zff; yff],
+    fb = [K; Z; Aff], Vxx, vx), kkt0 and the solution against the oracle -- and against the generic
+    kernels on the same problem."""
+    from aligator_amd.gar import ProximalRiccatiSolver, lqrInitializeSolution
+    rng = np.random.default_rng(600 + nx)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nc=nc, mode="W")
+    solver, sol, _ = pc.check_serial(prob, mu, 1e-8)
+    assert solver.kernel_name == f"wave<{nx},{nu},{nc}>"
+    monkeypatch.setenv("GAR_HIP_FORCE_GENERIC", "1")
+    g = ProximalRiccatiSolver(prob)
+    assert g.kernel_name == "generic"
+    g.backward(mu)
+    sg = lqrInitializeSolution(prob)
+    g.forward(*sg)
+    sc = pc.scale_of(sg)
+    for A, B in zip(sol, sg):
+        assert pc.maxdiff(A, B) <= 1e-9 * sc
 
 
 def test_constrained_small_with_2x2_pivots():
