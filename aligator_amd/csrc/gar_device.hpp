@@ -729,6 +729,162 @@ __device__ inline void wg_bk_solve_block(const WG &w, int n, const double *a, in
 #undef GXC
 }
 
+// Bunch-Kaufman solve of NCOLS (<= 48) right-hand sides by ONE wave with the triangular solves as
+// BLOCKED MFMA updates: X (N x NCOLS, row i at X[i*xrs + c]) is held in accumulator layout (tile
+// (ti, tj) register r = X(16ti + (lane>>4) + 4r, 16tj + (lane&15))); a k-step is a block of four
+// rows, which are ONE register across the four lane groups: its 4x4 triangular part is solved
+// with three shuffles + FMAs, and the rows beyond it are updated by v_mfma_f64_16x16x4 with the
+// block's register as B operand (D -> B identity) and L read from LDS as A operand.
+// The interchanges and the (1x1 / 2x2) D^{-1} step run in LDS, lane = column, exactly as
+// wg_bk_solve (bunchkaufman.hpp:451-518).  N % 4 == 0.  Sums are accumulated four products at a
+// time (MFMA order), not in the reference's dot-product order: equal to rounding.
+template <int N, int NCOLS, int MODE>
+__device__ inline void wave_bk_solve_mfma(const double *a, const double *subdiag, const int *piv,
+                                          double *X, int xrs, int lane) {
+#define GA(i, j) a[bk_idx<MODE>((i), (j), N)]
+  static_assert(N % 4 == 0 && NCOLS <= 48, "unsupported block");
+  constexpr int TR = (N + 15) / 16, TC = (NCOLS + 15) / 16, KSN = N / 4;
+  const int li = lane & 15, lk = lane >> 4;
+  double *xc = X + (lane < NCOLS ? lane : NCOLS - 1);
+  if (lane < NCOLS) { // forward interchanges (:458-468)
+    int k = 0;
+    while (k < N) {
+      int p = piv[k];
+      int row = k;
+      if (p < 0) {
+        p = -1 - p;
+        row = k + 1;
+        k += 2;
+      } else {
+        k += 1;
+      }
+      if (row != p) {
+        const double t = xc[row * xrs];
+        xc[row * xrs] = xc[p * xrs];
+        xc[p * xrs] = t;
+      }
+    }
+  }
+  wave_sync();
+  double4_t Xt[TR][TC];
+  auto load_tiles = [&]() {
+#pragma unroll
+    for (int ti = 0; ti < TR; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TC; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ti + lk + 4 * r;
+          Xt[ti][tj][r] = (16 * ti + 4 * r < N) ? X[row * xrs + 16 * tj + li] : 0.0;
+        }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int ti = 0; ti < TR; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TC; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * ti + 4 * r < N)
+            X[(16 * ti + lk + 4 * r) * xrs + 16 * tj + li] = Xt[ti][tj][r];
+  };
+  load_tiles();
+  // ---- unit-lower solve (:472), k-step blocks top down -----------------------------------------
+#pragma unroll
+  for (int s = 0; s < KSN; ++s) {
+    const int ti = s >> 2, r = s & 3, k0 = 4 * s;
+    // the 4x4 triangular part: row k0 + lk lives in lane group lk
+    const double c0 = lk >= 1 ? GA(k0 + lk, k0) : 0.0;
+    const double c1 = lk >= 2 ? GA(k0 + lk, k0 + 1) : 0.0;
+    const double c2 = lk == 3 ? GA(k0 + 3, k0 + 2) : 0.0;
+#pragma unroll
+    for (int tj = 0; tj < TC; ++tj) {
+      double v = Xt[ti][tj][r];
+      v = __builtin_fma(-c0, __shfl(v, li), v);
+      v = __builtin_fma(-c1, __shfl(v, 16 + li), v);
+      v = __builtin_fma(-c2, __shfl(v, 32 + li), v);
+      Xt[ti][tj][r] = v;
+    }
+    // rows beyond the block: X(i, :) -= L(i, k0 .. k0+3) X(k0 .. k0+3, :)
+#pragma unroll
+    for (int t2 = ti; t2 < TR; ++t2) {
+      const int row = 16 * t2 + li;
+      const double aq = (row > k0 + 3 && row < N) ? -GA(row < N ? row : N - 1, k0 + lk) : 0.0;
+#pragma unroll
+      for (int tj = 0; tj < TC; ++tj)
+        Xt[t2][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Xt[ti][tj][r], Xt[t2][tj], 0, 0, 0);
+    }
+  }
+  store_tiles();
+  wave_sync();
+  if (lane < NCOLS) { // inverse-D multiply (:474-502)
+    int k = 0;
+    while (k < N) {
+      if (piv[k] < 0) {
+        const double akp1k = subdiag[k], ak = GA(k, k), akp1 = GA(k + 1, k + 1);
+        const double xk = xc[k * xrs], xkp1 = xc[(k + 1) * xrs];
+        xc[k * xrs] = xk * ak + xkp1 * akp1k;
+        xc[(k + 1) * xrs] = xkp1 * akp1 + xk * akp1k;
+        k += 2;
+      } else {
+        xc[k * xrs] *= GA(k, k);
+        k += 1;
+      }
+    }
+  }
+  wave_sync();
+  load_tiles();
+  // ---- unit-upper (L^T) solve (:504), k-step blocks bottom up ----------------------------------
+#pragma unroll
+  for (int s = KSN - 1; s >= 0; --s) {
+    const int ti = s >> 2, r = s & 3, k0 = 4 * s;
+    const double c3 = lk < 3 ? GA(k0 + 3, k0 + lk) : 0.0;
+    const double c2 = lk < 2 ? GA(k0 + 2, k0 + lk) : 0.0;
+    const double c1 = lk < 1 ? GA(k0 + 1, k0) : 0.0;
+#pragma unroll
+    for (int tj = 0; tj < TC; ++tj) {
+      double v = Xt[ti][tj][r];
+      v = __builtin_fma(-c3, __shfl(v, 48 + li), v);
+      v = __builtin_fma(-c2, __shfl(v, 32 + li), v);
+      v = __builtin_fma(-c1, __shfl(v, 16 + li), v);
+      Xt[ti][tj][r] = v;
+    }
+    // rows above the block: X(i, :) -= L(k0 .. k0+3, i)^T X(k0 .. k0+3, :)
+#pragma unroll
+    for (int t2 = 0; t2 <= ti; ++t2) {
+      const int row = 16 * t2 + li;
+      const double aq = (row < k0) ? -GA(k0 + lk, row) : 0.0;
+#pragma unroll
+      for (int tj = 0; tj < TC; ++tj)
+        Xt[t2][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Xt[ti][tj][r], Xt[t2][tj], 0, 0, 0);
+    }
+  }
+  store_tiles();
+  wave_sync();
+  if (lane < NCOLS) { // reverse interchanges (:506-517)
+    int k = N;
+    while (k > 0) {
+      k -= 1;
+      int p = piv[k];
+      if (p < 0) {
+        p = -1 - p;
+        if (k != p) {
+          const double t = xc[k * xrs];
+          xc[k * xrs] = xc[p * xrs];
+          xc[p * xrs] = t;
+        }
+        k -= 1;
+      } else if (k != p) {
+        const double t = xc[k * xrs];
+        xc[k * xrs] = xc[p * xrs];
+        xc[p * xrs] = t;
+      }
+    }
+  }
+  wave_sync();
+#undef GA
+}
+
 template <int MODE = GAR_COLMAJOR>
 __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
                                    const double *subdiag, const int *piv, double *x, int xrs,

@@ -454,17 +454,16 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
 
 // Constrained stages: Bunch-Kaufman factorisation of the reduced KKT matrix (packed lower triangle in
 // LDS) and the solve of its right-hand sides, out of line (the stage keeps ~400 registers live).
-// (A fully unrolled variant with the column in registers was 1.8x SLOWER than the LDS-resident
-// column loop of wg_bk_solve: 1 900 hoisted LDS reads spill.)
-template <int NK, int BKS, int PG>
+// The triangular solves run as blocked MFMA updates (wave_bk_solve_mfma).  (A fully unrolled
+// column-in-registers substitution was 1.8x SLOWER than even the LDS-resident column loop of
+// wg_bk_solve: 1 900 hoisted LDS reads spill.)
+template <int NK, int BKS, int PG, int NCOLS>
 __device__ __attribute__((noinline)) int wave_kkt_factor_solve(double *Mm, double *sub, double *G,
-                                                               int ncols, int lane) {
+                                                               int lane) {
   int *piv = (int *)(sub + BKS);
   const WG w1 = wave_self();
   const int failed = wg_bk_factor<GAR_PACKED_LOWER>(w1, NK, Mm, NK, sub, piv, piv + BKS);
-  wg_bk_solve<GAR_PACKED_LOWER>(w1, NK, Mm, NK, sub, piv, G, PG, 1, ncols);
-  wave_sync();
-  (void)lane;
+  wave_bk_solve_mfma<NK, NCOLS, GAR_PACKED_LOWER>(Mm, sub, piv, G, PG, lane);
   return failed;
 }
 
@@ -725,7 +724,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
     for (int e = lane; e < NK * PG; e += 64)
       G[e] = -G[e];
     wave_sync();
-    failed |= wave_kkt_factor_solve<NK, C::BKS, PG>(Mm, sb + C::oBk, G, NX + 1, lane);
+    failed |= wave_kkt_factor_solve<NK, C::BKS, PG, NX + 1>(Mm, sb + C::oBk, G, lane);
   } else {
     double a_row[NU], nd[NU];
     const int verdict = wave_ldl_fast<NU>(Mm, lane, a_row, nd);

@@ -197,3 +197,36 @@ def check_leg_kernels_bunch_kaufman_fallback(lib_path=None, nthreads=3, horz=11)
     with pytest.raises(RuntimeError, match="LDL"):
         ParallelRiccatiSolver(bad, nthreads, lib_path=lib_path).backward(1e-10)
 
+
+def check_constrained_pivoting(lib_path=None, shapes=((8, 4, 4, 6, 1e-6), (16, 8, 8, 5, 1e-7))):
+    """Constrained stages whose reduced KKT matrix makes Bunch-Kaufman pivot: (a) small Rhat against
+    D entries of order one -> every pivot a 2x2 block; (b) mixed -> 1x1 interchanges.  (The
+    reference's generator, tests/gar/test_util.cpp:42-43, leaves D = 0: its KKT matrix is block
+    diagonal and never pivots.)  Factors, kkt0 and the solution against the oracle."""
+    for variant in ("all2x2", "mixed"):
+        for (nx, nu, nc, horz, mu) in shapes:
+            rng = np.random.default_rng(11)
+            prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nc=nc, mode="W")
+            for k in prob.stages[:-1]:
+                k.D[...] = rng.uniform(-1, 1, k.D.shape)
+                if variant == "all2x2":
+                    k.R[...] *= 1e-3
+                    k.S[...] *= 1e-3
+                    k.B[...] = 0.0
+                else:
+                    k.R[...] *= 1e-2
+            _, osol, _ = oracle_serial(prob, mu)
+            n2 = nsw = 0
+            for t in range(horz):
+                K = np.block([[osol.datas(t).Rhat, prob.stages[t].D.T],
+                              [prob.stages[t].D, -mu * np.eye(nc)]])
+                piv = ora.BunchKaufman(K).pivots
+                n2 += int((piv < 0).sum())
+                nsw += int(((piv >= 0) & (piv != np.arange(piv.size))).sum())
+            if variant == "all2x2":
+                assert n2 > 0, "test must force 2x2 pivots"
+            elif nx <= 16:
+                assert nsw > 0, "test must force interchanges"
+            solver, _, _ = check_serial(prob, mu, 1e-8, lib_path)
+            assert solver.kernel_name == f"wave<{nx},{nu},{nc}>"
+

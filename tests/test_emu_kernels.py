@@ -361,3 +361,8 @@ def test_constrained_wave_kernels(nx, nu, nc, horz, mu):
     solver, sol, ref = pc.check_serial(prob, mu, 1e-8, EMU)
     assert solver.kernel_name == f"wave<{nx},{nu},{nc}>"
     assert len(sol[2]) == horz + 1 and sol[2][horz].size == nc   # vs on every knot, terminal included
+
+
+def test_constrained_wave_kernels_bunch_kaufman_pivoting():
+    pc.check_constrained_pivoting(EMU)
+
