@@ -638,11 +638,15 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         if (16 * ti + 4 * r >= NX && 16 * ti + 4 * r < NW) { // compile-time: control rows
           if (c < NX)
             G[(row - NX) * PG + 1 + c] = S.Hc[ti][tj][r];
-          else if (c <= row)
+          else if (c <= row) {
             Mm[NC > 0 ? bk_idx<GAR_PACKED_LOWER>(row - NX, c - NX, NK) : (c - NX) * NK + (row - NX)] =
                 S.Hc[ti][tj][r];
+            if (NC > 0) // pitch-NU copy of Rhat for the decoupled (D = 0) path
+              (sb + C::oLr)[(c - NX) * NU + (row - NX)] = S.Hc[ti][tj][r];
+          }
         }
       }
+  bool d_is_zero = false; // NC > 0: D == 0 on this knot (wave-uniform)
   if (NC > 0) {
     // rows NU.. of G: [d | C]; the KKT matrix [Rhat D^T; D -mu I] (lower, column-major pitch NK):
     // Rhat was placed above with pitch NU -- re-place it, add D and the -mu diagonal
@@ -662,6 +666,13 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       td[q] = rec[M::kD + ((64 * q + 63 < NC * NU || e < NC * NU) ? e : NC * NU - 1)];
     }
     const double dv = rec[M::kd + (lane < NC ? lane : NC - 1)];
+    {
+      bool nz = false;
+#pragma unroll
+      for (int q = 0; q < NCD; ++q)
+        nz |= (td[q] != 0.0);
+      d_is_zero = (__ballot(nz) == 0ull);
+    }
 #pragma unroll
     for (int q = 0; q < NCC; ++q) { // C (NC x NX), column-major
       const int e = 64 * q + lane;
@@ -719,12 +730,41 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   GAR_WMARK(4)
   // ---- factor Rhat (lane = row) under the Bunch-Kaufman rule; solve [kff | K] ---
   if (NC > 0) {
-    // [kff K; zff Z] = -KKT^{-1} [rhat Shat^T; d C]  (:232-262): Bunch-Kaufman with interchanges and
-    // 2x2 pivots, exactly the reference's kktChol on the same matrix
-    for (int e = lane; e < NK * PG; e += 64)
-      G[e] = -G[e];
-    wave_sync();
-    failed |= wave_kkt_factor_solve<NK, C::BKS, PG, NX + 1>(Mm, sb + C::oBk, G, lane);
+    // [kff K; zff Z] = -KKT^{-1} [rhat Shat^T; d C]  (:232-262).
+    bool done = false;
+    if (d_is_zero) {
+      // D = 0 (what the reference's own generator produces, tests/gar/test_util.cpp:42-43): the KKT
+      // matrix is block diagonal, Bunch-Kaufman on it is Bunch-Kaufman on Rhat (the columns of the
+      // -mu I block never pivot) and [zff | Z] = (-[d | C]) * (1 / -mu) = [d | C] * (1/mu).
+      double a_row[NU], nd[NU];
+      const int verdict = wave_ldl_fast<NU>(sb + C::oLr, lane, a_row, nd);
+      if (verdict == 0) {
+        const int col = lane <= NX ? lane : NX;
+        double x[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+          x[k] = G[k * PG + col];
+        ldl_solve_regs_bcast<NU>(a_row, nd, x);
+        if (lane <= NX) {
+#pragma unroll
+          for (int k = 0; k < NU; ++k)
+            G[k * PG + col] = x[k];
+        }
+        const double imu = -(1.0 / -P.mueq); // the stored inverse pivot of the -mu block, negated
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          if (lane <= NX)
+            G[(NU + i) * PG + col] *= imu;
+        wave_sync();
+        done = true;
+      }
+    }
+    if (!done) { // Bunch-Kaufman with interchanges and 2x2 pivots: the reference's kktChol
+      for (int e = lane; e < NK * PG; e += 64)
+        G[e] = -G[e];
+      wave_sync();
+      failed |= wave_kkt_factor_solve<NK, C::BKS, PG, NX + 1>(Mm, sb + C::oBk, G, lane);
+    }
   } else {
     double a_row[NU], nd[NU];
     const int verdict = wave_ldl_fast<NU>(Mm, lane, a_row, nd);

@@ -9,6 +9,11 @@ from aligator_amd.gar import BatchedRiccatiSolver, lqrComputeKktError
 
 nx, nu, nc, N, mueq = 36, 12, 32, int(os.environ.get("HORIZON", "256")), 1e-11
 probs = [synth.generate_lq_problem(100 + i, np.zeros(nx), N, nx, nu, nc=nc, mode="W") for i in range(2)]
+if os.environ.get("DNONZERO"):   # the reference's generator leaves D = 0 (test_util.cpp:42-43)
+    for p in probs:
+        rng = np.random.default_rng(9)
+        for k in p.stages[:-1]:
+            k.D[...] = rng.uniform(-1, 1, k.D.shape)
 dims = [k.dims for k in probs[0].stages]
 for B in (64, 256, 1024):
     s = BatchedRiccatiSolver(dims, nx, batch=B)
@@ -22,4 +27,4 @@ for B in (64, 256, 1024):
         s.backward_async(mueq); s.forward_async()
     s.sync()
     dt = (time.perf_counter() - t0) / R
-    print(f"nc={nc} N={N} batch={B:5d} {s.kernel_name:10s} {dt*1e3:9.2f} ms/step {B/dt:9.0f} sweeps/s  kkt {kkt:.1e}", flush=True)
+    print(("D random " if os.environ.get("DNONZERO") else "D = 0    ") + f"nc={nc} N={N} batch={B:5d} {s.kernel_name:10s} {dt*1e3:9.2f} ms/step {B/dt:9.0f} sweeps/s  kkt {kkt:.1e}", flush=True)
