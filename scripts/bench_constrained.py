@@ -28,3 +28,20 @@ for B in (64, 256, 1024):
     s.sync()
     dt = (time.perf_counter() - t0) / R
     print(("D random " if os.environ.get("DNONZERO") else "D = 0    ") + f"nc={nc} N={N} batch={B:5d} {s.kernel_name:10s} {dt*1e3:9.2f} ms/step {B/dt:9.0f} sweeps/s  kkt {kkt:.1e}", flush=True)
+
+# the CPU oracle (restated reference, oracle/gar_oracle.c -O3 -march=native, OpenMP over problems) on
+# this box's host cores, same shape and data
+from oracle import oracle as ora
+ora.lib(native=True)
+cores = os.cpu_count() or 1
+many = [ora.Problem.from_knots(p.stages, p.G0, p.g0, native=True) for p in (probs * cores)[:2 * cores]]
+bs = ora.BatchSweep(many)
+threads = bs.max_threads()
+bs.sweep(mueq, threads)
+t0 = time.perf_counter(); reps = 0
+while time.perf_counter() - t0 < 8.0:
+    assert bs.sweep(mueq, threads) == 0
+    reps += 1
+dt = time.perf_counter() - t0
+print(f"CPU oracle nc={nc} N={N}: {len(many) * reps / dt:8.0f} sweeps/s on {threads} threads", flush=True)
+
