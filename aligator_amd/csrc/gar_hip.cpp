@@ -78,6 +78,7 @@ struct gar_hip_solver {
   void (*wave_kernel)(gar::MfmaParams, int) = nullptr;
   int wave_lds_doubles = 0, waves_per_block = 1;
   bool wave_fused_init = false;
+  bool init_closed = true; // closed-form initial stage when G0 = +-I (GAR_HIP_INIT=bk: always factorise)
   // one-wave-per-(problem, leg) kernels (gar_wave_leg.hpp), bound for uniform leg-mode problems
   void (*leg_bwd_kernel)(gar::LegParams) = nullptr;
   void (*leg_tuple_kernel)(gar::LegParams) = nullptr;
@@ -382,6 +383,10 @@ void select_kernel(gar_hip_solver *s) {
   s->mfma_fwd_kernel = nullptr;
   s->wave_kernel = nullptr;
   s->wave_fused_init = false;
+  {
+    const char *ik = std::getenv("GAR_HIP_INIT");
+    s->init_closed = !(ik && std::string(ik) == "bk");
+  }
   s->kernel_name = "generic";
   const char *force = std::getenv("GAR_HIP_FORCE_GENERIC");
   if (force && force[0] == '1')
@@ -553,6 +558,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.g0_off = s->g0_off;
     M.nc0 = s->nc0;
     M.mueq = mueq;
+    M.init_closed = s->init_closed ? 1 : 0;
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->wave_kernel) {

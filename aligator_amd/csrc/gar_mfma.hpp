@@ -42,6 +42,7 @@ struct MfmaParams {
   long long init_stride, G0_off, g0_off;
   int nc0;
   double mueq; // constrained stages: the proximal weight of [Rhat D^T; D -mu I]
+  int init_closed; // fused initial stage: closed form when G0 = +-I (0: always factorise kkt0)
 };
 
 // NC > 0: every knot carries NC equality constraints C x + D u + d = mu v (the one-wave-per-problem
