@@ -33,6 +33,7 @@ struct LdsPlan {
 };
 
 struct GenericParams {
+  int init_closed;            // gar_initial_wave: closed form when G0 = +-I (0: always factorise)
   const gar_stage_meta *meta; // horizon+1 entries (device)
   const double *prob;         // packed problems
   double *fac;                // factor records
@@ -450,6 +451,37 @@ __global__ void __launch_bounds__(64) gar_initial_wave(GenericParams P) {
   const gar_factor_offsets fo = gar_factor_layout(m0.nx, m0.nu, m0.nc, m0.nx2, m0.nth);
   const double *rec = P.fac + (long long)b * P.fac_stride + m0.fac_off;
   const int n0 = m0.nx + P.nc0, nth = m0.nth;
+  // "x0 given" (G0 = +-I, nc0 = nx, no parameters): the closed form of the fused initial stage of
+  // gar_backward_wave -- x0 = -s g0, lbd0 = -s (vx0 + Vxx0 x0) -- instead of the (2 nx)^2
+  // Bunch-Kaufman factorisation (0.18 ms of a 2.1 ms single-problem sweep)
+  if (P.init_closed && nth == 0 && P.nc0 == m0.nx && m0.nx <= 64) {
+    const int nx = m0.nx;
+    const double *prob = P.prob + (long long)b * P.prob_stride;
+    const double *G0 = prob + P.G0_off, *g0 = prob + P.g0_off;
+    const double g00 = G0[0];
+    bool ok = (g00 == 1.0 || g00 == -1.0);
+    for (int e = w.lane; e < nx * nx; e += 64) {
+      const int j = e / nx, i = e - j * nx;
+      ok &= (G0[e] == (i == j ? g00 : 0.0));
+    }
+    if (__ballot(!ok) == 0ull) {
+      const int ix = w.lane < nx ? w.lane : nx - 1;
+      const double x0 = -g00 * g0[ix];
+      double *xs = sm; // x0 through LDS: the state dimension is a run-time value here
+      if (w.lane < nx)
+        xs[w.lane] = x0;
+      wave_sync();
+      double acc = rec[fo.vx + ix];
+      for (int k = 0; k < nx; ++k)
+        acc += rec[fo.Vxx + (long long)k * nx + ix] * xs[k]; // Vxx0 symmetric: row ix
+      double *io = P.init + (long long)b * P.init_stride;
+      if (w.lane < nx) {
+        io[w.lane] = x0;
+        io[nx + w.lane] = -g00 * acc;
+      }
+      return;
+    }
+  }
   double *k0mat = sm, *k0rhs = k0mat + n0 * n0, *k0sub = k0rhs + n0 * (1 + nth);
   int *piv0 = (int *)(k0sub + n0 + (n0 & 1));
   const int failed = initial_stage_ptr(w, P, b, m0.nx, nth, rec + fo.Vxx, rec + fo.vx, rec + fo.Vxt,

@@ -455,6 +455,7 @@ gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
   P.nxb = s->nxb;
   P.mueq = mueq;
   P.lds = s->lds;
+  P.init_closed = s->init_closed ? 1 : 0;
   return P;
 }
 
