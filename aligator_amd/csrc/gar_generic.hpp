@@ -492,6 +492,33 @@ __global__ void __launch_bounds__(64) gar_initial_wave(GenericParams P) {
 }
 
 // ---------------------------------------------------------------------------
+// cycleAppend (proximal-riccati.hxx:79-86: rotate_vec_left of the stage data) on the device: the
+// `nrec` uniform records starting at `off` slide down by one, the last one is zeroed.  Thread e
+// owns element e of every record (no synchronisation: it only ever touches its own offsets),
+// eight records in flight per round trip.  grid (ceil(rec/256), batch).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gar_rotate_records(double *base, long long stride, long long off,
+                                                          long long rec, int nrec) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rec)
+    return;
+  double *a = base + (long long)blockIdx.y * stride + off + e;
+  int t = 0;
+  for (; t + 8 < nrec; t += 8) {
+    double tmp[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      tmp[q] = a[(t + 1 + q) * rec];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      a[(t + q) * rec] = tmp[q];
+  }
+  for (; t + 1 < nrec; ++t)
+    a[t * rec] = a[(t + 1) * rec];
+  a[(long long)(nrec - 1) * rec] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
 // Device-resident SolverProxDDPTpl::updateLQSubproblem (solver-proxddp.hxx:734-805): one
 // workgroup per (stage, problem) turns the stage's derivative record (gar_layout.h) into its
 // knot record -- Q = Lxx + preg I [+ Hxx], S = Lxu [+ Hxu], R = Luu + preg I [+ Huu],
