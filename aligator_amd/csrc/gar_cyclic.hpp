@@ -225,27 +225,6 @@ __device__ __forceinline__ void cyc_store_block(double *dst, const double *src_l
       dst[e] = tmp[q];
   }
 }
-// dst(LDS) = a - b, two global blocks
-template <int NX>
-__device__ __forceinline__ void cyc_load_diff(double *dst, const double *a, const double *b, bool sub,
-                                              int lane) {
-  constexpr int bs = NX * NX, NCH = (bs + 63) / 64;
-  double ta[NCH], tb[NCH];
-#pragma unroll
-  for (int q = 0; q < NCH; ++q) {
-    const int e = 64 * q + lane;
-    const int ec = (64 * q + 63 < bs || e < bs) ? e : bs - 1;
-    ta[q] = a[ec];
-    tb[q] = sub ? b[ec] : 0.0;
-  }
-#pragma unroll
-  for (int q = 0; q < NCH; ++q) {
-    const int e = 64 * q + lane;
-    if (64 * q + 63 < bs || e < bs)
-      dst[e] = ta[q] - tb[q];
-  }
-}
-
 // a block in flight: global loads issued now, written to LDS later (the latency hides behind
 // whatever runs in between)
 template <int NX> struct BlockRegs {

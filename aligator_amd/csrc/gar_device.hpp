@@ -129,21 +129,6 @@ __device__ inline void wg_load_colmajor(const WG &w, const double *src, int rows
     dst(i, j) = src[e];
   }
 }
-__device__ inline void wg_store_colmajor(const WG &w, MatV src, int rows, int cols, double *dst) {
-  const int n = rows * cols;
-  for (int e = w.tid; e < n; e += w.nthr) {
-    const int j = e / rows, i = e - j * rows;
-    dst[e] = src(i, j);
-  }
-}
-// dst is a ROW-major rows x cols contiguous block
-__device__ inline void wg_store_rowmajor(const WG &w, MatV src, int rows, int cols, double *dst) {
-  const int n = rows * cols;
-  for (int e = w.tid; e < n; e += w.nthr) {
-    const int i = e / cols, j = e - i * cols;
-    dst[e] = src(i, j);
-  }
-}
 __device__ inline void wg_fill(const WG &w, double *dst, int n, double v) {
   for (int e = w.tid; e < n; e += w.nthr)
     dst[e] = v;

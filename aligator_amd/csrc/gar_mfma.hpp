@@ -254,32 +254,6 @@ __device__ __forceinline__ void ldl_solve_bcast(const double (&a)[NU], const dou
   }
 }
 
-// x <- (L D L^T)^{-1} x with L packed strictly-lower row-wise in LDS (pl[i*(i-1)/2 + j])
-template <int NU>
-__device__ __forceinline__ void ldl_solve_regs(const double *pl, const double (&dinv)[NU],
-                                               double (&x)[NU]) {
-#pragma unroll
-  for (int i = 1; i < NU; ++i) {
-    double s = x[i];
-#pragma unroll
-    for (int j = 0; j < i; ++j)
-      s -= pl[i * (i - 1) / 2 + j] * x[j];
-    x[i] = s;
-  }
-#pragma unroll
-  for (int i = 0; i < NU; ++i)
-    x[i] *= dinv[i];
-  asm volatile("" ::: "memory"); // re-read L for the transposed solve (register pressure)
-#pragma unroll
-  for (int j = NU - 2; j >= 0; --j) {
-    double s = x[j];
-#pragma unroll
-    for (int i = j + 1; i < NU; ++i)
-      s -= pl[i * (i - 1) / 2 + j] * x[i];
-    x[j] = s;
-  }
-}
-
 template <int NX, int NU>
 __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
   using C = MfmaCfg<NX, NU>;
