@@ -241,6 +241,54 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
     // strict ">" scan) is found by the whole group when the column is long: every thread scans
     // its rows, waves reduce with xor-shuffles, thread 0 combines the per-wave results that
     // were parked in `subdiag` (free until the end of the factorisation).
+    if (w.wave_scope && n <= 64) {
+      // One wave, n <= 64: the whole decision lane-parallel, no LDS parking, no barrier -- lane i
+      // looks at row i of column k, xor-shuffles reduce (value, first index); the row maximum of
+      // the candidate (:62-70) the same way.  Every lane ends with the same (k_step, kp, fail).
+      const int i = w.lane;
+      double bv = (i > k && i < n) ? fabs(GA(i, k)) : -1.0;
+      int bi = (i > k && i < n) ? i : 0x7fffffff;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) {
+          bv = ov;
+          bi = oi;
+        }
+      }
+      const double abs_akk = fabs(GA(k, k));
+      const double colmax = bv < 0.0 ? 0.0 : bv;
+      const int imax = bv < 0.0 ? k + 1 : bi;
+      int k_step = 1, kp = k, fail = 0;
+      if (fmax(abs_akk, colmax) == 0.0) {
+        fail = 1;
+      } else if (!(abs_akk >= colmax * alpha)) {
+        double rv = 0.0; // |a(imax, j)|, j in [k, imax) ; |a(i, imax)|, i in (imax, n)
+        if (i >= k && i < imax)
+          rv = fabs(GA(imax, i));
+        else if (i > imax && i < n)
+          rv = fabs(GA(i, imax));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+          rv = fmax(rv, __shfl_xor(rv, off));
+        const double rowmax = rv;
+        if (abs_akk >= (alpha * colmax) * (colmax / rowmax)) {
+          kp = k;
+        } else if (fabs(GA(imax, imax)) >= alpha * rowmax) {
+          kp = imax;
+        } else {
+          kp = imax;
+          k_step = 2;
+        }
+      }
+      if (w.tid == 0) {
+        ctrl[0] = k_step;
+        ctrl[1] = kp;
+        ctrl[2] = fail;
+      }
+      wg_bar(w);
+    } else {
     const bool par_search = (n - k - 1) >= 16 && n >= 2 * w.nwaves;
     if (par_search) {
       double bv = -1.0;
@@ -318,6 +366,7 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       ctrl[2] = fail;
     }
     wg_bar(w);
+    }
     const int k_step = ctrl[0], kp = ctrl[1];
     if (ctrl[2]) { // NumericalIssue: keep the remaining pivots in range and stop
       for (int i = k + w.tid; i < n; i += w.nthr)
