@@ -225,8 +225,11 @@ int plan_lds(gar_hip_solver *s) {
   int p = 0;
   auto take = [&](int n) { int o = p; p += align2(std::max(n, 0)); return o; };
   for (int k = 0; k < 2; ++k) {
-    L.V[k] = take(nxM * nxM);
-    L.v[k] = take(nxM);
+    // Vxx', vx' are dead once P = V'[A B] and vplus are formed (S1), Vxx, vx are written in S5: one
+    // buffer serves both (25 KB at nx = 56, what lets the Talos shape fit a CU's LDS); the
+    // parameter blocks are read and written in the same phase and keep two
+    L.V[k] = k == 0 ? take(nxM * nxM) : L.V[0];
+    L.v[k] = k == 0 ? take(nxM) : L.v[0];
     L.Vxt[k] = take(nxM * nthM);
     L.Vtt[k] = take(nthM * nthM);
     L.vt[k] = take(nthM);

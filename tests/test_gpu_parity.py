@@ -335,3 +335,62 @@ def test_bench_two_ranks_on_one_gpu():
                      "--steps", "2", "--warmup", "1", "--batch", "128", "--backend", "gloo", "--same-device"])
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d and "parallel_in_time" not in d
     assert abs(d["value"] - 2 * 128 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+def _lq_from_blocks(A, B, c, Q, R, q, r, Qt, x0, horz):
+    """The LQ problem ProxDDP hands to gar for a linear-quadratic trajectory problem with x0 given."""
+    from aligator_amd.lqr import LqrKnot, LqrProblem
+    nx, nu = B.shape
+    knots = []
+    for _ in range(horz):
+        k = LqrKnot(nx, nu)
+        k.Q[...], k.R[...], k.q[...], k.r[...] = Q, R, q, r
+        k.A[...], k.B[...], k.f[...] = A, B, c
+        knots.append(k)
+    kt = LqrKnot(nx, 0)
+    kt.Q[...] = Qt
+    knots.append(kt)
+    prob = LqrProblem(knots, nx)
+    prob.G0[...] = -np.eye(nx)
+    prob.g0[...] = x0
+    return prob
+
+
+def test_config0_lqr_plumbing_shape():
+    """BASELINE.json configs[0] (tests/lqr.cpp:30-57, bench/lqr.cpp): random dense LQR, nx=4,
+    nu=2, A = I with a random lower-right 2x2, B ~ N(0,1), Q = M^T M, R = M^T M, terminal cost 10 Q,
+    mt19937_64{42}-style seed; pass = KKT <= 1e-9 and agreement with the oracle."""
+    rng = np.random.default_rng(42)
+    nx, nu, horz = 4, 2, 50
+    A = np.eye(nx)
+    A[2:, 2:] = rng.standard_normal((2, 2))
+    B = rng.standard_normal((nx, nu))
+    M = rng.standard_normal((nx, nx))
+    Q = M.T @ M
+    M = rng.standard_normal((nu, nu))
+    R = M.T @ M
+    prob = _lq_from_blocks(A, B, np.zeros(nx), Q, R, rng.standard_normal(nx), np.zeros(nu), 10 * Q,
+                           rng.standard_normal(nx), horz)
+    pc.check_serial(prob, 1e-12, 1e-9, kkt_tol=1e-9)
+
+
+def test_config4_talos_lq_shape():
+    """BASELINE.json configs[4] needs Pinocchio (absent): its LQ sub-problem SHAPE instead --
+    bench/lqr.cpp:25-57 with dim = 56, nu = 22 (A = I, B = [I; 0], c = 0.1, w_x = I with w_x(0,0) = 2,
+    w_u = 1e-2 I), N = 275 -- serial in time on the generic kernels (188 KB of LDS before the
+    value-function buffers were shared, 162 KB now)."""
+    nx, nu, horz = 56, 22, 275
+    A = np.eye(nx)
+    B = np.eye(nx, nu)
+    wx = np.eye(nx)
+    wx[0, 0] = 2.0
+    rng = np.random.default_rng(7)
+    prob = _lq_from_blocks(A, B, np.full(nx, 0.1), wx, 1e-2 * np.eye(nu), np.zeros(nx), np.zeros(nu), wx,
+                           rng.uniform(-1, 1, nx), horz)
+    solver, _, _ = pc.check_serial(prob, 1e-10, 1e-8, kkt_tol=1e-8)
+    assert solver.kernel_name == "generic"
+    # leg mode adds the parameter blocks (nth = 56): 318 KB of LDS in the generic kernels -- refused
+    # loudly (GAR_HIP_ERR_UNSUPPORTED), not silently run elsewhere
+    from aligator_amd.gar import ParallelRiccatiSolver
+    with pytest.raises(RuntimeError, match="LDS"):
+        ParallelRiccatiSolver(prob.copy(), 5)
