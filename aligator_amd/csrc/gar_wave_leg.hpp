@@ -1,13 +1,18 @@
 // gar_wave_leg.hpp -- the parallel-in-time (leg) sweeps of ParallelRiccatiSolver
 // (gar/parallel-solver.hxx:131-240) for uniform unconstrained problems, at the speed of
-// the one-wave-per-problem kernels of gar_wave.hpp: ONE WAVE PER (problem, leg).
+// the one-wave-per-problem kernels of gar_wave.hpp: one workgroup per (problem, leg).
 //
 //   backward: non-final legs run the parameterised recursion (nth = NX, the costate of the next
 //             leg's first state is the parameter): the leg-end knot through wave_stage<2>
-//             (terminalSolve under configure_knot), every other stage through wave_stage<1>
-//             (stageKernelSolve + :278-311); the final leg is the plain recursion
-//             (wave_stage<0>) down from the true terminal knot.  Parallelism comes from the legs:
-//             a single long-horizon problem occupies num_legs SIMDs instead of one.
+//             (terminalSolve under configure_knot), every other stage through
+//             stageKernelSolve + :278-311 -- by ONE wave (gar_backward_wave_leg: wave_stage<1>) or,
+//             the default, split over TWO (gar_backward_wave_leg2: wave A the plain recursion
+//             wave_stage<3>, wave B the parameter part wave_param_stage, one barrier behind);
+//             the final leg is the plain recursion (wave_stage<0>) down from the true terminal
+//             knot.  Parallelism comes from the legs: a single long-horizon problem occupies
+//             2 num_legs SIMDs instead of one.
+//   condensed: gar_condensed_wave (the reference's elimination chain, here) and block cyclic
+//             reduction (gar_cyclic.hpp, the default).
 //   tuples  : (Vxx, Vxt, Vtt, vx, vt) of every leg's first stage -> the boundary buffer that the
 //             all-gather / condensed solve consume.
 //   forward : the closed-loop roll-out of a leg from the condensed solution; theta (constant
