@@ -1,0 +1,42 @@
+"""Randomised parity soak on the GPU: many (shape, horizon, legs, generator, mu) draws through the
+Python mirror against the CPU oracle.  Prints one line per failure and a summary."""
+import os, sys, time, traceback
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from aligator_amd import synth
+import parity_cases as pc
+
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "2026")))
+budget = float(os.environ.get("SOAK_SECONDS", "150"))
+shapes = [(36, 12, 0), (32, 12, 0), (16, 8, 0), (12, 8, 0), (12, 4, 0), (8, 4, 0), (12, 6, 0), (8, 3, 0),
+          (36, 12, 32), (16, 8, 8), (8, 4, 4), (6, 3, 2), (5, 2, 0)]
+t0, n, fails, kinds = time.time(), 0, 0, {}
+while time.time() - t0 < budget:
+    nx, nu, nc = shapes[rng.integers(len(shapes))]
+    horz = int(rng.integers(3, 70))
+    mode = "F" if (rng.random() < 0.3 and nx <= 16) else "W"
+    # (constrained problems below mu ~ 1e-10 are conditioned like 1/mu: the oracle and the kernels then
+    # differ by cond * eps > 1e-6 from each other on EVERY kernel family, generic included)
+    mu = 10.0 ** rng.uniform(-12 if nc == 0 else -10, -5)
+    legs = 1 if (nc > 0 or rng.random() < 0.4) else int(rng.integers(2, max(3, min(9, horz // 2))))
+    seed = int(rng.integers(1 << 30))
+    prob = synth.generate_lq_problem(np.random.default_rng(seed), rng.standard_normal(nx), horz, nx, nu, nc=nc, mode=mode)
+    if nc > 0 and rng.random() < 0.5:
+        for k in prob.stages[:-1]:
+            k.D[...] = rng.uniform(-1, 1, k.D.shape)
+    tol = pc.TOL[mode] if nc == 0 else 1e-6
+    try:
+        if legs == 1:
+            s, _, _ = pc.check_serial(prob, mu, tol, factors=(nc == 0 or mu > 1e-9))
+            name = s.kernel_name
+        else:
+            par = pc.check_parallel(prob, mu, legs, max(tol, 1e-8))
+            name = par._impl.kernel_name
+        kinds[name] = kinds.get(name, 0) + 1
+    except Exception as e:
+        fails += 1
+        print(f"FAIL nx={nx} nu={nu} nc={nc} N={horz} legs={legs} mode={mode} mu={mu:.1e} seed={seed}: {type(e).__name__} {str(e)[:120]}")
+        traceback.print_exc(limit=2)
+    n += 1
+print(f"soak: {n} problems, {fails} failures, kernels {kinds}")
