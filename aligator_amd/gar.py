@@ -65,52 +65,58 @@ class _Kkt0View:
 SPECIALISED_SHAPES = {(36, 12), (32, 12), (16, 8), (12, 8), (12, 4), (8, 4)}
 
 
-def _padded_controls(dims: np.ndarray) -> int:
-    """Control padding: a uniform unconstrained problem whose nu is not a multiple of 4 is run on
-    the specialised kernels of (nx, 4*ceil(nu/4)) with DUMMY controls (R = I, S = 0, B = 0,
-    r = 0 on the padding: they solve to exactly zero and decouple).  Returns the padded nu, or 0
-    when padding does not apply."""
+def _padded_dims(dims: np.ndarray):
+    """Padding onto a specialised shape: a uniform unconstrained, unparameterised problem whose
+    (nx, nu) has no kernel of its own runs on the smallest specialised shape (NX >= nx, NU >= nu)
+    with DUMMY controls (R = I, S = 0, B = 0, r = 0) and DUMMY states (Q = I, A = 0, B = 0, f = 0,
+    pinned to zero by extra rows [0 -I] x0 = 0 of the initial constraint): both solve to exactly
+    zero, decouple from the real variables, and are stripped from every result.
+    Returns (NX, NU), or None when padding does not apply."""
     N = dims.shape[0] - 1
     if N < 1:
-        return 0
+        return None
     nx, nu = int(dims[0, 0]), int(dims[0, 1])
-    if nu % 4 == 0 or nu == 0:
-        return 0
+    if nu == 0 or (nx, nu) in SPECIALISED_SHAPES:
+        return None
     if not ((dims[:N] == (nx, nu, 0, nx, 0)).all() and tuple(dims[N]) == (nx, 0, 0, nx, 0)):
-        return 0
-    nup = 4 * ((nu + 3) // 4)
-    return nup if (nx, nup) in SPECIALISED_SHAPES else 0
+        return None
+    fits = [(NX * (NX + NU), NX, NU) for (NX, NU) in SPECIALISED_SHAPES if NX >= nx and NU >= nu]
+    if not fits:
+        return None
+    _, NX, NU = min(fits)
+    return NX, NU
 
 
-def _pad_knot(k: LqrKnot, nup: int) -> LqrKnot:
-    if k.nu == 0 or k.nu == nup:
+def _pad_knot(k: LqrKnot, nxp: int, nup: int) -> LqrKnot:
+    nup = nup if k.nu > 0 else 0
+    if (k.nx, k.nu) == (nxp, nup):
         return k
-    p = LqrKnot(k.nx, nup, k.nc, k.nx2, k.nth)
-    nu = k.nu
-    for name in ("Q", "q", "A", "f", "C", "d", "Gth", "Gx", "Gv", "gamma"):
-        getattr(p, name)[...] = getattr(k, name)
-    p.S[:, :nu] = k.S
-    p.R[:nu, :nu] = k.R
-    p.R[np.arange(nu, nup), np.arange(nu, nup)] = 1.0
-    p.r[:nu] = k.r
-    p.B[:, :nu] = k.B
-    p.D[:, :nu] = k.D
-    p.Gu[:nu] = k.Gu
+    # (leg mode: the caller's knots carry the parameterisation ParallelRiccatiSolver wrote into
+    # them; the device keeps it implicit, so the padded knot has none)
+    assert k.nc == 0 and k.nx2 == k.nx
+    nx, nu = k.nx, k.nu
+    p = LqrKnot(nxp, nup, 0, nxp, 0)
+    p.Q[:nx, :nx] = k.Q
+    p.Q[np.arange(nx, nxp), np.arange(nx, nxp)] = 1.0
+    p.q[:nx] = k.q
+    p.A[:nx, :nx] = k.A
+    p.f[:nx] = k.f
+    if nu > 0:
+        p.S[:nx, :nu] = k.S
+        p.R[:nu, :nu] = k.R
+        p.R[np.arange(nu, nup), np.arange(nu, nup)] = 1.0
+        p.r[:nu] = k.r
+        p.B[:nx, :nu] = k.B
     return p
 
 
-def _unpad_knot(p: LqrKnot, nu: int) -> LqrKnot:
-    if p.nu == 0 or p.nu == nu:
+def _unpad_knot(p: LqrKnot, nx: int, nu: int) -> LqrKnot:
+    if (p.nx, p.nu) == (nx, nu):
         return p
-    k = LqrKnot(p.nx, nu, p.nc, p.nx2, p.nth)
-    for name in ("Q", "q", "A", "f", "C", "d", "Gth", "Gx", "Gv", "gamma"):
-        getattr(k, name)[...] = getattr(p, name)
-    k.S[...] = p.S[:, :nu]
-    k.R[...] = p.R[:nu, :nu]
-    k.r[...] = p.r[:nu]
-    k.B[...] = p.B[:, :nu]
-    k.D[...] = p.D[:, :nu]
-    k.Gu[...] = p.Gu[:nu]
+    k = LqrKnot(nx, nu, 0, nx, 0)
+    k.Q[...], k.q[...], k.A[...], k.f[...] = p.Q[:nx, :nx], p.q[:nx], p.A[:nx, :nx], p.f[:nx]
+    if nu > 0:
+        k.S[...], k.R[...], k.r[...], k.B[...] = p.S[:nx, :nu], p.R[:nu, :nu], p.r[:nu], p.B[:nx, :nu]
     return k
 
 
@@ -119,8 +125,8 @@ class BatchedRiccatiSolver:
 
     dims: (horizon+1) x (nx, nu, nc, nx2, nth).  num_legs = 1 is the serial
     ProximalRiccatiSolver algorithm, >= 2 the ParallelRiccatiSolver one.
-    `dims` (attribute) are the dimensions of the device records; `user_dims` those of the caller's
-    problem (they differ only under control padding, see _padded_controls).
+    `dims`, `nc0` (attributes) are the dimensions of the device records; `user_dims`, `user_nc0`
+    those of the caller's problem (they differ only under padding, see _padded_dims).
     """
 
     def __init__(self, dims, nc0: int, batch: int = 1, num_legs: int = 1, device: int = 0,
@@ -128,11 +134,17 @@ class BatchedRiccatiSolver:
         self._L = _lib.load(lib_path)
         self.user_dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int32).reshape(-1, 5))
         self.dims = self.user_dims.copy()
-        self._nup = _padded_controls(self.user_dims) if pad_controls else 0
-        if self._nup:
+        self.user_nc0 = int(nc0)
+        import os
+        pad = _padded_dims(self.user_dims) if (pad_controls and os.environ.get("GAR_HIP_PAD", "1") != "0") else None
+        self._nxp, self._nup = pad if pad else (0, 0)   # padded (nx, nu) on the device; 0 = no padding
+        if pad:
+            self.dims[:, 0] = self.dims[:, 3] = self._nxp
             self.dims[:-1, 1] = self._nup
         self.horizon = self.dims.shape[0] - 1
-        self.nc0, self.batch, self.num_legs = int(nc0), int(batch), int(num_legs)
+        # dummy states are pinned by extra rows of the initial constraint
+        self.nc0 = self.user_nc0 + (self._nxp - int(self.user_dims[0, 0]) if pad else 0)
+        self.batch, self.num_legs = int(batch), int(num_legs)
         lb, le = leg_range if leg_range is not None else (0, self.num_legs)
         self._h = self._L.gar_hip_solver_create_sharded(
             int(device), self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
@@ -204,14 +216,15 @@ class BatchedRiccatiSolver:
         """One problem as the contiguous device record (csrc/gar_layout.h)."""
         buf = np.zeros(self.problem_doubles)
         nx0 = int(self.dims[0, 0])
-        buf[self.G0_off:self.G0_off + self.nc0 * nx0] = _f64(problem.G0).ravel(order="F")
-        buf[self.g0_off:self.g0_off + self.nc0] = problem.g0
+        G0, g0 = self._pad_init(problem.G0, problem.g0)
+        buf[self.G0_off:self.G0_off + self.nc0 * nx0] = _f64(G0).ravel(order="F")
+        buf[self.g0_off:self.g0_off + self.nc0] = g0
         for t, k in enumerate(problem.stages):
             nx, nu, nc, nx2, nth = (int(v) for v in self.dims[t])
             if (k.nx, k.nu, k.nc, k.nx2) != tuple(int(v) for v in self.user_dims[t, :4]):
                 raise ValueError(f"knot {t}: dimensions differ from the solver's")
-            if self._nup:
-                k = _pad_knot(k, self._nup)
+            if self._nxp:
+                k = _pad_knot(k, self._nxp, self._nup)
             stored = nth if self.num_legs == 1 else 0
             p = int(self.stage_offsets[t, 0])
             for name, shp in block_shapes(nx, nu, nc, nx2, stored).items():
@@ -234,12 +247,24 @@ class BatchedRiccatiSolver:
                 n = int(np.prod(shp))
                 getattr(k, name)[...] = buf[p:p + n].reshape(shp, order="F")
                 p += n
-            knots.append(_unpad_knot(k, int(self.user_dims[t, 1])) if self._nup else k)
-        prob = LqrProblem(knots, self.nc0)
+            knots.append(_unpad_knot(k, int(self.user_dims[t, 0]), int(self.user_dims[t, 1]))
+                         if self._nxp else k)
+        prob = LqrProblem(knots, self.user_nc0)
         nx0 = int(self.dims[0, 0])
-        prob.G0[...] = buf[self.G0_off:self.G0_off + self.nc0 * nx0].reshape((self.nc0, nx0), order="F")
-        prob.g0[...] = buf[self.g0_off:self.g0_off + self.nc0]
+        G0 = buf[self.G0_off:self.G0_off + self.nc0 * nx0].reshape((self.nc0, nx0), order="F")
+        prob.G0[...] = G0[:self.user_nc0, :int(self.user_dims[0, 0])]
+        prob.g0[...] = buf[self.g0_off:self.g0_off + self.user_nc0]
         return prob
+
+    def _pad_init(self, G0, g0):
+        """[G0 0; 0 -I], [g0; 0]: the dummy states start (and stay) at zero."""
+        if not self._nxp:
+            return G0, g0
+        nx, pad = int(self.user_dims[0, 0]), self.nc0 - self.user_nc0
+        G0p = np.zeros((self.nc0, self._nxp))
+        G0p[:self.user_nc0, :nx] = G0
+        G0p[self.user_nc0:, nx:] = -np.eye(pad)
+        return G0p, np.concatenate([np.asarray(g0, dtype=np.float64), np.zeros(pad)])
 
     def upload(self, problems: Sequence[LqrProblem], b0: int = 0):
         packed = np.concatenate([self.pack(p) for p in problems])
@@ -285,8 +310,8 @@ class BatchedRiccatiSolver:
     def pack_derivs(self, derivs, init) -> np.ndarray:
         """One problem's derivative buffer (csrc/gar_layout.h, gar_deriv_layout): header
         G0 | g0 | init Hxx, then one record per stage in DERIV_BLOCKS order."""
-        if self._nup:
-            raise NotImplementedError("derivative records of a control-padded solver")
+        if self._nxp:
+            raise NotImplementedError("derivative records of a padded solver")
         buf = np.zeros(self.deriv_doubles)
         off = np.zeros(4, dtype=np.int64)
         for t, d in enumerate(derivs):
@@ -312,12 +337,13 @@ class BatchedRiccatiSolver:
 
     def upload_knot(self, b: int, t: int, k: LqrKnot):
         """gar_hip_upload_stage: the 16 separately allocated blocks of LqrKnotTpl."""
-        if self._nup:
-            k = _pad_knot(k, self._nup)
+        if self._nxp:
+            k = _pad_knot(k, self._nxp, self._nup)
         a = {n: _f64(getattr(k, n)) for n in BLOCK_NAMES}
         self._check(self._L.gar_hip_upload_stage(self._h, b, t, *[_ptr(a[n]) for n in BLOCK_NAMES]))
 
     def set_init(self, b: int, G0, g0):
+        G0, g0 = self._pad_init(np.asarray(G0), np.asarray(g0))
         G0, g0 = _f64(G0), _f64(g0)
         self._check(self._L.gar_hip_set_init(self._h, b, _ptr(G0), _ptr(g0)))
 
@@ -376,8 +402,11 @@ class BatchedRiccatiSolver:
         lbdas = list(np.split(Lb, np.cumsum(ldim)[:-1]))
         if d[N, 1] == 0:
             us.pop()
-        if self._nup:
-            us = [u[:int(self.user_dims[t, 1])] for t, u in enumerate(us)]
+        if self._nxp: # drop the dummy states / controls / multipliers (exactly zero)
+            ud = self.user_dims
+            xs = [x[:int(ud[t, 0])] for t, x in enumerate(xs)]
+            us = [u[:int(ud[t, 1])] for t, u in enumerate(us)]
+            lbdas = [lbdas[0][:self.user_nc0]] + [l[:int(ud[t, 3])] for t, l in enumerate(lbdas[1:])]
         return xs, us, vs, lbdas
 
     def factor(self, t: int, b: int = 0) -> _FactorView:
@@ -393,10 +422,6 @@ class BatchedRiccatiSolver:
         f.fb = np.zeros((nr, nx))
         f.fth = np.zeros((nr, nth))
         self._check(self._L.gar_hip_get_gains(self._h, b, t, _ptr(f.ff), _ptr(f.fb), _ptr(f.fth)))
-        if self._nup and nu > 0: # drop the rows of the dummy controls (exactly zero)
-            unu = int(self.user_dims[t, 1])
-            keep = np.r_[0:unu, nu:nr]
-            f.nu, f.ff, f.fb, f.fth = unu, f.ff[keep], np.ascontiguousarray(f.fb[keep]), np.ascontiguousarray(f.fth[keep])
         vm = _ValueView()
         vm.Vxx = np.zeros((nx, nx), order="F")
         vm.vx = np.zeros(nx)
@@ -406,6 +431,19 @@ class BatchedRiccatiSolver:
         self._check(self._L.gar_hip_get_value(self._h, b, t, _ptr(vm.Vxx), _ptr(vm.vx),
                                               _ptr(vm.Vxt), _ptr(vm.Vtt), _ptr(vm.vt)))
         f.vm = vm
+        if self._nxp: # drop the rows / columns of the dummy controls and states
+            unx, unu = int(self.user_dims[t, 0]), int(self.user_dims[t, 1])
+            uth = unx if nth > 0 else 0
+            keep = np.r_[0:unu, nu:nu + unx]
+            f.nx, f.nu, f.nx2, f.nth = unx, unu, unx, uth
+            f.ff = f.ff[keep]
+            f.fb = np.ascontiguousarray(f.fb[keep][:, :unx])
+            f.fth = np.ascontiguousarray(f.fth[keep][:, :uth])
+            vm.Vxx = np.asfortranarray(vm.Vxx[:unx, :unx])
+            vm.vx = vm.vx[:unx]
+            vm.Vxt = np.asfortranarray(vm.Vxt[:unx, :uth])
+            vm.Vtt = np.asfortranarray(vm.Vtt[:uth, :uth])
+            vm.vt = vm.vt[:uth]
         self._factors_cache[key] = f
         return f
 
@@ -417,6 +455,10 @@ class BatchedRiccatiSolver:
         ff, fth = np.zeros(n0), np.zeros((n0, nth))
         g, H = np.zeros(nth), np.zeros((nth, nth), order="F")
         self._check(self._L.gar_hip_get_initial(self._h, b, _ptr(ff), _ptr(fth), _ptr(g), _ptr(H)))
+        if self._nxp: # kkt0.ff = [x0; lbd0]: the real entries of each part
+            unx = int(self.user_dims[0, 0])
+            keep = np.r_[0:unx, nx0:nx0 + self.user_nc0]
+            ff, fth = ff[keep], fth[keep]
         return ff, fth, g, H
 
     def cycle_append(self, dims5):
@@ -426,10 +468,11 @@ class BatchedRiccatiSolver:
             ud[:self.horizon - 1] = self.user_dims[1:self.horizon]
             ud[self.horizon - 1] = d
             self.user_dims = ud
-        if self._nup:
+        if self._nxp:
             if tuple(d) != tuple(self.user_dims[0]):
-                raise ValueError("cycle_append on a control-padded solver needs a knot of the same dimensions")
+                raise ValueError("cycle_append on a padded solver needs a knot of the same dimensions")
             d = d.copy()
+            d[0] = d[3] = self._nxp
             d[1] = self._nup
         self._check(self._L.gar_hip_cycle_append(self._h, d.ctypes.data_as(C.POINTER(C.c_int32))))
         N = self.horizon

@@ -199,28 +199,41 @@ public:
 
 namespace detail {
 
-// Control padding (same rule as aligator_amd/gar.py::_padded_controls): a uniform unconstrained
-// problem whose nu is not a multiple of 4 runs on the specialised kernels of (nx, 4*ceil(nu/4))
-// with DUMMY controls (R = I, S = 0, B = 0, r = 0 on the padding): they solve to exactly zero,
-// decouple, and are stripped from the gains and the solution.  Returns the padded nu, or 0.
-inline uint padded_controls(const LqrProblem &p) {
+// Padding onto a specialised shape (same rule as aligator_amd/gar.py::_padded_dims): a uniform
+// unconstrained, unparameterised problem whose (nx, nu) has no kernel of its own runs on the smallest
+// specialised shape (NX >= nx, NU >= nu) with DUMMY controls (R = I, S = 0, B = 0, r = 0) and DUMMY
+// states (Q = I, A = 0, f = 0, pinned by extra rows [0 -I] x0 = 0 of the initial constraint): both
+// solve to exactly zero, decouple, and are stripped from every result.  {0, 0}: no padding.
+struct PaddedDims {
+  uint nx = 0, nu = 0;
+  explicit operator bool() const { return nx != 0; }
+};
+inline PaddedDims padded_dims(const LqrProblem &p) {
   const int N = p.horizon();
   if (N < 1)
-    return 0;
+    return {};
   const uint nx = p.stages[0].nx, nu = p.stages[0].nu;
-  if (nu == 0 || nu % 4 == 0)
-    return 0;
+  if (nu == 0)
+    return {};
   for (int t = 0; t <= N; ++t) {
     const LqrKnot &k = p.stages[t];
     if (k.nx != nx || k.nx2 != nx || k.nc != 0 || k.nth != 0 || k.nu != (t < N ? nu : 0u))
-      return 0;
+      return {};
   }
-  const uint nup = 4 * ((nu + 3) / 4);
   const uint shapes[][2] = {{36, 12}, {32, 12}, {16, 8}, {12, 8}, {12, 4}, {8, 4}};
-  for (auto &sh : shapes)
-    if (sh[0] == nx && sh[1] == nup)
-      return nup;
-  return 0;
+  PaddedDims best;
+  uint best_cost = ~0u;
+  for (auto &sh : shapes) {
+    if (sh[0] == nx && sh[1] == nu)
+      return {}; // compiled in as it is
+    const uint cost = sh[0] * (sh[0] + sh[1]);
+    if (sh[0] >= nx && sh[1] >= nu && cost < best_cost) {
+      best_cost = cost;
+      best.nx = sh[0];
+      best.nu = sh[1];
+    }
+  }
+  return best;
 }
 
 // the six virtuals over the C ABI, shared by the two solvers
@@ -244,46 +257,55 @@ public:
       if (t < N)
         nls += k.nx2;
     }
-    if (nup_)
-      nus = (size_t)nup_ * (size_t)N;
+    if (pad_) { // the device solution carries the dummy states / controls (exactly zero): drop them
+      const size_t nxd = pad_.nx, nud = pad_.nu, nx = problem_->stages[0].nx;
+      const size_t nc0d = problem_->nc0() + (nxd - nx);
+      VectorXs X(nxd * (size_t)(N + 1)), U(nud * (size_t)N + 1), V(1), L(nc0d + nxd * (size_t)N + 1);
+      check(gar_hip_get_solution(h_, 0, X.data(), U.data(), V.data(), L.data()));
+      for (size_t t = 0; t < xs.size(); ++t)
+        std::copy(X.begin() + (long)(t * nxd), X.begin() + (long)(t * nxd + xs[t].size()), xs[t].begin());
+      for (size_t t = 0; t < us.size(); ++t)
+        std::copy(U.begin() + (long)(t * nud), U.begin() + (long)(t * nud + us[t].size()), us[t].begin());
+      std::copy(L.begin(), L.begin() + (long)lbdas[0].size(), lbdas[0].begin()); // user rows of G0 first
+      for (size_t t = 1; t < lbdas.size(); ++t) {
+        const long o = (long)(nc0d + (t - 1) * nxd);
+        std::copy(L.begin() + o, L.begin() + o + (long)lbdas[t].size(), lbdas[t].begin());
+      }
+      return true;
+    }
     VectorXs X(nxs), U(nus + 1), V(nvs + 1), L(nls + 1);
     check(gar_hip_get_solution(h_, 0, X.data(), U.data(), V.data(), L.data()));
     scatter(X, xs);
-    if (nup_) { // the device solution carries the dummy controls (exactly zero): drop them
-      for (size_t t = 0; t < us.size(); ++t)
-        std::copy(U.begin() + (long)(t * nup_), U.begin() + (long)(t * nup_ + us[t].size()),
-                  us[t].begin());
-    } else {
-      scatter(U, us);
-    }
+    scatter(U, us);
     scatter(V, vs);
     scatter(L, lbdas);
     return true;
   }
   void cycleAppend(const LqrKnot &knot) override {
-    const int32_t d[5] = {(int)knot.nx, (int)(nup_ && knot.nu ? nup_ : knot.nu), (int)knot.nc,
-                          (int)knot.nx2, (int)knot.nth};
+    const int32_t d[5] = {(int)dev_nx(knot), (int)dev_nu(knot), (int)knot.nc, (int)dev_nx(knot),
+                          (int)knot.nth};
     check(gar_hip_cycle_append(h_, d));
   }
   VectorXs getFeedforward(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
-    const uint nud = dev_nu(k);
-    VectorXs ff(nud + k.nc + k.nx2);
+    const uint nud = dev_nu(k), nxd = dev_nx(k);
+    VectorXs ff(nud + k.nc + nxd);
     check(gar_hip_get_gains(h_, 0, (int)i, ff.data(), nullptr, nullptr));
+    ff.resize(nud + k.nc + k.nx2);                 // rows of the dummy co-states (last)
     ff.erase(ff.begin() + k.nu, ff.begin() + nud); // rows of the dummy controls
     return ff;
   }
   Matrix getFeedback(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
-    const uint nud = dev_nu(k);
-    const int nrd = (int)(nud + k.nc + k.nx2), nr = (int)(k.nu + k.nc + k.nx2);
-    std::vector<double> rm((size_t)nrd * k.nx);
+    const uint nud = dev_nu(k), nxd = dev_nx(k);
+    const int nrd = (int)(nud + k.nc + nxd), nr = (int)(k.nu + k.nc + k.nx2);
+    std::vector<double> rm((size_t)nrd * nxd);
     check(gar_hip_get_gains(h_, 0, (int)i, nullptr, rm.data(), nullptr));
     Matrix fb(nr, (int)k.nx);
     for (int r = 0; r < nr; ++r) {
       const int rd = r < (int)k.nu ? r : r + (int)(nud - k.nu);
       for (uint j = 0; j < k.nx; ++j)
-        fb(r, (int)j) = rm[(size_t)rd * k.nx + j];
+        fb(r, (int)j) = rm[(size_t)rd * nxd + j];
     }
     return fb;
   }
@@ -291,15 +313,16 @@ public:
 
 protected:
   HipSolver(LqrProblem &problem, int num_legs, int device)
-      : problem_(&problem), nup_(padded_controls(problem)) {
+      : problem_(&problem), pad_(padded_dims(problem)) {
     const int N = problem.horizon();
     std::vector<int32_t> dims5;
     for (const LqrKnot &k : problem.stages) {
-      const int32_t d[5] = {(int)k.nx, (int)dev_nu(k), (int)k.nc, (int)k.nx2,
+      const int32_t d[5] = {(int)dev_nx(k), (int)dev_nu(k), (int)k.nc, (int)(pad_ ? pad_.nx : k.nx2),
                             num_legs > 1 ? 0 : (int)k.nth};
       dims5.insert(dims5.end(), d, d + 5);
     }
-    h_ = gar_hip_solver_create(device, N, dims5.data(), (int)problem.nc0(), 1, num_legs);
+    const uint nc0d = problem.nc0() + (pad_ ? pad_.nx - problem.stages[0].nx : 0u);
+    h_ = gar_hip_solver_create(device, N, dims5.data(), (int)nc0d, 1, num_legs);
     if (!h_)
       throw std::runtime_error(gar_hip_last_error());
   }
@@ -307,7 +330,7 @@ protected:
   void upload() const {
     const auto &st = problem_->stages;
     for (int t = 0; t < (int)st.size(); ++t) {
-      if (nup_ && st[t].nu > 0) {
+      if (pad_) {
         const LqrKnot k = pad(st[t]);
         check(gar_hip_upload_stage(h_, 0, t, k.Q.data(), k.S.data(), k.R.data(), k.q.data(),
                                    k.r.data(), k.A.data(), k.B.data(), k.f.data(), k.C.data(),
@@ -320,6 +343,19 @@ protected:
                                  k.r.data(), k.A.data(), k.B.data(), k.f.data(), k.C.data(),
                                  k.D.data(), k.d.data(), k.Gth.data(), k.Gx.data(), k.Gu.data(),
                                  k.Gv.data(), k.gamma.data()));
+    }
+    if (pad_ && pad_.nx > st[0].nx) { // G0' = [G0 0; 0 -I], g0' = [g0; 0]
+      const int nx = (int)st[0].nx, nxd = (int)pad_.nx, nc0 = (int)problem_->nc0();
+      Matrix G(nc0 + nxd - nx, nxd);
+      VectorXs g((size_t)(nc0 + nxd - nx), 0.0);
+      for (int j = 0; j < nx; ++j)
+        for (int i = 0; i < nc0; ++i)
+          G(i, j) = problem_->G0(i, j);
+      for (int j = nx; j < nxd; ++j)
+        G(nc0 + j - nx, j) = -1.0;
+      std::copy(problem_->g0.begin(), problem_->g0.end(), g.begin());
+      check(gar_hip_set_init(h_, 0, G.data(), g.data()));
+      return;
     }
     check(gar_hip_set_init(h_, 0, problem_->G0.data(), problem_->g0.data()));
   }
@@ -334,25 +370,36 @@ protected:
       p += v.size();
     }
   }
-  uint dev_nu(const LqrKnot &k) const { return (nup_ && k.nu > 0) ? nup_ : k.nu; }
+  uint dev_nu(const LqrKnot &k) const { return (pad_ && k.nu > 0) ? pad_.nu : k.nu; }
+  uint dev_nx(const LqrKnot &k) const { return pad_ ? pad_.nx : k.nx; }
   LqrKnot pad(const LqrKnot &k) const {
-    LqrKnot p(k.nx, nup_, k.nc, k.nx2, k.nth);
-    p.Q = k.Q; p.q = k.q; p.A = k.A; p.f = k.f; p.C = k.C; p.d = k.d;
+    const uint nxd = pad_.nx, nud = dev_nu(k);
+    LqrKnot p(nxd, nud, 0, nxd, 0);
+    for (uint j = 0; j < k.nx; ++j) {
+      for (uint i = 0; i < k.nx; ++i) {
+        p.Q((int)i, (int)j) = k.Q((int)i, (int)j);
+        p.A((int)i, (int)j) = k.A((int)i, (int)j);
+      }
+      p.q[j] = k.q[j];
+      p.f[j] = k.f[j];
+    }
+    for (uint j = k.nx; j < nxd; ++j)
+      p.Q((int)j, (int)j) = 1.0;
     for (uint j = 0; j < k.nu; ++j) {
-      for (uint i = 0; i < k.nx; ++i)
+      for (uint i = 0; i < k.nx; ++i) {
         p.S((int)i, (int)j) = k.S((int)i, (int)j);
-      for (uint i = 0; i < k.nx2; ++i)
         p.B((int)i, (int)j) = k.B((int)i, (int)j);
+      }
       for (uint i = 0; i < k.nu; ++i)
         p.R((int)i, (int)j) = k.R((int)i, (int)j);
       p.r[j] = k.r[j];
     }
-    for (uint j = k.nu; j < nup_; ++j)
+    for (uint j = k.nu; j < nud; ++j)
       p.R((int)j, (int)j) = 1.0;
     return p;
   }
   LqrProblem *problem_;
-  uint nup_ = 0; // padded control dimension on the device (0: no padding)
+  PaddedDims pad_; // device dimensions when the problem is padded onto a specialised shape
   gar_hip_solver *h_ = nullptr;
 };
 

@@ -183,12 +183,13 @@ static void parallel_solver_class(uint num_threads) {
   parSolver.collapseFeedback();
 }
 
-// BASELINE.json configs[2] shape (nx = 12, nu = 6): runs on the (12, 8) kernels with two dummy
-// controls, which must not show in the gains or the solution
-static void padded_controls_shape() {
-  std::printf("padded_controls_shape (nx=12, nu=6)\n");
+// BASELINE.json configs[2] shape (nx = 12, nu = 6) runs on the (12, 8) kernels with two dummy
+// controls; (10, 3) on the (12, 4) kernels with two dummy states and one dummy control.  Neither
+// may show in the gains or the solution.
+static void padded_shape(uint nx, uint nu, const char *kernel) {
+  std::printf("padded_shape (nx=%u, nu=%u)\n", nx, nu);
   std::mt19937 rng(17);
-  const uint nx = 12, nu = 6, horz = g_small ? 9 : 64;
+  const uint horz = g_small ? 9 : 64;
   auto problem = generate_problem(rng, VectorXs(nx, 0.3), horz, nx, nu);
   ProximalRiccatiSolver solver{problem};
   solver.backward(1e-12);
@@ -197,6 +198,9 @@ static void padded_controls_shape() {
   REQUIRE(us[0].size() == nu);
   REQUIRE(lqrComputeKktError(problem, xs, us, vs, lbdas, 1e-12).max <= 1e-9);
   REQUIRE(solver.getFeedback(0).rows == (int)(nu + nx));
+  REQUIRE(solver.getFeedback(0).cols == (int)nx);
+  REQUIRE(solver.getFeedforward(0).size() == nu + nx);
+  REQUIRE(std::string(solver.kernelName()).find(kernel) != std::string::npos);
   ParallelRiccatiSolver par(problem, 3);
   par.backward(1e-12);
   auto [xp, up, vp, lp] = lqrInitializeSolution(problem);
@@ -205,6 +209,7 @@ static void padded_controls_shape() {
               maxdiff(xp, xs));
   REQUIRE(maxdiff(xp, xs) <= 1e-9);
   REQUIRE(maxdiff(up, us) <= 1e-9);
+  REQUIRE(maxdiff(lp, lbdas) <= 1e-8);
 }
 
 static void error_behaviour() {
@@ -249,7 +254,8 @@ int main() {
   riccati_random_large_problem();
   for (uint th : {2u, 4u, 8u})
     parallel_solver_class(th);
-  padded_controls_shape();
+  padded_shape(12, 6, "12,8");
+  padded_shape(10, 3, "12,4");
   error_behaviour();
   std::printf(g_failed ? "%d REQUIRE(s) FAILED\n" : "all passed\n", g_failed);
   return g_failed ? 1 : 0;

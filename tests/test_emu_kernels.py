@@ -76,11 +76,28 @@ def test_heterogeneous_dimensions():
     pc.check_serial(prob, 1e-10, 1e-9, EMU, kkt_tol=1e-9)
 
 
-@pytest.mark.parametrize("nthreads,horz,nx,nu", [(2, 11, 4, 2), (4, 17, 6, 3), (3, 13, 12, 6)])
-def test_parallel_solver_class(nthreads, horz, nx, nu):       # tests/gar/parallel.cpp:185-245
+@pytest.mark.parametrize("pad,nthreads,horz,nx,nu", [("1", 2, 11, 4, 2), ("1", 4, 17, 6, 3), ("1", 3, 13, 12, 6),
+                                                     ("0", 2, 11, 4, 2), ("0", 4, 17, 6, 3)])
+def test_parallel_solver_class(monkeypatch, pad, nthreads, horz, nx, nu):       # tests/gar/parallel.cpp:185-245
+    # pad = 1: these shapes are padded onto the (8,4) / (12,8) kernels; pad = 0: the generic kernels
+    monkeypatch.setenv("GAR_HIP_PAD", pad)
     rng = np.random.default_rng(17)
     prob = synth.generate_lq_problem(rng, np.zeros(nx), horz, nx, nu)
     pc.check_parallel(prob, 1e-9, nthreads, 1e-7, EMU, rounds=1, rng=rng)
+
+
+@pytest.mark.parametrize("nx,nu,horz,legs,kernel", [(10, 3, 7, 3, "12,4"), (13, 5, 6, 2, "16,8"), (7, 2, 9, 1, "8,4")])
+def test_padded_states_and_controls(nx, nu, horz, legs, kernel):
+    """Shapes that are not compiled in run on the next larger specialised kernel: the Python mirror
+    adds pinned dummy states (Q = I, A = 0, rows [0 -I] of G0) and dummy controls (R = I, B = 0) and
+    strips them from every result, so the caller sees the reference's dimensions (gar.py::_pad_knot)."""
+    rng = np.random.default_rng(nx * 7 + nu)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+    s, _, _ = pc.check_serial(prob, 1e-10, 1e-9, EMU, kkt_tol=1e-9)
+    assert kernel in s._impl.kernel_name and tuple(s._impl.user_dims[0][:2]) == (nx, nu)
+    if legs > 1:
+        par = pc.check_parallel(prob, 1e-10, legs, 1e-8, EMU, rounds=1, rng=rng)
+        assert par._impl.kernel_name.startswith("wave_leg<")
 
 
 @pytest.mark.parametrize("nthreads,horz,nx,nu", [(3, 11, 8, 4), (2, 7, 12, 4), (3, 6, 16, 8)])

@@ -356,6 +356,19 @@ def _lq_from_blocks(A, B, c, Q, R, q, r, Qt, x0, horz):
     return prob
 
 
+@pytest.mark.parametrize("nx,nu,horz,legs,kernel", [(30, 10, 40, 4, "32,12"), (10, 3, 33, 3, "12,4"),
+                                                    (13, 5, 25, 2, "16,8"), (7, 2, 19, 4, "8,4")])
+def test_padded_states_and_controls(nx, nu, horz, legs, kernel):
+    """Uniform unconstrained shapes without a kernel of their own: padded by the host mirror onto the
+    smallest specialised shape (dummy states pinned through G0, dummy controls), results stripped."""
+    rng = np.random.default_rng(nx * 7 + nu)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+    s, _, _ = pc.check_serial(prob, 1e-10, 1e-9, kkt_tol=1e-9)
+    assert kernel in s._impl.kernel_name and tuple(s._impl.user_dims[0][:2]) == (nx, nu)
+    par = pc.check_parallel(prob, 1e-10, legs, 1e-8, rounds=1, rng=rng)
+    assert par._impl.kernel_name.startswith("wave_leg<")
+
+
 def test_config0_lqr_plumbing_shape():
     """BASELINE.json configs[0] (tests/lqr.cpp:30-57, bench/lqr.cpp): random dense LQR, nx=4,
     nu=2, A = I with a random lower-right 2x2, B ~ N(0,1), Q = M^T M, R = M^T M, terminal cost 10 Q,

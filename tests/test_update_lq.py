@@ -38,7 +38,7 @@ def random_derivs(rng, dims, nc0):
 def run_case(lib_path, dims, nc0, batch, preg, hess_exact, device):
     from aligator_amd.gar import BatchedRiccatiSolver
     rng = np.random.default_rng(77)
-    s = BatchedRiccatiSolver(dims, nc0, batch=batch, lib_path=lib_path)
+    s = BatchedRiccatiSolver(dims, nc0, batch=batch, lib_path=lib_path, pad_controls=False)  # device records = the caller's dims
     host_probs, bufs = [], []
     for b in range(batch):
         derivs, init = random_derivs(rng, dims, nc0)
