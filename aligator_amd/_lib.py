@@ -27,6 +27,7 @@ SIGNATURES = {
     "gar_hip_solver_create": (C.c_void_p, [C.c_int, C.c_int, _PI32, C.c_int, C.c_int, C.c_int]),
     "gar_hip_solver_create_sharded": (C.c_void_p, [C.c_int, C.c_int, _PI32, C.c_int, C.c_int,
                                                    C.c_int, C.c_int, C.c_int]),
+    "gar_hip_solver_create_dense": (C.c_void_p, [C.c_int, C.c_int, _PI32, C.c_int, C.c_int]),
     "gar_hip_solver_destroy": (None, [C.c_void_p]),
     "gar_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gar_hip_sync": (C.c_int, [C.c_void_p]),

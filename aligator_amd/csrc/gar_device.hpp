@@ -147,11 +147,11 @@ template <int MODE> __device__ __forceinline__ int bk_idx(int i, int j, int lda)
 // compiler cannot prove that a(i,j+1) does not alias the store to a(i,j), and would otherwise
 // serialise one LDS round trip per element); indices advance incrementally.
 template <int MODE>
-__device__ __forceinline__ void bk_update_row(double *a, int lda, int i, int k, double aik,
-                                              double d11) {
-  int pij = bk_idx<MODE>(i, k + 1, lda), pjk = bk_idx<MODE>(k + 1, k, lda);
-  int j = k + 1;
-  for (; j + 8 <= i + 1; j += 8) {
+__device__ __forceinline__ void bk_update_row_range(double *a, int lda, int i, int k, double aik,
+                                                    double d11, int jbeg, int jend) {
+  int pij = bk_idx<MODE>(i, jbeg, lda), pjk = bk_idx<MODE>(jbeg, k, lda);
+  int j = jbeg;
+  for (; j + 8 <= jend; j += 8) {
     double wv[8], v[8];
     int pp[8];
 #pragma unroll
@@ -169,12 +169,17 @@ __device__ __forceinline__ void bk_update_row(double *a, int lda, int i, int k, 
       a[pp[q]] = v[q];
     pjk += 8;
   }
-  for (; j <= i; ++j) {
+  for (; j < jend; ++j) {
     const double d11xj = a[pjk] * d11;
     a[pij] -= d11xj * aik;
     pij += (MODE == GAR_PACKED_LOWER) ? lda - j - 1 : lda;
     pjk += 1;
   }
+}
+template <int MODE>
+__device__ __forceinline__ void bk_update_row(double *a, int lda, int i, int k, double aik,
+                                              double d11) {
+  bk_update_row_range<MODE>(a, lda, i, k, aik, d11, k + 1, i + 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -314,24 +319,65 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
         subdiag[2 * w.wave + 1] = (double)bi;
       }
       wg_bar(w);
-    }
-    if (w.tid == 0) {
+      // Every thread combines the per-wave results (a handful of broadcast reads) and takes the
+      // decision itself; when the first test of the rule fails, the row maximum of the candidate
+      // (:62-70) is found by the whole group as well -- one more barrier instead of a serial scan
+      // of up to n elements by thread 0.
+      double colmax = subdiag[0];
+      int imax = (int)subdiag[1];
+      for (int q = 1; q < w.nwaves; ++q) {
+        const double v = subdiag[2 * q];
+        const int iq = (int)subdiag[2 * q + 1];
+        if (v > colmax || (v == colmax && iq < imax)) {
+          colmax = v;
+          imax = iq;
+        }
+      }
+      if (colmax < 0.0) {
+        colmax = 0.0;
+        imax = k + 1;
+      }
+      const double abs_akk = fabs(GA(k, k));
+      int k_step = 1, kp = k, fail = 0;
+      if (fmax(abs_akk, colmax) == 0.0) {
+        fail = 1;
+      } else if (!(abs_akk >= colmax * alpha)) {
+        double rv = 0.0;
+        for (int i = k + w.tid; i < n; i += w.nthr) {
+          if (i < imax)
+            rv = fmax(rv, fabs(GA(imax, i)));
+          else if (i > imax)
+            rv = fmax(rv, fabs(GA(i, imax)));
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+          rv = fmax(rv, __shfl_xor(rv, off));
+        if (w.lane == 0)
+          subdiag[2 * w.nwaves + w.wave] = rv; // n >= 17 > 3 nwaves here
+        wg_bar(w);
+        double rowmax = subdiag[2 * w.nwaves];
+        for (int q = 1; q < w.nwaves; ++q)
+          rowmax = fmax(rowmax, subdiag[2 * w.nwaves + q]);
+        if (abs_akk >= (alpha * colmax) * (colmax / rowmax)) {
+          kp = k;
+        } else if (fabs(GA(imax, imax)) >= alpha * rowmax) {
+          kp = imax;
+        } else {
+          kp = imax;
+          k_step = 2;
+        }
+      }
+      if (w.tid == 0) {
+        ctrl[0] = k_step;
+        ctrl[1] = kp;
+        ctrl[2] = fail;
+      }
+    } else if (w.tid == 0) {
       int k_step = 1, kp, fail = 0;
       const double abs_akk = fabs(GA(k, k));
       int imax = k + 1;
       double colmax = 0.0;
-      if (par_search) {
-        colmax = subdiag[0];
-        imax = (int)subdiag[1];
-        for (int q = 1; q < w.nwaves; ++q) {
-          const double v = subdiag[2 * q];
-          const int iq = (int)subdiag[2 * q + 1];
-          if (v > colmax || (v == colmax && iq < imax)) {
-            colmax = v;
-            imax = iq;
-          }
-        }
-      } else if (k + 1 < n) {
+      if (k + 1 < n) {
         colmax = fabs(GA(k + 1, k));
         for (int i = k + 2; i < n; ++i) {
           const double v = fabs(GA(i, k));
@@ -406,9 +452,15 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       // the threads touch consecutive i (conflict-free), a(j,k) is a broadcast read, and there
       // is no integer division in the loop
       // (incremental indices: element (i, j+1) is lda [- j - 1 when packed] past (i, j))
-      for (int i = k + 1 + w.tid; i < n; i += w.nthr)
-        bk_update_row<MODE>(a, lda, i, k, GA(i, k), d11);
-      (void)m;
+      // (a short trailing block leaves most of a workgroup idle with one thread per row: each row's
+      // j-range is then cut into g pieces -- every element still gets its one update of this step)
+      int g = m > 0 ? w.nthr / m : 1;
+      g = g < 1 ? 1 : (g > 8 ? 8 : g);
+      for (int idx = w.tid; idx < m * g; idx += w.nthr) {
+        const int part = idx / m, i = k + 1 + (idx - part * m), len = i - k;
+        bk_update_row_range<MODE>(a, lda, i, k, GA(i, k), d11, k + 1 + (len * part) / g,
+                                  k + 1 + (len * (part + 1)) / g);
+      }
       wg_bar(w);
       for (int i = w.tid; i < m; i += w.nthr)
         GA(k + 1 + i, k) *= d11;
@@ -424,12 +476,19 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       const double t = 1.0 / ((d11 * d22) - 1.0);
       const double d = t * d21_inv;
       const double d21 = GA(k + 1, k) * d21_inv;
-      for (int i = k + 2 + w.tid; i < n; i += w.nthr) {
-        const double aik = GA(i, k), aik1 = GA(i, k + 1);
-        for (int j = k + 2; j <= i; ++j) {
-          const double wk = ((GA(j, k) * d11) - (GA(j, k + 1) * d21)) * d;
-          const double wkp1 = ((GA(j, k + 1) * d22) - (GA(j, k) * d21)) * d;
-          GA(i, j) -= aik * wk + aik1 * wkp1;
+      {
+        const int m2 = n - k - 2;
+        int g = m2 > 0 ? w.nthr / m2 : 1;
+        g = g < 1 ? 1 : (g > 8 ? 8 : g);
+        for (int idx = w.tid; idx < m2 * g; idx += w.nthr) {
+          const int part = idx / m2, i = k + 2 + (idx - part * m2), len = i - k - 1;
+          const double aik = GA(i, k), aik1 = GA(i, k + 1);
+          const int j1 = k + 2 + (len * (part + 1)) / g;
+          for (int j = k + 2 + (len * part) / g; j < j1; ++j) {
+            const double wk = ((GA(j, k) * d11) - (GA(j, k + 1) * d21)) * d;
+            const double wkp1 = ((GA(j, k + 1) * d22) - (GA(j, k) * d21)) * d;
+            GA(i, j) -= aik * wk + aik1 * wkp1;
+          }
         }
       }
       double wk_r[2] = {0.0, 0.0}, wkp1_r[2] = {0.0, 0.0};
@@ -708,9 +767,24 @@ __device__ inline void wg_bk_solve_block(const WG &w, int n, const double *a, in
   for (int j = 0; j + 1 < n; ++j) { // unit-lower solve (:472)
     wg_bar(w);
     if (active) {
+      // four rows per round trip: the loads are issued together before the stores that follow
+      // (the compiler cannot prove that the store to x(i) does not alias the next loads)
       const double xj = GXC(j, c0);
-      for (int i = j + 1 + g0; i < n; i += ngrp)
-        GXC(i, c0) -= GA(i, j) * xj;
+      for (int i = j + 1 + g0; i < n; i += 4 * ngrp) {
+        double l[4], v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ii = i + q * ngrp;
+          l[q] = ii < n ? GA(ii, j) : 0.0;
+          v[q] = ii < n ? GXC(ii, c0) : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ii = i + q * ngrp;
+          if (ii < n)
+            GXC(ii, c0) = v[q] - l[q] * xj;
+        }
+      }
     }
   }
   wg_bar(w);
@@ -733,8 +807,21 @@ __device__ inline void wg_bk_solve_block(const WG &w, int n, const double *a, in
     wg_bar(w);
     if (active) {
       const double xi = GXC(i, c0);
-      for (int j = g0; j < i; j += ngrp)
-        GXC(j, c0) -= GA(i, j) * xi;
+      for (int j = g0; j < i; j += 4 * ngrp) {
+        double l[4], v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jj = j + q * ngrp;
+          l[q] = jj < i ? GA(i, jj) : 0.0;
+          v[q] = jj < i ? GXC(jj, c0) : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jj = j + q * ngrp;
+          if (jj < i)
+            GXC(jj, c0) = v[q] - l[q] * xi;
+        }
+      }
     }
   }
   wg_bar(w);

@@ -32,6 +32,11 @@ struct LdsPlan {
   int fx, fxn, fth, ftotal;       // forward kernel: x, x', theta
 };
 
+// LDS of the stage-dense kernels (gar_dense.hpp): KKT matrix, right-hand sides, subdiagonal, pivots
+struct DensePlan {
+  int K, R, sub, piv, total;
+};
+
 struct GenericParams {
   int init_closed;            // gar_initial_wave: closed form when G0 = +-I (0: always factorise)
   const gar_stage_meta *meta; // horizon+1 entries (device)
@@ -50,6 +55,7 @@ struct GenericParams {
   int tuple_doubles, nxb; // boundary tuple size, boundary block dim
   double mueq;
   LdsPlan lds;
+  DensePlan dense;
 };
 
 extern __shared__ double gar_smem[];

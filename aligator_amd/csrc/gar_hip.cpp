@@ -19,6 +19,7 @@
 #include "gar_wave.hpp"
 #include "gar_wave_leg.hpp"
 #include "gar_cyclic.hpp"
+#include "gar_dense.hpp"
 
 namespace {
 
@@ -67,6 +68,9 @@ struct gar_hip_solver {
   bool staged = false, dirty = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
   gar::LdsPlan lds{};
+  // RiccatiSolverDense (gar_dense.hpp): factor records carry nu+nc+2*nx2 gain rows
+  bool dense = false;
+  gar::DensePlan dense_lds{};
   int cond_lds_doubles = 0;
   std::string kernel_name = "generic";
   int last_failed = 0;
@@ -160,7 +164,7 @@ int build_layout(gar_hip_solver *s) {
     in += gar_knot_doubles(d[0], d[1], d[2], d[3], (flags[t] & GAR_KNOT_HAS_PARAM) ? d[4] : 0);
     in = (in + 1) & ~(int64_t)1; // keep records 16-byte aligned
     m.fac_off = fo;
-    fo += gar_factor_doubles(d[0], d[1], d[2], d[3], nth_eff[t]);
+    fo += gar_factor_doubles(d[0], d[1], d[2], s->dense ? 2 * d[3] : d[3], nth_eff[t]);
     fo = (fo + 1) & ~(int64_t)1;
     m.x_off = (int32_t)x; x += d[0];
     m.u_off = (int32_t)u; u += d[1];
@@ -267,6 +271,33 @@ int plan_lds(gar_hip_solver *s) {
   L.fxn = take(nxM);
   L.fth = take(nthM);
   L.ftotal = p;
+  if (s->dense) {
+    int nM = 0, rldM = 0;
+    for (const auto &m : s->meta) {
+      nM = std::max(nM, m.nu + m.nc + 2 * m.nx2);
+      rldM = std::max(rldM, 1 + m.nx + m.nth);
+    }
+    gar::DensePlan &D = s->dense_lds;
+    p = 0;
+    D.K = take(nM * (nM + 1) / 2); // packed lower triangle
+    D.R = take(nM * rldM);
+    D.sub = take(nM);
+    D.piv = take(264);
+    const int stage_total = p;
+    p = 0; // the initial stage reuses the buffer from its start (gar_backward_dense)
+    take(n0 * n0);
+    take(n0 * (1 + nth0));
+    take(n0);
+    take(264);
+    D.total = std::max(stage_total, p);
+    if (n0 > 512 || nM > 512)
+      return fail(GAR_HIP_ERR_UNSUPPORTED, "KKT dimension above 512");
+    if ((int64_t)D.total * 8 > 160 * 1024)
+      return fail(GAR_HIP_ERR_UNSUPPORTED,
+                  "stage-dense solver: stage dimensions need " + std::to_string((int64_t)D.total * 8) +
+                      " B of LDS (> 160 KiB per CU)");
+    return GAR_HIP_OK;
+  }
   if (n0 > 512 || nkM > 512)
     return fail(GAR_HIP_ERR_UNSUPPORTED, "KKT dimension above 512");
   if ((int64_t)L.total * 8 > 160 * 1024)
@@ -391,6 +422,10 @@ void select_kernel(gar_hip_solver *s) {
     s->init_closed = !(ik && std::string(ik) == "bk");
   }
   s->kernel_name = "generic";
+  if (s->dense) {
+    s->kernel_name = "dense";
+    return;
+  }
   const char *force = std::getenv("GAR_HIP_FORCE_GENERIC");
   if (force && force[0] == '1')
     return;
@@ -458,6 +493,7 @@ gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
   P.nxb = s->nxb;
   P.mueq = mueq;
   P.lds = s->lds;
+  P.dense = s->dense_lds;
   P.init_closed = s->init_closed ? 1 : 0;
   return P;
 }
@@ -540,6 +576,12 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     return GAR_HIP_OK;
   }
   gar::GenericParams P = make_params(s, mueq);
+  if (s->dense) {
+    hipLaunchKernelGGL(gar::gar_backward_dense, dim3((unsigned)s->batch), dim3(256),
+                       (size_t)s->dense_lds.total * sizeof(double), s->stream, P);
+    HIP_TRY(hipGetLastError());
+    return GAR_HIP_OK;
+  }
   if (s->mfma_kernel || s->wave_kernel) {
     gar::MfmaParams M{};
     M.prob = s->d_prob;
@@ -637,6 +679,12 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
   }
   gar::GenericParams P = make_params(s, 0.0);
   P.theta = theta_dev;
+  if (s->dense) {
+    hipLaunchKernelGGL(gar::gar_forward_dense, dim3((unsigned)s->batch), dim3(256),
+                       (size_t)s->lds.ftotal * sizeof(double), s->stream, P);
+    HIP_TRY(hipGetLastError());
+    return GAR_HIP_OK;
+  }
   const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
   hipLaunchKernelGGL(gar::gar_forward_generic, grid, dim3(256),
                      (size_t)s->lds.ftotal * sizeof(double), s->stream, P);
@@ -798,6 +846,12 @@ int allocate(gar_hip_solver *s) {
     s->staged = true;
   }
   select_kernel(s);
+  if (s->dense) {
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_backward_dense,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->dense_lds.total * sizeof(double))));
+    return GAR_HIP_OK;
+  }
   if (s->mfma_kernel)
     HIP_TRY(hipFuncSetAttribute((const void *)s->mfma_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -862,9 +916,26 @@ int64_t gar_hip_factor_doubles(const int32_t d[5]) {
   return gar_factor_doubles(d[0], d[1], d[2], d[3], d[4]);
 }
 
+namespace {
+gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int nc0, int batch,
+                            int num_legs, int leg_begin, int leg_end, bool dense);
+}
+
 gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon, const int32_t *dims5,
                                               int nc0, int batch, int num_legs, int leg_begin,
                                               int leg_end) {
+  return create_impl(device, horizon, dims5, nc0, batch, num_legs, leg_begin, leg_end, false);
+}
+
+// RiccatiSolverDense (gar/dense-riccati.hpp:19-56): serial in time, any dimensions
+gar_hip_solver *gar_hip_solver_create_dense(int device, int horizon, const int32_t *dims5, int nc0,
+                                            int batch) {
+  return create_impl(device, horizon, dims5, nc0, batch, 1, 0, 1, true);
+}
+
+namespace {
+gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int nc0, int batch,
+                            int num_legs, int leg_begin, int leg_end, bool dense) {
   if (horizon < 0 || !dims5 || nc0 < 0 || batch < 1 || num_legs < 1 || leg_begin < 0 ||
       leg_end > num_legs || leg_begin >= leg_end) {
     fail(GAR_HIP_ERR_ARG, "gar_hip_solver_create: bad argument");
@@ -883,6 +954,7 @@ gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon, const int
   s->num_legs = num_legs;
   s->leg_begin = leg_begin;
   s->leg_end = leg_end;
+  s->dense = dense;
   s->dims5.assign(dims5, dims5 + 5 * (horizon + 1));
   if (hipSetDevice(device) != hipSuccess) {
     fail(GAR_HIP_ERR_DEVICE, "hipSetDevice failed");
@@ -926,6 +998,7 @@ gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon, const int
   }
   return s;
 }
+} // namespace
 
 gar_hip_solver *gar_hip_solver_create(int device, int horizon, const int32_t *dims5, int nc0,
                                       int batch, int num_legs) {
@@ -1205,9 +1278,10 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
   if (int rc = check_bt(s, b, t))
     return rc;
   const gar_stage_meta &m = s->meta[t];
-  const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, m.nx2, m.nth);
+  const int nx2r = s->dense ? 2 * m.nx2 : m.nx2; // stage-dense solver: rows [K; Z; L; Y]
+  const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, nx2r, m.nth);
   const double *rec = s->d_fac + (int64_t)b * s->fac_doubles + m.fac_off;
-  const int64_t nr = (int64_t)m.nu + m.nc + m.nx2;
+  const int64_t nr = (int64_t)m.nu + m.nc + nx2r;
   int rc = d2h(s, ff, rec + o.ff, nr);
   std::vector<double> tmp;
   // the specialised kernel families keep fb (and fth) in the fbT2 device order
@@ -1250,7 +1324,7 @@ int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, 
   if (int rc = check_bt(s, b, t))
     return rc;
   const gar_stage_meta &m = s->meta[t];
-  const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, m.nx2, m.nth);
+  const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, s->dense ? 2 * m.nx2 : m.nx2, m.nth);
   const double *rec = s->d_fac + (int64_t)b * s->fac_doubles + m.fac_off;
   int rc = d2h(s, Vxx, rec + o.Vxx, (int64_t)m.nx * m.nx);
   rc |= d2h(s, vx, rec + o.vx, m.nx);

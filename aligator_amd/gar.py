@@ -130,8 +130,13 @@ class BatchedRiccatiSolver:
     """
 
     def __init__(self, dims, nc0: int, batch: int = 1, num_legs: int = 1, device: int = 0,
-                 leg_range=None, lib_path: Optional[str] = None, pad_controls: bool = True):
+                 leg_range=None, lib_path: Optional[str] = None, pad_controls: bool = True,
+                 dense: bool = False):
         self._L = _lib.load(lib_path)
+        self.dense = bool(dense)   # RiccatiSolverDense's algorithm (csrc/gar_dense.hpp): serial, no padding
+        if self.dense:
+            assert num_legs == 1 and leg_range is None, "the stage-dense solver is serial in time"
+            pad_controls = False
         self.user_dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int32).reshape(-1, 5))
         self.dims = self.user_dims.copy()
         self.user_nc0 = int(nc0)
@@ -146,9 +151,14 @@ class BatchedRiccatiSolver:
         self.nc0 = self.user_nc0 + (self._nxp - int(self.user_dims[0, 0]) if pad else 0)
         self.batch, self.num_legs = int(batch), int(num_legs)
         lb, le = leg_range if leg_range is not None else (0, self.num_legs)
-        self._h = self._L.gar_hip_solver_create_sharded(
-            int(device), self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
-            self.nc0, self.batch, self.num_legs, int(lb), int(le))
+        if self.dense:
+            self._h = self._L.gar_hip_solver_create_dense(
+                int(device), self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
+                self.nc0, self.batch)
+        else:
+            self._h = self._L.gar_hip_solver_create_sharded(
+                int(device), self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
+                self.nc0, self.batch, self.num_legs, int(lb), int(le))
         if not self._h:
             raise RuntimeError(self._err())
         self._refresh_layout()
@@ -415,7 +425,7 @@ class BatchedRiccatiSolver:
             return self._factors_cache[key]
         nx, nu, nc, nx2, _ = (int(v) for v in self.dims[t])
         nth = self.effective_nth(t)
-        nr = nu + nc + nx2
+        nr = nu + nc + (2 * nx2 if self.dense else nx2)   # dense: block rows [K; Z; L; Y]
         f = _FactorView()
         f.nx, f.nu, f.nc, f.nx2, f.nth = nx, nu, nc, nx2, nth
         f.ff = np.zeros(nr)
@@ -514,11 +524,13 @@ class _HipSolver(RiccatiSolverBase):
         self._device, self._lib_path = device, lib_path
         self._make(dims)
 
+    _dense = False
+
     def _make(self, dims):
         if self._num_legs > 1:
             dims = [(nx, nu, nc, nx2, 0) for (nx, nu, nc, nx2, _) in dims]
         self._impl = BatchedRiccatiSolver(dims, self.problem_.nc0, 1, self._num_legs,
-                                          self._device, lib_path=self._lib_path)
+                                          self._device, lib_path=self._lib_path, dense=self._dense)
 
     class _Datas:
         def __init__(self, impl):
@@ -589,6 +601,39 @@ class ProximalRiccatiSolver(_HipSolver):
 
     def cycleAppend(self, knot: LqrKnot) -> None:
         """proximal-riccati.hxx:79-86."""
+        self._impl.cycle_append(knot.dims)
+
+
+class RiccatiSolverDense(_HipSolver):
+    """gar::RiccatiSolverDense on the MI355X backend (gar/dense-riccati.hpp:19-56): per stage one
+    Bunch-Kaufman factorisation of the whole (nu+nc+2 nx2)^2 matrix instead of the condensation.
+    `datas[t]` holds ff / fb / fth with block rows [K; Z; L; Y] (the reference's stage_factors[t].ff,
+    .fb, .ft) and, as `vm.Vxx, vx, Vxt, Vtt, vt`, the reference's Pxx[t], px[t], Pxt[t], Ptt[t], pt[t]."""
+    _dense = True
+
+    def __init__(self, problem: LqrProblem, device: int = 0, lib_path=None):
+        super().__init__(problem, 1, device, lib_path)
+
+    def backward(self, mueq: float) -> bool:
+        self._upload()
+        return self._impl.backward(mueq)
+
+    @property
+    def kkt0(self):
+        k = _Kkt0View()
+        k.ff, k.fth, _, _ = self._impl.initial(0)
+        return k
+
+    @property
+    def thGrad(self):
+        return self._impl.initial(0)[2]
+
+    @property
+    def thHess(self):
+        return self._impl.initial(0)[3]
+
+    def cycleAppend(self, knot: LqrKnot) -> None:
+        """dense-riccati.hxx:118-146."""
         self._impl.cycle_append(knot.dims)
 
 

@@ -14,6 +14,10 @@
  *                                (gar/proximal-riccati.hxx:13-31) and
  *                                ParallelRiccatiSolver ctor + initialize()
  *                                (gar/parallel-solver.hxx:32-82, 261-287)
+ *   gar_hip_solver_create_dense  RiccatiSolverDense::RiccatiSolverDense
+ *                                (gar/dense-riccati.hxx:12-46): the stage-dense solver over
+ *                                DenseKernel (gar/dense-kernel.hpp:55-209); every other entry
+ *                                point serves it unchanged, with nu+nc+2*nx2 gain rows
  *   gar_hip_upload_stage         reads of LqrKnotTpl blocks (gar/lqr-problem.hpp:45-56);
  *                                the reference re-reads the caller's problem on every
  *                                backward() (proximal-riccati.hxx:37)
@@ -85,6 +89,13 @@ gar_hip_solver *gar_hip_solver_create(int device, int horizon, const int32_t *di
 gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon,
                                               const int32_t *dims5, int nc0, int batch,
                                               int num_legs, int leg_begin, int leg_end);
+/* RiccatiSolverDense(problem): serial in time, any dimensions.  backward() factorises the whole
+ * (nu+nc+2*nx2)^2 stage matrix (gar/dense-kernel.hpp:100-172); gar_hip_get_gains then returns
+ * ff (nu+nc+2*nx2) and fb (nu+nc+2*nx2, nx) row-major = block rows [K; Z; L; Y] as
+ * getFeedforward/getFeedback do (dense-riccati.hpp:49-50); gar_hip_get_value returns Pxx, px, Pxt,
+ * Ptt, pt (dense-riccati.hpp:32-36). */
+gar_hip_solver *gar_hip_solver_create_dense(int device, int horizon, const int32_t *dims5,
+                                            int nc0, int batch);
 void gar_hip_solver_destroy(gar_hip_solver *s);
 
 /* Launch every kernel of this solver on `hip_stream` (a hipStream_t); NULL

@@ -1,0 +1,189 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY -- never imported by the product path) for the reference's
+stage-dense solver: `RiccatiSolverDense` (include/aligator/gar/dense-riccati.hpp:19-56,
+dense-riccati.hxx:12-148) over `DenseKernel` (include/aligator/gar/dense-kernel.hpp:13-210).
+
+Restated in numpy, statement by statement; the factorisation is the oracle's restatement of the
+in-tree Bunch-Kaufman (core/bunchkaufman.hpp, `oracle.BunchKaufman`).  Parity unpinned against
+the reference BINARY (Eigen is not installed here): pinned instead against
+the independent LAPACK dense-KKT solve (oracle/dense_kkt.py) and the Riccati oracle, at the
+reference's own bar for this solver (tests/gar/riccati.cpp:141-155: KKT error <= 1e-8).
+
+One documented difference: `DenseKernel::terminalSolve` factorises the WHOLE (nu+nc+2 nx2)^2
+matrix, whose last 2 nx2 rows are zero (dense-kernel.hpp:57-74); the reference's Bunch-Kaufman
+stops at the first zero column with `NumericalIssue` (bunchkaufman.hpp:58-59), which nobody checks,
+and the solve then runs on a partial factorisation.  With nu = nc = 0 on the terminal knot (the
+reference's tests and benchmark) nothing is read from it.  `terminal_leading_block=True` (default)
+factorises the leading (nu+nc)^2 block instead -- the intended system, and what the HIP kernel
+does; `False` follows the reference literally.
+"""
+from typing import List, Optional
+
+import numpy as np
+
+from .oracle import BunchKaufman
+
+
+class DenseData:
+    """DenseKernel::Data (dense-kernel.hpp:18-44): ff / fb / ft with block rows {nu, nc, nx2, nx2}."""
+
+    def __init__(self, nx, nu, nc, nx2, nth):
+        self.dims = (nu, nc, nx2, nx2)
+        self.n = nu + nc + 2 * nx2
+        self.ff = np.zeros(self.n)
+        self.fb = np.zeros((self.n, nx))
+        self.ft = np.zeros((self.n, nth))
+        self.ldl = None
+
+    def rows(self, i):
+        o = int(np.sum(self.dims[:i]))
+        return slice(o, o + self.dims[i])
+
+
+def _solve(ldl, *rhs):
+    for x in rhs:
+        if x.size:
+            x[...] = ldl.solve(x)
+
+
+class RiccatiSolverDense:
+    """dense-riccati.hpp:19-56.  `problem` is any object with .stages (knots with the reference's
+    block names), .G0, .g0 -- e.g. aligator_amd.gar.LqrProblem or oracle.Problem views."""
+
+    def __init__(self, problem, terminal_leading_block: bool = True):
+        self.problem = problem
+        self.terminal_leading_block = terminal_leading_block
+        st = problem.stages
+        self.N = len(st) - 1
+        self.Pxx = [np.zeros((k.nx, k.nx)) for k in st]        # dense-riccati.hxx:20-34
+        self.Pxt = [np.zeros((k.nx, k.nth)) for k in st]
+        self.Ptt = [np.zeros((k.nth, k.nth)) for k in st]
+        self.px = [np.zeros(k.nx) for k in st]
+        self.pt = [np.zeros(k.nth) for k in st]
+        self.stage_factors: List[DenseData] = [DenseData(k.nx, k.nu, k.nc, k.nx2, k.nth) for k in st]
+        self.kkt0_ff = self.kkt0_fth = self.thGrad = self.thHess = None
+
+    # dense-kernel.hpp:55-98
+    def _terminal(self, k, d: DenseData, i, mueq):
+        nu, nc = k.nu, k.nc
+        m = nu + nc
+        K = np.zeros((d.n, d.n))
+        K[:nu, :nu] = k.R
+        K[:nu, nu:m] = k.D.T
+        K[nu:m, :nu] = k.D
+        K[nu:m, nu:m] = -mueq * np.eye(nc)
+        r0, r1 = d.rows(0), d.rows(1)
+        d.ff[r0] = -k.r
+        d.ff[r1] = -k.d
+        d.fb[r0] = -k.S.T
+        d.fb[r1] = -k.C
+        d.ft[r0] = -k.Gu
+        d.ft[r1] = -k.Gv
+        if self.terminal_leading_block:
+            if m:
+                d.ldl = BunchKaufman(K[:m, :m])
+                top = [d.ff[:m], d.fb[:m], d.ft[:m]]
+                _solve(d.ldl, *top)
+        else:  # the reference, literally (the factorisation's info is ignored there as well)
+            d.ldl = BunchKaufman(K)
+            _solve(d.ldl, d.ff, d.fb, d.ft)
+        Kf, Z, Kth, Zth = d.fb[r0], d.fb[r1], d.ft[r0], d.ft[r1]
+        kff, zff = d.ff[r0], d.ff[r1]
+        self.Pxx[i] = k.Q + k.S @ Kf + k.C.T @ Z
+        self.Pxt[i] = k.Gx + Kf.T @ k.Gu + Z.T @ k.Gv
+        self.Ptt[i] = k.Gth + k.Gu.T @ Kth + k.Gv.T @ Zth
+        self.px[i] = k.q + k.S @ kff + k.C.T @ zff
+        self.pt[i] = k.gamma + k.Gu.T @ kff + k.Gv.T @ zff
+
+    # dense-kernel.hpp:100-172
+    def _stage(self, k, d: DenseData, i, mueq):
+        nu, nc, nx2 = k.nu, k.nc, k.nx2
+        r0, r1, r2, r3 = (d.rows(j) for j in range(4))
+        K = np.zeros((d.n, d.n))
+        K[r0, r0] = k.R
+        K[r1, r0] = k.D
+        K[r0, r1] = k.D.T
+        K[r1, r1] = -mueq * np.eye(nc)
+        K[r2, r0] = k.B
+        K[r0, r2] = k.B.T
+        K[r2, r3] = -np.eye(nx2)
+        K[r3, r2] = -np.eye(nx2)
+        K[r3, r3] = self.Pxx[i + 1]
+        d.ldl = BunchKaufman(K)                                   # 1. factorize (:115)
+        d.ff[r0] = -k.r                                           # 2. rhs (:119-140)
+        d.ff[r1] = -k.d
+        d.ff[r2] = -k.f
+        d.ff[r3] = -self.px[i + 1]
+        d.fb[r0] = -k.S.T
+        d.fb[r1] = -k.C
+        d.fb[r2] = -k.A
+        d.fb[r3] = 0.0
+        d.ft[r0] = -k.Gu
+        d.ft[r1] = -k.Gv
+        d.ft[r2] = 0.0
+        d.ft[r3] = -self.Pxt[i + 1]
+        _solve(d.ldl, d.ff, d.fb, d.ft)                           # (:142-144)
+        Kf, Z, L, Y = (d.fb[r] for r in (r0, r1, r2, r3))
+        Kth, Zth, Yth = d.ft[r0], d.ft[r1], d.ft[r3]
+        kff, zff, lff, yff = (d.ff[r] for r in (r0, r1, r2, r3))
+        Pxt_n = self.Pxt[i + 1]
+        self.Pxx[i] = k.Q + k.S @ Kf + k.C.T @ Z + k.A.T @ L      # 3. value function (:150-171)
+        self.Pxt[i] = k.Gx + Kf.T @ k.Gu + Z.T @ k.Gv + Y.T @ Pxt_n
+        self.Ptt[i] = k.Gth + Kth.T @ k.Gu + Zth.T @ k.Gv + Yth.T @ Pxt_n
+        self.px[i] = k.q + k.S @ kff + k.C.T @ zff + k.A.T @ lff
+        self.pt[i] = k.gamma + k.Gu.T @ kff + k.Gv.T @ zff + Pxt_n.T @ yff
+
+    # dense-riccati.hxx:48-91
+    def backward(self, mueq: float) -> bool:
+        st = self.problem.stages
+        N = self.N
+        self._terminal(st[N], self.stage_factors[N], N, mueq)
+        for i in range(N - 1, -1, -1):
+            self._stage(st[i], self.stage_factors[i], i, mueq)
+        G0, g0 = np.asarray(self.problem.G0), np.asarray(self.problem.g0)
+        nc0, nx0 = G0.shape
+        K0 = np.zeros((nx0 + nc0, nx0 + nc0))
+        K0[:nx0, :nx0] = self.Pxx[0]
+        K0[:nx0, nx0:] = G0.T
+        K0[nx0:, :nx0] = G0
+        ldl = BunchKaufman(K0)
+        nth = st[0].nth
+        self.kkt0_ff = np.concatenate([-self.px[0], -g0])
+        self.kkt0_fth = np.concatenate([-self.Pxt[0], np.zeros((nc0, nth))])
+        _solve(ldl, self.kkt0_ff, self.kkt0_fth)
+        self.thGrad = self.pt[0] + self.Pxt[0].T @ self.kkt0_ff[:nx0]
+        self.thHess = self.Ptt[0] + self.Pxt[0].T @ self.kkt0_fth[:nx0]
+        return True
+
+    # dense-riccati.hxx:93-116, dense-kernel.hpp:174-209
+    def forward(self, xs, us, vs, lbdas, theta: Optional[np.ndarray] = None) -> bool:
+        st = self.problem.stages
+        nx0 = st[0].nx
+        xs[0][...] = self.kkt0_ff[:nx0]
+        lbdas[0][...] = self.kkt0_ff[nx0:]
+        if theta is not None:
+            xs[0][...] += self.kkt0_fth[:nx0] @ theta
+            lbdas[0][...] += self.kkt0_fth[nx0:] @ theta
+        for i in range(self.N + 1):
+            k, d = st[i], self.stage_factors[i]
+            r0, r1, r2, r3 = (d.rows(j) for j in range(4))
+            if k.nu > 0:
+                us[i][...] = d.ff[r0] + d.fb[r0] @ xs[i]
+            vs[i][...] = d.ff[r1] + d.fb[r1] @ xs[i]
+            if theta is not None:
+                if k.nu > 0:
+                    us[i][...] += d.ft[r0] @ theta
+                vs[i][...] += d.ft[r1] @ theta
+            if i == self.N:
+                break
+            lbdas[i + 1][...] = d.ff[r2] + d.fb[r2] @ xs[i]
+            xs[i + 1][...] = d.ff[r3] + d.fb[r3] @ xs[i]
+            if theta is not None:
+                lbdas[i + 1][...] += d.ft[r2] @ theta
+                xs[i + 1][...] += d.ft[r3] @ theta
+        return True
+
+    def getFeedforward(self, i):
+        return self.stage_factors[i].ff
+
+    def getFeedback(self, i):
+        return self.stage_factors[i].fb

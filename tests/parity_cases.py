@@ -12,9 +12,10 @@ import numpy as np
 
 from aligator_amd import synth
 from aligator_amd.gar import (BatchedRiccatiSolver, ParallelRiccatiSolver,
-                              ProximalRiccatiSolver, lqrComputeKktError,
+                              ProximalRiccatiSolver, RiccatiSolverDense, lqrComputeKktError,
                               lqrInitializeSolution)
 from oracle import oracle as ora
+from oracle.dense_riccati import RiccatiSolverDense as OracleDense
 
 TOL = {"W": 1e-9, "F": 1e-6}
 
@@ -72,6 +73,44 @@ def check_serial(prob, mueq, tol, lib_path=None, theta=None, kkt_tol=None, facto
         for a, b in ((ff, osol.kkt0_ff), (fth, osol.kkt0_fth), (g, osol.thGrad), (H, osol.thHess)):
             if a.size:
                 assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+    return solver, sol, ref
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max()) if b.size else 0.0
+
+
+def check_dense(prob, mueq, tol, lib_path=None, theta=None, kkt_tol=None):
+    """RiccatiSolverDense (tests/gar/riccati.cpp:141-155): the HIP stage-dense solver against its
+    oracle (oracle/dense_riccati.py) -- trajectory, every stage's ff / fb / ft rows [K; Z; L; Y],
+    Pxx, px, Pxt, Ptt, pt, kkt0, thGrad, thHess -- and against the Riccati oracle's trajectory."""
+    solver = RiccatiSolverDense(prob, lib_path=lib_path)
+    assert solver.kernel_name == "dense"
+    assert solver.backward(mueq)
+    sol = lqrInitializeSolution(prob)
+    assert solver.forward(*sol, theta)
+    o = OracleDense(prob)
+    o.backward(mueq)
+    ref = lqrInitializeSolution(prob)
+    o.forward(*ref, theta)
+    sc = scale_of(ref)
+    for A, B in zip(sol, ref):
+        assert maxdiff(A, B) <= tol * sc
+    _, _, ric = oracle_serial(prob, mueq, theta)
+    for A, B in zip(sol, ric):
+        assert maxdiff(A, B) <= 10 * tol * sc
+    if kkt_tol is not None:
+        assert max(lqrComputeKktError(prob, *sol, mueq=mueq, theta=theta)) <= kkt_tol
+    for t in range(prob.horizon + 1):
+        f, d = solver.datas[t], o.stage_factors[t]
+        assert f.ff.shape == d.ff.shape and f.fb.shape == d.fb.shape and f.fth.shape == d.ft.shape
+        for a, b in ((f.ff, d.ff), (f.fb, d.fb), (f.fth, d.ft), (f.vm.Vxx, o.Pxx[t]), (f.vm.vx, o.px[t]),
+                     (f.vm.Vxt, o.Pxt[t]), (f.vm.Vtt, o.Ptt[t]), (f.vm.vt, o.pt[t])):
+            assert _rel(a, b) <= tol, t
+        assert np.array_equal(solver.getFeedback(t), f.fb) and np.array_equal(solver.getFeedforward(t), f.ff)
+    for a, b in ((solver.kkt0.ff, o.kkt0_ff), (solver.kkt0.fth, o.kkt0_fth), (solver.thGrad, o.thGrad),
+                 (solver.thHess, o.thHess)):
+        assert _rel(a, b) <= tol
     return solver, sol, ref
 
 

@@ -86,6 +86,45 @@ def test_parallel_solver_class(monkeypatch, pad, nthreads, horz, nx, nu):       
     pc.check_parallel(prob, 1e-9, nthreads, 1e-7, EMU, rounds=1, rng=rng)
 
 
+@pytest.mark.parametrize("nx,nu,nc,nth,horz,mu", [(6, 3, 0, 0, 9, 1e-12), (8, 4, 3, 0, 7, 1e-6),
+                                                  (5, 2, 2, 3, 6, 1e-6), (12, 5, 0, 0, 8, 1e-10)])
+def test_dense_solver(nx, nu, nc, nth, horz, mu):               # tests/gar/riccati.cpp:141-155
+    """RiccatiSolverDense (csrc/gar_dense.hpp): unconstrained, constrained (terminal knot included),
+    parameterised with theta in the forward pass."""
+    rng = np.random.default_rng(5)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nth=nth, nc=nc, mode="W")
+    theta = rng.standard_normal(nth) if nth else None
+    pc.check_dense(prob, mu, 1e-9, EMU, theta=theta, kkt_tol=1e-8)
+
+
+def test_dense_solver_cycle_append_and_batch():
+    """cycleAppend (dense-riccati.hxx:118-146) keeps the solver usable on the rotated problem; the
+    batch axis gives every problem its own solve."""
+    from aligator_amd.gar import BatchedRiccatiSolver, RiccatiSolverDense
+    nx, nu, horz = 6, 3, 5
+    rng = np.random.default_rng(2)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+    s = RiccatiSolverDense(prob, lib_path=EMU)
+    assert s.backward(1e-10)
+    new = synth.generate_lq_problem(rng, np.zeros(nx), 1, nx, nu, mode="W").stages[0]
+    s.cycleAppend(new)
+    prob.stages[:horz - 1] = prob.stages[1:horz]
+    prob.stages[horz - 1] = new
+    pc.check_dense(prob, 1e-10, 1e-9, EMU, kkt_tol=1e-9)
+    assert s.backward(1e-10)
+    sol = pc.lqrInitializeSolution(prob)
+    s.forward(*sol)
+    assert max(pc.lqrComputeKktError(prob, *sol, mueq=1e-10)) <= 1e-9
+    probs = [synth.generate_lq_problem(40 + i, np.ones(nx), horz, nx, nu, mode="W") for i in range(3)]
+    bs = BatchedRiccatiSolver([k.dims for k in probs[0].stages], probs[0].nc0, batch=3, lib_path=EMU, dense=True)
+    bs.upload(probs)
+    assert bs.backward(1e-10) and bs.forward()
+    for b, p in enumerate(probs):
+        _, _, ref = pc.oracle_serial(p, 1e-10)
+        for A, B in zip(bs.solution(b), ref):
+            assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
+
+
 @pytest.mark.parametrize("nx,nu,horz,legs,kernel", [(10, 3, 7, 3, "12,4"), (13, 5, 6, 2, "16,8"), (7, 2, 9, 1, "8,4")])
 def test_padded_states_and_controls(nx, nu, horz, legs, kernel):
     """Shapes that are not compiled in run on the next larger specialised kernel: the Python mirror

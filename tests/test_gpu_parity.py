@@ -369,6 +369,45 @@ def test_padded_states_and_controls(nx, nu, horz, legs, kernel):
     assert par._impl.kernel_name.startswith("wave_leg<")
 
 
+@pytest.mark.parametrize("mode,horz,tol", [("W", 100, 1e-9), ("F", 50, 1e-6)])
+def test_dense_solver_random_large_problem(mode, horz, tol):   # tests/gar/riccati.cpp:141-155
+    nx, nu = 36, 12
+    prob = synth.generate_lq_problem(42, np.zeros(nx), horz, nx, nu, mode=mode)
+    pc.check_dense(prob, 1e-14, tol, kkt_tol=1e-8)
+
+
+@pytest.mark.parametrize("nx,nu,nc,nth,horz,mu", [(36, 12, 32, 0, 30, 1e-5), (16, 8, 5, 0, 40, 1e-6),
+                                                  (10, 4, 0, 2, 100, 1e-12), (7, 3, 2, 3, 25, 1e-6)])
+def test_dense_solver_constrained_and_parametric(nx, nu, nc, nth, horz, mu):
+    rng = np.random.default_rng(nx + nc)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nth=nth, nc=nc, mode="W")
+    theta = rng.uniform(-1, 1, nth) if nth else None
+    pc.check_dense(prob, mu, 1e-8, theta=theta, kkt_tol=1e-6)   # multipliers O(1/mu)
+
+
+def test_dense_solver_batch_and_cycle_append():
+    from aligator_amd.gar import BatchedRiccatiSolver
+    nx, nu, horz, mu = 36, 12, 24, 1e-12
+    probs = [synth.generate_lq_problem(900 + i, np.ones(nx), horz, nx, nu, mode="W") for i in range(40)]
+    s = BatchedRiccatiSolver([k.dims for k in probs[0].stages], probs[0].nc0, batch=len(probs), dense=True)
+    assert s.kernel_name == "dense"
+    s.upload(probs)
+    assert s.backward(mu) and s.forward()
+    for b in (0, 17, 39):
+        _, _, ref = pc.oracle_serial(probs[b], mu)
+        for A, B in zip(s.solution(b), ref):
+            assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
+    # cycleAppend (dense-riccati.hxx:118-146): records rotate on the device, the solver stays usable
+    s.cycle_append(probs[0].stages[0].dims)
+    for b, p in enumerate(probs):      # the caller writes the new last-but-one knot (here: the old first)
+        s.upload_knot(b, horz - 1, p.stages[0])
+        p.stages[:horz] = p.stages[1:horz] + [p.stages[0]]
+    assert s.backward(mu) and s.forward()
+    _, _, ref = pc.oracle_serial(probs[5], mu)
+    for A, B in zip(s.solution(5), ref):
+        assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
+
+
 def test_config0_lqr_plumbing_shape():
     """BASELINE.json configs[0] (tests/lqr.cpp:30-57, bench/lqr.cpp): random dense LQR, nx=4,
     nu=2, A = I with a random lower-right 2x2, B ~ N(0,1), Q = M^T M, R = M^T M, terminal cost 10 Q,
