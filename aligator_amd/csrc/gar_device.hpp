@@ -484,7 +484,24 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
           const int part = idx / m2, i = k + 2 + (idx - part * m2), len = i - k - 1;
           const double aik = GA(i, k), aik1 = GA(i, k + 1);
           const int j1 = k + 2 + (len * (part + 1)) / g;
-          for (int j = k + 2 + (len * part) / g; j < j1; ++j) {
+          int j = k + 2 + (len * part) / g;
+          // four elements per round trip (loads first, then the stores: see bk_update_row_range)
+          for (; j + 4 <= j1; j += 4) {
+            double ajk[4], ajk1[4], aij[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              ajk[q] = GA(j + q, k);
+              ajk1[q] = GA(j + q, k + 1);
+              aij[q] = GA(i, j + q);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const double wk = ((ajk[q] * d11) - (ajk1[q] * d21)) * d;
+              const double wkp1 = ((ajk1[q] * d22) - (ajk[q] * d21)) * d;
+              GA(i, j + q) = aij[q] - (aik * wk + aik1 * wkp1);
+            }
+          }
+          for (; j < j1; ++j) {
             const double wk = ((GA(j, k) * d11) - (GA(j, k + 1) * d21)) * d;
             const double wkp1 = ((GA(j, k + 1) * d22) - (GA(j, k) * d21)) * d;
             GA(i, j) -= aik * wk + aik1 * wkp1;

@@ -289,6 +289,11 @@ public:
   VectorXs getFeedforward(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
     const uint nud = dev_nu(k), nxd = dev_nx(k);
+    if (dense_) { // block rows [kff; zff; lff; yff] (dense-riccati.hpp:49)
+      VectorXs ffd(k.nu + k.nc + 2 * k.nx2);
+      check(gar_hip_get_gains(h_, 0, (int)i, ffd.data(), nullptr, nullptr));
+      return ffd;
+    }
     VectorXs ff(nud + k.nc + nxd);
     check(gar_hip_get_gains(h_, 0, (int)i, ff.data(), nullptr, nullptr));
     ff.resize(nud + k.nc + k.nx2);                 // rows of the dummy co-states (last)
@@ -298,7 +303,8 @@ public:
   Matrix getFeedback(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
     const uint nud = dev_nu(k), nxd = dev_nx(k);
-    const int nrd = (int)(nud + k.nc + nxd), nr = (int)(k.nu + k.nc + k.nx2);
+    const int nrd = (int)(nud + k.nc + (dense_ ? 2 * k.nx2 : nxd)), // dense: [K; Z; L; Y]
+        nr = (int)(k.nu + k.nc + (dense_ ? 2 * k.nx2 : k.nx2));
     std::vector<double> rm((size_t)nrd * nxd);
     check(gar_hip_get_gains(h_, 0, (int)i, nullptr, rm.data(), nullptr));
     Matrix fb(nr, (int)k.nx);
@@ -312,8 +318,8 @@ public:
   const char *kernelName() const { return gar_hip_kernel_name(h_); }
 
 protected:
-  HipSolver(LqrProblem &problem, int num_legs, int device)
-      : problem_(&problem), pad_(padded_dims(problem)) {
+  HipSolver(LqrProblem &problem, int num_legs, int device, bool dense = false)
+      : problem_(&problem), pad_(dense ? PaddedDims{} : padded_dims(problem)), dense_(dense) {
     const int N = problem.horizon();
     std::vector<int32_t> dims5;
     for (const LqrKnot &k : problem.stages) {
@@ -322,7 +328,8 @@ protected:
       dims5.insert(dims5.end(), d, d + 5);
     }
     const uint nc0d = problem.nc0() + (pad_ ? pad_.nx - problem.stages[0].nx : 0u);
-    h_ = gar_hip_solver_create(device, N, dims5.data(), (int)nc0d, 1, num_legs);
+    h_ = dense ? gar_hip_solver_create_dense(device, N, dims5.data(), (int)nc0d, 1)
+               : gar_hip_solver_create(device, N, dims5.data(), (int)nc0d, 1, num_legs);
     if (!h_)
       throw std::runtime_error(gar_hip_last_error());
   }
@@ -400,6 +407,7 @@ protected:
   }
   LqrProblem *problem_;
   PaddedDims pad_; // device dimensions when the problem is padded onto a specialised shape
+  bool dense_ = false; // RiccatiSolverDense: nu+nc+2*nx2 gain rows
   gar_hip_solver *h_ = nullptr;
 };
 
@@ -413,6 +421,20 @@ public:
   bool backward(const double mueq) override {
     upload();
     check(gar_hip_backward(h_, mueq)); // GAR_HIP_ERR_FACTOR -> "Failed stage LDL factorization"
+    return true;
+  }
+};
+
+// gar/dense-riccati.hpp:19-56: the stage-dense solver (one Bunch-Kaufman factorisation of the whole
+// (nu+nc+2 nx2)^2 stage matrix per knot); getFeedforward / getFeedback return the block rows
+// [K; Z; L; Y] as the reference's stage_factors[i].ff / .fb
+class RiccatiSolverDense : public detail::HipSolver {
+public:
+  explicit RiccatiSolverDense(LqrProblem &problem, int device = 0)
+      : HipSolver(problem, 1, device, true) {}
+  bool backward(const double mueq) override {
+    upload();
+    check(gar_hip_backward(h_, mueq));
     return true;
   }
 };

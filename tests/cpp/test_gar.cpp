@@ -212,6 +212,33 @@ static void padded_shape(uint nx, uint nu, const char *kernel) {
   REQUIRE(maxdiff(lp, lbdas) <= 1e-8);
 }
 
+// tests/gar/riccati.cpp:141-155 ("test dense solver"): KKT error <= 1e-8, and the same trajectory as
+// the Riccati recursion
+static void dense_solver() {
+  std::printf("dense_solver\n");
+  std::mt19937 rng(42);
+  const uint nx = g_small ? 6 : 36, nu = g_small ? 3 : 12, horz = g_small ? 7 : 100;
+  auto problem = generate_problem(rng, VectorXs(nx, 0.0), horz, nx, nu);
+  const double mueq = 1e-14;
+  RiccatiSolverDense denseSolver{problem};
+  denseSolver.backward(mueq);
+  auto [xsd, usd, vsd, lbdasd] = lqrInitializeSolution(problem);
+  denseSolver.forward(xsd, usd, vsd, lbdasd);
+  const KktError errd = lqrComputeKktError(problem, xsd, usd, vsd, lbdasd, mueq);
+  ProximalRiccatiSolver solver{problem};
+  solver.backward(mueq);
+  auto [xs, us, vs, lbdas] = lqrInitializeSolution(problem);
+  solver.forward(xs, us, vs, lbdas);
+  std::printf("  kernel %s  kkt max %.2e  |x - x_riccati| %.2e\n", denseSolver.kernelName(), errd.max,
+              maxdiff(xsd, xs));
+  REQUIRE(errd.max <= 1e-8);
+  REQUIRE(maxdiff(xsd, xs) <= 1e-8);
+  REQUIRE(maxdiff(usd, us) <= 1e-8);
+  REQUIRE(denseSolver.getFeedback(0).rows == (int)(nu + 2 * nx));
+  REQUIRE(denseSolver.getFeedforward(0).size() == nu + 2 * nx);
+  REQUIRE(std::string(denseSolver.kernelName()) == "dense");
+}
+
 static void error_behaviour() {
   std::printf("error_behaviour\n");
   std::mt19937 rng(3);
@@ -254,6 +281,7 @@ int main() {
   riccati_random_large_problem();
   for (uint th : {2u, 4u, 8u})
     parallel_solver_class(th);
+  dense_solver();
   padded_shape(12, 6, "12,8");
   padded_shape(10, 3, "12,4");
   error_behaviour();
