@@ -10,7 +10,9 @@ import parity_cases as pc
 rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "2026")))
 budget = float(os.environ.get("SOAK_SECONDS", "150"))
 shapes = [(36, 12, 0), (32, 12, 0), (16, 8, 0), (12, 8, 0), (12, 4, 0), (8, 4, 0), (12, 6, 0), (8, 3, 0),
-          (36, 12, 32), (16, 8, 8), (8, 4, 4), (6, 3, 2), (5, 2, 0)]
+          (36, 12, 32), (16, 8, 8), (8, 4, 4), (6, 3, 2), (5, 2, 0),
+          (30, 10, 0), (13, 5, 0), (10, 3, 0), (7, 2, 0), (33, 11, 0), (40, 9, 0), (20, 14, 0)]  # padded / generic
+dense_share = float(os.environ.get("SOAK_DENSE", "0.25"))
 t0, n, fails, kinds = time.time(), 0, 0, {}
 while time.time() - t0 < budget:
     nx, nu, nc = shapes[rng.integers(len(shapes))]
@@ -27,7 +29,15 @@ while time.time() - t0 < budget:
             k.D[...] = rng.uniform(-1, 1, k.D.shape)
     tol = pc.TOL[mode] if nc == 0 else 1e-6
     try:
-        if legs == 1:
+        if rng.random() < dense_share:      # RiccatiSolverDense (csrc/gar_dense.hpp) against its own oracle
+            # (constrained: gains and multipliers are compared stage by stage at 1e-5; two Bunch-Kaufman
+            # implementations of the same 116x116 system differ by more than that (cond * eps)
+            # below mu ~ 1e-9 -- the oracle and LAPACK differ by as much -- so mu >= 1e-8 here)
+            if nc > 0:
+                mu = max(mu, 1e-8)
+            pc.check_dense(prob, mu, tol if nc == 0 else 1e-5)
+            name, legs = "dense", 1
+        elif legs == 1:
             s, _, _ = pc.check_serial(prob, mu, tol, factors=(nc == 0 or mu > 1e-9))
             name = s.kernel_name
         else:
