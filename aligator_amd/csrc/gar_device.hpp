@@ -48,6 +48,31 @@ __device__ __forceinline__ void wg_bar(const WG &w) {
   else
     __syncthreads();
 }
+// Maximum of a double over the wave, in every lane.  Six DPP stages (row_shr 1, 2, 4, 8, then
+// row_bcast 15 and 31) reduce into lane 63, v_readlane broadcasts it: ~150 cycles.  The same
+// reduction through __shfl_xor costs 12 ds_bpermute round trips (the LDS crossbar, ~100 cycles
+// each), which is what a Bunch-Kaufman pivot search was spending most of its time on.
+__device__ __forceinline__ double wave_max_f64(double x) {
+#define GAR_DPP_MAX(ctrl, rmask)                                                                  \
+  {                                                                                               \
+    const long long xb = __double_as_longlong(x);                                                 \
+    const int lo = (int)xb, hi = (int)(xb >> 32);                                                 \
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, ctrl, rmask, 0xf, false);                 \
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, ctrl, rmask, 0xf, false);                 \
+    x = fmax(x, __longlong_as_double(((long long)hi2 << 32) | (long long)(unsigned)lo2));         \
+  }
+  GAR_DPP_MAX(0x111, 0xf)
+  GAR_DPP_MAX(0x112, 0xf)
+  GAR_DPP_MAX(0x114, 0xf)
+  GAR_DPP_MAX(0x118, 0xf)
+  GAR_DPP_MAX(0x142, 0xa)
+  GAR_DPP_MAX(0x143, 0xc)
+#undef GAR_DPP_MAX
+  const long long xb = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)xb, 63), hi = __builtin_amdgcn_readlane((int)(xb >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 __device__ __forceinline__ WG wg_self() {
   WG w;
   w.tid = (int)threadIdx.x;
@@ -211,8 +236,13 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
   }
   int k = 0;
   int info = 0;
+  int r_step = 0, r_kp = 0, r_fail = 0; // decision taken by every thread itself (workgroup search)
   while (k < n) {
-    wg_bar(w);
+    // (workgroup scope: no barrier between two pivot steps -- the scaling of column k that ends a
+    // step touches nothing the next step's search, interchange or update reads)
+    if (w.wave_scope || k == 0)
+      wg_bar(w);
+    bool in_regs = false;
     if (w.wave_scope && n <= 128) {
       // Common case inside one wave, decided without a reduction or a round trip through
       // thread 0: the first test of the rule, |a_kk| >= alpha * colmax (:61), holds iff
@@ -305,13 +335,22 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
           bi = i;
         }
       }
+      if (n - k - 1 <= w.nthr) {
+        // one row per thread, rows ascending with the lane: the wave maximum by DPP, then the
+        // first row attaining it is the lowest lane that holds it
+        const double mv = wave_max_f64(bv);
+        const unsigned long long hit = __ballot(bv == mv);
+        bi = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(hit));
+        bv = mv;
+      } else {
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(bv, off);
-        const int oi = __shfl_xor(bi, off);
-        if (ov > bv || (ov == bv && oi < bi)) {
-          bv = ov;
-          bi = oi;
+        for (int off = 32; off >= 1; off >>= 1) {
+          const double ov = __shfl_xor(bv, off);
+          const int oi = __shfl_xor(bi, off);
+          if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+          }
         }
       }
       if (w.lane == 0) {
@@ -343,15 +382,15 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
         fail = 1;
       } else if (!(abs_akk >= colmax * alpha)) {
         double rv = 0.0;
+        // (read before the barrier below: the interchange of a faster thread may move it)
+        const double abs_aii = fabs(GA(imax, imax));
         for (int i = k + w.tid; i < n; i += w.nthr) {
           if (i < imax)
             rv = fmax(rv, fabs(GA(imax, i)));
           else if (i > imax)
             rv = fmax(rv, fabs(GA(i, imax)));
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1)
-          rv = fmax(rv, __shfl_xor(rv, off));
+        rv = wave_max_f64(rv);
         if (w.lane == 0)
           subdiag[2 * w.nwaves + w.wave] = rv; // n >= 17 > 3 nwaves here
         wg_bar(w);
@@ -360,18 +399,18 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
           rowmax = fmax(rowmax, subdiag[2 * w.nwaves + q]);
         if (abs_akk >= (alpha * colmax) * (colmax / rowmax)) {
           kp = k;
-        } else if (fabs(GA(imax, imax)) >= alpha * rowmax) {
+        } else if (abs_aii >= alpha * rowmax) {
           kp = imax;
         } else {
           kp = imax;
           k_step = 2;
         }
       }
-      if (w.tid == 0) {
-        ctrl[0] = k_step;
-        ctrl[1] = kp;
-        ctrl[2] = fail;
-      }
+      // every thread holds the same decision: no round trip through `ctrl`, no barrier
+      r_step = k_step;
+      r_kp = kp;
+      r_fail = fail;
+      in_regs = true;
     } else if (w.tid == 0) {
       int k_step = 1, kp, fail = 0;
       const double abs_akk = fabs(GA(k, k));
@@ -411,10 +450,11 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       ctrl[1] = kp;
       ctrl[2] = fail;
     }
-    wg_bar(w);
+    if (!par_search)
+      wg_bar(w);
     }
-    const int k_step = ctrl[0], kp = ctrl[1];
-    if (ctrl[2]) { // NumericalIssue: keep the remaining pivots in range and stop
+    const int k_step = in_regs ? r_step : ctrl[0], kp = in_regs ? r_kp : ctrl[1];
+    if (in_regs ? r_fail : ctrl[2]) { // NumericalIssue: keep the remaining pivots in range and stop
       for (int i = k + w.tid; i < n; i += w.nthr)
         piv[i] = i;
       info = 1;

@@ -138,6 +138,30 @@ inline unsigned long long __ballot(int pred) {
 }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 inline long long __double_as_longlong(double d) { long long b; std::memcpy(&b, &d, 8); return b; }
+inline double __longlong_as_double(long long b) { double d; std::memcpy(&d, &b, 8); return d; }
+// DPP moves used by wave_max_f64 (gar_device.hpp): row_shr:n (0x110+n), row_bcast:15 (0x142),
+// row_bcast:31 (0x143); a lane without a valid source, or masked off, keeps `old`.
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool) {
+  emu::WaveCtx &W = emu::wave();
+  const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
+  W.b[lane] = (double)src; // exact for 32-bit ints
+  W.bar.arrive_and_wait();
+  int from = -1;
+  if (ctrl > 0x110 && ctrl <= 0x11f) {
+    if (l16 >= ctrl - 0x110)
+      from = lane - (ctrl - 0x110);
+  } else if (ctrl == 0x142) {
+    if (row > 0)
+      from = (row - 1) * 16 + 15;
+  } else if (ctrl == 0x143) {
+    if (row >= 2)
+      from = 31;
+  }
+  const bool en = ((row_mask >> row) & 1) && ((bank_mask >> (l16 >> 2)) & 1);
+  const int r = (from >= 0 && en) ? (int)W.b[from] : old;
+  W.bar.arrive_and_wait();
+  return r;
+}
 inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
 inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 inline double __hiloint2double(int hi, int lo) {
