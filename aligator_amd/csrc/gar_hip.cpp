@@ -39,6 +39,28 @@ int fail(int code, const std::string &msg) {
 
 inline int align2(int x) { return (x + 1) & ~1; }
 
+// Every entry point runs on the solver's own device, whatever the caller's current device is, and
+// leaves the caller's current device as it found it (two solvers on two GPUs in one process;
+// torch's notion of the current device).
+struct DeviceGuard {
+  int prev = -1, dev;
+  explicit DeviceGuard(int device) : dev(device) { // device < 0 (null solver): no-op
+    if (dev < 0)
+      return;
+    if (hipGetDevice(&prev) != hipSuccess)
+      prev = -1;
+    if (prev != dev)
+      (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (dev >= 0 && prev >= 0 && prev != dev)
+      (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define GAR_GUARD(s) DeviceGuard guard_((s) ? (s)->device : -1)
+
 } // namespace
 
 struct gar_hip_solver {
@@ -66,6 +88,10 @@ struct gar_hip_solver {
   // host staging
   double *h_prob = nullptr; // pinned, batch * prob_doubles (when small enough)
   bool staged = false, dirty = false;
+  // what the host wrote into the staging area since the last flush: per problem, a sorted list of
+  // disjoint [lo, hi) ranges (doubles).  commit() copies exactly these, so knots a device-resident
+  // producer wrote in place (gar_hip_device_problems) survive a later set_init / upload_stage
+  std::vector<std::vector<std::pair<int64_t, int64_t>>> dirty_iv;
   hipStream_t own_stream = nullptr, stream = nullptr;
   gar::LdsPlan lds{};
   // RiccatiSolverDense (gar_dense.hpp): factor records carry nu+nc+2*nx2 gain rows
@@ -498,13 +524,65 @@ gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
   return P;
 }
 
-int commit(gar_hip_solver *s) {
-  if (s->staged && s->dirty) {
-    HIP_TRY(hipMemcpyAsync(s->d_prob, s->h_prob,
-                           sizeof(double) * (size_t)s->prob_doubles * s->batch,
-                           hipMemcpyHostToDevice, s->stream));
-    s->dirty = false;
+void mark_dirty(gar_hip_solver *s, int b, int64_t lo, int64_t hi) {
+  auto &iv = s->dirty_iv[(size_t)b];
+  // the common pattern is "append right after the last range" (knot after knot): O(1); gaps of
+  // one double are record-alignment padding and merge as well
+  if (!iv.empty() && lo >= iv.back().first && lo <= iv.back().second + 1) {
+    iv.back().second = std::max(iv.back().second, hi);
+  } else {
+    iv.emplace_back(lo, hi);
+    if (iv.size() > 1 && iv[iv.size() - 2].first > lo) { // out of order: sort and merge
+      std::sort(iv.begin(), iv.end());
+      size_t w = 0;
+      for (size_t r = 1; r < iv.size(); ++r) {
+        if (iv[r].first <= iv[w].second + 1)
+          iv[w].second = std::max(iv[w].second, iv[r].second);
+        else
+          iv[++w] = iv[r];
+      }
+      iv.resize(w + 1);
+    }
   }
+  s->dirty = true;
+}
+
+int commit(gar_hip_solver *s) {
+  if (!(s->staged && s->dirty))
+    return GAR_HIP_OK;
+  const int64_t P = s->prob_doubles;
+  // whole problems, back to back: one copy per run of fully rewritten problems
+  int b = 0;
+  while (b < s->batch) {
+    auto &iv = s->dirty_iv[(size_t)b];
+    if (iv.empty()) {
+      ++b;
+      continue;
+    }
+    const bool whole = iv.size() == 1 && iv[0].first == 0 && iv[0].second >= P - 1;
+    if (whole) {
+      int e = b + 1;
+      while (e < s->batch && s->dirty_iv[(size_t)e].size() == 1 && s->dirty_iv[(size_t)e][0].first == 0 &&
+             s->dirty_iv[(size_t)e][0].second >= P - 1)
+        ++e;
+      HIP_TRY(hipMemcpyAsync(s->d_prob + (int64_t)b * P, s->h_prob + (int64_t)b * P,
+                             sizeof(double) * (size_t)P * (size_t)(e - b), hipMemcpyHostToDevice,
+                             s->stream));
+      for (int k = b; k < e; ++k)
+        s->dirty_iv[(size_t)k].clear();
+      b = e;
+      continue;
+    }
+    for (const auto &r : iv) {
+      const int64_t hi = std::min(r.second, P);
+      HIP_TRY(hipMemcpyAsync(s->d_prob + (int64_t)b * P + r.first, s->h_prob + (int64_t)b * P + r.first,
+                             sizeof(double) * (size_t)(hi - r.first), hipMemcpyHostToDevice,
+                             s->stream));
+    }
+    iv.clear();
+    ++b;
+  }
+  s->dirty = false;
   return GAR_HIP_OK;
 }
 
@@ -517,7 +595,7 @@ int write_block(gar_hip_solver *s, int b, int64_t off, const double *src, int64_
       std::memcpy(dst, src, sizeof(double) * (size_t)n);
     else
       std::memset(dst, 0, sizeof(double) * (size_t)n);
-    s->dirty = true;
+    mark_dirty(s, b, off, off + n);
     return GAR_HIP_OK;
   }
   double *dst = s->d_prob + (int64_t)b * s->prob_doubles + off;
@@ -534,6 +612,7 @@ gar::LegParams make_leg_params(gar_hip_solver *s) {
   Q.M.prob = s->d_prob;
   Q.M.fac = s->d_fac;
   Q.M.status = s->d_status;
+  Q.M.slow = s->d_status + s->batch;
   Q.M.prob_stride = s->prob_doubles;
   Q.M.fac_stride = s->fac_doubles;
   Q.M.in_off0 = s->meta[0].in_off;
@@ -587,6 +666,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.prob = s->d_prob;
     M.fac = s->d_fac;
     M.status = s->d_status;
+    M.slow = s->d_status + s->batch;
     M.prob_stride = s->prob_doubles;
     M.fac_stride = s->fac_doubles;
     const int N = s->horizon;
@@ -819,8 +899,9 @@ int allocate(gar_hip_solver *s) {
   HIP_TRY(hipMalloc((void **)&s->d_init, sizeof(double) * (size_t)s->init_doubles * B));
   HIP_TRY(hipMemset(s->d_init, 0, sizeof(double) * (size_t)s->init_doubles * B));
   HIP_TRY(hipMalloc((void **)&s->d_theta, sizeof(double) * (size_t)std::max(s->nth0, 1) * B));
-  HIP_TRY(hipMalloc((void **)&s->d_status, sizeof(int) * B));
-  HIP_TRY(hipMemset(s->d_status, 0, sizeof(int) * B));
+  // per-problem failure flags, then the two slow-path counters (MfmaParams::slow)
+  HIP_TRY(hipMalloc((void **)&s->d_status, sizeof(int) * (B + 2)));
+  HIP_TRY(hipMemset(s->d_status, 0, sizeof(int) * (B + 2)));
   if (s->num_legs > 1) {
     const int local = s->leg_end - s->leg_begin;
     const int nblk = 2 * s->num_legs;
@@ -845,6 +926,8 @@ int allocate(gar_hip_solver *s) {
     std::memset(s->h_prob, 0, staging);
     s->staged = true;
   }
+  s->dirty_iv.assign(B, {});
+  s->dirty = false;
   select_kernel(s);
   if (s->dense) {
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_backward_dense,
@@ -956,10 +1039,14 @@ gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int n
   s->leg_end = leg_end;
   s->dense = dense;
   s->dims5.assign(dims5, dims5 + 5 * (horizon + 1));
-  if (hipSetDevice(device) != hipSuccess) {
-    fail(GAR_HIP_ERR_DEVICE, "hipSetDevice failed");
-    delete s;
-    return nullptr;
+  DeviceGuard guard_(device); // the caller's current device is restored on return
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) {
+      fail(GAR_HIP_ERR_DEVICE, "hipSetDevice failed");
+      delete s;
+      return nullptr;
+    }
   }
   if (build_layout(s) != GAR_HIP_OK || plan_lds(s) != GAR_HIP_OK) {
     delete s;
@@ -1009,7 +1096,7 @@ gar_hip_solver *gar_hip_solver_create(int device, int horizon, const int32_t *di
 void gar_hip_solver_destroy(gar_hip_solver *s) {
   if (!s)
     return;
-  (void)hipSetDevice(s->device);
+  GAR_GUARD(s);
   (void)hipStreamSynchronize(s->stream);
   free_device(s);
   if (s->own_stream)
@@ -1021,6 +1108,7 @@ void gar_hip_solver_destroy(gar_hip_solver *s) {
 }
 
 int gar_hip_set_stream(gar_hip_solver *s, void *hip_stream) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1029,6 +1117,7 @@ int gar_hip_set_stream(gar_hip_solver *s, void *hip_stream) {
 }
 
 int gar_hip_sync(gar_hip_solver *s) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1070,6 +1159,7 @@ int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const
                          const double *B, const double *f, const double *C, const double *D,
                          const double *d, const double *Gth, const double *Gx,
                          const double *Gu, const double *Gv, const double *gamma) {
+  GAR_GUARD(s);
   if (int rc = check_bt(s, b, t))
     return rc;
   const gar_stage_meta &m = s->meta[t];
@@ -1102,6 +1192,7 @@ int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const
 }
 
 int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g0) {
+  GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
   if (s->nc0 > 0 && (!G0 || !g0))
@@ -1112,12 +1203,16 @@ int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g
 }
 
 int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packed) {
+  GAR_GUARD(s);
   if (!s || !packed || b0 < 0 || nb < 0 || b0 + nb > s->batch)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_packed: bad argument");
   const size_t bytes = sizeof(double) * (size_t)s->prob_doubles * nb;
   if (s->staged) {
     std::memcpy(s->h_prob + (int64_t)b0 * s->prob_doubles, packed, bytes);
-    s->dirty = true;
+    for (int b = b0; b < b0 + nb; ++b) {
+      s->dirty_iv[(size_t)b].clear();
+      mark_dirty(s, b, 0, s->prob_doubles);
+    }
     return GAR_HIP_OK;
   }
   HIP_TRY(hipMemcpyAsync(s->d_prob + (int64_t)b0 * s->prob_doubles, packed, bytes,
@@ -1127,6 +1222,7 @@ int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packe
 }
 
 int gar_hip_upload_packed_device(gar_hip_solver *s, int b0, int nb, const double *packed_dev) {
+  GAR_GUARD(s);
   if (!s || !packed_dev || b0 < 0 || nb < 0 || b0 + nb > s->batch)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_packed_device: bad argument");
   if (int rc = commit(s)) // staged host data first, then the device copy wins
@@ -1134,11 +1230,12 @@ int gar_hip_upload_packed_device(gar_hip_solver *s, int b0, int nb, const double
   HIP_TRY(hipMemcpyAsync(s->d_prob + (int64_t)b0 * s->prob_doubles, packed_dev,
                          sizeof(double) * (size_t)s->prob_doubles * nb, hipMemcpyDeviceToDevice,
                          s->stream));
-  s->staged = false; // the device copy is now the source of truth
+  // (the staging area stays in use: commit() flushes only the ranges the host writes later)
   return GAR_HIP_OK;
 }
 
 int gar_hip_commit(gar_hip_solver *s) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   return commit(s);
@@ -1149,27 +1246,31 @@ double *gar_hip_device_factors(gar_hip_solver *s) { return s ? s->d_fac : nullpt
 double *gar_hip_device_solutions(gar_hip_solver *s) { return s ? s->d_sol : nullptr; }
 
 int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   if (int rc = commit(s))
     return rc;
-  HIP_TRY(hipMemsetAsync(s->d_status, 0, sizeof(int) * (size_t)s->batch, s->stream));
+  HIP_TRY(hipMemsetAsync(s->d_status, 0, sizeof(int) * ((size_t)s->batch + 2), s->stream));
   return launch_backward(s, mueq);
 }
 
 int gar_hip_condensed_solve_async(gar_hip_solver *s) {
+  GAR_GUARD(s);
   if (!s || s->num_legs < 2)
     return fail(GAR_HIP_ERR_ARG, "condensed solve needs leg mode");
   return launch_condensed(s);
 }
 
 int gar_hip_forward_legs_async(gar_hip_solver *s) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   return launch_forward(s, nullptr);
 }
 
 int gar_hip_backward_async(gar_hip_solver *s, double mueq) {
+  GAR_GUARD(s);
   if (int rc = gar_hip_backward_legs_async(s, mueq))
     return rc;
   if (s->num_legs > 1) {
@@ -1182,6 +1283,7 @@ int gar_hip_backward_async(gar_hip_solver *s, double mueq) {
 }
 
 int gar_hip_num_failed(gar_hip_solver *s) {
+  GAR_GUARD(s);
   if (!s)
     return 0;
   std::vector<int> st((size_t)s->batch);
@@ -1196,7 +1298,20 @@ int gar_hip_num_failed(gar_hip_solver *s) {
   return n;
 }
 
+int gar_hip_slow_path_stages(gar_hip_solver *s, int64_t out[2]) {
+  GAR_GUARD(s);
+  if (!s || !out)
+    return fail(GAR_HIP_ERR_ARG, "bad argument");
+  int c[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(c, s->d_status + s->batch, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  out[0] = c[0];
+  out[1] = c[1];
+  return GAR_HIP_OK;
+}
+
 int gar_hip_backward(gar_hip_solver *s, double mueq) {
+  GAR_GUARD(s);
   if (int rc = gar_hip_backward_async(s, mueq))
     return rc;
   const int nf = gar_hip_num_failed(s);
@@ -1210,12 +1325,14 @@ int gar_hip_backward(gar_hip_solver *s, double mueq) {
 }
 
 int gar_hip_forward_async(gar_hip_solver *s, const double *theta_device) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   return launch_forward(s, theta_device);
 }
 
 int gar_hip_forward(gar_hip_solver *s, const double *theta) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   const double *th = nullptr;
@@ -1243,6 +1360,7 @@ int gar_hip_set_refinement(gar_hip_solver *s, double thr, int max_steps) {
 }
 
 int gar_hip_condensed_info(gar_hip_solver *s, int b, double out[2]) {
+  GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
   if (s->num_legs < 2 || !out)
@@ -1258,6 +1376,7 @@ int gar_hip_condensed_info(gar_hip_solver *s, int b, double out[2]) {
 
 int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, double *vs,
                          double *lbdas) {
+  GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
   const double *base = s->d_sol + (int64_t)b * s->sol_doubles;
@@ -1275,6 +1394,7 @@ int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, doubl
 }
 
 int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, double *fth) {
+  GAR_GUARD(s);
   if (int rc = check_bt(s, b, t))
     return rc;
   const gar_stage_meta &m = s->meta[t];
@@ -1321,6 +1441,7 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
 
 int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, double *Vxt,
                       double *Vtt, double *vt) {
+  GAR_GUARD(s);
   if (int rc = check_bt(s, b, t))
     return rc;
   const gar_stage_meta &m = s->meta[t];
@@ -1339,6 +1460,7 @@ int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, 
 
 int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff, double *kkt0_fth,
                         double *thGrad, double *thHess) {
+  GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
   const double *io = s->d_init + (int64_t)b * s->init_doubles;
@@ -1354,6 +1476,7 @@ int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff, double *kkt0_
 }
 
 int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1384,11 +1507,11 @@ int gar_hip_deriv_offsets(const gar_hip_solver *s, int t, int64_t out[4]) {
 
 int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_dev, double preg,
                                         int hess_exact) {
+  GAR_GUARD(s);
   if (!s || !deriv_dev)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_update_lq_subproblem_device: bad argument");
-  if (int rc = commit(s)) // pending host staging first; from now on the device copy is the truth
+  if (int rc = commit(s)) // pending host staging first; later host writes flush only their own ranges
     return rc;
-  s->staged = false;
   if (!s->d_deriv_off) {
     HIP_TRY(hipMalloc((void **)&s->d_deriv_off, sizeof(long long) * s->deriv_off.size()));
     HIP_TRY(hipMemcpy(s->d_deriv_off, s->deriv_off.data(), sizeof(long long) * s->deriv_off.size(),
@@ -1418,6 +1541,7 @@ int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_d
 }
 
 int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed) {
+  GAR_GUARD(s);
   if (!s || !packed || b0 < 0 || nb < 0 || b0 + nb > s->batch)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_download_packed: bad argument");
   if (int rc = commit(s))
@@ -1430,6 +1554,7 @@ int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed) {
 }
 
 int gar_hip_set_timing(gar_hip_solver *s, int enable) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1441,6 +1566,7 @@ int gar_hip_set_timing(gar_hip_solver *s, int enable) {
 }
 
 int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]) {
+  GAR_GUARD(s);
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
   if (!s->timing || !(s->mfma_kernel || s->wave_kernel || s->leg_bwd_kernel))
@@ -1458,6 +1584,7 @@ int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]) {
 }
 
 int gar_hip_collapse_feedback(gar_hip_solver *s) {
+  GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   if (s->num_legs < 2 || s->leg_begin != 0)
@@ -1471,11 +1598,14 @@ int gar_hip_collapse_feedback(gar_hip_solver *s) {
 }
 
 int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
+  GAR_GUARD(s);
   if (!s || !d)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
   const int N = s->horizon;
   if (N < 1)
     return GAR_HIP_OK;
+  if (int rc = commit(s)) // host writes addressed the old stage numbering: flush them first
+    return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   // new dims sequence: old[1..N-1], new knot, old[N]  (rotate_vec_left(datas,0,1) +
   // re-created last-but-one factor, proximal-riccati.hxx:79-86)
@@ -1506,13 +1636,8 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
       (void)inL;
       (void)fL;
     }
-    if (s->staged) {
-      for (int b = 0; b < s->batch; ++b) {
-        double *pb = s->h_prob + (int64_t)b * s->prob_doubles;
-        std::memmove(pb + in0, pb + in1, sizeof(double) * (size_t)(inL - in1));
-        std::memset(pb + inL - (in1 - in0), 0, sizeof(double) * (size_t)(in1 - in0));
-      }
-    }
+    // (the pinned staging area is not rotated: commit() only ever flushes ranges the host wrote
+    // after this call, and pending writes were flushed above)
     HIP_TRY(hipMemsetAsync(s->d_init, 0, sizeof(double) * (size_t)s->init_doubles * s->batch, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return GAR_HIP_OK;

@@ -31,6 +31,10 @@ struct MfmaParams {
   const double *prob;
   double *fac;
   int *status;
+  // diagnostics (bench.py's slow_path_stage_frac): slow[0] += stages whose Rhat failed the first
+  // Bunch-Kaufman test somewhere (they leave the register LDL^T), slow[1] += those of them where
+  // the complete rule really pivots (generic device Bunch-Kaufman)
+  int *slow;
   long long prob_stride, fac_stride;
   long long in_off0, in_rec, in_offN; // knot record of stage t < N at in_off0 + t*in_rec
   long long fac_rec, fac_offN;        // factor record of stage t < N at t*fac_rec
@@ -504,8 +508,14 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       // ---- factor Rhat in registers (lane = row) under the Bunch-Kaufman rule ----
       double a_row[NU], dinv[NU], x[NU];
       int verdict = wave_ldl_lean<NU>(Mm, lane, a_row, dinv);
-      if (verdict != 0) // rare: evaluate the complete Bunch-Kaufman rule
+      if (verdict != 0) { // rare: evaluate the complete Bunch-Kaufman rule
         verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
+        if (threadIdx.x == 0) {
+          atomicAdd(&P.slow[0], 1);
+          if (verdict != 0)
+            atomicAdd(&P.slow[1], 1);
+        }
+      }
       GAR_MARK(5)
       const int col = lane <= NX ? lane : NX; // G column: 0 = kff, 1 + j = K(:, j)
       if (verdict == 0) {

@@ -381,7 +381,7 @@ __device__ __forceinline__ void ldl_solve_regs_bcast2(const double (&a)[NU], con
 // device Bunch-Kaufman exactly as the reference would (interchanges, 2x2 pivots), solving
 // [kff | K] into G2.  Returns 1 if the factorisation failed (zero pivot column).
 template <int NX, int NU, bool PARAM = false>
-__device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int lane) {
+__device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int lane, int *slow) {
   using C = WaveCfg<NX, NU>;
   constexpr int PG = C::PG;
   double *G = sm + C::oG, *G2 = sm + C::oG2, *Mm = sm + C::oM;
@@ -406,8 +406,12 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
       }
     }
   }
-  if (lane == 0) // which factorisation the block holds: 0 = L, 1/d (unpivoted) ; 2 = Bunch-Kaufman
+  if (lane == 0) { // which factorisation the block holds: 0 = L, 1/d (unpivoted) ; 2 = Bunch-Kaufman
     sm[C::oFlag] = verdict == 0 ? 0.0 : 2.0;
+    atomicAdd(&slow[0], 1);
+    if (verdict != 0)
+      atomicAdd(&slow[1], 1);
+  }
   wave_sync();
   const int col = lane <= NX ? lane : NX;
   if (verdict == 0) {
@@ -813,7 +817,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
       }
       wave_sync();
     } else {
-      failed |= wave_slow_factor_solve<NX, NU, PRM>(sb, lane);
+      failed |= wave_slow_factor_solve<NX, NU, PRM>(sb, lane, P.slow);
     }
   }
   GAR_WMARK(6)

@@ -25,7 +25,7 @@ from .lqr import (BLOCK_NAMES, LqrKnot, LqrProblem, block_shapes,
                   lqrComputeKktError, lqrInitializeSolution, lqrNumRows)
 
 __all__ = ["LqrKnot", "LqrProblem", "RiccatiSolverBase", "ProximalRiccatiSolver",
-           "ParallelRiccatiSolver", "BatchedRiccatiSolver", "lqrInitializeSolution",
+           "ParallelRiccatiSolver", "RiccatiSolverDense", "BatchedRiccatiSolver", "lqrInitializeSolution",
            "lqrComputeKktError", "lqrNumRows", "get_work"]
 
 _PD = C.POINTER(C.c_double)
@@ -367,6 +367,9 @@ class BatchedRiccatiSolver:
         th = None
         if theta is not None:
             theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1)
+            nth0 = self.effective_nth(0) if self.num_legs == 1 else 0
+            if nth0 > 0 and theta.size != nth0 * self.batch:  # the C ABI reads nth0 * batch doubles
+                raise ValueError(f"theta has {theta.size} entries, expected nth * batch = {nth0 * self.batch}")
             th = _ptr(theta)
         self._check(self._L.gar_hip_forward(self._h, th))
         return True
@@ -380,6 +383,13 @@ class BatchedRiccatiSolver:
 
     def num_failed(self) -> int:
         return self._L.gar_hip_num_failed(self._h)
+
+    def slow_path_stages(self):
+        """(stages of the last backward that left the register LDL^T because Rhat failed the first
+        Bunch-Kaufman test, those of them where Bunch-Kaufman really pivoted), summed over the batch."""
+        out = np.zeros(2, dtype=np.int64)
+        self._check(self._L.gar_hip_slow_path_stages(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return int(out[0]), int(out[1])
 
     def set_refinement(self, threshold: float, max_steps: int):
         self._check(self._L.gar_hip_set_refinement(self._h, float(threshold), int(max_steps)))

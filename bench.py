@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--nx", type=int, default=36)
     ap.add_argument("--nu", type=int, default=12)
     ap.add_argument("--generator", default="W", choices=["W", "F"])
+    ap.add_argument("--single-generator", action="store_true",
+                    help="skip the second measurement on the other generator (value_F / value_W)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary parallel-in-time figure")
@@ -199,48 +201,56 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     solver.set_stream(stream.cuda_stream)
-    synth_device.fill_problems(solver, seed=1234 + 7919 * rank, mode=args.generator)
-    torch.cuda.synchronize()
 
     def step():
         solver.backward_async(mueq)
         solver.forward_async()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if solver.num_failed() != 0:
-        raise SystemExit("a stage factorisation failed during warm-up")
+    def measure(generator, seed):
+        """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both
+        sides (max over ranks); then the per-kernel durations (HIP events the library records on the
+        launch stream around the backward sweep kernel, the initial-stage kernel and the forward sweep
+        kernel, averaged over a few extra untimed steps) and the slow-path counters of one backward."""
+        synth_device.fill_problems(solver, seed=seed, mode=generator)
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if solver.num_failed() != 0:
+            raise SystemExit("a stage factorisation failed during warm-up")
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            solver.backward_async(mueq)
+            solver.forward_async()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        solver._check(solver._L.gar_hip_set_timing(solver.handle, 1))
+        kms = np.zeros(3)
+        reps = max(3, min(args.steps, 10))
+        for _ in range(reps):
+            step()
+            out3 = (C.c_double * 3)()
+            solver._check(solver._L.gar_hip_last_kernel_ms(solver.handle, out3))
+            kms += np.array(list(out3))
+        solver._check(solver._L.gar_hip_set_timing(solver.handle, 0))
+        slow, pivoted = solver.slow_path_stages()
+        return elapsed, kms / reps, slow / (args.batch * N), pivoted / (args.batch * N), solver.num_failed()
 
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        solver.backward_async(mueq)
-        solver.forward_async()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # per-kernel durations: HIP events the library recorded on the launch stream around the
-    # backward sweep kernel, the initial-stage kernel and the forward sweep kernel, averaged
-    # over a few extra (untimed) steps
-    solver._check(solver._L.gar_hip_set_timing(solver.handle, 1))
-    kms = np.zeros(3)
-    reps = max(3, min(args.steps, 10))
-    for _ in range(reps):
-        step()
-        out3 = (C.c_double * 3)()
-        solver._check(solver._L.gar_hip_last_kernel_ms(solver.handle, out3))
-        kms += np.array(list(out3))
-    kms /= reps
+    # the reference's own generator F first (secondary figure), then the headline generator: the
+    # parity spot check and everything below run on the data of the headline measurement
+    other = "F" if args.generator == "W" else "W"
+    second = None if args.single_generator else measure(other, 4321 + 7919 * rank)
+    elapsed, kms, slow_frac, piv_frac, failed = measure(args.generator, 1234 + 7919 * rank)
     bwd_ms, init_ms, fwd_ms = (float(v) for v in kms)
-    failed = solver.num_failed()
 
     err, kkt = parity_check(solver, args, mueq)
     pit = None
@@ -272,11 +282,27 @@ def main():
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK,
                          "traffic": pmc_traffic("backward", args.batch),
+                         "traffic_source": "committed rocprofv3 --pmc passes of this kernel at this batch "
+                                           "(profiles/pmc_traffic.json, scripts/collect_pmc.sh), NOT collected "
+                                           "in this run; null when the batch differs",
                          "algorithmic_bytes_per_launch": bwd_b * args.batch,
                          "forward_GBps": fwd_b * args.batch / (fwd_ms * 1e-3) / 1e9,
                          "sweep_frac_of_hbm_roofline": (sweeps / elapsed) * (bwd_b + fwd_b) / HBM_PEAK},
             "parity": {"max_rel_err_vs_oracle": err, "max_kkt": kkt, "failed_factorisations": failed},
+            # stages (fraction of batch x N) whose Rhat failed the first Bunch-Kaufman test and left the
+            # register LDL^T for the out-of-line path; "pivoted": those where Bunch-Kaufman interchanged
+            "slow_path_stage_frac": {args.generator: slow_frac},
+            "pivoted_stage_frac": {args.generator: piv_frac},
         }
+        if second is not None:
+            el2, kms2, sf2, pf2, _ = second
+            out[f"value_{other}"] = sweeps / el2
+            out[f"ms_per_step_{other}"] = el2 / args.steps * 1e3
+            out[f"kernel_ms_{other}"] = {"backward_sweep": float(kms2[0]), "initial_stage": float(kms2[1]),
+                                         "forward_sweep": float(kms2[2])}
+            out[f"roofline_frac_{other}"] = bwd_b * args.batch / (float(kms2[0]) * 1e-3) / HBM_PEAK
+            out["slow_path_stage_frac"][other] = sf2
+            out["pivoted_stage_frac"][other] = pf2
         if pit is not None:
             out["parallel_in_time"] = pit
         if world == 1 and not args.no_cpu:

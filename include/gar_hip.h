@@ -171,6 +171,13 @@ int gar_hip_forward_async(gar_hip_solver *s, const double *theta_device);
 /* number of problems whose backward reported a failed factorisation */
 int gar_hip_num_failed(gar_hip_solver *s);
 
+/* Diagnostics of the last backward (specialised kernel families; no reference counterpart): the
+ * register LDL^T of Rhat is what Bunch-Kaufman does whenever its first test |a_kk| >= alpha*colmax
+ * holds at every column (bunchkaufman.hpp:61); out[0] = stages (summed over the batch) where it did
+ * not and the complete rule was evaluated, out[1] = those of them where Bunch-Kaufman really
+ * interchanges or takes a 2x2 pivot (generic device Bunch-Kaufman, exactly the reference's). */
+int gar_hip_slow_path_stages(gar_hip_solver *s, int64_t out[2]);
+
 /* ---- horizon sharding (leg mode, one rank per GPU) ------------------------ */
 /* doubles per leg in the boundary tuple (Vxx | Vxt | Vtt | vx | vt of the leg's
  * first stage): 3 nx^2 + 2 nx */

@@ -17,7 +17,10 @@ t0, n, fails, kinds = time.time(), 0, 0, {}
 while time.time() - t0 < budget:
     nx, nu, nc = shapes[rng.integers(len(shapes))]
     horz = int(rng.integers(3, 70))
-    mode = "F" if (rng.random() < 0.3 and nx <= 16) else "W"
+    mode = "F" if (rng.random() < 0.3 and nc == 0) else "W"      # the reference's generator, every shape
+    # the THROUGHPUT kernel (one wave per problem; what the bench line runs: the library picks it for
+    # batch > #CUs) on half of the serial draws, the latency kernel (one workgroup per problem) else
+    os.environ["GAR_HIP_BACKWARD"] = "wave" if rng.random() < 0.5 else "wg4"
     # (constrained problems below mu ~ 1e-10 are conditioned like 1/mu: the oracle and the kernels then
     # differ by cond * eps > 1e-6 from each other on EVERY kernel family, generic included)
     mu = 10.0 ** rng.uniform(-12 if nc == 0 else -10, -5)

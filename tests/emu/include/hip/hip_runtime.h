@@ -183,7 +183,9 @@ inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_S
 
 // ---- runtime -------------------------------------------------------------------
 inline hipError_t hipGetDeviceCount(int *n) { *n = emu::device_count; return hipSuccess; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline int &emu_current_device() { static thread_local int d = 0; return d; }
+inline hipError_t hipSetDevice(int d) { emu_current_device() = d; return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = emu_current_device(); return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
 inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 0; return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 2; }

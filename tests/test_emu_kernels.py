@@ -422,3 +422,33 @@ def test_constrained_wave_kernels(nx, nu, nc, horz, mu):
 def test_constrained_wave_kernels_bunch_kaufman_pivoting():
     pc.check_constrained_pivoting(EMU)
 
+
+
+def test_device_written_knots_survive_host_set_init():
+    """A device-resident producer writes the knots in place (gar_hip_device_problems); a later
+    host-side set_init / upload_knot must flush ONLY what the host wrote (the whole
+    staging buffer used to be copied over the device records)."""
+    import ctypes
+    from aligator_amd.gar import BatchedRiccatiSolver
+    nx, nu, N = 8, 4, 6
+    probs = [synth.generate_lq_problem(50 + i, np.ones(nx), N, nx, nu, mode="W") for i in range(2)]
+    dims = [k.dims for k in probs[0].stages]
+    s = BatchedRiccatiSolver(dims, nx, batch=2, lib_path=EMU)
+    packed = np.concatenate([s.pack(p) for p in probs])
+    ctypes.memmove(s.device_pointers()[0], packed.ctypes.data, packed.nbytes)   # "device" write in place
+    x0 = np.full(nx, 0.5)
+    for b, p in enumerate(probs):
+        p.g0[...] = x0
+        s.set_init(b, p.G0, p.g0)                       # host write: G0 | g0 only
+    k = probs[1].stages[3]
+    k.q[...] += 1.0
+    s.upload_knot(1, 3, k)                              # host write: one knot of problem 1
+    assert s.backward(1e-10) and s.forward()
+    for b, p in enumerate(probs):
+        _, _, ref = pc.oracle_serial(p, 1e-10)
+        for A, B in zip(s.solution(b), ref):
+            assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
+    # and the device records still hold the producer's knots
+    back = s.download_packed(0, 2)
+    packed2 = np.concatenate([s.pack(p) for p in probs])
+    assert np.array_equal(back, packed2)

@@ -145,6 +145,49 @@ def test_full_size_batch_properties():
     del torch
 
 
+class _BatchDatas:
+    """datas[t] of problem b of a BatchedRiccatiSolver (what compare_factors indexes)."""
+
+    def __init__(self, solver, b):
+        self.s, self.b = solver, b
+
+    def __getitem__(self, t):
+        return self.s.factor(t, self.b)
+
+
+@pytest.mark.parametrize("mode,horz", [("W", 256), ("F", 100), ("F", 256)])
+def test_headline_wave_kernel_full_parity(mode, horz):
+    """The kernel the bench line is measured on -- gar_backward_wave<36,12>, which the library selects
+    once batch > #CUs -- at the north-star size (N=256; the reference's own generator F also at its
+    test size N=100, tests/gar/riccati.cpp:107-139, and bar 1e-6): eight problems spread over a
+    1024-problem device-generated batch, EVERY stage's ff / fb / Vxx / vx, kkt0 and the whole
+    solution against the oracle; plus the slow-path counters the bench line reports."""
+    from aligator_amd import synth_device
+    from aligator_amd.gar import BatchedRiccatiSolver, lqrComputeKktError
+    nx, nu, B, mueq = 36, 12, 1024, 1e-14
+    dims = [(nx, nu, 0, nx, 0)] * horz + [(nx, 0, 0, nx, 0)]
+    s = BatchedRiccatiSolver(dims, nx, batch=B)
+    assert s.kernel_name == "wave<36,12>"
+    keep = tuple(int(b) for b in np.linspace(0, B - 1, 8))
+    synth_device.fill_problems(s, seed=2024 + horz, mode=mode, keep=keep)
+    assert s.backward(mueq) and s.forward()
+    slow, pivoted = s.slow_path_stages()
+    assert 0 <= pivoted <= slow <= B * horz
+    tol = pc.TOL[mode]
+    for b in keep:
+        prob = synth_device.download_problem(s, b)
+        _, osol, ref = pc.oracle_serial(prob, mueq)
+        sol = s.solution(b)
+        sc = pc.scale_of(ref)
+        for A, C in zip(sol, ref):
+            assert pc.maxdiff(A, C) <= tol * sc, b
+        assert max(lqrComputeKktError(prob, *sol, mueq=mueq)) <= (1e-9 if mode == "W" else 1e-6) * sc
+        pc.compare_factors(_BatchDatas(s, b), osol, horz, tol, names=("ff", "fb"), vnames=("Vxx", "vx"))
+        ff0, _, _, _ = s.initial(b)
+        assert np.abs(ff0 - osol.kkt0_ff).max() <= tol * max(1.0, np.abs(osol.kkt0_ff).max())
+    print(f"wave<36,12> {mode} N={horz}: slow-path stages {slow} / {B * horz}, pivoted {pivoted}")
+
+
 def test_config4_shape_legs_on_one_gpu():
     """BASELINE.json configs[3] shape (N=2048, nx=36, nu=12) with the 8-way leg partition
     the 8-GPU run uses, all legs on this GPU: same condensed system, same forward."""
