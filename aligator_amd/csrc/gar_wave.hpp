@@ -1193,6 +1193,10 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
 #undef GAR_WMARK
 }
 
+} // namespace gar
+#include "gar_wave2.hpp"
+namespace gar {
+
 template <int NX, int NU, int NC = 0>
 __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int batch) {
   using C = WaveCfg<NX, NU, NC>;
@@ -1207,8 +1211,13 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   if (b >= batch)
     return;
   double *sm = gar_smem;
+#ifdef GAR_DIAG_SAMEREC // timing diagnostic: no HBM traffic (every wave works on problem 0, record 0)
+  const double *prob = P.prob;
+  double *fac = P.fac + (long long)b * P.fac_stride; // own problem's record 0: no write contention
+#else
   const double *prob = P.prob + (long long)b * P.prob_stride;
   double *fac = P.fac + (long long)b * P.fac_stride;
+#endif
   const int N = P.horizon;
   double *V = sm + C::oV, *vn = sm + C::oVn;
   // cycle stamps (scripts/trace_wave.py) only in the debug build (make trace, -DGAR_TRACE): the
@@ -1256,8 +1265,17 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   }
   wave_sync();
   int failed = 0;
-  for (int t = N - 1; t >= 0; --t)
-    wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+  for (int t = N - 1; t >= 0; --t) {
+    if constexpr (NC == 0) {
+#ifdef GAR_STAGE_V1
+      wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+#else
+      wave_stage2<NX, NU>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+#endif
+    } else {
+      wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+    }
+  }
   // ---- initial stage (proximal-riccati.hxx:42-60), fused: kkt0 = [Vxx0 G0^T; G0 0] is
   // Bunch-Kaufman-factorised by this wave right away (packed lower triangle in LDS, read from
   // the V and vx this wave still holds) and solved for kkt0.ff = -kkt0^{-1} [vx0; g0]

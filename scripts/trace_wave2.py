@@ -1,0 +1,24 @@
+"""Phase-by-phase cycle breakdown of one stage of the second-generation plain stage (gar_wave2.hpp)."""
+import ctypes as C, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from aligator_amd import synth_device
+from aligator_amd.gar import BatchedRiccatiSolver
+TRACE_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aligator_amd", "libgar_hip_trace.so")  # make -C aligator_amd/csrc trace
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+nx, nu, N = 36, 12, 256
+dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
+s = BatchedRiccatiSolver(dims, nx, batch=B, lib_path=TRACE_LIB)
+synth_device.fill_problems(s, seed=1, mode="W")
+s.backward(1e-14)
+out = (C.c_longlong * 64)()
+s._L.gar_hip_debug_trace(s.handle, 1, None)
+s.backward(1e-14)
+s._L.gar_hip_debug_trace(s.handle, 0, out)
+t = np.array(list(out))
+marks = [(0, "start"), (1, "P,H tile col 2"), (2, "Rhat->LDS,factor"), (3, "P,H cols 1,0"), (4, "hq,Bop-loads"),
+         (5, "solve-operands"), (6, "solve"), (11, "K-store"), (7, "kff,yff,vx"), (12, "Aff-mfma"), (8, "Aff-store,load_a"),
+         (13, "Vxx-mfma"), (14, "V->LDS"), (9, "load_b"), (10, "Vxx-store")]
+print(f"{s.kernel_name} batch {B}: cycles per phase (s_memtime ticks), total {t[10]-t[0]}")
+print(" | ".join(f"{marks[i][1]}={t[marks[i][0]]-t[marks[i-1][0]]}" for i in range(1, len(marks))))
