@@ -408,9 +408,11 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
   }
   if (lane == 0) { // which factorisation the block holds: 0 = L, 1/d (unpivoted) ; 2 = Bunch-Kaufman
     sm[C::oFlag] = verdict == 0 ? 0.0 : 2.0;
-    atomicAdd(&slow[0], 1);
-    if (verdict != 0)
-      atomicAdd(&slow[1], 1);
+    if (slow != nullptr) {
+      atomicAdd(&slow[0], 1);
+      if (verdict != 0)
+        atomicAdd(&slow[1], 1);
+    }
   }
   wave_sync();
   const int col = lane <= NX ? lane : NX;
@@ -1265,17 +1267,28 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   }
   wave_sync();
   int failed = 0;
+#ifndef GAR_STAGE_V1
+  // gar_wave2.hpp: a stage leaves its Vxx in LDS and the NEXT stage copies it to HBM behind its
+  // MFMAs; the first stage re-writes the terminal Vxx (same values), the last one is flushed below
+  [[maybe_unused]] double *vflush = fac + P.fac_offN + M::tVxx;
+#endif
   for (int t = N - 1; t >= 0; --t) {
     if constexpr (NC == 0) {
 #ifdef GAR_STAGE_V1
       wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
 #else
-      wave_stage2<NX, NU>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+      wave_stage2<NX, NU>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing);
 #endif
     } else {
       wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
     }
   }
+#ifndef GAR_STAGE_V1
+  if constexpr (NC == 0) {
+    if (N > 0)
+      wave_flush_vxx<NX>(V, vflush, lane);
+  }
+#endif
   // ---- initial stage (proximal-riccati.hxx:42-60), fused: kkt0 = [Vxx0 G0^T; G0 0] is
   // Bunch-Kaufman-factorised by this wave right away (packed lower triangle in LDS, read from
   // the V and vx this wave still holds) and solved for kkt0.ff = -kkt0^{-1} [vx0; g0]

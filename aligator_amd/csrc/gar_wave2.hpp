@@ -143,11 +143,170 @@ __device__ __forceinline__ void ldl_solve_mfma4(const double (&An)[KU][KU], cons
   }
 }
 
+// sum over the four 16-lane rows of the wave, in every lane: two v_permlane{16,32}_swap exchanges on
+// the VALU (gfx950) instead of two ds_bpermute round trips through the LDS crossbar
+__device__ __forceinline__ double rows_sum(double a, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+  (void)lane;
+  unsigned lo = (unsigned)__double2loint(a), hi = (unsigned)__double2hiint(a);
+  uint2v l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  uint2v h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double s = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  lo = (unsigned)__double2loint(s);
+  hi = (unsigned)__double2hiint(s);
+  l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+#else
+  a += __shfl_xor(a, 16);
+  a += __shfl_xor(a, 32);
+  return a;
+#endif
+}
+
+// Reduce-scatter over the four 16-lane rows: every lane holds partial sums p0..p3 (one per
+// destination row), row g ends up with the sum of p_g over the four rows.  Recursive halving on
+// v_permlane32_swap / v_permlane16_swap: a swap of (keep, send) register pairs IS the exchange --
+// three swaps + three adds per double instead of one all-reduce (two swaps, two copies, two adds)
+// per destination and a select.
+__device__ __forceinline__ double rows_reduce_scatter(double p0, double p1, double p2, double p3, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+  (void)lane;
+  // halves: lower rows {0,1} keep p0 / p1 and send p2 / p3, upper rows the other way round
+  auto swap32_add = [](double keep_lo, double keep_hi) {
+    const uint2v l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(keep_lo), (unsigned)__double2loint(keep_hi), false, false);
+    const uint2v h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(keep_lo), (unsigned)__double2hiint(keep_hi), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  };
+  const double s02 = swap32_add(p0, p2); // rows 0,1: p0 summed over {g, g^2}; rows 2,3: p2
+  const double s13 = swap32_add(p1, p3); // rows 0,1: p1 ...                 ; rows 2,3: p3
+  const uint2v l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(s02), (unsigned)__double2loint(s13), false, false);
+  const uint2v h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(s02), (unsigned)__double2hiint(s13), false, false);
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+#else
+  const int g = lane >> 4;
+  // step 1: the partner row g^2 sends what this half wants
+  const double ra = __shfl_xor((g & 2) ? p0 : p2, 32), rb = __shfl_xor((g & 2) ? p1 : p3, 32);
+  const double s_a = ((g & 2) ? p2 : p0) + ra, s_b = ((g & 2) ? p3 : p1) + rb;
+  // step 2: the partner row g^1
+  const double mine = (g & 1) ? s_b : s_a, give = (g & 1) ? s_a : s_b;
+  return mine + __shfl_xor(give, 16);
+#endif
+}
+
+// the register LDL^T of wave_ldl_fast_neg on rows already in registers (a[j] = Rhat(row, j))
+// Rare path, out of line: column k failed the FIRST Bunch-Kaufman test (|a_kk| >= alpha colmax,
+// bunchkaufman.hpp:61).  Evaluate the second one (:63-75) on the rows the factorisation holds in
+// registers (lane = row i: R.a[j] = trailing A(i, j), j <= i): imax = first row attaining colmax,
+// rowmax = largest off-diagonal entry of row / column imax of the trailing matrix; Bunch-Kaufman
+// keeps kp = k iff |a_kk| >= (alpha colmax) (colmax / rowmax).  Returns 0 in that case (the
+// unpivoted elimination the caller is doing IS Bunch-Kaufman's), 1 when it interchanges or takes a
+// 2x2 pivot (or the column is zero): the stage then goes to wave_slow_factor_solve.
+template <int NU> struct LdlRow { double a[NU]; };
+template <int NU>
+__device__ __attribute__((noinline)) int wave_bk_second_test(LdlRow<NU> R, double akk, int k, int lane) {
+  const double alpha = (1.0 + 4.123105625617661) / 8.0;
+  double ck = 0.0;
+#pragma unroll
+  for (int c = 0; c < NU; ++c)
+    ck = (c == k) ? R.a[c] : ck;
+  const bool below = lane > k && lane < NU;
+  const double absc = below ? fabs(ck) : 0.0;
+  const double colmax = wave_max_f64(absc);
+  const unsigned long long hit = __ballot(below && absc == colmax);
+  const int imax = hit ? (int)__builtin_ctzll(hit) : k + 1; // maxCoeff keeps the first maximum
+  double rp = 0.0; // own row, columns k .. lane-1
+#pragma unroll
+  for (int j = 0; j < NU; ++j)
+    rp = (j >= k && j < lane) ? fmax(rp, fabs(R.a[j])) : rp;
+  const double rowpart = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rp), imax),
+                                          __builtin_amdgcn_readlane(__double2loint(rp), imax));
+  double ti = 0.0;
+#pragma unroll
+  for (int c = 0; c < NU; ++c)
+    ti = (c == imax) ? R.a[c] : ti;
+  const double colpart = wave_max_f64((lane > imax && lane < NU) ? fabs(ti) : 0.0);
+  const double rowmax = fmax(rowpart, colpart);
+  // lane 0's verdict for the whole wave: akk is the pivot only in the first 16-lane row (the other
+  // rows hold copies of row NU-1, see wave_ldl_fast_neg)
+  return __builtin_amdgcn_readfirstlane((fabs(akk) >= (alpha * colmax) * (colmax / rowmax)) ? 0 : 1);
+}
+
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(p); // the v_cmp result itself (HIP's __ballot goes through an int)
+#else
+  return __ballot(p);
+#endif
+}
+// The register LDL^T of wave_ldl_fast_neg on rows already in registers (a[j] = Rhat(row, j)), under
+// the COMPLETE pivot rule: a column that fails the first test is checked out of line against the
+// second one and the elimination goes on when Bunch-Kaufman keeps kp = k.  Returns 0 when it kept
+// kp = k at every column; `first_failed` tells whether any column needed the second test.
+template <int NU>
+__device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], double (&nd)[NU], bool &first_failed) {
+  static_assert(NU <= 16, "lane = row inside one 16-lane DPP row");
+  const double alpha = (1.0 + 4.123105625617661) / 8.0;
+  int bad = 0;
+  first_failed = false;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const double akk = row_bcast(a[k], k, lane);
+    const unsigned long long nok = wave_ballot(!(fabs(akk) >= alpha * fabs(a[k])) || akk == 0.0);
+    const unsigned long long from_k = ((1ull << NU) - 1ull) & ~((1ull << k) - 1ull);
+    if (nok & from_k) { // wave-uniform, rare
+      first_failed = true;
+      LdlRow<NU> R;
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+        R.a[j] = a[j];
+      bad |= wave_bk_second_test<NU>(R, akk, k, lane);
+    }
+    const double nd_k = -fast_rcp(akk);
+    const double nlik = a[k] * nd_k; // -L(i,k)
+#pragma unroll
+    for (int j = k + 1; j < NU; ++j)
+      a[j] = __builtin_fma(row_bcast(nlik, j, lane), a[k], a[j]); // a(i,j) -= L(j,k) a(i,k)
+    a[k] = nlik;
+    nd[k] = nd_k;
+  }
+  return bad;
+}
+
+// Vxx (the symmetric content of V in LDS) -> HBM, 16 B per lane, linear
+template <int NX> __device__ __forceinline__ void wave_flush_vxx(const double *V, double *dst, int lane) {
+  constexpr int NCH = (NX * NX / 2 + 63) / 64;
+  double2_t vbuf[NCH];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    const int ec = (64 * q + 63 < NX * NX / 2) ? e : (e < NX * NX / 2 ? e : NX * NX / 2 - 1);
+    vbuf[q] = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
+  }
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
+      *reinterpret_cast<double2_t *>(&dst[2 * e]) = vbuf[q];
+  }
+}
+
+// A memory instruction issued right behind a v_mfma_f64_16x16x4 costs ~8 cycles of the wave's time
+// instead of ~20 (the MFMA holds the VALU for 64 cycles; LDS and memory instructions of the same
+// wave keep issuing: scripts/ubench/overlap.cpp).  The compiler's scheduler clusters memory
+// instructions instead, so the phases below pin their order (sched_barrier) and SLOT the stage's
+// independent memory work -- the previous stage's Vxx -> HBM, the rows of Rhat for the
+// factorisation, B for Aff, the gains' stores, the next knot's loads, the V tiles -> LDS -- behind
+// the MFMAs of the tile columns, of Aff and of Vxx.
+#define GAR_SB __builtin_amdgcn_sched_barrier(0)
+
 template <int NX, int NU>
 __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, const double *prob,
                                             double *fac, int t, int lane,
                                             const WaveLane<NX, NU, 0> &L, WaveStage<NX, NU> &S,
-                                            int &failed, const bool tracing) {
+                                            int &failed, double *&vflush, const bool tracing) {
   using C = WaveCfg<NX, NU, 0>;
   using M = MfmaCfg<NX, NU, 0>;
   constexpr int NK = C::NK, NR = C::NR;
@@ -193,11 +352,59 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   constexpr int TXF = C::REM4 ? TX - 1 : TX;
   const int i4 = lane & 3, k4 = lane >> 4;
   constexpr int cR = NX >> 4; // first tile column holding control columns: Rhat needs tj >= cR
-  double part[TW];            // (F^T vx' + P^T f)[16 tj + li], summed over this lane's rows
+  // V' as the A operand of P = V'F: the same registers serve every tile column
+  double Vop[TXF > 0 ? TXF : 1][KS], Vop4[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+#pragma unroll
+    for (int tm = 0; tm < TXF; ++tm) {
+      const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
+      Vop[tm][s] = V[ic * PK + 4 * s + lk];
+    }
+    Vop4[s] = C::REM4 ? V[(NX - 4 + i4) * PK + 4 * s + k4] : 0.0;
+  }
+  double part[TW]; // (F^T vx' + P^T f)[16 tj + li], summed over this lane's rows
   double a_row[NU], nd[NU];
-  int verdict = 0;
+  double Bop[TX][KU]; // B of this knot as the A operand of Aff = A + B K: B[16ti+li][4s'+lk]
+  double Bop4[KU];    // REM4: B[NX-4+i4][4s'+k4], the A operand of the 4x4x4 blocks
+  // ---- memory work slotted behind the MFMAs of the tile columns tj < cR (list A) ----------------
+  constexpr int NCH = (NX * NX / 2 + 63) / 64;
+  constexpr int nA_flush = NCH + 2, nA_rows = NU, nA_bop = TX * KU + (C::REM4 ? KU : 0);
+  constexpr int nA = nA_flush + nA_rows + nA_bop;
+  double2_t vbuf[NCH];
+  const int frow = lane < NU ? lane : NU - 1;
+  auto slotA = [&](int i) { // i: compile-time after unrolling
+    if (i < nA_flush) {     // the previous stage's Vxx -> HBM: LDS read of chunk i, store of chunk i-2
+      if (i < NCH) {
+        const int e = 64 * i + lane;
+        const int ec = (64 * i + 63 < NX * NX / 2) ? e : (e < NX * NX / 2 ? e : NX * NX / 2 - 1);
+        vbuf[i < NCH ? i : 0] = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
+      }
+      if (i >= 2) {
+        const int q = i - 2;
+        const int e = 64 * q + lane;
+        if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
+          *reinterpret_cast<double2_t *>(&vflush[2 * e]) = vbuf[q < NCH ? q : 0];
+      }
+    } else if (i < nA_flush + nA_rows) { // Rhat, lane = row
+      const int j = i - nA_flush;
+      a_row[j < NU ? j : 0] = Mm[j * NU + frow];
+    } else if (i < nA) {
+      const int q = i - nA_flush - nA_rows;
+      if (q < TX * KU) {
+        const int ti = q / KU, sq = q % KU;
+        Bop[ti < TX ? ti : 0][sq] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * sq * NX + 16 * ti, L.bop0)
+                                                            : ldg_b(rec, 4 * sq * NX, L.bopX);
+      } else {
+        const int sq = q - TX * KU;
+        Bop4[sq < KU ? sq : 0] = ldg_b(rec, 4 * sq * NX, L.bop4);
+      }
+    }
+  };
+  int sA = 0; // next op of list A
 #pragma unroll
   for (int tj = TW - 1; tj >= 0; --tj) {
+    const bool pinned = (tj < cR); // compile-time
     double4_t Pt[TX];
     double p4 = 0.0;
 #pragma unroll
@@ -208,12 +415,30 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
       const double bq = S.fo(tj, s);
 #pragma unroll
       for (int tm = 0; tm < TXF; ++tm) {
-        const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
-        const double aq = V[ic * PK + 4 * s + lk];
-        Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, Pt[tm], 0, 0, 0);
+        Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vop[tm][s], bq, Pt[tm], 0, 0, 0);
+        if (pinned) {
+          GAR_SB;
+          if (sA < nA)
+            slotA(sA++);
+          GAR_SB;
+        }
       }
       if (C::REM4)
-        p4 = __builtin_amdgcn_mfma_f64_4x4x4f64(V[(NX - 4 + i4) * PK + 4 * s + k4], bq, p4, 0, 0, 0);
+        p4 = __builtin_amdgcn_mfma_f64_4x4x4f64(Vop4[s], bq, p4, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = tj; ti < TW; ++ti) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const double pq = (C::REM4 && (s >> 2) == TX - 1) ? p4 : Pt[s >> 2][s & 3];
+        S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.fo(ti, s), pq, S.Hc[ti][tj], 0, 0, 0);
+        if (pinned) {
+          GAR_SB;
+          if (sA < nA)
+            slotA(sA++);
+          GAR_SB;
+        }
+      }
     }
     {
       double a0 = 0.0, a1 = 0.0;
@@ -225,18 +450,9 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
       }
       part[tj] = a0 + a1;
     }
-#pragma unroll
-    for (int ti = tj; ti < TW; ++ti) {
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const double pq = (C::REM4 && (s >> 2) == TX - 1) ? p4 : Pt[s >> 2][s & 3];
-        S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.fo(ti, s), pq, S.Hc[ti][tj], 0, 0, 0);
-      }
-    }
     if (tj == cR) {
       GAR_WMARK(1)
-      // ---- Rhat (lower) is complete: LDS -> lane = row -> register LDL^T under the first
-      // Bunch-Kaufman test, issued while the remaining tile columns run on the matrix pipe
+      // ---- Rhat (lower) is complete: to LDS (column-major), read back lane = row by list A
 #pragma unroll
       for (int ti = cR; ti < TW; ++ti)
 #pragma unroll
@@ -250,53 +466,46 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
             }
           }
       wave_lds_order();
-      verdict = wave_ldl_fast_neg<NU>(Mm, lane, a_row, nd);
-      if (lane < NU) {
-#pragma unroll
-        for (int j = 0; j < NU; ++j)
-          Lr[lane * NU + j] = a_row[j]; // -L row-major (entries j >= i: not L, masked at the reads)
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < NU; ++j)
-          ndi[j] = nd[j];
-      }
-      GAR_WMARK(2)
+      if (cR > 0)
+        GAR_SB;
     }
+  }
+  if (cR > 0)
+    GAR_SB;
+#pragma unroll
+  for (int i = 0; i < nA; ++i) // what did not find a shadow (all of it for the shapes with cR = 0)
+    if (i >= sA)
+      slotA(i);
+  GAR_WMARK(2)
+  // ---- register LDL^T of Rhat under the first Bunch-Kaufman test; -L and -1/d to LDS -------------
+  bool first_failed;
+  const int verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed);
+  if (first_failed && lane == 0) { // diagnostics: stages that needed the second test / that really pivot
+    atomicAdd(&P.slow[0], 1);
+    if (verdict != 0)
+      atomicAdd(&P.slow[1], 1);
+  }
+  if (lane < NU) {
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+      Lr[lane * NU + j] = a_row[j]; // -L row-major (entries j >= i: not L, masked at the reads)
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+      ndi[j] = nd[j];
   }
   GAR_WMARK(3)
   // ---- [qhat; rhat] = [q; r] + F^T vx' + P^T f (:217-218, :227-228) ---------------------------
   double hq;
   const double fi = S.fi;
   {
-#pragma unroll
-    for (int tt = 0; tt < TW; ++tt) {
-      double a = part[tt];
-      a += __shfl_xor(a, 16);
-      a += __shfl_xor(a, 32);
-      part[tt] = a; // column 16 tt + li, replicated over lk
-    }
-    double sel = part[0];
-#pragma unroll
-    for (int tt = 1; tt < TW; ++tt)
-      sel = (lk == tt) ? part[tt] : sel;
+    static_assert(TW <= 4, "one destination row of lanes per tile column");
+    const double sel = rows_reduce_scatter(part[0], TW > 1 ? part[TW > 1 ? 1 : 0] : 0.0,
+                                           TW > 2 ? part[TW > 2 ? 2 : 0] : 0.0, TW > 3 ? part[TW > 3 ? 3 : 0] : 0.0, lane);
     hq = S.qri + sel;
     if (lane >= NX && lane < NW)
       G[(lane - NX) * PG] = hq; // rhat
-  }
-  // B of this knot as the A operand of Aff = A + B K
-  double Bop[TX][KU];
-  double Bop4[KU];
-#pragma unroll
-  for (int ti = 0; ti < TX; ++ti)
-#pragma unroll
-    for (int s = 0; s < KU; ++s)
-      Bop[ti][s] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * s * NX + 16 * ti, L.bop0)
-                                              : ldg_b(rec, 4 * s * NX, L.bopX);
-  if (C::REM4) {
-#pragma unroll
-    for (int s = 0; s < KU; ++s)
-      Bop4[s] = ldg_b(rec, 4 * s * NX, L.bop4);
   }
   wave_lds_order();
   GAR_WMARK(4)
@@ -367,7 +576,7 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
           }
         }
     wave_sync();
-    failed |= wave_slow_factor_solve<NX, NU, false>(sm, lane, P.slow);
+    failed |= wave_slow_factor_solve<NX, NU, false>(sm, lane, nullptr); // (counted by wave_bk_rule_check)
 #pragma unroll
     for (int tj = 0; tj < TX; ++tj) {
       const int cc = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
@@ -378,14 +587,6 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   }
   wave_lds_order();
   GAR_WMARK(6)
-  // ---- K -> fb rows 0..NU-1 (fbT2) ---------------------------------------------------------------
-#pragma unroll
-  for (int tj = 0; tj < TX; ++tj)
-#pragma unroll
-    for (int s = 0; s < KU; ++s)
-      if (16 * tj + 15 < NX || 16 * tj + li < NX)
-        stg_b(out, M::fFB + 8 * tj * 2 * NR + 8 * s, L.fbl, Kb[tj][s]);
-  GAR_WMARK(11)
   // ---- kff; yff = f + B kff (:266); vx = qhat + Shat kff (:275-276) ----------------
   {
     double kf[KU]; // kff[4s'+lk]
@@ -401,19 +602,13 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
         a = __builtin_fma(Bop[ti][s], kf[s], a);
         c = __builtin_fma(S.Hc[C::shTile(s)][ti][C::shReg(s)], kf[s], c); // Shat(16ti+li, 4s+lk)
       }
-      a += __shfl_xor(a, 16);
-      c += __shfl_xor(c, 16);
-      a += __shfl_xor(a, 32);
-      c += __shfl_xor(c, 32);
       py[ti] = a;
       pv[ti] = c;
     }
-    double sy = py[0], sv = pv[0];
-#pragma unroll
-    for (int ti = 1; ti < TX; ++ti) {
-      sy = (lk == ti) ? py[ti] : sy;
-      sv = (lk == ti) ? pv[ti] : sv;
-    }
+    const double sy = rows_reduce_scatter(py[0], TX > 1 ? py[TX > 1 ? 1 : 0] : 0.0, TX > 2 ? py[TX > 2 ? 2 : 0] : 0.0,
+                                          TX > 3 ? py[TX > 3 ? 3 : 0] : 0.0, lane);
+    const double sv = rows_reduce_scatter(pv[0], TX > 1 ? pv[TX > 1 ? 1 : 0] : 0.0, TX > 2 ? pv[TX > 2 ? 2 : 0] : 0.0,
+                                          TX > 3 ? pv[TX > 3 ? 3 : 0] : 0.0, lane);
     const double yf = fi + sy, vxv = hq + sv;
     if (lane < NU)
       out[M::fFF + lane] = G[lane * PG];
@@ -424,7 +619,9 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
     }
   }
   GAR_WMARK(7)
-  // ---- Aff = A + B K (:267), in place on the F operand registers ------------------
+  // ---- Aff = A + B K (:267), in place on the F operand registers, one tile column after the
+  // other; behind the MFMAs of column tj: the stores of K (tj = 0) / of Aff's column tj-1 and the
+  // loads of the next knot's F operands into the registers that column just released ------------
   double4_t accT[TX];
   if (C::KST > 0 && !C::REM4) {
 #pragma unroll
@@ -433,113 +630,185 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
       for (int r = 0; r < 4; ++r)
         accT[tj][r] = (r < C::KST) ? S.FoT[tj][r] : 0.0;
   }
+  constexpr int nKst = TX * KU;
+  auto store_K = [&](int q) {
+    const int tj = q / KU, sq = q % KU;
+    if (16 * tj + 15 < NX || 16 * tj + li < NX)
+      stg_b(out, M::fFB + 8 * tj * 2 * NR + 8 * sq, L.fbl, Kb[tj < TX ? tj : 0][sq]);
+  };
+  // column tj of Aff -> fb rows NK.. (fbT2), then F's column tile tj of knot t-1 into the same registers
+  constexpr int nRow4 = (NX + 3) / 4; // (ti, r) pairs with 16 ti + 4 r < NX
+  constexpr int nCol = nRow4 + KS;    // stores, then loads
+  auto col_op = [&](int tj, int q) {
+    if (q < nRow4) {
+      const int ti = q >> 2, r = q & 3;
+      const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
+      if (i < NX && j < NX)
+        stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NK + 16 * ti + 4 * r), L.fbl,
+              ti < C::KSF ? S.Fo[tj][ti < C::KSF ? ti : 0][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r]));
+    } else if (q < nCol) {
+      const int sq = q - nRow4; // k-step of F's column tile tj
+      const double v = WaveLane<NX, NU>::fo_in(tj) ? ldg_b(recn, 16 * tj * NX + 4 * sq, L.fo0)
+                                                   : ldg_b(recn, 4 * sq, L.foX);
+      if (sq < 4 * C::KSF)
+        S.Fo[tj][(sq >> 2) < C::KSF ? (sq >> 2) : 0][sq & 3] = v;
+      else
+        S.FoT[tj][(sq - 4 * C::KSF) < C::KST ? (sq - 4 * C::KSF) : 0] = v;
+    }
+  };
+  GAR_SB;
+  int pend_col = -1, pend_q = 0; // column whose stores/loads are being slotted, next op of it
+  int sK = 0;
 #pragma unroll
-  for (int s = 0; s < KU; ++s)
+  for (int tj = 0; tj < TX; ++tj) {
 #pragma unroll
-    for (int tj = 0; tj < TX; ++tj)
+    for (int s = 0; s < KU; ++s)
 #pragma unroll
       for (int ti = 0; ti < TX; ++ti) {
-        if (ti < C::KSF)
+        if (ti < C::KSF) {
           S.Fo[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], S.Fo[tj][ti], 0, 0, 0);
-        else if (C::REM4)
+        } else if (C::REM4) {
           S.FoT[tj][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(Bop4[s], Kb[tj][s], S.FoT[tj][0], 0, 0, 0);
-        else
+        } else {
           accT[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], accT[tj], 0, 0, 0);
-      }
-  GAR_WMARK(12)
+        }
+        if (ti < C::KSF || !C::REM4) { // behind a 16x16x4
+          GAR_SB;
 #pragma unroll
-  for (int tj = 0; tj < TX; ++tj)
-#pragma unroll
-    for (int ti = 0; ti < TX; ++ti)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
-        if (16 * ti + 4 * r < NX) { // compile-time
-          if (i < NX && j < NX)     // fbT2(NU+i, j), i = 16ti+4r+lk
-            stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NK + 16 * ti + 4 * r), L.fbl,
-                  ti < C::KSF ? S.Fo[tj][ti][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r]));
+          for (int rep = 0; rep < 3; ++rep) {
+            if (sK < nKst)
+              store_K(sK++);
+            else if (pend_col >= 0 && pend_q < nCol)
+              col_op(pend_col, pend_q++);
+          }
+          GAR_SB;
         }
       }
-  // ---- knot t-1: the F operands and vectors go into the registers Aff just released
-  wave_load_a<NX, NU>(recn, L, S);
+    // finish the previous column's list before this column becomes the pending one
+#pragma unroll
+    for (int q = 0; q < nCol; ++q)
+      if (pend_col >= 0 && q >= pend_q)
+        col_op(pend_col, q);
+    pend_col = tj;
+    pend_q = 0;
+  }
   GAR_WMARK(8)
-  // ---- Vxx = Qhat + Shat K (:272-273), lower tiles, mirrored into LDS --------------
+  // ---- Vxx = Qhat + Shat K (:272-273), lower tiles, tile after tile; behind the MFMAs: what is left
+  // of list B (K, the last Aff column, its F loads) and the finished tiles -> V in LDS (mirrored) ----
   constexpr int shLo = C::shTile(0);
-  double4_t accS[TX][TX];
-  double acc4[TX];
   double sh4[KU];
-#pragma unroll
-  for (int tj = 0; tj < TX; ++tj)
-#pragma unroll
-    for (int ti = tj; ti < TX; ++ti)
-      if (ti >= shLo) {
-        if (C::REM4 && ti == TX - 1)
-          acc4[tj] = S.Hc[ti][tj][0];
-        else
-          accS[ti][tj] = S.Hc[ti][tj];
-      }
   if (C::REM4) {
 #pragma unroll
     for (int s = 0; s < KU; ++s)
       sh4[s] = __shfl(S.Hc[C::shTile(s)][TX - 1][C::shReg(s)], (lane & 48) | ((NX - 4) & 15) | (lane & 3));
   }
+  auto v_write = [&](int ti, int tj, int r, double v) { // element (16ti+lk+4r, 16tj+li) and its mirror
+    const int i = 16 * ti + lk + 4 * r, c = 16 * tj + li;
+    const bool ok = (i < NX && c < NX && i >= c);
+    if (ti > tj && 16 * ti + 4 * r + 3 < NX && 16 * tj + 15 < NX) { // compile-time: all lanes valid
+      V[i * PK + c] = v;
+      V[c * PK + i] = v;
+    } else {
+      V[ok ? i * PK + c : C::oDump] = v;
+      V[ok ? c * PK + i : C::oDump + 1] = v;
+    }
+  };
+  // the 4-row remainder tiles first (16-cycle MFMAs: no shadow worth slotting into)
+  double acc4[TX];
+  if (C::REM4) {
 #pragma unroll
-  for (int s = 0; s < KU; ++s)
+    for (int tj = 0; tj < TX; ++tj) {
+      acc4[tj] = S.Hc[TX - 1][tj][0];
 #pragma unroll
-    for (int tj = 0; tj < TX; ++tj)
-#pragma unroll
-      for (int ti = tj; ti < TX; ++ti) {
-        const double aq = S.Hc[C::shTile(s)][ti][C::shReg(s)];
-        if (C::REM4 && ti == TX - 1)
-          acc4[tj] = __builtin_amdgcn_mfma_f64_4x4x4f64(sh4[s], Kb[tj][s], acc4[tj], 0, 0, 0);
-        else if (ti >= shLo)
-          accS[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], accS[ti][tj], 0, 0, 0);
-        else
-          S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], S.Hc[ti][tj], 0, 0, 0);
-      }
-  GAR_WMARK(13)
+      for (int s = 0; s < KU; ++s)
+        acc4[tj] = __builtin_amdgcn_mfma_f64_4x4x4f64(sh4[s], Kb[tj][s], acc4[tj], 0, 0, 0);
+    }
+  }
+  GAR_SB;
+  // tiles on the 16x16x4 instruction, one after the other; the tile finished last is written while
+  // the next one accumulates
+  int wr_ti = -1, wr_tj = -1, wr_q = 0; // tile being written (its accumulator is wr_acc), next register
+  double4_t wr_acc = double4_t{0.0, 0.0, 0.0, 0.0};
+  bool r4_written = !C::REM4;
 #pragma unroll
   for (int tj = 0; tj < TX; ++tj)
 #pragma unroll
-    for (int ti = tj; ti < TX; ++ti)
+    for (int ti = tj; ti < (C::REM4 ? TX - 1 : TX); ++ti) {
+      double4_t acc = S.Hc[ti][tj];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * ti + lk + 4 * r, c = 16 * tj + li;
-        if (16 * ti + 4 * r < NX) { // compile-time
-          const bool ok = (i < NX && c < NX && i >= c);
-          const double v = (C::REM4 && ti == TX - 1) ? acc4[tj]
-                                                     : (ti >= shLo ? accS[ti][tj][r] : S.Hc[ti][tj][r]);
-          if (ti > tj && 16 * ti + 4 * r + 3 < NX && 16 * tj + 15 < NX) { // compile-time: all lanes valid
-            V[i * PK + c] = v;
-            V[c * PK + i] = v;
-          } else {
-            V[ok ? i * PK + c : C::oDump] = v;
-            V[ok ? c * PK + i : C::oDump + 1] = v;
+      for (int s = 0; s < KU; ++s) {
+        const double aq = S.Hc[C::shTile(s)][ti][C::shReg(s)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], acc, 0, 0, 0);
+        GAR_SB;
+#pragma unroll
+        for (int rep = 0; rep < 3; ++rep) {
+          if (sK < nKst) {
+            store_K(sK++);
+          } else if (pend_col >= 0 && pend_q < nCol) {
+            col_op(pend_col, pend_q++);
+          } else if (!r4_written) {
+#pragma unroll
+            for (int c4 = 0; c4 < TX; ++c4)
+              v_write(TX - 1, c4, 0, acc4[c4]);
+            r4_written = true;
+          } else if (wr_ti >= 0 && wr_q < 4) {
+            if (16 * wr_ti + 4 * wr_q < NX)
+              v_write(wr_ti, wr_tj, wr_q, wr_acc[wr_q]);
+            ++wr_q;
           }
         }
+        GAR_SB;
       }
+      // the previous tile must be fully written before its slot is reused
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (wr_ti >= 0 && q >= wr_q && 16 * wr_ti + 4 * q < NX)
+          v_write(wr_ti, wr_tj, q, wr_acc[q]);
+      wr_acc = acc;
+      wr_ti = ti;
+      wr_tj = tj;
+      wr_q = 0;
+    }
+  GAR_SB;
+  // drain: list B, the remainder tiles, the last tile
+#pragma unroll
+  for (int q = 0; q < nKst; ++q)
+    if (q >= sK)
+      store_K(q);
+#pragma unroll
+  for (int q = 0; q < nCol; ++q)
+    if (pend_col >= 0 && q >= pend_q)
+      col_op(pend_col, q);
+  if (!r4_written) {
+#pragma unroll
+    for (int c4 = 0; c4 < TX; ++c4)
+      v_write(TX - 1, c4, 0, acc4[c4]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (wr_ti >= 0 && q >= wr_q && 16 * wr_ti + 4 * q < NX)
+      v_write(wr_ti, wr_tj, q, wr_acc[q]);
+  // F column tiles Aff does not touch (pure B columns), and the vectors of knot t-1
+#pragma unroll
+  for (int tcol = TX; tcol < TW; ++tcol)
+#pragma unroll
+    for (int sq = 0; sq < KS; ++sq) {
+      const double v = WaveLane<NX, NU>::fo_in(tcol) ? ldg_b(recn, 16 * tcol * NX + 4 * sq, L.fo0)
+                                                     : ldg_b(recn, 4 * sq, L.foX);
+      if (sq < 4 * C::KSF)
+        S.Fo[tcol][sq >> 2][sq & 3] = v;
+      else
+        S.FoT[tcol][sq - 4 * C::KSF] = v;
+    }
+  S.fi = ldg_b(recn, 0, L.fi);
+  S.qri = ldg_b(recn, 0, L.qri);
   wave_sync();
   GAR_WMARK(14)
   // ---- knot t-1: its Hessian tiles replace H
   wave_load_b<NX, NU>(recn, L, S);
   GAR_WMARK(9)
-  // ---- Vxx -> HBM (column-major, symmetric), 16 B per lane -----------------------
-  {
-    constexpr int NCH = (NX * NX / 2 + 63) / 64;
-    double2_t vbuf[NCH];
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-      const int e = 64 * q + lane;
-      const int ec = (64 * q + 63 < NX * NX / 2) ? e : (e < NX * NX / 2 ? e : NX * NX / 2 - 1);
-      vbuf[q] = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
-    }
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-      const int e = 64 * q + lane;
-      if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
-        *reinterpret_cast<double2_t *>(&out[oVxx + 2 * e]) = vbuf[q];
-    }
-  }
+  // ---- Vxx -> HBM is left to the next stage (list A) / to the caller after the last one -----------
+  vflush = out + oVxx;
   GAR_WMARK(10)
 #undef GAR_WMARK
 }

@@ -17,8 +17,7 @@ s._L.gar_hip_debug_trace(s.handle, 1, None)
 s.backward(1e-14)
 s._L.gar_hip_debug_trace(s.handle, 0, out)
 t = np.array(list(out))
-marks = [(0, "start"), (1, "P,H tile col 2"), (2, "Rhat->LDS,factor"), (3, "P,H cols 1,0"), (4, "hq,Bop-loads"),
-         (5, "solve-operands"), (6, "solve"), (11, "K-store"), (7, "kff,yff,vx"), (12, "Aff-mfma"), (8, "Aff-store,load_a"),
-         (13, "Vxx-mfma"), (14, "V->LDS"), (9, "load_b"), (10, "Vxx-store")]
+marks = [(0, "start"), (1, "P,H col 2"), (2, "P,H cols 1,0 + slots A"), (3, "factor"), (4, "hq"),
+         (5, "solve-operands"), (6, "solve"), (7, "kff,yff,vx"), (8, "Aff + slots B"), (14, "Vxx + slots, V->LDS"), (9, "load_b"), (10, "end")]
 print(f"{s.kernel_name} batch {B}: cycles per phase (s_memtime ticks), total {t[10]-t[0]}")
 print(" | ".join(f"{marks[i][1]}={t[marks[i][0]]-t[marks[i-1][0]]}" for i in range(1, len(marks))))

@@ -269,3 +269,46 @@ def check_constrained_pivoting(lib_path=None, shapes=((8, 4, 4, 6, 1e-6), (16, 8
             solver, _, _ = check_serial(prob, mu, 1e-8, lib_path)
             assert solver.kernel_name == f"wave<{nx},{nu},{nc}>"
 
+
+
+def check_second_bunch_kaufman_test(lib_path=None):
+    """Stages whose Rhat fails the FIRST Bunch-Kaufman test (|a_kk| < alpha colmax) but passes the second
+    (|a_kk| rowmax >= alpha colmax^2, bunchkaufman.hpp:63-75): Bunch-Kaufman keeps kp = k, the kernel
+    must stay on its register LDL^T (checked out of line at that column only) -- and a variant where the
+    second test fails too, which must take the generic device Bunch-Kaufman.  Counters: (stages that
+    needed the second test, stages that really pivoted)."""
+    import os
+    from aligator_amd.gar import BatchedRiccatiSolver
+    nx, nu, horz = 8, 4, 6
+    keep = np.array([[1.0, 2.0, 0.0, 0.0], [2.0, 10.0, 3.0, 0.0], [0.0, 3.0, 20.0, 0.1], [0.0, 0.0, 0.1, 4.0]])
+    pivot = keep.copy()
+    pivot[2, 1] = pivot[1, 2] = 0.5                      # rowmax 2 < alpha * 4 / 1: interchange
+    old = os.environ.get("GAR_HIP_BACKWARD")
+    os.environ["GAR_HIP_BACKWARD"] = "wave"
+    try:
+        for Rm, want in ((keep, (horz, 0)), (pivot, (horz, horz))):
+            prob = synth.generate_lq_problem(21, np.zeros(nx), horz, nx, nu, mode="W")
+            for k in prob.stages[:-1]:
+                k.R[...] = Rm
+                k.S[...] = 0.0
+                k.B[...] = 0.0                           # Rhat = R at every stage
+            piv = ora.BunchKaufman(Rm).pivots
+            assert np.array_equal(piv, np.arange(nu)) == (want[1] == 0), piv
+            s = BatchedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, batch=1, lib_path=lib_path)
+            assert s.kernel_name == "wave<8,4>"
+            s.upload([prob])
+            assert s.backward(1e-12) and s.forward()
+            assert s.slow_path_stages() == want
+            _, osol, ref = oracle_serial(prob, 1e-12)
+            for A, B in zip(s.solution(0), ref):
+                assert maxdiff(A, B) <= 1e-9 * scale_of(ref)
+
+            class D:
+                def __getitem__(self, t):
+                    return s.factor(t, 0)
+            compare_factors(D(), osol, horz, 1e-9, names=("ff", "fb"), vnames=("Vxx", "vx"))
+    finally:
+        if old is None:
+            del os.environ["GAR_HIP_BACKWARD"]
+        else:
+            os.environ["GAR_HIP_BACKWARD"] = old

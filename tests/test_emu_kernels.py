@@ -452,3 +452,7 @@ def test_device_written_knots_survive_host_set_init():
     back = s.download_packed(0, 2)
     packed2 = np.concatenate([s.pack(p) for p in probs])
     assert np.array_equal(back, packed2)
+
+
+def test_wave_kernel_second_bunch_kaufman_test():
+    pc.check_second_bunch_kaufman_test(EMU)

@@ -332,6 +332,10 @@ def test_wave_family_bunch_kaufman_fallback_and_failure(monkeypatch):
         ProximalRiccatiSolver(bad).backward(1e-10)
 
 
+def test_wave_kernel_second_bunch_kaufman_test():
+    pc.check_second_bunch_kaufman_test()
+
+
 def test_constrained_wave_kernels_bunch_kaufman_pivoting():
     pc.check_constrained_pivoting(shapes=((8, 4, 4, 6, 1e-6), (16, 8, 8, 5, 1e-7), (36, 12, 32, 12, 1e-6)))
 
