@@ -525,6 +525,33 @@ __global__ void __launch_bounds__(256) gar_rotate_records(double *base, long lon
 }
 
 // ---------------------------------------------------------------------------
+// Bulk read-back of the gains (the loop of SolverProxDDPTpl::computeDirection that copies
+// getFeedforward(i) / getFeedback(i) of every stage, solver-proxddp.hxx:620-632): ff and fb of all
+// stages of ONE problem are gathered into two dense arrays in the reference's own storage order
+// (fb ROW-major, riccati-kernel.hpp:96-97; the specialised kernel families keep it in the fbT2
+// device order) so that the host needs ONE copy instead of 2(N+1).  grid (N+1), 256 threads.
+// goff[2t], goff[2t+1]: offsets of stage t inside ff_all / fb_all.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gar_gather_gains(const gar_stage_meta *meta, const double *fac,
+                                                        double *ff_all, double *fb_all,
+                                                        const long long *goff, int horizon, int t2, int dense) {
+  const int t = (int)blockIdx.x;
+  const gar_stage_meta m = meta[t];
+  const int nx2r = dense ? 2 * m.nx2 : m.nx2;
+  const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, nx2r, m.nth);
+  const int nr = m.nu + m.nc + nx2r, nx = m.nx;
+  const double *rec = fac + m.fac_off;
+  double *ff = ff_all + goff[2 * t], *fb = fb_all + goff[2 * t + 1];
+  for (int e = (int)threadIdx.x; e < nr; e += 256)
+    ff[e] = rec[o.ff + e];
+  const bool tr = t2 && t < horizon; // fbT2: element (r, j) at (j/2) 2nr + 2r + (j&1)
+  for (int e = (int)threadIdx.x; e < nr * nx; e += 256) {
+    const int r = e / nx, j = e - r * nx;
+    fb[e] = rec[o.fb + (tr ? (j >> 1) * (2 * nr) + 2 * r + (j & 1) : e)];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Device-resident SolverProxDDPTpl::updateLQSubproblem (solver-proxddp.hxx:734-805): one
 // workgroup per (stage, problem) turns the stage's derivative record (gar_layout.h) into its
 // knot record -- Q = Lxx + preg I [+ Hxx], S = Lxu [+ Hxu], R = Luu + preg I [+ Huu],

@@ -73,6 +73,10 @@ struct gar_hip_solver {
   int64_t G0_off = 0, g0_off = 0;
   int64_t sol_x = 0, sol_u = 0, sol_v = 0, sol_l = 0; // base offsets of xs/us/vs/lbdas
   int nx0 = 0, nth0 = 0, n0 = 0;
+  // MPC cycling as a ring (uniform serial problems): logical stage t < horizon lives in record slot
+  // (t + ring0) mod horizon; meta[t].in_off / fac_off follow, the records never move
+  int ring0 = 0;
+  int64_t uni_in0 = 0, uni_in_rec = 0, uni_fac_rec = 0; // slot 0 and the record pitches (layout time)
   double *d_prob = nullptr, *d_fac = nullptr, *d_sol = nullptr, *d_init = nullptr;
   double *d_theta = nullptr;
   int *d_status = nullptr;
@@ -132,6 +136,12 @@ struct gar_hip_solver {
   std::vector<long long> deriv_off; // per stage
   long long deriv_doubles = 0, d_G0 = 0, d_g0 = 0, d_iH = 0;
   long long *d_deriv_off = nullptr;
+  // bulk read-back (gar_hip_fetch_results): per-stage offsets inside ff_all / fb_all, the device
+  // gather buffer and the pinned host buffer [solution | ff_all | fb_all] of one problem
+  std::vector<long long> gain_off; // 2 per stage
+  long long ff_all_doubles = 0, fb_all_doubles = 0;
+  long long *d_gain_off = nullptr;
+  double *d_gains = nullptr, *h_results = nullptr;
   bool timing = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -236,8 +246,26 @@ int build_layout(gar_hip_solver *s) {
     }
     s->deriv_doubles = p;
   }
+  {
+    long long pf = 0, pb = 0;
+    s->gain_off.assign(2 * (size_t)(N + 1), 0);
+    for (int t = 0; t <= N; ++t) {
+      const int32_t *d = &s->dims5[5 * t];
+      const long long nr = (long long)d[1] + d[2] + (s->dense ? 2 * d[3] : d[3]);
+      s->gain_off[2 * t] = pf;
+      s->gain_off[2 * t + 1] = pb;
+      pf += nr;
+      pb += nr * d[0];
+    }
+    s->ff_all_doubles = pf;
+    s->fb_all_doubles = pb;
+  }
   s->init_doubles = ((int64_t)s->n0 + (int64_t)s->n0 * s->nth0 + s->nth0 +
                      (int64_t)s->nth0 * s->nth0 + 1) & ~(int64_t)1;
+  s->ring0 = 0;
+  s->uni_in0 = s->meta[0].in_off;
+  s->uni_in_rec = N > 1 ? s->meta[1].in_off - s->meta[0].in_off : s->meta[N].in_off - s->meta[0].in_off;
+  s->uni_fac_rec = N > 1 ? s->meta[1].fac_off - s->meta[0].fac_off : s->meta[N].fac_off;
   return GAR_HIP_OK;
 }
 
@@ -596,6 +624,17 @@ int write_block(gar_hip_solver *s, int b, int64_t off, const double *src, int64_
     else
       std::memset(dst, 0, sizeof(double) * (size_t)n);
     mark_dirty(s, b, off, off + n);
+    // pipeline the upload: once the range being appended to has grown past 1 MiB it goes out
+    // (asynchronously, pinned -> HBM) while the caller packs the next knots -- one Newton
+    // iteration's 7.6 MB of knots then costs max(host packing, PCIe), not their sum
+    auto &iv = s->dirty_iv[(size_t)b];
+    if (iv.back().second - iv.back().first >= (int64_t)(1 << 17)) {
+      const int64_t lo = iv.back().first, hi = std::min(iv.back().second, s->prob_doubles);
+      HIP_TRY(hipMemcpyAsync(s->d_prob + (int64_t)b * s->prob_doubles + lo,
+                             s->h_prob + (int64_t)b * s->prob_doubles + lo,
+                             sizeof(double) * (size_t)(hi - lo), hipMemcpyHostToDevice, s->stream));
+      iv.pop_back();
+    }
     return GAR_HIP_OK;
   }
   double *dst = s->d_prob + (int64_t)b * s->prob_doubles + off;
@@ -615,8 +654,8 @@ gar::LegParams make_leg_params(gar_hip_solver *s) {
   Q.M.slow = s->d_status + s->batch;
   Q.M.prob_stride = s->prob_doubles;
   Q.M.fac_stride = s->fac_doubles;
-  Q.M.in_off0 = s->meta[0].in_off;
-  Q.M.in_rec = N > 1 ? s->meta[1].in_off - s->meta[0].in_off : s->meta[N].in_off - s->meta[0].in_off;
+  Q.M.in_off0 = s->uni_in0;
+  Q.M.in_rec = s->uni_in_rec;
   Q.M.in_offN = s->meta[N].in_off;
   Q.M.horizon = N;
   Q.M.trace = s->d_trace;
@@ -670,10 +709,10 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.prob_stride = s->prob_doubles;
     M.fac_stride = s->fac_doubles;
     const int N = s->horizon;
-    M.in_off0 = s->meta[0].in_off;
-    M.in_rec = N > 1 ? s->meta[1].in_off - s->meta[0].in_off : s->meta[N].in_off - s->meta[0].in_off;
+    M.in_off0 = s->uni_in0;
+    M.in_rec = s->uni_in_rec;
     M.in_offN = s->meta[N].in_off;
-    M.fac_rec = N > 1 ? s->meta[1].fac_off - s->meta[0].fac_off : s->meta[N].fac_off;
+    M.fac_rec = s->uni_fac_rec;
     M.fac_offN = s->meta[N].fac_off;
     M.horizon = N;
     M.trace = s->d_trace;
@@ -685,6 +724,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.nc0 = s->nc0;
     M.mueq = mueq;
     M.init_closed = s->init_closed ? 1 : 0;
+    M.ring0 = s->ring0;
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->wave_kernel) {
@@ -742,13 +782,14 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
     F.fac_stride = s->fac_doubles;
     F.init_stride = s->init_doubles;
     F.sol_stride = s->sol_doubles;
-    F.fac_rec = N > 1 ? s->meta[1].fac_off - s->meta[0].fac_off : s->meta[N].fac_off;
+    F.fac_rec = s->uni_fac_rec;
     F.fac_offN = s->meta[N].fac_off;
     F.horizon = N;
     F.nc0 = s->nc0;
     F.sol_u = (int)s->sol_u;
     F.sol_l = (int)s->sol_l;
     F.sol_v = (int)s->sol_v;
+    F.ring0 = s->ring0;
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[3], s->stream));
     hipLaunchKernelGGL(s->mfma_fwd_kernel, dim3((unsigned)s->batch), dim3(64), 0, s->stream, F);
@@ -876,6 +917,13 @@ void free_device(gar_hip_solver *s) {
   s->d_trace = nullptr;
   (void)hipFree(s->d_deriv_off);
   s->d_deriv_off = nullptr;
+  (void)hipFree(s->d_gain_off);
+  (void)hipFree(s->d_gains);
+  if (s->h_results)
+    (void)hipHostFree(s->h_results);
+  s->d_gain_off = nullptr;
+  s->d_gains = nullptr;
+  s->h_results = nullptr;
   if (s->h_prob)
     (void)hipHostFree(s->h_prob);
   s->d_meta = nullptr;
@@ -1439,6 +1487,73 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
   return GAR_HIP_OK;
 }
 
+int gar_hip_gains_doubles(const gar_hip_solver *s, int64_t out[2]) {
+  if (!s || !out)
+    return fail(GAR_HIP_ERR_ARG, "bad argument");
+  out[0] = s->ff_all_doubles;
+  out[1] = s->fb_all_doubles;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_gains_offsets(const gar_hip_solver *s, int t, int64_t out[2]) {
+  if (int rc = check_bt(s, 0, t))
+    return rc;
+  out[0] = s->gain_off[2 * (size_t)t];
+  out[1] = s->gain_off[2 * (size_t)t + 1];
+  return GAR_HIP_OK;
+}
+
+int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  const size_t nsol = (size_t)s->sol_doubles, ngain = (size_t)(s->ff_all_doubles + s->fb_all_doubles);
+  if (!s->h_results) { // first use: the buffers live as long as the solver's layout
+    HIP_TRY(hipHostMalloc((void **)&s->h_results, sizeof(double) * (nsol + ngain), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&s->d_gains, sizeof(double) * std::max<size_t>(ngain, 1)));
+    HIP_TRY(hipMalloc((void **)&s->d_gain_off, sizeof(long long) * s->gain_off.size()));
+    HIP_TRY(hipMemcpyAsync(s->d_gain_off, s->gain_off.data(), sizeof(long long) * s->gain_off.size(),
+                           hipMemcpyHostToDevice, s->stream));
+  }
+  if (what & 2) { // device-side gather (fbT2 -> row-major), then ONE device-to-host copy
+    const bool t2 = s->mfma_kernel || s->wave_kernel || s->leg_bwd_kernel;
+    hipLaunchKernelGGL(gar::gar_gather_gains, dim3((unsigned)(s->horizon + 1)), dim3(256), 0, s->stream,
+                       s->d_meta, s->d_fac + (int64_t)b * s->fac_doubles, s->d_gains,
+                       s->d_gains + s->ff_all_doubles, s->d_gain_off, s->horizon, t2 ? 1 : 0,
+                       s->dense ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(s->h_results + nsol, s->d_gains, sizeof(double) * ngain, hipMemcpyDeviceToHost,
+                           s->stream));
+  }
+  if (what & 1)
+    HIP_TRY(hipMemcpyAsync(s->h_results, s->d_sol + (int64_t)b * s->sol_doubles, sizeof(double) * nsol,
+                           hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+const double *gar_hip_host_results(gar_hip_solver *s, int64_t offs[3]) {
+  if (!s)
+    return nullptr;
+  if (offs) {
+    offs[0] = 0;
+    offs[1] = s->sol_doubles;
+    offs[2] = s->sol_doubles + s->ff_all_doubles;
+  }
+  return s->h_results;
+}
+
+int gar_hip_get_gains_all(gar_hip_solver *s, int b, double *ff_all, double *fb_all) {
+  if (int rc = gar_hip_fetch_results(s, b, 2))
+    return rc;
+  if (ff_all)
+    std::memcpy(ff_all, s->h_results + s->sol_doubles, sizeof(double) * (size_t)s->ff_all_doubles);
+  if (fb_all)
+    std::memcpy(fb_all, s->h_results + s->sol_doubles + s->ff_all_doubles,
+                sizeof(double) * (size_t)s->fb_all_doubles);
+  return GAR_HIP_OK;
+}
+
 int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, double *Vxt,
                       double *Vtt, double *vt) {
   GAR_GUARD(s);
@@ -1606,7 +1721,6 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
     return GAR_HIP_OK;
   if (int rc = commit(s)) // host writes addressed the old stage numbering: flush them first
     return rc;
-  HIP_TRY(hipStreamSynchronize(s->stream));
   // new dims sequence: old[1..N-1], new knot, old[N]  (rotate_vec_left(datas,0,1) +
   // re-created last-but-one factor, proximal-riccati.hxx:79-86)
   std::vector<int32_t> nd(s->dims5.size());
@@ -1619,38 +1733,47 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
     for (int k = 0; k < 5; ++k)
       uniform &= (nd[5 * t + k] == d[k]) && (s->dims5[5 * t + k] == d[k]);
   if (uniform && s->num_legs == 1) {
-    // device ring rotate: records of stages 1..N-1 slide to 0..N-2
-    const int64_t in0 = s->meta[0].in_off, in1 = s->meta[1].in_off, inL = s->meta[N].in_off;
-    const int64_t f0 = s->meta[0].fac_off, f1 = s->meta[1].fac_off, fL = s->meta[N].fac_off;
-    // (two launches; the first version issued 2 N device-to-device copies per problem: 2.5 ms of
-    // API calls for N = 256, longer than a sweep)
-    {
-      const long long prec = in1 - in0, frec = f1 - f0;
-      hipLaunchKernelGGL(gar::gar_rotate_records, dim3((unsigned)((prec + 255) / 256), (unsigned)s->batch),
-                         dim3(256), 0, s->stream, s->d_prob, (long long)s->prob_doubles, (long long)in0,
-                         prec, N);
-      hipLaunchKernelGGL(gar::gar_rotate_records, dim3((unsigned)((frec + 255) / 256), (unsigned)s->batch),
-                         dim3(256), 0, s->stream, s->d_fac, (long long)s->fac_doubles, (long long)f0,
-                         frec, N);
-      HIP_TRY(hipGetLastError());
-      (void)inL;
-      (void)fL;
+    // A RING, not a copy: logical stage t (< N) moves to slot (t + ring0) mod N, i.e. every record
+    // stays where it is -- problem knots and factors alike (rotate_vec_left(datas, 0, 1)) -- and what
+    // was stage 0 becomes the last-but-one slot the caller overwrites next.  The kernels get ring0
+    // (specialised families) or the rotated per-stage offsets (generic / dense kernels read them
+    // from the stage descriptors): 14 KB of descriptors, asynchronously; no record is touched, the
+    // stream is not synchronised.  (Round 1 copied (N-1) x 54 KB per problem and synchronised twice.)
+    s->ring0 = (s->ring0 + 1) % N;
+    for (int t = 0; t < N; ++t) {
+      const int64_t p = (t + s->ring0) % N;
+      s->meta[t].in_off = s->uni_in0 + p * s->uni_in_rec;
+      s->meta[t].fac_off = p * s->uni_fac_rec;
     }
-    // (the pinned staging area is not rotated: commit() only ever flushes ranges the host wrote
-    // after this call, and pending writes were flushed above)
+    HIP_TRY(hipMemcpyAsync(s->d_meta, s->meta.data(), sizeof(gar_stage_meta) * s->meta.size(),
+                           hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_init, 0, sizeof(double) * (size_t)s->init_doubles * s->batch, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    // the last-but-one factor is re-created (zero) like the reference's StageFactor (:84-85): one
+    // strided memset over the batch, asynchronous
+    HIP_TRY(hipMemset2DAsync(s->d_fac + s->meta[N - 1].fac_off, sizeof(double) * (size_t)s->fac_doubles, 0,
+                             sizeof(double) * (size_t)s->uni_fac_rec, (size_t)s->batch, s->stream));
     return GAR_HIP_OK;
   }
   // dimensions changed (or leg mode: "just reinitialise everything",
   // parallel-solver.hxx:246-258): rebuild the layout and the buffers
+  // The new layout is validated BEFORE anything is released: on failure the solver keeps its old
+  // dimensions, layout and device buffers.  On success every device pointer handed out earlier
+  // (gar_hip_device_*) is invalid and must be fetched again; resident problem data is not carried over.
+  const std::vector<int32_t> old = s->dims5;
   s->dims5 = nd;
+  int rc = build_layout(s);
+  if (rc == GAR_HIP_OK)
+    rc = plan_lds(s);
+  if (rc != GAR_HIP_OK) {
+    const std::string why = g_last_error;
+    s->dims5 = old;
+    (void)build_layout(s);
+    (void)plan_lds(s);
+    return fail(rc, why);
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
   free_device(s);
   s->staged = s->dirty = false;
-  if (int rc = build_layout(s))
-    return rc;
-  if (int rc = plan_lds(s))
-    return rc;
   return allocate(s);
 }
 

@@ -47,6 +47,13 @@ struct MfmaParams {
   int nc0;
   double mueq; // constrained stages: the proximal weight of [Rhat D^T; D -mu I]
   int init_closed; // fused initial stage: closed form when G0 = +-I (0: always factorise kkt0)
+  // MPC cycling (cycleAppend, proximal-riccati.hxx:79-86) as a RING: the records of the stages
+  // t < horizon are never moved; logical stage t lives in slot (t + ring0) mod horizon
+  int ring0;
+  __host__ __device__ long long slot(int t) const {
+    const int p = t + ring0;
+    return (ring0 != 0 && p >= horizon) ? p - horizon : p;
+  }
 };
 
 // NC > 0: every knot carries NC equality constraints C x + D u + d = mu v (the one-wave-per-problem
@@ -292,7 +299,7 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       out[C::tvx + e] = v;
     }
     if (N >= 1) { // prologue: knot N-1 -> Ft[(N-1)&1]
-      const double *r1 = prob + P.in_off0 + (long long)(N - 1) * P.in_rec;
+      const double *r1 = prob + P.in_off0 + P.slot(N - 1) * P.in_rec;
       double *Ft = sm + (((N - 1) & 1) ? C::oFt1 : C::oFt0);
       for (int e = tid; e < NX * NW; e += 256) {
         const int j = e / NX, k = e - j * NX;
@@ -315,8 +322,8 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
     const int cc = c < NX ? c : NX - 1;
     for (int t = N - 1; t >= 0; --t) {
       GAR_MARK(0)
-      const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
-      double *out = fac + (long long)t * P.fac_rec;
+      const double *rec = prob + P.in_off0 + P.slot(t) * P.in_rec;
+      double *out = fac + P.slot(t) * P.fac_rec;
       const double *Ft = sm + ((t & 1) ? C::oFt1 : C::oFt0);
       double4_t Hc[C::TW]; // H tiles (ti, tj), ti >= tj
       if (tj < C::TW) {
@@ -443,14 +450,14 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
     int failed = 0;
     for (int t = N - 1; t >= 0; --t) {
       GAR_MARK(0)
-      const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
-      double *out = fac + (long long)t * P.fac_rec;
+      const double *rec = prob + P.in_off0 + P.slot(t) * P.in_rec;
+      double *out = fac + P.slot(t) * P.fac_rec;
       const int cur = t & 1;
       const double *Ft = sm + (cur ? C::oFt1 : C::oFt0);
       double *Ftn = sm + (cur ? C::oFt0 : C::oFt1);
       const double *fv = sm + C::oFv + cur * NX;
       const double *qr = sm + C::oQr + cur * NW;
-      const double *rn = rec - (t > 0 ? P.in_rec : 0); // knot t-1 (t = 0: harmless re-read)
+      const double *rn = prob + P.in_off0 + P.slot(t > 0 ? t - 1 : 0) * P.in_rec; // knot t-1 (t = 0: harmless re-read)
       // [A B] of knot t-1 moves HBM -> registers -> LDS in 3 chunks interleaved with
       // the arithmetic below; indices are clamped, never predicated, so the loads
       // stay in flight together
@@ -607,6 +614,11 @@ struct MfmaFwdParams {
   int horizon, nc0;
   int sol_u, sol_l; // base offsets of us / lbdas inside a solution record
   int sol_v;        // ... and of vs (constrained stages)
+  int ring0;        // logical stage t lives in factor slot (t + ring0) mod horizon (MfmaParams::ring0)
+  __host__ __device__ long long slot(int t) const {
+    const int p = t + ring0;
+    return (ring0 != 0 && p >= horizon) ? p - horizon : p;
+  }
 };
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -628,8 +640,8 @@ __device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *f
   constexpr int NW = C::NR;
   const int N = P.horizon;
   const int tc = t < N ? t : N - 1; // past the end: harmless re-read of the last stage
-  const double *rec = fac + (long long)tc * P.fac_rec;
-  const double *recn = (tc + 1 < N) ? rec + P.fac_rec : fac + P.fac_offN;
+  const double *rec = fac + P.slot(tc) * P.fac_rec;
+  const double *recn = (tc + 1 < N) ? fac + P.slot(tc + 1) * P.fac_rec : fac + P.fac_offN;
   const int oVn = (tc + 1 < N) ? C::fVxx : C::tVxx, ovn = (tc + 1 < N) ? C::fvx : C::tvx;
 #pragma unroll
   for (int m = 0; m < NX / 2; ++m)

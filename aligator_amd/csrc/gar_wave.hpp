@@ -514,9 +514,9 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   double *Gt = sm + C::oGt, *vtl = sm + C::oVt, *yfl = sm + (MODE == 3 && PAR ? C::oYf1 : C::oYf);
   constexpr int oVxx = MODE ? C::pVxx : M::fVxx, ovx = MODE ? C::pvx : M::fvx;
   const unsigned lkx = 8u * (unsigned)(lk * NX + li); // element (lk, li) of a pitch-NX block
-  double *out = fac + (long long)t * P.fac_rec;
-  const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
-  const double *recn = rec - (t > 0 ? P.in_rec : 0); // knot t-1 (t = 0: harmless re-read)
+  double *out = fac + P.slot(t) * P.fac_rec;
+  const double *rec = prob + P.in_off0 + P.slot(t) * P.in_rec;
+  const double *recn = prob + P.in_off0 + P.slot(t > 0 ? t - 1 : 0) * P.in_rec; // knot t-1 (t = 0: harmless re-read)
 // phase boundaries are pinned (sched_barrier) so that the per-phase cycle stamps of
 // scripts/trace_wave.py mean what they say; measured: un-pinning them changes nothing
 #define GAR_WMARK(id)                                                          \
@@ -1233,8 +1233,8 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   WaveLane<NX, NU, NC> L;
   wave_lane_init<NX, NU>(L, lane);
   WaveStage<NX, NU> S;
-  wave_load_a<NX, NU>(prob + P.in_off0 + (long long)(N - 1) * P.in_rec, L, S);
-  wave_load_b<NX, NU>(prob + P.in_off0 + (long long)(N - 1) * P.in_rec, L, S);
+  wave_load_a<NX, NU>(prob + P.in_off0 + P.slot(N - 1) * P.in_rec, L, S);
+  wave_load_b<NX, NU>(prob + P.in_off0 + P.slot(N - 1) * P.in_rec, L, S);
 
   // ---- terminal knot (terminalSolve, nu = 0, :146-149, :175-178): Z = C/mu, zff = d/mu,
   // Vxx = Q + C^T Z, vx = q + C^T zff (nc = 0: Vxx = Q, vx = q)

@@ -321,9 +321,9 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   const double *rec = prob + P.in_off0;
   const double *recn = rec;
 #else
-  double *out = fac + (long long)t * P.fac_rec;
-  const double *rec = prob + P.in_off0 + (long long)t * P.in_rec;
-  const double *recn = rec - (t > 0 ? P.in_rec : 0); // knot t-1 (t = 0: harmless re-read)
+  double *out = fac + P.slot(t) * P.fac_rec;
+  const double *rec = prob + P.in_off0 + P.slot(t) * P.in_rec;
+  const double *recn = prob + P.in_off0 + P.slot(t > 0 ? t - 1 : 0) * P.in_rec; // knot t-1 (t = 0: harmless re-read)
 #endif
 // cycle stamps of scripts/trace_wave2.py: only in the debug build (make trace), where every mark also
 // pins the schedule (sched_barrier) so that a phase's instructions stay inside its stamps

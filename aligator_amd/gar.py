@@ -429,6 +429,44 @@ class BatchedRiccatiSolver:
             lbdas = [lbdas[0][:self.user_nc0]] + [l[:int(ud[t, 3])] for t, l in enumerate(lbdas[1:])]
         return xs, us, vs, lbdas
 
+    def fetch_results(self, b: int = 0, solution: bool = True, gains: bool = True):
+        """gar_hip_fetch_results: ONE device-side gather + ONE device-to-host copy + ONE synchronisation
+        for the whole solution and/or the gains of every stage of problem b (instead of 4 + 3 (N+1)
+        small copies).  Returns (solution_record, ff_all, fb_all) as numpy views of the library's
+        pinned host buffer (valid until the next fetch); None for what was not requested."""
+        what = (1 if solution else 0) | (2 if gains else 0)
+        self._check(self._L.gar_hip_fetch_results(self._h, int(b), what))
+        offs = np.zeros(3, dtype=np.int64)
+        ptr = self._L.gar_hip_host_results(self._h, offs.ctypes.data_as(C.POINTER(C.c_int64)))
+        gd = np.zeros(2, dtype=np.int64)
+        self._check(self._L.gar_hip_gains_doubles(self._h, gd.ctypes.data_as(C.POINTER(C.c_int64))))
+        total = int(offs[2] + gd[1])
+        buf = np.ctypeslib.as_array((C.c_double * total).from_address(ptr))
+        sol = buf[:int(offs[1])] if solution else None
+        ff = buf[int(offs[1]):int(offs[2])] if gains else None
+        fb = buf[int(offs[2]):total] if gains else None
+        return sol, ff, fb
+
+    def gains_all(self, b: int = 0):
+        """-> ([ff_t], [fb_t]) for every stage t, fb_t of shape (nu+nc+nx2, nx) (StageFactor's row-major
+        fb), through the bulk path; the same values gar_hip_get_gains returns stage by stage."""
+        _, ff, fb = self.fetch_results(b, solution=False, gains=True)
+        ffs, fbs = [], []
+        off = np.zeros(2, dtype=np.int64)
+        for t in range(self.horizon + 1):
+            nx, nu, nc, nx2, _ = (int(v) for v in self.dims[t])
+            nr = nu + nc + (2 * nx2 if self.dense else nx2)
+            self._check(self._L.gar_hip_gains_offsets(self._h, t, off.ctypes.data_as(C.POINTER(C.c_int64))))
+            f = ff[int(off[0]):int(off[0]) + nr].copy()
+            g = fb[int(off[1]):int(off[1]) + nr * nx].reshape(nr, nx).copy()
+            if self._nxp:  # drop the rows / columns of the dummy controls and states
+                unx, unu = int(self.user_dims[t, 0]), int(self.user_dims[t, 1])
+                keep = np.r_[0:unu, nu:nu + unx]
+                f, g = f[keep], np.ascontiguousarray(g[keep][:, :unx])
+            ffs.append(f)
+            fbs.append(g)
+        return ffs, fbs
+
     def factor(self, t: int, b: int = 0) -> _FactorView:
         key = (b, t)
         if key in self._factors_cache:

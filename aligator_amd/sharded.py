@@ -73,28 +73,44 @@ class ShardedRiccatiSolver:
         n_local = batch * self.legs_per_rank * tup
         self._local = _view(L.gar_hip_device_boundary_local(h), n_local, self.on_device)
         self._all = _view(L.gar_hip_device_boundary_all(h), n_local * self.world, self.on_device)
+        self.stream = None
+        if self.on_device:
+            # one (non-null) stream for the kernels and the collective: no host round trip inside a
+            # sweep (gar_hip_set_stream(NULL) would select the library's private stream)
+            self.stream = torch.cuda.Stream()
+            self.impl.set_stream(self.stream.cuda_stream)
         self.stage_range = (get_work(self.impl.horizon, lo, num_legs)[0],
                             get_work(self.impl.horizon, lo + self.legs_per_rank - 1, num_legs)[1])
 
     # ---- the sweep -----------------------------------------------------------------
-    def backward(self, mueq: float) -> bool:
+    def backward(self, mueq: float, check: bool = True) -> bool:
+        """Leg sweep -> ONE all-gather of the boundary tuples -> redundant condensed solve.
+        On the GPU nothing here synchronises the host: the library's kernels are enqueued on torch's
+        current stream (set in __init__), the RCCL collective orders itself after them and the
+        condensed solve after the collective through torch's own stream events.  `check` (the
+        reference throws on a failed stage factorisation, riccati-kernel.hxx:239-241) costs one
+        device-to-host copy and an all-reduce of the flag, so that EVERY rank raises together."""
         L, h = self.impl._L, self.impl.handle
-        self.impl._check(L.gar_hip_backward_legs_async(h, float(mueq)))   # parallel-solver.hxx:150-164
-        self.impl.sync()
-        # the boundary exchange: one all-gather, rank-major == the layout the condensed solve reads
-        dist.all_gather_into_tensor(self._all, self._local, group=self.group)
-        if self.on_device:
-            torch.cuda.synchronize()
-        self.impl._check(L.gar_hip_condensed_solve_async(h))             # :169-202, redundant per rank
-        self.impl.sync()
-        if self.impl.num_failed() != 0:
-            raise RuntimeError("Failed stage LDL factorization")
+        self.impl._factors_cache = {}
+        import contextlib
+        with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
+            self.impl._check(L.gar_hip_backward_legs_async(h, float(mueq)))   # parallel-solver.hxx:150-164
+            # the boundary exchange: one all-gather, rank-major == the layout the condensed solve reads
+            dist.all_gather_into_tensor(self._all, self._local, group=self.group)
+            self.impl._check(L.gar_hip_condensed_solve_async(h))             # :169-202, redundant per rank
+        if check:
+            nf = torch.tensor([self.impl.num_failed()], dtype=torch.int32,
+                              device=self._local.device if self.on_device else "cpu")
+            dist.all_reduce(nf, op=dist.ReduceOp.MAX, group=self.group)
+            if int(nf.item()) != 0:
+                raise RuntimeError("Failed stage LDL factorization")
         return True
 
-    def forward(self) -> bool:
+    def forward(self, sync: bool = True) -> bool:
         L, h = self.impl._L, self.impl.handle
         self.impl._check(L.gar_hip_forward_legs_async(h))                # :209-243
-        self.impl.sync()
+        if sync:
+            self.impl.sync()
         return True
 
     # ---- results ---------------------------------------------------------------------
@@ -128,8 +144,7 @@ class ShardedRiccatiSolver:
                 # xs[t], us[t], vs[t] belong to stage t; lbdas[t] (t >= 1) is produced with
                 # x_t by the leg holding stage t-1 ... except at a leg start, where it comes
                 # from the condensed solution every rank holds (parallel-solver.hxx:215-220)
-                st = min(t, N)
-                r = owner[st] if pi != 3 or t == 0 else owner[st]
+                r = owner[min(t, N)]
                 merged.append(parts[r][pos:pos + v.size].reshape(v.shape).copy())
                 pos += v.size
             out.append(merged)

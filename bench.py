@@ -133,6 +133,62 @@ def parallel_in_time(args, device, stream, nx, nu, mueq, N=2048, legs=256, reps=
     return out
 
 
+def horizon_sharded(args, world, rank, device, dist, N=2048, legs=256, reps=10):
+    """BASELINE.json configs[3]: ONE problem (N=2048, nx=36, nu=12) whose horizon is split into `legs`
+    legs, the legs split evenly over the ranks (aligator_amd/sharded.py): leg sweep -> ONE RCCL
+    all-gather of the 31.7 KB/leg boundary tuples -> redundant condensed solve -> leg roll-out, no
+    host synchronisation inside a sweep.  ms per sweep = max over ranks; the all-gather is also timed
+    on its own.  Rank 0 checks its own stages against a serial sweep of the same problem."""
+    from aligator_amd.sharded import ShardedRiccatiSolver
+    nx, nu, mueq = 36, 12, 1e-14
+    dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
+    s = ShardedRiccatiSolver(dims, nx, legs, batch=1, device=device)
+    synth_device.fill_problems(s.impl, seed=4242, mode=args.generator, keep=())  # every rank: the same problem
+    torch.cuda.synchronize()
+    for _ in range(2):
+        s.backward(mueq, check=False)
+        s.forward(sync=False)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        s.backward(mueq, check=False)
+        s.forward(sync=False)
+    torch.cuda.synchronize()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ms = float(el.item()) / reps * 1e3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(s.stream):
+        e0.record()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(s._all, s._local)
+        e1.record()
+    torch.cuda.synchronize()
+    ag_ms = e0.elapsed_time(e1) / reps
+    s.backward(mueq, check=True)   # the checked form: raises on every rank if any stage failed
+    s.forward()
+    resid, steps = s.impl.condensed_info(0)
+    out = {"workload": f"one problem, N={N} nx={nx} nu={nu} fp64 (BASELINE.json configs[3]), horizon sharded",
+           "ranks": world, "legs": legs, "legs_per_rank": legs // world, "ms_per_sweep": ms,
+           "all_gather_ms": ag_ms, "all_gather_bytes_per_rank": 8 * (3 * nx * nx + 2 * nx) * (legs // world),
+           "condensed_residual": resid, "refinement_steps": steps, "kernel": s.impl.kernel_name,
+           "host_syncs_per_sweep": 0}
+    if rank == 0:
+        ref = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=1, device=device)
+        synth_device.fill_problems(ref, seed=4242, mode=args.generator, keep=())
+        ref.backward(mueq)
+        ref.forward()
+        a, b = s.local_solution(0), ref.solution(0)
+        lo, hi = s.stage_range
+        scale = max(1.0, max(float(np.abs(v).max()) for v in b[3]))
+        out["max_rel_diff_vs_serial_on_rank0_stages"] = max(
+            float(np.abs(a[0][t] - b[0][t]).max()) for t in range(lo, hi)) / scale
+    return out
+
+
 def parity_check(solver, args, mueq, nsample=2):
     """Spot-check the timed data: pull a few problems back, solve with the oracle."""
     from aligator_amd.gar import lqrComputeKktError
@@ -166,6 +222,10 @@ def main():
     ap.add_argument("--nx", type=int, default=36)
     ap.add_argument("--nu", type=int, default=12)
     ap.add_argument("--generator", default="W", choices=["W", "F"])
+    ap.add_argument("--mode", default="batch", choices=["batch", "horizon"],
+                    help="batch: the headline (independent problems per GPU, weak scaling); horizon: ONE "
+                         "problem's horizon sharded over the ranks (configs[3]) -- also reported as "
+                         "`horizon_sharded` inside the batch-mode line whenever there is more than one rank")
     ap.add_argument("--single-generator", action="store_true",
                     help="skip the second measurement on the other generator (value_F / value_W)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -186,12 +246,32 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.mode == "horizon":
         import torch.distributed as dist
-        if args.backend == "nccl":
+        if world == 1 and "MASTER_ADDR" not in os.environ:  # --mode horizon on one GPU: a 1-rank group
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+                                    device_id=torch.device("cuda", local_rank))
+        elif args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+    if args.mode == "horizon":
+        hs = horizon_sharded(args, world, rank, local_rank, dist)
+        big = horizon_sharded(args, world, rank, local_rank, dist, N=16384, legs=512, reps=5)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "Riccati sweeps/sec (bwd+fwd), ONE problem N=2048 nx=36 nu=12, horizon sharded",
+                "value": 1e3 / hs["ms_per_sweep"], "unit": "sweeps/s", "n_gpus": world, "steps": 10, "warmup": 2,
+                "ms_per_step": hs["ms_per_sweep"], "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": f"synthetic (generator {args.generator})",
+                "config": {"workload": hs["workload"], "parallelism": f"horizon-sharded x{world}, one RCCL all-gather per sweep"},
+                "horizon_sharded": hs, "horizon_sharded_N16384": big}))
+        dist.destroy_process_group()
+        return
 
     N, nx, nu, mueq = args.horizon, args.nx, args.nu, 1e-14
     dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
@@ -256,6 +336,9 @@ def main():
     pit = None
     if world == 1 and not args.no_legs and (nx, nu) == (36, 12):
         pit = parallel_in_time(args, local_rank, stream, nx, nu, mueq)
+    hs = None
+    if world > 1 and args.backend == "nccl" and not args.no_legs and (nx, nu) == (36, 12):
+        hs = horizon_sharded(args, world, rank, local_rank, dist)  # secondary figure (configs[3])
     if rank == 0:
         sweeps = args.batch * world * args.steps
         bwd_b, fwd_b = algorithmic_bytes(N, nx, nu)
@@ -305,6 +388,8 @@ def main():
             out["pivoted_stage_frac"][other] = pf2
         if pit is not None:
             out["parallel_in_time"] = pit
+        if hs is not None:
+            out["horizon_sharded"] = hs
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, nx, nu, N, mueq)
         print(json.dumps(out))

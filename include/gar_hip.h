@@ -204,6 +204,26 @@ int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us,
 /* ff (nu+nc+nx2), fb ((nu+nc+nx2) x nx ROW-major), fth (.. x nth ROW-major) */
 int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb,
                       double *fth);
+/* Bulk read-back for the caller's per-iteration loop (SolverProxDDPTpl::computeDirection copies
+ * getFeedforward(i) / getFeedback(i) of EVERY stage, solver-proxddp.hxx:620-632): the gains of all
+ * stages of problem b as two dense arrays, ff_all = [ff_0 | ff_1 | ...] and fb_all = [fb_0 | fb_1 |
+ * ...], every fb_t ROW-major like StageFactor::fb.  One device-side gather (the specialised kernel
+ * families keep fb in a device order), ONE device-to-host copy, ONE synchronisation -- instead of
+ * 2-3 copies and a synchronisation per stage through gar_hip_get_gains.
+ *   gar_hip_gains_doubles   out[0] = doubles in ff_all, out[1] = doubles in fb_all
+ *   gar_hip_gains_offsets   out[0], out[1] = offset of stage t inside ff_all / fb_all
+ *   gar_hip_fetch_results   what = 1: the solution xs|us|vs|lbdas, 2: the gains, 3: both -- into a
+ *                           pinned host buffer the library owns; synchronous on return
+ *   gar_hip_host_results    that buffer; offs[0..2] = offsets (doubles) of the solution record, of
+ *                           ff_all and of fb_all inside it.  The subclass maps its getFeedforward /
+ *                           getFeedback views straight onto it ("views into solver-owned host
+ *                           memory, valid until the next backward", as in the reference).
+ *   gar_hip_get_gains_all   fetch + copy into caller-owned arrays (either may be NULL) */
+int gar_hip_gains_doubles(const gar_hip_solver *s, int64_t out[2]);
+int gar_hip_gains_offsets(const gar_hip_solver *s, int t, int64_t out[2]);
+int gar_hip_fetch_results(gar_hip_solver *s, int b, int what);
+const double *gar_hip_host_results(gar_hip_solver *s, int64_t offs[3]);
+int gar_hip_get_gains_all(gar_hip_solver *s, int b, double *ff_all, double *fb_all);
 int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx,
                       double *Vxt, double *Vtt, double *vt);
 /* kkt0.ff (nx0+nc0), kkt0.fth ((nx0+nc0) x nth ROW-major), thGrad, thHess */
@@ -220,7 +240,13 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
  * backward/forward pair as out[0..2].  Specialised kernel family only. */
 int gar_hip_set_timing(gar_hip_solver *s, int enable);
 int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]);
-/* MPC cycling: drop knot 0, shift left, last-but-one knot gets dims5_new */
+/* MPC cycling: drop knot 0, shift left, last-but-one knot gets dims5_new.
+ * Uniform serial problems (every stage of the same dimensions as the new knot): a RING -- no record
+ * of the problem or of the factors is copied, the stream is not synchronised; gar_hip_stage_offsets
+ * reports where each (logical) stage now lives.  Otherwise (dimensions change, leg mode: "just
+ * reinitialise everything", parallel-solver.hxx:246-258) the layout and the buffers are rebuilt:
+ * the new layout is validated first (on error the solver is unchanged), device pointers fetched
+ * earlier become invalid, resident problem data is not carried over. */
 int gar_hip_cycle_append(gar_hip_solver *s, const int32_t dims5_new[5]);
 
 #ifdef __cplusplus

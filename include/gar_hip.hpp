@@ -257,31 +257,35 @@ public:
       if (t < N)
         nls += k.nx2;
     }
+    // ONE device-to-host copy of the whole solution record xs | us | vs | lbdas into the library's
+    // pinned buffer (gar_hip_fetch_results), then the scatter into the caller's vectors
+    check(gar_hip_fetch_results(h_, 0, 1));
+    int64_t offs[3];
+    const double *rec = gar_hip_host_results(h_, offs) + offs[0];
     if (pad_) { // the device solution carries the dummy states / controls (exactly zero): drop them
       const size_t nxd = pad_.nx, nud = pad_.nu, nx = problem_->stages[0].nx;
       const size_t nc0d = problem_->nc0() + (nxd - nx);
-      VectorXs X(nxd * (size_t)(N + 1)), U(nud * (size_t)N + 1), V(1), L(nc0d + nxd * (size_t)N + 1);
-      check(gar_hip_get_solution(h_, 0, X.data(), U.data(), V.data(), L.data()));
+      const double *X = rec, *U = X + nxd * (size_t)(N + 1), *L = U + nud * (size_t)N;
       for (size_t t = 0; t < xs.size(); ++t)
-        std::copy(X.begin() + (long)(t * nxd), X.begin() + (long)(t * nxd + xs[t].size()), xs[t].begin());
+        std::copy(X + t * nxd, X + t * nxd + xs[t].size(), xs[t].begin());
       for (size_t t = 0; t < us.size(); ++t)
-        std::copy(U.begin() + (long)(t * nud), U.begin() + (long)(t * nud + us[t].size()), us[t].begin());
-      std::copy(L.begin(), L.begin() + (long)lbdas[0].size(), lbdas[0].begin()); // user rows of G0 first
+        std::copy(U + t * nud, U + t * nud + us[t].size(), us[t].begin());
+      std::copy(L, L + lbdas[0].size(), lbdas[0].begin()); // user rows of G0 first
       for (size_t t = 1; t < lbdas.size(); ++t) {
-        const long o = (long)(nc0d + (t - 1) * nxd);
-        std::copy(L.begin() + o, L.begin() + o + (long)lbdas[t].size(), lbdas[t].begin());
+        const size_t o = nc0d + (t - 1) * nxd;
+        std::copy(L + o, L + o + lbdas[t].size(), lbdas[t].begin());
       }
       return true;
     }
-    VectorXs X(nxs), U(nus + 1), V(nvs + 1), L(nls + 1);
-    check(gar_hip_get_solution(h_, 0, X.data(), U.data(), V.data(), L.data()));
-    scatter(X, xs);
-    scatter(U, us);
-    scatter(V, vs);
-    scatter(L, lbdas);
+    const double *p = rec;
+    p = scatter(p, xs, nxs);
+    p = scatter(p, us, nus);
+    p = scatter(p, vs, nvs);
+    scatter(p, lbdas, nls);
     return true;
   }
   void cycleAppend(const LqrKnot &knot) override {
+    gains_valid_ = false;
     const int32_t d[5] = {(int)dev_nx(knot), (int)dev_nu(knot), (int)knot.nc, (int)dev_nx(knot),
                           (int)knot.nth};
     check(gar_hip_cycle_append(h_, d));
@@ -289,13 +293,10 @@ public:
   VectorXs getFeedforward(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
     const uint nud = dev_nu(k), nxd = dev_nx(k);
-    if (dense_) { // block rows [kff; zff; lff; yff] (dense-riccati.hpp:49)
-      VectorXs ffd(k.nu + k.nc + 2 * k.nx2);
-      check(gar_hip_get_gains(h_, 0, (int)i, ffd.data(), nullptr, nullptr));
-      return ffd;
-    }
-    VectorXs ff(nud + k.nc + nxd);
-    check(gar_hip_get_gains(h_, 0, (int)i, ff.data(), nullptr, nullptr));
+    const double *src = gains(i, 0);
+    if (dense_) // block rows [kff; zff; lff; yff] (dense-riccati.hpp:49)
+      return VectorXs(src, src + k.nu + k.nc + 2 * k.nx2);
+    VectorXs ff(src, src + nud + k.nc + nxd);
     ff.resize(nud + k.nc + k.nx2);                 // rows of the dummy co-states (last)
     ff.erase(ff.begin() + k.nu, ff.begin() + nud); // rows of the dummy controls
     return ff;
@@ -303,10 +304,8 @@ public:
   Matrix getFeedback(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
     const uint nud = dev_nu(k), nxd = dev_nx(k);
-    const int nrd = (int)(nud + k.nc + (dense_ ? 2 * k.nx2 : nxd)), // dense: [K; Z; L; Y]
-        nr = (int)(k.nu + k.nc + (dense_ ? 2 * k.nx2 : k.nx2));
-    std::vector<double> rm((size_t)nrd * nxd);
-    check(gar_hip_get_gains(h_, 0, (int)i, nullptr, rm.data(), nullptr));
+    const int nr = (int)(k.nu + k.nc + (dense_ ? 2 * k.nx2 : k.nx2));
+    const double *rm = gains(i, 1); // row-major (nud + nc + nxd | 2 nx2) x nxd
     Matrix fb(nr, (int)k.nx);
     for (int r = 0; r < nr; ++r) {
       const int rd = r < (int)k.nu ? r : r + (int)(nud - k.nu);
@@ -370,12 +369,26 @@ protected:
     if (rc != GAR_HIP_OK)
       throw std::runtime_error(gar_hip_last_error());
   }
-  static void scatter(const VectorXs &packed, VectorOfVectors &out) {
+  // one part of the packed solution record (`total` doubles on the device) into the caller's vectors
+  static const double *scatter(const double *packed, VectorOfVectors &out, size_t total) {
     size_t p = 0;
     for (VectorXs &v : out) {
-      std::copy(packed.begin() + (long)p, packed.begin() + (long)(p + v.size()), v.begin());
+      std::copy(packed + p, packed + p + v.size(), v.begin());
       p += v.size();
     }
+    return packed + total;
+  }
+  // the gains of every stage through ONE device-side gather and ONE copy (gar_hip_fetch_results),
+  // kept until the next backward / collapseFeedback / cycleAppend
+  const double *gains(size_t i, int which) const {
+    if (!gains_valid_) {
+      check(gar_hip_fetch_results(h_, 0, 2));
+      gains_valid_ = true;
+    }
+    int64_t offs[3], go[2];
+    const double *base = gar_hip_host_results(h_, offs);
+    check(gar_hip_gains_offsets(h_, (int)i, go));
+    return base + offs[1 + which] + go[which];
   }
   uint dev_nu(const LqrKnot &k) const { return (pad_ && k.nu > 0) ? pad_.nu : k.nu; }
   uint dev_nx(const LqrKnot &k) const { return pad_ ? pad_.nx : k.nx; }
@@ -408,6 +421,7 @@ protected:
   LqrProblem *problem_;
   PaddedDims pad_; // device dimensions when the problem is padded onto a specialised shape
   bool dense_ = false; // RiccatiSolverDense: nu+nc+2*nx2 gain rows
+  mutable bool gains_valid_ = false;
   gar_hip_solver *h_ = nullptr;
 };
 
@@ -419,6 +433,7 @@ public:
   explicit ProximalRiccatiSolver(LqrProblem &problem, int device = 0)
       : HipSolver(problem, 1, device) {}
   bool backward(const double mueq) override {
+    gains_valid_ = false;
     upload();
     check(gar_hip_backward(h_, mueq)); // GAR_HIP_ERR_FACTOR -> "Failed stage LDL factorization"
     return true;
@@ -433,6 +448,7 @@ public:
   explicit RiccatiSolverDense(LqrProblem &problem, int device = 0)
       : HipSolver(problem, 1, device, true) {}
   bool backward(const double mueq) override {
+    gains_valid_ = false;
     upload();
     check(gar_hip_backward(h_, mueq));
     return true;
@@ -446,11 +462,15 @@ public:
       : HipSolver(problem, check_threads(num_threads), device), numThreads_(num_threads) {}
   bool backward(const double mueq) override {
     check(gar_hip_set_refinement(h_, condensedThreshold, (int)maxRefinementSteps));
+    gains_valid_ = false;
     upload();
     check(gar_hip_backward(h_, mueq));
     return true;
   }
-  void collapseFeedback() override { check(gar_hip_collapse_feedback(h_)); }
+  void collapseFeedback() override {
+    gains_valid_ = false;
+    check(gar_hip_collapse_feedback(h_));
+  }
   uint getNumThreads() const { return numThreads_; }
   double condensedThreshold = 1e-10; // parallel-solver.hpp:92
   uint maxRefinementSteps = 5;       // parallel-solver.hpp:94

@@ -63,6 +63,7 @@ static void mm_acc(int M, int N, int K, double alpha, const double *A, long ars,
         const double *ai = A + (long)i * ars;
         const double *bj = B + (long)j * bcs;
         double s = 0.0;
+#pragma omp simd reduction(+ : s) /* SIMD partial sums, as an optimised BLAS/Eigen kernel forms them */
         for (int k = 0; k < K; ++k)
           s += ai[k] * bj[k];
         C[(long)i * crs + (long)j * ccs] += alpha * s;
@@ -757,7 +758,7 @@ int ora_stage_kernel_solve(const ora_knot *m, ora_stage_factor *d, ora_value *vn
     for (int i = j + 1; i < nx2; ++i)
       CM(vn->Vxx, nx2, j, i) = CM(vn->Vxx, nx2, i, j);
   /* :217-218  vplus = vx' + Vxx' f */
-  double *vplus = dalloc(nx2);
+  double vplus[nx2 > 0 ? nx2 : 1]; /* (the reference allocates this temporary from its pmr arena, :215) */
   dcopy(nx2, vn->vx, vplus);
   mm_acc(nx2, 1, nx2, 1.0, vn->Vxx, 1, nx2, m->f, 1, 1, vplus, 1, nx2);
   /* :220-221  AtV = A^T Vxx' (row-major nx x nx2), BtV = B^T Vxx' */
@@ -776,7 +777,6 @@ int ora_stage_kernel_solve(const ora_knot *m, ora_stage_factor *d, ora_value *vn
   mm_acc(nx, 1, nx2, 1.0, m->A, nx2, 1, vplus, 1, 1, d->qhat, 1, nx);
   dcopy(nu, m->r, d->rhat);
   mm_acc(nu, 1, nx2, 1.0, m->B, nx2, 1, vplus, 1, 1, d->rhat, 1, nu);
-  free(vplus);
 
   /* :232-241  kktMat = sym_from_lower([Rhat D^T; D -mu I]); factorise */
   double *M = d->kktMat;
@@ -1442,5 +1442,67 @@ int ora_batch_sweep(ora_prox_solver **solvers, int nbatch, double mueq, double *
     ora_prox_forward(solvers[b], xs[b], us[b], vs[b], lbdas[b], NULL);
     fails += !ok;
   }
+  return fails;
+}
+
+/* The CPU baseline of bench.py, measured the way a tuned host code would run it:
+ * every OpenMP thread deep-copies the problems it owns (static partition: its memory is first
+ * touched, hence placed, on its own NUMA node), builds its solvers and solution vectors there, then
+ * all threads sweep `reps` times between two barriers.  Returns the number of failed sweeps;
+ * *seconds = wall time of the timed region (what the slowest thread needs). */
+int ora_batch_sweep_local(const ora_problem *const *problems, int nbatch, double mueq, int nthreads,
+                          int reps, double *seconds) {
+  int fails = 0;
+  double t_begin = 0.0, t_end = 0.0;
+  if (nthreads < 1)
+    nthreads = 1;
+#pragma omp parallel num_threads(nthreads) reduction(+ : fails)
+  {
+    const int nt = omp_get_num_threads(), id = omp_get_thread_num();
+    const int b0 = (int)((long)nbatch * id / nt), b1 = (int)((long)nbatch * (id + 1) / nt), nb = b1 - b0;
+    ora_problem **P = (ora_problem **)calloc((size_t)(nb > 0 ? nb : 1), sizeof(*P));
+    ora_prox_solver **S = (ora_prox_solver **)calloc((size_t)(nb > 0 ? nb : 1), sizeof(*S));
+    double ***X = (double ***)calloc((size_t)(4 * (nb > 0 ? nb : 1)), sizeof(*X));
+    for (int i = 0; i < nb; ++i) {
+      P[i] = ora_problem_copy(problems[b0 + i]);
+      S[i] = ora_prox_new(P[i]);
+      const int N = P[i]->N;
+      for (int k = 0; k < 4; ++k) {
+        X[4 * i + k] = (double **)calloc((size_t)(N + 2), sizeof(double *));
+        for (int t = 0; t <= N; ++t) {
+          const ora_knot *kn = &P[i]->stages[t];
+          const int n = k == 0 ? kn->nx : k == 1 ? kn->nu : k == 2 ? kn->nc
+                        : (t == 0 ? P[i]->nc0 : P[i]->stages[t - 1].nx2);
+          X[4 * i + k][t] = dalloc(n > 0 ? n : 1);
+        }
+      }
+    }
+#pragma omp barrier
+#pragma omp master
+    t_begin = omp_get_wtime();
+    for (int r = 0; r < reps; ++r)
+      for (int i = 0; i < nb; ++i) {
+        const int ok = ora_prox_backward(S[i], mueq);
+        ora_prox_forward(S[i], X[4 * i], X[4 * i + 1], X[4 * i + 2], X[4 * i + 3], NULL);
+        fails += !ok;
+      }
+#pragma omp barrier
+#pragma omp master
+    t_end = omp_get_wtime();
+    for (int i = 0; i < nb; ++i) {
+      for (int k = 0; k < 4; ++k) {
+        for (int t = 0; t <= P[i]->N; ++t)
+          free(X[4 * i + k][t]);
+        free(X[4 * i + k]);
+      }
+      ora_prox_free(S[i]);
+      ora_problem_free(P[i]);
+    }
+    free(X);
+    free(S);
+    free(P);
+  }
+  if (seconds)
+    *seconds = t_end - t_begin;
   return fails;
 }

@@ -191,6 +191,10 @@ int ora_batch_sweep(ora_prox_solver **solvers, int nbatch, double mueq,
                     int nthreads);
 int ora_omp_max_threads(void);
 
+/* first-touch-local batched sweep (bench.py's cpu_baseline): see gar_oracle.c */
+int ora_batch_sweep_local(const ora_problem *const *problems, int nbatch, double mueq, int nthreads,
+                          int reps, double *seconds);
+
 #ifdef __cplusplus
 }
 #endif

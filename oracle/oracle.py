@@ -129,6 +129,8 @@ def _bind(L):
     L.ora_batch_sweep.argtypes = [C.POINTER(C.POINTER(_Prox)), C.c_int, C.c_double,
                                   C.POINTER(_PPD), C.POINTER(_PPD),
                                   C.POINTER(_PPD), C.POINTER(_PPD), C.c_int]
+    L.ora_batch_sweep_local.argtypes = [C.POINTER(C.POINTER(_Problem)), C.c_int, C.c_double, C.c_int,
+                                        C.c_int, _PD]
     L.ora_omp_max_threads.restype = C.c_int
     return L
 
@@ -466,6 +468,15 @@ class BatchSweep:
         return self._L.ora_batch_sweep(self._arr, len(self.problems), float(mueq),
                                        self._pp[0][1], self._pp[1][1],
                                        self._pp[2][1], self._pp[3][1], int(nthreads))
+
+    def sweep_local(self, mueq: float, nthreads: int, reps: int):
+        """`reps` sweeps of every problem with thread-local (first-touch) copies of the data
+        (ora_batch_sweep_local) -> (failed sweeps, seconds of the timed region)."""
+        arr = (C.POINTER(_Problem) * len(self.problems))(*[p._p for p in self.problems])
+        sec = C.c_double(0.0)
+        fails = self._L.ora_batch_sweep_local(arr, len(self.problems), float(mueq), int(nthreads),
+                                              int(reps), C.byref(sec))
+        return int(fails), float(sec.value)
 
     def solution(self, b):
         return self._sols[b]

@@ -1,0 +1,175 @@
+// bench_lqr_loop.cpp -- what ONE Newton iteration of SolverProxDDP costs through the drop-in seam.
+//
+// BASELINE.json configs[4] (bench/talos-walk.cpp) needs Pinocchio; SURVEY section 8(d) prescribes the
+// substitute: bench/lqr.cpp's pure-LQR ProxDDP loop (/root/reference/bench/lqr.cpp:25-57, max_iters = 2)
+// restated on the host boundary.  Per iteration the reference does
+//   updateLQSubproblem()                  rewrite every knot of the caller's LqrProblem on the host
+//                                         (solvers/proxddp/solver-proxddp.hxx:734-805)
+//   linear_solver_->backward(mu)          (:608)
+//   linear_solver_->forward(dxs,dus,dvs,dlams)   (:610-611)
+//   linear_solver_->collapseFeedback(); getFeedforward(i), getFeedback(i) for EVERY i   (:619-632)
+// and that is what is timed here, through include/gar_hip.hpp (the C++ host mirror of the
+// reference's classes over the C ABI): upload of N+1 knots (pinned staging, one H2D), the sweep, one
+// device-side gather + one D2H for all gains, one D2H for the solution.  Beside it: the oracle
+// (restated reference, one thread) on the same problem.  Shapes: bench/lqr.cpp's own (dim 56, nu 22:
+// no specialised kernels yet) and the north star (36, 12), N = 256, serial and with N/8 legs.
+//
+// build: make -C tests/cpp bench   (links libgar_hip.so and the oracle: test infrastructure)
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "gar_hip.hpp"
+extern "C" {
+#include "../../oracle/gar_oracle.h"
+}
+
+using namespace aligator_hip::gar;
+using clk = std::chrono::steady_clock;
+
+// bench/lqr.cpp:25-57: A = I, B = [I; 0], c = 0.1, w_x = I with w_x(0,0) = 2, w_u = 1e-2 I,
+// terminal cost = the running cost's state part, x0 random; the LQ sub-problem ProxDDP hands to gar
+static LqrProblem define_problem(int nsteps, int dim, int nu, unsigned seed) {
+  std::vector<LqrKnot> knots;
+  for (int t = 0; t <= nsteps; ++t) {
+    LqrKnot k((uint)dim, t < nsteps ? (uint)nu : 0u, 0);
+    for (int i = 0; i < dim; ++i) {
+      k.Q(i, i) = (i == 0) ? 2.0 : 1.0;
+      k.A(i, i) = 1.0;
+      k.f[(size_t)i] = 0.1;
+    }
+    if (t < nsteps)
+      for (int i = 0; i < nu; ++i) {
+        k.R(i, i) = 1e-2;
+        k.B(i, i) = 1.0;
+      }
+    knots.push_back(k);
+  }
+  LqrProblem p(knots, (uint)dim);
+  std::mt19937_64 rng(seed);
+  std::uniform_real_distribution<double> u(-1.0, 1.0);
+  for (int i = 0; i < dim; ++i) {
+    p.G0(i, i) = -1.0;
+    p.g0[(size_t)i] = u(rng);
+  }
+  return p;
+}
+
+// the in-place rewrite of every knot a Newton iteration starts with (cost gradients change)
+static void update_lq_subproblem(LqrProblem &p, int iter) {
+  for (LqrKnot &k : p.stages) {
+    for (double &v : k.q)
+      v = 1e-3 * (iter + 1);
+    for (double &v : k.r)
+      v = -1e-3 * (iter + 1);
+  }
+}
+
+static ora_problem *to_oracle(const LqrProblem &p) {
+  const int N = p.horizon();
+  std::vector<int> d5;
+  for (const LqrKnot &k : p.stages) {
+    const int d[5] = {(int)k.nx, (int)k.nu, (int)k.nc, (int)k.nx2, (int)k.nth};
+    d5.insert(d5.end(), d, d + 5);
+  }
+  ora_problem *o = ora_problem_new(N, d5.data(), (int)p.nc0());
+  std::copy(p.G0.data(), p.G0.data() + p.nc0() * p.stages[0].nx, o->G0);
+  std::copy(p.g0.begin(), p.g0.end(), o->g0);
+  return o;
+}
+static void sync_oracle(const LqrProblem &p, ora_problem *o) { // the oracle re-reads the knots too
+  for (size_t t = 0; t < p.stages.size(); ++t) {
+    const LqrKnot &k = p.stages[t];
+    ora_knot &q = o->stages[t];
+    std::copy(k.Q.data(), k.Q.data() + k.nx * k.nx, q.Q);
+    std::copy(k.q.begin(), k.q.end(), q.q);
+    std::copy(k.A.data(), k.A.data() + k.nx2 * k.nx, q.A);
+    std::copy(k.f.begin(), k.f.end(), q.f);
+    if (k.nu > 0) {
+      std::copy(k.S.data(), k.S.data() + k.nx * k.nu, q.S);
+      std::copy(k.R.data(), k.R.data() + k.nu * k.nu, q.R);
+      std::copy(k.r.begin(), k.r.end(), q.r);
+      std::copy(k.B.data(), k.B.data() + k.nx2 * k.nu, q.B);
+    }
+  }
+}
+
+template <class Solver> static double time_loop(Solver &solver, LqrProblem &p, int iters, double mu, double *checksum) {
+  auto sol4 = lqrInitializeSolution(p);
+  struct { VectorOfVectors &xs, &us, &vs, &lbdas; } sol{sol4[0], sol4[1], sol4[2], sol4[3]};
+  const size_t N = (size_t)p.horizon();
+  std::vector<VectorXs> ffs(N + 1);
+  std::vector<Matrix> fbs(N + 1);
+  double best = 1e30;
+  for (int it = 0; it < iters + 2; ++it) { // two warm-up iterations
+    update_lq_subproblem(p, it);
+    const auto t0 = clk::now();
+    solver.backward(mu);
+    solver.forward(sol.xs, sol.us, sol.vs, sol.lbdas);
+    solver.collapseFeedback();
+    for (size_t i = 0; i <= N; ++i) {
+      ffs[i] = solver.getFeedforward(i);
+      fbs[i] = solver.getFeedback(i);
+    }
+    const double us = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+    if (it >= 2 && us < best)
+      best = us;
+  }
+  double c = 0.0;
+  for (const auto &x : sol.xs)
+    for (double v : x)
+      c += v;
+  c += fbs[0](0, 0) + ffs[N / 2][0];
+  *checksum = c;
+  return best;
+}
+
+int main(int argc, char **argv) {
+  if (gar_hip_device_count() <= 0) {
+    std::printf("bench_lqr_loop: no HIP device (the backend has no CPU fallback)\n");
+    return 77;
+  }
+  const int N = argc > 1 ? std::atoi(argv[1]) : 256, iters = 20;
+  const double mu = 1e-10; // bench/lqr.cpp: mu_init = 1e-10
+  struct Shape { int dim, nu; const char *what; };
+  const Shape shapes[] = {{36, 12, "north star (36, 12)"}, {56, 22, "bench/lqr.cpp (56, 22)"}};
+  for (const Shape &sh : shapes) {
+    LqrProblem p = define_problem(N, sh.dim, sh.nu, 42);
+    // the oracle, one thread (the reference's BM_lqr_prox<SERIAL> role)
+    ora_problem *op = to_oracle(p);
+    ora_prox_solver *os = ora_prox_new(op);
+    double ora_us = 1e30;
+    for (int it = 0; it < 5; ++it) {
+      update_lq_subproblem(p, it);
+      const auto t0 = clk::now();
+      sync_oracle(p, op);
+      ora_prox_backward(os, mu);
+      const double us = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+      if (us < ora_us)
+        ora_us = us;
+    }
+    ora_prox_free(os);
+    ora_problem_free(op);
+    double cs = 0.0, cp = 0.0;
+    {
+      ProximalRiccatiSolver s(p);
+      const double us = time_loop(s, p, iters, mu, &cs);
+      std::printf("%-24s N=%d  serial      %9.1f us / Newton iteration  (kernel %s)   oracle backward alone, 1 thread: %.0f us\n",
+                  sh.what, N, us, s.kernelName(), ora_us);
+    }
+    const unsigned legs = (unsigned)(N / 8);
+    try {
+      LqrProblem pp = define_problem(N, sh.dim, sh.nu, 42);
+      ParallelRiccatiSolver s(pp, legs);
+      const double us = time_loop(s, pp, iters, mu, &cp);
+      std::printf("%-24s N=%d  %3u legs    %9.1f us / Newton iteration  (kernel %s)   |checksum serial - legs| = %.2e\n",
+                  sh.what, N, legs, us, s.kernelName(), std::fabs(cs - cp));
+    } catch (const std::exception &e) {
+      std::printf("%-24s N=%d  %3u legs    refused: %s\n", sh.what, N, legs, e.what());
+    }
+  }
+  return 0;
+}

@@ -239,6 +239,42 @@ static void dense_solver() {
   REQUIRE(std::string(denseSolver.kernelName()) == "dense");
 }
 
+// tests/mpc-cycle.cpp / proximal-riccati.hxx:79-86: cycleAppend rotates the solver's stages (a ring on
+// the device: no record moves), the caller rotates its problem and writes the new last-but-one knot;
+// the next sweep must solve the rotated problem -- through more cycles than there are stages
+static void mpc_cycle() {
+  std::printf("mpc_cycle\n");
+  std::mt19937 rng(5);
+  const uint nx = g_small ? 8 : 36, nu = g_small ? 4 : 12, horz = g_small ? 5 : 12;
+  VectorXs x0(nx, 0.5);
+  auto prob = generate_problem(rng, x0, horz, nx, nu);
+  ProximalRiccatiSolver solver{prob};
+  const double mu = 1e-12;
+  solver.backward(mu);
+  for (uint c = 0; c < horz + 2; ++c) {
+    LqrKnot knot = generate_knot(rng, nx, nu);
+    for (uint t = 0; t + 1 < horz; ++t)
+      prob.stages[t] = prob.stages[t + 1];
+    prob.stages[horz - 1] = knot;
+    solver.cycleAppend(knot);
+    solver.backward(mu);
+    auto [xs, us, vs, lbdas] = lqrInitializeSolution(prob);
+    solver.forward(xs, us, vs, lbdas);
+    KktError err = lqrComputeKktError(prob, xs, us, vs, lbdas, mu);
+    REQUIRE(err.max <= 1e-9);
+    // a fresh solver on the rotated problem gives the same gains
+    ProximalRiccatiSolver fresh{prob};
+    fresh.backward(mu);
+    const Matrix a = solver.getFeedback(horz / 2), b = fresh.getFeedback(horz / 2);
+    double d = 0.0;
+    for (int i = 0; i < a.rows; ++i)
+      for (int j = 0; j < a.cols; ++j)
+        d = std::max(d, std::fabs(a(i, j) - b(i, j)));
+    REQUIRE(d == 0.0);
+  }
+  std::printf("  kernel %s, %u cycles\n", solver.kernelName(), horz + 2);
+}
+
 static void error_behaviour() {
   std::printf("error_behaviour\n");
   std::mt19937 rng(3);
@@ -284,6 +320,7 @@ int main() {
     if (!(g_small && th == 8u))
       parallel_solver_class(th);
   dense_solver();
+  mpc_cycle();
   padded_shape(12, 6, "12,8");
   padded_shape(10, 3, "12,4");
   error_behaviour();

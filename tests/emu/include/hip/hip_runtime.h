@@ -196,6 +196,10 @@ inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { s
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return 0; }
 inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
+inline hipError_t hipMemset2DAsync(void *d, size_t pitch, int v, size_t w, size_t h, hipStream_t) {
+  for (size_t r = 0; r < h; ++r) std::memset((char *)d + r * pitch, v, w);
+  return 0;
+}
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }

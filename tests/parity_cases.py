@@ -312,3 +312,70 @@ def check_second_bunch_kaufman_test(lib_path=None):
             del os.environ["GAR_HIP_BACKWARD"]
         else:
             os.environ["GAR_HIP_BACKWARD"] = old
+
+
+def check_bulk_gains(prob, mueq, lib_path=None, num_legs=1):
+    """gar_hip_fetch_results / gar_hip_get_gains_all against the per-stage gar_hip_get_gains and the
+    per-part gar_hip_get_solution: bitwise the same numbers, one copy instead of 3 (N+1) + 4."""
+    dims = [k.dims for k in prob.stages]
+    s = BatchedRiccatiSolver(dims, prob.nc0, batch=2, num_legs=num_legs, lib_path=lib_path)
+    s.upload([prob, prob])
+    assert s.backward(mueq) and s.forward()
+    if num_legs > 1:
+        s.collapse_feedback()
+    for b in (1, 0):
+        ffs, fbs = s.gains_all(b)
+        for t in range(prob.horizon + 1):
+            f = s.factor(t, b)
+            assert np.array_equal(ffs[t], f.ff) and np.array_equal(fbs[t], f.fb), t
+        rec, _, _ = s.fetch_results(b, gains=False)
+        flat = np.concatenate([np.concatenate([np.ravel(v) for v in part]) if part else np.zeros(0)
+                               for part in s.solution(b)]) if not s._nxp else None
+        if flat is not None:
+            assert np.array_equal(rec[:flat.size], flat)
+    return s
+
+
+def check_cycle_append_ring(lib_path=None, nx=8, nu=4, horz=5, cycles=8, family=None, dense=False):
+    """MPC cycling as a ring (proximal-riccati.hxx:79-86, tests/mpc-cycle.cpp): after cycleAppend only the
+    NEW last-but-one knot is uploaded -- every other knot must still be where the kernels look for it,
+    through more cycles than there are stages (the ring wraps) -- and the sweep must match the oracle on
+    the caller's rotated problem: solution, every stage's gains and value function."""
+    import os
+    old = os.environ.get("GAR_HIP_BACKWARD")
+    if family:
+        os.environ["GAR_HIP_BACKWARD"] = family
+    try:
+        rng = np.random.default_rng(77)
+        probs = [synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W") for _ in range(2)]
+        dims = [k.dims for k in probs[0].stages]
+        s = BatchedRiccatiSolver(dims, probs[0].nc0, batch=2, lib_path=lib_path, dense=dense)
+        s.upload(probs)
+        mu = 1e-10
+        assert s.backward(mu) and s.forward()
+        for c in range(cycles):
+            s.cycle_append(dims[0])
+            for b, p in enumerate(probs):
+                new = synth.generate_knot(rng, nx, nu, mode="W")
+                p.stages[:horz] = p.stages[1:horz] + [new]        # the caller's own rotation
+                s.upload_knot(b, horz - 1, new)                   # ONLY the new knot goes to the device
+            assert s.backward(mu) and s.forward()
+            for b, p in enumerate(probs):
+                if dense:
+                    _, _, ref = oracle_serial(p, mu)
+                else:
+                    _, osol, ref = oracle_serial(p, mu)
+                for A, B in zip(s.solution(b), ref):
+                    assert maxdiff(A, B) <= 1e-9 * scale_of(ref), (c, b)
+                if not dense:
+                    class D:
+                        def __getitem__(self, t, b=b):
+                            return s.factor(t, b)
+                    compare_factors(D(), osol, horz, 1e-9, names=("ff", "fb"), vnames=("Vxx", "vx"))
+        return s
+    finally:
+        if family:
+            if old is None:
+                del os.environ["GAR_HIP_BACKWARD"]
+            else:
+                os.environ["GAR_HIP_BACKWARD"] = old

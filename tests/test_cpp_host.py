@@ -43,3 +43,22 @@ def test_cpp_host_mirror_on_gpu():
     r = _run("test_gar")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_newton_iteration_through_the_seam_on_gpu():
+    """bench/lqr.cpp's loop restated on the host boundary (tests/cpp/bench_lqr_loop.cpp): upload of every
+    knot, backward, forward, collapseFeedback, every stage's gains -- serial and N/8 legs agree, and the
+    bulk read-back keeps an iteration in the sub-millisecond range at the north-star shape."""
+    import re
+    subprocess.run(["make", "-s", "-C", os.path.join(os.path.dirname(HERE), "oracle")], check=True)
+    subprocess.run(["make", "-s", "-C", CPP], check=True)
+    r = subprocess.run([os.path.join(CPP, "_build", "bench_lqr_loop"), "256"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout)
+    lines = [ln for ln in r.stdout.splitlines() if "north star" in ln]
+    assert len(lines) == 2 and "wave_leg<36,12>" in lines[1]
+    us = [float(re.search(r"([0-9.]+) us / Newton", ln).group(1)) for ln in lines]
+    diff = float(re.search(r"= ([0-9.e+-]+)$", lines[1]).group(1))
+    assert diff < 1e-6 and us[1] < 2500.0, r.stdout

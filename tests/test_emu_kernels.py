@@ -456,3 +456,18 @@ def test_device_written_knots_survive_host_set_init():
 
 def test_wave_kernel_second_bunch_kaufman_test():
     pc.check_second_bunch_kaufman_test(EMU)
+
+
+@pytest.mark.parametrize("nx,nu,horz,legs", [(8, 4, 7, 1), (12, 4, 9, 3), (5, 2, 6, 1), (10, 3, 8, 1)])
+def test_bulk_gains_and_solution_readback(nx, nu, horz, legs):
+    """wave / wave-leg kernels (fbT2 device order), generic kernels (row-major), a padded shape."""
+    prob = synth.generate_lq_problem(300 + nx, np.ones(nx), horz, nx, nu, mode="W")
+    pc.check_bulk_gains(prob, 1e-10, EMU, num_legs=legs)
+
+
+@pytest.mark.parametrize("nx,nu,family,dense", [(8, 4, "wave", False), (8, 4, "wg4", False), (5, 2, None, False),
+                                                (12, 4, "wave", False), (6, 3, None, True)])
+def test_cycle_append_is_a_ring(nx, nu, family, dense):
+    s = pc.check_cycle_append_ring(EMU, nx=nx, nu=nu, family=family, dense=dense)
+    if family:
+        assert s.kernel_name.startswith("wave<" if family == "wave" else "mfma<")

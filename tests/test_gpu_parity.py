@@ -332,6 +332,14 @@ def test_wave_family_bunch_kaufman_fallback_and_failure(monkeypatch):
         ProximalRiccatiSolver(bad).backward(1e-10)
 
 
+@pytest.mark.parametrize("nx,nu,horz,legs", [(36, 12, 64, 1), (36, 12, 64, 8), (12, 6, 40, 1), (30, 10, 33, 1)])
+def test_bulk_gains_and_solution_readback(nx, nu, horz, legs):
+    """gar_hip_fetch_results / gar_hip_get_gains_all: one gather + one copy, bitwise what the per-stage
+    calls return (wave / wave-leg kernels, generic kernels, a padded shape)."""
+    prob = synth.generate_lq_problem(300 + nx, np.ones(nx), horz, nx, nu, mode="W")
+    pc.check_bulk_gains(prob, 1e-10, num_legs=legs)
+
+
 def test_wave_kernel_second_bunch_kaufman_test():
     pc.check_second_bunch_kaufman_test()
 
@@ -382,6 +390,44 @@ def test_bench_two_ranks_on_one_gpu():
                      "--steps", "2", "--warmup", "1", "--batch", "128", "--backend", "gloo", "--same-device"])
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d and "parallel_in_time" not in d
     assert abs(d["value"] - 2 * 128 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+@pytest.mark.parametrize("nx,nu,horz,family,dense", [(36, 12, 24, "wave", False), (36, 12, 24, "wg4", False),
+                                                     (16, 8, 9, "wave", False), (10, 3, 12, None, False),
+                                                     (12, 6, 10, None, True)])
+def test_cycle_append_is_a_ring(nx, nu, horz, family, dense):
+    """cycleAppend on ProximalRiccatiSolver's kernels (both specialised families, a padded shape, the
+    stage-dense solver): no record moves, only the new knot is uploaded, the ring wraps."""
+    pc.check_cycle_append_ring(nx=nx, nu=nu, horz=horz, cycles=horz + 3, family=family, dense=dense)
+
+
+def test_bench_horizon_mode_one_rank_rccl():
+    """bench.py --mode horizon (BASELINE.json configs[3]: one N=2048 problem, horizon sharded over the
+    ranks, ONE RCCL all-gather per sweep, no host synchronisation inside a sweep) with the 1-rank group
+    a 1-GPU box offers; the 2-rank flow runs on CPU (tests/test_sharded_gloo.py) and below when the
+    box has two GPUs."""
+    d = _bench_line(["bench.py", "--mode", "horizon"])
+    hs = d["horizon_sharded"]
+    assert d["n_gpus"] == 1 and hs["ranks"] == 1 and hs["legs"] == 256 and hs["host_syncs_per_sweep"] == 0
+    assert hs["kernel"] == "wave_leg<36,12>" and hs["max_rel_diff_vs_serial_on_rank0_stages"] < 1e-9
+    assert 0.0 < hs["ms_per_sweep"] < 5.0 and hs["all_gather_ms"] < hs["ms_per_sweep"]
+    assert d["horizon_sharded_N16384"]["max_rel_diff_vs_serial_on_rank0_stages"] < 1e-8
+
+
+def test_bench_horizon_mode_two_ranks_rccl():
+    """The same with a real 2-rank RCCL all-gather; skipped on a 1-GPU box."""
+    import socket
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                     "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                     "--mode", "horizon"])
+    hs = d["horizon_sharded"]
+    assert d["n_gpus"] == 2 and hs["legs_per_rank"] == 128 and hs["max_rel_diff_vs_serial_on_rank0_stages"] < 1e-9
 
 
 def _lq_from_blocks(A, B, c, Q, R, q, r, Qt, x0, horz):
