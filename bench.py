@@ -26,6 +26,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# thread placement of the CPU baseline (read by libgomp when the oracle library is first loaded)
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "close")
 
 from aligator_amd import synth_device  # noqa: E402
 from aligator_amd.gar import BatchedRiccatiSolver  # noqa: E402
@@ -60,42 +63,81 @@ def algorithmic_bytes(N, nx, nu):
 
 
 def cpu_baseline(args, nx, nu, N, mueq):
-    """The oracle (restated reference, NOT the Eigen build) timed on this box's
-    host cores: OpenMP parallel-for over a bounded sample of the same workload."""
+    """The oracle (restated reference, NOT the Eigen build) timed on this box's host cores
+    (BASELINE.md section 2): C2 = OpenMP over independent problems, every thread sweeping thread-local
+    (first-touch, NUMA-local) copies of its problems with OMP_PLACES=cores / OMP_PROC_BIND=close; C1 = one
+    thread, one problem; C3 = the leg-parallel solver (J threads) on one problem, J in {2, 3, 4, 6}
+    (bench/gar-riccati.cpp:87-90); C4 = the reference's own benchmark shape nc = 32 (:19-22).
+    A bounded sample (~15 s of CPU work); a reported baseline, never the target."""
     from aligator_amd import synth
     from oracle import oracle as ora
 
-    cores = os.cpu_count() or 1
-    nprob = max(2 * cores, 8)
-    rng = np.random.default_rng(1234)
+    budget = max(args.cpu_seconds, 0.5)
     L = ora.lib(native=True)  # rebuilt with -march=native on THIS host
+    base = []
     t0 = time.time()
-    probs = []
-    for i in range(nprob):
+    for i in range(8):
         p = synth.generate_lq_problem(np.random.default_rng(1234 + i), np.zeros(nx), N, nx, nu,
                                       mode=args.generator)
-        probs.append(ora.Problem.from_knots(p.stages, p.G0, p.g0, native=True))
-        if time.time() - t0 > 60:
+        base.append(ora.Problem.from_knots(p.stages, p.G0, p.g0, native=True))
+        if i == 0:
+            first = p
+        if time.time() - t0 > 20:
             break
-    bs = ora.BatchSweep(probs)
-    threads = bs.max_threads()
-    bs.sweep(mueq, threads)  # warm-up
-    reps, t_acc = 0, 0.0
-    while t_acc < args.cpu_seconds and reps < 50:
-        t1 = time.perf_counter()
-        fails = bs.sweep(mueq, threads)
-        t_acc += time.perf_counter() - t1
-        reps += 1
-        assert fails == 0
-    t1 = time.perf_counter()
-    ora.BatchSweep(probs[:1]).sweep(mueq, 1)
-    lat = time.perf_counter() - t1
-    del rng, L
-    return {"value": len(probs) * reps / t_acc, "unit": "sweeps/s", "cores": threads,
-            "kind": "port",
-            "sample": f"{len(probs)} problems x {reps} reps, OpenMP parallel-for over problems, "
-                      f"oracle/gar_oracle.c -O3 -march=native (restated reference, not the Eigen "
-                      f"build); 1-thread latency {lat * 1e3:.2f} ms/sweep"}
+    threads = ora.BatchSweep(base[:1]).max_threads()
+    # C1: one thread
+    bs1 = ora.BatchSweep(base[:2])
+    bs1.sweep_local(mueq, 1, 1)
+    f1, s1 = bs1.sweep_local(mueq, 1, 3)
+    lat = s1 / 6.0
+    # C2: all threads, two problems per thread, repetitions sized to the budget
+    probs = [base[i % len(base)] for i in range(2 * threads)]
+    bs = ora.BatchSweep(probs[:1])
+    bs.problems = probs
+    _, sw = bs.sweep_local(mueq, threads, 1)
+    reps = int(max(1, min(50, 0.6 * budget / max(sw, 1e-3))))
+    fails, sec = bs.sweep_local(mueq, threads, reps)
+    assert fails == 0 and f1 == 0
+    rate = len(probs) * reps / sec
+    out = {"value": rate, "unit": "sweeps/s", "cores": threads, "kind": "port",
+           "sample": f"{len(probs)} problems ({len(base)} distinct) x {reps} reps, one OpenMP thread per "
+                     f"problem pair, thread-local copies, OMP_PLACES={os.environ.get('OMP_PLACES')} "
+                     f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}; oracle/gar_oracle.c -O3 "
+                     f"-march=native (restated reference, not the Eigen build)",
+           "one_thread_ms_per_sweep": lat * 1e3,
+           "parallel_efficiency": rate * lat / threads}
+    # C3: leg-parallel, one problem (its OpenMP team = J threads)
+    legs = {}
+    t_c3 = time.time()
+    for J in (2, 3, 4, 6):
+        if J > threads or time.time() - t_c3 > 0.2 * budget + 2:
+            break
+        op = ora.Problem.from_knots(first.stages, first.G0, first.g0, native=True)  # (the solver mutates it)
+        par = ora.ParallelRiccatiSolver(op, J)
+        sol = op.initialize_solution()
+        best = 1e30
+        for _ in range(3):
+            t1 = time.perf_counter()
+            par.backward(mueq)
+            par.forward(*sol)
+            best = min(best, time.perf_counter() - t1)
+        legs[str(J)] = best * 1e3
+    out["leg_parallel_ms_per_sweep"] = legs
+    # C4: nc = 32 on every knot (C = [I 0], the reference's generator), mu = 1e-11
+    try:
+        pc_ = synth.generate_lq_problem(np.random.default_rng(99), np.zeros(nx), N, nx, nu, nc=32,
+                                        mode=args.generator)
+        oc = ora.Problem.from_knots(pc_.stages, pc_.G0, pc_.g0, native=True)
+        bc = ora.BatchSweep([oc])
+        bc.problems = [oc] * threads
+        bc.sweep_local(1e-11, threads, 1)
+        _, sc = bc.sweep_local(1e-11, threads, 2)
+        out["nc32_sweeps_per_s"] = threads * 2 / sc
+    except Exception as e:  # the baseline never fails the bench line
+        out["nc32_sweeps_per_s"] = None
+        out["nc32_error"] = str(e)[:100]
+    del L
+    return out
 
 
 def parallel_in_time(args, device, stream, nx, nu, mueq, N=2048, legs=256, reps=10):

@@ -58,12 +58,44 @@ static void mm_acc(int M, int N, int K, double alpha, const double *A, long ars,
       }
     }
   } else if (acs == 1 && brs == 1) { /* dot-product form, contiguous k */
-    for (int j = 0; j < N; ++j)
-      for (int i = 0; i < M; ++i) {
+    /* register-blocked: 2 rows of A against 4 columns of B, eight SIMD partial-sum accumulators
+     * (what an optimised BLAS / Eigen's gebp kernel does for these sizes; the summation order inside a
+     * dot product is the vector unit's, as there) */
+    int i = 0;
+    for (; i + 2 <= M; i += 2) {
+      const double *a0 = A + (long)i * ars, *a1 = a0 + ars;
+      int j = 0;
+      for (; j + 4 <= N; j += 4) {
+        const double *b0 = B + (long)j * bcs, *b1 = b0 + bcs, *b2 = b1 + bcs, *b3 = b2 + bcs;
+        double s00 = 0, s01 = 0, s02 = 0, s03 = 0, s10 = 0, s11 = 0, s12 = 0, s13 = 0;
+#pragma omp simd reduction(+ : s00, s01, s02, s03, s10, s11, s12, s13)
+        for (int k = 0; k < K; ++k) {
+          const double x0 = a0[k], x1 = a1[k];
+          s00 += x0 * b0[k]; s01 += x0 * b1[k]; s02 += x0 * b2[k]; s03 += x0 * b3[k];
+          s10 += x1 * b0[k]; s11 += x1 * b1[k]; s12 += x1 * b2[k]; s13 += x1 * b3[k];
+        }
+        double *c0 = C + (long)i * crs + (long)j * ccs, *c1 = c0 + crs;
+        c0[0] += alpha * s00; c0[ccs] += alpha * s01; c0[2 * ccs] += alpha * s02; c0[3 * ccs] += alpha * s03;
+        c1[0] += alpha * s10; c1[ccs] += alpha * s11; c1[2 * ccs] += alpha * s12; c1[3 * ccs] += alpha * s13;
+      }
+      for (; j < N; ++j) {
+        const double *bj = B + (long)j * bcs;
+        double s0 = 0.0, s1 = 0.0;
+#pragma omp simd reduction(+ : s0, s1)
+        for (int k = 0; k < K; ++k) {
+          s0 += a0[k] * bj[k];
+          s1 += a1[k] * bj[k];
+        }
+        C[(long)i * crs + (long)j * ccs] += alpha * s0;
+        C[(long)(i + 1) * crs + (long)j * ccs] += alpha * s1;
+      }
+    }
+    for (; i < M; ++i)
+      for (int j = 0; j < N; ++j) {
         const double *ai = A + (long)i * ars;
         const double *bj = B + (long)j * bcs;
         double s = 0.0;
-#pragma omp simd reduction(+ : s) /* SIMD partial sums, as an optimised BLAS/Eigen kernel forms them */
+#pragma omp simd reduction(+ : s)
         for (int k = 0; k < K; ++k)
           s += ai[k] * bj[k];
         C[(long)i * crs + (long)j * ccs] += alpha * s;
