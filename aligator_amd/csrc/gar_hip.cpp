@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +40,41 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 inline int align2(int x) { return (x + 1) & ~1; }
+
+// Tracing hooks (the reference brackets the same places with Tracy zones: backwardImpl
+// riccati-kernel.hxx:108, "factor_initial" proximal-riccati.hxx:43, forwardImpl riccati-kernel.hxx:320,
+// "parallel_backward" / "parallel_forward" parallel-solver.hxx:134,213, assembleCondensedSystem :87):
+// roctx ranges around the launches, visible in rocprofv3 --marker-trace.  Opt-in (GAR_HIP_ROCTX=1) and
+// resolved at run time, so the library carries no link dependency on the tracer.
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char *e = std::getenv("GAR_HIP_ROCTX");
+    if (!e || e[0] != '1')
+      return;
+    if (void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL)) {
+      push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (!push || !pop)
+        push = nullptr, pop = nullptr;
+    }
+  }
+};
+inline const Roctx &roctx() {
+  static const Roctx r;
+  return r;
+}
+struct RoctxRange {
+  explicit RoctxRange(const char *name) {
+    if (roctx().push)
+      roctx().push(name);
+  }
+  ~RoctxRange() {
+    if (roctx().pop)
+      roctx().pop();
+  }
+};
 
 // Every entry point runs on the solver's own device, whatever the caller's current device is, and
 // leaves the caller's current device as it found it (two solvers on two GPUs in one process;
@@ -680,6 +717,7 @@ gar::LegParams make_leg_params(gar_hip_solver *s) {
 }
 
 int launch_backward(gar_hip_solver *s, double mueq) {
+  RoctxRange range_(s->num_legs > 1 ? "gar::parallel_backward" : "gar::backwardImpl+factor_initial");
   if (s->leg_bwd_kernel) {
     gar::LegParams Q = make_leg_params(s);
     const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
@@ -762,6 +800,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
 }
 
 int launch_forward(gar_hip_solver *s, const double *theta_dev) {
+  RoctxRange range_(s->num_legs > 1 ? "gar::parallel_forward" : "gar::forwardImpl");
   if (s->leg_fwd_kernel) {
     gar::LegParams Q = make_leg_params(s);
     if (s->timing)
@@ -814,6 +853,7 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
 }
 
 int launch_condensed(gar_hip_solver *s) {
+  RoctxRange range_("gar::assembleCondensedSystem+symmetricBlockTridiagSolve");
   gar::CondensedParams C{};
   C.ball = s->d_bound_all;
   C.prob = s->d_prob;
