@@ -148,6 +148,8 @@ struct gar_hip_solver {
   // one-wave-per-problem backward kernel (gar_wave.hpp), preferred when bound
   void (*wave_kernel)(gar::MfmaParams, int) = nullptr;
   int wave_lds_doubles = 0, waves_per_block = 1;
+  bool fb_t2 = false;      // factor records keep fb / fth in the fbT2 device order (gar_mfma.hpp)
+  std::string lds_error;   // the generic kernels do not fit a CU's LDS (fatal unless a specialised family serves the shape)
   bool wave_fused_init = false;
   bool init_closed = true; // closed-form initial stage when G0 = +-I (GAR_HIP_INIT=bk: always factorise)
   // one-wave-per-(problem, leg) kernels (gar_wave_leg.hpp), bound for uniform leg-mode problems
@@ -391,10 +393,10 @@ int plan_lds(gar_hip_solver *s) {
   }
   if (n0 > 512 || nkM > 512)
     return fail(GAR_HIP_ERR_UNSUPPORTED, "KKT dimension above 512");
-  if ((int64_t)L.total * 8 > 160 * 1024)
-    return fail(GAR_HIP_ERR_UNSUPPORTED,
-                "stage dimensions need " + std::to_string((int64_t)L.total * 8) +
-                    " B of LDS (> 160 KiB per CU)");
+  s->lds_error.clear();
+  if ((int64_t)L.total * 8 > 160 * 1024) // fatal only if no specialised family serves the shape (allocate)
+    s->lds_error = "stage dimensions need " + std::to_string((int64_t)L.total * 8) +
+                   " B of LDS (> 160 KiB per CU)";
   return GAR_HIP_OK;
 }
 
@@ -402,6 +404,7 @@ int plan_lds(gar_hip_solver *s) {
 template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   s->mfma_kernel = gar::gar_backward_mfma<NX, NU>;
   s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU>;
+  s->fb_t2 = true;
   s->mfma_lds_doubles = gar::MfmaCfg<NX, NU>::total;
   s->kernel_name = "mfma<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
   // Two backward kernels: one wave per problem (throughput: every SIMD runs its own problem) and
@@ -424,7 +427,20 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   }
 }
 
+// Wide shapes (nx + nu > 64, e.g. the Talos walk's (56, 22) padded to (56, 24)): the one-wave-per-problem
+// backward sweep only (gar_wave2.hpp; fb ROW-major = the generic record layout), the initial stage
+// and the forward sweep on the generic kernels.
+template <int NX, int NU> void bind_wide(gar_hip_solver *s) {
+  s->wave_kernel = gar::gar_backward_wave<NX, NU>;
+  s->wave_fused_init = false;
+  s->wave_lds_doubles = gar::WaveCfg<NX, NU>::total;
+  s->waves_per_block = 1;
+  s->fb_t2 = false;
+  s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+}
+
 template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
+  s->fb_t2 = true;
   // two waves per leg (plain part / parameter part) unless GAR_HIP_LEG_WAVES=1
   const char *lw = std::getenv("GAR_HIP_LEG_WAVES");
   s->leg_waves = (lw && std::string(lw) == "1") ? 1 : 2;
@@ -486,6 +502,7 @@ void select_leg_kernel(gar_hip_solver *s) {
 template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
   s->wave_kernel = gar::gar_backward_wave<NX, NU, NC>;
   s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU, NC>;
+  s->fb_t2 = true;
   const int with_init = gar::WaveCfg<NX, NU, NC>::total_with_init(s->nc0);
   s->wave_fused_init = (size_t)with_init * sizeof(double) <= 64 * 1024 && s->nth0 == 0;
   s->wave_lds_doubles = s->wave_fused_init ? with_init : gar::WaveCfg<NX, NU, NC>::total;
@@ -508,6 +525,7 @@ void select_kernel(gar_hip_solver *s) {
   s->mfma_fwd_kernel = nullptr;
   s->wave_kernel = nullptr;
   s->wave_fused_init = false;
+  s->fb_t2 = false;
   {
     const char *ik = std::getenv("GAR_HIP_INIT");
     s->init_closed = !(ik && std::string(ik) == "bk");
@@ -553,6 +571,7 @@ void select_kernel(gar_hip_solver *s) {
   else if (nx == 12 && nu == 8) bind_mfma<12, 8>(s);
   else if (nx == 12 && nu == 4) bind_mfma<12, 4>(s);
   else if (nx == 8 && nu == 4) bind_mfma<8, 4>(s);
+  else if (nx == 56 && nu == 24) bind_wide<56, 24>(s);
 }
 
 gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
@@ -846,9 +865,13 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
     return GAR_HIP_OK;
   }
   const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
+  if (s->timing)
+    HIP_TRY(hipEventRecord(s->ev[3], s->stream));
   hipLaunchKernelGGL(gar::gar_forward_generic, grid, dim3(256),
                      (size_t)s->lds.ftotal * sizeof(double), s->stream, P);
   HIP_TRY(hipGetLastError());
+  if (s->timing)
+    HIP_TRY(hipEventRecord(s->ev[4], s->stream));
   return GAR_HIP_OK;
 }
 
@@ -1017,6 +1040,8 @@ int allocate(gar_hip_solver *s) {
   s->dirty_iv.assign(B, {});
   s->dirty = false;
   select_kernel(s);
+  if (!s->lds_error.empty() && !(s->wave_kernel || s->mfma_kernel || s->leg_bwd_kernel))
+    return fail(GAR_HIP_ERR_UNSUPPORTED, s->lds_error);
   if (s->dense) {
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_backward_dense,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1048,17 +1073,19 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipFuncSetAttribute((const void *)s->wave_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->wave_lds_doubles * s->waves_per_block * sizeof(double))));
-  HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_initial_generic,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(s->lds.total * sizeof(double))));
+  if (s->lds_error.empty())
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_initial_generic,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->lds.total * sizeof(double))));
   if (s->n0 <= 128)
     HIP_TRY(hipFuncSetAttribute(
         (const void *)gar::gar_initial_wave, hipFuncAttributeMaxDynamicSharedMemorySize,
         (int)(gar::gar_initial_wave_lds_doubles(s->n0, s->nth0) * sizeof(double))));
   // > 64 KiB of dynamic LDS needs the opt-in attribute
-  HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_backward_generic,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(s->lds.total * sizeof(double))));
+  if (s->lds_error.empty())
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_backward_generic,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->lds.total * sizeof(double))));
   if (s->num_legs > 1)
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_generic,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1493,7 +1520,7 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
   int rc = d2h(s, ff, rec + o.ff, nr);
   std::vector<double> tmp;
   // the specialised kernel families keep fb (and fth) in the fbT2 device order
-  const bool t2 = (s->mfma_kernel || s->wave_kernel || s->leg_bwd_kernel) && t < s->horizon;
+  const bool t2 = s->fb_t2 && t < s->horizon;
   const bool fbt2 = t2 && fb;
   const bool ftht2 = t2 && fth && m.nth > 0;
   std::vector<double> tmpth;
@@ -1556,7 +1583,7 @@ int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
                            hipMemcpyHostToDevice, s->stream));
   }
   if (what & 2) { // device-side gather (fbT2 -> row-major), then ONE device-to-host copy
-    const bool t2 = s->mfma_kernel || s->wave_kernel || s->leg_bwd_kernel;
+    const bool t2 = s->fb_t2;
     hipLaunchKernelGGL(gar::gar_gather_gains, dim3((unsigned)(s->horizon + 1)), dim3(256), 0, s->stream,
                        s->d_meta, s->d_fac + (int64_t)b * s->fac_doubles, s->d_gains,
                        s->d_gains + s->ff_all_doubles, s->d_gain_off, s->horizon, t2 ? 1 : 0,

@@ -60,7 +60,7 @@ struct MfmaParams {
 // backward sweep and the forward sweep; the 4-wave backward kernel is unconstrained only)
 template <int NX, int NU, int NC = 0> struct MfmaCfg {
   static_assert(NX % 4 == 0 && NU % 4 == 0 && NC % 4 == 0, "NX, NU, NC must be multiples of 4");
-  static_assert(NU >= 4 && NU <= 16 && NX >= NU, "4 <= NU <= 16 <= NX");
+  static_assert(NU >= 4 && NU <= 32 && NX >= NU, "4 <= NU <= 32 <= NX");
   static constexpr int NW = NX + NU;
   static constexpr int NK = NU + NC; // rows of the reduced KKT system [Rhat D^T; D -mu I]
   static constexpr int NR = NK + NX; // rows of ff / fb: [kff; zff; yff], [K; Z; Aff]
@@ -68,7 +68,9 @@ template <int NX, int NU, int NC = 0> struct MfmaCfg {
   static constexpr int TW = (NW + 15) / 16; // tiles over [x; u]
   static constexpr int KS = NX / 4;         // k-steps over the next-state index
   static constexpr int KU = NU / 4;         // k-steps over the control index
-  static_assert(TW <= 3, "one column tile per worker wave (3 workers)");
+  // (the 4-wave kernel gar_backward_mfma needs TW <= 3: one column tile per worker wave, NW <= 64;
+  // the wide shapes -- NW > 64, e.g. (56, 24) -- exist in the one-wave-per-problem family only)
+  static constexpr bool WIDE = (NW > 64);
   // pitch of the k-fast buffers: p = 2 mod 4 makes "16 lanes stride p, 4 lane
   // groups +1" conflict-free for ds_read_b64 (bank = dword address mod 64)
   static constexpr int PK = NX + 2;
@@ -268,6 +270,7 @@ __device__ __forceinline__ void ldl_solve_bcast(const double (&a)[NU], const dou
 template <int NX, int NU>
 __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
   using C = MfmaCfg<NX, NU>;
+  static_assert(C::TW <= 3 && NU <= 16, "one column tile per worker wave (3 workers), NW <= 64");
   constexpr int NW = C::NW, PK = C::PK, PG = C::PG;
   double *sm = gar_smem;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -245,15 +245,21 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) {
 // the COMPLETE pivot rule: a column that fails the first test is checked out of line against the
 // second one and the elimination goes on when Bunch-Kaufman keeps kp = k.  Returns 0 when it kept
 // kp = k at every column; `first_failed` tells whether any column needed the second test.
+// (NU <= 16: the rows sit in one 16-lane DPP row and every broadcast is a v_mov_b64_dpp; wider
+// Rhat -- the (56, 24) shape -- broadcasts through v_readlane)
+template <int NU> __device__ __forceinline__ double ldl_bcast(double v, int n, int lane) {
+  if (NU <= 16)
+    return row_bcast(v, n & 15, lane);
+  return lane_bcast(v, n);
+}
 template <int NU>
 __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], double (&nd)[NU], bool &first_failed) {
-  static_assert(NU <= 16, "lane = row inside one 16-lane DPP row");
   const double alpha = (1.0 + 4.123105625617661) / 8.0;
   int bad = 0;
   first_failed = false;
 #pragma unroll
   for (int k = 0; k < NU; ++k) {
-    const double akk = row_bcast(a[k], k, lane);
+    const double akk = ldl_bcast<NU>(a[k], k, lane);
     const unsigned long long nok = wave_ballot(!(fabs(akk) >= alpha * fabs(a[k])) || akk == 0.0);
     const unsigned long long from_k = ((1ull << NU) - 1ull) & ~((1ull << k) - 1ull);
     if (nok & from_k) { // wave-uniform, rare
@@ -268,7 +274,7 @@ __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], 
     const double nlik = a[k] * nd_k; // -L(i,k)
 #pragma unroll
     for (int j = k + 1; j < NU; ++j)
-      a[j] = __builtin_fma(row_bcast(nlik, j, lane), a[k], a[j]); // a(i,j) -= L(j,k) a(i,k)
+      a[j] = __builtin_fma(ldl_bcast<NU>(nlik, j, lane), a[k], a[j]); // a(i,j) -= L(j,k) a(i,k)
     a[k] = nlik;
     nd[k] = nd_k;
   }
@@ -311,8 +317,13 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   using M = MfmaCfg<NX, NU, 0>;
   constexpr int NK = C::NK, NR = C::NR;
   constexpr int NW = C::NW, PK = C::PK, PG = C::PG, TX = C::TX, TW = C::TW, KS = C::KS, KU = C::KU;
-  static_assert(NW <= 64, "the vector recursions keep [qhat; rhat] one entry per lane");
+  // [qhat; rhat] one entry per lane; the wide shapes (NW > 64: (56, 24)) keep entries 64.. in a
+  // second register (they are control entries: NX <= 64), and write fb ROW-major (the generic
+  // record layout: their forward sweep is the generic kernel) instead of the fbT2 device order
+  constexpr bool WIDE = M::WIDE;
+  static_assert(NX <= 64 && NW <= 128 && TW <= 5, "state entries in the first register");
   const int li = lane & 15, lk = lane >> 4;
+  const unsigned fbrm = 8u * (unsigned)(lk * NX + li); // row-major fb: element (lk, li)
   double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM, *vn = sm + C::oVn;
   double *Lr = sm + C::oLr, *ndi = sm + C::oDi;
   constexpr int oVxx = M::fVxx, ovx = M::fvx;
@@ -348,20 +359,27 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
     for (int s = 0; s < KS; ++s)
       fs[s] = ldg_b(rec, M::kf + 4 * s, lkb);
   }
+  double qri1 = 0.0; // WIDE: [q; r][64 + lane]
+  if (WIDE)
+    qri1 = ldg_b(rec, M::kq + 64, 8u * (unsigned)(lane < NW - 64 ? lane : NW - 65));
   // ---- P = V' F, H = W + F^T P (:216-228), tile columns from the control columns down ---------
   constexpr int TXF = C::REM4 ? TX - 1 : TX;
   const int i4 = lane & 3, k4 = lane >> 4;
   constexpr int cR = NX >> 4; // first tile column holding control columns: Rhat needs tj >= cR
-  // V' as the A operand of P = V'F: the same registers serve every tile column
-  double Vop[TXF > 0 ? TXF : 1][KS], Vop4[KS];
+  // V' as the A operand of P = V'F: the same registers serve every tile column (the wide shapes
+  // have no registers to spare for that: they read the operands from LDS at every use)
+  constexpr bool PRELOAD_V = !WIDE;
+  double Vop[PRELOAD_V ? (TXF > 0 ? TXF : 1) : 1][PRELOAD_V ? KS : 1], Vop4[PRELOAD_V ? KS : 1];
+  if (PRELOAD_V) {
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
+    for (int s = 0; s < KS; ++s) {
 #pragma unroll
-    for (int tm = 0; tm < TXF; ++tm) {
-      const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
-      Vop[tm][s] = V[ic * PK + 4 * s + lk];
+      for (int tm = 0; tm < TXF; ++tm) {
+        const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
+        Vop[PRELOAD_V ? tm : 0][PRELOAD_V ? s : 0] = V[ic * PK + 4 * s + lk];
+      }
+      Vop4[PRELOAD_V ? s : 0] = C::REM4 ? V[(NX - 4 + i4) * PK + 4 * s + k4] : 0.0;
     }
-    Vop4[s] = C::REM4 ? V[(NX - 4 + i4) * PK + 4 * s + k4] : 0.0;
   }
   double part[TW]; // (F^T vx' + P^T f)[16 tj + li], summed over this lane's rows
   double a_row[NU], nd[NU];
@@ -402,9 +420,16 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
     }
   };
   int sA = 0; // next op of list A
+  if (WIDE) { // no registers to spare for operands fetched ahead of their use: the flush goes first,
+              // the rows of Rhat and B are loaded right where they are consumed
+#pragma unroll
+    for (int i = 0; i < nA_flush; ++i)
+      slotA(i);
+    sA = nA_flush;
+  }
 #pragma unroll
   for (int tj = TW - 1; tj >= 0; --tj) {
-    const bool pinned = (tj < cR); // compile-time
+    const bool pinned = !WIDE && (tj < cR); // compile-time
     double4_t Pt[TX];
     double p4 = 0.0;
 #pragma unroll
@@ -415,7 +440,9 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
       const double bq = S.fo(tj, s);
 #pragma unroll
       for (int tm = 0; tm < TXF; ++tm) {
-        Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vop[tm][s], bq, Pt[tm], 0, 0, 0);
+        const int icv = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
+        const double aq = PRELOAD_V ? Vop[PRELOAD_V ? tm : 0][PRELOAD_V ? s : 0] : V[icv * PK + 4 * s + lk];
+        Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, Pt[tm], 0, 0, 0);
         if (pinned) {
           GAR_SB;
           if (sA < nA)
@@ -424,7 +451,7 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
         }
       }
       if (C::REM4)
-        p4 = __builtin_amdgcn_mfma_f64_4x4x4f64(Vop4[s], bq, p4, 0, 0, 0);
+        p4 = __builtin_amdgcn_mfma_f64_4x4x4f64(Vop4[PRELOAD_V ? s : 0], bq, p4, 0, 0, 0);
     }
 #pragma unroll
     for (int ti = tj; ti < TW; ++ti) {
@@ -474,7 +501,7 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
     GAR_SB;
 #pragma unroll
   for (int i = 0; i < nA; ++i) // what did not find a shadow (all of it for the shapes with cR = 0)
-    if (i >= sA)
+    if (i >= sA && !(WIDE && i >= nA_flush + nA_rows))
       slotA(i);
   GAR_WMARK(2)
   // ---- register LDL^T of Rhat under the first Bunch-Kaufman test; -L and -1/d to LDS -------------
@@ -500,11 +527,15 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   double hq;
   const double fi = S.fi;
   {
-    static_assert(TW <= 4, "one destination row of lanes per tile column");
     const double sel = rows_reduce_scatter(part[0], TW > 1 ? part[TW > 1 ? 1 : 0] : 0.0,
                                            TW > 2 ? part[TW > 2 ? 2 : 0] : 0.0, TW > 3 ? part[TW > 3 ? 3 : 0] : 0.0, lane);
     hq = S.qri + sel;
-    if (lane >= NX && lane < NW)
+    if (WIDE) { // entries 64 + li (tile column 4): summed over the four rows of lanes, in every lane
+      const double hq1 = qri1 + rows_sum(part[TW > 4 ? 4 : 0], lane);
+      if (lane < NW - 64)
+        G[(64 + lane - NX) * PG] = hq1;
+    }
+    if (lane >= NX && lane < (NW < 64 ? NW : 64))
       G[(lane - NX) * PG] = hq; // rhat
   }
   wave_lds_order();
@@ -587,6 +618,11 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   }
   wave_lds_order();
   GAR_WMARK(6)
+  if (WIDE) {
+#pragma unroll
+    for (int i = nA_flush + nA_rows; i < nA; ++i)
+      slotA(i); // B as the A operand of Aff, and of yff = f + B kff
+  }
   // ---- kff; yff = f + B kff (:266); vx = qhat + Shat kff (:275-276) ----------------
   {
     double kf[KU]; // kff[4s'+lk]
@@ -633,8 +669,12 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   constexpr int nKst = TX * KU;
   auto store_K = [&](int q) {
     const int tj = q / KU, sq = q % KU;
-    if (16 * tj + 15 < NX || 16 * tj + li < NX)
-      stg_b(out, M::fFB + 8 * tj * 2 * NR + 8 * sq, L.fbl, Kb[tj < TX ? tj : 0][sq]);
+    if (16 * tj + 15 < NX || 16 * tj + li < NX) {
+      if (WIDE)
+        stg_b(out, M::fFB + 4 * sq * NX + 16 * tj, fbrm, Kb[tj < TX ? tj : 0][sq]);
+      else
+        stg_b(out, M::fFB + 8 * tj * 2 * NR + 8 * sq, L.fbl, Kb[tj < TX ? tj : 0][sq]);
+    }
   };
   // column tj of Aff -> fb rows NK.. (fbT2), then F's column tile tj of knot t-1 into the same registers
   constexpr int nRow4 = (NX + 3) / 4; // (ti, r) pairs with 16 ti + 4 r < NX
@@ -643,9 +683,13 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
     if (q < nRow4) {
       const int ti = q >> 2, r = q & 3;
       const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
-      if (i < NX && j < NX)
-        stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NK + 16 * ti + 4 * r), L.fbl,
-              ti < C::KSF ? S.Fo[tj][ti < C::KSF ? ti : 0][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r]));
+      if (i < NX && j < NX) {
+        const double v = ti < C::KSF ? S.Fo[tj][ti < C::KSF ? ti : 0][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r]);
+        if (WIDE)
+          stg_b(out, M::fFB + (NK + 16 * ti + 4 * r) * NX + 16 * tj, fbrm, v);
+        else
+          stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NK + 16 * ti + 4 * r), L.fbl, v);
+      }
     } else if (q < nCol) {
       const int sq = q - nRow4; // k-step of F's column tile tj
       const double v = WaveLane<NX, NU>::fo_in(tj) ? ldg_b(recn, 16 * tj * NX + 4 * sq, L.fo0)

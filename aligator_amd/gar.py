@@ -62,7 +62,7 @@ class _Kkt0View:
 
 
 # (nx, nu) shapes with specialised kernels (csrc/gar_hip.cpp: bind_mfma / bind_leg)
-SPECIALISED_SHAPES = {(36, 12), (32, 12), (16, 8), (12, 8), (12, 4), (8, 4)}
+SPECIALISED_SHAPES = {(36, 12), (32, 12), (16, 8), (12, 8), (12, 4), (8, 4), (56, 24)}
 
 
 def _padded_dims(dims: np.ndarray):

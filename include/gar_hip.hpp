@@ -220,7 +220,7 @@ inline PaddedDims padded_dims(const LqrProblem &p) {
     if (k.nx != nx || k.nx2 != nx || k.nc != 0 || k.nth != 0 || k.nu != (t < N ? nu : 0u))
       return {};
   }
-  const uint shapes[][2] = {{36, 12}, {32, 12}, {16, 8}, {12, 8}, {12, 4}, {8, 4}};
+  const uint shapes[][2] = {{36, 12}, {32, 12}, {16, 8}, {12, 8}, {12, 4}, {8, 4}, {56, 24}};
   PaddedDims best;
   uint best_cost = ~0u;
   for (auto &sh : shapes) {

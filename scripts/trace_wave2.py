@@ -7,10 +7,18 @@ from aligator_amd import synth_device
 from aligator_amd.gar import BatchedRiccatiSolver
 TRACE_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aligator_amd", "libgar_hip_trace.so")  # make -C aligator_amd/csrc trace
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-nx, nu, N = 36, 12, 256
+nx, nu = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (36, 12)
+N = 256 if nx <= 36 else 64
 dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
 s = BatchedRiccatiSolver(dims, nx, batch=B, lib_path=TRACE_LIB)
-synth_device.fill_problems(s, seed=1, mode="W")
+if nx <= 36:
+    synth_device.fill_problems(s, seed=1, mode="W")
+else:
+    from aligator_amd import synth
+    import numpy as np
+    pk = s.pack(synth.generate_lq_problem(3, np.ones(nx), N, nx, nu, mode="W"))
+    for b in range(B):
+        s.upload_packed(pk, b, 1)
 s.backward(1e-14)
 out = (C.c_longlong * 64)()
 s._L.gar_hip_debug_trace(s.handle, 1, None)

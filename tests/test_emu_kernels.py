@@ -471,3 +471,15 @@ def test_cycle_append_is_a_ring(nx, nu, family, dense):
     s = pc.check_cycle_append_ring(EMU, nx=nx, nu=nu, family=family, dense=dense)
     if family:
         assert s.kernel_name.startswith("wave<" if family == "wave" else "mfma<")
+
+
+def test_wide_shape_wave_kernel():
+    """The Talos-walk LQ shape (bench/talos-walk.cpp:20-28: nx = 56, nu = 22 -> controls padded to 24) on the
+    one-wave-per-problem kernel: five tile columns, [qhat; rhat] in two registers, Rhat 24 x 24 factorised with
+    v_readlane broadcasts, fb row-major (generic forward sweep)."""
+    prob = synth.generate_lq_problem(560, np.ones(56), 3, 56, 22, mode="W")
+    solver, _, _ = pc.check_serial(prob, 1e-10, 1e-9, EMU, kkt_tol=1e-9)
+    assert solver.kernel_name == "wave<56,24>"
+    probf = synth.generate_lq_problem(561, np.zeros(56), 2, 56, 24, mode="F")
+    solver, _, _ = pc.check_serial(probf, 1e-10, 1e-6, EMU)
+    assert solver.kernel_name == "wave<56,24>"

@@ -533,8 +533,15 @@ def test_config4_talos_lq_shape():
     prob = _lq_from_blocks(A, B, np.full(nx, 0.1), wx, 1e-2 * np.eye(nu), np.zeros(nx), np.zeros(nu), wx,
                            rng.uniform(-1, 1, nx), horz)
     solver, _, _ = pc.check_serial(prob, 1e-10, 1e-8, kkt_tol=1e-8)
-    assert solver.kernel_name == "generic"
-    # leg mode adds the parameter blocks (nth = 56): 318 KB of LDS in the generic kernels -- refused
+    # round 2: off the generic kernels -- the controls are padded to 24 and the backward sweep runs on the
+    # one-wave-per-problem kernel (five tile columns; forward and initial stage: generic kernels)
+    assert solver.kernel_name == "wave<56,24>"
+    # the reference's own generators on this shape, a batch > #CUs, every factor block
+    for mode, tol in (("W", 1e-9), ("F", 1e-6)):
+        p2 = synth.generate_lq_problem(5600, np.ones(nx), 40, nx, nu, mode=mode)
+        s2, _, _ = pc.check_serial(p2, 1e-12, tol, kkt_tol=1e-6 if mode == "F" else 1e-9)
+        assert s2.kernel_name == "wave<56,24>"
+    # leg mode adds the parameter blocks (nth = 56): 318 KB of LDS in the generic leg kernels -- still refused
     # loudly (GAR_HIP_ERR_UNSUPPORTED), not silently run elsewhere
     from aligator_amd.gar import ParallelRiccatiSolver
     with pytest.raises(RuntimeError, match="LDS"):
