@@ -20,6 +20,7 @@
 #include "gar_mfma.hpp"
 #include "gar_wave.hpp"
 #include "gar_wave_leg.hpp"
+#include "gar_wave_pair.hpp"
 #include "gar_cyclic.hpp"
 #include "gar_dense.hpp"
 
@@ -148,6 +149,7 @@ struct gar_hip_solver {
   // one-wave-per-problem backward kernel (gar_wave.hpp), preferred when bound
   void (*wave_kernel)(gar::MfmaParams, int) = nullptr;
   int wave_lds_doubles = 0, waves_per_block = 1;
+  int wave_block_threads = 64; // 128: two waves per problem (gar_wave_pair.hpp)
   bool fb_t2 = false;      // factor records keep fb / fth in the fbT2 device order (gar_mfma.hpp)
   std::string lds_error;   // the generic kernels do not fit a CU's LDS (fatal unless a specialised family serves the shape)
   bool wave_fused_init = false;
@@ -431,12 +433,22 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
 // backward sweep only (gar_wave2.hpp; fb ROW-major = the generic record layout), the initial stage
 // and the forward sweep on the generic kernels.
 template <int NX, int NU> void bind_wide(gar_hip_solver *s) {
-  s->wave_kernel = gar::gar_backward_wave<NX, NU>;
+  // two waves per problem (the tile columns split between them) unless GAR_HIP_WIDE=single
+  const char *w = std::getenv("GAR_HIP_WIDE");
+  const bool pair = !(w && std::string(w) == "single");
   s->wave_fused_init = false;
-  s->wave_lds_doubles = gar::WaveCfg<NX, NU>::total;
   s->waves_per_block = 1;
   s->fb_t2 = false;
-  s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+  if (pair) {
+    s->wave_kernel = gar::gar_backward_pair<NX, NU>;
+    s->wave_lds_doubles = gar::PairCfg<NX, NU>::total;
+    s->wave_block_threads = 128;
+    s->kernel_name = "pair<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+  } else {
+    s->wave_kernel = gar::gar_backward_wave<NX, NU>;
+    s->wave_lds_doubles = gar::WaveCfg<NX, NU>::total;
+    s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+  }
 }
 
 template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
@@ -525,6 +537,7 @@ void select_kernel(gar_hip_solver *s) {
   s->mfma_fwd_kernel = nullptr;
   s->wave_kernel = nullptr;
   s->wave_fused_init = false;
+  s->wave_block_threads = 64;
   s->fb_t2 = false;
   {
     const char *ik = std::getenv("GAR_HIP_INIT");
@@ -787,7 +800,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     if (s->wave_kernel) {
       const int wpb = s->waves_per_block;
       hipLaunchKernelGGL(s->wave_kernel, dim3((unsigned)((s->batch + wpb - 1) / wpb)),
-                         dim3(64 * wpb), (size_t)s->wave_lds_doubles * wpb * sizeof(double),
+                         dim3(s->wave_block_threads * wpb), (size_t)s->wave_lds_doubles * wpb * sizeof(double),
                          s->stream, M, s->batch);
     } else {
       hipLaunchKernelGGL(s->mfma_kernel, dim3((unsigned)s->batch), dim3(256),

@@ -75,7 +75,7 @@ template <int NX, int NU, int NC = 0> struct WaveCfg {
   static constexpr int oLc = oLr;                 // (the transposed solve reads L strided)
   static constexpr int oDi = oLr + NU * NU;       // -1/d_k
   static constexpr int oBk = (oDi + NU + 1) & ~1; // Bunch-Kaufman: sub(BKS) | piv, ctrl (BKS ints each)
-  static constexpr int BKS = NC > 0 ? ((NK + 15) & ~15) : 16;
+  static constexpr int BKS = (NK + 15) & ~15; // (16 for the unconstrained shapes with NU <= 16)
   static constexpr int oDump = (oBk + 2 * BKS + 1) & ~1; // 2 doubles: target of masked-out LDS writes
   static constexpr int oFlag = oDump + 2;           // MODE 3: verdict of the factorisation (as a double)
   static constexpr int total = oDump + 4;
@@ -446,10 +446,10 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
       for (int e = lane; e < NU * PG; e += 64)
         Gt[e] = -Gt[e];
     double *sub = sm + C::oBk;
-    int *piv = (int *)(sub + 16);
+    int *piv = (int *)(sub + C::BKS);
     const WG w1 = wave_self();
     wave_sync();
-    failed |= wg_bk_factor(w1, NU, Mm, NU, sub, piv, piv + 16);
+    failed |= wg_bk_factor(w1, NU, Mm, NU, sub, piv, piv + C::BKS);
     wg_bk_solve(w1, NU, Mm, NU, sub, piv, G2, PG, 1, NX + 1);
     if (PARAM)
       wg_bk_solve(w1, NU, Mm, NU, sub, piv, Gt, PG, 1, NX);

@@ -1,0 +1,431 @@
+// gar_wave_pair.hpp -- TWO WAVES PER PROBLEM: the backward sweep for the wide shapes (nx + nu > 64;
+// the Talos-walk LQ shape nx = 56, nu = 22 -> 24, bench/talos-walk.cpp:20-28, bench/lqr.cpp:25-26).
+//
+// Same arithmetic as ProximalRiccatiKernel::stageKernelSolve (gar/riccati-kernel.hxx:209-277) and the
+// same building blocks as the one-wave stage (gar_wave2.hpp: F in MFMA operand layout, P = V'F feeding
+// H = W + F^T P from its D registers, [qhat; rhat] = [q; r] + F^T vx' + P^T f, register LDL^T of Rhat
+// under the complete Bunch-Kaufman rule, triangular solves on v_mfma_f64_4x4x4, Aff in place on the F
+// registers).  What a single wave cannot do at this size is HOLD the stage: F is 70 doubles per lane,
+// the 15 lower tiles of H another 60, and the register file's split into 256 VALU-addressable and 256
+// accumulator registers overflows (wave<56,24>: 1.9 KB of scratch per lane, 4.7x the useful HBM
+// traffic in spills, 230 k cycles per stage for 46 k of MFMA).  So the tile COLUMNS are split:
+//   wave 0: tile columns 0 .. SPLIT-1      wave 1: tile columns SPLIT .. TW-1   (SPLIT = TW/2)
+// For (56, 24): wave 0 holds all of F and 9 tiles of H (238 MFMAs in the first half), wave 1 holds F's
+// tile columns 2..4 and 6 tiles (252 MFMAs) -- and Rhat, whose tiles all lie in wave 1's columns, so
+// wave 1 factorises.  Every later step is column-local: a wave solves K = -Rhat^{-1} Shat^T for ITS
+// state columns (the solve is column-independent; rhat rides in wave 1's spare lane column), forms Aff
+// and the Vxx tiles of its columns, stores its part of the record.  What crosses between the waves
+// goes through LDS: V' (shared operand), L and 1/d, Shat^T (the A operand of the other wave's Vxx
+// tiles), [qhat; rhat], kff, vx.  Four workgroup barriers per stage.
+// fb is written ROW-major (the generic record layout): the initial stage and the forward sweep of
+// these shapes are the generic kernels.
+#pragma once
+#include "gar_wave2.hpp"
+
+namespace gar {
+
+template <int NX, int NU> struct PairCfg {
+  using C = WaveCfg<NX, NU, 0>;
+  static constexpr int SPLIT = C::TW / 2;
+  static constexpr int oHq = (C::total + 1) & ~1;          // [qhat; rhat], one entry per index
+  static constexpr int oFlag2 = oHq + ((C::NW + 1) & ~1);  // verdict of the factorisation (int)
+  static constexpr int total = oFlag2 + 2;
+  __host__ __device__ static constexpr int owner(int tj) { return tj >= SPLIT ? 1 : 0; }
+};
+
+// knot t's operands for wave W: F tile columns it multiplies with (all of them for wave 0: H(ti, tj)
+// needs F(:, ti) for every ti >= tj), the Hessian tiles of its own tile columns
+template <int NX, int NU, int W, class LANE>
+__device__ __forceinline__ void pair_load(const double *rec, const LANE &L, WaveStage<NX, NU> &S) {
+  using C = WaveCfg<NX, NU>;
+  using PC = PairCfg<NX, NU>;
+#pragma unroll
+  for (int t = 0; t < C::TW; ++t) {
+    if (W == 1 && t < PC::SPLIT)
+      continue;
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+      const double v = WaveLane<NX, NU>::fo_in(t) ? ldg_b(rec, 16 * t * NX + 4 * s, L.fo0) : ldg_b(rec, 4 * s, L.foX);
+      if (s < 4 * C::KSF)
+        S.Fo[t][s >> 2][s & 3] = v;
+      else
+        S.FoT[t][s - 4 * C::KSF] = v;
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < C::TW; ++ti)
+#pragma unroll
+    for (int tj = 0; tj <= ti; ++tj) {
+      if (PC::owner(tj) != W)
+        continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row0 = 16 * ti + 4 * r; // + lk
+        if (row0 + 3 < NX)
+          S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, 16 * tj * NX + row0, L.hcx0) : ldg_b(rec, row0, L.hcxX[tj]);
+        else if (row0 >= NX && row0 + 3 < C::NW)
+          S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, (row0 - NX) * NX + 16 * tj, L.hcu0)
+                                                       : ldg_b(rec, 0, L.hcuX[tj][(row0 - NX) >> 2]);
+        else
+          S.Hc[ti][tj][r] = 0.0;
+      }
+    }
+}
+
+template <int NX, int NU, int W>
+__device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, const double *prob, double *fac,
+                                           int t, int lane, const WaveLane<NX, NU, 0> &L,
+                                           WaveStage<NX, NU> &S, int &failed) {
+  using C = WaveCfg<NX, NU, 0>;
+  using M = MfmaCfg<NX, NU, 0>;
+  using PC = PairCfg<NX, NU>;
+  constexpr int NK = C::NK, NW = C::NW, PK = C::PK, PG = C::PG, TX = C::TX, TW = C::TW, KS = C::KS, KU = C::KU;
+  constexpr int SPLIT = PC::SPLIT, cR = NX >> 4;
+  static_assert(!C::REM4 && cR >= SPLIT && (NX % 16) != 0, "Rhat and the spare column belong to wave 1");
+  const int li = lane & 15, lk = lane >> 4;
+  const unsigned fbrm = 8u * (unsigned)(lk * NX + li); // row-major fb: element (lk, li)
+  const unsigned lib = 8u * (unsigned)li;
+  double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM, *vn = sm + C::oVn;
+  double *Lr = sm + C::oLr, *ndi = sm + C::oDi, *hqv = sm + PC::oHq;
+  int *flag = reinterpret_cast<int *>(sm + PC::oFlag2);
+  constexpr int oVxx = M::fVxx, ovx = M::fvx;
+  double *out = fac + P.slot(t) * P.fac_rec;
+  const double *rec = prob + P.in_off0 + P.slot(t) * P.in_rec;
+  const double *recn = prob + P.in_off0 + P.slot(t > 0 ? t - 1 : 0) * P.in_rec;
+  // ---- first half: P = V'F and H = W + F^T P for this wave's tile columns -----------------------
+  double vxs[KS], fs[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    vxs[s] = vn[4 * s + lk];
+  {
+    const unsigned lkb = 8u * (unsigned)lk;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      fs[s] = ldg_b(rec, M::kf + 4 * s, lkb);
+  }
+  double part[TW];
+#pragma unroll
+  for (int tj = TW - 1; tj >= 0; --tj) {
+    if (PC::owner(tj) != W)
+      continue;
+    double4_t Pt[TX];
+#pragma unroll
+    for (int tm = 0; tm < TX; ++tm)
+      Pt[tm] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const double bq = S.fo(tj, s);
+#pragma unroll
+      for (int tm = 0; tm < TX; ++tm) {
+        const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
+        Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[ic * PK + 4 * s + lk], bq, Pt[tm], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ti = tj; ti < TW; ++ti)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        S.Hc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.fo(ti, s), Pt[s >> 2][s & 3], S.Hc[ti][tj], 0, 0, 0);
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      a0 = __builtin_fma(S.fo(tj, s), vxs[s], a0);
+      a1 = __builtin_fma(Pt[s >> 2][s & 3], fs[s], a1);
+    }
+    part[tj] = a0 + a1;
+  }
+  // ---- [qhat; rhat] entries of this wave's columns (:217-218, :227-228), Shat^T, Rhat -> LDS -------
+#pragma unroll
+  for (int tj = 0; tj < TW; ++tj) {
+    if (PC::owner(tj) != W)
+      continue;
+    const int j = 16 * tj + li;
+    const double qr = ldg_b(rec, M::kq + (16 * tj + 15 < NW ? 16 * tj : 0), 16 * tj + 15 < NW ? lib : 8u * (unsigned)(j < NW ? j : NW - 1));
+    const double e = qr + rows_sum(part[tj], lane);
+    if (lk == 0 && j < NW) {
+      hqv[j] = e;
+      if (j >= NX)
+        G[(j - NX) * PG] = e; // rhat: right-hand side of kff (:248), sign applied in the solve
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < TW; ++ti)
+#pragma unroll
+    for (int tj = 0; tj <= ti; ++tj) {
+      if (PC::owner(tj) != W)
+        continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + lk + 4 * r, c = 16 * tj + li;
+        if (16 * ti + 4 * r >= NX && 16 * ti + 4 * r < NW) { // compile-time: control rows
+          if (c < NX)
+            G[(row - NX) * PG + 1 + c] = S.Hc[ti][tj][r]; // Shat^T(u, c)
+          else if (c <= row)
+            Mm[(c - NX) * NK + (row - NX)] = S.Hc[ti][tj][r]; // Rhat (lower), wave 1 only
+        }
+      }
+    }
+  __syncthreads(); // (1) [qhat; rhat], Shat^T, Rhat in LDS
+  // ---- wave 1: register LDL^T of Rhat under the complete Bunch-Kaufman rule; -L, -1/d -> LDS -------
+  if (W == 1) {
+    double a_row[NU], nd[NU];
+    const int frow = lane < NU ? lane : NU - 1;
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+      a_row[j] = Mm[j * NU + frow];
+    bool first_failed;
+    const int verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed);
+    if (lane < NU) {
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+        Lr[lane * NU + j] = a_row[j];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+        ndi[j] = nd[j];
+      flag[0] = verdict;
+      if (first_failed) {
+        atomicAdd(&P.slow[0], 1);
+        if (verdict != 0)
+          atomicAdd(&P.slow[1], 1);
+      }
+    }
+    if (verdict != 0) {
+      // Bunch-Kaufman interchanges or takes a 2x2 pivot here: the generic device Bunch-Kaufman, exactly
+      // what the reference does, by this wave alone; [kff | K] goes to the V buffer (V' is dead until
+      // this stage's Vxx is written), Shat^T stays in G for the Vxx products
+      wave_sync();
+      double *Kv = V;
+      for (int e = lane; e < NU * PG; e += 64)
+        Kv[e] = -G[e];
+      double *sub = sm + C::oBk;
+      int *piv = (int *)(sub + C::BKS);
+      const WG w1 = wave_self();
+      wave_sync();
+      failed |= wg_bk_factor(w1, NU, Mm, NU, sub, piv, piv + C::BKS);
+      wg_bk_solve(w1, NU, Mm, NU, sub, piv, Kv, PG, 1, NX + 1);
+      wave_sync();
+    }
+  }
+  __syncthreads(); // (2) the factorisation (or [kff | K] itself) is in LDS
+  const int verdict = flag[0];
+  // ---- [kff | K] = -Rhat^{-1} [rhat | Shat^T] (:248-262) for this wave's state columns ------------
+  double Kb[TX][KU];
+  constexpr int lc = NX % 16;
+  if (verdict == 0) {
+    double An[KU][KU], At[KU][KU], ndv[KU];
+    const int i3 = li & 3;
+#pragma unroll
+    for (int p = 0; p < KU; ++p) {
+#pragma unroll
+      for (int q = 0; q <= p; ++q) {
+        const double vn_ = Lr[(4 * p + i3) * NU + 4 * q + lk];
+        const double vt_ = Lr[(4 * p + lk) * NU + 4 * q + i3];
+        An[p][q] = (p == q && !(i3 > lk)) ? 0.0 : vn_;
+        At[p][q] = (p == q && !(lk > i3)) ? 0.0 : vt_;
+      }
+      ndv[p] = ndi[4 * p + lk];
+    }
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+      if (PC::owner(tj) != W)
+        continue;
+#pragma unroll
+      for (int sp = 0; sp < KU; ++sp) {
+        const double sv = S.Hc[C::shTile(sp)][tj][C::shReg(sp)]; // Shat^T(4sp+lk, 16tj+li)
+        Kb[tj][sp] = (tj == TX - 1 && li == lc) ? G[(4 * sp + lk) * PG] : sv;
+      }
+      ldl_solve_mfma4<KU>(An, At, ndv, Kb[tj]);
+    }
+    if (W == 1) {
+#pragma unroll
+      for (int sp = 0; sp < KU; ++sp)
+        if (li == lc)
+          G[(4 * sp + lk) * PG] = Kb[TX - 1][sp]; // kff
+    }
+  } else {
+    const double *Kv = V;
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+      if (PC::owner(tj) != W)
+        continue;
+      const int cc = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
+#pragma unroll
+      for (int s = 0; s < KU; ++s)
+        Kb[tj][s] = Kv[(4 * s + lk) * PG + 1 + cc];
+    }
+    if (W == 1 && lane < NU)
+      G[lane * PG] = Kv[lane * PG]; // kff
+  }
+  __syncthreads(); // (3) kff in G(:, 0); every read of [kff | K] from the V buffer is done
+  // ---- K -> fb rows 0..NU-1 (row-major); kff; yff = f + B kff (:266); vx = qhat + Shat kff (:275-276)
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj) {
+    if (PC::owner(tj) != W)
+      continue;
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      if (16 * tj + 15 < NX || 16 * tj + li < NX)
+        stg_b(out, M::fFB + 4 * s * NX + 16 * tj, fbrm, Kb[tj][s]);
+  }
+  double Bop[TX][KU]; // B[16ti+li][4s'+lk]: the A operand of Aff
+#pragma unroll
+  for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      Bop[ti][s] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * s * NX + 16 * ti, L.bop0) : ldg_b(rec, 4 * s * NX, L.bopX);
+  {
+    double kf[KU];
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      kf[s] = G[(4 * s + lk) * PG];
+    if (W == 1 && lane < NU)
+      out[M::fFF + lane] = G[lane * PG];
+#pragma unroll
+    for (int ti = 0; ti < TX; ++ti) {
+      if (PC::owner(ti) != W)
+        continue;
+      const int i = 16 * ti + li, ic = i < NX ? i : NX - 1;
+      double a = 0.0, c = 0.0;
+#pragma unroll
+      for (int s = 0; s < KU; ++s) {
+        a = __builtin_fma(Bop[ti][s], kf[s], a);
+        c = __builtin_fma(G[(4 * s + lk) * PG + 1 + ic], kf[s], c); // Shat(i, 4s+lk)
+      }
+      const double yf = ldg_b(rec, M::kf, 8u * (unsigned)ic) + rows_sum(a, lane);
+      const double vxv = hqv[ic] + rows_sum(c, lane);
+      if (lk == 0 && i < NX) {
+        out[M::fFF + NK + i] = yf;
+        out[ovx + i] = vxv;
+        vn[i] = vxv;
+      }
+    }
+  }
+  // ---- Aff = A + B K (:267), in place on the F operand registers, this wave's state columns ---------
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj) {
+    if (PC::owner(tj) != W)
+      continue;
+    double4_t accT = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      accT[r] = (r < C::KST) ? S.FoT[tj][r < C::KST ? r : 0] : 0.0;
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+#pragma unroll
+      for (int ti = 0; ti < TX; ++ti) {
+        if (ti < C::KSF)
+          S.Fo[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], S.Fo[tj][ti], 0, 0, 0);
+        else
+          accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], accT, 0, 0, 0);
+      }
+#pragma unroll
+    for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
+        if (16 * ti + 4 * r < NX) {
+          if (i < NX && j < NX)
+            stg_b(out, M::fFB + (NK + 16 * ti + 4 * r) * NX + 16 * tj, fbrm, ti < C::KSF ? S.Fo[tj][ti < C::KSF ? ti : 0][r] : accT[r]);
+        }
+      }
+  }
+  // ---- Vxx = Qhat + Shat K (:272-273), lower tiles of this wave's columns, mirrored into LDS ----------
+  // (V' was last read before barrier (1); Shat comes from G: the other wave's columns too)
+#pragma unroll
+  for (int tj = 0; tj < TX; ++tj) {
+    if (PC::owner(tj) != W)
+      continue;
+#pragma unroll
+    for (int ti = tj; ti < TX; ++ti) {
+      double4_t acc = S.Hc[ti][tj];
+      const int ic = (16 * ti + li) < NX ? (16 * ti + li) : NX - 1;
+#pragma unroll
+      for (int s = 0; s < KU; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(G[(4 * s + lk) * PG + 1 + ic], Kb[tj][s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + lk + 4 * r, c = 16 * tj + li;
+        if (16 * ti + 4 * r < NX) {
+          const bool ok = (i < NX && c < NX && i >= c);
+          if (ti > tj && 16 * ti + 4 * r + 3 < NX && 16 * tj + 15 < NX) {
+            V[i * PK + c] = acc[r];
+            V[c * PK + i] = acc[r];
+          } else {
+            V[ok ? i * PK + c : C::oDump + W] = acc[r];
+            V[ok ? c * PK + i : C::oDump + 2 + W] = acc[r];
+          }
+        }
+      }
+    }
+  }
+  // knot t-1 into the registers this stage released
+  pair_load<NX, NU, W>(recn, L, S);
+  __syncthreads(); // (4) V, vx complete
+  // ---- Vxx -> HBM (column-major, symmetric), 16 B per lane, the chunks alternate between the waves ----
+  {
+    constexpr int NCH = (NX * NX / 2 + 63) / 64;
+#pragma unroll
+    for (int q = W; q < NCH; q += 2) {
+      const int e = 64 * q + lane;
+      const int ec = (64 * q + 63 < NX * NX / 2) ? e : (e < NX * NX / 2 ? e : NX * NX / 2 - 1);
+      const double2_t v = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
+      if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
+        *reinterpret_cast<double2_t *>(&out[oVxx + 2 * e]) = v;
+    }
+  }
+}
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(128, 1) gar_backward_pair(MfmaParams P, int batch) {
+  using C = WaveCfg<NX, NU, 0>;
+  using M = MfmaCfg<NX, NU, 0>;
+  constexpr int PK = C::PK;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = (int)blockIdx.x;
+  if (b >= batch)
+    return;
+  double *sm = gar_smem;
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  double *fac = P.fac + (long long)b * P.fac_stride;
+  const int N = P.horizon;
+  double *V = sm + C::oV, *vn = sm + C::oVn;
+  WaveLane<NX, NU, 0> L;
+  wave_lane_init<NX, NU>(L, lane);
+  const double *recN1 = prob + P.in_off0 + P.slot(N - 1) * P.in_rec;
+  { // terminal knot (terminalSolve, nu = 0, :146-149, :175-178): Vxx = Q, vx = q
+    const double *rec = prob + P.in_offN;
+    double *out = fac + P.fac_offN;
+    for (int e = tid; e < NX * NX; e += 128) {
+      const int j = e / NX, i = e - j * NX;
+      const double v = (i >= j) ? rec[M::tQ + e] : rec[M::tQ + i * NX + j];
+      V[i * PK + j] = v;
+      out[M::tVxx + e] = v;
+    }
+    if (tid < NX) {
+      const double v = rec[M::tq + tid];
+      vn[tid] = v;
+      out[M::tvx + tid] = v;
+    }
+  }
+  __syncthreads();
+  int failed = 0;
+  // one loop per wave: each keeps only ITS tiles in registers across the stages (a common loop would
+  // carry the union of both waves' state through either path)
+  if (wave == 0) {
+    WaveStage<NX, NU> S;
+    pair_load<NX, NU, 0>(recN1, L, S);
+    for (int t = N - 1; t >= 0; --t)
+      pair_stage<NX, NU, 0>(P, sm, prob, fac, t, lane, L, S, failed);
+  } else {
+    WaveStage<NX, NU> S;
+    pair_load<NX, NU, 1>(recN1, L, S);
+    for (int t = N - 1; t >= 0; --t)
+      pair_stage<NX, NU, 1>(P, sm, prob, fac, t, lane, L, S, failed);
+  }
+  if (failed && lane == 0)
+    atomicOr(&P.status[b], failed);
+}
+
+} // namespace gar

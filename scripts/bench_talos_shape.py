@@ -13,10 +13,11 @@ fac = (nu + nx) * nx + (nu + nx) + nx * nx + nx
 dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
 probs = [synth.generate_lq_problem(900 + i, np.ones(nx), N, nx, nu, mode="W") for i in range(4)]
 for batch in [int(a) for a in sys.argv[1:]] or [256, 768, 1536]:
-    for force in ("0", "1"):
+    for force, wide in (("0", "pair"), ("0", "single"), ("1", "pair")):
         if force == "1" and batch > 256:
             continue
         os.environ["GAR_HIP_FORCE_GENERIC"] = force
+        os.environ["GAR_HIP_WIDE"] = wide
         os.environ["GAR_HIP_PAD"] = "1" if force == "0" else "0"
         s = BatchedRiccatiSolver(dims, nx, batch=batch)
         packed = np.concatenate([s.pack(p) for p in probs])

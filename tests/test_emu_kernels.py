@@ -473,13 +473,34 @@ def test_cycle_append_is_a_ring(nx, nu, family, dense):
         assert s.kernel_name.startswith("wave<" if family == "wave" else "mfma<")
 
 
-def test_wide_shape_wave_kernel():
-    """The Talos-walk LQ shape (bench/talos-walk.cpp:20-28: nx = 56, nu = 22 -> controls padded to 24) on the
-    one-wave-per-problem kernel: five tile columns, [qhat; rhat] in two registers, Rhat 24 x 24 factorised with
-    v_readlane broadcasts, fb row-major (generic forward sweep)."""
+@pytest.mark.parametrize("variant,name", [("pair", "pair<56,24>"), ("single", "wave<56,24>")])
+def test_wide_shape_kernels(monkeypatch, variant, name):
+    """The Talos-walk LQ shape (bench/talos-walk.cpp:20-28: nx = 56, nu = 22 -> controls padded to 24): two
+    waves per problem (gar_wave_pair.hpp, the default) and the one-wave stage generalised to five tile
+    columns (GAR_HIP_WIDE=single); fb row-major, generic initial stage and forward sweep.  Generators W and
+    F, a stage that makes Bunch-Kaufman pivot (generic device Bunch-Kaufman on the 24 x 24 Rhat), a failure."""
+    from aligator_amd.gar import ProximalRiccatiSolver
+    monkeypatch.setenv("GAR_HIP_WIDE", variant)
     prob = synth.generate_lq_problem(560, np.ones(56), 3, 56, 22, mode="W")
     solver, _, _ = pc.check_serial(prob, 1e-10, 1e-9, EMU, kkt_tol=1e-9)
-    assert solver.kernel_name == "wave<56,24>"
+    assert solver.kernel_name == name
     probf = synth.generate_lq_problem(561, np.zeros(56), 2, 56, 24, mode="F")
     solver, _, _ = pc.check_serial(probf, 1e-10, 1e-6, EMU)
-    assert solver.kernel_name == "wave<56,24>"
+    assert solver.kernel_name == name
+    piv = synth.generate_lq_problem(562, np.zeros(56), 2, 56, 24, mode="W")
+    for k in piv.stages[:-1]:
+        R = np.eye(24) * 3.0
+        R[0, 0] = R[1, 1] = 1e-3
+        R[0, 1] = R[1, 0] = 2.0
+        k.R[...] = R
+        k.S[...] = 0.0
+        k.B[...] *= 1e-2
+    solver, _, _ = pc.check_serial(piv, 1e-12, 1e-9, EMU)
+    assert solver._impl.slow_path_stages()[1] > 0
+    bad = synth.generate_lq_problem(563, np.zeros(56), 2, 56, 24, mode="W")
+    for k in bad.stages[:-1]:
+        k.R[...] = 0.0
+        k.S[...] = 0.0
+        k.B[...] = 0.0
+    with pytest.raises(RuntimeError, match="LDL"):
+        ProximalRiccatiSolver(bad, lib_path=EMU).backward(1e-10)

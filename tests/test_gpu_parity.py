@@ -535,12 +535,18 @@ def test_config4_talos_lq_shape():
     solver, _, _ = pc.check_serial(prob, 1e-10, 1e-8, kkt_tol=1e-8)
     # round 2: off the generic kernels -- the controls are padded to 24 and the backward sweep runs on the
     # one-wave-per-problem kernel (five tile columns; forward and initial stage: generic kernels)
-    assert solver.kernel_name == "wave<56,24>"
-    # the reference's own generators on this shape, a batch > #CUs, every factor block
-    for mode, tol in (("W", 1e-9), ("F", 1e-6)):
-        p2 = synth.generate_lq_problem(5600, np.ones(nx), 40, nx, nu, mode=mode)
-        s2, _, _ = pc.check_serial(p2, 1e-12, tol, kkt_tol=1e-6 if mode == "F" else 1e-9)
-        assert s2.kernel_name == "wave<56,24>"
+    assert solver.kernel_name == "pair<56,24>"
+    # the reference's own generators on this shape, every factor block; both kernels of the wide family
+    import os
+    for variant, name in (("pair", "pair<56,24>"), ("single", "wave<56,24>")):
+        os.environ["GAR_HIP_WIDE"] = variant
+        try:
+            for mode, tol in (("W", 1e-9), ("F", 1e-6)):
+                p2 = synth.generate_lq_problem(5600, np.ones(nx), 40, nx, nu, mode=mode)
+                s2, _, _ = pc.check_serial(p2, 1e-12, tol, kkt_tol=1e-6 if mode == "F" else 1e-9)
+                assert s2.kernel_name == name
+        finally:
+            del os.environ["GAR_HIP_WIDE"]
     # leg mode adds the parameter blocks (nth = 56): 318 KB of LDS in the generic leg kernels -- still refused
     # loudly (GAR_HIP_ERR_UNSUPPORTED), not silently run elsewhere
     from aligator_amd.gar import ParallelRiccatiSolver
