@@ -417,7 +417,19 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
   const bool want_wave = bw ? std::string(bw) != "wg4" : s->batch > cus;
-  if (want_wave) {
+  // GAR_HIP_BACKWARD=pair: two waves per problem, the tile columns split between them
+  // (gar_wave_pair.hpp; <= 256 registers per wave, so two waves share a SIMD)
+  constexpr bool can_pair = (NX % 16) != 0 && ((NX >> 4) >= (gar::WaveCfg<NX, NU>::TW / 2)) && (gar::WaveCfg<NX, NU>::TW / 2) >= 1;
+  if (bw && std::string(bw) == "pair" && can_pair) {
+    if constexpr (can_pair) {
+      s->wave_kernel = gar::gar_backward_pair<NX, NU>;
+      s->wave_fused_init = false;
+      s->wave_lds_doubles = gar::PairCfg<NX, NU>::total;
+      s->wave_block_threads = 128;
+      s->waves_per_block = 1;
+      s->kernel_name = "pair<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+    }
+  } else if (want_wave) {
     s->wave_kernel = gar::gar_backward_wave<NX, NU>;
     // the initial stage is fused into the sweep when its packed kkt0 fits beside V in a
     // quarter of the CU's LDS (four waves per CU)

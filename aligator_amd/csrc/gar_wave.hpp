@@ -1213,13 +1213,8 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   if (b >= batch)
     return;
   double *sm = gar_smem;
-#ifdef GAR_DIAG_SAMEREC // timing diagnostic: no HBM traffic (every wave works on problem 0, record 0)
-  const double *prob = P.prob;
-  double *fac = P.fac + (long long)b * P.fac_stride; // own problem's record 0: no write contention
-#else
   const double *prob = P.prob + (long long)b * P.prob_stride;
   double *fac = P.fac + (long long)b * P.fac_stride;
-#endif
   const int N = P.horizon;
   double *V = sm + C::oV, *vn = sm + C::oVn;
   // cycle stamps (scripts/trace_wave.py) only in the debug build (make trace, -DGAR_TRACE): the

@@ -76,38 +76,6 @@ __device__ __forceinline__ double row_bcast(double v, int n, int lane) {
   }
 }
 
-// wave_ldl_fast (gar_wave.hpp) leaving -L(i,j) in a[j] (j < i): the sign the block updates
-// X_p += (-L_pq) X_q want.  Product for product the same factorisation (a * (-d) == -(a * d)).
-// The rows live in the first 16-lane row of the wave (NU <= 16) and every broadcast is a DPP row
-// broadcast; the other three rows of lanes compute on copies of row NU-1 (never read: nd is taken
-// from lane 0, L from lanes < NU, the verdict from lanes k..NU-1).
-template <int NU>
-__device__ __forceinline__ int wave_ldl_fast_neg(const double *M, int lane, double (&a)[NU],
-                                                 double (&nd)[NU]) {
-  static_assert(NU <= 16, "lane = row inside one 16-lane DPP row");
-  const double alpha = (1.0 + 4.123105625617661) / 8.0;
-  const int row = lane < NU ? lane : NU - 1;
-#pragma unroll
-  for (int j = 0; j < NU; ++j)
-    a[j] = M[j * NU + row];
-  unsigned long long bad = 0ull;
-#pragma unroll
-  for (int k = 0; k < NU; ++k) {
-    const double akk = row_bcast(a[k], k, lane);
-    const unsigned long long nok = __ballot(!(fabs(akk) >= alpha * fabs(a[k])) || akk == 0.0);
-    const unsigned long long from_k = ((1ull << NU) - 1ull) & ~((1ull << k) - 1ull);
-    bad |= nok & from_k;
-    const double nd_k = -fast_rcp(akk);
-    const double nlik = a[k] * nd_k; // -L(i,k)
-#pragma unroll
-    for (int j = k + 1; j < NU; ++j)
-      a[j] = __builtin_fma(row_bcast(nlik, j, lane), a[k], a[j]); // a(i,j) -= L(j,k) a(i,k)
-    a[k] = nlik;
-    nd[k] = nd_k;
-  }
-  return bad != 0ull;
-}
-
 // X <- -(L D L^T)^{-1} X on the MFMA layout: X[p] holds rows 4p+lk of one 16-column tile.
 // An[p][q] / At[p][q] (p >= q): A operands of -L_pq and of its transpose (diagonal blocks:
 // strictly lower / strictly upper part only); ndv[p] = -1/d[4p+lk].
@@ -327,15 +295,9 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   double *V = sm + C::oV, *G = sm + C::oG, *Mm = sm + C::oM, *vn = sm + C::oVn;
   double *Lr = sm + C::oLr, *ndi = sm + C::oDi;
   constexpr int oVxx = M::fVxx, ovx = M::fvx;
-#ifdef GAR_DIAG_SAMEREC // timing diagnostic (wrong results): every stage reads / writes record 0
-  double *out = fac;
-  const double *rec = prob + P.in_off0;
-  const double *recn = rec;
-#else
   double *out = fac + P.slot(t) * P.fac_rec;
   const double *rec = prob + P.in_off0 + P.slot(t) * P.in_rec;
   const double *recn = prob + P.in_off0 + P.slot(t > 0 ? t - 1 : 0) * P.in_rec; // knot t-1 (t = 0: harmless re-read)
-#endif
 // cycle stamps of scripts/trace_wave2.py: only in the debug build (make trace), where every mark also
 // pins the schedule (sched_barrier) so that a phase's instructions stay inside its stamps
 #ifdef GAR_TRACE

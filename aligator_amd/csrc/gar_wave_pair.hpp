@@ -81,7 +81,11 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   using PC = PairCfg<NX, NU>;
   constexpr int NK = C::NK, NW = C::NW, PK = C::PK, PG = C::PG, TX = C::TX, TW = C::TW, KS = C::KS, KU = C::KU;
   constexpr int SPLIT = PC::SPLIT, cR = NX >> 4;
-  static_assert(!C::REM4 && cR >= SPLIT && (NX % 16) != 0, "Rhat and the spare column belong to wave 1");
+  // (Rhat and the spare lane column for rhat belong to wave 1; a 4-row remainder tile (NX % 16 == 4)
+  // runs on the 16x16x4 instruction here)
+  static_assert(cR >= SPLIT && (NX % 16) != 0 && SPLIT >= 1, "Rhat and the spare column belong to wave 1");
+  constexpr bool WIDE = M::WIDE; // fb row-major (generic forward sweep) / fbT2 (gar_forward_mfma)
+  constexpr int NR = C::NR;
   const int li = lane & 15, lk = lane >> 4;
   const unsigned fbrm = 8u * (unsigned)(lk * NX + li); // row-major fb: element (lk, li)
   const unsigned lib = 8u * (unsigned)li;
@@ -266,8 +270,12 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
       continue;
 #pragma unroll
     for (int s = 0; s < KU; ++s)
-      if (16 * tj + 15 < NX || 16 * tj + li < NX)
-        stg_b(out, M::fFB + 4 * s * NX + 16 * tj, fbrm, Kb[tj][s]);
+      if (16 * tj + 15 < NX || 16 * tj + li < NX) {
+        if (WIDE)
+          stg_b(out, M::fFB + 4 * s * NX + 16 * tj, fbrm, Kb[tj][s]);
+        else
+          stg_b(out, M::fFB + 8 * tj * 2 * NR + 8 * s, L.fbl, Kb[tj][s]);
+      }
   }
   double Bop[TX][KU]; // B[16ti+li][4s'+lk]: the A operand of Aff
 #pragma unroll
@@ -326,8 +334,13 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
         if (16 * ti + 4 * r < NX) {
-          if (i < NX && j < NX)
-            stg_b(out, M::fFB + (NK + 16 * ti + 4 * r) * NX + 16 * tj, fbrm, ti < C::KSF ? S.Fo[tj][ti < C::KSF ? ti : 0][r] : accT[r]);
+          if (i < NX && j < NX) {
+            const double v = ti < C::KSF ? S.Fo[tj][ti < C::KSF ? ti : 0][r] : accT[r];
+            if (WIDE)
+              stg_b(out, M::fFB + (NK + 16 * ti + 4 * r) * NX + 16 * tj, fbrm, v);
+            else
+              stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NK + 16 * ti + 4 * r), L.fbl, v);
+          }
         }
       }
   }
@@ -377,8 +390,10 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   }
 }
 
+// (the narrow shapes fit 256 registers per wave: two waves share a SIMD, i.e. four problems per CU, and
+// one problem's waits hide behind the other's arithmetic; the wide ones need the whole register file)
 template <int NX, int NU>
-__global__ void __launch_bounds__(128, 1) gar_backward_pair(MfmaParams P, int batch) {
+__global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair(MfmaParams P, int batch) {
   using C = WaveCfg<NX, NU, 0>;
   using M = MfmaCfg<NX, NU, 0>;
   constexpr int PK = C::PK;

@@ -504,3 +504,13 @@ def test_wide_shape_kernels(monkeypatch, variant, name):
         k.B[...] = 0.0
     with pytest.raises(RuntimeError, match="LDL"):
         ProximalRiccatiSolver(bad, lib_path=EMU).backward(1e-10)
+
+
+@pytest.mark.parametrize("nx,nu,horz,mode", [(36, 12, 4, "W"), (36, 12, 3, "F"), (12, 4, 5, "W"), (8, 4, 4, "W")])
+def test_pair_kernel_on_the_narrow_shapes(monkeypatch, nx, nu, horz, mode):
+    """GAR_HIP_BACKWARD=pair: the two-waves-per-problem sweep (gar_wave_pair.hpp) on the shapes whose tile
+    layout allows the split (fbT2 gains, gar_forward_mfma)."""
+    monkeypatch.setenv("GAR_HIP_BACKWARD", "pair")
+    prob = synth.generate_lq_problem(80 + nx, np.ones(nx), horz, nx, nu, mode=mode)
+    solver, _, _ = pc.check_serial(prob, 1e-12, pc.TOL[mode], EMU, kkt_tol=1e-6 if mode == "F" else 1e-9)
+    assert solver.kernel_name == (f"pair<{nx},{nu}>" if nx == 36 else f"wave<{nx},{nu}>")
