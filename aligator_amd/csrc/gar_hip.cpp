@@ -448,6 +448,8 @@ template <int NX, int NU> void bind_wide(gar_hip_solver *s) {
   // two waves per problem (the tile columns split between them) unless GAR_HIP_WIDE=single
   const char *w = std::getenv("GAR_HIP_WIDE");
   const bool pair = !(w && std::string(w) == "single");
+  if (!(w && std::string(w) == "generic-forward"))
+    s->mfma_fwd_kernel = gar::gar_forward_wide<NX, NU>; // row-major fb: fb_t2 stays false
   s->wave_fused_init = false;
   s->waves_per_block = 1;
   s->fb_t2 = false;

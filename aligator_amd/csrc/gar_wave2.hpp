@@ -697,6 +697,11 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
         col_op(pend_col, q);
     pend_col = tj;
     pend_q = 0;
+    if (tj == 0) {
+      GAR_WMARK(11)
+    } else if (tj == 1) {
+      GAR_WMARK(12)
+    }
   }
   GAR_WMARK(8)
   // ---- Vxx = Qhat + Shat K (:272-273), lower tiles, tile after tile; behind the MFMAs: what is left
@@ -730,6 +735,7 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
         acc4[tj] = __builtin_amdgcn_mfma_f64_4x4x4f64(sh4[s], Kb[tj][s], acc4[tj], 0, 0, 0);
     }
   }
+  GAR_WMARK(13)
   GAR_SB;
   // tiles on the 16x16x4 instruction, one after the other; the tile finished last is written while
   // the next one accumulates
@@ -775,6 +781,7 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
       wr_tj = tj;
       wr_q = 0;
     }
+  GAR_WMARK(15)
   GAR_SB;
   // drain: list B, the remainder tiles, the last tile
 #pragma unroll

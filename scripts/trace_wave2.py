@@ -26,6 +26,6 @@ s.backward(1e-14)
 s._L.gar_hip_debug_trace(s.handle, 0, out)
 t = np.array(list(out))
 marks = [(0, "start"), (1, "P,H col 2"), (2, "P,H cols 1,0 + slots A"), (3, "factor"), (4, "hq"),
-         (5, "solve-operands"), (6, "solve"), (7, "kff,yff,vx"), (8, "Aff + slots B"), (14, "Vxx + slots, V->LDS"), (9, "load_b"), (10, "end")]
+         (5, "solve-operands"), (6, "solve"), (7, "kff,yff,vx"), (11, "Aff col 0 (+K stores)"), (12, "Aff col 1 (+col 0 st/ld)"), (8, "Aff col 2 (+col 1 st/ld)"), (13, "Vxx rem4 tiles"), (15, "Vxx 16x16 tiles + slots"), (14, "drain + sync"), (9, "load_b"), (10, "end")]
 print(f"{s.kernel_name} batch {B}: cycles per phase (s_memtime ticks), total {t[10]-t[0]}")
 print(" | ".join(f"{marks[i][1]}={t[marks[i][0]]-t[marks[i-1][0]]}" for i in range(1, len(marks))))
