@@ -65,7 +65,11 @@ class _Kkt0View:
 SPECIALISED_SHAPES = {(36, 12), (32, 12), (16, 8), (12, 8), (12, 4), (8, 4), (56, 24)}
 
 
-def _padded_dims(dims: np.ndarray):
+# ... of which these have no parallel-in-time (wave-leg) kernels: never a padding target in leg mode
+SERIAL_ONLY_SHAPES = {(56, 24)}
+
+
+def _padded_dims(dims: np.ndarray, num_legs: int = 1):
     """Padding onto a specialised shape: a uniform unconstrained, unparameterised problem whose
     (nx, nu) has no kernel of its own runs on the smallest specialised shape (NX >= nx, NU >= nu)
     with DUMMY controls (R = I, S = 0, B = 0, r = 0) and DUMMY states (Q = I, A = 0, B = 0, f = 0,
@@ -76,11 +80,12 @@ def _padded_dims(dims: np.ndarray):
     if N < 1:
         return None
     nx, nu = int(dims[0, 0]), int(dims[0, 1])
-    if nu == 0 or (nx, nu) in SPECIALISED_SHAPES:
+    if nu == 0 or ((nx, nu) in SPECIALISED_SHAPES and not (num_legs > 1 and (nx, nu) in SERIAL_ONLY_SHAPES)):
         return None
     if not ((dims[:N] == (nx, nu, 0, nx, 0)).all() and tuple(dims[N]) == (nx, 0, 0, nx, 0)):
         return None
-    fits = [(NX * (NX + NU), NX, NU) for (NX, NU) in SPECIALISED_SHAPES if NX >= nx and NU >= nu]
+    fits = [(NX * (NX + NU), NX, NU) for (NX, NU) in SPECIALISED_SHAPES
+            if NX >= nx and NU >= nu and not (num_legs > 1 and (NX, NU) in SERIAL_ONLY_SHAPES)]
     if not fits:
         return None
     _, NX, NU = min(fits)
@@ -141,7 +146,7 @@ class BatchedRiccatiSolver:
         self.dims = self.user_dims.copy()
         self.user_nc0 = int(nc0)
         import os
-        pad = _padded_dims(self.user_dims) if (pad_controls and os.environ.get("GAR_HIP_PAD", "1") != "0") else None
+        pad = _padded_dims(self.user_dims, int(num_legs)) if (pad_controls and os.environ.get("GAR_HIP_PAD", "1") != "0") else None
         self._nxp, self._nup = pad if pad else (0, 0)   # padded (nx, nu) on the device; 0 = no padding
         if pad:
             self.dims[:, 0] = self.dims[:, 3] = self._nxp

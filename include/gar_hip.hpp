@@ -208,7 +208,7 @@ struct PaddedDims {
   uint nx = 0, nu = 0;
   explicit operator bool() const { return nx != 0; }
 };
-inline PaddedDims padded_dims(const LqrProblem &p) {
+inline PaddedDims padded_dims(const LqrProblem &p, int num_legs = 1) {
   const int N = p.horizon();
   if (N < 1)
     return {};
@@ -224,6 +224,8 @@ inline PaddedDims padded_dims(const LqrProblem &p) {
   PaddedDims best;
   uint best_cost = ~0u;
   for (auto &sh : shapes) {
+    if (num_legs > 1 && sh[0] == 56) // the wide family has no parallel-in-time kernels: not a target in leg mode
+      continue;
     if (sh[0] == nx && sh[1] == nu)
       return {}; // compiled in as it is
     const uint cost = sh[0] * (sh[0] + sh[1]);
@@ -318,7 +320,7 @@ public:
 
 protected:
   HipSolver(LqrProblem &problem, int num_legs, int device, bool dense = false)
-      : problem_(&problem), pad_(dense ? PaddedDims{} : padded_dims(problem)), dense_(dense) {
+      : problem_(&problem), pad_(dense ? PaddedDims{} : padded_dims(problem, num_legs)), dense_(dense) {
     const int N = problem.horizon();
     std::vector<int32_t> dims5;
     for (const LqrKnot &k : problem.stages) {
