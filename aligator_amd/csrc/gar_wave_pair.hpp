@@ -35,41 +35,47 @@ template <int NX, int NU> struct PairCfg {
 
 // knot t's operands for wave W: F tile columns it multiplies with (all of them for wave 0: H(ti, tj)
 // needs F(:, ti) for every ti >= tj), the Hessian tiles of its own tile columns
+template <int NX, int NU, class LANE>
+__device__ __forceinline__ void pair_load_F(const double *rec, const LANE &L, WaveStage<NX, NU> &S, int t) {
+  using C = WaveCfg<NX, NU>;
+#pragma unroll
+  for (int s = 0; s < C::KS; ++s) {
+    const double v = WaveLane<NX, NU>::fo_in(t) ? ldg_b(rec, 16 * t * NX + 4 * s, L.fo0) : ldg_b(rec, 4 * s, L.foX);
+    if (s < 4 * C::KSF)
+      S.Fo[t][s >> 2][s & 3] = v;
+    else
+      S.FoT[t][s - 4 * C::KSF] = v;
+  }
+}
+template <int NX, int NU, class LANE>
+__device__ __forceinline__ void pair_load_H(const double *rec, const LANE &L, WaveStage<NX, NU> &S, int ti, int tj) {
+  using C = WaveCfg<NX, NU>;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row0 = 16 * ti + 4 * r; // + lk
+    if (row0 + 3 < NX)
+      S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, 16 * tj * NX + row0, L.hcx0) : ldg_b(rec, row0, L.hcxX[tj]);
+    else if (row0 >= NX && row0 + 3 < C::NW)
+      S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, (row0 - NX) * NX + 16 * tj, L.hcu0)
+                                                   : ldg_b(rec, 0, L.hcuX[tj][(row0 - NX) >> 2]);
+    else
+      S.Hc[ti][tj][r] = 0.0;
+  }
+}
 template <int NX, int NU, int W, class LANE>
 __device__ __forceinline__ void pair_load(const double *rec, const LANE &L, WaveStage<NX, NU> &S) {
   using C = WaveCfg<NX, NU>;
   using PC = PairCfg<NX, NU>;
 #pragma unroll
-  for (int t = 0; t < C::TW; ++t) {
-    if (W == 1 && t < PC::SPLIT)
-      continue;
-#pragma unroll
-    for (int s = 0; s < C::KS; ++s) {
-      const double v = WaveLane<NX, NU>::fo_in(t) ? ldg_b(rec, 16 * t * NX + 4 * s, L.fo0) : ldg_b(rec, 4 * s, L.foX);
-      if (s < 4 * C::KSF)
-        S.Fo[t][s >> 2][s & 3] = v;
-      else
-        S.FoT[t][s - 4 * C::KSF] = v;
-    }
-  }
+  for (int t = 0; t < C::TW; ++t)
+    if (!(W == 1 && t < PC::SPLIT))
+      pair_load_F<NX, NU>(rec, L, S, t);
 #pragma unroll
   for (int ti = 0; ti < C::TW; ++ti)
 #pragma unroll
-    for (int tj = 0; tj <= ti; ++tj) {
-      if (PC::owner(tj) != W)
-        continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row0 = 16 * ti + 4 * r; // + lk
-        if (row0 + 3 < NX)
-          S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, 16 * tj * NX + row0, L.hcx0) : ldg_b(rec, row0, L.hcxX[tj]);
-        else if (row0 >= NX && row0 + 3 < C::NW)
-          S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, (row0 - NX) * NX + 16 * tj, L.hcu0)
-                                                       : ldg_b(rec, 0, L.hcuX[tj][(row0 - NX) >> 2]);
-        else
-          S.Hc[ti][tj][r] = 0.0;
-      }
-    }
+    for (int tj = 0; tj <= ti; ++tj)
+      if (PC::owner(tj) == W)
+        pair_load_H<NX, NU>(rec, L, S, ti, tj);
 }
 
 template <int NX, int NU, int W>
@@ -96,6 +102,16 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   double *out = fac + P.slot(t) * P.fac_rec;
   const double *rec = prob + P.in_off0 + P.slot(t) * P.in_rec;
   const double *recn = prob + P.in_off0 + P.slot(t > 0 ? t - 1 : 0) * P.in_rec;
+#ifdef GAR_TRACE
+#define GAR_PMARK(id)                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  if (P.trace != nullptr && blockIdx.x == 0 && lane == 0 && t == (P.horizon >> 1)) \
+    P.trace[W * 16 + (id)] = (long long)clock64();                             \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define GAR_PMARK(id)
+#endif
+  GAR_PMARK(0)
   // ---- first half: P = V'F and H = W + F^T P for this wave's tile columns -----------------------
   double vxs[KS], fs[KS];
 #pragma unroll
@@ -107,6 +123,13 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
     for (int s = 0; s < KS; ++s)
       fs[s] = ldg_b(rec, M::kf + 4 * s, lkb);
   }
+  double qrv[TW]; // [q; r] entries of this wave's columns: issued here, used after the products
+#pragma unroll
+  for (int tj = 0; tj < TW; ++tj)
+    if (PC::owner(tj) == W) {
+      const int j = 16 * tj + li;
+      qrv[tj] = ldg_b(rec, M::kq + (16 * tj + 15 < NW ? 16 * tj : 0), 16 * tj + 15 < NW ? lib : 8u * (unsigned)(j < NW ? j : NW - 1));
+    }
   double part[TW];
 #pragma unroll
   for (int tj = TW - 1; tj >= 0; --tj) {
@@ -138,14 +161,31 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
     }
     part[tj] = a0 + a1;
   }
+  // B (the A operand of Aff) and f of this knot: in flight during the factorisation instead of at their
+  // first use.  (Measured and NOT kept: spreading knot t-1's operand loads over the stage as registers
+  // are released -- live ranges grow, 0.32 -> 0.26 of the roofline; warming L2 with one load per line
+  // ahead of the burst at the end of the stage -- 0.33 -> 0.31.)
+  double Bop[TX][KU]; // B[16ti+li][4s'+lk]: the A operand of Aff
+#pragma unroll
+  for (int ti = 0; ti < TX; ++ti)
+#pragma unroll
+    for (int s = 0; s < KU; ++s)
+      Bop[ti][s] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * s * NX + 16 * ti, L.bop0) : ldg_b(rec, 4 * s * NX, L.bopX);
+  double fyf[TX];
+#pragma unroll
+  for (int ti = 0; ti < TX; ++ti)
+    if (PC::owner(ti) == W) {
+      const int i = 16 * ti + li, ic = i < NX ? i : NX - 1;
+      fyf[ti] = ldg_b(rec, M::kf, 8u * (unsigned)ic);
+    }
+  GAR_PMARK(1)
   // ---- [qhat; rhat] entries of this wave's columns (:217-218, :227-228), Shat^T, Rhat -> LDS -------
 #pragma unroll
   for (int tj = 0; tj < TW; ++tj) {
     if (PC::owner(tj) != W)
       continue;
     const int j = 16 * tj + li;
-    const double qr = ldg_b(rec, M::kq + (16 * tj + 15 < NW ? 16 * tj : 0), 16 * tj + 15 < NW ? lib : 8u * (unsigned)(j < NW ? j : NW - 1));
-    const double e = qr + rows_sum(part[tj], lane);
+    const double e = qrv[tj] + rows_sum(part[tj], lane);
     if (lk == 0 && j < NW) {
       hqv[j] = e;
       if (j >= NX)
@@ -169,7 +209,9 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
         }
       }
     }
+  GAR_PMARK(2)
   __syncthreads(); // (1) [qhat; rhat], Shat^T, Rhat in LDS
+  GAR_PMARK(3)
   // ---- wave 1: register LDL^T of Rhat under the complete Bunch-Kaufman rule; -L, -1/d -> LDS -------
   if (W == 1) {
     double a_row[NU], nd[NU];
@@ -212,7 +254,9 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
       wave_sync();
     }
   }
+  GAR_PMARK(4)
   __syncthreads(); // (2) the factorisation (or [kff | K] itself) is in LDS
+  GAR_PMARK(5)
   const int verdict = flag[0];
   // ---- [kff | K] = -Rhat^{-1} [rhat | Shat^T] (:248-262) for this wave's state columns ------------
   double Kb[TX][KU];
@@ -262,7 +306,9 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
     if (W == 1 && lane < NU)
       G[lane * PG] = Kv[lane * PG]; // kff
   }
+  GAR_PMARK(6)
   __syncthreads(); // (3) kff in G(:, 0); every read of [kff | K] from the V buffer is done
+  GAR_PMARK(7)
   // ---- K -> fb rows 0..NU-1 (row-major); kff; yff = f + B kff (:266); vx = qhat + Shat kff (:275-276)
 #pragma unroll
   for (int tj = 0; tj < TX; ++tj) {
@@ -277,12 +323,6 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
           stg_b(out, M::fFB + 8 * tj * 2 * NR + 8 * s, L.fbl, Kb[tj][s]);
       }
   }
-  double Bop[TX][KU]; // B[16ti+li][4s'+lk]: the A operand of Aff
-#pragma unroll
-  for (int ti = 0; ti < TX; ++ti)
-#pragma unroll
-    for (int s = 0; s < KU; ++s)
-      Bop[ti][s] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * s * NX + 16 * ti, L.bop0) : ldg_b(rec, 4 * s * NX, L.bopX);
   {
     double kf[KU];
 #pragma unroll
@@ -301,7 +341,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
         a = __builtin_fma(Bop[ti][s], kf[s], a);
         c = __builtin_fma(G[(4 * s + lk) * PG + 1 + ic], kf[s], c); // Shat(i, 4s+lk)
       }
-      const double yf = ldg_b(rec, M::kf, 8u * (unsigned)ic) + rows_sum(a, lane);
+      const double yf = fyf[ti] + rows_sum(a, lane);
       const double vxv = hqv[ic] + rows_sum(c, lane);
       if (lk == 0 && i < NX) {
         out[M::fFF + NK + i] = yf;
@@ -310,6 +350,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
       }
     }
   }
+  GAR_PMARK(8)
   // ---- Aff = A + B K (:267), in place on the F operand registers, this wave's state columns ---------
 #pragma unroll
   for (int tj = 0; tj < TX; ++tj) {
@@ -344,6 +385,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
         }
       }
   }
+  GAR_PMARK(9)
   // ---- Vxx = Qhat + Shat K (:272-273), lower tiles of this wave's columns, mirrored into LDS ----------
   // (V' was last read before barrier (1); Shat comes from G: the other wave's columns too)
 #pragma unroll
@@ -373,9 +415,11 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
       }
     }
   }
-  // knot t-1 into the registers this stage released
-  pair_load<NX, NU, W>(recn, L, S);
+  GAR_PMARK(10)
+  pair_load<NX, NU, W>(recn, L, S); // knot t-1 into the registers this stage released
+  GAR_PMARK(11)
   __syncthreads(); // (4) V, vx complete
+  GAR_PMARK(12)
   // ---- Vxx -> HBM (column-major, symmetric), 16 B per lane, the chunks alternate between the waves ----
   {
     constexpr int NCH = (NX * NX / 2 + 63) / 64;

@@ -16,10 +16,12 @@ for batch in [int(a) for a in sys.argv[1:]] or [256, 768, 1536]:
     for force, wide in (("0", "pair"), ("0", "single"), ("1", "pair")):
         if force == "1" and batch > 256:
             continue
+        if os.environ.get("GAR_LIB") and (force, wide) != ("0", "pair"):
+            continue  # A/B runs of kernel variants: the pair kernel only
         os.environ["GAR_HIP_FORCE_GENERIC"] = force
         os.environ["GAR_HIP_WIDE"] = wide
         os.environ["GAR_HIP_PAD"] = "1" if force == "0" else "0"
-        s = BatchedRiccatiSolver(dims, nx, batch=batch)
+        s = BatchedRiccatiSolver(dims, nx, batch=batch, lib_path=os.environ.get("GAR_LIB") or None)
         packed = np.concatenate([s.pack(p) for p in probs])
         for b0 in range(0, batch, 4):
             s.upload_packed(packed[: min(4, batch - b0) * s.problem_doubles], b0, min(4, batch - b0))
