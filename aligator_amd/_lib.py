@@ -53,6 +53,7 @@ SIGNATURES = {
     "gar_hip_forward_async": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gar_hip_num_failed": (C.c_int, [C.c_void_p]),
     "gar_hip_slow_path_stages": (C.c_int, [C.c_void_p, _PI64]),
+    "gar_hip_constrained_bk_stages": (C.c_int, [C.c_void_p, _PI64]),
     "gar_hip_boundary_doubles": (C.c_int64, [C.c_void_p]),
     "gar_hip_device_boundary_local": (C.c_void_p, [C.c_void_p]),
     "gar_hip_device_boundary_all": (C.c_void_p, [C.c_void_p]),

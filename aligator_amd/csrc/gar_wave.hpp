@@ -1199,8 +1199,16 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
 #include "gar_wave2.hpp"
 namespace gar {
 
-template <int NX, int NU, int NC = 0>
-__global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int batch) {
+// BK_RESUME (NC > 0 only): the SECOND kernel of a constrained sweep.  The first one runs the decoupled
+// stage (gar_wave2.hpp: D = 0, Rhat in its natural order) and, at the first knot that is not of that
+// kind, records the knot in P.resume[b] and leaves; this one picks such problems up at that knot --
+// V', vx' from the record the first kernel completed -- and runs every remaining stage with the
+// (NU+NC) x (NU+NC) Bunch-Kaufman.  Two kernels instead of a branch per stage: one kernel holding both
+// stage implementations allocates registers for the union (724 B of scratch per lane, 63 k cycles per
+// decoupled stage instead of 37 k, measured).  Problems the first kernel finished cost the second one an
+// early exit; no host synchronisation in between.
+template <int NX, int NU, int NC, bool BK_RESUME>
+__device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int batch) {
   using C = WaveCfg<NX, NU, NC>;
   using M = MfmaCfg<NX, NU, NC>;
   constexpr int PK = C::PK;
@@ -1225,15 +1233,33 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   const bool tracing = false;
 #endif
 
+  int tstart = N - 1;
+  if constexpr (BK_RESUME) {
+    tstart = P.resume[b];
+    if (tstart < 0)
+      return;
+  }
   WaveLane<NX, NU, NC> L;
   wave_lane_init<NX, NU>(L, lane);
   WaveStage<NX, NU> S;
-  wave_load_a<NX, NU>(prob + P.in_off0 + P.slot(N - 1) * P.in_rec, L, S);
-  wave_load_b<NX, NU>(prob + P.in_off0 + P.slot(N - 1) * P.in_rec, L, S);
+  if (N > 0) {
+    wave_load_a<NX, NU>(prob + P.in_off0 + P.slot(tstart) * P.in_rec, L, S);
+    wave_load_b<NX, NU>(prob + P.in_off0 + P.slot(tstart) * P.in_rec, L, S);
+  }
 
   // ---- terminal knot (terminalSolve, nu = 0, :146-149, :175-178): Z = C/mu, zff = d/mu,
   // Vxx = Q + C^T Z, vx = q + C^T zff (nc = 0: Vxx = Q, vx = q)
-  {
+  if (BK_RESUME && tstart < N - 1) {
+    // V' = Vxx, vx' = vx of knot tstart+1: complete in its record (the first kernel's deferred flush of
+    // that Vxx runs at the start of the stage it then abandoned)
+    const double *rn = fac + P.slot(tstart + 1) * P.fac_rec;
+    for (int e = lane; e < NX * NX; e += 64) {
+      const int j = e / NX, i = e - j * NX;
+      V[i * PK + j] = rn[M::fVxx + e];
+    }
+    if (lane < NX)
+      vn[lane] = rn[M::fvx + lane];
+  } else {
     const double *rec = prob + P.in_offN;
     double *out = fac + P.fac_offN;
     for (int e = lane; e < NX * NX; e += 64) {
@@ -1262,28 +1288,39 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   }
   wave_sync();
   int failed = 0;
-#ifndef GAR_STAGE_V1
   // gar_wave2.hpp: a stage leaves its Vxx in LDS and the NEXT stage copies it to HBM behind its
   // MFMAs; the first stage re-writes the terminal Vxx (same values), the last one is flushed below
   [[maybe_unused]] double *vflush = fac + P.fac_offN + M::tVxx;
-#endif
-  for (int t = N - 1; t >= 0; --t) {
+  for (int t = tstart; t >= 0; --t) {
     if constexpr (NC == 0) {
-#ifdef GAR_STAGE_V1
-      wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
-#else
       wave_stage2<NX, NU>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing);
-#endif
     } else {
-      wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+      if constexpr (BK_RESUME) {
+        if (lane == 0)
+          atomicAdd(&P.slow[2], 1);
+        wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+      } else {
+        // D = 0 and an Rhat that needs no pivot: the unconstrained stage plus the constraint terms
+        // (gar_wave2.hpp); anything else: over to the second kernel from this knot on
+        if (!wave_stage2<NX, NU, NC>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing)) {
+          if (lane == 0) {
+            P.resume[b] = t;
+            if (failed)
+              atomicOr(&P.status[b], failed);
+          }
+          return;
+        }
+      }
     }
   }
-#ifndef GAR_STAGE_V1
-  if constexpr (NC == 0) {
+  if constexpr (NC > 0 && !BK_RESUME) {
+    if (lane == 0)
+      P.resume[b] = -1;
+  }
+  if constexpr (!BK_RESUME) {
     if (N > 0)
       wave_flush_vxx<NX>(V, vflush, lane);
   }
-#endif
   // ---- initial stage (proximal-riccati.hxx:42-60), fused: kkt0 = [Vxx0 G0^T; G0 0] is
   // Bunch-Kaufman-factorised by this wave right away (packed lower triangle in LDS, read from
   // the V and vx this wave still holds) and solved for kkt0.ff = -kkt0^{-1} [vx0; g0]
@@ -1356,6 +1393,17 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int bat
   }
   if (failed && lane == 0)
     atomicOr(&P.status[b], failed);
+}
+
+template <int NX, int NU, int NC = 0>
+__global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int batch) {
+  gar_backward_wave_body<NX, NU, NC, false>(P, batch);
+}
+// constrained sweeps, second kernel (see gar_backward_wave_body)
+template <int NX, int NU, int NC>
+__global__ void __launch_bounds__(64, 1) gar_backward_wave_bk(MfmaParams P, int batch) {
+  static_assert(NC > 0, "the unconstrained stage handles its own pivoting");
+  gar_backward_wave_body<NX, NU, NC, true>(P, batch);
 }
 
 } // namespace gar

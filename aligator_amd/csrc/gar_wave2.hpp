@@ -276,14 +276,24 @@ template <int NX> __device__ __forceinline__ void wave_flush_vxx(const double *V
 // the MFMAs of the tile columns, of Aff and of Vxx.
 #define GAR_SB __builtin_amdgcn_sched_barrier(0)
 
-template <int NX, int NU>
-__device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, const double *prob,
-                                            double *fac, int t, int lane,
-                                            const WaveLane<NX, NU, 0> &L, WaveStage<NX, NU> &S,
-                                            int &failed, double *&vflush, const bool tracing) {
-  using C = WaveCfg<NX, NU, 0>;
-  using M = MfmaCfg<NX, NU, 0>;
-  constexpr int NK = C::NK, NR = C::NR;
+// NC > 0 (equality constraints C x + D u + d = 0 on the knot, riccati-kernel.hxx:232-262): this stage
+// serves the DECOUPLED case D = 0 -- what the reference's own generator and benchmark produce
+// (tests/gar/test_util.cpp:42-43, bench/gar-riccati.cpp:19-22).  The reduced KKT matrix
+// [Rhat D^T; D -mu I] is then block diagonal: Bunch-Kaufman on it is Bunch-Kaufman on Rhat (a column of
+// the -mu I block has no off-diagonal entry: it never pivots), [zff | Z] = [d | C] / mu, and the stage
+// is the unconstrained one plus Vxx += C^T Z (KC more k-steps per tile), vx += C^T zff and the rows
+// [zff | Z] of the record.  Returns 0 WITHOUT having changed anything the caller cannot restore (S.Hc:
+// reload with wave_load_b) when D != 0 or Rhat needs a pivot: the caller then runs the stage with the
+// (NU+NC) x (NU+NC) Bunch-Kaufman (wave_stage).  NC = 0: always returns 1.
+template <int NX, int NU, int NC = 0>
+__device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, const double *prob,
+                                           double *fac, int t, int lane,
+                                           const WaveLane<NX, NU, NC> &L, WaveStage<NX, NU> &S,
+                                           int &failed, double *&vflush, const bool tracing) {
+  using C = WaveCfg<NX, NU, NC>;
+  using M = MfmaCfg<NX, NU, NC>;
+  constexpr int NK = C::NK, NR = C::NR, KC = C::KC; // NK = NU + NC rows [K; Z] ahead of Aff in the record
+  static_assert(NC % 4 == 0 && (NC == 0 || !M::WIDE), "constraints in k-steps of four");
   constexpr int NW = C::NW, PK = C::PK, PG = C::PG, TX = C::TX, TW = C::TW, KS = C::KS, KU = C::KU;
   // [qhat; rhat] one entry per lane; the wide shapes (NW > 64: (56, 24)) keep entries 64.. in a
   // second register (they are control entries: NX <= 64), and write fb ROW-major (the generic
@@ -320,6 +330,15 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
 #pragma unroll
     for (int s = 0; s < KS; ++s)
       fs[s] = ldg_b(rec, M::kf + 4 * s, lkb);
+  }
+  constexpr int NCD = NC > 0 ? (NC * NU + 63) / 64 : 1;
+  double td[NCD]; // NC > 0: D of this knot, for the D == 0 test after the products
+  if (NC > 0) {
+#pragma unroll
+    for (int q = 0; q < NCD; ++q) {
+      const int e = 64 * q + lane;
+      td[q] = rec[M::kD + ((64 * q + 63 < NC * NU || e < NC * NU) ? e : NC * NU - 1)];
+    }
   }
   double qri1 = 0.0; // WIDE: [q; r][64 + lane]
   if (WIDE)
@@ -451,7 +470,7 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
             const int row = 16 * ti + lk + 4 * r, c = 16 * tc + li;
             if (16 * ti + 4 * r >= NX && 16 * ti + 4 * r < NW) { // compile-time: control rows
               if (c >= NX && c <= row)
-                Mm[(c - NX) * NK + (row - NX)] = S.Hc[ti][tc][r];
+                Mm[(c - NX) * NU + (row - NX)] = S.Hc[ti][tc][r];
             }
           }
       wave_lds_order();
@@ -483,6 +502,32 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
 #pragma unroll
     for (int j = 0; j < NU; ++j)
       ndi[j] = nd[j];
+  }
+  constexpr int KC1 = KC > 0 ? KC : 1;
+  double Cop[TX][KC1]; // C[4s+lk][16t+li]: A operand (C^T) and, times 1/mu, B operand (Z) of Vxx += C^T Z
+  double Cop4[KC1];    // REM4: C[4s+k4][NX-4+i4]
+  double dz[KC1];      // zff[4s+lk] = d[4s+lk] / mu
+  const double imu = 1.0 / P.mueq;
+  if (NC > 0) {
+    bool nz = false;
+#pragma unroll
+    for (int q = 0; q < NCD; ++q)
+      nz |= (td[q] != 0.0);
+    if (verdict != 0 || wave_ballot(nz) != 0ull)
+      return 0;
+#pragma unroll
+    for (int tc = 0; tc < TX; ++tc) {
+      const int x = (16 * tc + li) < NX ? (16 * tc + li) : NX - 1;
+#pragma unroll
+      for (int sc = 0; sc < KC; ++sc)
+        Cop[tc][sc] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)(x * NC + lk));
+    }
+#pragma unroll
+    for (int sc = 0; sc < KC; ++sc) {
+      dz[sc] = ldg_b(rec, M::kd + 4 * sc, 8u * (unsigned)lk);
+      if (C::REM4)
+        Cop4[sc] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)((NX - 4 + i4) * NC + k4));
+    }
   }
   GAR_WMARK(3)
   // ---- [qhat; rhat] = [q; r] + F^T vx' + P^T f (:217-218, :227-228) ---------------------------
@@ -569,7 +614,8 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
           }
         }
     wave_sync();
-    failed |= wave_slow_factor_solve<NX, NU, false>(sm, lane, nullptr); // (counted by wave_bk_rule_check)
+    if constexpr (NC == 0) // (NC > 0 left above: verdict != 0 returns 0)
+      failed |= wave_slow_factor_solve<NX, NU, false>(sm, lane, nullptr); // (counted by wave_bk_rule_check)
 #pragma unroll
     for (int tj = 0; tj < TX; ++tj) {
       const int cc = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
@@ -600,9 +646,16 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
         a = __builtin_fma(Bop[ti][s], kf[s], a);
         c = __builtin_fma(S.Hc[C::shTile(s)][ti][C::shReg(s)], kf[s], c); // Shat(16ti+li, 4s+lk)
       }
+      if (NC > 0) { // vx += C^T zff (:275-276 with the constraint rows)
+#pragma unroll
+        for (int sc = 0; sc < KC; ++sc)
+          c = __builtin_fma(Cop[ti][sc], dz[sc] * imu, c);
+      }
       py[ti] = a;
       pv[ti] = c;
     }
+    if (NC > 0 && lane < NC)
+      out[M::fFF + NU + lane] = ldg_b(rec, M::kd, 8u * (unsigned)(lane < NC ? lane : 0)) * imu; // zff
     const double sy = rows_reduce_scatter(py[0], TX > 1 ? py[TX > 1 ? 1 : 0] : 0.0, TX > 2 ? py[TX > 2 ? 2 : 0] : 0.0,
                                           TX > 3 ? py[TX > 3 ? 3 : 0] : 0.0, lane);
     const double sv = rows_reduce_scatter(pv[0], TX > 1 ? pv[TX > 1 ? 1 : 0] : 0.0, TX > 2 ? pv[TX > 2 ? 2 : 0] : 0.0,
@@ -638,6 +691,13 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
         stg_b(out, M::fFB + 8 * tj * 2 * NR + 8 * sq, L.fbl, Kb[tj < TX ? tj : 0][sq]);
     }
   };
+  constexpr int nZst = TX * KC; // Z = C / mu -> fb rows NU .. NU+NC-1
+  auto store_Z = [&](int q) {
+    const int tj = q / KC1, sq = q % KC1;
+    if (16 * tj + 15 < NX || 16 * tj + li < NX)
+      stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NU + 4 * sq), L.fbl, Cop[tj < TX ? tj : 0][sq] * imu);
+  };
+  int sZ = 0;
   // column tj of Aff -> fb rows NK.. (fbT2), then F's column tile tj of knot t-1 into the same registers
   constexpr int nRow4 = (NX + 3) / 4; // (ti, r) pairs with 16 ti + 4 r < NX
   constexpr int nCol = nRow4 + KS;    // stores, then loads
@@ -733,6 +793,11 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
 #pragma unroll
       for (int s = 0; s < KU; ++s)
         acc4[tj] = __builtin_amdgcn_mfma_f64_4x4x4f64(sh4[s], Kb[tj][s], acc4[tj], 0, 0, 0);
+      if (NC > 0) {
+#pragma unroll
+        for (int sc = 0; sc < KC; ++sc)
+          acc4[tj] = __builtin_amdgcn_mfma_f64_4x4x4f64(Cop4[sc], Cop[tj][sc] * imu, acc4[tj], 0, 0, 0);
+      }
     }
   }
   GAR_WMARK(13)
@@ -748,9 +813,11 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
     for (int ti = tj; ti < (C::REM4 ? TX - 1 : TX); ++ti) {
       double4_t acc = S.Hc[ti][tj];
 #pragma unroll
-      for (int s = 0; s < KU; ++s) {
-        const double aq = S.Hc[C::shTile(s)][ti][C::shReg(s)];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, Kb[tj][s], acc, 0, 0, 0);
+      for (int s = 0; s < KU + KC; ++s) {
+        // Shat K, then (NC > 0) C^T Z: A = C^T(16ti+li, 4sc+lk), B = Z(4sc+lk, 16tj+li)
+        const double aq = s < KU ? S.Hc[C::shTile(s < KU ? s : 0)][ti][C::shReg(s < KU ? s : 0)] : Cop[ti][s >= KU ? s - KU : 0];
+        const double bq = s < KU ? Kb[tj][s < KU ? s : 0] : Cop[tj][s >= KU ? s - KU : 0] * imu;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, acc, 0, 0, 0);
         GAR_SB;
 #pragma unroll
         for (int rep = 0; rep < 3; ++rep) {
@@ -758,6 +825,8 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
             store_K(sK++);
           } else if (pend_col >= 0 && pend_q < nCol) {
             col_op(pend_col, pend_q++);
+          } else if (sZ < nZst) {
+            store_Z(sZ++);
           } else if (!r4_written) {
 #pragma unroll
             for (int c4 = 0; c4 < TX; ++c4)
@@ -792,6 +861,10 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   for (int q = 0; q < nCol; ++q)
     if (pend_col >= 0 && q >= pend_q)
       col_op(pend_col, q);
+#pragma unroll
+  for (int q = 0; q < nZst; ++q)
+    if (q >= sZ)
+      store_Z(q);
   if (!r4_written) {
 #pragma unroll
     for (int c4 = 0; c4 < TX; ++c4)
@@ -824,6 +897,7 @@ __device__ __forceinline__ void wave_stage2(const MfmaParams &P, double *sm, con
   vflush = out + oVxx;
   GAR_WMARK(10)
 #undef GAR_WMARK
+  return 1;
 }
 
 } // namespace gar

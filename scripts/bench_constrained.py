@@ -15,7 +15,7 @@ if os.environ.get("DNONZERO"):   # the reference's generator leaves D = 0 (test_
         for k in p.stages[:-1]:
             k.D[...] = rng.uniform(-1, 1, k.D.shape)
 dims = [k.dims for k in probs[0].stages]
-for B in (64, 256, 1024):
+for B in (64, 256, 1024, 4096):
     s = BatchedRiccatiSolver(dims, nx, batch=B)
     packed = np.concatenate([s.pack(p) for p in probs])
     for b0 in range(0, B, 2):
@@ -27,7 +27,17 @@ for B in (64, 256, 1024):
         s.backward_async(mueq); s.forward_async()
     s.sync()
     dt = (time.perf_counter() - t0) / R
-    print(("D random " if os.environ.get("DNONZERO") else "D = 0    ") + f"nc={nc} N={N} batch={B:5d} {s.kernel_name:10s} {dt*1e3:9.2f} ms/step {B/dt:9.0f} sweeps/s  kkt {kkt:.1e}", flush=True)
+    knot = 2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu + nc * (nx + nu + 1)      # Q S R q r A B f + C D d
+    fac = (nu + nc + nx) * (nx + 1) + nx * nx + nx                                   # [K; Z; Aff | kff; zff; yff], Vxx, vx
+    s._check(s._L.gar_hip_set_timing(s.handle, 1))
+    s.backward_async(mueq); s.forward_async(); s.sync()
+    import ctypes as C
+    o = (C.c_double * 3)(); s._check(s._L.gar_hip_last_kernel_ms(s.handle, o))
+    frac = 8 * (knot + fac) * N * B / (o[0] * 1e-3) / 8e12
+    first, piv = s.slow_path_stages()
+    print(("D random " if os.environ.get("DNONZERO") else "D = 0    ") + f"nc={nc} N={N} batch={B:5d} {s.kernel_name:10s} {dt*1e3:9.2f} ms/step {B/dt:9.0f} sweeps/s  kkt {kkt:.1e}"
+          f"  backward kernels {o[0]:.2f} ms = {frac:.3f} of 8 TB/s; stages: {s.constrained_bk_stages() / (N * B):.3f} on the (nu+nc) Bunch-Kaufman,"
+          f" {first / (N * B):.3f} needed the second Bunch-Kaufman test", flush=True)
 
 # the CPU oracle (restated reference, oracle/gar_oracle.c -O3 -march=native, OpenMP over problems) on
 # this box's host cores, same shape and data

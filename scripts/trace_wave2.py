@@ -8,21 +8,22 @@ from aligator_amd.gar import BatchedRiccatiSolver
 TRACE_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aligator_amd", "libgar_hip_trace.so")  # make -C aligator_amd/csrc trace
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nx, nu = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (36, 12)
-N = 256 if nx <= 36 else 64
-dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
+nc = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # nc > 0: the decoupled constrained stage (generator: D = 0)
+N = 256 if nx <= 36 and nc == 0 else 64
+dims = [(nx, nu, nc, nx, 0)] * N + [(nx, 0, nc, nx, 0)]
 s = BatchedRiccatiSolver(dims, nx, batch=B, lib_path=TRACE_LIB)
-if nx <= 36:
+if nx <= 36 and nc == 0:
     synth_device.fill_problems(s, seed=1, mode="W")
 else:
     from aligator_amd import synth
     import numpy as np
-    pk = s.pack(synth.generate_lq_problem(3, np.ones(nx), N, nx, nu, mode="W"))
+    pk = s.pack(synth.generate_lq_problem(3, np.ones(nx), N, nx, nu, nc=nc, mode="W"))
     for b in range(B):
         s.upload_packed(pk, b, 1)
-s.backward(1e-14)
+s.backward(1e-11 if nc else 1e-14)
 out = (C.c_longlong * 64)()
 s._L.gar_hip_debug_trace(s.handle, 1, None)
-s.backward(1e-14)
+s.backward(1e-11 if nc else 1e-14)
 s._L.gar_hip_debug_trace(s.handle, 0, out)
 t = np.array(list(out))
 marks = [(0, "start"), (1, "P,H col 2"), (2, "P,H cols 1,0 + slots A"), (3, "factor"), (4, "hq"),

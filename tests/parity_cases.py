@@ -271,6 +271,36 @@ def check_constrained_pivoting(lib_path=None, shapes=((8, 4, 4, 6, 1e-6), (16, 8
 
 
 
+def check_constrained_decoupled(lib_path=None, shapes=((8, 4, 4, 7, 1e-6), (16, 8, 8, 5, 1e-8), (36, 12, 32, 4, 1e-9)),
+                                tol=1e-8):
+    """The decoupled constrained stage (D = 0: gar_wave2.hpp, NC > 0) with a DENSE random C -- the
+    reference's generator has C = [I 0] (tests/gar/test_util.cpp:42-43), which would hide an index slip in
+    Vxx += C^T Z -- and problems that alternate between knots with D = 0 and knots with D != 0, so that the
+    sweep switches between the two stage implementations (deferred Vxx flush on one side, own flush on the
+    other).  Factors, kkt0 and the solution against the oracle."""
+    decoupled_stages = 0
+    for variant in ("all_decoupled", "alternating"):
+        for (nx, nu, nc, horz, mu) in shapes:
+            rng = np.random.default_rng(77 + nx)
+            prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nc=nc, mode="W")
+            for t, k in enumerate(prob.stages):
+                k.C[...] = rng.uniform(-1, 1, k.C.shape)
+                if variant == "alternating" and t % 2 == 1 and t < horz:
+                    k.D[...] = rng.uniform(-1, 1, k.D.shape)
+            solver, _, _ = check_serial(prob, mu, tol, lib_path)
+            assert solver.kernel_name == f"wave<{nx},{nu},{nc}>"
+            # the first kernel runs decoupled stages down to the first knot that is not one (D != 0, or an
+            # Rhat on which Bunch-Kaufman pivots); the second kernel takes every stage from there on
+            bk, pivoted = solver._impl.constrained_bk_stages(), solver._impl.slow_path_stages()[1]
+            if variant == "all_decoupled":
+                assert (bk == 0) == (pivoted == 0) and bk <= horz, (nx, bk, pivoted)
+                decoupled_stages += horz - bk
+            else:
+                t_first = max(t for t in range(horz) if t % 2 == 1)
+                assert t_first + 1 <= bk <= horz, (nx, bk, t_first)
+    assert decoupled_stages > 0, "no stage ran decoupled: the test does not reach gar_wave2.hpp's NC > 0 path"
+
+
 def check_second_bunch_kaufman_test(lib_path=None):
     """Stages whose Rhat fails the FIRST Bunch-Kaufman test (|a_kk| < alpha colmax) but passes the second
     (|a_kk| rowmax >= alpha colmax^2, bunchkaufman.hpp:63-75): Bunch-Kaufman keeps kp = k, the kernel

@@ -423,6 +423,10 @@ def test_constrained_wave_kernels_bunch_kaufman_pivoting():
     pc.check_constrained_pivoting(EMU)
 
 
+def test_constrained_wave_kernels_decoupled_dense_c_and_alternating_d():
+    pc.check_constrained_decoupled(EMU)
+
+
 
 def test_device_written_knots_survive_host_set_init():
     """A device-resident producer writes the knots in place (gar_hip_device_problems); a later

@@ -49,6 +49,12 @@ def test_constrained_bench_shape():
     assert solver.kernel_name == "wave<36,12,32>"     # the constrained wave kernels, not the generic ones
 
 
+def test_constrained_decoupled_dense_c_and_alternating_d():
+    """D = 0 stages (gar_wave2.hpp, NC > 0) with a dense C, and sweeps that alternate between the decoupled
+    stage and the (NU+NC) Bunch-Kaufman stage."""
+    pc.check_constrained_decoupled(shapes=((8, 4, 4, 25, 1e-6), (16, 8, 8, 30, 1e-8), (36, 12, 32, 40, 1e-8)))
+
+
 @pytest.mark.parametrize("nx,nu,nc,horz,mu", [(36, 12, 32, 40, 1e-6), (16, 8, 8, 30, 1e-8), (8, 4, 4, 25, 1e-5)])
 def test_constrained_wave_kernels_factors(monkeypatch, nx, nu, nc, horz, mu):
     """Constrained stages on the wave kernels: every factor block (ff = [kff; zff; yff],
