@@ -148,7 +148,8 @@ struct gar_hip_solver {
   int mfma_lds_doubles = 0;
   // one-wave-per-problem backward kernel (gar_wave.hpp), preferred when bound
   void (*wave_kernel)(gar::MfmaParams, int) = nullptr;
-  void (*wave_bk_kernel)(gar::MfmaParams, int) = nullptr; // constrained sweeps: the second kernel
+  void (*wave_coupled_kernel)(gar::MfmaParams, int) = nullptr; // constrained sweeps: the second ...
+  void (*wave_bk_kernel)(gar::MfmaParams, int) = nullptr;      // ... and the third kernel of the chain
   int wave_lds_doubles = 0, waves_per_block = 1;
   int wave_block_threads = 64; // 128: two waves per problem (gar_wave_pair.hpp)
   bool fb_t2 = false;      // factor records keep fb / fth in the fbT2 device order (gar_mfma.hpp)
@@ -528,6 +529,7 @@ void select_leg_kernel(gar_hip_solver *s) {
 // reduced KKT system factorised by the wave-scope Bunch-Kaufman (gar_wave.hpp, NC > 0)
 template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
   s->wave_kernel = gar::gar_backward_wave<NX, NU, NC>;
+  s->wave_coupled_kernel = gar::gar_backward_wave_coupled<NX, NU, NC>;
   s->wave_bk_kernel = gar::gar_backward_wave_bk<NX, NU, NC>;
   s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU, NC>;
   s->fb_t2 = true;
@@ -552,6 +554,7 @@ void select_kernel(gar_hip_solver *s) {
   s->mfma_kernel = nullptr;
   s->mfma_fwd_kernel = nullptr;
   s->wave_kernel = nullptr;
+  s->wave_coupled_kernel = nullptr;
   s->wave_bk_kernel = nullptr;
   s->wave_fused_init = false;
   s->wave_block_threads = 64;
@@ -793,7 +796,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.fac = s->d_fac;
     M.status = s->d_status;
     M.slow = s->d_status + s->batch;
-    M.resume = s->d_status + s->batch + 3;
+    M.resume = s->d_status + s->batch + 4;
     M.prob_stride = s->prob_doubles;
     M.fac_stride = s->fac_doubles;
     const int N = s->horizon;
@@ -820,10 +823,11 @@ int launch_backward(gar_hip_solver *s, double mueq) {
       hipLaunchKernelGGL(s->wave_kernel, dim3((unsigned)((s->batch + wpb - 1) / wpb)),
                          dim3(s->wave_block_threads * wpb), (size_t)s->wave_lds_doubles * wpb * sizeof(double),
                          s->stream, M, s->batch);
-      if (s->wave_bk_kernel) // constrained: knots that are not decoupled (D != 0 / a pivoting Rhat), from the first one on
-        hipLaunchKernelGGL(s->wave_bk_kernel, dim3((unsigned)((s->batch + wpb - 1) / wpb)),
-                           dim3(s->wave_block_threads * wpb), (size_t)s->wave_lds_doubles * wpb * sizeof(double),
-                           s->stream, M, s->batch);
+      // constrained sweeps: the chain decoupled stage -> coupled stage -> LDS Bunch-Kaufman (gar_wave.hpp)
+      for (auto k : {s->wave_coupled_kernel, s->wave_bk_kernel})
+        if (k)
+          hipLaunchKernelGGL(k, dim3((unsigned)((s->batch + wpb - 1) / wpb)), dim3(s->wave_block_threads * wpb),
+                             (size_t)s->wave_lds_doubles * wpb * sizeof(double), s->stream, M, s->batch);
     } else {
       hipLaunchKernelGGL(s->mfma_kernel, dim3((unsigned)s->batch), dim3(256),
                          (size_t)s->mfma_lds_doubles * sizeof(double), s->stream, M);
@@ -1045,9 +1049,9 @@ int allocate(gar_hip_solver *s) {
   HIP_TRY(hipMalloc((void **)&s->d_init, sizeof(double) * (size_t)s->init_doubles * B));
   HIP_TRY(hipMemset(s->d_init, 0, sizeof(double) * (size_t)s->init_doubles * B));
   HIP_TRY(hipMalloc((void **)&s->d_theta, sizeof(double) * (size_t)std::max(s->nth0, 1) * B));
-  // per-problem failure flags, then the three slow-path counters (MfmaParams::slow), then MfmaParams::resume
-  HIP_TRY(hipMalloc((void **)&s->d_status, sizeof(int) * (2 * B + 3)));
-  HIP_TRY(hipMemset(s->d_status, 0, sizeof(int) * (2 * B + 3)));
+  // per-problem failure flags, then the four slow-path counters (MfmaParams::slow), then MfmaParams::resume
+  HIP_TRY(hipMalloc((void **)&s->d_status, sizeof(int) * (2 * B + 4)));
+  HIP_TRY(hipMemset(s->d_status, 0, sizeof(int) * (2 * B + 4)));
   if (s->num_legs > 1) {
     const int local = s->leg_end - s->leg_begin;
     const int nblk = 2 * s->num_legs;
@@ -1108,10 +1112,10 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipFuncSetAttribute((const void *)s->wave_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->wave_lds_doubles * s->waves_per_block * sizeof(double))));
-  if (s->wave_bk_kernel)
-    HIP_TRY(hipFuncSetAttribute((const void *)s->wave_bk_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(s->wave_lds_doubles * s->waves_per_block * sizeof(double))));
+  for (auto k : {s->wave_coupled_kernel, s->wave_bk_kernel})
+    if (k)
+      HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(s->wave_lds_doubles * s->waves_per_block * sizeof(double))));
   if (s->lds_error.empty())
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_initial_generic,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1405,7 +1409,7 @@ int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
     return fail(GAR_HIP_ERR_ARG, "null solver");
   if (int rc = commit(s))
     return rc;
-  HIP_TRY(hipMemsetAsync(s->d_status, 0, sizeof(int) * ((size_t)s->batch + 3), s->stream));
+  HIP_TRY(hipMemsetAsync(s->d_status, 0, sizeof(int) * ((size_t)s->batch + 4), s->stream));
   return launch_backward(s, mueq);
 }
 
@@ -1464,14 +1468,15 @@ int gar_hip_slow_path_stages(gar_hip_solver *s, int64_t out[2]) {
   return GAR_HIP_OK;
 }
 
-int gar_hip_constrained_bk_stages(gar_hip_solver *s, int64_t *out) {
+int gar_hip_constrained_bk_stages(gar_hip_solver *s, int64_t out[2]) {
   GAR_GUARD(s);
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
-  int c = 0;
-  HIP_TRY(hipMemcpyAsync(&c, s->d_status + s->batch + 2, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+  int c[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(c, s->d_status + s->batch + 2, sizeof(c), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  *out = c;
+  out[0] = c[0];
+  out[1] = c[1];
   return GAR_HIP_OK;
 }
 

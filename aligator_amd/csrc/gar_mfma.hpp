@@ -34,7 +34,7 @@ struct MfmaParams {
   // diagnostics (bench.py's slow_path_stage_frac): slow[0] += stages whose Rhat failed the first
   // Bunch-Kaufman test somewhere (they leave the register LDL^T), slow[1] += those of them where
   // the complete rule really pivots (generic device Bunch-Kaufman)
-  int *slow; // (slow[2] += constrained stages run with the (nu+nc) Bunch-Kaufman: gar_backward_wave_bk)
+  int *slow; // (constrained sweeps: slow[2] += coupled stages, slow[3] += stages on the LDS Bunch-Kaufman)
   int *resume; // constrained sweeps: per problem, the knot the second kernel takes over at (-1: none)
   long long prob_stride, fac_stride;
   long long in_off0, in_rec, in_offN; // knot record of stage t < N at in_off0 + t*in_rec

@@ -1199,15 +1199,18 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
 #include "gar_wave2.hpp"
 namespace gar {
 
-// BK_RESUME (NC > 0 only): the SECOND kernel of a constrained sweep.  The first one runs the decoupled
-// stage (gar_wave2.hpp: D = 0, Rhat in its natural order) and, at the first knot that is not of that
-// kind, records the knot in P.resume[b] and leaves; this one picks such problems up at that knot --
-// V', vx' from the record the first kernel completed -- and runs every remaining stage with the
-// (NU+NC) x (NU+NC) Bunch-Kaufman.  Two kernels instead of a branch per stage: one kernel holding both
-// stage implementations allocates registers for the union (724 B of scratch per lane, 63 k cycles per
-// decoupled stage instead of 37 k, measured).  Problems the first kernel finished cost the second one an
-// early exit; no host synchronisation in between.
-template <int NX, int NU, int NC, bool BK_RESUME>
+// Constrained sweeps (NC > 0) are a chain of three kernels on one stream, PHASE = 0, 1, 2:
+//   0  the decoupled stage (gar_wave2.hpp: D = 0, Bunch-Kaufman keeps Rhat's natural order);
+//   1  the coupled stage (any D; register LDL^T of the (NU+NC) x (NU+NC) reduced KKT matrix while
+//      Bunch-Kaufman keeps its natural order);
+//   2  the stage with the LDS Bunch-Kaufman (interchanges, 2x2 pivots: the reference's kktChol).
+// A kernel that meets a knot it does not serve records the knot in P.resume[b] and leaves -- nothing
+// irreversible has happened: the deferred flush of the previous Vxx is complete by then -- and the next
+// kernel picks the problem up at that knot (V', vx' from the record) and keeps it to the end or to the
+// first knot IT does not serve.  Problems that are finished cost the later kernels an early exit; no host
+// synchronisation.  One kernel with a branch per stage was measured first: the register allocation of
+// the union (724 B of scratch per lane) made a decoupled stage 63 k cycles instead of 37 k.
+template <int NX, int NU, int NC, int PHASE>
 __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int batch) {
   using C = WaveCfg<NX, NU, NC>;
   using M = MfmaCfg<NX, NU, NC>;
@@ -1233,6 +1236,8 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
   const bool tracing = false;
 #endif
 
+  constexpr bool BK_RESUME = PHASE > 0;
+  static_assert(PHASE == 0 || NC > 0, "the unconstrained stage handles its own pivoting");
   int tstart = N - 1;
   if constexpr (BK_RESUME) {
     tstart = P.resume[b];
@@ -1290,21 +1295,24 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
   int failed = 0;
   // gar_wave2.hpp: a stage leaves its Vxx in LDS and the NEXT stage copies it to HBM behind its
   // MFMAs; the first stage re-writes the terminal Vxx (same values), the last one is flushed below
-  [[maybe_unused]] double *vflush = fac + P.fac_offN + M::tVxx;
+  [[maybe_unused]] double *vflush = (BK_RESUME && tstart < N - 1) ? fac + P.slot(tstart + 1) * P.fac_rec + M::fVxx
+                                                                   : fac + P.fac_offN + M::tVxx;
   for (int t = tstart; t >= 0; --t) {
     if constexpr (NC == 0) {
       wave_stage2<NX, NU>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing);
     } else {
-      if constexpr (BK_RESUME) {
+      if constexpr (PHASE == 2) {
         if (lane == 0)
-          atomicAdd(&P.slow[2], 1);
+          atomicAdd(&P.slow[3], 1);
         wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
       } else {
-        // D = 0 and an Rhat that needs no pivot: the unconstrained stage plus the constraint terms
-        // (gar_wave2.hpp); anything else: over to the second kernel from this knot on
-        if (!wave_stage2<NX, NU, NC>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing)) {
-          if (lane == 0) {
+        if (PHASE == 1 && lane == 0)
+          atomicAdd(&P.slow[2], 1);
+        if (!wave_stage2<NX, NU, NC, PHASE == 1>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing)) {
+          if (lane == 0) { // over to the next kernel of the chain from this knot on
             P.resume[b] = t;
+            if (PHASE == 1)
+              atomicAdd(&P.slow[2], -1);
             if (failed)
               atomicOr(&P.status[b], failed);
           }
@@ -1313,11 +1321,11 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
       }
     }
   }
-  if constexpr (NC > 0 && !BK_RESUME) {
+  if constexpr (NC > 0 && PHASE < 2) {
     if (lane == 0)
       P.resume[b] = -1;
   }
-  if constexpr (!BK_RESUME) {
+  if constexpr (PHASE < 2) {
     if (N > 0)
       wave_flush_vxx<NX>(V, vflush, lane);
   }
@@ -1397,13 +1405,16 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
 
 template <int NX, int NU, int NC = 0>
 __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int batch) {
-  gar_backward_wave_body<NX, NU, NC, false>(P, batch);
+  gar_backward_wave_body<NX, NU, NC, 0>(P, batch);
 }
-// constrained sweeps, second kernel (see gar_backward_wave_body)
+// constrained sweeps, second and third kernel of the chain (see gar_backward_wave_body)
+template <int NX, int NU, int NC>
+__global__ void __launch_bounds__(64, 1) gar_backward_wave_coupled(MfmaParams P, int batch) {
+  gar_backward_wave_body<NX, NU, NC, 1>(P, batch);
+}
 template <int NX, int NU, int NC>
 __global__ void __launch_bounds__(64, 1) gar_backward_wave_bk(MfmaParams P, int batch) {
-  static_assert(NC > 0, "the unconstrained stage handles its own pivoting");
-  gar_backward_wave_body<NX, NU, NC, true>(P, batch);
+  gar_backward_wave_body<NX, NU, NC, 2>(P, batch);
 }
 
 } // namespace gar

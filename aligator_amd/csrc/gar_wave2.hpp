@@ -111,6 +111,71 @@ __device__ __forceinline__ void ldl_solve_mfma4(const double (&An)[KU][KU], cons
   }
 }
 
+// The same solve for a factor too large to hold as register operands (the 44 x 44 reduced KKT matrix
+// of a constrained stage: 66 + 66 blocks): -L in LDS, PACKED by rows (row r at r(r+1)/2), every 4x4
+// block read where it is used and applied to all T right-hand-side tiles; ndp[r] = -1/d[r].
+template <int KK, int T>
+__device__ __forceinline__ void ldl_solve_mfma4_packed(const double *Lp, const double *ndp, double (&X)[T][KK], int lane) {
+  const int i3 = lane & 3, lk = lane >> 4;
+  // start of row 4p+x in the packed factor: (4p+x)(4p+x+1)/2 = 2p(4p+1) + 4p x + x(x+1)/2
+  const int ti0 = (i3 * (i3 + 1)) >> 1, tk0 = (lk * (lk + 1)) >> 1;
+  auto tr_i = [&](int p) { return 2 * p * (4 * p + 1) + 4 * p * i3 + ti0; };
+  auto tr_k = [&](int p) { return 2 * p * (4 * p + 1) + 4 * p * lk + tk0; };
+#pragma unroll
+  for (int p = 0; p < KK; ++p) {
+#pragma unroll
+    for (int q = 0; q < p; ++q) {
+      const double a = Lp[tr_i(p) + 4 * q + lk]; // -L(4p+i3, 4q+lk)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        X[t][p] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, X[t][q], X[t][p], 0, 0, 0);
+    }
+    const double ad = (i3 > lk) ? Lp[tr_i(p) + 4 * p + lk] : 0.0;
+    double x0[T], y[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      x0[t] = y[t] = X[t][p];
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        y[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, y[t], x0[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      X[t][p] = y[t];
+  }
+#pragma unroll
+  for (int p = 0; p < KK; ++p) {
+    const double nd = ndp[4 * p + lk];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      X[t][p] *= nd;
+  }
+#pragma unroll
+  for (int p = KK - 1; p >= 0; --p) {
+#pragma unroll
+    for (int q = KK - 1; q > p; --q) {
+      const double a = Lp[tr_k(q) + 4 * p + i3]; // -L(4q+lk, 4p+i3): the transposed block
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        X[t][p] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, X[t][q], X[t][p], 0, 0, 0);
+    }
+    const double ad = (lk > i3) ? Lp[tr_k(p) + 4 * p + i3] : 0.0;
+    double x0[T], y[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      x0[t] = y[t] = X[t][p];
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        y[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, y[t], x0[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      X[t][p] = y[t];
+  }
+}
+
 // sum over the four 16-lane rows of the wave, in every lane: two v_permlane{16,32}_swap exchanges on
 // the VALU (gfx950) instead of two ds_bpermute round trips through the LDS crossbar
 __device__ __forceinline__ double rows_sum(double a, int lane) {
@@ -220,8 +285,11 @@ template <int NU> __device__ __forceinline__ double ldl_bcast(double v, int n, i
     return row_bcast(v, n & 15, lane);
   return lane_bcast(v, n);
 }
-template <int NU>
-__device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], double (&nd)[NU], bool &first_failed) {
+// (nd_lds != nullptr: -1/d_k goes to LDS as it is produced -- it is wave-uniform -- instead of into nd[]:
+// 2 NU registers less while a wide factorisation runs)
+template <int NU, int NDN = NU>
+__device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], double (&nd)[NDN], bool &first_failed,
+                                                     double *nd_lds = nullptr) {
   const double alpha = (1.0 + 4.123105625617661) / 8.0;
   int bad = 0;
   first_failed = false;
@@ -244,7 +312,10 @@ __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], 
     for (int j = k + 1; j < NU; ++j)
       a[j] = __builtin_fma(ldl_bcast<NU>(nlik, j, lane), a[k], a[j]); // a(i,j) -= L(j,k) a(i,k)
     a[k] = nlik;
-    nd[k] = nd_k;
+    if (NDN == NU)
+      nd[NDN == NU ? k : 0] = nd_k;
+    else if (lane == 0)
+      nd_lds[k] = nd_k;
   }
   return bad;
 }
@@ -283,9 +354,15 @@ template <int NX> __device__ __forceinline__ void wave_flush_vxx(const double *V
 // the -mu I block has no off-diagonal entry: it never pivots), [zff | Z] = [d | C] / mu, and the stage
 // is the unconstrained one plus Vxx += C^T Z (KC more k-steps per tile), vx += C^T zff and the rows
 // [zff | Z] of the record.  Returns 0 WITHOUT having changed anything the caller cannot restore (S.Hc:
-// reload with wave_load_b) when D != 0 or Rhat needs a pivot: the caller then runs the stage with the
-// (NU+NC) x (NU+NC) Bunch-Kaufman (wave_stage).  NC = 0: always returns 1.
-template <int NX, int NU, int NC = 0>
+// reload with wave_load_b) when D != 0 or Rhat needs a pivot.
+// COUPLED (NC > 0): any D.  The register LDL^T under the complete Bunch-Kaufman rule runs on the
+// NK = NU + NC rows of [Rhat D^T; D -mu I] (lane = row: rows NU.. are [D(i,:) | 0 .. -mu]); -L goes to
+// LDS packed, and the 1 + NX right-hand sides [rhat Shat^T; d C] -- the constraint rows are the C
+// operand registers themselves -- are solved on v_mfma_f64_4x4x4 in NK/4 block rows
+// (ldl_solve_mfma4_packed).  Returns 0 only when Bunch-Kaufman interchanges or takes a 2x2 pivot
+// somewhere: the caller then runs the stage with the LDS Bunch-Kaufman (wave_stage).
+// NC = 0: always returns 1.
+template <int NX, int NU, int NC = 0, bool COUPLED = false>
 __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, const double *prob,
                                            double *fac, int t, int lane,
                                            const WaveLane<NX, NU, NC> &L, WaveStage<NX, NU> &S,
@@ -293,7 +370,8 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   using C = WaveCfg<NX, NU, NC>;
   using M = MfmaCfg<NX, NU, NC>;
   constexpr int NK = C::NK, NR = C::NR, KC = C::KC; // NK = NU + NC rows [K; Z] ahead of Aff in the record
-  static_assert(NC % 4 == 0 && (NC == 0 || !M::WIDE), "constraints in k-steps of four");
+  static_assert(NC % 4 == 0 && (NC == 0 || !M::WIDE) && (NC > 0 || !COUPLED), "constraints in k-steps of four");
+  constexpr int KUK = NK / 4; // block rows of the reduced KKT matrix
   constexpr int NW = C::NW, PK = C::PK, PG = C::PG, TX = C::TX, TW = C::TW, KS = C::KS, KU = C::KU;
   // [qhat; rhat] one entry per lane; the wide shapes (NW > 64: (56, 24)) keep entries 64.. in a
   // second register (they are control entries: NX <= 64), and write fb ROW-major (the generic
@@ -331,14 +409,12 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
     for (int s = 0; s < KS; ++s)
       fs[s] = ldg_b(rec, M::kf + 4 * s, lkb);
   }
-  constexpr int NCD = NC > 0 ? (NC * NU + 63) / 64 : 1;
-  double td[NCD]; // NC > 0: D of this knot, for the D == 0 test after the products
+  double td[NC > 0 ? NU : 1]; // NC > 0: D(lane - NU, :) in lanes NU .. NK-1 (row lane of the reduced KKT matrix)
   if (NC > 0) {
+    const int crow = lane < NU ? 0 : (lane < NK ? lane - NU : NC - 1);
 #pragma unroll
-    for (int q = 0; q < NCD; ++q) {
-      const int e = 64 * q + lane;
-      td[q] = rec[M::kD + ((64 * q + 63 < NC * NU || e < NC * NU) ? e : NC * NU - 1)];
-    }
+    for (int j = 0; j < NU; ++j)
+      td[j] = ldg_b(rec, M::kD + j * NC, 8u * (unsigned)crow);
   }
   double qri1 = 0.0; // WIDE: [q; r][64 + lane]
   if (WIDE)
@@ -487,34 +563,61 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   GAR_WMARK(2)
   // ---- register LDL^T of Rhat under the first Bunch-Kaufman test; -L and -1/d to LDS -------------
   bool first_failed;
-  const int verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed);
+  int verdict;
+  bool d_nonzero = false;
+  if (NC > 0) {
+    bool nz = false;
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+      nz |= (td[j] != 0.0);
+    d_nonzero = wave_ballot(nz && lane >= NU && lane < NK) != 0ull;
+  }
+  constexpr int NKC = COUPLED ? NK : 1;
+  double a44[NKC], nd44[1];
+  double *Lpk = Mm, *nd44p = sm + C::oBk; // COUPLED: -L packed by rows (Rhat in Mm is consumed), -1/d
+  if constexpr (COUPLED) {
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      if (j < NU)
+        a44[j] = lane < NU ? a_row[j] : td[j];
+      else
+        a44[j] = (lane == j || (lane >= NK && j == NK - 1)) ? -P.mueq : 0.0;
+    }
+    verdict = wave_ldl_fast_neg_pre<NK, 1>(lane, a44, nd44, first_failed, nd44p);
+  } else {
+    verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed);
+  }
   if (first_failed && lane == 0) { // diagnostics: stages that needed the second test / that really pivot
     atomicAdd(&P.slow[0], 1);
     if (verdict != 0)
       atomicAdd(&P.slow[1], 1);
   }
-  if (lane < NU) {
+  if constexpr (COUPLED) {
+    if (verdict != 0)
+      return 0;
+    const int base = (lane * (lane + 1)) >> 1;
 #pragma unroll
-    for (int j = 0; j < NU; ++j)
-      Lr[lane * NU + j] = a_row[j]; // -L row-major (entries j >= i: not L, masked at the reads)
-  }
-  if (lane == 0) {
+    for (int j = 0; j < NK - 1; ++j)
+      if (j < lane && lane < NK)
+        Lpk[base + j] = a44[j];
+  } else {
+    if (lane < NU) {
 #pragma unroll
-    for (int j = 0; j < NU; ++j)
-      ndi[j] = nd[j];
+      for (int j = 0; j < NU; ++j)
+        Lr[lane * NU + j] = a_row[j]; // -L row-major (entries j >= i: not L, masked at the reads)
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+        ndi[j] = nd[j];
+    }
   }
   constexpr int KC1 = KC > 0 ? KC : 1;
   double Cop[TX][KC1]; // C[4s+lk][16t+li]: A operand (C^T) and, times 1/mu, B operand (Z) of Vxx += C^T Z
   double Cop4[KC1];    // REM4: C[4s+k4][NX-4+i4]
   double dz[KC1];      // zff[4s+lk] = d[4s+lk] / mu
   const double imu = 1.0 / P.mueq;
-  if (NC > 0) {
-    bool nz = false;
-#pragma unroll
-    for (int q = 0; q < NCD; ++q)
-      nz |= (td[q] != 0.0);
-    if (verdict != 0 || wave_ballot(nz) != 0ull)
-      return 0;
+  auto load_cop = [&]() {
 #pragma unroll
     for (int tc = 0; tc < TX; ++tc) {
       const int x = (16 * tc + li) < NX ? (16 * tc + li) : NX - 1;
@@ -523,11 +626,17 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
         Cop[tc][sc] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)(x * NC + lk));
     }
 #pragma unroll
-    for (int sc = 0; sc < KC; ++sc) {
-      dz[sc] = ldg_b(rec, M::kd + 4 * sc, 8u * (unsigned)lk);
+    for (int sc = 0; sc < KC; ++sc)
       if (C::REM4)
         Cop4[sc] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)((NX - 4 + i4) * NC + k4));
-    }
+  };
+  if (NC > 0) {
+    if (verdict != 0 || (!COUPLED && d_nonzero))
+      return 0;
+    load_cop();
+#pragma unroll
+    for (int sc = 0; sc < KC; ++sc)
+      dz[sc] = ldg_b(rec, M::kd + 4 * sc, 8u * (unsigned)lk);
   }
   GAR_WMARK(3)
   // ---- [qhat; rhat] = [q; r] + F^T vx' + P^T f (:217-218, :227-228) ---------------------------
@@ -551,7 +660,52 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   double Kb[TX][KU]; // K[4s'+lk][16tj+li]: the B operand of Aff and Vxx
   constexpr bool SPARE = (NX % 16) != 0; // a free lane column in the last state tile for rhat
   constexpr int lc = NX % 16;
-  if (verdict == 0) {
+  constexpr int KC2 = COUPLED ? KC1 : 1;
+  double Zb[TX][KC2]; // COUPLED: Z[4sc+lk][16tj+li] out of the solve (decoupled: Cop * (1/mu))
+  if constexpr (COUPLED) {
+    // right-hand sides in B-operand layout: block rows 0..KU-1 = [rhat | Shat^T] (rhat in the spare lane
+    // column of the last state tile, or a tile of its own), block rows KU.. = [d | C]
+    constexpr bool SPARE_C = (NX % 16) != 0;
+    constexpr int lcc = NX % 16, TXN = SPARE_C ? TX : TX + 1;
+    double X[TXN][KUK];
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+#pragma unroll
+      for (int sp = 0; sp < KU; ++sp) {
+        const double sv = S.Hc[C::shTile(sp)][tj][C::shReg(sp)];
+        X[tj][sp] = (SPARE_C && tj == TX - 1 && li == lcc) ? G[(4 * sp + lk) * PG] : sv;
+      }
+#pragma unroll
+      for (int sc = 0; sc < KC; ++sc)
+        X[tj][KU + sc] = (SPARE_C && tj == TX - 1 && li == lcc) ? dz[sc] : Cop[tj][sc];
+    }
+    if (!SPARE_C) {
+#pragma unroll
+      for (int sp = 0; sp < KU; ++sp)
+        X[TXN - 1][sp] = G[(4 * sp + lk) * PG];
+#pragma unroll
+      for (int sc = 0; sc < KC; ++sc)
+        X[TXN - 1][KU + sc] = dz[sc];
+    }
+    GAR_WMARK(5)
+    ldl_solve_mfma4_packed<KUK, TXN>(Lpk, nd44p, X, lane);
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+#pragma unroll
+      for (int sp = 0; sp < KU; ++sp)
+        Kb[tj][sp] = X[tj][sp];
+#pragma unroll
+      for (int sc = 0; sc < KC; ++sc)
+        Zb[tj][sc] = X[tj][KU + sc];
+    }
+    load_cop(); // (again, L2 hits: the operands do not stay in registers across the solve)
+    // [kff; zff] -> column 0 of G (rows 0..NK-1): read back one entry per lane row below
+    if (li == (SPARE_C ? lcc : 0)) {
+#pragma unroll
+      for (int sp = 0; sp < KUK; ++sp)
+        G[(4 * sp + lk) * PG] = X[TXN - 1][sp];
+    }
+  } else if (verdict == 0) {
     double An[KU][KU], At[KU][KU], ndv[KU], rh[KU];
     {
       const int i3 = li & 3;
@@ -649,13 +803,13 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
       if (NC > 0) { // vx += C^T zff (:275-276 with the constraint rows)
 #pragma unroll
         for (int sc = 0; sc < KC; ++sc)
-          c = __builtin_fma(Cop[ti][sc], dz[sc] * imu, c);
+          c = __builtin_fma(Cop[ti][sc], COUPLED ? G[(NU + 4 * sc + lk) * PG] : dz[sc] * imu, c);
       }
       py[ti] = a;
       pv[ti] = c;
     }
     if (NC > 0 && lane < NC)
-      out[M::fFF + NU + lane] = ldg_b(rec, M::kd, 8u * (unsigned)(lane < NC ? lane : 0)) * imu; // zff
+      out[M::fFF + NU + lane] = COUPLED ? G[(NU + lane) * PG] : ldg_b(rec, M::kd, 8u * (unsigned)(lane < NC ? lane : 0)) * imu; // zff
     const double sy = rows_reduce_scatter(py[0], TX > 1 ? py[TX > 1 ? 1 : 0] : 0.0, TX > 2 ? py[TX > 2 ? 2 : 0] : 0.0,
                                           TX > 3 ? py[TX > 3 ? 3 : 0] : 0.0, lane);
     const double sv = rows_reduce_scatter(pv[0], TX > 1 ? pv[TX > 1 ? 1 : 0] : 0.0, TX > 2 ? pv[TX > 2 ? 2 : 0] : 0.0,
@@ -695,7 +849,8 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   auto store_Z = [&](int q) {
     const int tj = q / KC1, sq = q % KC1;
     if (16 * tj + 15 < NX || 16 * tj + li < NX)
-      stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NU + 4 * sq), L.fbl, Cop[tj < TX ? tj : 0][sq] * imu);
+      stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NU + 4 * sq), L.fbl,
+            COUPLED ? Zb[tj < TX ? tj : 0][COUPLED ? sq : 0] : Cop[tj < TX ? tj : 0][sq] * imu);
   };
   int sZ = 0;
   // column tj of Aff -> fb rows NK.. (fbT2), then F's column tile tj of knot t-1 into the same registers
@@ -796,7 +951,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
       if (NC > 0) {
 #pragma unroll
         for (int sc = 0; sc < KC; ++sc)
-          acc4[tj] = __builtin_amdgcn_mfma_f64_4x4x4f64(Cop4[sc], Cop[tj][sc] * imu, acc4[tj], 0, 0, 0);
+          acc4[tj] = __builtin_amdgcn_mfma_f64_4x4x4f64(Cop4[sc], COUPLED ? Zb[tj][COUPLED ? sc : 0] : Cop[tj][sc] * imu, acc4[tj], 0, 0, 0);
       }
     }
   }
@@ -816,7 +971,8 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
       for (int s = 0; s < KU + KC; ++s) {
         // Shat K, then (NC > 0) C^T Z: A = C^T(16ti+li, 4sc+lk), B = Z(4sc+lk, 16tj+li)
         const double aq = s < KU ? S.Hc[C::shTile(s < KU ? s : 0)][ti][C::shReg(s < KU ? s : 0)] : Cop[ti][s >= KU ? s - KU : 0];
-        const double bq = s < KU ? Kb[tj][s < KU ? s : 0] : Cop[tj][s >= KU ? s - KU : 0] * imu;
+        const double bq = s < KU ? Kb[tj][s < KU ? s : 0]
+                                 : (COUPLED ? Zb[tj][COUPLED && s >= KU ? s - KU : 0] : Cop[tj][s >= KU ? s - KU : 0] * imu);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, acc, 0, 0, 0);
         GAR_SB;
 #pragma unroll

@@ -396,12 +396,13 @@ class BatchedRiccatiSolver:
         self._check(self._L.gar_hip_slow_path_stages(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
         return int(out[0]), int(out[1])
 
-    def constrained_bk_stages(self) -> int:
-        """Constrained wave kernels: stages of the last backward (summed over the batch) that needed the
-        (nu+nc) x (nu+nc) Bunch-Kaufman, i.e. were not the decoupled D = 0 stage."""
-        out = np.zeros(1, dtype=np.int64)
+    def constrained_bk_stages(self):
+        """Constrained wave kernels, last backward, summed over the batch: (stages run as the coupled stage --
+        register LDL^T of the (nu+nc) reduced KKT matrix --, stages run with the LDS Bunch-Kaufman); the rest
+        ran as the decoupled D = 0 stage."""
+        out = np.zeros(2, dtype=np.int64)
         self._check(self._L.gar_hip_constrained_bk_stages(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
-        return int(out[0])
+        return int(out[0]), int(out[1])
 
     def set_refinement(self, threshold: float, max_steps: int):
         self._check(self._L.gar_hip_set_refinement(self._h, float(threshold), int(max_steps)))

@@ -178,10 +178,13 @@ int gar_hip_num_failed(gar_hip_solver *s);
  * interchanges or takes a 2x2 pivot (generic device Bunch-Kaufman, exactly the reference's). */
 int gar_hip_slow_path_stages(gar_hip_solver *s, int64_t out[2]);
 /* Constrained wave kernels (nc > 0 on every knot): a knot with D = 0 -- the reference's own generator,
- * tests/gar/test_util.cpp:42-43 -- whose Rhat needs no pivot is the unconstrained stage plus
- * [zff | Z] = [d | C] / mu (riccati-kernel.hxx:232-262 on a block-diagonal KKT matrix); *out = stages of
- * the last backward (summed over the batch) that needed the (nu+nc) x (nu+nc) Bunch-Kaufman instead. */
-int gar_hip_constrained_bk_stages(gar_hip_solver *s, int64_t *out);
+ * tests/gar/test_util.cpp:42-43 -- on whose Rhat Bunch-Kaufman keeps the natural order is the
+ * unconstrained stage plus [zff | Z] = [d | C] / mu (riccati-kernel.hxx:232-262 on a block-diagonal KKT
+ * matrix).  Of the last backward, summed over the batch: out[0] = stages run as the coupled stage (register
+ * LDL^T of the (nu+nc) x (nu+nc) reduced KKT matrix, Bunch-Kaufman keeping its natural order), out[1] =
+ * stages run with the LDS Bunch-Kaufman (interchanges / 2x2 pivots).  A problem stays on the kernel it
+ * reached until that one meets a knot it does not serve. */
+int gar_hip_constrained_bk_stages(gar_hip_solver *s, int64_t out[2]);
 
 /* ---- horizon sharding (leg mode, one rank per GPU) ------------------------ */
 /* doubles per leg in the boundary tuple (Vxx | Vxt | Vtt | vx | vt of the leg's

@@ -36,7 +36,7 @@ for B in (64, 256, 1024, 4096):
     frac = 8 * (knot + fac) * N * B / (o[0] * 1e-3) / 8e12
     first, piv = s.slow_path_stages()
     print(("D random " if os.environ.get("DNONZERO") else "D = 0    ") + f"nc={nc} N={N} batch={B:5d} {s.kernel_name:10s} {dt*1e3:9.2f} ms/step {B/dt:9.0f} sweeps/s  kkt {kkt:.1e}"
-          f"  backward kernels {o[0]:.2f} ms = {frac:.3f} of 8 TB/s; stages: {s.constrained_bk_stages() / (N * B):.3f} on the (nu+nc) Bunch-Kaufman,"
+          f"  backward kernels {o[0]:.2f} ms = {frac:.3f} of 8 TB/s; stages: {s.constrained_bk_stages()[0] / (N * B):.3f} coupled (register LDL^T of the 44 x 44), {s.constrained_bk_stages()[1] / (N * B):.3f} on the LDS Bunch-Kaufman,"
           f" {first / (N * B):.3f} needed the second Bunch-Kaufman test", flush=True)
 
 # the CPU oracle (restated reference, oracle/gar_oracle.c -O3 -march=native, OpenMP over problems) on

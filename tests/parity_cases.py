@@ -278,7 +278,7 @@ def check_constrained_decoupled(lib_path=None, shapes=((8, 4, 4, 7, 1e-6), (16, 
     Vxx += C^T Z -- and problems that alternate between knots with D = 0 and knots with D != 0, so that the
     sweep switches between the two stage implementations (deferred Vxx flush on one side, own flush on the
     other).  Factors, kkt0 and the solution against the oracle."""
-    decoupled_stages = 0
+    decoupled_stages = coupled_stages = 0
     for variant in ("all_decoupled", "alternating"):
         for (nx, nu, nc, horz, mu) in shapes:
             rng = np.random.default_rng(77 + nx)
@@ -289,16 +289,18 @@ def check_constrained_decoupled(lib_path=None, shapes=((8, 4, 4, 7, 1e-6), (16, 
                     k.D[...] = rng.uniform(-1, 1, k.D.shape)
             solver, _, _ = check_serial(prob, mu, tol, lib_path)
             assert solver.kernel_name == f"wave<{nx},{nu},{nc}>"
-            # the first kernel runs decoupled stages down to the first knot that is not one (D != 0, or an
-            # Rhat on which Bunch-Kaufman pivots); the second kernel takes every stage from there on
-            bk, pivoted = solver._impl.constrained_bk_stages(), solver._impl.slow_path_stages()[1]
-            if variant == "all_decoupled":
-                assert (bk == 0) == (pivoted == 0) and bk <= horz, (nx, bk, pivoted)
-                decoupled_stages += horz - bk
-            else:
+            # kernel chain: decoupled stages down to the first knot that is not one (D != 0, or an Rhat on
+            # which Bunch-Kaufman pivots), coupled stages from there to the first pivoting KKT matrix, the LDS
+            # Bunch-Kaufman for the rest
+            coupled, bk = solver._impl.constrained_bk_stages()
+            assert coupled + bk <= horz, (nx, coupled, bk)
+            if variant == "alternating":
                 t_first = max(t for t in range(horz) if t % 2 == 1)
-                assert t_first + 1 <= bk <= horz, (nx, bk, t_first)
+                assert coupled + bk >= t_first + 1, (nx, coupled, bk, t_first)
+                coupled_stages += coupled
+            decoupled_stages += horz - coupled - bk
     assert decoupled_stages > 0, "no stage ran decoupled: the test does not reach gar_wave2.hpp's NC > 0 path"
+    assert coupled_stages > 0, "no stage ran coupled: the test does not reach gar_wave2.hpp's COUPLED path"
 
 
 def check_second_bunch_kaufman_test(lib_path=None):
