@@ -26,6 +26,7 @@ namespace gar {
 // per-stage dimensions (gar_hip.cpp: plan_generic_lds).
 struct LdsPlan {
   int V[2], v[2], Vxt[2], Vtt[2], vt[2];
+  int lean; // 1: one buffer for the parameter blocks too; stage t reads Vxt', Vtt', vt' from stage t+1's record
   int H, h, F, fv, P, vp, CD, dd, Gu, Guh, Gv, M, msub, piv, G, Yth, yff;
   int k0mat, k0rhs, k0sub, k0piv; // initial-stage KKT (aliases the stage buffers)
   int total;                      // doubles (backward kernel)
@@ -180,6 +181,17 @@ __global__ void __launch_bounds__(256) gar_backward_generic(GenericParams P) {
     MatV Vxtn = colmajor(sm + L.Vxt[nxt], nx2), Vxtc = colmajor(sm + L.Vxt[cur], nx);
     MatV Vttn = colmajor(sm + L.Vtt[nxt], nth), Vttc = colmajor(sm + L.Vtt[cur], nth);
     double *vtn = sm + L.vt[nxt], *vtc = sm + L.vt[cur];
+    if (L.lean && !terminal && nth > 0) {
+      // the plan that keeps both generations of the parameter blocks does not fit a CU's LDS (nx = 36,
+      // nc = 32, nth = 36: 183 KB): Vxt', Vtt', vt' are read where this workgroup stored them one
+      // iteration ago -- stage t+1's record (L2; the barrier at the end of the stage orders the two)
+      const gar_stage_meta mn = P.meta[t + 1];
+      const gar_factor_offsets fn = gar_factor_layout(mn.nx, mn.nu, mn.nc, mn.nx2, mn.nth);
+      double *recn = fac + mn.fac_off;
+      Vxtn = colmajor(recn + fn.Vxt, nx2);
+      Vttn = colmajor(recn + fn.Vtt, nth);
+      vtn = recn + fn.vt;
+    }
     MatV Aff = rowmajor(sm + L.P, nx); // aliases P (dead once H is formed)
     MatV Yth = rowmajor(sm + L.Yth, nth);
     double *yff = sm + L.yff;

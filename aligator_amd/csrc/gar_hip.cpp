@@ -325,15 +325,18 @@ int plan_lds(gar_hip_solver *s) {
   gar::LdsPlan &L = s->lds;
   int p = 0;
   auto take = [&](int n) { int o = p; p += align2(std::max(n, 0)); return o; };
+  L.lean = 0;
+replan:
+  p = 0;
   for (int k = 0; k < 2; ++k) {
     // Vxx', vx' are dead once P = V'[A B] and vplus are formed (S1), Vxx, vx are written in S5: one
     // buffer serves both (25 KB at nx = 56, what lets the Talos shape fit a CU's LDS); the
     // parameter blocks are read and written in the same phase and keep two
     L.V[k] = k == 0 ? take(nxM * nxM) : L.V[0];
     L.v[k] = k == 0 ? take(nxM) : L.v[0];
-    L.Vxt[k] = take(nxM * nthM);
-    L.Vtt[k] = take(nthM * nthM);
-    L.vt[k] = take(nthM);
+    L.Vxt[k] = (k == 1 && L.lean) ? L.Vxt[0] : take(nxM * nthM);
+    L.Vtt[k] = (k == 1 && L.lean) ? L.Vtt[0] : take(nthM * nthM);
+    L.vt[k] = (k == 1 && L.lean) ? L.vt[0] : take(nthM);
   }
   const int stage_begin = p;
   L.H = take(nwM * nwM);
@@ -362,6 +365,10 @@ int plan_lds(gar_hip_solver *s) {
   L.k0sub = take(n0);
   L.k0piv = take(264);
   L.total = std::max(stage_end, p);
+  if (!L.lean && nthM > 0 && (size_t)L.total * sizeof(double) > 160 * 1024) {
+    L.lean = 1; // one generation of the parameter blocks in LDS, the other read back from the records
+    goto replan;
+  }
   // forward kernel
   p = 0;
   L.fx = take(nxM);

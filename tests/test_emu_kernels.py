@@ -423,6 +423,16 @@ def test_constrained_wave_kernels_bunch_kaufman_pivoting():
     pc.check_constrained_pivoting(EMU)
 
 
+def test_parallel_solver_on_the_reference_bench_shape_nc32():
+    """bench/gar-riccati.cpp:64-90 (BM_parallel): nx = 36, nu = 12, nc = 32 in leg mode.  The generic leg
+    kernels' LDS plan with both generations of the parameter blocks needs 183 KB; the lean plan (one
+    generation in LDS, Vxt', Vtt', vt' read back from stage t+1's record) fits."""
+    nx, nu, nc = 36, 12, 32
+    rng = np.random.default_rng(3)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 8, nx, nu, nc=nc, mode="W")
+    pc.check_parallel(prob, 1e-8, 2, 1e-7, EMU)
+
+
 def test_constrained_wave_kernels_decoupled_dense_c_and_alternating_d():
     pc.check_constrained_decoupled(EMU)
 

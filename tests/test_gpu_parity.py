@@ -49,6 +49,15 @@ def test_constrained_bench_shape():
     assert solver.kernel_name == "wave<36,12,32>"     # the constrained wave kernels, not the generic ones
 
 
+@pytest.mark.parametrize("legs", [2, 3, 4, 6])
+def test_parallel_solver_on_the_reference_bench_shape_nc32(legs):
+    """bench/gar-riccati.cpp:64-90 (BM_parallel<2,3,4,6>): nx = 36, nu = 12, nc = 32, leg mode."""
+    nx, nu, nc = 36, 12, 32
+    rng = np.random.default_rng(3)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 32, nx, nu, nc=nc, mode="W")
+    pc.check_parallel(prob, 1e-8, legs, 1e-7)
+
+
 def test_constrained_decoupled_dense_c_and_alternating_d():
     """D = 0 stages (gar_wave2.hpp, NC > 0) with a dense C, and sweeps that alternate between the decoupled
     stage and the (NU+NC) Bunch-Kaufman stage."""
