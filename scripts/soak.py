@@ -13,6 +13,8 @@ shapes = [(36, 12, 0), (32, 12, 0), (16, 8, 0), (12, 8, 0), (12, 4, 0), (8, 4, 0
           (36, 12, 32), (16, 8, 8), (8, 4, 4), (6, 3, 2), (5, 2, 0),
           (30, 10, 0), (13, 5, 0), (10, 3, 0), (7, 2, 0), (33, 11, 0), (40, 9, 0), (20, 14, 0),  # padded
           (56, 22, 0), (56, 24, 0), (50, 20, 0)]  # the wide family (two waves per problem / one wave)
+if os.environ.get("SOAK_FOCUS") == "constrained":   # the three-kernel chain of constrained sweeps (gar_wave.hpp)
+    shapes = [sh for sh in shapes if sh[2] > 0]
 dense_share = float(os.environ.get("SOAK_DENSE", "0.25"))
 t0, n, fails, kinds, why = time.time(), 0, 0, {}, {}
 while time.time() - t0 < budget:
@@ -26,12 +28,23 @@ while time.time() - t0 < budget:
     # (constrained problems below mu ~ 1e-10 are conditioned like 1/mu: the oracle and the kernels then
     # differ by cond * eps > 1e-6 from each other on EVERY kernel family, generic included)
     mu = 10.0 ** rng.uniform(-12 if nc == 0 else -10, -5)
-    legs = 1 if (nc > 0 or nx > 36 or rng.random() < 0.4) else int(rng.integers(2, max(3, min(9, horz // 2))))
+    legs = 1 if (nx > 36 or rng.random() < (0.8 if nc > 0 else 0.4)) else int(rng.integers(2, max(3, min(9, horz // 2))))
     seed = int(rng.integers(1 << 30))
     prob = synth.generate_lq_problem(np.random.default_rng(seed), rng.standard_normal(nx), horz, nx, nu, nc=nc, mode=mode)
-    if nc > 0 and rng.random() < 0.5:
+    if nc > 0:
+        # D = 0 everywhere (the reference's generator) / on every knot / on a random subset: the sweep then
+        # moves along the chain decoupled stage -> coupled stage (-> LDS Bunch-Kaufman where a knot's R, S are
+        # scaled down so that the reduced KKT matrix pivots); a dense C half of the time
+        what = rng.random()
         for k in prob.stages[:-1]:
-            k.D[...] = rng.uniform(-1, 1, k.D.shape)
+            if what > 0.35 and (what > 0.7 or rng.random() < 0.3):
+                k.D[...] = rng.uniform(-1, 1, k.D.shape)
+                if rng.random() < 0.15:
+                    k.R[...] *= 1e-3
+                    k.S[...] *= 1e-3
+        if rng.random() < 0.5:
+            for k in prob.stages:
+                k.C[...] = rng.uniform(-1, 1, k.C.shape)
     tol = pc.TOL[mode] if nc == 0 else 1e-6
     try:
         if rng.random() < dense_share:      # RiccatiSolverDense (csrc/gar_dense.hpp) against its own oracle
@@ -46,6 +59,11 @@ while time.time() - t0 < budget:
             s, _, _ = pc.check_serial(prob, mu, tol, factors=(nc == 0 or mu > 1e-9))
             name = s.kernel_name
         else:
+            # (constrained problems in leg mode: the condensed leg-boundary system inherits the 1/mu
+            # conditioning twice -- below mu ~ 5e-9 the leg-parallel and the serial solutions of the SAME
+            # oracle differ by more than 1e-6 -- so mu >= 1e-8 here)
+            if nc > 0:
+                mu = max(mu, 1e-8)
             par = pc.check_parallel(prob, mu, legs, max(tol, 1e-8))
             name = par._impl.kernel_name
         kinds[name] = kinds.get(name, 0) + 1
