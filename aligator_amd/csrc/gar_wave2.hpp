@@ -121,16 +121,37 @@ __device__ __forceinline__ void ldl_solve_mfma4_packed(const double *Lp, const d
   const int ti0 = (i3 * (i3 + 1)) >> 1, tk0 = (lk * (lk + 1)) >> 1;
   auto tr_i = [&](int p) { return 2 * p * (4 * p + 1) + 4 * p * i3 + ti0; };
   auto tr_k = [&](int p) { return 2 * p * (4 * p + 1) + 4 * p * lk + tk0; };
+  // (the blocks of one block row are fetched together, one block row AHEAD of the products that use them:
+  // read where they are used, every ds_read's latency -- 132 of them -- would sit on the critical path)
+  double ar[2][KK], adg[2];
+  auto load_fwd = [&](int p, int buf) {
+#pragma unroll
+    for (int q = 0; q < KK; ++q)
+      if (q < p)
+        ar[buf][q] = Lp[tr_i(p) + 4 * q + lk]; // -L(4p+i3, 4q+lk)
+    const double dgv = Lp[tr_i(p) + 4 * p + lk]; // (read by every lane -- the address is valid -- then masked:
+    adg[buf] = (i3 > lk) ? dgv : 0.0;            //  a conditional load becomes a branch)
+  };
+  auto load_bwd = [&](int p, int buf) {
+#pragma unroll
+    for (int q = 0; q < KK; ++q)
+      if (q > p)
+        ar[buf][q] = Lp[tr_k(q) + 4 * p + i3]; // -L(4q+lk, 4p+i3): the transposed block
+    const double dgv = Lp[tr_k(p) + 4 * p + i3];
+    adg[buf] = (lk > i3) ? dgv : 0.0;
+  };
+  load_fwd(0, 0);
 #pragma unroll
   for (int p = 0; p < KK; ++p) {
+    const int cb = p & 1;
+    if (p + 1 < KK)
+      load_fwd(p + 1, cb ^ 1);
 #pragma unroll
     for (int q = 0; q < p; ++q) {
-      const double a = Lp[tr_i(p) + 4 * q + lk]; // -L(4p+i3, 4q+lk)
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        X[t][p] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, X[t][q], X[t][p], 0, 0, 0);
+        X[t][p] = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[cb][q], X[t][q], X[t][p], 0, 0, 0);
     }
-    const double ad = (i3 > lk) ? Lp[tr_i(p) + 4 * p + lk] : 0.0;
     double x0[T], y[T];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -139,11 +160,12 @@ __device__ __forceinline__ void ldl_solve_mfma4_packed(const double *Lp, const d
     for (int it = 0; it < 3; ++it)
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        y[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, y[t], x0[t], 0, 0, 0);
+        y[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(adg[cb], y[t], x0[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < T; ++t)
       X[t][p] = y[t];
   }
+  load_bwd(KK - 1, 0);
 #pragma unroll
   for (int p = 0; p < KK; ++p) {
     const double nd = ndp[4 * p + lk];
@@ -153,14 +175,15 @@ __device__ __forceinline__ void ldl_solve_mfma4_packed(const double *Lp, const d
   }
 #pragma unroll
   for (int p = KK - 1; p >= 0; --p) {
+    const int cb = (KK - 1 - p) & 1;
+    if (p > 0)
+      load_bwd(p - 1, cb ^ 1);
 #pragma unroll
     for (int q = KK - 1; q > p; --q) {
-      const double a = Lp[tr_k(q) + 4 * p + i3]; // -L(4q+lk, 4p+i3): the transposed block
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        X[t][p] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, X[t][q], X[t][p], 0, 0, 0);
+        X[t][p] = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[cb][q], X[t][q], X[t][p], 0, 0, 0);
     }
-    const double ad = (lk > i3) ? Lp[tr_k(p) + 4 * p + i3] : 0.0;
     double x0[T], y[T];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -169,7 +192,7 @@ __device__ __forceinline__ void ldl_solve_mfma4_packed(const double *Lp, const d
     for (int it = 0; it < 3; ++it)
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        y[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, y[t], x0[t], 0, 0, 0);
+        y[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(adg[cb], y[t], x0[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < T; ++t)
       X[t][p] = y[t];
@@ -688,7 +711,9 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
         X[TXN - 1][KU + sc] = dz[sc];
     }
     GAR_WMARK(5)
+    GAR_WMARK(20)
     ldl_solve_mfma4_packed<KUK, TXN>(Lpk, nd44p, X, lane);
+    GAR_WMARK(21)
 #pragma unroll
     for (int tj = 0; tj < TX; ++tj) {
 #pragma unroll
@@ -699,6 +724,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
         Zb[tj][sc] = X[tj][KU + sc];
     }
     load_cop(); // (again, L2 hits: the operands do not stay in registers across the solve)
+    GAR_WMARK(22)
     // [kff; zff] -> column 0 of G (rows 0..NK-1): read back one entry per lane row below
     if (li == (SPARE_C ? lcc : 0)) {
 #pragma unroll
@@ -824,6 +850,21 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
     }
   }
   GAR_WMARK(7)
+  if constexpr (COUPLED) {
+    // the coupled stage is short of registers while the 44-row factorisation and the solve run: the F
+    // operands of the state columns are not kept across them but fetched again here (L2 hits)
+#pragma unroll
+    for (int tcol = 0; tcol < TX; ++tcol)
+#pragma unroll
+      for (int sq = 0; sq < KS; ++sq) {
+        const double v = WaveLane<NX, NU>::fo_in(tcol) ? ldg_b(rec, 16 * tcol * NX + 4 * sq, L.fo0)
+                                                       : ldg_b(rec, 4 * sq, L.foX);
+        if (sq < 4 * C::KSF)
+          S.Fo[tcol][sq >> 2][sq & 3] = v;
+        else
+          S.FoT[tcol][sq - 4 * C::KSF] = v;
+      }
+  }
   // ---- Aff = A + B K (:267), in place on the F operand registers, one tile column after the
   // other; behind the MFMAs of column tj: the stores of K (tj = 0) / of Aff's column tj-1 and the
   // loads of the next knot's F operands into the registers that column just released ------------

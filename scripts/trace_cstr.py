@@ -28,3 +28,7 @@ prev = t[0]
 for i in range(1, 11):
     if t[i]:
         print(f"  {names[i]:18s} {t[i]-prev:8d}"); prev = t[i]
+
+tt = np.array(list(out))
+if tt[20]:
+    print(f"  coupled stage: X init {tt[20]-tt[5]}, packed MFMA solve {tt[21]-tt[20]}, C reload issue {tt[22]-tt[21]}, to mark 6 {tt[6]-tt[22]}")
