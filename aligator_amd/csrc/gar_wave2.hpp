@@ -696,7 +696,8 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
 #pragma unroll
       for (int sp = 0; sp < KU; ++sp) {
         const double sv = S.Hc[C::shTile(sp)][tj][C::shReg(sp)];
-        X[tj][sp] = (SPARE_C && tj == TX - 1 && li == lcc) ? G[(4 * sp + lk) * PG] : sv;
+        const double g0 = (SPARE_C && tj == TX - 1) ? G[(4 * sp + lk) * PG] : 0.0; // (unconditional read, then select)
+        X[tj][sp] = (SPARE_C && tj == TX - 1 && li == lcc) ? g0 : sv;
       }
 #pragma unroll
       for (int sc = 0; sc < KC; ++sc)

@@ -282,7 +282,8 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
 #pragma unroll
       for (int sp = 0; sp < KU; ++sp) {
         const double sv = S.Hc[C::shTile(sp)][tj][C::shReg(sp)]; // Shat^T(4sp+lk, 16tj+li)
-        Kb[tj][sp] = (tj == TX - 1 && li == lc) ? G[(4 * sp + lk) * PG] : sv;
+        const double g0 = tj == TX - 1 ? G[(4 * sp + lk) * PG] : 0.0; // (read by every lane, then selected: a
+        Kb[tj][sp] = (tj == TX - 1 && li == lc) ? g0 : sv;            //  conditional load becomes a branch)
       }
       ldl_solve_mfma4<KU>(An, At, ndv, Kb[tj]);
     }
