@@ -70,6 +70,7 @@ SIGNATURES = {
     "gar_hip_host_results": (C.c_void_p, [C.c_void_p, _PI64]),
     "gar_hip_get_gains_all": (C.c_int, [C.c_void_p, C.c_int, _PD, _PD]),
     "gar_hip_get_value": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _PD, _PD, _PD, _PD, _PD]),
+    "gar_hip_get_kkt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, _PD]),
     "gar_hip_get_initial": (C.c_int, [C.c_void_p, C.c_int, _PD, _PD, _PD, _PD]),
     "gar_hip_collapse_feedback": (C.c_int, [C.c_void_p]),
     "gar_hip_debug_trace": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),

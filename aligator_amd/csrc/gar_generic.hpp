@@ -1000,4 +1000,39 @@ __global__ void gar_collapse_feedback(const gar_stage_meta *meta, double *fac,
   }
 }
 
+// StageFactor::kktMat (gar/riccati-kernel.hpp:30-102; read from Python as datas[t].kktMat,
+// bindings/python/src/gar/expose-prox-riccati.cpp:30-31): the reduced KKT matrix [Rhat D^T; D -mu I] of one
+// stage, Rhat = R + B^T Vxx' B (riccati-kernel.hxx:224-226, :232-247).  The sweeps never store it (Rhat lives
+// in registers / LDS for the length of a stage); this kernel forms it on request from what IS resident -- the
+// knot and stage t+1's Vxx (symmetrised from its lower triangle, as the consuming stage does, :216).
+// One workgroup; Vn == nullptr: no value-function term (terminal knot, last knot of a leg).
+__global__ void __launch_bounds__(256) gar_kkt_matrix(const double *knot, gar_knot_offsets ko, const double *Vn,
+                                                      int nx2, int nu, int nc, double mueq, double *out) {
+  const int nk = nu + nc;
+  for (int e = (int)threadIdx.x; e < nk * nk; e += (int)blockDim.x) {
+    const int j = e / nk, i = e - j * nk;
+    double v;
+    if (i < nu && j < nu) {
+      v = knot[ko.R + j * nu + i];
+      if (Vn != nullptr) {
+        double acc = 0.0;
+        for (int l = 0; l < nx2; ++l) {
+          double w = 0.0; // (Vxx' B)(l, j)
+          for (int k = 0; k < nx2; ++k)
+            w = __builtin_fma(k >= l ? Vn[l * nx2 + k] : Vn[k * nx2 + l], knot[ko.B + j * nx2 + k], w);
+          acc = __builtin_fma(knot[ko.B + i * nx2 + l], w, acc);
+        }
+        v += acc;
+      }
+    } else if (i >= nu && j < nu) {
+      v = knot[ko.D + j * nc + (i - nu)];
+    } else if (i < nu) {
+      v = knot[ko.D + i * nc + (j - nu)];
+    } else {
+      v = (i == j) ? -mueq : 0.0;
+    }
+    out[e] = v;
+  }
+}
+
 } // namespace gar

@@ -118,6 +118,8 @@ struct gar_hip_solver {
   double *d_prob = nullptr, *d_fac = nullptr, *d_sol = nullptr, *d_init = nullptr;
   double *d_theta = nullptr;
   int *d_status = nullptr;
+  double *d_kkt = nullptr; // gar_hip_get_kkt's staging ((nu+nc)^2 doubles, allocated on first use)
+  int64_t kkt_doubles = 0;
   // leg mode
   int nxb = 0;
   int64_t tuple_doubles = 0, cscratch_doubles = 0;
@@ -1016,6 +1018,10 @@ void free_device(gar_hip_solver *s) {
   (void)hipFree(s->d_init);
   (void)hipFree(s->d_theta);
   (void)hipFree(s->d_status);
+  if (s->d_kkt)
+    (void)hipFree(s->d_kkt);
+  s->d_kkt = nullptr;
+  s->kkt_doubles = 0;
   (void)hipFree(s->d_bound_local);
   if (s->bound_all_owned)
     (void)hipFree(s->d_bound_all);
@@ -1697,6 +1703,47 @@ int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, 
   rc |= d2h(s, Vtt, rec + o.Vtt, (int64_t)m.nth * m.nth);
   rc |= d2h(s, vt, rec + o.vt, m.nth);
   if (rc)
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_kkt(gar_hip_solver *s, int b, int t, double mueq, double *out) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, t))
+    return rc;
+  if (s->dense)
+    return fail(GAR_HIP_ERR_UNSUPPORTED, "kktMat of the stage-dense solver is not kept (the whole stage matrix: gar_dense.hpp)");
+  if (!out)
+    return fail(GAR_HIP_ERR_ARG, "null output");
+  const gar_stage_meta &m = s->meta[t];
+  const int nk = m.nu + m.nc;
+  if (nk == 0)
+    return GAR_HIP_OK;
+  if ((int64_t)nk * nk > s->kkt_doubles) {
+    if (s->d_kkt)
+      (void)hipFree(s->d_kkt);
+    s->d_kkt = nullptr;
+    HIP_TRY(hipMalloc((void **)&s->d_kkt, sizeof(double) * (size_t)nk * nk));
+    s->kkt_doubles = (int64_t)nk * nk;
+  }
+  if (commit(s) != GAR_HIP_OK)
+    return GAR_HIP_ERR_DEVICE;
+  const int nth_st = (m.flags & GAR_KNOT_HAS_PARAM) ? m.nth : 0;
+  const gar_knot_offsets ko = gar_knot_layout(m.nx, m.nu, m.nc, m.nx2, nth_st);
+  const double *knot = s->d_prob + (int64_t)b * s->prob_doubles + m.in_off;
+  // the stage's value-function term: none at the terminal knot and at the last knot of a leg (each leg ends
+  // with terminalSolve, parallel-solver.hxx:150-160)
+  const double *Vn = nullptr;
+  if (t < s->horizon && !(m.flags & GAR_KNOT_LEG_END) && m.nu > 0) {
+    const gar_stage_meta &mn = s->meta[t + 1];
+    const gar_factor_offsets fn = gar_factor_layout(mn.nx, mn.nu, mn.nc, mn.nx2, mn.nth);
+    Vn = s->d_fac + (int64_t)b * s->fac_doubles + mn.fac_off + fn.Vxx;
+  }
+  hipLaunchKernelGGL(gar::gar_kkt_matrix, dim3(1), dim3(256), 0, s->stream, knot, ko, Vn, m.nx2, m.nu, m.nc, mueq,
+                     s->d_kkt);
+  HIP_TRY(hipGetLastError());
+  if (int rc = d2h(s, out, s->d_kkt, (int64_t)nk * nk))
     return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   return GAR_HIP_OK;

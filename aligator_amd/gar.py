@@ -54,7 +54,7 @@ class _ValueView:
 
 class _FactorView:
     """The surviving outputs of gar::StageFactor (riccati-kernel.hpp:88-101)."""
-    __slots__ = ("nx", "nu", "nc", "nx2", "nth", "ff", "fb", "fth", "vm")
+    __slots__ = ("nx", "nu", "nc", "nx2", "nth", "ff", "fb", "fth", "vm", "kktMat")
 
 
 class _Kkt0View:
@@ -193,6 +193,7 @@ class BatchedRiccatiSolver:
         self.G0_off, self.g0_off = int(io[0]), int(io[1])
         self.kernel_name = L.gar_hip_kernel_name(h).decode()
         self._factors_cache = {}
+        self._mueq = None   # of the last backward (datas[t].kktMat is formed on request)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -365,6 +366,7 @@ class BatchedRiccatiSolver:
     # ---- the sweep ---------------------------------------------------------------
     def backward(self, mueq: float) -> bool:
         self._factors_cache = {}
+        self._mueq = float(mueq)
         self._check(self._L.gar_hip_backward(self._h, float(mueq)))
         return True
 
@@ -381,6 +383,7 @@ class BatchedRiccatiSolver:
 
     def backward_async(self, mueq: float):
         self._factors_cache = {}
+        self._mueq = float(mueq)
         self._check(self._L.gar_hip_backward_async(self._h, float(mueq)))
 
     def forward_async(self, theta_device_ptr: int = 0):
@@ -502,11 +505,18 @@ class BatchedRiccatiSolver:
         self._check(self._L.gar_hip_get_value(self._h, b, t, _ptr(vm.Vxx), _ptr(vm.vx),
                                               _ptr(vm.Vxt), _ptr(vm.Vtt), _ptr(vm.vt)))
         f.vm = vm
+        # StageFactor::kktMat = [Rhat D^T; D -mu I] (expose-prox-riccati.cpp:30-31): not kept by the sweeps, formed
+        # on the device on request from the knot and stage t+1's Vxx (gar_hip_get_kkt)
+        f.kktMat = np.zeros((nu + nc, nu + nc), order="F")
+        if not self.dense and nu + nc > 0 and self._mueq is not None:
+            self._check(self._L.gar_hip_get_kkt(self._h, b, t, float(self._mueq), _ptr(f.kktMat)))
         if self._nxp: # drop the rows / columns of the dummy controls and states
             unx, unu = int(self.user_dims[t, 0]), int(self.user_dims[t, 1])
             uth = unx if nth > 0 else 0
             keep = np.r_[0:unu, nu:nu + unx]
             f.nx, f.nu, f.nx2, f.nth = unx, unu, unx, uth
+            kk = np.r_[0:unu, nu:nu + nc]
+            f.kktMat = np.asfortranarray(f.kktMat[np.ix_(kk, kk)])
             f.ff = f.ff[keep]
             f.fb = np.ascontiguousarray(f.fb[keep][:, :unx])
             f.fth = np.ascontiguousarray(f.fth[keep][:, :uth])

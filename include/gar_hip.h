@@ -232,6 +232,12 @@ int gar_hip_gains_offsets(const gar_hip_solver *s, int t, int64_t out[2]);
 int gar_hip_fetch_results(gar_hip_solver *s, int b, int what);
 const double *gar_hip_host_results(gar_hip_solver *s, int64_t offs[3]);
 int gar_hip_get_gains_all(gar_hip_solver *s, int b, double *ff_all, double *fb_all);
+/* StageFactor::kktMat of stage t (gar/riccati-kernel.hpp:30-102; Python: datas[t].kktMat,
+ * bindings/python/src/gar/expose-prox-riccati.cpp:30-31): the reduced KKT matrix [Rhat D^T; D -mu I],
+ * (nu+nc) x (nu+nc) column-major, Rhat = R + B^T Vxx' B.  The sweeps do not keep it; it is formed on the
+ * device, on request, from the knot and stage t+1's Vxx as the last backward left them (pass that sweep's
+ * mueq).  Not available on the stage-dense solver. */
+int gar_hip_get_kkt(gar_hip_solver *s, int b, int t, double mueq, double *out);
 int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx,
                       double *Vxt, double *Vtt, double *vt);
 /* kkt0.ff (nx0+nc0), kkt0.fth ((nx0+nc0) x nth ROW-major), thGrad, thHess */

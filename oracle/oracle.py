@@ -258,6 +258,7 @@ class FactorView:
         self.Shat = _view(f.Shat, (nx, nu))
         self.qhat = _view(f.qhat, (nx,))
         self.rhat = _view(f.rhat, (nu,))
+        self.kktMat = _view(f.kktMat, (nu + nc, nu + nc))   # [Rhat D^T; D -mu I] as handed to Bunch-Kaufman
         self.Vxx = _view(f.vm.Vxx, (nx, nx))
         self.vx = _view(f.vm.vx, (nx,))
         self.Vxt = _view(f.vm.Vxt, (nx, nth))

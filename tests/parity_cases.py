@@ -54,6 +54,12 @@ def compare_factors(hip_datas, ora_solver, N, tol, names=("ff", "fb", "fth"),
             a, b = getattr(f.vm, nm), getattr(o, nm)
             if a.size:
                 assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (t, nm)
+        # StageFactor::kktMat (formed on the device on request: gar_hip_get_kkt).  (nu = 0: the reference's
+        # terminalSolve never assembles it, :146-149)
+        km = getattr(f, "kktMat", None)
+        if km is not None and km.size and f.nu > 0 and "fb" in names:
+            b = o.kktMat
+            assert np.abs(km - b).max() <= max(tol, 1e-9) * max(1.0, np.abs(b).max()), (t, "kktMat")
 
 
 def check_serial(prob, mueq, tol, lib_path=None, theta=None, kkt_tol=None, factors=True):
