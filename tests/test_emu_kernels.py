@@ -429,12 +429,12 @@ def test_parallel_solver_on_the_reference_bench_shape_nc32():
     generation in LDS, Vxt', Vtt', vt' read back from stage t+1's record) fits."""
     nx, nu, nc = 36, 12, 32
     rng = np.random.default_rng(3)
-    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 8, nx, nu, nc=nc, mode="W")
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 5, nx, nu, nc=nc, mode="W")
     pc.check_parallel(prob, 1e-8, 2, 1e-7, EMU)
 
 
 def test_constrained_wave_kernels_decoupled_dense_c_and_alternating_d():
-    pc.check_constrained_decoupled(EMU)
+    pc.check_constrained_decoupled(EMU, shapes=((8, 4, 4, 5, 1e-6), (16, 8, 8, 4, 1e-8), (36, 12, 32, 3, 1e-9)))
 
 
 
@@ -482,7 +482,7 @@ def test_bulk_gains_and_solution_readback(nx, nu, horz, legs):
 @pytest.mark.parametrize("nx,nu,family,dense", [(8, 4, "wave", False), (8, 4, "wg4", False), (5, 2, None, False),
                                                 (12, 4, "wave", False), (6, 3, None, True)])
 def test_cycle_append_is_a_ring(nx, nu, family, dense):
-    s = pc.check_cycle_append_ring(EMU, nx=nx, nu=nu, family=family, dense=dense)
+    s = pc.check_cycle_append_ring(EMU, nx=nx, nu=nu, horz=4, cycles=6, family=family, dense=dense)  # (wraps: cycles > horz)
     if family:
         assert s.kernel_name.startswith("wave<" if family == "wave" else "mfma<")
 
