@@ -231,6 +231,45 @@ def horizon_sharded(args, world, rank, device, dist, N=2048, legs=256, reps=10):
     return out
 
 
+def secondary_shapes(device, batch=1024):
+    """Two more shapes of the same hot path, outside the timed region (rank 0, one GPU), so that the round's
+    bench record carries them: the reference's OWN gar benchmark shape (bench/gar-riccati.cpp:19-22: nx=36,
+    nu=12, nc=32 equality constraints on every knot, mu=1e-11, generator with D=0) and the Talos-walk LQ shape
+    of BASELINE.json configs[4] (bench/talos-walk.cpp:20-28: nx=56, nu=22, N=275).  sweeps/s and the backward
+    kernels' fraction of the HBM roofline on each shape's own algorithmic bytes."""
+    import ctypes as C
+    from aligator_amd import synth
+    from aligator_amd.gar import BatchedRiccatiSolver
+    out = {}
+    for key, (nx, nu, nc, N, mu, what) in {
+            "reference_bench_shape_nc32": (36, 12, 32, 256, 1e-11, "bench/gar-riccati.cpp: nx=36 nu=12 nc=32 N=256, D=0 (its generator)"),
+            "talos_walk_lq_shape": (56, 22, 0, 275, 1e-10, "bench/talos-walk.cpp LQ sub-problem shape: nx=56 nu=22 N=275")}.items():
+        probs = [synth.generate_lq_problem(100 + i, np.zeros(nx), N, nx, nu, nc=nc, mode="W") for i in range(2)]
+        s = BatchedRiccatiSolver([k.dims for k in probs[0].stages], nx, batch=batch, device=device)
+        packed = np.concatenate([s.pack(p) for p in probs])
+        for b0 in range(0, batch, 2):
+            s.upload_packed(packed, b0, 2)
+        s.backward(mu); s.forward(); s.sync()
+        failed = s.num_failed()
+        s._check(s._L.gar_hip_set_timing(s.handle, 1))
+        reps, kb = 3, 0.0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s.backward_async(mu); s.forward_async()
+            o = (C.c_double * 3)()
+            s._check(s._L.gar_hip_last_kernel_ms(s.handle, o))
+            kb += o[0]
+        s.sync()
+        dt = (time.perf_counter() - t0) / reps
+        knot = 2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu + nc * (nx + nu + 1)
+        fac = (nu + nc + nx) * (nx + 1) + nx * nx + nx
+        out[key] = {"workload": what, "batch": batch, "kernel": s.kernel_name, "sweeps_per_s": batch / dt,
+                    "backward_ms": kb / reps, "failed_factorisations": failed,
+                    "backward_frac_of_hbm_roofline": 8 * (knot + fac) * N * batch / (kb / reps * 1e-3) / HBM_PEAK}
+        s.close()
+    return out
+
+
 def parity_check(solver, args, mueq, nsample=2):
     """Spot-check the timed data: pull a few problems back, solve with the oracle."""
     from aligator_amd.gar import lqrComputeKktError
@@ -273,6 +312,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary parallel-in-time figure")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary shapes (constrained, Talos)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the timing barrier (gloo + --same-device lets two "
                          "ranks share one GPU to exercise the N>1 path on a 1-GPU box)")
@@ -432,6 +472,8 @@ def main():
             out["parallel_in_time"] = pit
         if hs is not None:
             out["horizon_sharded"] = hs
+        if world == 1 and not args.no_extras:
+            out["secondary_shapes"] = secondary_shapes(local_rank)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, nx, nu, N, mueq)
         print(json.dumps(out))

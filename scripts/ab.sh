@@ -11,7 +11,7 @@ sys.path.insert(0, ".")
 from aligator_amd import _lib
 _lib.DEFAULT_PATH = "/tmp/lib_ab.so"
 import bench
-sys.argv = ["bench.py", "--steps", "5", "--warmup", "2", "--batch", "1024", "--no-cpu"]
+sys.argv = ["bench.py", "--steps", "5", "--warmup", "2", "--batch", "1024", "--no-cpu", "--no-extras"]
 import io, contextlib
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):

@@ -9,7 +9,7 @@ sys.path.insert(0, ".")
 from aligator_amd import _lib
 _lib.DEFAULT_PATH = os.environ["GAR_AB_LIB"]
 import bench
-sys.argv = ["bench.py", "--steps", "10", "--warmup", "2", "--batch", "$B", "--no-cpu", "--no-legs"]
+sys.argv = ["bench.py", "--steps", "10", "--warmup", "2", "--batch", "$B", "--no-cpu", "--no-legs", "--no-extras"]
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     bench.main()

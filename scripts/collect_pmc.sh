@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; B=${PBATCH:-1024}
 mkdir -p $R/gpurun_out/pmc; export TMPDIR=/tmp; cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc/cal_$C -o cal -- $R/scripts/ubench/memcal > $R/gpurun_out/pmc/cal_$C.log 2>&1
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc/bench_$C -o bench -- python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu --no-legs --single-generator > $R/gpurun_out/pmc/bench_$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc/bench_$C -o bench -- python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu --no-legs --no-extras --single-generator > $R/gpurun_out/pmc/bench_$C.log 2>&1
 done
 cd $R && python scripts/pmc_reduce.py gpurun_out/pmc $B | tee gpurun_out/pmc_traffic.json
 # the raw per-dispatch CSVs are large (gpurun_out is capped at 64 MiB): keep the reductions only

@@ -391,6 +391,10 @@ def test_bench_contract_single_gpu():
         assert key in d["cpu_baseline"], key
     assert d["parity"]["max_rel_err_vs_oracle"] < 1e-9 and d["parity"]["failed_factorisations"] == 0
     assert d["parallel_in_time"]["max_rel_diff_vs_serial"] < 1e-9
+    sec = d["secondary_shapes"]   # the reference's own benchmark shape and the Talos-walk LQ shape
+    assert sec["reference_bench_shape_nc32"]["kernel"] == "wave<36,12,32>" and sec["talos_walk_lq_shape"]["kernel"] == "pair<56,24>"
+    for v in sec.values():
+        assert v["sweeps_per_s"] > 0 and v["failed_factorisations"] == 0 and 0 < v["backward_frac_of_hbm_roofline"] < 1
 
 
 def test_bench_two_ranks_on_one_gpu():
