@@ -380,7 +380,9 @@ __device__ __forceinline__ void ldl_solve_regs_bcast2(const double (&a)[NU], con
 // if BK still takes kp = k everywhere redo the unpivoted factorisation, else run the generic
 // device Bunch-Kaufman exactly as the reference would (interchanges, 2x2 pivots), solving
 // [kff | K] into G2.  Returns 1 if the factorisation failed (zero pivot column).
-template <int NX, int NU, bool PARAM = false>
+// PIVOTS_KNOWN (the round-2 stage, which has evaluated the complete rule in line): straight to the
+// device Bunch-Kaufman, and the 1 + NX right-hand sides on the blocked MFMA solve.
+template <int NX, int NU, bool PARAM = false, bool PIVOTS_KNOWN = false>
 __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int lane, int *slow) {
   using C = WaveCfg<NX, NU>;
   constexpr int PG = C::PG;
@@ -388,8 +390,8 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
   double *Gt = sm + C::oGt; // PARAM: [Ghat_u] -> [Kth], NX columns
   double *Lr = sm + C::oLr, *ndi = sm + C::oDi;
   int failed = 0;
-  int verdict;
-  {
+  int verdict = 1;
+  if (!PIVOTS_KNOWN) {
     double a_row[NU], dinv[NU];
     verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
     if (verdict == 0) {
@@ -450,7 +452,10 @@ __device__ __attribute__((noinline)) int wave_slow_factor_solve(double *sm, int 
     const WG w1 = wave_self();
     wave_sync();
     failed |= wg_bk_factor(w1, NU, Mm, NU, sub, piv, piv + C::BKS);
-    wg_bk_solve(w1, NU, Mm, NU, sub, piv, G2, PG, 1, NX + 1);
+    if constexpr (PIVOTS_KNOWN && NU % 4 == 0 && NX + 1 <= 48)
+      wave_bk_solve_mfma<NU, NX + 1, GAR_COLMAJOR>(Mm, sub, piv, G2, PG, lane);
+    else
+      wg_bk_solve(w1, NU, Mm, NU, sub, piv, G2, PG, 1, NX + 1);
     if (PARAM)
       wg_bk_solve(w1, NU, Mm, NU, sub, piv, Gt, PG, 1, NX);
   }

@@ -796,7 +796,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
         }
     wave_sync();
     if constexpr (NC == 0) // (NC > 0 left above: verdict != 0 returns 0)
-      failed |= wave_slow_factor_solve<NX, NU, false>(sm, lane, nullptr); // (counted by wave_bk_rule_check)
+      failed |= wave_slow_factor_solve<NX, NU, false, true>(sm, lane, nullptr); // (counted above)
 #pragma unroll
     for (int tj = 0; tj < TX; ++tj) {
       const int cc = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
