@@ -1,0 +1,20 @@
+"""Two sweeps each of the secondary shapes of bench.py (the reference's own benchmark shape nc = 32 with D = 0, and the
+Talos-walk LQ shape) at batch 1024: the process rocprofv3 is pointed at by scripts/collect_pmc_secondary.sh."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aligator_amd import synth
+from aligator_amd.gar import BatchedRiccatiSolver
+B = 1024
+for nx, nu, nc, N, mu in ((36, 12, 32, 256, 1e-11), (56, 22, 0, 275, 1e-10)):
+    probs = [synth.generate_lq_problem(100 + i, np.zeros(nx), N, nx, nu, nc=nc, mode="W") for i in range(2)]
+    s = BatchedRiccatiSolver([k.dims for k in probs[0].stages], nx, batch=B)
+    packed = np.concatenate([s.pack(p) for p in probs])
+    for b0 in range(0, B, 2):
+        s.upload_packed(packed, b0, 2)
+    for _ in range(3):
+        s.backward_async(mu); s.forward_async()
+    s.sync()
+    assert s.num_failed() == 0
+    print(s.kernel_name, "ok", flush=True)
+    s.close()
