@@ -324,7 +324,13 @@ def check_second_bunch_kaufman_test(lib_path=None):
     old = os.environ.get("GAR_HIP_BACKWARD")
     os.environ["GAR_HIP_BACKWARD"] = "wave"
     try:
-        for Rm, want in ((keep, (horz, 0)), (pivot, (horz, horz))):
+        # 2x2 pivots on the plain stage's pivoting path: at column 0 with its partner next to it, and at column 1
+        # with the partner two rows down (interchange 2 <-> 3)
+        two = np.array([[0.1, 5.0, 0.0, 0.0], [5.0, 0.2, 1.0, 0.0], [0.0, 1.0, 20.0, 0.1], [0.0, 0.0, 0.1, 4.0]])
+        far = np.array([[10.0, 0.1, 0.1, 0.1], [0.1, 0.05, 0.2, 6.0], [0.1, 0.2, 8.0, 0.1], [0.1, 6.0, 0.1, 0.03]])
+        assert (ora.BunchKaufman(two).pivots < 0).sum() == 2 and (ora.BunchKaufman(far).pivots < 0).sum() == 2
+        assert ora.BunchKaufman(far).pivots[1] == -1 - 3          # partner row 3, moved next to the pivot
+        for Rm, want in ((keep, (horz, 0)), (pivot, (horz, horz)), (two, (horz, horz)), (far, (horz, horz))):
             prob = synth.generate_lq_problem(21, np.zeros(nx), horz, nx, nu, mode="W")
             for k in prob.stages[:-1]:
                 k.R[...] = Rm
