@@ -22,6 +22,7 @@ SIGNATURES = {
     "gar_hip_version": (C.c_char_p, []),
     "gar_hip_last_error": (C.c_char_p, []),
     "gar_hip_device_count": (C.c_int, []),
+    "gar_hip_stream_ceiling_ms": (C.c_double, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int]),
     "gar_hip_knot_doubles": (C.c_int64, [_PI32]),
     "gar_hip_factor_doubles": (C.c_int64, [_PI32]),
     "gar_hip_solver_create": (C.c_void_p, [C.c_int, C.c_int, _PI32, C.c_int, C.c_int, C.c_int]),

@@ -1035,4 +1035,48 @@ __global__ void __launch_bounds__(256) gar_kkt_matrix(const double *knot, gar_kn
   }
 }
 
+// Measurement aid (bench.py's roofline.stream_ceiling): the bytes of a serial-in-time backward sweep WITHOUT
+// its arithmetic.  One wave per problem walks the horizon backwards, reads `in_pieces` 16-byte pieces per
+// stage (the knot; the next one is requested while the current one is consumed), carries a 72-FMA dependent
+// chain per stage and writes `out_pieces` pieces (the factor record).  What this kernel reaches is what HBM
+// sustains for the sweep's read/write mix and walk; no product path calls it.
+typedef double gar_double2 __attribute__((ext_vector_type(2)));
+template <int IN_PL, int OUT_PL>
+__global__ void __launch_bounds__(64) gar_stream_sweep(const gar_double2 *in, gar_double2 *out, double *sink,
+                                                       int nrec, int in_pieces, int out_pieces) {
+  const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
+  gar_double2 cur[IN_PL], nxt[IN_PL];
+  const gar_double2 *pin = in + (size_t)b * nrec * in_pieces;
+  gar_double2 *pout = out + (size_t)b * nrec * out_pieces;
+  auto load = [&](const gar_double2 *p, gar_double2 (&r)[IN_PL]) {
+#pragma unroll
+    for (int q = 0; q < IN_PL; ++q) {
+      const int e = 64 * q + lane;
+      r[q] = p[e < in_pieces ? e : in_pieces - 1];
+    }
+  };
+  load(pin + (size_t)(nrec - 1) * in_pieces, cur);
+  double acc = 0.0;
+  for (int t = nrec - 1; t >= 0; --t) {
+    if (t > 0)
+      load(pin + (size_t)(t - 1) * in_pieces, nxt);
+#pragma unroll
+    for (int q = 0; q < IN_PL; ++q)
+      acc += cur[q].x * 1.0000001 + cur[q].y;
+#pragma unroll 8
+    for (int i = 0; i < 72; ++i)
+      acc = __builtin_fma(acc, 0.999999, 1e-9);
+#pragma unroll
+    for (int q = 0; q < OUT_PL; ++q) {
+      const int e = 64 * q + lane;
+      if (e < out_pieces)
+        pout[(size_t)t * out_pieces + e] = gar_double2{acc, cur[q < IN_PL ? q : 0].x};
+    }
+#pragma unroll
+    for (int q = 0; q < IN_PL; ++q)
+      cur[q] = nxt[q];
+  }
+  sink[(size_t)b * 64 + lane] = acc;
+}
+
 } // namespace gar

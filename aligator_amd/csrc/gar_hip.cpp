@@ -1156,6 +1156,47 @@ extern "C" {
 const char *gar_hip_version(void) { return "gar-hip 0.1 (gfx950)"; }
 const char *gar_hip_last_error(void) { return g_last_error.c_str(); }
 
+double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_bytes_per_stage,
+                                 int64_t out_bytes_per_stage, int reps) {
+  // (north-star records fit the compiled piece counts: <= 32 x 64 x 16 B = 32 KB in, 28 KB out per stage)
+  const int in_pieces = (int)((in_bytes_per_stage + 15) / 16), out_pieces = (int)((out_bytes_per_stage + 15) / 16);
+  if (batch <= 0 || horizon <= 0 || in_pieces <= 0 || out_pieces <= 0 || in_pieces > 32 * 64 || out_pieces > 28 * 64 ||
+      reps <= 0)
+    return -1.0;
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess)
+    return -1.0;
+  gar::gar_double2 *in = nullptr, *out = nullptr;
+  double *sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double best = -1.0;
+  const size_t nin = (size_t)batch * horizon * in_pieces * 16, nout = (size_t)batch * horizon * out_pieces * 16;
+  if (hipMalloc((void **)&in, nin) == hipSuccess && hipMalloc((void **)&out, nout) == hipSuccess &&
+      hipMalloc((void **)&sink, (size_t)batch * 64 * 8) == hipSuccess && hipMemset(in, 0, nin) == hipSuccess &&
+      hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    for (int r = 0; r < reps + 1; ++r) { // first launch: warm-up
+      (void)hipEventRecord(e0, nullptr);
+      hipLaunchKernelGGL((gar::gar_stream_sweep<32, 28>), dim3((unsigned)batch), dim3(64), 0, nullptr, in, out, sink,
+                         horizon, in_pieces, out_pieces);
+      (void)hipEventRecord(e1, nullptr);
+      float ms = 0.f;
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+        best = -1.0;
+        break;
+      }
+      if (r > 0 && (best < 0.0 || ms < best))
+        best = ms;
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(in);
+  (void)hipFree(out);
+  (void)hipFree(sink);
+  (void)hipSetDevice(prev);
+  return best;
+}
+
 int gar_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess)

@@ -270,6 +270,19 @@ def secondary_shapes(device, batch=1024):
     return out
 
 
+def stream_ceiling(solver, device, batch, N, nx, nu, bwd_bytes, bwd_ms):
+    knot_b = 8 * (2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu)
+    fac_b = 8 * ((nu + nx) * (nx + 1) + nx * nx + nx)
+    if knot_b > 32 * 1024 or fac_b > 28 * 1024:
+        return None
+    ms = solver._L.gar_hip_stream_ceiling_ms(int(device), int(batch), int(N), knot_b, fac_b, 3)
+    if ms <= 0:
+        return None
+    return {"ms": ms, "GBps": bwd_bytes * batch / (ms * 1e-3) / 1e9, "frac_of_peak": bwd_bytes * batch / (ms * 1e-3) / HBM_PEAK,
+            "kernel_over_stream": bwd_ms / ms,
+            "note": "a kernel that only moves the backward sweep's bytes (same waves, same walk), measured in this run"}
+
+
 def parity_check(solver, args, mueq, nsample=2):
     """Spot-check the timed data: pull a few problems back, solve with the oracle."""
     from aligator_amd.gar import lqrComputeKktError
@@ -451,6 +464,10 @@ def main():
                                            "(profiles/pmc_traffic.json, scripts/collect_pmc.sh), NOT collected "
                                            "in this run; null when the batch differs",
                          "algorithmic_bytes_per_launch": bwd_b * args.batch,
+                         # what this box's HBM sustains for the backward sweep's bytes alone: the same number of
+                         # one-wave-per-problem streams, per stage the knot read (one ahead in flight) and the
+                         # factor record written, no arithmetic (gar_hip_stream_ceiling_ms, csrc/gar_generic.hpp)
+                         "stream_ceiling": stream_ceiling(solver, local_rank, args.batch, N, nx, nu, bwd_b, bwd_ms),
                          "forward_GBps": fwd_b * args.batch / (fwd_ms * 1e-3) / 1e9,
                          "sweep_frac_of_hbm_roofline": (sweeps / elapsed) * (bwd_b + fwd_b) / HBM_PEAK},
             "parity": {"max_rel_err_vs_oracle": err, "max_kkt": kkt, "failed_factorisations": failed},

@@ -70,6 +70,13 @@ typedef struct gar_hip_solver gar_hip_solver;
 const char *gar_hip_version(void);
 const char *gar_hip_last_error(void);
 int gar_hip_device_count(void);
+/* Measurement aid, no reference counterpart (bench.py's roofline.stream_ceiling): milliseconds (best of `reps`)
+ * that `batch` one-wave-per-problem streams need for the BYTES of a serial-in-time backward sweep and nothing
+ * else -- per stage in_bytes read (one knot ahead in flight), out_bytes written, a 72-FMA dependent chain -- i.e.
+ * what this GPU's HBM sustains for the sweep's read/write mix and walk.  Allocates and frees its own buffers
+ * (batch * horizon * (in + out) bytes); in_bytes <= 32 KiB, out_bytes <= 28 KiB.  Negative on error. */
+double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_bytes_per_stage,
+                                 int64_t out_bytes_per_stage, int reps);
 
 /* ---- layout queries (pure host arithmetic, no GPU needed) ---------------- */
 /* doubles in the packed record of one knot / one factor (csrc/gar_layout.h) */

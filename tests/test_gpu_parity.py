@@ -391,6 +391,8 @@ def test_bench_contract_single_gpu():
         assert key in d["cpu_baseline"], key
     assert d["parity"]["max_rel_err_vs_oracle"] < 1e-9 and d["parity"]["failed_factorisations"] == 0
     assert d["parallel_in_time"]["max_rel_diff_vs_serial"] < 1e-9
+    sc = d["roofline"]["stream_ceiling"]   # the sweep's bytes alone, same run: the kernel cannot beat it by much
+    assert sc["ms"] > 0 and 0.3 < sc["frac_of_peak"] < 1.0 and sc["kernel_over_stream"] > 0.5
     sec = d["secondary_shapes"]   # the reference's own benchmark shape and the Talos-walk LQ shape
     assert sec["reference_bench_shape_nc32"]["kernel"] == "wave<36,12,32>" and sec["talos_walk_lq_shape"]["kernel"] == "pair<56,24>"
     for v in sec.values():
