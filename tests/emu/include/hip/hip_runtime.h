@@ -209,6 +209,7 @@ inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)std::malloc(1
 inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 
