@@ -37,12 +37,12 @@ template <int MODE> __global__ void __launch_bounds__(64) sweep(const double2_t 
 // The backward sweep's mix: per stage 29 472 B read (the knot) and 24 864 B written (the factor record), one knot in
 // flight per wave.
 constexpr int KNOT = 29472 / 16, KPL = (KNOT + 63) / 64; // 1842 pieces, 29 per lane
-__global__ void __launch_bounds__(64) sweep_rw(const double2_t *in, double2_t *outrec, double *out, int nrec) {
+template <int NT> __global__ void __launch_bounds__(64) sweep_rw(const double2_t *in, double2_t *outrec, double *out, int nrec) {
   const int b = blockIdx.x, lane = threadIdx.x;
   double2_t cur[KPL], nxt[KPL];
   auto load = [&](const double2_t *p, double2_t (&r)[KPL]) {
 #pragma unroll
-    for (int q = 0; q < KPL; ++q) { const int e = 64 * q + lane; r[q] = p[e < KNOT ? e : KNOT - 1]; }
+    for (int q = 0; q < KPL; ++q) { const int e = 64 * q + lane; const double2_t *a = &p[e < KNOT ? e : KNOT - 1]; r[q] = (NT & 1) ? __builtin_nontemporal_load(a) : *a; }
   };
   const double2_t *pin = in + (size_t)b * nrec * KNOT;
   double2_t *pout = outrec + (size_t)b * nrec * REC;
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(64) sweep_rw(const double2_t *in, double2_t *o
 #pragma unroll 8
     for (int i = 0; i < 72; ++i) acc = __builtin_fma(acc, 0.999999, 1e-9);
 #pragma unroll
-    for (int q = 0; q < PER_LANE; ++q) { const int e = 64 * q + lane; if (e < REC) pout[(size_t)t * REC + e] = double2_t{acc, cur[q].x}; }
+    for (int q = 0; q < PER_LANE; ++q) { const int e = 64 * q + lane; if (e < REC) { double2_t v = double2_t{acc, cur[q].x}; if (NT & 2) __builtin_nontemporal_store(v, &pout[(size_t)t * REC + e]); else pout[(size_t)t * REC + e] = v; } }
 #pragma unroll
     for (int q = 0; q < KPL; ++q) cur[q] = nxt[q];
   }
@@ -80,12 +80,16 @@ int main() {
   {
     double2_t *kin; CHECK(hipMalloc(&kin, (size_t)batch * nrec * KNOT * 16)); CHECK(hipMemset(kin, 0, (size_t)batch * nrec * KNOT * 16));
     const double tot = (double)batch * nrec * (KNOT + REC) * 16;
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int nt = 0; nt < 4; ++nt)
+    for (int rep = 0; rep < 2; ++rep) {
       CHECK(hipEventRecord(e0));
-      hipLaunchKernelGGL(sweep_rw, dim3(batch), dim3(64), 0, 0, kin, buf, out, nrec);
+      if (nt == 0) hipLaunchKernelGGL(sweep_rw<0>, dim3(batch), dim3(64), 0, 0, kin, buf, out, nrec);
+      if (nt == 1) hipLaunchKernelGGL(sweep_rw<1>, dim3(batch), dim3(64), 0, 0, kin, buf, out, nrec);
+      if (nt == 2) hipLaunchKernelGGL(sweep_rw<2>, dim3(batch), dim3(64), 0, 0, kin, buf, out, nrec);
+      if (nt == 3) hipLaunchKernelGGL(sweep_rw<3>, dim3(batch), dim3(64), 0, 0, kin, buf, out, nrec);
       CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-      printf("%-14s rep %d: %7.3f ms  %6.2f TB/s  (29 472 B read + 24 864 B written per stage: the backward sweep's bytes)\n", "read+write", rep, ms, tot / (ms * 1e-3) / 1e12);
+      printf("%-14s nt-load %d nt-store %d rep %d: %7.3f ms  %6.2f TB/s  (29 472 B read + 24 864 B written per stage: the backward sweep's bytes)\n", "read+write", nt & 1, (nt >> 1) & 1, rep, ms, tot / (ms * 1e-3) / 1e12);
     }
   }
   return 0;
