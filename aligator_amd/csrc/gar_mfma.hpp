@@ -657,9 +657,18 @@ __device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *f
       S.gz[m] = *reinterpret_cast<const double2_t *>(rec + C::fFB + m * 2 * NW + 2 * rz);
     S.ffz = rec[C::fFF + rz];
   }
+  // Vxx' is symmetric: row iv = its lower-triangle part (column j, row iv, coalesced over the lanes iv >= j)
+  // followed by the part of COLUMN iv below the diagonal (this lane's own contiguous run) -- only the lower
+  // triangle of the record is read
+#ifndef GAR_FWD_FULL_VXX
+#pragma unroll
+  for (int j = 0; j < NX; ++j)
+    S.vrow[j] = recn[oVn + (iv >= j ? j * NX + iv : iv * NX + j)];
+#else
 #pragma unroll
   for (int j = 0; j < NX; ++j)
     S.vrow[j] = recn[oVn + j * NX + iv]; // Vxx' symmetric: column j, row iv
+#endif
   S.ff = rec[C::fFF + r];
   S.vxn = recn[ovn + iv];
 }
