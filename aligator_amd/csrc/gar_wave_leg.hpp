@@ -1025,7 +1025,7 @@ __device__ __forceinline__ void leg_fwd_load(const double *rec, const double *re
   if (with_next) {
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
-      S.vrow[j] = recn[oVn + j * NX + iv]; // symmetric: column j, row iv
+      S.vrow[j] = recn[oVn + (iv >= j ? j * NX + iv : iv * NX + j)]; // symmetric: the lower triangle only (as gar_mfma.hpp::fwd_load)
       if (PARAM)
         S.trow[j] = recn[C::pVxt + j * NX + iv];
     }
