@@ -92,5 +92,18 @@ int main() {
       printf("%-14s nt-load %d nt-store %d rep %d: %7.3f ms  %6.2f TB/s  (29 472 B read + 24 864 B written per stage: the backward sweep's bytes)\n", "read+write", nt & 1, (nt >> 1) & 1, rep, ms, tot / (ms * 1e-3) / 1e12);
     }
   }
+  { // the same read+write stream at ONE wave per SIMD (what the backward kernel's registers allow): 40 KB of
+    // dynamic LDS per workgroup -> four workgroups per CU
+    double2_t *kin; CHECK(hipMalloc(&kin, (size_t)batch * nrec * KNOT * 16)); CHECK(hipMemset(kin, 0, (size_t)batch * nrec * KNOT * 16));
+    const double tot = (double)batch * nrec * (KNOT + REC) * 16;
+    CHECK(hipFuncSetAttribute((const void *)sweep_rw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
+    for (int rep = 0; rep < 3; ++rep) {
+      CHECK(hipEventRecord(e0));
+      hipLaunchKernelGGL(sweep_rw<0>, dim3(batch), dim3(64), 40 * 1024, 0, kin, buf, out, nrec);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      printf("%-14s 1 wave/SIMD rep %d: %7.3f ms  %6.2f TB/s\n", "read+write", rep, ms, tot / (ms * 1e-3) / 1e12);
+    }
+  }
   return 0;
 }
