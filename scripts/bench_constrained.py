@@ -47,6 +47,10 @@ cores = os.cpu_count() or 1
 many = [ora.Problem.from_knots(p.stages, p.G0, p.g0, native=True) for p in (probs * cores)[:2 * cores]]
 bs = ora.BatchSweep(many)
 threads = bs.max_threads()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import cpu_quota_cores   # (the pool's boxes: 256 logical CPUs, a 16-CPU cgroup quota)
+if cpu_quota_cores() is not None:
+    threads = max(1, min(threads, cpu_quota_cores()))
 bs.sweep(mueq, threads)
 t0 = time.perf_counter(); reps = 0
 while time.perf_counter() - t0 < 8.0:
