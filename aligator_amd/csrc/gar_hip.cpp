@@ -1685,11 +1685,27 @@ int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
     return rc;
   const size_t nsol = (size_t)s->sol_doubles, ngain = (size_t)(s->ff_all_doubles + s->fb_all_doubles);
   if (!s->h_results) { // first use: the buffers live as long as the solver's layout
-    HIP_TRY(hipHostMalloc((void **)&s->h_results, sizeof(double) * (nsol + ngain), hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&s->d_gains, sizeof(double) * std::max<size_t>(ngain, 1)));
-    HIP_TRY(hipMalloc((void **)&s->d_gain_off, sizeof(long long) * s->gain_off.size()));
-    HIP_TRY(hipMemcpyAsync(s->d_gain_off, s->gain_off.data(), sizeof(long long) * s->gain_off.size(),
-                           hipMemcpyHostToDevice, s->stream));
+    // all three or none: a partial failure must not leave h_results set with the device buffers missing
+    double *h = nullptr, *dg = nullptr;
+    long long *dgo = nullptr;
+    hipError_t e = hipHostMalloc((void **)&h, sizeof(double) * (nsol + ngain), hipHostMallocDefault);
+    if (e == hipSuccess)
+      e = hipMalloc((void **)&dg, sizeof(double) * std::max<size_t>(ngain, 1));
+    if (e == hipSuccess)
+      e = hipMalloc((void **)&dgo, sizeof(long long) * s->gain_off.size());
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(dgo, s->gain_off.data(), sizeof(long long) * s->gain_off.size(), hipMemcpyHostToDevice,
+                         s->stream);
+    if (e != hipSuccess) {
+      if (h)
+        (void)hipHostFree(h);
+      (void)hipFree(dg);
+      (void)hipFree(dgo);
+      return fail(GAR_HIP_ERR_DEVICE, std::string("gar_hip_fetch_results: ") + hipGetErrorString(e));
+    }
+    s->h_results = h;
+    s->d_gains = dg;
+    s->d_gain_off = dgo;
   }
   if (what & 2) { // device-side gather (fbT2 -> row-major), then ONE device-to-host copy
     const bool t2 = s->fb_t2;

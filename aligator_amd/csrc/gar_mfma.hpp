@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       int verdict = wave_ldl_lean<NU>(Mm, lane, a_row, dinv);
       if (verdict != 0) { // rare: evaluate the complete Bunch-Kaufman rule
         verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
-        if (threadIdx.x == 0) {
+        if (lane == 0) { // (this code runs in wave 3 only: threadIdx.x == 0 never gets here)
           atomicAdd(&P.slow[0], 1);
           if (verdict != 0)
             atomicAdd(&P.slow[1], 1);

@@ -58,6 +58,54 @@ def test_parallel_solver_on_the_reference_bench_shape_nc32(legs):
     pc.check_parallel(prob, 1e-8, legs, 1e-7)
 
 
+SOAK_FAILURES = [(101, 353783436, None, 42, 2), (2026, 755480262, "constrained", 22, 8)]
+
+
+@pytest.mark.parametrize("soak_seed,inner_seed,focus,horz,legs", SOAK_FAILURES)
+def test_soak_failures_replayed_and_arbitrated(soak_seed, inner_seed, focus, horz, legs, capsys):
+    """The two round-2 soak failures (profiles/r02_soak_gpu.log:8, r02_soak_constrained_gpu.log:2; nx = 36,
+    nu = 12, nc = 32 in leg mode at mu = 1e-8), replayed exactly (tests/soak_draws.py) and arbitrated four
+    ways: HIP-leg, oracle-leg, oracle-serial, LAPACK on the global dense KKT matrix.  The log line says which
+    pairs disagree.  Finding (same on the wave emulator): x and u agree to 1e-15 between ALL FOUR; v and lambda
+    (of order 1/mu) differ by 1e-7 ... 2e-6 relative between ANY two of them, oracle-serial vs LAPACK
+    included -- conditioning, not a kernel: HIP-leg is no outlier.  The check therefore bounds HIP-leg by what
+    the problem's conditioning allows (pc.check_parallel(conditioned=True)) -- and x, u at the plain tolerance."""
+    from soak_draws import find_draw
+    d = find_draw(soak_seed, inner_seed, focus)
+    assert (d["nx"], d["nu"], d["nc"], d["horz"], d["legs"]) == (36, 12, 32, horz, legs)
+    mu = max(d["mu"], 1e-8)                                     # the value the failing run used
+    rep = {}
+    pc.check_parallel(d["prob"], mu, legs, 1e-8, conditioned=True, report=rep)
+    with capsys.disabled():
+        print(f"\nsoak replay seed={inner_seed} N={horz} legs={legs} mu={mu:.1e} scale={rep['scale']:.2e}  (x, u, v, lambda) relative:")
+        for k in ("hip_leg-oracle_leg", "hip_leg-oracle_serial", "hip_leg-lapack", "oracle_leg-oracle_serial",
+                  "oracle_leg-lapack", "oracle_serial-lapack"):
+            print(f"  {k:26s}", " ".join(f"{v:.2e}" for v in rep[k]))
+        print(f"  kkt/scale: hip_leg {rep['kkt_hip_leg']:.2e} oracle_leg {rep['kkt_oracle_leg']:.2e}")
+    # x and u are well determined: every pair within 1e-12
+    for k in ("hip_leg-oracle_leg", "hip_leg-oracle_serial", "hip_leg-lapack"):
+        assert max(rep[k][:2]) <= 1e-12, (k, rep[k])
+    # HIP-leg is no outlier: no farther from LAPACK than 4 x the worst of the CPU solvers among themselves
+    cpu = max(max(rep[k][2:]) for k in ("oracle_leg-oracle_serial", "oracle_leg-lapack", "oracle_serial-lapack"))
+    assert max(rep["hip_leg-lapack"][2:]) <= 4 * cpu, (rep["hip_leg-lapack"], cpu)
+
+
+def test_constrained_bench_shape_full_factors_at_benchmark_size():
+    """The reference's own benchmark configuration at its benchmark SIZE and mu (bench/gar-riccati.cpp:19-22,
+    53-62: nx = 36, nu = 12, nc = 32, N = 256, mu = 1e-11): every factor block of every stage, kkt0 and the
+    solution against the oracle.  Multipliers and Vxx are O(1/mu) here; errors are relative to each block's
+    scale (the reference's bench never checks residuals)."""
+    nx, nu, nc, N, mu = 36, 12, 32, 256, 1e-11
+    rng = np.random.default_rng(19)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), N, nx, nu, nc=nc, mode="W")
+    solver, sol, ref = pc.check_serial(prob, mu, 1e-7, factors=True)
+    assert solver.kernel_name == "wave<36,12,32>"
+    bound, _ = pc.conditioning_bound(prob, mu, ref)
+    sc = pc.scale_of(ref)
+    err = [pc.maxdiff(a, b) / sc for a, b in zip(sol, ref)]
+    print(f"nc=32 N=256 mu=1e-11: hip-oracle {err}, oracle-lapack {bound}, scale {sc:.2e}")
+
+
 def test_constrained_decoupled_dense_c_and_alternating_d():
     """D = 0 stages (gar_wave2.hpp, NC > 0) with a dense C, and sweeps that alternate between the decoupled
     stage and the (NU+NC) Bunch-Kaufman stage."""

@@ -254,3 +254,29 @@ def test_get_work_partition(oracle):
             b, e = oracle.get_work(horz, i, nt)
             cover += list(range(b, e))
         assert cover == list(range(horz + 1))
+
+
+@pytest.mark.parametrize("soak_seed,inner_seed,focus,legs", [(101, 353783436, None, 2), (2026, 755480262, "constrained", 8)])
+def test_soak_failures_are_conditioning_on_the_cpu_side(oracle, soak_seed, inner_seed, focus, legs):
+    ora = oracle
+    """The CPU half of tests/test_gpu_parity.py::test_soak_failures_replayed_and_arbitrated: on the two
+    round-2 soak draws (nc = 32, leg mode, mu = 1e-8) the oracle's serial and leg-parallel solutions and LAPACK
+    on the dense KKT matrix agree to 1e-14 in x, u and differ by 1e-8 ... 3e-6 (relative to the O(1/mu)
+    multipliers) in v, lambda -- the spread any fourth solver has to be judged against."""
+    import parity_cases as pc
+    from soak_draws import find_draw
+    from aligator_amd.lqr import lqrInitializeSolution
+    d = find_draw(soak_seed, inner_seed, focus)
+    prob, mu = d["prob"], max(d["mu"], 1e-8)
+    _, _, ref = pc.oracle_serial(prob, mu)
+    bound, lap = pc.conditioning_bound(prob, mu, ref)
+    opar = ora.ParallelRiccatiSolver(pc.to_oracle(prob), legs)
+    opar.maxRefinementSteps = 10
+    opar.backward(mu)
+    osol = lqrInitializeSolution(prob)
+    opar.forward(*osol)
+    sc = pc.scale_of(ref)
+    leg = [pc.maxdiff(a, b) / sc for a, b in zip(osol, ref)]
+    assert sc > 1e9                                           # multipliers of order 1/mu
+    assert max(bound[:2]) < 1e-13 and max(leg[:2]) < 1e-13    # x, u: well determined
+    assert 1e-8 < max(bound[2:]) < 1e-5 and max(leg[2:]) < 1e-5
