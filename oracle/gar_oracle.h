@@ -9,12 +9,23 @@
  * call into this library.  The product path (aligator_amd/, include/) never
  * links, imports or executes anything from oracle/.
  *
- * PARITY STATUS: "parity unpinned" with respect to the reference *binary*:
- * the reference needs Eigen 3.4 (absent in this image, no network) so it can
- * not be executed here, and it ships no golden vectors for this path
- * (SURVEY.md section 8c).  The oracle is pinned instead by (1) the reference's
- * own test thresholds (KKT residuals, serial-vs-parallel agreement), and
- * (2) an independent LAPACK dense-KKT solve (oracle/dense_kkt.py).
+ * PARITY STATUS: PINNED against the reference's own code.  Eigen 3.4 is absent
+ * from this image, so the reference *binary* (Eigen's GEMM kernels included)
+ * cannot be produced; but the reference's OWN gar sources -- core/bunchkaufman.hpp,
+ * gar/riccati-kernel.hxx, gar/proximal-riccati.hxx, gar/parallel-solver.hxx,
+ * gar/block-tridiagonal.hpp, gar/lqr-problem.hxx, core/arena-matrix.hpp,
+ * core/blk-matrix.hpp -- compile UNCHANGED from /root/reference over a minimal
+ * Eigen-API stand-in (oracle/ref_shim, eager evaluation; oracle/ref_build.sh ->
+ * oracle/_ref/libgar_ref.so) and this oracle is checked against them live
+ * (tests/test_ref_pin.py: Bunch-Kaufman pivot sequences identical over 300
+ * matrices incl. the blocked n > 32 path; solution, every StageFactor block,
+ * kkt0, thGrad/thHess, leg-parallel factors, condensed solution, collapsed K0 to
+ * rounding) and against the committed outputs of that build
+ * (tests/golden/ref/*.npz, tests/test_golden.py).  What the stand-in cannot
+ * reproduce is the association order of sums inside Eigen's product kernels --
+ * the difference between any two BLAS.  Further pins: the reference's own test
+ * thresholds (tests/test_oracle.py) and an independent LAPACK dense-KKT solve
+ * (oracle/dense_kkt.py, tests/golden/*.npz).
  *
  * Data model mirrors the reference: every matrix is its own column-major
  * allocation (LqrKnotTpl, lqr-problem.hpp:34-103); ff/fb/fth, AtV and BtV are

@@ -4,8 +4,9 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  It wraps oracle/gar_oracle.c (a plain-C restatement of the
 reference's gar algorithm, see gar_oracle.h for the file:line map).
 
-Parity status: "parity unpinned" against the reference binary (Eigen absent);
-pinned by the reference's test thresholds and by dense_kkt.py (LAPACK).
+Parity status: PINNED against the reference's own gar sources compiled unchanged over
+oracle/ref_shim (oracle/ref.py, tests/test_ref_pin.py, tests/golden/ref/*.npz); see gar_oracle.h.
+Also by the reference's test thresholds and by dense_kkt.py (LAPACK).
 """
 from __future__ import annotations
 
