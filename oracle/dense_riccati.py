@@ -3,10 +3,11 @@ stage-dense solver: `RiccatiSolverDense` (include/aligator/gar/dense-riccati.hpp
 dense-riccati.hxx:12-148) over `DenseKernel` (include/aligator/gar/dense-kernel.hpp:13-210).
 
 Restated in numpy, statement by statement; the factorisation is the oracle's restatement of the
-in-tree Bunch-Kaufman (core/bunchkaufman.hpp, `oracle.BunchKaufman`).  Parity unpinned against
-the reference BINARY (Eigen is not installed here): pinned instead against
-the independent LAPACK dense-KKT solve (oracle/dense_kkt.py) and the Riccati oracle, at the
-reference's own bar for this solver (tests/gar/riccati.cpp:141-155: KKT error <= 1e-8).
+in-tree Bunch-Kaufman (core/bunchkaufman.hpp, `oracle.BunchKaufman`).  Pinned against the reference's OWN
+RiccatiSolverDense, compiled unchanged over oracle/ref_shim (tests/test_ref_pin.py::test_stage_dense_solver_*:
+solution, [K; Z; L; Y] rows, Pxx..pt, kkt0 to rounding), and against the independent LAPACK dense-KKT solve
+(oracle/dense_kkt.py) and the Riccati oracle at the reference's own bar for this solver
+(tests/gar/riccati.cpp:141-155: KKT error <= 1e-8).
 
 One documented difference: `DenseKernel::terminalSolve` factorises the WHOLE (nu+nc+2 nx2)^2
 matrix, whose last 2 nx2 rows are zero (dense-kernel.hpp:57-74); the reference's Bunch-Kaufman

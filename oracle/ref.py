@@ -54,6 +54,13 @@ def lib():
         L.ref_parallel_collapse_feedback.argtypes = [C.c_void_p]
         L.ref_parallel_condensed_dim.argtypes = [C.c_void_p]
         L.ref_parallel_condensed_solution.argtypes = [C.c_void_p, _PD]
+        L.ref_dense_new.restype = C.c_void_p
+        L.ref_dense_new.argtypes = [C.c_void_p]
+        L.ref_dense_free.argtypes = [C.c_void_p]
+        L.ref_dense_backward.argtypes = [C.c_void_p, C.c_double]
+        L.ref_dense_forward.argtypes = [C.c_void_p, C.c_void_p, _PD, _PD, _PD, _PD, _PD]
+        L.ref_dense_factor.argtypes = [C.c_void_p, C.c_int, C.c_int, _PD]
+        L.ref_dense_initial.argtypes = [C.c_void_p, C.c_int, _PD]
         L.ref_bk_compute.argtypes = [C.c_int, _PD, _PD, _PD, C.POINTER(C.c_int)]
         L.ref_bk_solve.argtypes = [C.c_int, _PD, C.c_int, _PD]
         L.ref_block_tridiag_solve.argtypes = [C.c_int, C.POINTER(C.c_int), _PD, _PD, _PD, _PD, C.c_int]
@@ -227,6 +234,57 @@ class ParallelRiccatiSolver(_SolverBase):
     def condensed_solution(self):
         out = np.zeros(lib().ref_parallel_condensed_dim(self._h))
         lib().ref_parallel_condensed_solution(self._h, _p(out))
+        return out
+
+
+class RiccatiSolverDense:
+    """aligator::gar::RiccatiSolverDense<double> (gar/dense-riccati.hxx over gar/dense-kernel.hpp)."""
+
+    def __init__(self, problem: Problem):
+        self.problem = problem
+        self._h = lib().ref_dense_new(problem._h)
+
+    def __del__(self):
+        try:
+            lib().ref_dense_free(self._h)
+        except Exception:
+            pass
+
+    def backward(self, mueq: float) -> bool:
+        rc = lib().ref_dense_backward(self._h, float(mueq))
+        if rc < 0:
+            raise RuntimeError(lib().ref_last_error().decode())
+        return rc == 0
+
+    def forward(self, theta=None):
+        nx, nu, nc, nl = self.problem.sizes()
+        xs, us, vs, ls = np.zeros(nx), np.zeros(nu), np.zeros(nc), np.zeros(nl)
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        lib().ref_dense_forward(self._h, self.problem._h, _p(th) if th is not None else None, _p(xs), _p(us), _p(vs), _p(ls))
+        return self.problem.split(xs, us, vs, ls)
+
+    def datas(self, t):
+        """ff, fb, ft with rows [K; Z; L; Y] and Pxx, px, Pxt, Ptt, pt of stage t."""
+        nx, nu, nc, nx2, nth = (int(v) for v in self.problem.dims[t])
+        n = nu + nc + 2 * nx2
+        f = _Factor()
+        for what, (nm, shp) in enumerate((("ff", (n,)), ("fb", (n, nx)), ("ft", (n, nth)), ("Pxx", (nx, nx)), ("px", (nx,)),
+                                          ("Pxt", (nx, nth)), ("Ptt", (nth, nth)), ("pt", (nth,)))):
+            a = np.zeros(shp, order="F")
+            if a.size:
+                lib().ref_dense_factor(self._h, t, what, _p(a))
+            setattr(f, nm, np.ascontiguousarray(a))
+        return f
+
+    def initial(self):
+        nx0, nth = int(self.problem.dims[0, 0]), int(self.problem.dims[0, 4])
+        n0 = nx0 + self.problem.nc0
+        out = []
+        for what, shp in enumerate(((n0,), (n0, nth), (nth,), (nth, nth))):
+            a = np.zeros(shp, order="F")
+            if a.size:
+                lib().ref_dense_initial(self._h, what, _p(a))
+            out.append(np.ascontiguousarray(a))
         return out
 
 

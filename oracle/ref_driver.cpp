@@ -6,6 +6,7 @@
 //   aligator::gar::LqrProblemTpl / LqrKnotTpl                 (gar/lqr-problem.hpp, .hxx)
 //   aligator::gar::ProximalRiccatiSolver                      (gar/proximal-riccati.hpp, .hxx -> riccati-kernel.hxx)
 //   aligator::gar::ParallelRiccatiSolver                      (gar/parallel-solver.hpp, .hxx -> block-tridiagonal.hpp)
+//   aligator::gar::RiccatiSolverDense                         (gar/dense-riccati.hpp, .hxx -> dense-kernel.hpp)
 //   aligator::BunchKaufman                                    (core/bunchkaufman.hpp)
 //   aligator::gar::symmetricBlockTridiagSolve                 (gar/block-tridiagonal.hpp)
 #define ALIGATOR_MULTITHREADING
@@ -18,6 +19,7 @@
 #include "aligator/gar/proximal-riccati.hxx"
 #include "aligator/gar/parallel-solver.hxx"
 #include "aligator/gar/block-tridiagonal.hpp"
+#include "aligator/gar/dense-riccati.hxx"
 
 #include <cstring>
 #include <memory>
@@ -28,6 +30,7 @@ using Problem = gar::LqrProblemTpl<double>;
 using Knot = gar::LqrKnotTpl<double>;
 using Serial = gar::ProximalRiccatiSolver<double>;
 using Parallel = gar::ParallelRiccatiSolver<double>;
+using DenseSolver = gar::RiccatiSolverDense<double>;
 using VectorXs = Eigen::Matrix<double, Eigen::Dynamic, 1>;
 using MatrixXs = Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic>;
 
@@ -215,6 +218,60 @@ void ref_parallel_factor(void *s, int t, int what, double *out) { factor_out(*st
 void ref_parallel_collapse_feedback(void *s) { static_cast<Parallel *>(s)->collapseFeedback(); }
 int ref_parallel_condensed_dim(void *s) { return int(static_cast<Parallel *>(s)->condensedKktSolution.size()); }
 void ref_parallel_condensed_solution(void *s, double *out) { put(static_cast<Parallel *>(s)->condensedKktSolution, out); }
+
+// ---- RiccatiSolverDense ------------------------------------------------------------------------------------------
+void *ref_dense_new(void *pp) { return new DenseSolver(*static_cast<Problem *>(pp)); }
+void ref_dense_free(void *s) { delete static_cast<DenseSolver *>(s); }
+int ref_dense_backward(void *s, double mueq) {
+  try {
+    return static_cast<DenseSolver *>(s)->backward(mueq) ? 0 : 1;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int ref_dense_forward(void *sp, void *pp, const double *theta, double *xs, double *us, double *vs, double *lbdas) {
+  auto *s = static_cast<DenseSolver *>(sp);
+  const Problem &p = *static_cast<Problem *>(pp);
+  Sol sol(p);
+  bool ok;
+  if (theta && p.ntheta() > 0) {
+    VectorXs th(Eigen::Index(p.ntheta()));
+    get(th, theta);
+    Eigen::Ref<const VectorXs> thr(th);
+    ok = s->forward(sol.xs, sol.us, sol.vs, sol.lbdas, thr);
+  } else {
+    ok = s->forward(sol.xs, sol.us, sol.vs, sol.lbdas);
+  }
+  flatten(sol.xs, xs); flatten(sol.us, us); flatten(sol.vs, vs); flatten(sol.lbdas, lbdas);
+  return ok ? 0 : 1;
+}
+// what: 0 ff, 1 fb, 2 fth (rows [K; Z; L; Y]), 3 Pxx, 4 px, 5 Pxt, 6 Ptt, 7 pt
+void ref_dense_factor(void *sp, int t, int what, double *out) {
+  auto *s = static_cast<DenseSolver *>(sp);
+  auto &d = s->stage_factors[size_t(t)];
+  switch (what) {
+  case 0: put(d.ff.matrix(), out); break;
+  case 1: put(d.fb.matrix(), out); break;
+  case 2: put(d.ft.matrix(), out); break;
+  case 3: put(s->Pxx[size_t(t)], out); break;
+  case 4: put(s->px[size_t(t)], out); break;
+  case 5: put(s->Pxt[size_t(t)], out); break;
+  case 6: put(s->Ptt[size_t(t)], out); break;
+  case 7: put(s->pt[size_t(t)], out); break;
+  default: break;
+  }
+}
+void ref_dense_initial(void *sp, int what, double *out) {
+  auto *s = static_cast<DenseSolver *>(sp);
+  switch (what) {
+  case 0: put(s->kkt0.ff.matrix(), out); break;
+  case 1: put(s->kkt0.fth.matrix(), out); break;
+  case 2: put(s->thGrad, out); break;
+  case 3: put(s->thHess, out); break;
+  default: break;
+  }
+}
 
 // ---- BunchKaufman ---------------------------------------------------------------------------------------------
 int ref_bk_compute(int n, const double *A, double *ldlt, double *subdiag, int *pivots) {

@@ -157,3 +157,47 @@ def test_block_tridiagonal_solves(oracle):
         ok2, x2 = oracle.block_tridiag_solve(sub, diag, sup, rhs, down)
         assert ok1 and ok2
         assert max(np.abs(a - b).max() for a, b in zip(x1, x2)) <= 1e-13
+
+
+def test_stage_dense_solver_oracle_equals_reference_code():
+    """oracle/dense_riccati.py (numpy restatement of gar/dense-kernel.hpp, dense-riccati.hxx) against the reference's
+    RiccatiSolverDense itself: solution, [K; Z; L; Y] rows of ff / fb / ft, Pxx / px / Pxt / Ptt / pt of every stage,
+    kkt0, thGrad / thHess.  (Terminal knot with nu = nc = 0, as in the reference's test and benchmark: with a
+    constrained terminal knot the reference factorises a matrix with zero rows, see oracle/dense_riccati.py.)"""
+    from oracle.dense_riccati import RiccatiSolverDense as OracleDense
+    rng = np.random.default_rng(21)
+    par, theta = _parametric()
+    cases = [(synth.generate_lq_problem(5, np.zeros(36), 12, 36, 12, mode="W"), 1e-12, None, 1e-11),
+             (synth.generate_lq_problem(6, np.zeros(8), 20, 8, 3, mode="F"), 1e-12, None, 1e-9),
+             (par, 1e-12, theta, 1e-10)]
+    c = _constrained(6, 3, 4, 9, 31)
+    last = c.stages[-1]
+    from aligator_amd.lqr import LqrKnot, LqrProblem
+    term = LqrKnot(last.nx, 0, 0)
+    term.Q[...], term.q[...] = last.Q, last.q
+    cp = LqrProblem(c.stages[:-1] + [term], c.nc0)
+    cp.G0[...], cp.g0[...] = c.G0, c.g0
+    cases.append((cp, 1e-7, None, 1e-10))
+    for prob, mu, th, tol in cases:
+        rs = ref.RiccatiSolverDense(ref.Problem(prob))
+        assert rs.backward(mu)
+        rsol = rs.forward(th)
+        o = OracleDense(prob, terminal_leading_block=False)
+        o.backward(mu)
+        osol = lqrInitializeSolution(prob)
+        o.forward(*osol, th)
+        sc = pc.scale_of(osol)
+        for a, b in zip(rsol, osol):
+            assert pc.maxdiff(a, b) <= tol * sc
+        for t in range(prob.horizon + 1):
+            f, d = rs.datas(t), o.stage_factors[t]
+            if t < prob.horizon:
+                for a, b in ((f.ff, d.ff), (f.fb, d.fb), (f.ft, d.ft)):
+                    if a.size:
+                        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), t
+            for a, b in ((f.Pxx, o.Pxx[t]), (f.px, o.px[t]), (f.Pxt, o.Pxt[t]), (f.Ptt, o.Ptt[t]), (f.pt, o.pt[t])):
+                if a.size:
+                    assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), t
+        for a, b in zip(rs.initial(), (o.kkt0_ff, o.kkt0_fth, o.thGrad, o.thHess)):
+            if a.size:
+                assert np.abs(a - np.asarray(b).reshape(a.shape)).max() <= tol * max(1.0, np.abs(b).max())
