@@ -23,11 +23,14 @@ SIGNATURES = {
     "gar_hip_last_error": (C.c_char_p, []),
     "gar_hip_device_count": (C.c_int, []),
     "gar_hip_stream_ceiling_ms": (C.c_double, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int]),
+    "gar_hip_copy_ceiling_ms": (C.c_double, [C.c_int, C.c_int64, C.c_int]),
     "gar_hip_knot_doubles": (C.c_int64, [_PI32]),
     "gar_hip_factor_doubles": (C.c_int64, [_PI32]),
     "gar_hip_solver_create": (C.c_void_p, [C.c_int, C.c_int, _PI32, C.c_int, C.c_int, C.c_int]),
     "gar_hip_solver_create_sharded": (C.c_void_p, [C.c_int, C.c_int, _PI32, C.c_int, C.c_int,
                                                    C.c_int, C.c_int, C.c_int]),
+    "gar_hip_solver_create_ranked": (C.c_void_p, [C.c_int, C.c_int, _PI32, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int, C.c_int]),
     "gar_hip_solver_create_dense": (C.c_void_p, [C.c_int, C.c_int, _PI32, C.c_int, C.c_int]),
     "gar_hip_solver_destroy": (None, [C.c_void_p]),
     "gar_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -48,6 +51,8 @@ SIGNATURES = {
     "gar_hip_device_problems": (C.c_void_p, [C.c_void_p]),
     "gar_hip_device_factors": (C.c_void_p, [C.c_void_p]),
     "gar_hip_device_solutions": (C.c_void_p, [C.c_void_p]),
+    "gar_hip_device_stage_layout": (C.c_int, [C.c_void_p, C.c_int, _PI64]),
+    "gar_hip_device_sizes": (C.c_int, [C.c_void_p, _PI64]),
     "gar_hip_backward": (C.c_int, [C.c_void_p, C.c_double]),
     "gar_hip_backward_async": (C.c_int, [C.c_void_p, C.c_double]),
     "gar_hip_forward": (C.c_int, [C.c_void_p, _PD]),

@@ -546,20 +546,25 @@ __global__ void __launch_bounds__(256) gar_rotate_records(double *base, long lon
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gar_gather_gains(const gar_stage_meta *meta, const double *fac,
                                                         double *ff_all, double *fb_all,
-                                                        const long long *goff, int horizon, int t2, int dense) {
+                                                        const long long *goff, int horizon, int t2, int dense,
+                                                        int unx, int unu) {
+  // unx > 0: the solver is padded (gar_hip.cpp, gar_hip_solver::padded) -- the caller's arrays hold the rows of the
+  // real controls [0, unu) and states [nu, nu + unx) and the first unx columns only; goff are the caller's offsets
   const int t = (int)blockIdx.x;
   const gar_stage_meta m = meta[t];
   const int nx2r = dense ? 2 * m.nx2 : m.nx2;
   const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, nx2r, m.nth);
   const int nr = m.nu + m.nc + nx2r, nx = m.nx;
+  const int un = unx > 0 ? (m.nu > 0 ? unu : 0) : m.nu;      // control rows kept
+  const int onr = unx > 0 ? un + unx : nr, onx = unx > 0 ? unx : nx;
   const double *rec = fac + m.fac_off;
   double *ff = ff_all + goff[2 * t], *fb = fb_all + goff[2 * t + 1];
-  for (int e = (int)threadIdx.x; e < nr; e += 256)
-    ff[e] = rec[o.ff + e];
+  for (int e = (int)threadIdx.x; e < onr; e += 256)
+    ff[e] = rec[o.ff + (e < un ? e : e - un + m.nu)];
   const bool tr = t2 && t < horizon; // fbT2: element (r, j) at (j/2) 2nr + 2r + (j&1)
-  for (int e = (int)threadIdx.x; e < nr * nx; e += 256) {
-    const int r = e / nx, j = e - r * nx;
-    fb[e] = rec[o.fb + (tr ? (j >> 1) * (2 * nr) + 2 * r + (j & 1) : e)];
+  for (int e = (int)threadIdx.x; e < onr * onx; e += 256) {
+    const int ro = e / onx, j = e - ro * onx, r = ro < un ? ro : ro - un + m.nu;
+    fb[e] = rec[o.fb + (tr ? (j >> 1) * (2 * nr) + 2 * r + (j & 1) : r * nx + j)];
   }
 }
 
@@ -768,13 +773,16 @@ namespace gar {
 // boundary tuples, so no second collective is needed.
 // ---------------------------------------------------------------------------
 struct CondensedParams {
-  const double *ball;  // gathered tuples: [rank][problem][legs_per_rank][tuple]
+  const double *ball;  // gathered tuples: [rank][problem][legs_per_rank][tuple]; rank r owns legs
+                       // [r J / W, (r+1) J / W) of J = num_legs over W = world ranks (any W <= J:
+                       // legs_per_rank = ceil(J / W) is the chunk pitch, short chunks leave their tail unused)
   const double *prob;  // packed problems (G0, g0)
   double *scratch;     // per problem: see offsets below
   double *csol;        // per problem: [2*num_legs][nxb]
   int *status;
   long long prob_stride, scratch_stride, G0_off, g0_off;
   int batch, num_legs, legs_per_rank, tuple_doubles, nxb, nc0, nx0;
+  int world; // ranks the legs are split over (1 on a single-GPU solver)
   int max_refinement;
   double threshold;
   long long *trace; // debug: cycle stamps of two elimination steps of problem 0 (or null)
@@ -786,7 +794,8 @@ struct CondensedParams {
 };
 
 __device__ __forceinline__ const double *cond_tuple(const CondensedParams &P, int b, int leg) {
-  const int rank = leg / P.legs_per_rank, ll = leg - rank * P.legs_per_rank;
+  // owner of a leg under the floor partition r J / W (equals leg / legs_per_rank when W divides J)
+  const int rank = ((leg + 1) * P.world - 1) / P.num_legs, ll = leg - rank * P.num_legs / P.world;
   return P.ball + (((long long)rank * P.batch + b) * P.legs_per_rank + ll) * P.tuple_doubles;
 }
 
@@ -1077,6 +1086,16 @@ __global__ void __launch_bounds__(64) gar_stream_sweep(const gar_double2 *in, ga
       cur[q] = nxt[q];
   }
   sink[(size_t)b * 64 + lane] = acc;
+}
+
+// Measurement aid (bench.py, roofline.stream_ceiling.plain_copy): the plain grid-stride copy the guide's
+// "achievable" HBM figure refers to -- 16 B per lane, every byte read once and written once, all waves resident --
+// to put beside gar_stream_sweep (the sweep's own walk: one record in flight per wave).  No product path calls it.
+__global__ void __launch_bounds__(256) gar_plain_copy(const gar_double2 *__restrict__ src, gar_double2 *__restrict__ dst,
+                                                      long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = src[i];
 }
 
 } // namespace gar

@@ -104,8 +104,21 @@ struct DeviceGuard {
 struct gar_hip_solver {
   int device = 0, horizon = 0, nc0 = 0, batch = 0;
   int num_legs = 1, leg_begin = 0, leg_end = 1;
+  int world = 1, rank = 0; // horizon sharding: this solver owns legs [rank J / W, (rank + 1) J / W)
   std::vector<gar_stage_meta> meta;
-  std::vector<int32_t> dims5;
+  std::vector<int32_t> dims5; // dimensions of the DEVICE records (= the caller's unless padded)
+  // Padding onto a specialised kernel family happens HERE, behind the C ABI (riccati-base.hpp:13-37 is what
+  // binds: the caller passes the knots' own dimensions).  A uniform, unconstrained, unparameterised problem whose
+  // (nx, nu) has no kernel of its own runs on the smallest specialised shape (NX >= nx, NU >= nu) with DUMMY
+  // controls (R = I, S = 0, B = 0, r = 0) and DUMMY states (Q = I, A = 0, f = 0, pinned to zero by extra rows
+  // [0 -I] x0 = 0 of the initial constraint): both solve to exactly zero, decouple from the real variables, and
+  // are stripped from every result.  user_* = what the caller passed; `ulay` = the layout of the caller-facing
+  // records (packed problem, solution, gains) when they differ from the device's.
+  std::vector<int32_t> user_dims5;
+  int user_nc0 = 0;
+  bool padded = false;
+  int unx = 0, unu = 0, pnx = 0, pnu = 0; // caller's / device (nx, nu) of the uniform stages
+  gar_hip_solver *ulay = nullptr;         // host-only layout object (no device memory), owned
   gar_stage_meta *d_meta = nullptr;
   int64_t prob_doubles = 0, fac_doubles = 0, sol_doubles = 0, init_doubles = 0;
   int64_t G0_off = 0, g0_off = 0;
@@ -616,6 +629,102 @@ void select_kernel(gar_hip_solver *s) {
   else if (nx == 56 && nu == 24) bind_wide<56, 24>(s);
 }
 
+// (nx, nu) shapes with kernels of their own (bind_mfma / bind_leg / bind_wide above); {56, 24} has no wave-leg family
+struct SpecShape { int nx, nu; bool serial_only; };
+constexpr SpecShape kSpecialised[] = {{36, 12, false}, {32, 12, false}, {16, 8, false}, {12, 8, false},
+                                      {12, 4, false}, {8, 4, false},   {56, 24, true}};
+
+// Decide the device dimensions from the caller's (see gar_hip_solver::padded).  GAR_HIP_PAD=0: never pad.
+void choose_padding(gar_hip_solver *s) {
+  s->dims5 = s->user_dims5;
+  s->nc0 = s->user_nc0;
+  s->padded = false;
+  s->unx = s->unu = s->pnx = s->pnu = 0;
+  const char *pe = std::getenv("GAR_HIP_PAD");
+  const int N = s->horizon;
+  if (s->dense || (pe && pe[0] == '0') || N < 1)
+    return;
+  const int32_t *d0 = &s->user_dims5[0];
+  const int nx = d0[0], nu = d0[1];
+  if (nu == 0 || nx <= 0)
+    return;
+  for (int t = 0; t <= N; ++t) {
+    const int32_t *d = &s->user_dims5[5 * t];
+    if (d[0] != nx || d[1] != (t < N ? nu : 0) || d[2] != 0 || d[3] != nx || d[4] != 0)
+      return;
+  }
+  long best = -1;
+  int bx = 0, bu = 0;
+  for (const SpecShape &sh : kSpecialised) {
+    if (s->num_legs > 1 && sh.serial_only)
+      continue;
+    if (sh.nx == nx && sh.nu == nu)
+      return; // the shape has its own kernels
+    if (sh.nx >= nx && sh.nu >= nu) {
+      const long cost = (long)sh.nx * (sh.nx + sh.nu);
+      if (best < 0 || cost < best)
+        best = cost, bx = sh.nx, bu = sh.nu;
+    }
+  }
+  if (best < 0)
+    return;
+  s->padded = true;
+  s->unx = nx;
+  s->unu = nu;
+  s->pnx = bx;
+  s->pnu = bu;
+  for (int t = 0; t <= N; ++t) {
+    int32_t *d = &s->dims5[5 * t];
+    d[0] = d[3] = bx;
+    if (t < N)
+      d[1] = bu;
+  }
+  s->nc0 = s->user_nc0 + (bx - nx); // the dummy states are pinned by extra rows of the initial constraint
+}
+
+// Everything that can be decided and validated WITHOUT touching device memory: padding, both layouts, the LDS
+// plan, leg-mode geometry, the kernel family.  create and cycle_append (on a trial object) share it.
+int configure(gar_hip_solver *s) {
+  choose_padding(s);
+  if (int rc = build_layout(s))
+    return rc;
+  if (int rc = plan_lds(s))
+    return rc;
+  delete s->ulay;
+  s->ulay = nullptr;
+  if (s->padded) {
+    gar_hip_solver *u = new gar_hip_solver();
+    u->horizon = s->horizon;
+    u->batch = s->batch;
+    u->num_legs = s->num_legs;
+    u->dense = s->dense;
+    u->nc0 = s->user_nc0;
+    u->dims5 = s->user_dims5;
+    s->ulay = u;
+    if (int rc = build_layout(u))
+      return rc;
+  }
+  if (s->num_legs > 1) {
+    const int J = s->num_legs, W = s->world;
+    if (W < 1 || W > J || s->rank < 0 || s->rank >= W)
+      return fail(GAR_HIP_ERR_ARG, "horizon sharding needs 1 <= ranks <= num_legs");
+    s->leg_begin = (int)((long long)s->rank * J / W);
+    s->leg_end = (int)((long long)(s->rank + 1) * J / W);
+    s->legs_per_rank = (J + W - 1) / W; // chunk pitch of the gathered tuples (gar_generic.hpp, cond_tuple)
+    int nxb = 0;
+    for (const auto &m : s->meta)
+      nxb = std::max(nxb, std::max(m.nx, m.nx2));
+    if (s->nc0 > nxb)
+      return fail(GAR_HIP_ERR_UNSUPPORTED, "leg mode needs nc0 <= nx");
+    s->nxb = nxb;
+    s->tuple_doubles = 3 * (int64_t)nxb * nxb + 2 * nxb;
+  }
+  select_kernel(s);
+  if (!s->lds_error.empty() && !(s->wave_kernel || s->mfma_kernel || s->leg_bwd_kernel))
+    return fail(GAR_HIP_ERR_UNSUPPORTED, s->lds_error);
+  return GAR_HIP_OK;
+}
+
 gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
   gar::GenericParams P{};
   P.meta = s->d_meta;
@@ -631,7 +740,7 @@ gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
   P.fac_stride = s->fac_doubles;
   P.sol_stride = s->sol_doubles;
   P.init_stride = s->init_doubles;
-  P.boundary_stride = (long long)(s->leg_end - s->leg_begin) * s->tuple_doubles;
+  P.boundary_stride = (long long)s->legs_per_rank * s->tuple_doubles;
   P.G0_off = s->G0_off;
   P.g0_off = s->g0_off;
   P.horizon = s->horizon;
@@ -767,7 +876,7 @@ gar::LegParams make_leg_params(gar_hip_solver *s) {
   Q.sol_l = (int)s->sol_l;
   Q.nc0 = s->nc0;
   Q.boundary = s->d_bound_local;
-  Q.boundary_stride = (long long)(s->leg_end - s->leg_begin) * s->tuple_doubles;
+  Q.boundary_stride = (long long)s->legs_per_rank * s->tuple_doubles;
   Q.tuple_doubles = (int)s->tuple_doubles;
   {
     const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
@@ -938,6 +1047,7 @@ int launch_condensed(gar_hip_solver *s) {
   C.batch = s->batch;
   C.num_legs = s->num_legs;
   C.legs_per_rank = s->legs_per_rank;
+  C.world = s->world;
   C.tuple_doubles = (int)s->tuple_doubles;
   C.nxb = s->nxb;
   C.nc0 = s->nc0;
@@ -1066,16 +1176,17 @@ int allocate(gar_hip_solver *s) {
   HIP_TRY(hipMalloc((void **)&s->d_status, sizeof(int) * (2 * B + 4)));
   HIP_TRY(hipMemset(s->d_status, 0, sizeof(int) * (2 * B + 4)));
   if (s->num_legs > 1) {
-    const int local = s->leg_end - s->leg_begin;
+    const int chunk = s->legs_per_rank; // >= this rank's own leg count; equal-sized chunks for the all-gather
     const int nblk = 2 * s->num_legs;
     const size_t bs = (size_t)s->nxb * s->nxb;
-    HIP_TRY(hipMalloc((void **)&s->d_bound_local, sizeof(double) * s->tuple_doubles * local * B));
-    if (local == s->num_legs) {
+    HIP_TRY(hipMalloc((void **)&s->d_bound_local, sizeof(double) * s->tuple_doubles * chunk * B));
+    HIP_TRY(hipMemset(s->d_bound_local, 0, sizeof(double) * s->tuple_doubles * chunk * B));
+    if (s->world == 1) {
       s->d_bound_all = s->d_bound_local;
       s->bound_all_owned = false;
     } else {
       HIP_TRY(hipMalloc((void **)&s->d_bound_all,
-                        sizeof(double) * s->tuple_doubles * s->num_legs * B));
+                        sizeof(double) * s->tuple_doubles * chunk * s->world * B));
       s->bound_all_owned = true;
     }
     HIP_TRY(hipMalloc((void **)&s->d_csol, sizeof(double) * (size_t)nblk * s->nxb * B));
@@ -1091,9 +1202,6 @@ int allocate(gar_hip_solver *s) {
   }
   s->dirty_iv.assign(B, {});
   s->dirty = false;
-  select_kernel(s);
-  if (!s->lds_error.empty() && !(s->wave_kernel || s->mfma_kernel || s->leg_bwd_kernel))
-    return fail(GAR_HIP_ERR_UNSUPPORTED, s->lds_error);
   if (s->dense) {
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_backward_dense,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1151,6 +1259,50 @@ int allocate(gar_hip_solver *s) {
 
 } // namespace
 
+// ---- padding helpers (gar_hip_solver::padded) ------------------------------------------------------------------
+namespace {
+// r x c column-major `src` (null: zeros) into the top-left corner of an R x C column-major block; `diag` on the
+// part of the diagonal beyond (r, c)
+const double *padded_block(std::vector<double> &buf, const double *src, int r, int c, int R, int C, double diag) {
+  buf.assign((size_t)R * C, 0.0);
+  if (src)
+    for (int j = 0; j < c; ++j)
+      std::memcpy(&buf[(size_t)j * R], src + (size_t)j * r, sizeof(double) * (size_t)r);
+  if (diag != 0.0)
+    for (int i = std::min(r, c); i < std::min(R, C); ++i)
+      buf[(size_t)i * R + i] = diag;
+  return buf.data();
+}
+// rows [0, unu) and [NU, NU + unx) of a gain block with NU + NX (+...) rows: the real controls and states
+inline int gain_row(const gar_hip_solver *s, int r, int nu_dev) {
+  const int unu = nu_dev > 0 ? s->unu : 0;
+  return r < unu ? r : r - unu + nu_dev;
+}
+// the caller's solution arrays out of one device solution record
+void strip_solution(const gar_hip_solver *s, const double *rec, double *xs, double *us, double *vs, double *lbdas) {
+  const int N = s->horizon, nx = s->unx;
+  (void)vs; // padding applies to unconstrained problems only
+  for (int t = 0; t <= N; ++t) {
+    const gar_stage_meta &m = s->meta[t];
+    if (xs)
+      std::memcpy(xs + (size_t)t * nx, rec + m.x_off, sizeof(double) * (size_t)nx);
+    if (us && m.nu > 0)
+      std::memcpy(us + (size_t)t * s->unu, rec + m.u_off, sizeof(double) * (size_t)s->unu);
+    if (lbdas) {
+      if (t == 0)
+        std::memcpy(lbdas, rec + m.l_off, sizeof(double) * (size_t)s->user_nc0);
+      else
+        std::memcpy(lbdas + s->user_nc0 + (size_t)(t - 1) * nx, rec + m.l_off, sizeof(double) * (size_t)nx);
+    }
+  }
+}
+// one device solution record -> the caller's record layout (ulay)
+void strip_solution_rec(const gar_hip_solver *s, const double *dev, double *rec) {
+  const gar_hip_solver *u = s->ulay;
+  strip_solution(s, dev, rec + u->sol_x, rec + u->sol_u, rec + u->sol_v, rec + u->sol_l);
+}
+} // namespace
+
 extern "C" {
 
 const char *gar_hip_version(void) { return "gar-hip 0.1 (gfx950)"; }
@@ -1197,6 +1349,43 @@ double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_
   return best;
 }
 
+double gar_hip_copy_ceiling_ms(int device, int64_t bytes_moved, int reps) {
+  // bytes_moved = read + written: bytes_moved / 2 are copied
+  const long long n = (long long)(bytes_moved / 2 / 16);
+  if (n <= 0 || reps <= 0)
+    return -1.0;
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess)
+    return -1.0;
+  gar::gar_double2 *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double best = -1.0;
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  if (hipMalloc((void **)&src, (size_t)n * 16) == hipSuccess && hipMalloc((void **)&dst, (size_t)n * 16) == hipSuccess &&
+      hipMemset(src, 0, (size_t)n * 16) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+      hipEventCreate(&e1) == hipSuccess) {
+    for (int r = 0; r < reps + 1; ++r) { // first launch: warm-up
+      (void)hipEventRecord(e0, nullptr);
+      hipLaunchKernelGGL(gar::gar_plain_copy, dim3((unsigned)(cus * 8)), dim3(256), 0, nullptr, src, dst, n);
+      (void)hipEventRecord(e1, nullptr);
+      float ms = 0.f;
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+        best = -1.0;
+        break;
+      }
+      if (r > 0 && (best < 0.0 || ms < best))
+        best = ms;
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  (void)hipSetDevice(prev);
+  return best;
+}
+
 int gar_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess)
@@ -1213,26 +1402,9 @@ int64_t gar_hip_factor_doubles(const int32_t d[5]) {
 
 namespace {
 gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int nc0, int batch,
-                            int num_legs, int leg_begin, int leg_end, bool dense);
-}
-
-gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon, const int32_t *dims5,
-                                              int nc0, int batch, int num_legs, int leg_begin,
-                                              int leg_end) {
-  return create_impl(device, horizon, dims5, nc0, batch, num_legs, leg_begin, leg_end, false);
-}
-
-// RiccatiSolverDense (gar/dense-riccati.hpp:19-56): serial in time, any dimensions
-gar_hip_solver *gar_hip_solver_create_dense(int device, int horizon, const int32_t *dims5, int nc0,
-                                            int batch) {
-  return create_impl(device, horizon, dims5, nc0, batch, 1, 0, 1, true);
-}
-
-namespace {
-gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int nc0, int batch,
-                            int num_legs, int leg_begin, int leg_end, bool dense) {
-  if (horizon < 0 || !dims5 || nc0 < 0 || batch < 1 || num_legs < 1 || leg_begin < 0 ||
-      leg_end > num_legs || leg_begin >= leg_end) {
+                            int num_legs, int rank, int world, bool dense) {
+  if (horizon < 0 || !dims5 || nc0 < 0 || batch < 1 || num_legs < 1 || world < 1 || rank < 0 || rank >= world ||
+      (num_legs == 1 && world != 1)) {
     fail(GAR_HIP_ERR_ARG, "gar_hip_solver_create: bad argument");
     return nullptr;
   }
@@ -1244,13 +1416,13 @@ gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int n
   gar_hip_solver *s = new gar_hip_solver();
   s->device = device;
   s->horizon = horizon;
-  s->nc0 = nc0;
+  s->user_nc0 = nc0;
   s->batch = batch;
   s->num_legs = num_legs;
-  s->leg_begin = leg_begin;
-  s->leg_end = leg_end;
+  s->rank = rank;
+  s->world = world;
   s->dense = dense;
-  s->dims5.assign(dims5, dims5 + 5 * (horizon + 1));
+  s->user_dims5.assign(dims5, dims5 + 5 * (horizon + 1));
   DeviceGuard guard_(device); // the caller's current device is restored on return
   {
     int cur = -1;
@@ -1260,31 +1432,14 @@ gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int n
       return nullptr;
     }
   }
-  if (build_layout(s) != GAR_HIP_OK || plan_lds(s) != GAR_HIP_OK) {
+  if (configure(s) != GAR_HIP_OK) {
+    delete s->ulay;
     delete s;
     return nullptr;
   }
-  if (num_legs > 1) {
-    const int local = leg_end - leg_begin;
-    if (num_legs % local != 0 || leg_begin % local != 0) {
-      fail(GAR_HIP_ERR_ARG, "legs must be split evenly over ranks");
-      delete s;
-      return nullptr;
-    }
-    s->legs_per_rank = local;
-    int nxb = 0;
-    for (const auto &m : s->meta)
-      nxb = std::max(nxb, std::max(m.nx, m.nx2));
-    if (nc0 > nxb) {
-      fail(GAR_HIP_ERR_UNSUPPORTED, "leg mode needs nc0 <= nx");
-      delete s;
-      return nullptr;
-    }
-    s->nxb = nxb;
-    s->tuple_doubles = 3 * (int64_t)nxb * nxb + 2 * nxb;
-  }
   if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) {
     fail(GAR_HIP_ERR_DEVICE, "hipStreamCreate failed");
+    delete s->ulay;
     delete s;
     return nullptr;
   }
@@ -1292,6 +1447,7 @@ gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int n
   if (allocate(s) != GAR_HIP_OK) {
     free_device(s);
     (void)hipStreamDestroy(s->own_stream);
+    delete s->ulay;
     delete s;
     return nullptr;
   }
@@ -1299,10 +1455,33 @@ gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int n
 }
 } // namespace
 
+gar_hip_solver *gar_hip_solver_create_ranked(int device, int horizon, const int32_t *dims5, int nc0, int batch,
+                                             int num_legs, int rank, int world) {
+  return create_impl(device, horizon, dims5, nc0, batch, num_legs, rank, world, false);
+}
+
+// legs [leg_begin, leg_end) of an EVEN split (every rank the same number of legs); any split: _ranked
+gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon, const int32_t *dims5,
+                                              int nc0, int batch, int num_legs, int leg_begin,
+                                              int leg_end) {
+  const int local = leg_end - leg_begin;
+  if (num_legs < 1 || local < 1 || leg_begin < 0 || leg_end > num_legs || num_legs % local != 0 || leg_begin % local != 0) {
+    fail(GAR_HIP_ERR_ARG, "gar_hip_solver_create_sharded: legs must be split evenly over ranks "
+                          "(use gar_hip_solver_create_ranked for any split)");
+    return nullptr;
+  }
+  return create_impl(device, horizon, dims5, nc0, batch, num_legs, leg_begin / local, num_legs / local, false);
+}
+
+// RiccatiSolverDense (gar/dense-riccati.hpp:19-56): serial in time, any dimensions
+gar_hip_solver *gar_hip_solver_create_dense(int device, int horizon, const int32_t *dims5, int nc0,
+                                            int batch) {
+  return create_impl(device, horizon, dims5, nc0, batch, 1, 0, 1, true);
+}
+
 gar_hip_solver *gar_hip_solver_create(int device, int horizon, const int32_t *dims5, int nc0,
                                       int batch, int num_legs) {
-  return gar_hip_solver_create_sharded(device, horizon, dims5, nc0, batch, num_legs, 0,
-                                       num_legs);
+  return create_impl(device, horizon, dims5, nc0, batch, num_legs, 0, 1, false);
 }
 
 void gar_hip_solver_destroy(gar_hip_solver *s) {
@@ -1316,6 +1495,7 @@ void gar_hip_solver_destroy(gar_hip_solver *s) {
   for (auto &e : s->ev)
     if (e)
       (void)hipEventDestroy(e);
+  delete s->ulay;
   delete s;
 }
 
@@ -1336,9 +1516,10 @@ int gar_hip_sync(gar_hip_solver *s) {
   return GAR_HIP_OK;
 }
 
-int64_t gar_hip_problem_doubles(const gar_hip_solver *s) { return s ? s->prob_doubles : 0; }
+// (the caller's records: under padding they are laid out by the caller's dimensions, `ulay`)
+int64_t gar_hip_problem_doubles(const gar_hip_solver *s) { return s ? (s->ulay ? s->ulay->prob_doubles : s->prob_doubles) : 0; }
 int64_t gar_hip_factors_doubles(const gar_hip_solver *s) { return s ? s->fac_doubles : 0; }
-int64_t gar_hip_solution_doubles(const gar_hip_solver *s) { return s ? s->sol_doubles : 0; }
+int64_t gar_hip_solution_doubles(const gar_hip_solver *s) { return s ? (s->ulay ? s->ulay->sol_doubles : s->sol_doubles) : 0; }
 int gar_hip_batch(const gar_hip_solver *s) { return s ? s->batch : 0; }
 int gar_hip_horizon(const gar_hip_solver *s) { return s ? s->horizon : -1; }
 const char *gar_hip_kernel_name(const gar_hip_solver *s) {
@@ -1348,9 +1529,9 @@ const char *gar_hip_kernel_name(const gar_hip_solver *s) {
 int gar_hip_stage_offsets(const gar_hip_solver *s, int t, int64_t out[6]) {
   if (int rc = check_bt(s, 0, t))
     return rc;
-  const gar_stage_meta &m = s->meta[t];
+  const gar_stage_meta &m = s->ulay ? s->ulay->meta[t] : s->meta[t];
   out[0] = m.in_off;
-  out[1] = m.fac_off;
+  out[1] = s->meta[t].fac_off; // factor records exist on the device only
   out[2] = m.x_off;
   out[3] = m.u_off;
   out[4] = m.v_off;
@@ -1361,19 +1542,16 @@ int gar_hip_stage_offsets(const gar_hip_solver *s, int t, int64_t out[6]) {
 int gar_hip_init_offsets(const gar_hip_solver *s, int64_t out[2]) {
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
-  out[0] = s->G0_off;
-  out[1] = s->g0_off;
+  out[0] = s->ulay ? s->ulay->G0_off : s->G0_off;
+  out[1] = s->ulay ? s->ulay->g0_off : s->g0_off;
   return GAR_HIP_OK;
 }
 
-int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const double *S,
+static int upload_stage_dev(gar_hip_solver *s, int b, int t, const double *Q, const double *S,
                          const double *R, const double *q, const double *r, const double *A,
                          const double *B, const double *f, const double *C, const double *D,
                          const double *d, const double *Gth, const double *Gx,
                          const double *Gu, const double *Gv, const double *gamma) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, t))
-    return rc;
   const gar_stage_meta &m = s->meta[t];
   const int nth_st = (m.flags & GAR_KNOT_HAS_PARAM) ? m.nth : 0;
   const gar_knot_offsets o = gar_knot_layout(m.nx, m.nu, m.nc, m.nx2, nth_st);
@@ -1403,10 +1581,7 @@ int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const
   return rc ? GAR_HIP_ERR_DEVICE : GAR_HIP_OK;
 }
 
-int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g0) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
+static int set_init_dev(gar_hip_solver *s, int b, const double *G0, const double *g0) {
   if (s->nc0 > 0 && (!G0 || !g0))
     return fail(GAR_HIP_ERR_ARG, "gar_hip_set_init: null block");
   int rc = write_block(s, b, s->G0_off, G0, (int64_t)s->nc0 * s->nx0);
@@ -1418,6 +1593,23 @@ int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packe
   GAR_GUARD(s);
   if (!s || !packed || b0 < 0 || nb < 0 || b0 + nb > s->batch)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_packed: bad argument");
+  if (s->padded) { // the caller's records: knot by knot through the padding path
+    const gar_hip_solver *u = s->ulay;
+    for (int b = b0; b < b0 + nb; ++b) {
+      const double *rec = packed + (int64_t)(b - b0) * u->prob_doubles;
+      for (int t = 0; t <= s->horizon; ++t) {
+        const gar_stage_meta &m = u->meta[t];
+        const gar_knot_offsets o = gar_knot_layout(m.nx, m.nu, 0, m.nx2, 0);
+        const double *k = rec + m.in_off;
+        if (int rc = gar_hip_upload_stage(s, b, t, k + o.Q, k + o.S, k + o.R, k + o.q, k + o.r, k + o.A, k + o.B, k + o.f,
+                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))
+          return rc;
+      }
+      if (int rc = gar_hip_set_init(s, b, rec + u->G0_off, rec + u->g0_off))
+        return rc;
+    }
+    return GAR_HIP_OK;
+  }
   const size_t bytes = sizeof(double) * (size_t)s->prob_doubles * nb;
   if (s->staged) {
     std::memcpy(s->h_prob + (int64_t)b0 * s->prob_doubles, packed, bytes);
@@ -1486,7 +1678,7 @@ int gar_hip_backward_async(gar_hip_solver *s, double mueq) {
   if (int rc = gar_hip_backward_legs_async(s, mueq))
     return rc;
   if (s->num_legs > 1) {
-    if (s->leg_end - s->leg_begin != s->num_legs)
+    if (s->world > 1)
       return fail(GAR_HIP_ERR_ARG, "sharded solver: exchange boundaries, then call "
                                    "gar_hip_condensed_solve_async");
     return launch_condensed(s);
@@ -1598,11 +1790,8 @@ int gar_hip_condensed_info(gar_hip_solver *s, int b, double out[2]) {
   return GAR_HIP_OK;
 }
 
-int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, double *vs,
+static int get_solution_dev(gar_hip_solver *s, int b, double *xs, double *us, double *vs,
                          double *lbdas) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
   const double *base = s->d_sol + (int64_t)b * s->sol_doubles;
   int rc = d2h(s, xs, base + s->sol_x, s->sol_u - s->sol_x);
   rc |= d2h(s, us, base + s->sol_u, s->sol_v - s->sol_u);
@@ -1617,10 +1806,7 @@ int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, doubl
   return GAR_HIP_OK;
 }
 
-int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, double *fth) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, t))
-    return rc;
+static int get_gains_dev(gar_hip_solver *s, int b, int t, double *ff, double *fb, double *fth) {
   const gar_stage_meta &m = s->meta[t];
   const int nx2r = s->dense ? 2 * m.nx2 : m.nx2; // stage-dense solver: rows [K; Z; L; Y]
   const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, nx2r, m.nth);
@@ -1666,16 +1852,17 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
 int gar_hip_gains_doubles(const gar_hip_solver *s, int64_t out[2]) {
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
-  out[0] = s->ff_all_doubles;
-  out[1] = s->fb_all_doubles;
+  out[0] = s->ulay ? s->ulay->ff_all_doubles : s->ff_all_doubles;
+  out[1] = s->ulay ? s->ulay->fb_all_doubles : s->fb_all_doubles;
   return GAR_HIP_OK;
 }
 
 int gar_hip_gains_offsets(const gar_hip_solver *s, int t, int64_t out[2]) {
   if (int rc = check_bt(s, 0, t))
     return rc;
-  out[0] = s->gain_off[2 * (size_t)t];
-  out[1] = s->gain_off[2 * (size_t)t + 1];
+  const std::vector<long long> &go = s->ulay ? s->ulay->gain_off : s->gain_off;
+  out[0] = go[2 * (size_t)t];
+  out[1] = go[2 * (size_t)t + 1];
   return GAR_HIP_OK;
 }
 
@@ -1683,18 +1870,22 @@ int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
-  const size_t nsol = (size_t)s->sol_doubles, ngain = (size_t)(s->ff_all_doubles + s->fb_all_doubles);
+  // the caller's records (under padding: the real rows / columns only); the device solution record is staged
+  // behind them when it has to be stripped on the host
+  const gar_hip_solver *u = s->ulay ? s->ulay : s;
+  const size_t nsol = (size_t)u->sol_doubles, ngain = (size_t)(u->ff_all_doubles + u->fb_all_doubles);
+  const size_t nscratch = s->padded ? (size_t)s->sol_doubles : 0;
   if (!s->h_results) { // first use: the buffers live as long as the solver's layout
     // all three or none: a partial failure must not leave h_results set with the device buffers missing
     double *h = nullptr, *dg = nullptr;
     long long *dgo = nullptr;
-    hipError_t e = hipHostMalloc((void **)&h, sizeof(double) * (nsol + ngain), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void **)&h, sizeof(double) * (nsol + ngain + nscratch), hipHostMallocDefault);
     if (e == hipSuccess)
       e = hipMalloc((void **)&dg, sizeof(double) * std::max<size_t>(ngain, 1));
     if (e == hipSuccess)
-      e = hipMalloc((void **)&dgo, sizeof(long long) * s->gain_off.size());
+      e = hipMalloc((void **)&dgo, sizeof(long long) * u->gain_off.size());
     if (e == hipSuccess)
-      e = hipMemcpyAsync(dgo, s->gain_off.data(), sizeof(long long) * s->gain_off.size(), hipMemcpyHostToDevice,
+      e = hipMemcpyAsync(dgo, u->gain_off.data(), sizeof(long long) * u->gain_off.size(), hipMemcpyHostToDevice,
                          s->stream);
     if (e != hipSuccess) {
       if (h)
@@ -1707,30 +1898,33 @@ int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
     s->d_gains = dg;
     s->d_gain_off = dgo;
   }
-  if (what & 2) { // device-side gather (fbT2 -> row-major), then ONE device-to-host copy
+  if (what & 2) { // device-side gather (fbT2 -> row-major, dummy rows / columns dropped), then ONE device-to-host copy
     const bool t2 = s->fb_t2;
     hipLaunchKernelGGL(gar::gar_gather_gains, dim3((unsigned)(s->horizon + 1)), dim3(256), 0, s->stream,
                        s->d_meta, s->d_fac + (int64_t)b * s->fac_doubles, s->d_gains,
-                       s->d_gains + s->ff_all_doubles, s->d_gain_off, s->horizon, t2 ? 1 : 0,
-                       s->dense ? 1 : 0);
+                       s->d_gains + u->ff_all_doubles, s->d_gain_off, s->horizon, t2 ? 1 : 0,
+                       s->dense ? 1 : 0, s->padded ? s->unx : 0, s->padded ? s->unu : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(s->h_results + nsol, s->d_gains, sizeof(double) * ngain, hipMemcpyDeviceToHost,
                            s->stream));
   }
   if (what & 1)
-    HIP_TRY(hipMemcpyAsync(s->h_results, s->d_sol + (int64_t)b * s->sol_doubles, sizeof(double) * nsol,
-                           hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_results + (s->padded ? nsol + ngain : 0), s->d_sol + (int64_t)b * s->sol_doubles,
+                           sizeof(double) * (size_t)s->sol_doubles, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if ((what & 1) && s->padded)
+    strip_solution_rec(s, s->h_results + nsol + ngain, s->h_results);
   return GAR_HIP_OK;
 }
 
 const double *gar_hip_host_results(gar_hip_solver *s, int64_t offs[3]) {
   if (!s)
     return nullptr;
+  const gar_hip_solver *u = s->ulay ? s->ulay : s;
   if (offs) {
     offs[0] = 0;
-    offs[1] = s->sol_doubles;
-    offs[2] = s->sol_doubles + s->ff_all_doubles;
+    offs[1] = u->sol_doubles;
+    offs[2] = u->sol_doubles + u->ff_all_doubles;
   }
   return s->h_results;
 }
@@ -1738,19 +1932,17 @@ const double *gar_hip_host_results(gar_hip_solver *s, int64_t offs[3]) {
 int gar_hip_get_gains_all(gar_hip_solver *s, int b, double *ff_all, double *fb_all) {
   if (int rc = gar_hip_fetch_results(s, b, 2))
     return rc;
+  const gar_hip_solver *u = s->ulay ? s->ulay : s;
   if (ff_all)
-    std::memcpy(ff_all, s->h_results + s->sol_doubles, sizeof(double) * (size_t)s->ff_all_doubles);
+    std::memcpy(ff_all, s->h_results + u->sol_doubles, sizeof(double) * (size_t)u->ff_all_doubles);
   if (fb_all)
-    std::memcpy(fb_all, s->h_results + s->sol_doubles + s->ff_all_doubles,
-                sizeof(double) * (size_t)s->fb_all_doubles);
+    std::memcpy(fb_all, s->h_results + u->sol_doubles + u->ff_all_doubles,
+                sizeof(double) * (size_t)u->fb_all_doubles);
   return GAR_HIP_OK;
 }
 
-int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, double *Vxt,
+static int get_value_dev(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, double *Vxt,
                       double *Vtt, double *vt) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, t))
-    return rc;
   const gar_stage_meta &m = s->meta[t];
   const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, s->dense ? 2 * m.nx2 : m.nx2, m.nth);
   const double *rec = s->d_fac + (int64_t)b * s->fac_doubles + m.fac_off;
@@ -1765,10 +1957,7 @@ int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, 
   return GAR_HIP_OK;
 }
 
-int gar_hip_get_kkt(gar_hip_solver *s, int b, int t, double mueq, double *out) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, t))
-    return rc;
+static int get_kkt_dev(gar_hip_solver *s, int b, int t, double mueq, double *out) {
   if (s->dense)
     return fail(GAR_HIP_ERR_UNSUPPORTED, "kktMat of the stage-dense solver is not kept (the whole stage matrix: gar_dense.hpp)");
   if (!out)
@@ -1806,11 +1995,8 @@ int gar_hip_get_kkt(gar_hip_solver *s, int b, int t, double mueq, double *out) {
   return GAR_HIP_OK;
 }
 
-int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff, double *kkt0_fth,
+static int get_initial_dev(gar_hip_solver *s, int b, double *kkt0_ff, double *kkt0_fth,
                         double *thGrad, double *thHess) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
   const double *io = s->d_init + (int64_t)b * s->init_doubles;
   const int64_t n0 = s->n0, nth = s->nth0;
   int rc = d2h(s, kkt0_ff, io, n0);
@@ -1858,6 +2044,9 @@ int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_d
   GAR_GUARD(s);
   if (!s || !deriv_dev)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_update_lq_subproblem_device: bad argument");
+  if (s->padded)
+    return fail(GAR_HIP_ERR_UNSUPPORTED, "device-resident LQ assembly on a padded solver: the derivative records would "
+                                         "have to carry the dummy states / controls (GAR_HIP_PAD=0 keeps the caller's shape)");
   if (int rc = commit(s)) // pending host staging first; later host writes flush only their own ranges
     return rc;
   if (!s->d_deriv_off) {
@@ -1894,6 +2083,38 @@ int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed) {
     return fail(GAR_HIP_ERR_ARG, "gar_hip_download_packed: bad argument");
   if (int rc = commit(s))
     return rc;
+  if (s->padded) { // device records -> the caller's: the real rows / columns of every block
+    const gar_hip_solver *u = s->ulay;
+    std::vector<double> dev((size_t)s->prob_doubles);
+    for (int b = b0; b < b0 + nb; ++b) {
+      HIP_TRY(hipMemcpyAsync(dev.data(), s->d_prob + (int64_t)b * s->prob_doubles, sizeof(double) * dev.size(),
+                             hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      double *rec = packed + (int64_t)(b - b0) * u->prob_doubles;
+      std::memset(rec, 0, sizeof(double) * (size_t)u->prob_doubles);
+      auto take = [](double *dst, const double *src, int r, int c, int R) {
+        for (int j = 0; j < c; ++j)
+          std::memcpy(dst + (size_t)j * r, src + (size_t)j * R, sizeof(double) * (size_t)r);
+      };
+      take(rec + u->G0_off, dev.data() + s->G0_off, s->user_nc0, s->unx, s->nc0);
+      take(rec + u->g0_off, dev.data() + s->g0_off, s->user_nc0, 1, s->nc0);
+      for (int t = 0; t <= s->horizon; ++t) {
+        const gar_stage_meta &m = u->meta[t], &M = s->meta[t];
+        const gar_knot_offsets o = gar_knot_layout(m.nx, m.nu, 0, m.nx2, 0), O = gar_knot_layout(M.nx, M.nu, 0, M.nx2, 0);
+        double *k = rec + m.in_off;
+        const double *K = dev.data() + M.in_off;
+        take(k + o.Q, K + O.Q, m.nx, m.nx, M.nx);
+        take(k + o.S, K + O.S, m.nx, m.nu, M.nx);
+        take(k + o.R, K + O.R, m.nu, m.nu, M.nu);
+        take(k + o.q, K + O.q, m.nx, 1, M.nx);
+        take(k + o.r, K + O.r, m.nu, 1, M.nu);
+        take(k + o.A, K + O.A, m.nx2, m.nx, M.nx2);
+        take(k + o.B, K + O.B, m.nx2, m.nu, M.nx2);
+        take(k + o.f, K + O.f, m.nx2, 1, M.nx2);
+      }
+    }
+    return GAR_HIP_OK;
+  }
   HIP_TRY(hipMemcpyAsync(packed, s->d_prob + (int64_t)b0 * s->prob_doubles,
                          sizeof(double) * (size_t)s->prob_doubles * nb, hipMemcpyDeviceToHost,
                          s->stream));
@@ -1954,17 +2175,18 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
     return GAR_HIP_OK;
   if (int rc = commit(s)) // host writes addressed the old stage numbering: flush them first
     return rc;
-  // new dims sequence: old[1..N-1], new knot, old[N]  (rotate_vec_left(datas,0,1) +
+  // new dims sequence (the CALLER's dimensions): old[1..N-1], new knot, old[N]  (rotate_vec_left(datas,0,1) +
   // re-created last-but-one factor, proximal-riccati.hxx:79-86)
-  std::vector<int32_t> nd(s->dims5.size());
+  const std::vector<int32_t> &od = s->user_dims5;
+  std::vector<int32_t> nd(od.size());
   for (int t = 0; t + 1 < N; ++t)
-    std::copy(&s->dims5[5 * (t + 1)], &s->dims5[5 * (t + 1)] + 5, &nd[5 * t]);
+    std::copy(&od[5 * (t + 1)], &od[5 * (t + 1)] + 5, &nd[5 * t]);
   std::copy(d, d + 5, &nd[5 * (N - 1)]);
-  std::copy(&s->dims5[5 * N], &s->dims5[5 * N] + 5, &nd[5 * N]);
+  std::copy(&od[5 * N], &od[5 * N] + 5, &nd[5 * N]);
   bool uniform = true;
   for (int t = 0; t < N; ++t)
     for (int k = 0; k < 5; ++k)
-      uniform &= (nd[5 * t + k] == d[k]) && (s->dims5[5 * t + k] == d[k]);
+      uniform &= (nd[5 * t + k] == d[k]) && (od[5 * t + k] == d[k]);
   if (uniform && s->num_legs == 1) {
     // A RING, not a copy: logical stage t (< N) moves to slot (t + ring0) mod N, i.e. every record
     // stays where it is -- problem knots and factors alike (rotate_vec_left(datas, 0, 1)) -- and what
@@ -1972,6 +2194,7 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
     // (specialised families) or the rotated per-stage offsets (generic / dense kernels read them
     // from the stage descriptors): 14 KB of descriptors, asynchronously; no record is touched, the
     // stream is not synchronised.  (Round 1 copied (N-1) x 54 KB per problem and synchronised twice.)
+    // (the caller's and the device's dimension sequences are unchanged; a padded solver's dummy rows stay in place)
     s->ring0 = (s->ring0 + 1) % N;
     for (int t = 0; t < N; ++t) {
       const int64_t p = (t + s->ring0) % N;
@@ -1985,29 +2208,223 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
     // strided memset over the batch, asynchronous
     HIP_TRY(hipMemset2DAsync(s->d_fac + s->meta[N - 1].fac_off, sizeof(double) * (size_t)s->fac_doubles, 0,
                              sizeof(double) * (size_t)s->uni_fac_rec, (size_t)s->batch, s->stream));
+    if (s->padded) { // the slot's dummy diagonals (Q = I, R = I on the padded part) are part of the knot the caller
+      // uploads next through gar_hip_upload_stage, which writes whole padded blocks: nothing to do here
+    }
     return GAR_HIP_OK;
   }
-  // dimensions changed (or leg mode: "just reinitialise everything",
-  // parallel-solver.hxx:246-258): rebuild the layout and the buffers
-  // The new layout is validated BEFORE anything is released: on failure the solver keeps its old
-  // dimensions, layout and device buffers.  On success every device pointer handed out earlier
-  // (gar_hip_device_*) is invalid and must be fetched again; resident problem data is not carried over.
-  const std::vector<int32_t> old = s->dims5;
-  s->dims5 = nd;
-  int rc = build_layout(s);
-  if (rc == GAR_HIP_OK)
-    rc = plan_lds(s);
-  if (rc != GAR_HIP_OK) {
-    const std::string why = g_last_error;
-    s->dims5 = old;
-    (void)build_layout(s);
-    (void)plan_lds(s);
-    return fail(rc, why);
+  // dimensions changed (or leg mode: "just reinitialise everything", parallel-solver.hxx:246-258): rebuild the
+  // layout and the buffers.  The new configuration -- padding, layouts, LDS plan, kernel family -- is validated on
+  // a TRIAL object first: on failure this solver is untouched (ring position, stage offsets, device records and
+  // descriptors included).  On success every device pointer handed out earlier (gar_hip_device_*) is invalid and
+  // must be fetched again; resident problem data is not carried over.
+  {
+    gar_hip_solver trial;
+    trial.device = s->device;
+    trial.horizon = s->horizon;
+    trial.user_nc0 = s->user_nc0;
+    trial.batch = s->batch;
+    trial.num_legs = s->num_legs;
+    trial.rank = s->rank;
+    trial.world = s->world;
+    trial.dense = s->dense;
+    trial.user_dims5 = nd;
+    const int rc = configure(&trial);
+    delete trial.ulay;
+    trial.ulay = nullptr;
+    if (rc != GAR_HIP_OK)
+      return rc; // g_last_error says why
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
   free_device(s);
   s->staged = s->dirty = false;
+  s->user_dims5 = nd;
+  if (int rc = configure(s))
+    return rc;
   return allocate(s);
+}
+
+
+// ---- caller-facing entry points whose records differ under padding (gar_hip_solver::padded) --------------------
+int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const double *S, const double *R,
+                         const double *q, const double *r, const double *A, const double *B, const double *f,
+                         const double *C, const double *D, const double *d, const double *Gth, const double *Gx,
+                         const double *Gu, const double *Gv, const double *gamma) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, t))
+    return rc;
+  if (!s->padded)
+    return upload_stage_dev(s, b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma);
+  const gar_stage_meta &m = s->meta[t];
+  const int nx = s->unx, nu = m.nu > 0 ? s->unu : 0, NX = m.nx, NU = m.nu;
+  if (!Q || !q || !A || !f || (nu > 0 && (!S || !R || !r || !B)))
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_stage: null block");
+  thread_local std::vector<double> bQ, bS, bR, bq, br, bA, bB, bf;
+  return upload_stage_dev(s, b, t, padded_block(bQ, Q, nx, nx, NX, NX, 1.0), padded_block(bS, S, nx, nu, NX, NU, 0.0),
+                          padded_block(bR, R, nu, nu, NU, NU, 1.0), padded_block(bq, q, nx, 1, NX, 1, 0.0),
+                          padded_block(br, r, nu, 1, NU, 1, 0.0), padded_block(bA, A, nx, nx, NX, NX, 0.0),
+                          padded_block(bB, B, nx, nu, NX, NU, 0.0), padded_block(bf, f, nx, 1, NX, 1, 0.0), nullptr,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g0) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  if (!s->padded)
+    return set_init_dev(s, b, G0, g0);
+  if (s->user_nc0 > 0 && (!G0 || !g0))
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_set_init: null block");
+  // [G0 0; 0 -I], [g0; 0]: the dummy states start (and stay) at zero
+  const int nc0u = s->user_nc0, nc0 = s->nc0, nx = s->unx, NX = s->pnx;
+  thread_local std::vector<double> G, g;
+  G.assign((size_t)nc0 * NX, 0.0);
+  g.assign((size_t)nc0, 0.0);
+  for (int j = 0; j < nx; ++j)
+    for (int i = 0; i < nc0u; ++i)
+      G[(size_t)j * nc0 + i] = G0[(size_t)j * nc0u + i];
+  for (int i = 0; i < NX - nx; ++i)
+    G[(size_t)(nx + i) * nc0 + nc0u + i] = -1.0;
+  for (int i = 0; i < nc0u; ++i)
+    g[i] = g0[i];
+  return set_init_dev(s, b, G.data(), g.data());
+}
+
+int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, double *vs, double *lbdas) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  if (!s->padded)
+    return get_solution_dev(s, b, xs, us, vs, lbdas);
+  std::vector<double> rec((size_t)s->sol_doubles);
+  HIP_TRY(hipMemcpyAsync(rec.data(), s->d_sol + (int64_t)b * s->sol_doubles, sizeof(double) * rec.size(),
+                         hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  strip_solution(s, rec.data(), xs, us, vs, lbdas);
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, double *fth) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, t))
+    return rc;
+  if (!s->padded)
+    return get_gains_dev(s, b, t, ff, fb, fth);
+  const gar_stage_meta &m = s->meta[t];
+  const int NR = m.nu + m.nx2, NX = m.nx, NT = m.nth;
+  const int nx = s->unx, nu = m.nu > 0 ? s->unu : 0, nr = nu + nx, nt = NT > 0 ? nx : 0;
+  std::vector<double> F((size_t)NR), Fb((size_t)NR * NX), Ft((size_t)NR * std::max(NT, 1));
+  if (int rc = get_gains_dev(s, b, t, F.data(), Fb.data(), NT > 0 ? Ft.data() : nullptr))
+    return rc;
+  for (int r = 0; r < nr; ++r) {
+    const int rd = gain_row(s, r, m.nu);
+    if (ff)
+      ff[r] = F[(size_t)rd];
+    if (fb)
+      for (int j = 0; j < nx; ++j)
+        fb[(size_t)r * nx + j] = Fb[(size_t)rd * NX + j];
+    if (fth)
+      for (int j = 0; j < nt; ++j)
+        fth[(size_t)r * nt + j] = Ft[(size_t)rd * NT + j];
+  }
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, double *Vxt, double *Vtt,
+                      double *vt) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, t))
+    return rc;
+  if (!s->padded)
+    return get_value_dev(s, b, t, Vxx, vx, Vxt, Vtt, vt);
+  const gar_stage_meta &m = s->meta[t];
+  const int NX = m.nx, NT = m.nth, nx = s->unx, nt = NT > 0 ? nx : 0;
+  std::vector<double> V((size_t)NX * NX), v((size_t)NX), Xt((size_t)NX * std::max(NT, 1)),
+      Tt((size_t)std::max(NT, 1) * std::max(NT, 1)), tv((size_t)std::max(NT, 1));
+  if (int rc = get_value_dev(s, b, t, V.data(), v.data(), Xt.data(), Tt.data(), tv.data()))
+    return rc;
+  for (int j = 0; j < nx; ++j) {
+    if (Vxx)
+      std::memcpy(Vxx + (size_t)j * nx, &V[(size_t)j * NX], sizeof(double) * (size_t)nx);
+    if (vx)
+      vx[j] = v[(size_t)j];
+  }
+  for (int j = 0; j < nt; ++j) {
+    if (Vxt)
+      std::memcpy(Vxt + (size_t)j * nx, &Xt[(size_t)j * NX], sizeof(double) * (size_t)nx);
+    if (Vtt)
+      std::memcpy(Vtt + (size_t)j * nt, &Tt[(size_t)j * NT], sizeof(double) * (size_t)nt);
+    if (vt)
+      vt[j] = tv[(size_t)j];
+  }
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_kkt(gar_hip_solver *s, int b, int t, double mueq, double *out) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, t))
+    return rc;
+  if (!s->padded)
+    return get_kkt_dev(s, b, t, mueq, out);
+  if (!out)
+    return fail(GAR_HIP_ERR_ARG, "null output");
+  const gar_stage_meta &m = s->meta[t];
+  const int NU = m.nu, nu = NU > 0 ? s->unu : 0;
+  if (nu == 0)
+    return GAR_HIP_OK;
+  std::vector<double> K((size_t)NU * NU);
+  if (int rc = get_kkt_dev(s, b, t, mueq, K.data()))
+    return rc;
+  for (int j = 0; j < nu; ++j)
+    std::memcpy(out + (size_t)j * nu, &K[(size_t)j * NU], sizeof(double) * (size_t)nu);
+  return GAR_HIP_OK;
+}
+
+int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff, double *kkt0_fth, double *thGrad,
+                        double *thHess) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  if (!s->padded)
+    return get_initial_dev(s, b, kkt0_ff, kkt0_fth, thGrad, thHess);
+  const int n0 = s->n0, NT = s->nth0, NX = s->pnx, nx = s->unx, nt = NT > 0 ? nx : 0, n0u = nx + s->user_nc0;
+  std::vector<double> F((size_t)n0), Ft((size_t)n0 * std::max(NT, 1)), g((size_t)std::max(NT, 1)),
+      H((size_t)std::max(NT, 1) * std::max(NT, 1));
+  if (int rc = get_initial_dev(s, b, F.data(), Ft.data(), g.data(), H.data()))
+    return rc;
+  for (int r = 0; r < n0u; ++r) { // kkt0.ff = [x0; lbd0]: the real entries of each part
+    const int rd = r < nx ? r : r - nx + NX;
+    if (kkt0_ff)
+      kkt0_ff[r] = F[(size_t)rd];
+    if (kkt0_fth)
+      for (int j = 0; j < nt; ++j)
+        kkt0_fth[(size_t)r * nt + j] = Ft[(size_t)rd * NT + j];
+  }
+  for (int j = 0; j < nt; ++j) {
+    if (thGrad)
+      thGrad[j] = g[(size_t)j];
+    if (thHess)
+      std::memcpy(thHess + (size_t)j * nt, &H[(size_t)j * NT], sizeof(double) * (size_t)nt);
+  }
+  return GAR_HIP_OK;
+}
+
+/* ---- the device side of a (possibly padded) solver, for device-resident producers and consumers ---------------- */
+int gar_hip_device_stage_layout(const gar_hip_solver *s, int t, int64_t out[11]) {
+  if (int rc = check_bt(s, 0, t))
+    return rc;
+  const gar_stage_meta &m = s->meta[t];
+  out[0] = m.nx; out[1] = m.nu; out[2] = m.nc; out[3] = m.nx2; out[4] = s->dims5[5 * (size_t)t + 4];
+  out[5] = m.in_off; out[6] = m.fac_off; out[7] = m.x_off; out[8] = m.u_off; out[9] = m.v_off; out[10] = m.l_off;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_device_sizes(const gar_hip_solver *s, int64_t out[8]) {
+  if (!s || !out)
+    return fail(GAR_HIP_ERR_ARG, "bad argument");
+  out[0] = s->prob_doubles; out[1] = s->fac_doubles; out[2] = s->sol_doubles; out[3] = s->nc0;
+  out[4] = s->G0_off; out[5] = s->g0_off; out[6] = s->padded ? 1 : 0; out[7] = s->init_doubles;
+  return GAR_HIP_OK;
 }
 
 } // extern "C"

@@ -53,117 +53,50 @@ class _ValueView:
 
 
 class _FactorView:
-    """The surviving outputs of gar::StageFactor (riccati-kernel.hpp:88-101)."""
-    __slots__ = ("nx", "nu", "nc", "nx2", "nth", "ff", "fb", "fth", "vm", "kktMat")
+    """The surviving outputs of gar::StageFactor (riccati-kernel.hpp:88-101).  `kktMat` is formed on the device on
+    first access (gar_hip_get_kkt: a kernel launch and a synchronisation nobody pays who does not read it)."""
+    __slots__ = ("nx", "nu", "nc", "nx2", "nth", "ff", "fb", "fth", "vm", "_kkt", "_kkt_fn")
+
+    @property
+    def kktMat(self):
+        if self._kkt is None:
+            self._kkt = self._kkt_fn()
+        return self._kkt
 
 
 class _Kkt0View:
     __slots__ = ("ff", "fth")
 
 
-# (nx, nu) shapes with specialised kernels (csrc/gar_hip.cpp: bind_mfma / bind_leg)
-SPECIALISED_SHAPES = {(36, 12), (32, 12), (16, 8), (12, 8), (12, 4), (8, 4), (56, 24)}
-
-
-# ... of which these have no parallel-in-time (wave-leg) kernels: never a padding target in leg mode
-SERIAL_ONLY_SHAPES = {(56, 24)}
-
-
-def _padded_dims(dims: np.ndarray, num_legs: int = 1):
-    """Padding onto a specialised shape: a uniform unconstrained, unparameterised problem whose
-    (nx, nu) has no kernel of its own runs on the smallest specialised shape (NX >= nx, NU >= nu)
-    with DUMMY controls (R = I, S = 0, B = 0, r = 0) and DUMMY states (Q = I, A = 0, B = 0, f = 0,
-    pinned to zero by extra rows [0 -I] x0 = 0 of the initial constraint): both solve to exactly
-    zero, decouple from the real variables, and are stripped from every result.
-    Returns (NX, NU), or None when padding does not apply."""
-    N = dims.shape[0] - 1
-    if N < 1:
-        return None
-    nx, nu = int(dims[0, 0]), int(dims[0, 1])
-    if nu == 0 or ((nx, nu) in SPECIALISED_SHAPES and not (num_legs > 1 and (nx, nu) in SERIAL_ONLY_SHAPES)):
-        return None
-    if not ((dims[:N] == (nx, nu, 0, nx, 0)).all() and tuple(dims[N]) == (nx, 0, 0, nx, 0)):
-        return None
-    fits = [(NX * (NX + NU), NX, NU) for (NX, NU) in SPECIALISED_SHAPES
-            if NX >= nx and NU >= nu and not (num_legs > 1 and (NX, NU) in SERIAL_ONLY_SHAPES)]
-    if not fits:
-        return None
-    _, NX, NU = min(fits)
-    return NX, NU
-
-
-def _pad_knot(k: LqrKnot, nxp: int, nup: int) -> LqrKnot:
-    nup = nup if k.nu > 0 else 0
-    if (k.nx, k.nu) == (nxp, nup):
-        return k
-    # (leg mode: the caller's knots carry the parameterisation ParallelRiccatiSolver wrote into
-    # them; the device keeps it implicit, so the padded knot has none)
-    assert k.nc == 0 and k.nx2 == k.nx
-    nx, nu = k.nx, k.nu
-    p = LqrKnot(nxp, nup, 0, nxp, 0)
-    p.Q[:nx, :nx] = k.Q
-    p.Q[np.arange(nx, nxp), np.arange(nx, nxp)] = 1.0
-    p.q[:nx] = k.q
-    p.A[:nx, :nx] = k.A
-    p.f[:nx] = k.f
-    if nu > 0:
-        p.S[:nx, :nu] = k.S
-        p.R[:nu, :nu] = k.R
-        p.R[np.arange(nu, nup), np.arange(nu, nup)] = 1.0
-        p.r[:nu] = k.r
-        p.B[:nx, :nu] = k.B
-    return p
-
-
-def _unpad_knot(p: LqrKnot, nx: int, nu: int) -> LqrKnot:
-    if (p.nx, p.nu) == (nx, nu):
-        return p
-    k = LqrKnot(nx, nu, 0, nx, 0)
-    k.Q[...], k.q[...], k.A[...], k.f[...] = p.Q[:nx, :nx], p.q[:nx], p.A[:nx, :nx], p.f[:nx]
-    if nu > 0:
-        k.S[...], k.R[...], k.r[...], k.B[...] = p.S[:nx, :nu], p.R[:nu, :nu], p.r[:nu], p.B[:nx, :nu]
-    return k
-
-
 class BatchedRiccatiSolver:
     """`batch` LQ problems with the same per-stage dimensions on one GPU.
 
-    dims: (horizon+1) x (nx, nu, nc, nx2, nth).  num_legs = 1 is the serial
-    ProximalRiccatiSolver algorithm, >= 2 the ParallelRiccatiSolver one.
-    `dims`, `nc0` (attributes) are the dimensions of the device records; `user_dims`, `user_nc0`
-    those of the caller's problem (they differ only under padding, see _padded_dims).
+    dims: (horizon+1) x (nx, nu, nc, nx2, nth) -- the caller's dimensions.  num_legs = 1 is the serial
+    ProximalRiccatiSolver algorithm, >= 2 the ParallelRiccatiSolver one.  Kernel selection and padding onto a
+    specialised shape happen inside the C ABI (include/gar_hip.h, gar_hip_solver_create): everything here speaks
+    the caller's dimensions; `device_dims` / `device_layout()` report the device records (device-resident producers).
+    rank_of: (rank, world) -- horizon sharding, this solver owns legs [rank J / W, (rank+1) J / W).
     """
 
     def __init__(self, dims, nc0: int, batch: int = 1, num_legs: int = 1, device: int = 0,
-                 leg_range=None, lib_path: Optional[str] = None, pad_controls: bool = True,
-                 dense: bool = False):
+                 rank_of=None, lib_path: Optional[str] = None, dense: bool = False):
         self._L = _lib.load(lib_path)
-        self.dense = bool(dense)   # RiccatiSolverDense's algorithm (csrc/gar_dense.hpp): serial, no padding
+        self.dense = bool(dense)   # RiccatiSolverDense's algorithm (csrc/gar_dense.hpp): serial in time
         if self.dense:
-            assert num_legs == 1 and leg_range is None, "the stage-dense solver is serial in time"
-            pad_controls = False
-        self.user_dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int32).reshape(-1, 5))
-        self.dims = self.user_dims.copy()
-        self.user_nc0 = int(nc0)
-        import os
-        pad = _padded_dims(self.user_dims, int(num_legs)) if (pad_controls and os.environ.get("GAR_HIP_PAD", "1") != "0") else None
-        self._nxp, self._nup = pad if pad else (0, 0)   # padded (nx, nu) on the device; 0 = no padding
-        if pad:
-            self.dims[:, 0] = self.dims[:, 3] = self._nxp
-            self.dims[:-1, 1] = self._nup
+            assert num_legs == 1 and rank_of is None, "the stage-dense solver is serial in time"
+        self.dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int32).reshape(-1, 5))
+        self.nc0 = int(nc0)
         self.horizon = self.dims.shape[0] - 1
-        # dummy states are pinned by extra rows of the initial constraint
-        self.nc0 = self.user_nc0 + (self._nxp - int(self.user_dims[0, 0]) if pad else 0)
         self.batch, self.num_legs = int(batch), int(num_legs)
-        lb, le = leg_range if leg_range is not None else (0, self.num_legs)
+        rank, world = rank_of if rank_of is not None else (0, 1)
         if self.dense:
             self._h = self._L.gar_hip_solver_create_dense(
                 int(device), self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
                 self.nc0, self.batch)
         else:
-            self._h = self._L.gar_hip_solver_create_sharded(
+            self._h = self._L.gar_hip_solver_create_ranked(
                 int(device), self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
-                self.nc0, self.batch, self.num_legs, int(lb), int(le))
+                self.nc0, self.batch, self.num_legs, int(rank), int(world))
         if not self._h:
             raise RuntimeError(self._err())
         self._refresh_layout()
@@ -192,6 +125,16 @@ class BatchedRiccatiSolver:
         self._check(L.gar_hip_init_offsets(h, io.ctypes.data_as(C.POINTER(C.c_int64))))
         self.G0_off, self.g0_off = int(io[0]), int(io[1])
         self.kernel_name = L.gar_hip_kernel_name(h).decode()
+        # the device side (identical unless the library padded the shape onto a specialised family)
+        dl = np.zeros((self.horizon + 1, 11), dtype=np.int64)
+        for t in range(self.horizon + 1):
+            self._check(L.gar_hip_device_stage_layout(h, t, dl[t].ctypes.data_as(C.POINTER(C.c_int64))))
+        ds = np.zeros(8, dtype=np.int64)
+        self._check(L.gar_hip_device_sizes(h, ds.ctypes.data_as(C.POINTER(C.c_int64))))
+        self.device_dims = dl[:, :5].astype(np.int32)
+        self.device_stage_offsets = dl[:, 5:].copy()   # knot, factor, x, u, v, lbda
+        self.device_problem_doubles, self.device_factors_doubles, self.device_solution_doubles = (int(v) for v in ds[:3])
+        self.device_nc0, self.device_G0_off, self.device_g0_off, self.padded = int(ds[3]), int(ds[4]), int(ds[5]), bool(ds[6])
         self._factors_cache = {}
         self._mueq = None   # of the last backward (datas[t].kktMat is formed on request)
 
@@ -232,15 +175,13 @@ class BatchedRiccatiSolver:
         """One problem as the contiguous device record (csrc/gar_layout.h)."""
         buf = np.zeros(self.problem_doubles)
         nx0 = int(self.dims[0, 0])
-        G0, g0 = self._pad_init(problem.G0, problem.g0)
+        G0, g0 = problem.G0, problem.g0
         buf[self.G0_off:self.G0_off + self.nc0 * nx0] = _f64(G0).ravel(order="F")
         buf[self.g0_off:self.g0_off + self.nc0] = g0
         for t, k in enumerate(problem.stages):
             nx, nu, nc, nx2, nth = (int(v) for v in self.dims[t])
-            if (k.nx, k.nu, k.nc, k.nx2) != tuple(int(v) for v in self.user_dims[t, :4]):
+            if (k.nx, k.nu, k.nc, k.nx2) != tuple(int(v) for v in self.dims[t, :4]):
                 raise ValueError(f"knot {t}: dimensions differ from the solver's")
-            if self._nxp:
-                k = _pad_knot(k, self._nxp, self._nup)
             stored = nth if self.num_legs == 1 else 0
             p = int(self.stage_offsets[t, 0])
             for name, shp in block_shapes(nx, nu, nc, nx2, stored).items():
@@ -263,24 +204,12 @@ class BatchedRiccatiSolver:
                 n = int(np.prod(shp))
                 getattr(k, name)[...] = buf[p:p + n].reshape(shp, order="F")
                 p += n
-            knots.append(_unpad_knot(k, int(self.user_dims[t, 0]), int(self.user_dims[t, 1]))
-                         if self._nxp else k)
-        prob = LqrProblem(knots, self.user_nc0)
+            knots.append(k)
+        prob = LqrProblem(knots, self.nc0)
         nx0 = int(self.dims[0, 0])
-        G0 = buf[self.G0_off:self.G0_off + self.nc0 * nx0].reshape((self.nc0, nx0), order="F")
-        prob.G0[...] = G0[:self.user_nc0, :int(self.user_dims[0, 0])]
-        prob.g0[...] = buf[self.g0_off:self.g0_off + self.user_nc0]
+        prob.G0[...] = buf[self.G0_off:self.G0_off + self.nc0 * nx0].reshape((self.nc0, nx0), order="F")
+        prob.g0[...] = buf[self.g0_off:self.g0_off + self.nc0]
         return prob
-
-    def _pad_init(self, G0, g0):
-        """[G0 0; 0 -I], [g0; 0]: the dummy states start (and stay) at zero."""
-        if not self._nxp:
-            return G0, g0
-        nx, pad = int(self.user_dims[0, 0]), self.nc0 - self.user_nc0
-        G0p = np.zeros((self.nc0, self._nxp))
-        G0p[:self.user_nc0, :nx] = G0
-        G0p[self.user_nc0:, nx:] = -np.eye(pad)
-        return G0p, np.concatenate([np.asarray(g0, dtype=np.float64), np.zeros(pad)])
 
     def upload(self, problems: Sequence[LqrProblem], b0: int = 0):
         packed = np.concatenate([self.pack(p) for p in problems])
@@ -292,7 +221,8 @@ class BatchedRiccatiSolver:
         self._check(self._L.gar_hip_upload_packed(self._h, b0, nb, _ptr(packed)))
 
     def upload_packed_device(self, dev_ptr: int, b0: int = 0, nb: Optional[int] = None):
-        """`dev_ptr`: device address of nb packed problems (e.g. a torch tensor's data_ptr())."""
+        """`dev_ptr`: device address of nb packed DEVICE records (`device_problem_doubles` each, laid out by
+        `device_dims` / `device_stage_offsets`; e.g. a torch tensor's data_ptr())."""
         nb = self.batch - b0 if nb is None else nb
         self._check(self._L.gar_hip_upload_packed_device(self._h, b0, nb, C.c_void_p(dev_ptr)))
 
@@ -326,7 +256,7 @@ class BatchedRiccatiSolver:
     def pack_derivs(self, derivs, init) -> np.ndarray:
         """One problem's derivative buffer (csrc/gar_layout.h, gar_deriv_layout): header
         G0 | g0 | init Hxx, then one record per stage in DERIV_BLOCKS order."""
-        if self._nxp:
+        if self.padded:
             raise NotImplementedError("derivative records of a padded solver")
         buf = np.zeros(self.deriv_doubles)
         off = np.zeros(4, dtype=np.int64)
@@ -353,14 +283,11 @@ class BatchedRiccatiSolver:
 
     def upload_knot(self, b: int, t: int, k: LqrKnot):
         """gar_hip_upload_stage: the 16 separately allocated blocks of LqrKnotTpl."""
-        if self._nxp:
-            k = _pad_knot(k, self._nxp, self._nup)
         a = {n: _f64(getattr(k, n)) for n in BLOCK_NAMES}
         self._check(self._L.gar_hip_upload_stage(self._h, b, t, *[_ptr(a[n]) for n in BLOCK_NAMES]))
 
     def set_init(self, b: int, G0, g0):
-        G0, g0 = self._pad_init(np.asarray(G0), np.asarray(g0))
-        G0, g0 = _f64(G0), _f64(g0)
+        G0, g0 = _f64(np.asarray(G0)), _f64(np.asarray(g0))
         self._check(self._L.gar_hip_set_init(self._h, b, _ptr(G0), _ptr(g0)))
 
     # ---- the sweep ---------------------------------------------------------------
@@ -438,11 +365,6 @@ class BatchedRiccatiSolver:
         lbdas = list(np.split(Lb, np.cumsum(ldim)[:-1]))
         if d[N, 1] == 0:
             us.pop()
-        if self._nxp: # drop the dummy states / controls / multipliers (exactly zero)
-            ud = self.user_dims
-            xs = [x[:int(ud[t, 0])] for t, x in enumerate(xs)]
-            us = [u[:int(ud[t, 1])] for t, u in enumerate(us)]
-            lbdas = [lbdas[0][:self.user_nc0]] + [l[:int(ud[t, 3])] for t, l in enumerate(lbdas[1:])]
         return xs, us, vs, lbdas
 
     def fetch_results(self, b: int = 0, solution: bool = True, gains: bool = True):
@@ -475,10 +397,6 @@ class BatchedRiccatiSolver:
             self._check(self._L.gar_hip_gains_offsets(self._h, t, off.ctypes.data_as(C.POINTER(C.c_int64))))
             f = ff[int(off[0]):int(off[0]) + nr].copy()
             g = fb[int(off[1]):int(off[1]) + nr * nx].reshape(nr, nx).copy()
-            if self._nxp:  # drop the rows / columns of the dummy controls and states
-                unx, unu = int(self.user_dims[t, 0]), int(self.user_dims[t, 1])
-                keep = np.r_[0:unu, nu:nu + unx]
-                f, g = f[keep], np.ascontiguousarray(g[keep][:, :unx])
             ffs.append(f)
             fbs.append(g)
         return ffs, fbs
@@ -507,24 +425,14 @@ class BatchedRiccatiSolver:
         f.vm = vm
         # StageFactor::kktMat = [Rhat D^T; D -mu I] (expose-prox-riccati.cpp:30-31): not kept by the sweeps, formed
         # on the device on request from the knot and stage t+1's Vxx (gar_hip_get_kkt)
-        f.kktMat = np.zeros((nu + nc, nu + nc), order="F")
-        if not self.dense and nu + nc > 0 and self._mueq is not None:
-            self._check(self._L.gar_hip_get_kkt(self._h, b, t, float(self._mueq), _ptr(f.kktMat)))
-        if self._nxp: # drop the rows / columns of the dummy controls and states
-            unx, unu = int(self.user_dims[t, 0]), int(self.user_dims[t, 1])
-            uth = unx if nth > 0 else 0
-            keep = np.r_[0:unu, nu:nu + unx]
-            f.nx, f.nu, f.nx2, f.nth = unx, unu, unx, uth
-            kk = np.r_[0:unu, nu:nu + nc]
-            f.kktMat = np.asfortranarray(f.kktMat[np.ix_(kk, kk)])
-            f.ff = f.ff[keep]
-            f.fb = np.ascontiguousarray(f.fb[keep][:, :unx])
-            f.fth = np.ascontiguousarray(f.fth[keep][:, :uth])
-            vm.Vxx = np.asfortranarray(vm.Vxx[:unx, :unx])
-            vm.vx = vm.vx[:unx]
-            vm.Vxt = np.asfortranarray(vm.Vxt[:unx, :uth])
-            vm.Vtt = np.asfortranarray(vm.Vtt[:uth, :uth])
-            vm.vt = vm.vt[:uth]
+        mueq = self._mueq
+
+        def kkt():
+            out = np.zeros((nu + nc, nu + nc), order="F")
+            if not self.dense and nu + nc > 0 and mueq is not None:
+                self._check(self._L.gar_hip_get_kkt(self._h, b, t, float(mueq), _ptr(out)))
+            return out
+        f._kkt, f._kkt_fn = None, kkt
         self._factors_cache[key] = f
         return f
 
@@ -536,25 +444,10 @@ class BatchedRiccatiSolver:
         ff, fth = np.zeros(n0), np.zeros((n0, nth))
         g, H = np.zeros(nth), np.zeros((nth, nth), order="F")
         self._check(self._L.gar_hip_get_initial(self._h, b, _ptr(ff), _ptr(fth), _ptr(g), _ptr(H)))
-        if self._nxp: # kkt0.ff = [x0; lbd0]: the real entries of each part
-            unx = int(self.user_dims[0, 0])
-            keep = np.r_[0:unx, nx0:nx0 + self.user_nc0]
-            ff, fth = ff[keep], fth[keep]
         return ff, fth, g, H
 
     def cycle_append(self, dims5):
         d = np.ascontiguousarray(np.asarray(dims5, dtype=np.int32))
-        if self.horizon >= 1:
-            ud = self.user_dims.copy()
-            ud[:self.horizon - 1] = self.user_dims[1:self.horizon]
-            ud[self.horizon - 1] = d
-            self.user_dims = ud
-        if self._nxp:
-            if tuple(d) != tuple(self.user_dims[0]):
-                raise ValueError("cycle_append on a padded solver needs a knot of the same dimensions")
-            d = d.copy()
-            d[0] = d[3] = self._nxp
-            d[1] = self._nup
         self._check(self._L.gar_hip_cycle_append(self._h, d.ctypes.data_as(C.POINTER(C.c_int32))))
         N = self.horizon
         if N >= 1:

@@ -5,7 +5,7 @@ This is the multi-GPU form of gar::ParallelRiccatiSolver
 (gar/parallel-solver.hxx:132-243).  In the reference the legs are OpenMP threads
 of one process and the "boundary exchange" is the implicit barrier that closes
 the parallel region (:150-164 -> assembleCondensedSystem at :169).  Here rank r
-owns legs [r*L, (r+1)*L) of `num_legs` (L = num_legs / world):
+owns legs [r J / W, (r+1) J / W) of J = `num_legs` over W ranks (any W <= J, like get_work over threads):
 
   1. per-rank leg-parallel backward          gar_hip_backward_legs_async
   2. ONE all-gather of the per-leg boundary tuples (Vxx | Vxt | Vtt | vx | vt of
@@ -52,7 +52,7 @@ def _view(ptr: int, n: int, on_device: bool) -> torch.Tensor:
 
 class ShardedRiccatiSolver:
     """`batch` problems of identical dimensions, horizon split into `num_legs` legs,
-    the legs split evenly over the ranks of `group`."""
+    the legs split over the ranks of `group` (any number of ranks <= num_legs)."""
 
     def __init__(self, dims, nc0: int, num_legs: int, batch: int = 1, device: int = 0,
                  group: Optional[dist.ProcessGroup] = None, lib_path: Optional[str] = None,
@@ -60,19 +60,26 @@ class ShardedRiccatiSolver:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        if num_legs % self.world != 0 or num_legs < 2:
-            raise ValueError("num_legs must be >= 2 and a multiple of the number of ranks")
-        self.legs_per_rank = num_legs // self.world
+        if num_legs < 2 or num_legs < self.world:
+            # (the reference takes any thread count >= 2, parallel-solver.hxx:42-46; every rank needs a leg)
+            raise ValueError("num_legs must be >= 2 and >= the number of ranks")
         self.num_legs = num_legs
-        lo = self.rank * self.legs_per_rank
+        # rank r owns legs [r J / W, (r+1) J / W) -- any split, like get_work over threads (:23-28); the
+        # all-gather moves equal chunks of ceil(J / W) tuples, short chunks leave their tail unused
+        self.leg_range = (self.rank * num_legs // self.world, (self.rank + 1) * num_legs // self.world)
+        self.legs_per_rank = -(-num_legs // self.world)
+        lo = self.leg_range[0]
         self.impl = BatchedRiccatiSolver(dims, nc0, batch=batch, num_legs=num_legs, device=device,
-                                         leg_range=(lo, lo + self.legs_per_rank), lib_path=lib_path)
+                                         rank_of=(self.rank, self.world), lib_path=lib_path)
         self.on_device = torch.cuda.is_available() if on_device is None else on_device
         L, h = self.impl._L, self.impl.handle
         tup = int(L.gar_hip_boundary_doubles(h))
         n_local = batch * self.legs_per_rank * tup
         self._local = _view(L.gar_hip_device_boundary_local(h), n_local, self.on_device)
         self._all = _view(L.gar_hip_device_boundary_all(h), n_local * self.world, self.on_device)
+        # gloo moves host memory only: with device buffers (two ranks sharing one GPU in the tests, bench.py
+        # --backend gloo) the exchange is staged through the host -- a test path; RCCL gathers in place
+        self._staged = self.on_device and dist.get_backend(group) == "gloo"
         self.stream = None
         if self.on_device:
             # one (non-null) stream for the kernels and the collective: no host round trip inside a
@@ -80,7 +87,7 @@ class ShardedRiccatiSolver:
             self.stream = torch.cuda.Stream()
             self.impl.set_stream(self.stream.cuda_stream)
         self.stage_range = (get_work(self.impl.horizon, lo, num_legs)[0],
-                            get_work(self.impl.horizon, lo + self.legs_per_rank - 1, num_legs)[1])
+                            get_work(self.impl.horizon, self.leg_range[1] - 1, num_legs)[1])
 
     # ---- the sweep -----------------------------------------------------------------
     def backward(self, mueq: float, check: bool = True) -> bool:
@@ -92,11 +99,12 @@ class ShardedRiccatiSolver:
         device-to-host copy and an all-reduce of the flag, so that EVERY rank raises together."""
         L, h = self.impl._L, self.impl.handle
         self.impl._factors_cache = {}
+        self.impl._mueq = float(mueq)   # datas[t].kktMat is formed on request from this sweep's mueq
         import contextlib
         with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
             self.impl._check(L.gar_hip_backward_legs_async(h, float(mueq)))   # parallel-solver.hxx:150-164
             # the boundary exchange: one all-gather, rank-major == the layout the condensed solve reads
-            dist.all_gather_into_tensor(self._all, self._local, group=self.group)
+            self.exchange()
             self.impl._check(L.gar_hip_condensed_solve_async(h))             # :169-202, redundant per rank
         if check:
             nf = torch.tensor([self.impl.num_failed()], dtype=torch.int32,
@@ -105,6 +113,17 @@ class ShardedRiccatiSolver:
             if int(nf.item()) != 0:
                 raise RuntimeError("Failed stage LDL factorization")
         return True
+
+    def exchange(self):
+        """ONE all-gather of the boundary tuples into the buffer the condensed solve reads (equal chunks of
+        ceil(J / W) tuples per rank)."""
+        if not self._staged:
+            dist.all_gather_into_tensor(self._all, self._local, group=self.group)
+            return
+        self.stream.synchronize()
+        host = torch.empty(self._all.numel(), dtype=torch.float64)
+        dist.all_gather_into_tensor(host, self._local.cpu(), group=self.group)
+        self._all.copy_(host)
 
     def forward(self, sync: bool = True) -> bool:
         L, h = self.impl._L, self.impl.handle
@@ -133,8 +152,9 @@ class ShardedRiccatiSolver:
         N = self.impl.horizon
         owner = np.zeros(N + 1, dtype=int)
         for r in range(self.world):
-            s0 = get_work(N, r * self.legs_per_rank, self.num_legs)[0]
-            s1 = get_work(N, (r + 1) * self.legs_per_rank - 1, self.num_legs)[1]
+            l0, l1 = r * self.num_legs // self.world, (r + 1) * self.num_legs // self.world
+            s0 = get_work(N, l0, self.num_legs)[0]
+            s1 = get_work(N, l1 - 1, self.num_legs)[1]
             owner[s0:s1] = r
         out = []
         pos = 0

@@ -29,14 +29,21 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
     nx, nu = int(d[0, 0]), int(d[0, 1])
     assert N >= 1 and (d[:N] == d[0]).all() and d[0, 2] == 0 and d[0, 4] == 0 and d[N, 1] == 0
     assert solver.nc0 == nx
+    # the DEVICE records (= the caller's unless the library padded the shape onto a specialised family: then the
+    # dummy states / controls are filled in as the library itself does -- Q = I, R = I on them, everything else 0,
+    # pinned by the extra rows [0 -I] of G0)
+    dd = solver.device_dims
+    NX, NU = int(dd[0, 0]), int(dd[0, 1])
     dev = torch.device("cuda", torch.cuda.current_device())
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     f64 = torch.float64
-    rec = int(solver.stage_offsets[1, 0] - solver.stage_offsets[0, 0])
-    off0 = int(solver.stage_offsets[0, 0])
-    offN = int(solver.stage_offsets[N, 0])
-    P = solver.problem_doubles
+    so = solver.device_stage_offsets
+    rec = int(so[1, 0] - so[0, 0]) if N > 1 else int(so[N, 0] - so[0, 0])
+    off0 = int(so[0, 0])
+    offN = int(so[N, 0])
+    P = solver.device_problem_doubles
+    nc0d, G0_off = solver.device_nc0, solver.device_G0_off
     nw = nx + nu
     keep_idx = sorted({k % solver.batch for k in keep})
     solver._host_samples = {}
@@ -51,8 +58,8 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
         nb = min(chunk, solver.batch - b0)
         buf = torch.zeros(nb, P, device=dev, dtype=f64)
         # G0 = -I, g0 = x0 = 0   (tests/gar/test_util.cpp:72-74)
-        G0 = -torch.eye(nx, device=dev, dtype=f64)
-        buf[:, solver.G0_off:solver.G0_off + nx * nx] = _colmajor(G0)
+        G0 = -torch.eye(nc0d, NX, device=dev, dtype=f64)
+        buf[:, G0_off:G0_off + nc0d * NX] = _colmajor(G0)
         root = randn(nb, N, nw, nw + 1)
         qsr = root @ root.transpose(-1, -2) / max(nx, nu)
         Q = qsr[..., :nx, :nx]
@@ -67,8 +74,22 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
         else:
             A = torch.eye(nx, device=dev, dtype=f64) + 0.1 * randu(nb, N, nx, nx)
             B = 0.5 * randu(nb, N, nx, nu)
-        stage = torch.cat([_colmajor(Q), _colmajor(S), _colmajor(R), randu(nb, N, nx),
-                           randu(nb, N, nu), _colmajor(A), _colmajor(B), randn(nb, N, nx)], dim=-1)
+        def pad(m, R, C, diag=0.0):
+            """[..., r, c] -> [..., R, C] with `diag` on the new part of the diagonal."""
+            if m.shape[-2:] == (R, C):
+                return m
+            out = torch.zeros(*m.shape[:-2], R, C, device=dev, dtype=f64)
+            out[..., :m.shape[-2], :m.shape[-1]] = m
+            if diag:
+                i = torch.arange(min(m.shape[-2], m.shape[-1]), min(R, C), device=dev)
+                out[..., i, i] = diag
+            return out
+
+        def padv(v, R):
+            return torch.nn.functional.pad(v, (0, R - v.shape[-1]))
+        stage = torch.cat([_colmajor(pad(Q, NX, NX, 1.0)), _colmajor(pad(S, NX, NU)), _colmajor(pad(R, NU, NU, 1.0)),
+                           padv(randu(nb, N, nx), NX), padv(randu(nb, N, nu), NU), _colmajor(pad(A, NX, NX)),
+                           _colmajor(pad(B, NX, NU)), padv(randn(nb, N, nx), NX)], dim=-1)
         assert stage.shape[-1] <= rec
         view = buf[:, off0:off0 + N * rec].view(nb, N, rec)
         view[..., :stage.shape[-1]] = stage
@@ -76,7 +97,8 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
         rt = randn(nb, nx, nx + 1)
         Qt = rt @ rt.transpose(-1, -2) / nx
         At = randu(nb, nx, nx) if mode == "F" else (torch.eye(nx, device=dev, dtype=f64) + 0.1 * randu(nb, nx, nx))
-        term = torch.cat([_colmajor(Qt), randu(nb, nx), _colmajor(At), randn(nb, nx)], dim=-1)
+        term = torch.cat([_colmajor(pad(Qt, NX, NX, 1.0)), padv(randu(nb, nx), NX), _colmajor(pad(At, NX, NX)),
+                          padv(randn(nb, nx), NX)], dim=-1)
         buf[:, offN:offN + term.shape[-1]] = term
         torch.cuda.synchronize()  # generation done before the solver's stream copies it
         solver.upload_packed_device(buf.data_ptr(), b0, nb)
@@ -90,5 +112,8 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
 
 
 def download_problem(solver, b: int) -> LqrProblem:
-    """Host LqrProblem of a sampled problem (kept by fill_problems)."""
-    return solver.unpack(solver._host_samples[b % solver.batch])
+    """Host LqrProblem (the caller's dimensions) of a sampled problem."""
+    k = b % solver.batch
+    if solver.padded:   # the library strips the dummy rows / columns: gar_hip_download_packed
+        return solver.unpack(solver.download_packed(k, 1))
+    return solver.unpack(solver._host_samples[k])

@@ -9,6 +9,9 @@ nc=0, fp64, serial in time, `--batch` independent problems per GPU.
 
 N>1 GPUs: the batch axis shards with no data-path collective (weak scaling:
 `--batch` problems PER GPU); RCCL is used only for the timing barrier/max.
+`--gpus N` without a torchrun environment (WORLD_SIZE unset) spawns its own N ranks through
+torch.distributed.run on 127.0.0.1 -- like ParallelRiccatiSolver(problem, num_threads) spawns its own team
+(parallel-solver.hxx:150) -- and fails loudly when fewer than N devices are visible.
 
 Prints ONE JSON line on rank 0.
 """
@@ -50,6 +53,92 @@ def pmc_traffic(kernel, batch):
         return float(e["hbm_bytes_per_launch"])
     except Exception:
         return None
+
+
+def pmc_traffic_in_run(args, N, nx, nu, timeout=240):
+    """HBM bytes per launch of the backward sweep kernel measured IN THIS RUN when rocprofv3 is on PATH: two
+    counter-only passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; `--pmc X --kernel-trace`, nothing else, as
+    MI355X_MICROARCH.md prescribes) over a short child run of this script (`--pmc-child`: the same solver, batch and
+    data, one warm-up and two steps, then the library's own streaming kernel on the same number of records).  The
+    counters' units are calibrated in the same pass on that streaming kernel, whose byte counts are known exactly
+    and whose access pattern is the sweep's (16 B per lane, one record in flight per wave): bytes = counts x
+    (known bytes / counts of gar_stream_sweep).  Returns (bytes, detail) or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    knot_b = 8 * (2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu)
+    fac_b = 8 * ((nu + nx) * (nx + 1) + nx * nx + nx)
+    known = {"FETCH_SIZE": float(args.batch) * N * (-(-knot_b // 16) * 16), "WRITE_SIZE": float(args.batch) * N * (-(-fac_b // 16) * 16)}
+    got, detail = {}, {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gar_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(args.batch), "--horizon", str(N),
+               "--nx", str(nx), "--nu", str(nu), "--generator", args.generator]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}: {r.stdout.decode(errors='replace')[-200:]}"
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter:
+                        per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            bwd = [v for k, v in per.items() if "gar_backward" in k]
+            cal = [v for k, v in per.items() if "gar_stream_sweep" in k]
+            if not bwd or not cal or not sum(cal[0]):
+                return None, f"no {counter} rows for the sweep / calibration kernels"
+            per_count = known[counter] / (sum(cal[0]) / len(cal[0]))
+            got[counter] = sum(bwd[0]) / len(bwd[0]) * per_count
+            detail[counter] = {"counts_per_launch": sum(bwd[0]) / len(bwd[0]), "bytes_per_count": per_count,
+                               "launches": len(bwd[0])}
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out after {timeout} s"
+        except Exception as e:  # the measurement never fails the bench line
+            return None, f"{type(e).__name__}: {str(e)[:120]}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    detail["read_bytes"], detail["write_bytes"] = got["FETCH_SIZE"], got["WRITE_SIZE"]
+    return got["FETCH_SIZE"] + got["WRITE_SIZE"], detail
+
+
+def pmc_child(args):
+    """The workload of pmc_traffic_in_run's counter passes (run under rocprofv3): the bench's solver and data, one
+    warm-up and two steps, then the streaming kernel the counters are calibrated on."""
+    N, nx, nu = args.horizon, args.nx, args.nu
+    dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
+    torch.cuda.set_device(0)
+    solver = BatchedRiccatiSolver(dims, nx, batch=args.batch, num_legs=1, device=0)
+    synth_device.fill_problems(solver, seed=1234, mode=args.generator, keep=())
+    for _ in range(3):
+        solver.backward_async(1e-14)
+        solver.forward_async()
+    solver.sync()
+    knot_b = 8 * (2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu)
+    fac_b = 8 * ((nu + nx) * (nx + 1) + nx * nx + nx)
+    solver.close()
+    ms = solver._L.gar_hip_stream_ceiling_ms(0, int(args.batch), int(N), knot_b, fac_b, 1)
+    print(json.dumps({"pmc_child": True, "stream_ms": ms}))
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a torchrun environment: re-exec through torch.distributed.run with N local ranks."""
+    import socket, subprocess
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n < args.gpus and not args.same_device:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n} HIP device(s) visible")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def algorithmic_bytes(N, nx, nu):
@@ -220,14 +309,15 @@ def horizon_sharded(args, world, rank, device, dist, N=2048, legs=256, reps=10):
         s.forward(sync=False)
     torch.cuda.synchronize()
     dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+    el = torch.tensor([time.perf_counter() - t0], device="cuda" if dist.get_backend() == "nccl" else "cpu",
+                      dtype=torch.float64)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     ms = float(el.item()) / reps * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(s.stream):
         e0.record()
         for _ in range(reps):
-            dist.all_gather_into_tensor(s._all, s._local)
+            s.exchange()
         e1.record()
     torch.cuda.synchronize()
     ag_ms = e0.elapsed_time(e1) / reps
@@ -235,8 +325,8 @@ def horizon_sharded(args, world, rank, device, dist, N=2048, legs=256, reps=10):
     s.forward()
     resid, steps = s.impl.condensed_info(0)
     out = {"workload": f"one problem, N={N} nx={nx} nu={nu} fp64 (BASELINE.json configs[3]), horizon sharded",
-           "ranks": world, "legs": legs, "legs_per_rank": legs // world, "ms_per_sweep": ms,
-           "all_gather_ms": ag_ms, "all_gather_bytes_per_rank": 8 * (3 * nx * nx + 2 * nx) * (legs // world),
+           "ranks": world, "legs": legs, "legs_per_rank": s.legs_per_rank, "ms_per_sweep": ms,
+           "all_gather_ms": ag_ms, "all_gather_bytes_per_rank": 8 * (3 * nx * nx + 2 * nx) * s.legs_per_rank,
            "condensed_residual": resid, "refinement_steps": steps, "kernel": s.impl.kernel_name,
            "host_syncs_per_sweep": 0}
     if rank == 0:
@@ -284,9 +374,27 @@ def secondary_shapes(device, batch=1024):
         dt = (time.perf_counter() - t0) / reps
         knot = 2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu + nc * (nx + nu + 1)
         fac = (nu + nc + nx) * (nx + 1) + nx * nx + nx
+        # parity of what was just timed, in the same run: two problems of the batch (the first and the last) against
+        # the oracle -- solution, relative to the largest multiplier (O(1/mu) on the constrained shape), and the
+        # reference's own residual lqrComputeKktError (gar/utils.hxx:88-182) relative to the same scale
+        from aligator_amd.gar import lqrComputeKktError
+        from oracle import oracle as ora
+        err = kkt = 0.0
+        for b in (0, batch - 1):
+            prob = probs[b % 2]
+            sol = s.solution(b)
+            op = ora.Problem.from_knots(prob.stages, prob.G0, prob.g0)
+            osol = ora.ProximalRiccatiSolver(op)
+            osol.backward(mu)
+            ref = op.initialize_solution()
+            osol.forward(*ref)
+            scale = max(1.0, max(float(np.abs(v).max()) for part in ref for v in part if v.size))
+            err = max(err, max(float(np.abs(a - c).max()) for A, B in zip(sol, ref) for a, c in zip(A, B) if a.size) / scale)
+            kkt = max(kkt, max(lqrComputeKktError(prob, *sol, mueq=mu)) / scale)
         out[key] = {"workload": what, "batch": batch, "kernel": s.kernel_name, "sweeps_per_s": batch / dt,
                     "backward_ms": kb / reps, "failed_factorisations": failed,
-                    "backward_frac_of_hbm_roofline": 8 * (knot + fac) * N * batch / (kb / reps * 1e-3) / HBM_PEAK}
+                    "backward_frac_of_hbm_roofline": 8 * (knot + fac) * N * batch / (kb / reps * 1e-3) / HBM_PEAK,
+                    "max_rel_err_vs_oracle": err, "max_kkt_rel": kkt}
         s.close()
     return out
 
@@ -299,9 +407,18 @@ def stream_ceiling(solver, device, batch, N, nx, nu, bwd_bytes, bwd_ms):
     ms = solver._L.gar_hip_stream_ceiling_ms(int(device), int(batch), int(N), knot_b, fac_b, 3)
     if ms <= 0:
         return None
-    return {"ms": ms, "GBps": bwd_bytes * batch / (ms * 1e-3) / 1e9, "frac_of_peak": bwd_bytes * batch / (ms * 1e-3) / HBM_PEAK,
-            "kernel_over_stream": bwd_ms / ms,
-            "note": "a kernel that only moves the backward sweep's bytes (same waves, same walk), measured in this run"}
+    out = {"ms": ms, "GBps": bwd_bytes * batch / (ms * 1e-3) / 1e9, "frac_of_peak": bwd_bytes * batch / (ms * 1e-3) / HBM_PEAK,
+           "kernel_over_stream": bwd_ms / ms,
+           "note": "a kernel that only moves the backward sweep's bytes (same waves, same walk), measured in this run"}
+    # ... and a PLAIN grid-stride 16 B/lane copy of the same number of bytes (all waves resident, half read half
+    # written), in the same process: what this box's HBM gives the kernel the guide's 6.3 TB/s describes.  The gap
+    # between the two is what the sweep's walk (one record in flight per wave, 54:46 read:write) costs.
+    cms = solver._L.gar_hip_copy_ceiling_ms(int(device), int(bwd_bytes * batch), 3)
+    if cms > 0:
+        out["plain_copy"] = {"ms": cms, "GBps": bwd_bytes * batch / (cms * 1e-3) / 1e9,
+                             "frac_of_peak": bwd_bytes * batch / (cms * 1e-3) / HBM_PEAK,
+                             "kernel_over_copy": bwd_ms / cms, "stream_over_copy": ms / cms}
+    return out
 
 
 def parity_check(solver, args, mueq, nsample=2):
@@ -351,9 +468,19 @@ def main():
                     help="process-group backend for the timing barrier (gloo + --same-device lets two "
                          "ranks share one GPU to exercise the N>1 path on a 1-GPU box)")
     ap.add_argument("--same-device", action="store_true", help="testing: every rank uses cuda:0")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
+                    help="auto: roofline.traffic from rocprofv3 counter passes run inside this bench (rank 0, one GPU) "
+                         "when rocprofv3 is on PATH, the committed profiles/pmc_traffic.json otherwise; off: the file")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and "WORLD_SIZE" in os.environ and int(os.environ.get("RANK", "0")) == 0 and args.gpus != 1:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -453,8 +580,21 @@ def main():
     if world == 1 and not args.no_legs and (nx, nu) == (36, 12):
         pit = parallel_in_time(args, local_rank, stream, nx, nu, mueq)
     hs = None
-    if world > 1 and args.backend == "nccl" and not args.no_legs and (nx, nu) == (36, 12):
+    if world > 1 and not args.no_legs and (nx, nu) == (36, 12):
         hs = horizon_sharded(args, world, rank, local_rank, dist)  # secondary figure (configs[3])
+    traffic, traffic_src = pmc_traffic("backward", args.batch), None
+    if rank == 0:
+        traffic_src = ("committed rocprofv3 --pmc passes of this kernel at this batch (profiles/pmc_traffic.json, "
+                       "scripts/collect_pmc.sh), NOT collected in this run; null when the batch differs")
+        if world == 1 and args.pmc == "auto":
+            solver.sync()
+            live, detail = pmc_traffic_in_run(args, N, nx, nu)
+            if live is not None:
+                traffic, traffic_src = live, {"collected": "in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                                              "--kernel-trace only) over a child run of the same solver, batch and data; units "
+                                              "calibrated in the same pass on gar_stream_sweep's known byte counts", **detail}
+            else:
+                traffic_src += f" [in-run collection unavailable: {detail}]"
     if rank == 0:
         sweeps = args.batch * world * args.steps
         bwd_b, fwd_b = algorithmic_bytes(N, nx, nu)
@@ -480,10 +620,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"gar_backward_{solver.kernel_name}",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK,
-                         "traffic": pmc_traffic("backward", args.batch),
-                         "traffic_source": "committed rocprofv3 --pmc passes of this kernel at this batch "
-                                           "(profiles/pmc_traffic.json, scripts/collect_pmc.sh), NOT collected "
-                                           "in this run; null when the batch differs",
+                         "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bwd_b * args.batch,
                          # what this box's HBM sustains for the backward sweep's bytes alone: the same number of
                          # one-wave-per-problem streams, per stage the knot read (one ahead in flight) and the

@@ -78,21 +78,38 @@ int gar_hip_device_count(void);
 double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_bytes_per_stage,
                                  int64_t out_bytes_per_stage, int reps);
 
+/* Measurement aid beside it (roofline.stream_ceiling.plain_copy): milliseconds (best of `reps`) of a plain
+ * grid-stride 16-byte-per-lane copy that moves `bytes_moved` bytes in total (half read, half written) -- the
+ * kernel the guide's "achievable" HBM figure describes.  Allocates and frees bytes_moved bytes.  Negative on error. */
+double gar_hip_copy_ceiling_ms(int device, int64_t bytes_moved, int reps);
+
 /* ---- layout queries (pure host arithmetic, no GPU needed) ---------------- */
 /* doubles in the packed record of one knot / one factor (csrc/gar_layout.h) */
 int64_t gar_hip_knot_doubles(const int32_t dims5[5]);
 int64_t gar_hip_factor_doubles(const int32_t dims5[5]);
 
 /* ---- lifetime ------------------------------------------------------------ */
-/* dims5: (horizon+1) x {nx,nu,nc,nx2,nth} exactly as LqrKnotTpl's fields.
+/* dims5: (horizon+1) x {nx,nu,nc,nx2,nth} exactly as LqrKnotTpl's fields -- the CALLER's dimensions: what
+ *   `knot.nx, knot.nu, ...` say (ProximalRiccatiSolver's constructor reads them off the problem,
+ *   proximal-riccati.hxx:24-27).  Every entry point below that takes or returns a block, a packed problem, a
+ *   solution or a gain speaks these dimensions.
+ * Kernel selection and padding happen behind this call: a uniform unconstrained, unparameterised problem whose
+ *   (nx, nu) has no kernel family of its own -- e.g. the Talos walk's (56, 22), BASELINE configs[2]'s (12, 6),
+ *   configs[0]'s (4, 2) -- runs on the smallest specialised shape that holds it ((56, 24), (12, 8), (8, 4)), with
+ *   dummy controls / states that solve to exactly zero and are stripped from every result; gar_hip_kernel_name
+ *   reports the family that runs.  The device records then have the padded dimensions: device-resident producers
+ *   and consumers (gar_hip_device_*) ask gar_hip_device_stage_layout.  GAR_HIP_PAD=0 in the environment disables it.
  * num_legs = 1: serial-in-time ProximalRiccatiSolver semantics.
  * num_legs >= 2: ParallelRiccatiSolver(problem, num_legs) semantics; like the
  *   reference, every knot of a non-final leg is (implicitly) re-parameterised
  *   with nth = nx2 of the leg's last knot.
- * Horizon sharding over ranks: this solver owns legs [leg_begin, leg_end) of
- *   num_legs; pass (0, num_legs) for a single-GPU solver. */
+ * Horizon sharding over ranks (one rank per GPU): _ranked -- this solver owns legs [rank J / W, (rank+1) J / W) of
+ *   J = num_legs over W = world ranks, any 1 <= W <= J (the reference takes any thread count >= 2,
+ *   parallel-solver.hxx:42-46); _sharded is the even split [leg_begin, leg_end), kept for callers that count legs. */
 gar_hip_solver *gar_hip_solver_create(int device, int horizon, const int32_t *dims5,
                                       int nc0, int batch, int num_legs);
+gar_hip_solver *gar_hip_solver_create_ranked(int device, int horizon, const int32_t *dims5, int nc0, int batch,
+                                             int num_legs, int rank, int world);
 gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon,
                                               const int32_t *dims5, int nc0, int batch,
                                               int num_legs, int leg_begin, int leg_end);
@@ -110,16 +127,17 @@ void gar_hip_solver_destroy(gar_hip_solver *s);
 int gar_hip_set_stream(gar_hip_solver *s, void *hip_stream);
 int gar_hip_sync(gar_hip_solver *s);
 
-/* ---- sizes --------------------------------------------------------------- */
-int64_t gar_hip_problem_doubles(const gar_hip_solver *s);  /* one packed problem  */
-int64_t gar_hip_factors_doubles(const gar_hip_solver *s);  /* one problem's factors */
+/* ---- sizes (the caller's records: laid out by the caller's dimensions, csrc/gar_layout.h) ------------------ */
+int64_t gar_hip_problem_doubles(const gar_hip_solver *s);  /* one packed problem (gar_hip_upload_packed)  */
+int64_t gar_hip_factors_doubles(const gar_hip_solver *s);  /* one problem's factor records ON THE DEVICE */
 int64_t gar_hip_solution_doubles(const gar_hip_solver *s); /* one problem's xs|us|vs|lbdas */
 int gar_hip_batch(const gar_hip_solver *s);
 int gar_hip_horizon(const gar_hip_solver *s);
-/* which kernel family serves this solver: "generic" or "mfma<NX,NU>" */
+/* which kernel family serves this solver: "generic", "dense", or a specialised family such as "wave<36,12>",
+ * "mfma<36,12>", "wave<36,12,32>", "pair<56,24>", "wave_leg<12,8>" -- under padding the PADDED family */
 const char *gar_hip_kernel_name(const gar_hip_solver *s);
-/* offsets (doubles) of stage t inside one packed problem / one solution record:
- * out[0]=knot record, out[1]=factor record, out[2..5]= x,u,v,lbda offsets */
+/* offsets (doubles) of stage t inside one packed problem / one solution record of the caller:
+ * out[0]=knot record, out[1]=factor record (device), out[2..5]= x,u,v,lbda offsets */
 int gar_hip_stage_offsets(const gar_hip_solver *s, int t, int64_t out[6]);
 /* offset (doubles) of G0 and g0 inside one packed problem */
 int gar_hip_init_offsets(const gar_hip_solver *s, int64_t out[2]);
@@ -135,9 +153,9 @@ int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q,
                          const double *d, const double *Gth, const double *Gx,
                          const double *Gu, const double *Gv, const double *gamma);
 int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g0);
-/* nb already-packed problems (gar_hip_problem_doubles() each) starting at b0 */
+/* nb already-packed problems (gar_hip_problem_doubles() each, the caller's dimensions) starting at b0 */
 int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packed);
-/* same, but `packed_dev` is a DEVICE pointer (device-resident producers) */
+/* same, but `packed_dev` is a DEVICE pointer to DEVICE records (gar_hip_device_sizes()[0] doubles each) */
 int gar_hip_upload_packed_device(gar_hip_solver *s, int b0, int nb, const double *packed_dev);
 /* Flush the pinned staging area filled by upload_stage/set_init to the GPU.
  * backward() calls it implicitly when staging is dirty. */
@@ -148,6 +166,15 @@ int gar_hip_commit(gar_hip_solver *s);
 double *gar_hip_device_problems(gar_hip_solver *s);
 double *gar_hip_device_factors(gar_hip_solver *s);
 double *gar_hip_device_solutions(gar_hip_solver *s);
+/* The DEVICE side of the records behind those pointers (and behind gar_hip_upload_packed_device): identical to the
+ * caller's unless the solver is padded.
+ *   gar_hip_device_stage_layout  out[0..4] = nx,nu,nc,nx2,nth of stage t's device records, out[5] = knot record
+ *                                offset, out[6] = factor record offset, out[7..10] = x,u,v,lbda offsets
+ *   gar_hip_device_sizes         out[0..2] = doubles of one device problem / factor set / solution record,
+ *                                out[3] = rows of the device G0 (nc0 + dummy states), out[4..5] = offsets of G0, g0,
+ *                                out[6] = 1 if padded, out[7] = doubles of one initial-stage record */
+int gar_hip_device_stage_layout(const gar_hip_solver *s, int t, int64_t out[11]);
+int gar_hip_device_sizes(const gar_hip_solver *s, int64_t out[8]);
 
 /* nb packed problems (gar_hip_problem_doubles() each) back to the host (diagnostics, tests) */
 int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed);
@@ -160,7 +187,8 @@ int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed);
  * knot records in place (Q,R get `preg` on the diagonal, the dynamics Hessians are added when
  * hess_exact != 0, stage 0 gets the initial condition's Hessian).  Asynchronous on the solver's
  * stream: follow with gar_hip_backward_async.  out[0] of gar_hip_deriv_offsets = offset of stage
- * t's record, out[1..3] = offsets of G0, g0, init Hxx inside one problem's derivative buffer. */
+ * t's record, out[1..3] = offsets of G0, g0, init Hxx inside one problem's derivative buffer.
+ * Not available on a padded solver (GAR_HIP_ERR_UNSUPPORTED; GAR_HIP_PAD=0 keeps the caller's shape). */
 int64_t gar_hip_deriv_doubles(const gar_hip_solver *s);
 int gar_hip_deriv_offsets(const gar_hip_solver *s, int t, int64_t out[4]);
 int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_dev, double preg,
@@ -266,8 +294,9 @@ int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]);
  * of the problem or of the factors is copied, the stream is not synchronised; gar_hip_stage_offsets
  * reports where each (logical) stage now lives.  Otherwise (dimensions change, leg mode: "just
  * reinitialise everything", parallel-solver.hxx:246-258) the layout and the buffers are rebuilt:
- * the new layout is validated first (on error the solver is unchanged), device pointers fetched
- * earlier become invalid, resident problem data is not carried over. */
+ * the new configuration (padding, layout, LDS plan, kernel family) is validated on a trial object first -- on
+ * error the solver is unchanged, ring position included -- device pointers fetched earlier become invalid,
+ * resident problem data is not carried over.  dims5_new: the caller's dimensions of the new knot. */
 int gar_hip_cycle_append(gar_hip_solver *s, const int32_t dims5_new[5]);
 
 #ifdef __cplusplus

@@ -199,44 +199,8 @@ public:
 
 namespace detail {
 
-// Padding onto a specialised shape (same rule as aligator_amd/gar.py::_padded_dims): a uniform
-// unconstrained, unparameterised problem whose (nx, nu) has no kernel of its own runs on the smallest
-// specialised shape (NX >= nx, NU >= nu) with DUMMY controls (R = I, S = 0, B = 0, r = 0) and DUMMY
-// states (Q = I, A = 0, f = 0, pinned by extra rows [0 -I] x0 = 0 of the initial constraint): both
-// solve to exactly zero, decouple, and are stripped from every result.  {0, 0}: no padding.
-struct PaddedDims {
-  uint nx = 0, nu = 0;
-  explicit operator bool() const { return nx != 0; }
-};
-inline PaddedDims padded_dims(const LqrProblem &p, int num_legs = 1) {
-  const int N = p.horizon();
-  if (N < 1)
-    return {};
-  const uint nx = p.stages[0].nx, nu = p.stages[0].nu;
-  if (nu == 0)
-    return {};
-  for (int t = 0; t <= N; ++t) {
-    const LqrKnot &k = p.stages[t];
-    if (k.nx != nx || k.nx2 != nx || k.nc != 0 || k.nth != 0 || k.nu != (t < N ? nu : 0u))
-      return {};
-  }
-  const uint shapes[][2] = {{36, 12}, {32, 12}, {16, 8}, {12, 8}, {12, 4}, {8, 4}, {56, 24}};
-  PaddedDims best;
-  uint best_cost = ~0u;
-  for (auto &sh : shapes) {
-    if (num_legs > 1 && sh[0] == 56) // the wide family has no parallel-in-time kernels: not a target in leg mode
-      continue;
-    if (sh[0] == nx && sh[1] == nu)
-      return {}; // compiled in as it is
-    const uint cost = sh[0] * (sh[0] + sh[1]);
-    if (sh[0] >= nx && sh[1] >= nu && cost < best_cost) {
-      best_cost = cost;
-      best.nx = sh[0];
-      best.nu = sh[1];
-    }
-  }
-  return best;
-}
+// (Kernel selection and padding onto a specialised shape happen inside the C ABI, gar_hip_solver_create: this
+// mirror passes the knots' own dimensions and receives results in them.)
 
 // the six virtuals over the C ABI, shared by the two solvers
 class HipSolver : public RiccatiSolverBase {
@@ -264,21 +228,6 @@ public:
     check(gar_hip_fetch_results(h_, 0, 1));
     int64_t offs[3];
     const double *rec = gar_hip_host_results(h_, offs) + offs[0];
-    if (pad_) { // the device solution carries the dummy states / controls (exactly zero): drop them
-      const size_t nxd = pad_.nx, nud = pad_.nu, nx = problem_->stages[0].nx;
-      const size_t nc0d = problem_->nc0() + (nxd - nx);
-      const double *X = rec, *U = X + nxd * (size_t)(N + 1), *L = U + nud * (size_t)N;
-      for (size_t t = 0; t < xs.size(); ++t)
-        std::copy(X + t * nxd, X + t * nxd + xs[t].size(), xs[t].begin());
-      for (size_t t = 0; t < us.size(); ++t)
-        std::copy(U + t * nud, U + t * nud + us[t].size(), us[t].begin());
-      std::copy(L, L + lbdas[0].size(), lbdas[0].begin()); // user rows of G0 first
-      for (size_t t = 1; t < lbdas.size(); ++t) {
-        const size_t o = nc0d + (t - 1) * nxd;
-        std::copy(L + o, L + o + lbdas[t].size(), lbdas[t].begin());
-      }
-      return true;
-    }
     const double *p = rec;
     p = scatter(p, xs, nxs);
     p = scatter(p, us, nus);
@@ -288,49 +237,37 @@ public:
   }
   void cycleAppend(const LqrKnot &knot) override {
     gains_valid_ = false;
-    const int32_t d[5] = {(int)dev_nx(knot), (int)dev_nu(knot), (int)knot.nc, (int)dev_nx(knot),
-                          (int)knot.nth};
+    const int32_t d[5] = {(int)knot.nx, (int)knot.nu, (int)knot.nc, (int)knot.nx2, (int)knot.nth};
     check(gar_hip_cycle_append(h_, d));
   }
   VectorXs getFeedforward(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
-    const uint nud = dev_nu(k), nxd = dev_nx(k);
-    const double *src = gains(i, 0);
-    if (dense_) // block rows [kff; zff; lff; yff] (dense-riccati.hpp:49)
-      return VectorXs(src, src + k.nu + k.nc + 2 * k.nx2);
-    VectorXs ff(src, src + nud + k.nc + nxd);
-    ff.resize(nud + k.nc + k.nx2);                 // rows of the dummy co-states (last)
-    ff.erase(ff.begin() + k.nu, ff.begin() + nud); // rows of the dummy controls
-    return ff;
+    const double *src = gains(i, 0); // block rows [kff; zff; yff] (dense: [kff; zff; lff; yff], dense-riccati.hpp:49)
+    return VectorXs(src, src + k.nu + k.nc + (dense_ ? 2 * k.nx2 : k.nx2));
   }
   Matrix getFeedback(size_t i) override {
     const LqrKnot &k = problem_->stages[i];
-    const uint nud = dev_nu(k), nxd = dev_nx(k);
     const int nr = (int)(k.nu + k.nc + (dense_ ? 2 * k.nx2 : k.nx2));
-    const double *rm = gains(i, 1); // row-major (nud + nc + nxd | 2 nx2) x nxd
+    const double *rm = gains(i, 1); // row-major nr x nx like StageFactor::fb
     Matrix fb(nr, (int)k.nx);
-    for (int r = 0; r < nr; ++r) {
-      const int rd = r < (int)k.nu ? r : r + (int)(nud - k.nu);
+    for (int r = 0; r < nr; ++r)
       for (uint j = 0; j < k.nx; ++j)
-        fb(r, (int)j) = rm[(size_t)rd * nxd + j];
-    }
+        fb(r, (int)j) = rm[(size_t)r * k.nx + j];
     return fb;
   }
   const char *kernelName() const { return gar_hip_kernel_name(h_); }
 
 protected:
   HipSolver(LqrProblem &problem, int num_legs, int device, bool dense = false)
-      : problem_(&problem), pad_(dense ? PaddedDims{} : padded_dims(problem, num_legs)), dense_(dense) {
+      : problem_(&problem), dense_(dense) {
     const int N = problem.horizon();
     std::vector<int32_t> dims5;
     for (const LqrKnot &k : problem.stages) {
-      const int32_t d[5] = {(int)dev_nx(k), (int)dev_nu(k), (int)k.nc, (int)(pad_ ? pad_.nx : k.nx2),
-                            num_legs > 1 ? 0 : (int)k.nth};
+      const int32_t d[5] = {(int)k.nx, (int)k.nu, (int)k.nc, (int)k.nx2, num_legs > 1 ? 0 : (int)k.nth};
       dims5.insert(dims5.end(), d, d + 5);
     }
-    const uint nc0d = problem.nc0() + (pad_ ? pad_.nx - problem.stages[0].nx : 0u);
-    h_ = dense ? gar_hip_solver_create_dense(device, N, dims5.data(), (int)nc0d, 1)
-               : gar_hip_solver_create(device, N, dims5.data(), (int)nc0d, 1, num_legs);
+    h_ = dense ? gar_hip_solver_create_dense(device, N, dims5.data(), (int)problem.nc0(), 1)
+               : gar_hip_solver_create(device, N, dims5.data(), (int)problem.nc0(), 1, num_legs);
     if (!h_)
       throw std::runtime_error(gar_hip_last_error());
   }
@@ -338,32 +275,11 @@ protected:
   void upload() const {
     const auto &st = problem_->stages;
     for (int t = 0; t < (int)st.size(); ++t) {
-      if (pad_) {
-        const LqrKnot k = pad(st[t]);
-        check(gar_hip_upload_stage(h_, 0, t, k.Q.data(), k.S.data(), k.R.data(), k.q.data(),
-                                   k.r.data(), k.A.data(), k.B.data(), k.f.data(), k.C.data(),
-                                   k.D.data(), k.d.data(), k.Gth.data(), k.Gx.data(), k.Gu.data(),
-                                   k.Gv.data(), k.gamma.data()));
-        continue;
-      }
       const LqrKnot &k = st[t];
       check(gar_hip_upload_stage(h_, 0, t, k.Q.data(), k.S.data(), k.R.data(), k.q.data(),
                                  k.r.data(), k.A.data(), k.B.data(), k.f.data(), k.C.data(),
                                  k.D.data(), k.d.data(), k.Gth.data(), k.Gx.data(), k.Gu.data(),
                                  k.Gv.data(), k.gamma.data()));
-    }
-    if (pad_ && pad_.nx > st[0].nx) { // G0' = [G0 0; 0 -I], g0' = [g0; 0]
-      const int nx = (int)st[0].nx, nxd = (int)pad_.nx, nc0 = (int)problem_->nc0();
-      Matrix G(nc0 + nxd - nx, nxd);
-      VectorXs g((size_t)(nc0 + nxd - nx), 0.0);
-      for (int j = 0; j < nx; ++j)
-        for (int i = 0; i < nc0; ++i)
-          G(i, j) = problem_->G0(i, j);
-      for (int j = nx; j < nxd; ++j)
-        G(nc0 + j - nx, j) = -1.0;
-      std::copy(problem_->g0.begin(), problem_->g0.end(), g.begin());
-      check(gar_hip_set_init(h_, 0, G.data(), g.data()));
-      return;
     }
     check(gar_hip_set_init(h_, 0, problem_->G0.data(), problem_->g0.data()));
   }
@@ -392,36 +308,7 @@ protected:
     check(gar_hip_gains_offsets(h_, (int)i, go));
     return base + offs[1 + which] + go[which];
   }
-  uint dev_nu(const LqrKnot &k) const { return (pad_ && k.nu > 0) ? pad_.nu : k.nu; }
-  uint dev_nx(const LqrKnot &k) const { return pad_ ? pad_.nx : k.nx; }
-  LqrKnot pad(const LqrKnot &k) const {
-    const uint nxd = pad_.nx, nud = dev_nu(k);
-    LqrKnot p(nxd, nud, 0, nxd, 0);
-    for (uint j = 0; j < k.nx; ++j) {
-      for (uint i = 0; i < k.nx; ++i) {
-        p.Q((int)i, (int)j) = k.Q((int)i, (int)j);
-        p.A((int)i, (int)j) = k.A((int)i, (int)j);
-      }
-      p.q[j] = k.q[j];
-      p.f[j] = k.f[j];
-    }
-    for (uint j = k.nx; j < nxd; ++j)
-      p.Q((int)j, (int)j) = 1.0;
-    for (uint j = 0; j < k.nu; ++j) {
-      for (uint i = 0; i < k.nx; ++i) {
-        p.S((int)i, (int)j) = k.S((int)i, (int)j);
-        p.B((int)i, (int)j) = k.B((int)i, (int)j);
-      }
-      for (uint i = 0; i < k.nu; ++i)
-        p.R((int)i, (int)j) = k.R((int)i, (int)j);
-      p.r[j] = k.r[j];
-    }
-    for (uint j = k.nu; j < nud; ++j)
-      p.R((int)j, (int)j) = 1.0;
-    return p;
-  }
   LqrProblem *problem_;
-  PaddedDims pad_; // device dimensions when the problem is padded onto a specialised shape
   bool dense_ = false; // RiccatiSolverDense: nu+nc+2*nx2 gain rows
   mutable bool gains_valid_ = false;
   gar_hip_solver *h_ = nullptr;

@@ -212,6 +212,74 @@ static void padded_shape(uint nx, uint nu, const char *kernel) {
   REQUIRE(maxdiff(lp, lbdas) <= 1e-8);
 }
 
+// The raw C ABI with the CALLER's dimensions (what the HipRiccatiSolver of INTEGRATION.md passes: knot.nx, knot.nu
+// as they are): kernel selection and padding happen inside gar_hip_solver_create -- the Talos walk's (56, 22) must
+// reach pair<56,24>, every result must come back in the caller's shapes, and the solution must satisfy the
+// reference's residual (lqrComputeKktError, gar/utils.hxx:88-182) and equal the stage-dense solver's (which never
+// pads) -- two kernel families, two algorithms, one answer.
+static void raw_c_abi_wide_shape() {
+  const uint nx = 56, nu = 22, horz = g_small ? 3 : 275;
+  std::printf("raw_c_abi_wide_shape (nx=%u, nu=%u, N=%u)\n", nx, nu, horz);
+  std::mt19937 rng(23);
+  auto problem = generate_problem(rng, VectorXs(nx, 0.1), horz, nx, nu);
+  std::vector<int32_t> dims5;
+  for (const LqrKnot &k : problem.stages) {
+    const int32_t d[5] = {(int)k.nx, (int)k.nu, (int)k.nc, (int)k.nx2, (int)k.nth};
+    dims5.insert(dims5.end(), d, d + 5);
+  }
+  gar_hip_solver *h = gar_hip_solver_create(0, (int)horz, dims5.data(), (int)problem.nc0(), 1, 1);
+  REQUIRE(h != nullptr);
+  if (!h)
+    return;
+  std::printf("  kernel %s\n", gar_hip_kernel_name(h));
+  REQUIRE(std::string(gar_hip_kernel_name(h)) == "pair<56,24>");
+  for (int t = 0; t <= (int)horz; ++t) {
+    const LqrKnot &k = problem.stages[(size_t)t];
+    REQUIRE(gar_hip_upload_stage(h, 0, t, k.Q.data(), k.S.data(), k.R.data(), k.q.data(), k.r.data(), k.A.data(),
+                                 k.B.data(), k.f.data(), k.C.data(), k.D.data(), k.d.data(), k.Gth.data(), k.Gx.data(),
+                                 k.Gu.data(), k.Gv.data(), k.gamma.data()) == GAR_HIP_OK);
+  }
+  REQUIRE(gar_hip_set_init(h, 0, problem.G0.data(), problem.g0.data()) == GAR_HIP_OK);
+  REQUIRE(gar_hip_backward(h, 1e-12) == GAR_HIP_OK);
+  REQUIRE(gar_hip_forward(h, nullptr) == GAR_HIP_OK);
+  auto [xs, us, vs, lbdas] = lqrInitializeSolution(problem);
+  std::vector<double> X((size_t)(horz + 1) * nx), U((size_t)horz * nu), Lb((size_t)problem.nc0() + (size_t)horz * nx);
+  REQUIRE(gar_hip_get_solution(h, 0, X.data(), U.data(), nullptr, Lb.data()) == GAR_HIP_OK);
+  for (size_t t = 0; t <= horz; ++t)
+    std::copy(X.begin() + (long)(t * nx), X.begin() + (long)((t + 1) * nx), xs[t].begin());
+  for (size_t t = 0; t < horz; ++t)
+    std::copy(U.begin() + (long)(t * nu), U.begin() + (long)((t + 1) * nu), us[t].begin());
+  std::copy(Lb.begin(), Lb.begin() + (long)problem.nc0(), lbdas[0].begin());
+  for (size_t t = 1; t <= horz; ++t)
+    std::copy(Lb.begin() + (long)(problem.nc0() + (t - 1) * nx), Lb.begin() + (long)(problem.nc0() + t * nx), lbdas[t].begin());
+  const double kkt = lqrComputeKktError(problem, xs, us, vs, lbdas, 1e-12).max;
+  std::printf("  kkt %.2e\n", kkt);
+  REQUIRE(kkt <= 1e-9);
+  int64_t gd[2];
+  REQUIRE(gar_hip_gains_doubles(h, gd) == GAR_HIP_OK);
+  REQUIRE(gd[0] == (int64_t)horz * (nu + nx) + nx && gd[1] == (int64_t)horz * (nu + nx) * nx + (int64_t)nx * nx);
+  std::vector<double> ff(nu + nx), fb((size_t)(nu + nx) * nx);
+  REQUIRE(gar_hip_get_gains(h, 0, 0, ff.data(), fb.data(), nullptr) == GAR_HIP_OK);
+  // u0 = kff + K x0 with the returned (22 x 56) gains reproduces the returned control
+  double worst = 0.0;
+  for (uint i = 0; i < nu; ++i) {
+    double u = ff[i];
+    for (uint j = 0; j < nx; ++j)
+      u += fb[(size_t)i * nx + j] * xs[0][j];
+    worst = std::max(worst, std::abs(u - us[0][i]));
+  }
+  REQUIRE(worst <= 1e-10);
+  gar_hip_solver_destroy(h);
+  if (g_small) { // and against the stage-dense solver, which runs at the caller's own dimensions
+    RiccatiSolverDense dense{problem};
+    dense.backward(1e-12);
+    auto [xd, ud, vd, ld] = lqrInitializeSolution(problem);
+    dense.forward(xd, ud, vd, ld);
+    REQUIRE(maxdiff(xd, xs) <= 1e-9);
+    REQUIRE(maxdiff(ud, us) <= 1e-9);
+  }
+}
+
 // tests/gar/riccati.cpp:141-155 ("test dense solver"): KKT error <= 1e-8, and the same trajectory as
 // the Riccati recursion
 static void dense_solver() {
@@ -323,6 +391,7 @@ int main() {
   mpc_cycle();
   padded_shape(12, 6, "12,8");
   padded_shape(10, 3, "12,4");
+  raw_c_abi_wide_shape();
   error_behaviour();
   std::printf(g_failed ? "%d REQUIRE(s) FAILED\n" : "all passed\n", g_failed);
   return g_failed ? 1 : 0;

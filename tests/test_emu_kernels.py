@@ -133,7 +133,7 @@ def test_padded_states_and_controls(nx, nu, horz, legs, kernel):
     rng = np.random.default_rng(nx * 7 + nu)
     prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
     s, _, _ = pc.check_serial(prob, 1e-10, 1e-9, EMU, kkt_tol=1e-9)
-    assert kernel in s._impl.kernel_name and tuple(s._impl.user_dims[0][:2]) == (nx, nu)
+    assert kernel in s._impl.kernel_name and tuple(s._impl.dims[0][:2]) == (nx, nu) and s._impl.padded
     if legs > 1:
         par = pc.check_parallel(prob, 1e-10, legs, 1e-8, EMU, rounds=1, rng=rng)
         assert par._impl.kernel_name.startswith("wave_leg<")
@@ -528,3 +528,48 @@ def test_pair_kernel_on_the_narrow_shapes(monkeypatch, nx, nu, horz, mode):
     prob = synth.generate_lq_problem(80 + nx, np.ones(nx), horz, nx, nu, mode=mode)
     solver, _, _ = pc.check_serial(prob, 1e-12, pc.TOL[mode], EMU, kkt_tol=1e-6 if mode == "F" else 1e-9)
     assert solver.kernel_name == (f"pair<{nx},{nu}>" if nx == 36 else f"wave<{nx},{nu}>")
+
+
+@pytest.mark.parametrize("nx,nu", [(8, 4), (7, 3)])
+def test_rejected_cycle_append_leaves_the_ring_intact(nx, nu):
+    """a cycle_append whose new layout is rejected must leave the solver exactly as it was --
+    ring position, stage offsets, descriptors, device records -- also AFTER earlier uniform cycles (ring0 != 0, the
+    normal MPC case), on a plain and on a padded shape.  The new configuration is validated on a trial object."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    horz = 6
+    rng = np.random.default_rng(5)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+    dims = [k.dims for k in prob.stages]
+    s = BatchedRiccatiSolver(dims, prob.nc0, batch=1, lib_path=EMU)
+    s.upload([prob])
+    assert s.backward(1e-10) and s.forward()
+    for _ in range(2):                                             # two uniform cycles: ring0 = 2
+        s.cycle_append(dims[0])
+        new = synth.generate_knot(rng, nx, nu, mode="W")
+        prob.stages[:horz] = prob.stages[1:horz] + [new]
+        s.upload_knot(0, horz - 1, new)
+    assert s.backward(1e-10) and s.forward()
+    before, offs = s.solution(0), s.stage_offsets.copy()
+    gains = [s.factor(t).fb.copy() for t in range(horz + 1)]
+    for bad in ((-1, nu, 0, nx, 0), (400, 100, 0, 400, 0)):       # invalid dims; a knot no kernel's LDS plan holds
+        with pytest.raises(RuntimeError):
+            s.cycle_append(bad)
+        assert np.array_equal(s.stage_offsets, offs)
+        assert s.backward(1e-10) and s.forward()
+        after = s.solution(0)
+        for A, B in zip(after, before):
+            assert pc.maxdiff(A, B) == 0.0
+        for t in range(horz + 1):
+            assert np.array_equal(s.factor(t).fb, gains[t])
+    _, _, ref = pc.oracle_serial(prob, 1e-10)
+    for A, B in zip(before, ref):
+        assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
+    # ... and a VALID change of dimensions after the ring cycles still works (layout rebuilt, data re-uploaded)
+    wider = (nx, nu + 1, 0, nx, 0)
+    s.cycle_append(wider)
+    prob.stages[:horz] = prob.stages[1:horz] + [synth.generate_knot(rng, nx, nu + 1, mode="W")]
+    s.upload([prob])
+    assert s.backward(1e-10) and s.forward()
+    _, _, ref = pc.oracle_serial(prob, 1e-10)
+    for A, B in zip(s.solution(0), ref):
+        assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)

@@ -445,6 +445,13 @@ def test_bench_contract_single_gpu():
     assert sec["reference_bench_shape_nc32"]["kernel"] == "wave<36,12,32>" and sec["talos_walk_lq_shape"]["kernel"] == "pair<56,24>"
     for v in sec.values():
         assert v["sweeps_per_s"] > 0 and v["failed_factorisations"] == 0 and 0 < v["backward_frac_of_hbm_roofline"] < 1
+        # parity of what was timed, in the same run (relative to the largest multiplier: O(1/mu) at nc = 32)
+        assert v["max_rel_err_vs_oracle"] < 1e-7 and v["max_kkt_rel"] < 1e-9
+    assert sec["talos_walk_lq_shape"]["max_rel_err_vs_oracle"] < 1e-9
+    cp = sc["plain_copy"]            # the plain 16 B/lane copy of the same bytes, same process
+    assert cp["ms"] > 0 and 0.3 < cp["frac_of_peak"] < 1.0
+    # roofline.traffic: collected in this run when rocprofv3 is there (a dict describes how), else the committed file
+    assert isinstance(d["roofline"]["traffic_source"], (dict, str))
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -459,6 +466,32 @@ def test_bench_two_ranks_on_one_gpu():
                      "--steps", "2", "--warmup", "1", "--batch", "128", "--backend", "gloo", "--same-device"])
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d and "parallel_in_time" not in d
     assert abs(d["value"] - 2 * 128 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun around it (WORLD_SIZE unset): bench.py launches its own two ranks
+    (torch.distributed.run on 127.0.0.1) and reports n_gpus = 2 with the horizon-sharded figure (two ranks share
+    this box's GPU, gloo + host-staged exchange).  Asking for more GPUs than are visible fails loudly."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "128",
+                        "--backend", "gloo", "--same-device", "--single-generator"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import json
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2
+    hs = d["horizon_sharded"]
+    assert hs["ranks"] == 2 and hs["legs_per_rank"] == 128 and hs["max_rel_diff_vs_serial_on_rank0_stages"] < 1e-9
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n + 1), "--steps", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible" in (r.stdout + r.stderr)
 
 
 @pytest.mark.parametrize("nx,nu,horz,family,dense", [(36, 12, 24, "wave", False), (36, 12, 24, "wg4", False),
@@ -526,7 +559,7 @@ def test_padded_states_and_controls(nx, nu, horz, legs, kernel):
     rng = np.random.default_rng(nx * 7 + nu)
     prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
     s, _, _ = pc.check_serial(prob, 1e-10, 1e-9, kkt_tol=1e-9)
-    assert kernel in s._impl.kernel_name and tuple(s._impl.user_dims[0][:2]) == (nx, nu)
+    assert kernel in s._impl.kernel_name and tuple(s._impl.dims[0][:2]) == (nx, nu) and s._impl.padded
     par = pc.check_parallel(prob, 1e-10, legs, 1e-8, rounds=1, rng=rng)
     assert par._impl.kernel_name.startswith("wave_leg<")
 

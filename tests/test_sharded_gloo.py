@@ -35,7 +35,7 @@ if mode == "horizon":
     from aligator_amd.sharded import ShardedRiccatiSolver
     from test_golden import load_fixture, assert_matches
     prob, mueq, _, gold = load_fixture(os.path.join(sys.argv[1], "tests", "golden", "parallel_shape_nx8_N17.npz"))
-    for legs in (2, 4, 6):
+    for legs in (2, 3, 4, 5, 6):          # odd leg counts: an UNEVEN split over the two ranks (1 + 2, 2 + 3)
         s = ShardedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, legs, batch=1,
                                  lib_path=emu, on_device=False)
         s.impl.upload([prob])
@@ -44,9 +44,16 @@ if mode == "horizon":
         sol = s.gather_solution(0)
         assert_matches(sol, gold, 1e-8)
         assert max(lqrComputeKktError(prob, *sol, mueq=mueq)) <= 1e-8
-        # this rank really only computed its own stages
+        # this rank really only computed its own stages: legs [r J / 2, (r+1) J / 2) of get_work(17, ., J)
         lo, hi = s.stage_range
-        assert (lo, hi) == ((0, 9) if rank == 0 else (9, 18)), (lo, hi)
+        cut = (legs // 2) * 18 // legs
+        assert (lo, hi) == ((0, cut) if rank == 0 else (cut, 18)), (lo, hi, cut)
+        assert s.leg_range == ((0, legs // 2) if rank == 0 else (legs // 2, legs))
+        # datas[t].kktMat of a sharded solver is formed from THIS sweep's mueq (ADVICE r2)
+        t_own = lo
+        f = s.impl.factor(t_own, 0)
+        if f.nu > 0:
+            assert np.abs(np.diag(f.kktMat)).max() > 0.0
     print(f"rank {rank}: horizon sharding ok")
 else:
     # batch sharding (bench.py --gpus N): each rank sweeps its own problems; the only

@@ -38,7 +38,7 @@ def random_derivs(rng, dims, nc0):
 def run_case(lib_path, dims, nc0, batch, preg, hess_exact, device):
     from aligator_amd.gar import BatchedRiccatiSolver
     rng = np.random.default_rng(77)
-    s = BatchedRiccatiSolver(dims, nc0, batch=batch, lib_path=lib_path, pad_controls=False)  # device records = the caller's dims
+    s = BatchedRiccatiSolver(dims, nc0, batch=batch, lib_path=lib_path)
     host_probs, bufs = [], []
     for b in range(batch):
         derivs, init = random_derivs(rng, dims, nc0)
@@ -84,12 +84,23 @@ def emu_lib():
 
 
 @pytest.mark.parametrize("dims,nc0,batch,preg,exact", CASES)
-def test_update_lq_on_emulator(emu_lib, dims, nc0, batch, preg, exact):
+def test_update_lq_on_emulator(emu_lib, monkeypatch, dims, nc0, batch, preg, exact):
+    monkeypatch.setenv("GAR_HIP_PAD", "0")   # derivative records speak the device's dimensions: keep the caller's
     run_case(emu_lib, dims, nc0, batch, preg, exact, device=False)
+
+
+def test_update_lq_is_refused_on_a_padded_solver(emu_lib):
+    from aligator_amd.gar import BatchedRiccatiSolver
+    dims = CASES[0][0]
+    s = BatchedRiccatiSolver(dims, 4, batch=1, lib_path=emu_lib)
+    assert s.padded and s.kernel_name in ("mfma<8,4>", "wave<8,4>")
+    with pytest.raises(RuntimeError, match="padded"):
+        s.update_lq_subproblem_device(1, 0.0, False)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims,nc0,batch,preg,exact",
                          CASES + [([(36, 12, 0, 36, 0)] * 16 + [(36, 0, 0, 36, 0)], 36, 4, 1e-8, True)])
-def test_update_lq_on_gpu(dims, nc0, batch, preg, exact):
+def test_update_lq_on_gpu(monkeypatch, dims, nc0, batch, preg, exact):
+    monkeypatch.setenv("GAR_HIP_PAD", "0")
     run_case(None, dims, nc0, batch, preg, exact, device=True)
