@@ -68,6 +68,23 @@ template <int NX> __device__ __forceinline__ double cyc_matvec(const double *Mc,
   }
   return s0 + s1;
 }
+// sum_k |M(row, k)| |x_k| and its transpose: the denominators of the componentwise backward error
+template <int NX> __device__ __forceinline__ double cyc_absmatvec(const double *Mc, double x, int row) {
+  double s0 = 0.0;
+  const double ax = fabs(x);
+#pragma unroll
+  for (int k = 0; k < NX; ++k)
+    s0 = __builtin_fma(fabs(Mc[k * NX + row]), lane_bcast(ax, k), s0);
+  return s0;
+}
+template <int NX> __device__ __forceinline__ double cyc_absmatvecT(const double *Mc, double x, int row) {
+  double s0 = 0.0;
+  const double ax = fabs(x);
+#pragma unroll
+  for (int k = 0; k < NX; ++k)
+    s0 = __builtin_fma(fabs(Mc[row * NX + k]), lane_bcast(ax, k), s0);
+  return s0;
+}
 template <int NX> __device__ __forceinline__ double cyc_matvecT(const double *Mc, double x, int row) {
   double s0 = 0.0, s1 = 0.0; // sum_k M(k, row) x_k
 #pragma unroll
@@ -588,8 +605,26 @@ __global__ void __launch_bounds__(64) gar_cyclic_recover(CyclicParams Y) {
   rx -= (k == 0) ? G0T(lam) : -lam;
   if (k + 1 < J)
     rx -= cyc_matvec<NX>(tup + bs, lamn, row);
+  // |rhs| + |A| |sol| of the same rows; omega = max_i |r_i| / max_i (|rhs_i| + (|A| |sol|)_i) is the (row-scaled
+  // normwise) backward error of the solve.
+  // A residual at omega ~ n eps is all a backward-stable solve can deliver and all that refinement with fp64
+  // residuals can reach: with value functions of order 1/mu (constrained knots) the ABSOLUTE threshold of
+  // parallel-solver.hpp:92 is out of reach for ANY solver -- the reference then spends its maxRefinementSteps
+  // without effect (parallel-solver.hxx:184-202) -- so the gate below also accepts on omega (info[2]).
+  double dx = fabs(tup[3 * bs + row]) + cyc_absmatvec<NX>(tup, x, row);
+  if (k == 0) {
+    double g = 0.0;
+    const double al = fabs(lam);
+    for (int c = 0; c < nc0; ++c)
+      g += fabs(prob[P.G0_off + row * nc0 + c]) * lane_bcast(al, c);
+    dx += g;
+  } else {
+    dx += fabs(lam);
+  }
+  if (k + 1 < J)
+    dx += cyc_absmatvec<NX>(tup + bs, lamn, row);
   // lambda_k row
-  double rl;
+  double rl, dl = 0.0;
   if (k == 0) { // -g0 - G0 x_0
     double s = 0.0;
     for (int c = 0; c < NX; ++c)
@@ -597,6 +632,11 @@ __global__ void __launch_bounds__(64) gar_cyclic_recover(CyclicParams Y) {
     rl = (row < nc0 ? -prob[P.g0_off + row] : 0.0) - s;
     if (lane >= nc0)
       rl = 0.0;
+    double sa = 0.0;
+    const double axx = fabs(x);
+    for (int c = 0; c < NX; ++c)
+      sa += (row < nc0 ? fabs(prob[P.G0_off + c * nc0 + row]) : 0.0) * lane_bcast(axx, c);
+    dl = (row < nc0 ? fabs(prob[P.g0_off + row]) : 0.0) + sa;
   } else { // -vt_{k-1} - Vxt_{k-1}^T x_{k-1} - Vtt_{k-1} lambda_k + x_k
     double lamp = X.z[(k - 1) * NX + row];
     if (k - 1 == 0 && lane >= nc0)
@@ -605,6 +645,8 @@ __global__ void __launch_bounds__(64) gar_cyclic_recover(CyclicParams Y) {
     const double *tp = cond_tuple(P, b, k - 1);
     rl = -tp[3 * bs + NX + row] - cyc_matvecT<NX>(tp + bs, xp, row) -
          cyc_matvec<NX>(tp + 2 * bs, lam, row) + x;
+    dl = fabs(tp[3 * bs + NX + row]) + cyc_absmatvecT<NX>(tp + bs, xp, row) + cyc_absmatvec<NX>(tp + 2 * bs, lam, row) +
+         fabs(x);
   }
   double mx = fmax(fabs(rx), fabs(rl));
   if (rx != rx || rl != rl)
@@ -619,6 +661,19 @@ __global__ void __launch_bounds__(64) gar_cyclic_recover(CyclicParams Y) {
   if (lane == 0)
     atomicMax(reinterpret_cast<unsigned long long *>(&X.info[0]),
               (unsigned long long)__double_as_longlong(fabs(mx)));
+  double om = fmax(dx, dl); // (the ratio is formed by the reader: info[0] / info[2])
+  if (om != om)
+    om = 0.0;
+  if (lane >= NX)
+    om = 0.0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double other = __shfl_xor(om, o);
+    om = (other > om || other != other) ? other : om;
+  }
+  if (lane == 0)
+    atomicMax(reinterpret_cast<unsigned long long *>(&X.info[2]),
+              (unsigned long long)__double_as_longlong(fabs(om)));
 }
 
 } // namespace gar

@@ -57,6 +57,7 @@ struct GenericParams {
   double mueq;
   LdsPlan lds;
   DensePlan dense;
+  const int *only; // folded solvers (gar_fold.hpp): sweep only the problems with only[b] != 0 (null: all)
 };
 
 extern __shared__ double gar_smem[];
@@ -142,6 +143,8 @@ __global__ void __launch_bounds__(256) gar_backward_generic(GenericParams P) {
   double *sm = gar_smem;
   const int leg = (int)blockIdx.x + P.leg_begin;
   const int b = (int)blockIdx.y;
+  if (P.only != nullptr && P.only[b] == 0)
+    return;
   const double *prob = P.prob + (long long)b * P.prob_stride;
   double *fac = P.fac + (long long)b * P.fac_stride;
   int t_beg, t_end;
@@ -653,6 +656,8 @@ __global__ void __launch_bounds__(256) gar_forward_generic(GenericParams P) {
   double *sm = gar_smem;
   const int leg = (int)blockIdx.x + P.leg_begin;
   const int b = (int)blockIdx.y;
+  if (P.only != nullptr && P.only[b] == 0)
+    return;
   const double *fac = P.fac + (long long)b * P.fac_stride;
   double *sol = P.sol + (long long)b * P.sol_stride;
   int t_beg, t_end;
@@ -772,6 +777,9 @@ namespace gar {
 // One workgroup per problem; every rank runs it redundantly on the gathered
 // boundary tuples, so no second collective is needed.
 // ---------------------------------------------------------------------------
+// componentwise backward error at which a cyclic-reduction solve of the condensed system stands even though the
+// reference's ABSOLUTE residual threshold is out of reach (gar_cyclic_recover): ~ 100 n eps at n = 72
+#define GAR_CONDENSED_BACKWARD_OK 1e-12
 struct CondensedParams {
   const double *ball;  // gathered tuples: [rank][problem][legs_per_rank][tuple]; rank r owns legs
                        // [r J / W, (r+1) J / W) of J = num_legs over W = world ranks (any W <= J:
@@ -783,6 +791,7 @@ struct CondensedParams {
   long long prob_stride, scratch_stride, G0_off, g0_off;
   int batch, num_legs, legs_per_rank, tuple_doubles, nxb, nc0, nx0;
   int world; // ranks the legs are split over (1 on a single-GPU solver)
+  double backward_ok; // componentwise backward error at which a cyclic-reduction solve stands (0: never)
   int max_refinement;
   double threshold;
   long long *trace; // debug: cycle stamps of two elimination steps of problem 0 (or null)
@@ -809,7 +818,8 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
     const double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * bs + 4ll * nblk * nxb;
     // (refinement disabled: the cyclic-reduction result stands -- unless a block inverse failed
     // outright, which poisons the residual with +inf)
-    if (inf[0] <= P.threshold || (P.max_refinement == 0 && inf[0] <= 1.79e308))
+    if (inf[0] <= P.threshold || (P.max_refinement == 0 && inf[0] <= 1.79e308) ||
+        (inf[0] <= 1.79e308 && inf[0] <= P.backward_ok * inf[2])) // (see gar_cyclic_recover)
       return;
   }
   double *S = P.scratch + (long long)b * P.scratch_stride;
@@ -993,9 +1003,9 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
 // factor record of stage 0 (subdiagonal[1] holds the UNFACTORED Vxt(b0)^T after
 // backward()).
 __global__ void gar_collapse_feedback(const gar_stage_meta *meta, double *fac,
-                                      long long fac_stride, int batch) {
+                                      long long fac_stride, int batch, const int *flags, int want) {
   const int b = (int)blockIdx.x;
-  if (b >= batch)
+  if (b >= batch || (flags != nullptr && (flags[b] != 0) != (want != 0)))
     return;
   const gar_stage_meta m = meta[0];
   const gar_factor_offsets fo = gar_factor_layout(m.nx, m.nu, m.nc, m.nx2, m.nth);

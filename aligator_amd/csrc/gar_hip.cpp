@@ -23,6 +23,7 @@
 #include "gar_wave_pair.hpp"
 #include "gar_cyclic.hpp"
 #include "gar_dense.hpp"
+#include "gar_fold.hpp"
 
 namespace {
 
@@ -119,6 +120,15 @@ struct gar_hip_solver {
   bool padded = false;
   int unx = 0, unu = 0, pnx = 0, pnu = 0; // caller's / device (nx, nu) of the uniform stages
   gar_hip_solver *ulay = nullptr;         // host-only layout object (no device memory), owned
+  // Constrained knots (nc > 0) in leg mode on the unconstrained wave-leg kernels (gar_fold.hpp): `flay` = the
+  // layout of the folded problem (same knots, nc = 0), d_prob2 / d_fac2 / d_meta2 its device records.  Problems
+  // with D != 0 are flagged on the device (d_status + batch + 4) and taken by the generic leg kernels.
+  bool fold = false, fold_expanded = false, coupled_known = false;
+  gar_hip_solver *flay = nullptr;
+  double *d_prob2 = nullptr, *d_fac2 = nullptr;
+  gar_stage_meta *d_meta2 = nullptr;
+  double fold_mueq = 0.0;
+  std::vector<int> h_coupled;
   gar_stage_meta *d_meta = nullptr;
   int64_t prob_doubles = 0, fac_doubles = 0, sol_doubles = 0, init_doubles = 0;
   int64_t G0_off = 0, g0_off = 0;
@@ -141,6 +151,7 @@ struct gar_hip_solver {
   bool bound_all_owned = false;
   int legs_per_rank = 0;
   double cond_threshold = 1e-10; // parallel-solver.hpp:92
+  double cond_backward_ok = GAR_CONDENSED_BACKWARD_OK; // gar_hip_set_condensed_backward_ok
   int max_refinement = 5;        // parallel-solver.hpp:94
   // host staging
   double *h_prob = nullptr; // pinned, batch * prob_doubles (when small enough)
@@ -175,7 +186,7 @@ struct gar_hip_solver {
   void (*leg_bwd_kernel)(gar::LegParams) = nullptr;
   void (*leg_tuple_kernel)(gar::LegParams) = nullptr;
   void (*leg_fwd_kernel)(gar::LegParams) = nullptr;
-  void (*leg_collapse_kernel)(const gar_stage_meta *, double *, long long, int) = nullptr;
+  void (*leg_collapse_kernel)(const gar_stage_meta *, double *, long long, int, const int *, int) = nullptr;
   int leg_lds_doubles = 0, leg_waves = 1;
   void (*cond_wave_kernel)(gar::CondensedParams) = nullptr;
   int cond_wave_lds_doubles = 0;
@@ -528,11 +539,18 @@ void select_leg_kernel(gar_hip_solver *s) {
   if (N < 1 || s->nxb != s->dims5[0])
     return;
   const int nx = s->dims5[0], nu = s->dims5[1];
+  bool any_nc = false;
   for (int t = 0; t <= N; ++t) {
     const int32_t *d = &s->dims5[5 * t];
-    if (d[0] != nx || d[1] != (t < N ? nu : 0) || d[2] != 0 || d[3] != nx || d[4] != 0)
+    if (d[0] != nx || d[1] != (t < N ? nu : 0) || d[3] != nx || d[4] != 0)
       return;
+    any_nc |= d[2] != 0;
   }
+  // constrained knots: folded onto the unconstrained family (gar_fold.hpp); the generic leg kernels are the
+  // fallback for problems with D != 0, so they must fit a CU's LDS
+  const char *fe = std::getenv("GAR_HIP_FOLD");
+  if (any_nc && (!s->lds_error.empty() || (fe && fe[0] == '0')))
+    return;
   for (int i = 0; i < s->num_legs; ++i) {
     int i0, i1;
     gar_get_work(N, i, s->num_legs, &i0, &i1);
@@ -545,6 +563,7 @@ void select_leg_kernel(gar_hip_solver *s) {
   else if (nx == 12 && nu == 8) bind_leg<12, 8>(s);
   else if (nx == 12 && nu == 4) bind_leg<12, 4>(s);
   else if (nx == 8 && nu == 4) bind_leg<8, 4>(s);
+  s->fold = any_nc && s->leg_bwd_kernel != nullptr;
 }
 
 // uniform problems with NC constraints on every knot: the one-wave-per-problem kernels with the
@@ -563,6 +582,7 @@ template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
 }
 
 void select_kernel(gar_hip_solver *s) {
+  s->fold = false;
   s->leg_bwd_kernel = nullptr;
   s->leg_tuple_kernel = nullptr;
   s->leg_fwd_kernel = nullptr;
@@ -722,6 +742,22 @@ int configure(gar_hip_solver *s) {
   select_kernel(s);
   if (!s->lds_error.empty() && !(s->wave_kernel || s->mfma_kernel || s->leg_bwd_kernel))
     return fail(GAR_HIP_ERR_UNSUPPORTED, s->lds_error);
+  delete s->flay;
+  s->flay = nullptr;
+  if (s->fold) {
+    gar_hip_solver *f = new gar_hip_solver();
+    f->horizon = s->horizon;
+    f->batch = s->batch;
+    f->num_legs = s->num_legs;
+    f->nc0 = s->nc0;
+    f->dims5 = s->dims5;
+    for (int t = 0; t <= s->horizon; ++t)
+      f->dims5[5 * (size_t)t + 2] = 0;
+    s->flay = f;
+    if (int rc = build_layout(f))
+      return rc;
+    s->kernel_name += "+fold";
+  }
   return GAR_HIP_OK;
 }
 
@@ -867,6 +903,19 @@ gar::LegParams make_leg_params(gar_hip_solver *s) {
   Q.M.horizon = N;
   Q.M.trace = s->d_trace;
   Q.meta = s->d_meta;
+  Q.skip = nullptr;
+  if (s->fold) { // the wave-leg family sweeps the folded knots and keeps its own (nc = 0) factor records
+    const gar_hip_solver *f = s->flay;
+    Q.M.prob = s->d_prob2;
+    Q.M.fac = s->d_fac2;
+    Q.M.prob_stride = f->prob_doubles;
+    Q.M.fac_stride = f->fac_doubles;
+    Q.M.in_off0 = f->uni_in0;
+    Q.M.in_rec = f->uni_in_rec;
+    Q.M.in_offN = f->meta[N].in_off;
+    Q.meta = s->d_meta2;
+    Q.skip = s->d_status + s->batch + 4; // problems with D != 0: the generic leg kernels take them
+  }
   Q.num_legs = s->num_legs;
   Q.leg_begin = s->leg_begin;
   Q.csol = s->d_csol;
@@ -886,6 +935,59 @@ gar::LegParams make_leg_params(gar_hip_solver *s) {
   return Q;
 }
 
+gar::FoldParams make_fold_params(gar_hip_solver *s) {
+  gar::FoldParams F{};
+  const gar_hip_solver *f = s->flay;
+  F.meta = s->d_meta;
+  F.meta2 = s->d_meta2;
+  F.prob = s->d_prob;
+  F.prob2 = s->d_prob2;
+  F.fac = s->d_fac;
+  F.fac2 = s->d_fac2;
+  F.sol = s->d_sol;
+  F.prob_stride = s->prob_doubles;
+  F.prob2_stride = f->prob_doubles;
+  F.fac_stride = s->fac_doubles;
+  F.fac2_stride = f->fac_doubles;
+  F.sol_stride = s->sol_doubles;
+  F.coupled = s->d_status + s->batch + 4;
+  F.horizon = s->horizon;
+  F.t2 = s->fb_t2 ? 1 : 0;
+  int lo, hi, dummy;
+  gar_get_work(s->horizon, s->leg_begin, s->num_legs, &lo, &dummy);
+  gar_get_work(s->horizon, s->leg_end - 1, s->num_legs, &dummy, &hi);
+  F.t_lo = lo;
+  F.t_hi = hi;
+  F.mueq = s->fold_mueq;
+  return F;
+}
+
+// Folded solvers (gar_hip_solver::fold): the caller-visible factor records are formed on first request after a
+// backward (nobody who only reads the solution pays for them), and which problems the generic kernels took
+// (D != 0: row-major fb in their records instead of fbT2) is read back once.
+int ensure_expanded(gar_hip_solver *s) {
+  if (!s->fold)
+    return GAR_HIP_OK;
+  if (!s->fold_expanded) {
+    hipLaunchKernelGGL(gar::gar_expand_constrained, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch), dim3(256), 0,
+                       s->stream, make_fold_params(s));
+    HIP_TRY(hipGetLastError());
+    s->fold_expanded = true;
+  }
+  if (!s->coupled_known) {
+    s->h_coupled.assign((size_t)s->batch, 0);
+    HIP_TRY(hipMemcpyAsync(s->h_coupled.data(), s->d_status + s->batch + 4, sizeof(int) * (size_t)s->batch,
+                           hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->coupled_known = true;
+  }
+  return GAR_HIP_OK;
+}
+// fb / fth of problem b in the fbT2 device order?
+inline bool records_t2(const gar_hip_solver *s, int b) {
+  return s->fb_t2 && !(s->fold && s->coupled_known && s->h_coupled[(size_t)b] != 0);
+}
+
 int launch_backward(gar_hip_solver *s, double mueq) {
   RoctxRange range_(s->num_legs > 1 ? "gar::parallel_backward" : "gar::backwardImpl+factor_initial");
   if (s->leg_bwd_kernel) {
@@ -893,9 +995,20 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+    if (s->fold) { // knots with nc > 0: fold C, d into Q, q (gar_fold.hpp); problems with D != 0 get flagged
+      s->fold_mueq = mueq;
+      s->fold_expanded = s->coupled_known = false;
+      hipLaunchKernelGGL(gar::gar_fold_constraints, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch), dim3(256), 0,
+                         s->stream, make_fold_params(s));
+    }
     hipLaunchKernelGGL(s->leg_bwd_kernel, grid, dim3(64 * s->leg_waves),
                        (size_t)s->leg_lds_doubles * sizeof(double), s->stream, Q);
     hipLaunchKernelGGL(s->leg_tuple_kernel, grid, dim3(256), 0, s->stream, Q);
+    if (s->fold) { // ... and are swept by the generic leg kernels (every other problem: an early exit)
+      gar::GenericParams G = make_params(s, mueq);
+      G.only = s->d_status + s->batch + 4;
+      hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(256), (size_t)s->lds.total * sizeof(double), s->stream, G);
+    }
     HIP_TRY(hipGetLastError());
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[1], s->stream));
@@ -983,6 +1096,14 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
       HIP_TRY(hipEventRecord(s->ev[3], s->stream));
     hipLaunchKernelGGL(s->leg_fwd_kernel, dim3((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch),
                        dim3(64), 0, s->stream, Q);
+    if (s->fold) { // v_t = zff + Z x_t on this rank's stages; flagged problems: the generic roll-out
+      hipLaunchKernelGGL(gar::gar_constraint_multipliers, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch), dim3(64), 0,
+                         s->stream, make_fold_params(s));
+      gar::GenericParams G = make_params(s, 0.0);
+      G.only = s->d_status + s->batch + 4;
+      hipLaunchKernelGGL(gar::gar_forward_generic, dim3((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch), dim3(256),
+                         (size_t)s->lds.ftotal * sizeof(double), s->stream, G);
+    }
     HIP_TRY(hipGetLastError());
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[4], s->stream));
@@ -1054,6 +1175,7 @@ int launch_condensed(gar_hip_solver *s) {
   C.nx0 = s->nx0;
   C.max_refinement = s->max_refinement;
   C.threshold = s->cond_threshold;
+  C.backward_ok = s->cond_backward_ok;
   C.trace = s->d_trace;
   C.gated = 0;
   if (s->cyc_setup_kernel) {
@@ -1138,6 +1260,11 @@ void free_device(gar_hip_solver *s) {
   (void)hipFree(s->d_csol);
   (void)hipFree(s->d_cscratch);
 
+  (void)hipFree(s->d_prob2);
+  (void)hipFree(s->d_fac2);
+  (void)hipFree(s->d_meta2);
+  s->d_prob2 = s->d_fac2 = nullptr;
+  s->d_meta2 = nullptr;
   (void)hipFree(s->d_trace);
   s->d_trace = nullptr;
   (void)hipFree(s->d_deriv_off);
@@ -1194,6 +1321,16 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipMalloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
     s->cond_lds_doubles = (int)(2 * bs + s->nxb + 2 + (s->nxb + 16) / 2 + 2);
   }
+  if (s->fold) {
+    const gar_hip_solver *f = s->flay;
+    HIP_TRY(hipMalloc((void **)&s->d_prob2, sizeof(double) * (size_t)f->prob_doubles * B));
+    HIP_TRY(hipMemset(s->d_prob2, 0, sizeof(double) * (size_t)f->prob_doubles * B));
+    HIP_TRY(hipMalloc((void **)&s->d_fac2, sizeof(double) * (size_t)f->fac_doubles * B));
+    HIP_TRY(hipMemset(s->d_fac2, 0, sizeof(double) * (size_t)f->fac_doubles * B));
+    HIP_TRY(hipMalloc((void **)&s->d_meta2, sizeof(gar_stage_meta) * f->meta.size()));
+    HIP_TRY(hipMemcpy(s->d_meta2, f->meta.data(), sizeof(gar_stage_meta) * f->meta.size(), hipMemcpyHostToDevice));
+  }
+  s->fold_expanded = s->coupled_known = false;
   const size_t staging = sizeof(double) * (size_t)s->prob_doubles * B;
   if (staging <= ((size_t)1 << 30)) {
     HIP_TRY(hipHostMalloc((void **)&s->h_prob, staging, hipHostMallocDefault));
@@ -1434,12 +1571,14 @@ gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int n
   }
   if (configure(s) != GAR_HIP_OK) {
     delete s->ulay;
+    delete s->flay;
     delete s;
     return nullptr;
   }
   if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) {
     fail(GAR_HIP_ERR_DEVICE, "hipStreamCreate failed");
     delete s->ulay;
+    delete s->flay;
     delete s;
     return nullptr;
   }
@@ -1448,6 +1587,7 @@ gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int n
     free_device(s);
     (void)hipStreamDestroy(s->own_stream);
     delete s->ulay;
+    delete s->flay;
     delete s;
     return nullptr;
   }
@@ -1496,6 +1636,7 @@ void gar_hip_solver_destroy(gar_hip_solver *s) {
     if (e)
       (void)hipEventDestroy(e);
   delete s->ulay;
+  delete s->flay;
   delete s;
 }
 
@@ -1646,7 +1787,13 @@ int gar_hip_commit(gar_hip_solver *s) {
 }
 
 double *gar_hip_device_problems(gar_hip_solver *s) { return s ? s->d_prob : nullptr; }
-double *gar_hip_device_factors(gar_hip_solver *s) { return s ? s->d_fac : nullptr; }
+double *gar_hip_device_factors(gar_hip_solver *s) {
+  if (s && s->fold) { // the caller-visible records of a folded solver are formed on request
+    GAR_GUARD(s);
+    (void)ensure_expanded(s);
+  }
+  return s ? s->d_fac : nullptr;
+}
 double *gar_hip_device_solutions(gar_hip_solver *s) { return s ? s->d_sol : nullptr; }
 
 int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
@@ -1655,7 +1802,7 @@ int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
     return fail(GAR_HIP_ERR_ARG, "null solver");
   if (int rc = commit(s))
     return rc;
-  HIP_TRY(hipMemsetAsync(s->d_status, 0, sizeof(int) * ((size_t)s->batch + 4), s->stream));
+  HIP_TRY(hipMemsetAsync(s->d_status, 0, sizeof(int) * ((size_t)s->batch + 4 + (s->fold ? (size_t)s->batch : 0)), s->stream));
   return launch_backward(s, mueq);
 }
 
@@ -1807,6 +1954,8 @@ static int get_solution_dev(gar_hip_solver *s, int b, double *xs, double *us, do
 }
 
 static int get_gains_dev(gar_hip_solver *s, int b, int t, double *ff, double *fb, double *fth) {
+  if (int rc = ensure_expanded(s))
+    return rc;
   const gar_stage_meta &m = s->meta[t];
   const int nx2r = s->dense ? 2 * m.nx2 : m.nx2; // stage-dense solver: rows [K; Z; L; Y]
   const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, nx2r, m.nth);
@@ -1815,7 +1964,7 @@ static int get_gains_dev(gar_hip_solver *s, int b, int t, double *ff, double *fb
   int rc = d2h(s, ff, rec + o.ff, nr);
   std::vector<double> tmp;
   // the specialised kernel families keep fb (and fth) in the fbT2 device order
-  const bool t2 = s->fb_t2 && t < s->horizon;
+  const bool t2 = records_t2(s, b) && t < s->horizon;
   const bool fbt2 = t2 && fb;
   const bool ftht2 = t2 && fth && m.nth > 0;
   std::vector<double> tmpth;
@@ -1899,7 +2048,9 @@ int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
     s->d_gain_off = dgo;
   }
   if (what & 2) { // device-side gather (fbT2 -> row-major, dummy rows / columns dropped), then ONE device-to-host copy
-    const bool t2 = s->fb_t2;
+    if (int rc = ensure_expanded(s))
+      return rc;
+    const bool t2 = records_t2(s, b);
     hipLaunchKernelGGL(gar::gar_gather_gains, dim3((unsigned)(s->horizon + 1)), dim3(256), 0, s->stream,
                        s->d_meta, s->d_fac + (int64_t)b * s->fac_doubles, s->d_gains,
                        s->d_gains + u->ff_all_doubles, s->d_gain_off, s->horizon, t2 ? 1 : 0,
@@ -1943,6 +2094,8 @@ int gar_hip_get_gains_all(gar_hip_solver *s, int b, double *ff_all, double *fb_a
 
 static int get_value_dev(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, double *Vxt,
                       double *Vtt, double *vt) {
+  if (int rc = ensure_expanded(s))
+    return rc;
   const gar_stage_meta &m = s->meta[t];
   const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, s->dense ? 2 * m.nx2 : m.nx2, m.nth);
   const double *rec = s->d_fac + (int64_t)b * s->fac_doubles + m.fac_off;
@@ -1962,6 +2115,8 @@ static int get_kkt_dev(gar_hip_solver *s, int b, int t, double mueq, double *out
     return fail(GAR_HIP_ERR_UNSUPPORTED, "kktMat of the stage-dense solver is not kept (the whole stage matrix: gar_dense.hpp)");
   if (!out)
     return fail(GAR_HIP_ERR_ARG, "null output");
+  if (int rc = ensure_expanded(s))
+    return rc;
   const gar_stage_meta &m = s->meta[t];
   const int nk = m.nu + m.nc;
   if (nk == 0)
@@ -2158,9 +2313,18 @@ int gar_hip_collapse_feedback(gar_hip_solver *s) {
     return fail(GAR_HIP_ERR_ARG, "null solver");
   if (s->num_legs < 2 || s->leg_begin != 0)
     return GAR_HIP_OK; // no-op except Parallel (riccati-base.hpp:33)
-  hipLaunchKernelGGL(s->leg_collapse_kernel ? s->leg_collapse_kernel : gar::gar_collapse_feedback,
-                     dim3((unsigned)s->batch), dim3(256), 0, s->stream, s->d_meta, s->d_fac,
-                     (long long)s->fac_doubles, s->batch);
+  if (s->fold) { // the wave-leg family's own records (then re-expanded on request); flagged problems: generic records
+    const int *flags = s->d_status + s->batch + 4;
+    hipLaunchKernelGGL(s->leg_collapse_kernel, dim3((unsigned)s->batch), dim3(256), 0, s->stream, s->d_meta2, s->d_fac2,
+                       (long long)s->flay->fac_doubles, s->batch, flags, 0);
+    hipLaunchKernelGGL(gar::gar_collapse_feedback, dim3((unsigned)s->batch), dim3(256), 0, s->stream, s->d_meta, s->d_fac,
+                       (long long)s->fac_doubles, s->batch, flags, 1);
+    s->fold_expanded = false;
+  } else {
+    hipLaunchKernelGGL(s->leg_collapse_kernel ? s->leg_collapse_kernel : gar::gar_collapse_feedback,
+                       dim3((unsigned)s->batch), dim3(256), 0, s->stream, s->d_meta, s->d_fac,
+                       (long long)s->fac_doubles, s->batch, (const int *)nullptr, 0);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
   return GAR_HIP_OK;
@@ -2231,7 +2395,8 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
     trial.user_dims5 = nd;
     const int rc = configure(&trial);
     delete trial.ulay;
-    trial.ulay = nullptr;
+    delete trial.flay;
+    trial.ulay = trial.flay = nullptr;
     if (rc != GAR_HIP_OK)
       return rc; // g_last_error says why
   }
@@ -2288,6 +2453,29 @@ int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g
   for (int i = 0; i < nc0u; ++i)
     g[i] = g0[i];
   return set_init_dev(s, b, G.data(), g.data());
+}
+
+int gar_hip_set_condensed_backward_ok(gar_hip_solver *s, double omega) {
+  if (!s || !(omega >= 0.0))
+    return fail(GAR_HIP_ERR_ARG, "bad backward-error bound");
+  s->cond_backward_ok = omega;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_condensed_backward_error(gar_hip_solver *s, int b, double *out) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  if (s->num_legs < 2 || !out)
+    return fail(GAR_HIP_ERR_ARG, "condensed info needs leg mode");
+  const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
+  const double *info = s->d_cscratch + (int64_t)b * s->cscratch_doubles + 4 * nblk * bs + 4 * nblk * s->nxb;
+  double v[3] = {0.0, 0.0, 0.0};
+  if (int rc = d2h(s, v, info, 3))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *out = v[2] > 0.0 ? v[0] / v[2] : 0.0;
+  return GAR_HIP_OK;
 }
 
 int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, double *vs, double *lbdas) {

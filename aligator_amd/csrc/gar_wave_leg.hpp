@@ -39,6 +39,7 @@ struct LegParams {
   int tuple_doubles;
   double *cinfo;           // condensed-solve scratch: info slot of problem 0 (residual, steps)
   long long cinfo_stride;
+  const int *skip;         // folded solvers (gar_fold.hpp): problems with skip[b] != 0 belong to the generic kernels
 };
 
 template <int NX, int NU>
@@ -49,6 +50,8 @@ __global__ void __launch_bounds__(64, 1) gar_backward_wave_leg(LegParams Q) {
   const int lane = (int)threadIdx.x & 63;
   const int leg = (int)blockIdx.x + Q.leg_begin;
   const int b = (int)blockIdx.y;
+  if (Q.skip != nullptr && Q.skip[b] != 0)
+    return;
   double *sm = gar_smem;
   MfmaParams P = Q.M;
   const double *prob = P.prob + (long long)b * P.prob_stride;
@@ -343,6 +346,8 @@ __global__ void __launch_bounds__(128, 1) gar_backward_wave_leg2(LegParams Q) {
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
   const int leg = (int)blockIdx.x + Q.leg_begin;
   const int b = (int)blockIdx.y;
+  if (Q.skip != nullptr && Q.skip[b] != 0)
+    return;
   double *sm = gar_smem;
   MfmaParams P = Q.M;
   const double *prob = P.prob + (long long)b * P.prob_stride;
@@ -433,7 +438,10 @@ __global__ void __launch_bounds__(256) gar_leg_tuples(LegParams Q) {
     // the cyclic-reduction kernels accumulate the residual norm with atomicMax
     Q.cinfo[(long long)b * Q.cinfo_stride] = 0.0;
     Q.cinfo[(long long)b * Q.cinfo_stride + 1] = 0.0;
+    Q.cinfo[(long long)b * Q.cinfo_stride + 2] = 0.0; // max_i (|rhs| + |A| |sol|)_i (gar_cyclic_recover)
   }
+  if (Q.skip != nullptr && Q.skip[b] != 0)
+    return; // (the generic backward kernel writes this problem's tuples itself)
   const bool term = (t_beg == Q.M.horizon); // a leg made of the terminal knot alone
   const int oVxx = last_leg ? (term ? M::tVxx : M::fVxx) : C::pVxx;
   const int ovx = last_leg ? (term ? M::tvx : M::fvx) : C::pvx;
@@ -453,11 +461,11 @@ __global__ void __launch_bounds__(256) gar_leg_tuples(LegParams Q) {
 // K0 -= Kth0 * Vxt(0)^T on the factor record of stage 0
 template <int NX, int NU>
 __global__ void gar_collapse_feedback_t2(const gar_stage_meta *meta, double *fac,
-                                         long long fac_stride, int batch) {
+                                         long long fac_stride, int batch, const int *flags, int want) {
   using C = WaveCfg<NX, NU>;
   using M = MfmaCfg<NX, NU>;
   const int b = (int)blockIdx.x;
-  if (b >= batch || meta[0].nth == 0)
+  if (b >= batch || meta[0].nth == 0 || (flags != nullptr && (flags[b] != 0) != (want != 0)))
     return;
   double *rec = fac + (long long)b * fac_stride + meta[0].fac_off;
   for (int e = (int)threadIdx.x; e < NU * NX; e += (int)blockDim.x) {
@@ -664,7 +672,8 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
     const double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * NX * NX + 4ll * nblk * NX;
     // (refinement disabled: the cyclic-reduction result stands -- unless a block inverse failed
     // outright, which poisons the residual with +inf)
-    if (inf[0] <= P.threshold || (P.max_refinement == 0 && inf[0] <= 1.79e308))
+    if (inf[0] <= P.threshold || (P.max_refinement == 0 && inf[0] <= 1.79e308) ||
+        (inf[0] <= 1.79e308 && inf[0] <= P.backward_ok * inf[2])) // (see gar_cyclic_recover)
       return;
   }
   const WG w1 = wave_self();
@@ -1132,6 +1141,8 @@ __global__ void __launch_bounds__(64) gar_forward_wave_leg(LegParams Q) {
   const int lane = (int)threadIdx.x;
   const int leg = (int)blockIdx.x + Q.leg_begin;
   const int b = (int)blockIdx.y;
+  if (Q.skip != nullptr && Q.skip[b] != 0)
+    return;
   if (leg < Q.num_legs - 1)
     leg_forward_body<NX, NU, true>(Q, leg, b, lane);
   else

@@ -334,14 +334,22 @@ class BatchedRiccatiSolver:
         self._check(self._L.gar_hip_constrained_bk_stages(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
         return int(out[0]), int(out[1])
 
-    def set_refinement(self, threshold: float, max_steps: int):
+    def set_refinement(self, threshold: float, max_steps: int, backward_ok: Optional[float] = None):
         self._check(self._L.gar_hip_set_refinement(self._h, float(threshold), int(max_steps)))
+        if backward_ok is not None:
+            self._check(self._L.gar_hip_set_condensed_backward_ok(self._h, float(backward_ok)))
 
     def condensed_info(self, b: int = 0):
         """(infinity norm of the last condensed residual evaluated, refinement steps taken)."""
         out = (C.c_double * 2)()
         self._check(self._L.gar_hip_condensed_info(self._h, int(b), out))
         return float(out[0]), int(out[1])
+
+    def condensed_backward_error(self, b: int = 0) -> float:
+        """Componentwise backward error of the block-cyclic-reduction solve of the condensed system (gar_hip.h)."""
+        out = (C.c_double * 1)()
+        self._check(self._L.gar_hip_condensed_backward_error(self._h, int(b), out))
+        return float(out[0])
 
     def collapse_feedback(self):
         self._factors_cache = {}

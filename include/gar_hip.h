@@ -238,6 +238,14 @@ int gar_hip_set_refinement(gar_hip_solver *s, double condensed_threshold, int ma
 /* outcome of the last condensed solve of problem b: out[0] = infinity norm of the last residual
  * evaluated (the quantity parallel-solver.hxx:191 tests), out[1] = refinement steps taken */
 int gar_hip_condensed_info(gar_hip_solver *s, int b, double out[2]);
+/* Block cyclic reduction of the condensed system (specialised leg families): the backward error
+ * omega = max_i |r_i| / max_i (|rhs_i| + sum_j |K_ij| |s_j|) of its solution.  The solve stands when the reference's
+ * absolute residual threshold is met OR omega <= 1e-12: with value functions of order 1/mu (constrained knots) the
+ * absolute threshold (parallel-solver.hpp:92) is out of reach of any fp64 solver -- the reference then spends its
+ * maxRefinementSteps without effect (parallel-solver.hxx:184-202).  0 when the elimination chain solved instead. */
+int gar_hip_condensed_backward_error(gar_hip_solver *s, int b, double *out);
+/* the omega bound above (default 1e-12); 0: only the reference's absolute threshold counts */
+int gar_hip_set_condensed_backward_ok(gar_hip_solver *s, double omega);
 
 /* ---- results (HBM -> host) ------------------------------------------------ */
 /* packed solution of problem b: xs | us | vs | lbdas (per-stage offsets from

@@ -461,3 +461,58 @@ def check_cycle_append_ring(lib_path=None, nx=8, nu=4, horz=5, cycles=8, family=
                 del os.environ["GAR_HIP_BACKWARD"]
             else:
                 os.environ["GAR_HIP_BACKWARD"] = old
+
+
+def check_constrained_legs_fold(lib_path=None, shapes=((8, 4, 4, 11, 3, 1e-6), (16, 8, 8, 9, 2, 1e-7)), tol=1e-8):
+    """Equality-constrained knots in leg mode (the reference's BM_parallel configuration, bench/gar-riccati.cpp:64-90)
+    on the UNCONSTRAINED wave-leg kernels through the fold of gar_fold.hpp (Q += C^T C / mu, q += C^T d / mu when
+    D = 0; Z, zff from C, d): solution, every stage's ff = [kff; zff; yff] / fb = [K; Z; Aff] / fth / value function,
+    collapsed K0 against the oracle's leg-parallel solver -- with a dense C, with constraints on SOME knots only --
+    and problems with D != 0, which the same solver hands to the generic leg kernels: one batch mixes both kinds."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    rng = np.random.default_rng(41)
+    for (nx, nu, nc, horz, legs, mu) in shapes:
+        prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nc=nc, mode="W")
+        for k in prob.stages:
+            k.C[...] = rng.uniform(-1, 1, k.C.shape)
+        # (multipliers of order 1/mu: v and lambda are judged against what the problem's conditioning allows)
+        par = check_parallel(prob, mu, legs, tol, lib_path, conditioned=True)
+        assert par._impl.kernel_name == f"wave_leg<{nx},{nu}>+fold"
+        coupled = prob.copy()
+        for k in coupled.stages[1:horz:3]:
+            k.D[...] = rng.uniform(-1, 1, k.D.shape)
+        par = check_parallel(coupled, mu, legs, tol, lib_path, conditioned=True)   # same family name, generic kernels underneath
+        # one batch, both kinds: problem 1 has D != 0
+        probs = [prob, coupled, prob.copy()]
+        probs[2].stages[0].q[...] += 1.0
+        dims = [k.dims for k in prob.stages]
+        s = BatchedRiccatiSolver(dims, prob.nc0, batch=3, num_legs=legs, lib_path=lib_path)
+        s.upload(probs)
+        assert s.backward(mu) and s.forward()
+        for b, p in enumerate(probs):
+            _, osol, ref = oracle_serial(p, mu)
+            sc = scale_of(ref)
+            for A, B in zip(s.solution(b), ref):
+                assert maxdiff(A, B) <= max(tol, 1e-7) * sc, b
+            opar = ora.ParallelRiccatiSolver(to_oracle(p), legs)
+            opar.backward(mu)
+
+            class D:
+                def __getitem__(self, t, b=b):
+                    return s.factor(t, b)
+            compare_factors(D(), opar, horz, max(tol, 1e-7))
+        ffs, fbs = s.gains_all(1)                                         # bulk read-back of a generic-family problem
+        for t in range(horz + 1):
+            assert np.array_equal(fbs[t], s.factor(t, 1).fb) and np.array_equal(ffs[t], s.factor(t, 1).ff)
+    # constraints on SOME knots only (mixed nc): still one uniform (nx, nu), still folded
+    nx, nu, horz = 8, 4, 10
+    knots = []
+    for t in range(horz):
+        knots.append(synth.generate_knot(rng, nx, nu, nc=(3 if t % 3 == 1 else 0), mode="W"))
+    knots.append(synth.generate_knot(rng, nx, 0, nc=2, mode="W"))
+    from aligator_amd.lqr import LqrProblem
+    mixed = LqrProblem(knots, nx)
+    mixed.G0[...] = -np.eye(nx)
+    mixed.g0[...] = rng.standard_normal(nx)
+    par = check_parallel(mixed, 1e-6, 3, tol, lib_path, conditioned=True)
+    assert par._impl.kernel_name == f"wave_leg<{nx},{nu}>+fold"

@@ -156,12 +156,12 @@ def test_parallel_wave_leg_batched():
     assert s.kernel_name.startswith("wave_leg<")
 
 
-def _leg_solution(probs, legs, mueq, refine=None, threshold=1e-10):
+def _leg_solution(probs, legs, mueq, refine=None, threshold=1e-10, backward_ok=None):
     from aligator_amd.gar import BatchedRiccatiSolver
     dims = [k.dims for k in probs[0].stages]
     s = BatchedRiccatiSolver(dims, probs[0].nc0, batch=len(probs), num_legs=legs, lib_path=EMU)
     if refine is not None:
-        s.set_refinement(threshold, refine)
+        s.set_refinement(threshold, refine, backward_ok)
     s.upload(probs)
     assert s.backward(mueq) and s.forward()
     return s, [s.solution(b) for b in range(len(probs))]
@@ -199,9 +199,14 @@ def test_condensed_cyclic_fallback_to_chain():
     """A threshold the cyclic-reduction residual cannot meet gates the elimination-chain kernel
     in: it re-solves with the reference's iterative refinement and reports its steps."""
     probs = [synth.generate_lq_problem(950, np.ones(8), 21, 8, 4, mode="W")]
-    s, sol = _leg_solution(probs, 4, 1e-10, refine=3, threshold=1e-300)
+    s, sol = _leg_solution(probs, 4, 1e-10, refine=3, threshold=1e-300, backward_ok=0.0)
     resid, steps = s.condensed_info(0)
     assert steps == 3                       # the chain kernel ran (cyclic reduction reports 0 steps)
+    # ... while the default gate lets the cyclic-reduction solve stand on its componentwise backward error
+    s2, sol2 = _leg_solution(probs, 4, 1e-10, refine=3, threshold=1e-300)
+    assert s2.condensed_info(0)[1] == 0 and 0.0 < s2.condensed_backward_error(0) <= 1e-12
+    for A, B in zip(sol2[0], sol[0]):
+        assert pc.maxdiff(A, B) <= 1e-10 * pc.scale_of(sol[0])
     _, _, ref = pc.oracle_serial(probs[0], 1e-10)
     for A, B in zip(sol[0], ref):
         assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
@@ -430,7 +435,22 @@ def test_parallel_solver_on_the_reference_bench_shape_nc32():
     nx, nu, nc = 36, 12, 32
     rng = np.random.default_rng(3)
     prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 5, nx, nu, nc=nc, mode="W")
-    pc.check_parallel(prob, 1e-8, 2, 1e-7, EMU)
+    par = pc.check_parallel(prob, 1e-8, 2, 1e-7, EMU)
+    assert par._impl.kernel_name == "wave_leg<36,12>+fold"      # round 3: folded onto the wave-leg family (gar_fold.hpp)
+
+
+def test_parallel_solver_nc32_on_the_generic_leg_kernels(monkeypatch):
+    """... and the generic leg kernels (the fallback for D != 0) on the same shape: GAR_HIP_FOLD=0."""
+    monkeypatch.setenv("GAR_HIP_FOLD", "0")
+    nx, nu, nc = 36, 12, 32
+    rng = np.random.default_rng(3)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 5, nx, nu, nc=nc, mode="W")
+    par = pc.check_parallel(prob, 1e-8, 2, 1e-7, EMU)
+    assert par._impl.kernel_name == "generic"
+
+
+def test_constrained_legs_fold_onto_the_wave_leg_kernels():
+    pc.check_constrained_legs_fold(EMU)
 
 
 def test_constrained_wave_kernels_decoupled_dense_c_and_alternating_d():

@@ -55,7 +55,27 @@ def test_parallel_solver_on_the_reference_bench_shape_nc32(legs):
     nx, nu, nc = 36, 12, 32
     rng = np.random.default_rng(3)
     prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 32, nx, nu, nc=nc, mode="W")
-    pc.check_parallel(prob, 1e-8, legs, 1e-7)
+    par = pc.check_parallel(prob, 1e-8, legs, 1e-7)
+    assert par._impl.kernel_name == "wave_leg<36,12>+fold"      # round 3: no longer on the generic leg kernels
+
+
+@pytest.mark.parametrize("legs", [2, 6])
+def test_parallel_solver_on_the_reference_bench_shape_nc32_at_benchmark_size(legs):
+    """BM_parallel at the benchmark's own size and mu (bench/gar-riccati.cpp:19-22, 64-90: N = 256, mu = 1e-11): the
+    multipliers are O(1/mu), so v and lambda are judged against what the problem's conditioning allows
+    (pc.check_parallel(conditioned=True): the oracle's own serial / leg-parallel / LAPACK spread), x and u at 1e-8."""
+    nx, nu, nc = 36, 12, 32
+    rng = np.random.default_rng(19)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 256, nx, nu, nc=nc, mode="W")
+    rep = {}
+    par = pc.check_parallel(prob, 1e-11, legs, 1e-8, conditioned=True, report=rep)
+    assert par._impl.kernel_name == "wave_leg<36,12>+fold"
+    assert max(rep["hip_leg-oracle_leg"][:2]) <= 1e-10
+    print(f"nc=32 N=256 mu=1e-11 legs={legs}: hip-oracle_leg {rep['hip_leg-oracle_leg']} tolerances {rep['tolerances']}")
+
+
+def test_constrained_legs_fold_onto_the_wave_leg_kernels():
+    pc.check_constrained_legs_fold(shapes=((8, 4, 4, 41, 5, 1e-6), (16, 8, 8, 30, 4, 1e-7), (36, 12, 32, 24, 3, 1e-7)))
 
 
 SOAK_FAILURES = [(101, 353783436, None, 42, 2), (2026, 755480262, "constrained", 22, 8)]
@@ -287,10 +307,10 @@ def test_condensed_solvers_agree_on_gpu(monkeypatch):
     probs = [synth.generate_lq_problem(4100 + i, np.full(nx, 0.1 * i), N, nx, nu, mode="W") for i in range(3)]
     dims = [k.dims for k in probs[0].stages]
 
-    def solve(refine=None, thr=1e-10):
+    def solve(refine=None, thr=1e-10, backward_ok=None):
         s = BatchedRiccatiSolver(dims, nx, batch=len(probs), num_legs=legs)
         if refine is not None:
-            s.set_refinement(thr, refine)
+            s.set_refinement(thr, refine, backward_ok)
         s.upload(probs)
         assert s.backward(1e-10) and s.forward()
         return s, [s.solution(b) for b in range(len(probs))]
@@ -300,8 +320,10 @@ def test_condensed_solvers_agree_on_gpu(monkeypatch):
     for b in range(len(probs)):
         resid, steps = s.condensed_info(b)
         assert resid < 1e-9 and steps == 0
-    s2, gated = solve(refine=2, thr=1e-300)
+    s2, gated = solve(refine=2, thr=1e-300, backward_ok=0.0)
     assert s2.condensed_info(0)[1] == 2          # the chain kernel (with refinement) took over
+    s3, _ = solve(refine=2, thr=1e-300)          # default gate: the cyclic-reduction solve stands on its backward error
+    assert s3.condensed_info(0)[1] == 0 and 0.0 < s3.condensed_backward_error(0) <= 1e-13
     monkeypatch.setenv("GAR_HIP_CONDENSED", "chain")
     _, chain = solve()
     monkeypatch.setenv("GAR_HIP_CONDENSED", "generic")
