@@ -24,6 +24,7 @@
 #include "gar_cyclic.hpp"
 #include "gar_dense.hpp"
 #include "gar_fold.hpp"
+#include "gar_leg_seg.hpp"
 
 namespace {
 
@@ -123,6 +124,11 @@ struct gar_hip_solver {
   // Constrained knots (nc > 0) in leg mode on the unconstrained wave-leg kernels (gar_fold.hpp): `flay` = the
   // layout of the folded problem (same knots, nc = 0), d_prob2 / d_fac2 / d_meta2 its device records.  Problems
   // with D != 0 are flagged on the device (d_status + batch + 4) and taken by the generic leg kernels.
+  // Segment legs (gar_leg_seg.hpp): leg mode for shapes with a serial stage kernel but no wave-leg family -- the
+  // plain part of every leg by that kernel into scratch records (flay: the same knots, nth = 0; d_fac2), the
+  // parameter part by the generic matrix recursion, which writes the caller-visible records and the tuples
+  void (*seg_bwd_kernel)(gar::MfmaParams, int, int) = nullptr;
+  int seg_lds_doubles = 0, seg_param_lds_doubles = 0;
   bool fold = false, fold_expanded = false, coupled_known = false;
   gar_hip_solver *flay = nullptr;
   double *d_prob2 = nullptr, *d_fac2 = nullptr;
@@ -530,6 +536,15 @@ template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
   s->kernel_name = "wave_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
 }
 
+// the wide shape in leg mode: segment legs (gar_leg_seg.hpp) on the two-wave stage kernel
+template <int NX, int NU> void bind_seg_leg(gar_hip_solver *s) {
+  s->seg_bwd_kernel = gar::gar_backward_pair_leg<NX, NU>;
+  s->seg_lds_doubles = gar::PairCfg<NX, NU>::total;
+  s->seg_param_lds_doubles = gar::leg_param_lds_doubles(NX, NU);
+  s->fb_t2 = false; // row-major fb: the generic roll-out, condensed solve and collapse serve the family
+  s->kernel_name = "pair_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+}
+
 // leg mode: uniform unconstrained problem whose every leg holds at least two knots
 void select_leg_kernel(gar_hip_solver *s) {
   const int N = s->horizon;
@@ -563,6 +578,11 @@ void select_leg_kernel(gar_hip_solver *s) {
   else if (nx == 12 && nu == 8) bind_leg<12, 8>(s);
   else if (nx == 12 && nu == 4) bind_leg<12, 4>(s);
   else if (nx == 8 && nu == 4) bind_leg<8, 4>(s);
+  else if (nx == 56 && nu == 24 && !any_nc) {
+    const char *sg = std::getenv("GAR_HIP_SEG_LEGS");
+    if (!(sg && sg[0] == '0') && (size_t)gar::leg_param_lds_doubles(56, 24) * sizeof(double) <= 160 * 1024)
+      bind_seg_leg<56, 24>(s);
+  }
   s->fold = any_nc && s->leg_bwd_kernel != nullptr;
 }
 
@@ -583,6 +603,7 @@ template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
 
 void select_kernel(gar_hip_solver *s) {
   s->fold = false;
+  s->seg_bwd_kernel = nullptr;
   s->leg_bwd_kernel = nullptr;
   s->leg_tuple_kernel = nullptr;
   s->leg_fwd_kernel = nullptr;
@@ -649,10 +670,10 @@ void select_kernel(gar_hip_solver *s) {
   else if (nx == 56 && nu == 24) bind_wide<56, 24>(s);
 }
 
-// (nx, nu) shapes with kernels of their own (bind_mfma / bind_leg / bind_wide above); {56, 24} has no wave-leg family
+// (nx, nu) shapes with kernels of their own (bind_mfma / bind_leg / bind_wide / bind_seg_leg above)
 struct SpecShape { int nx, nu; bool serial_only; };
 constexpr SpecShape kSpecialised[] = {{36, 12, false}, {32, 12, false}, {16, 8, false}, {12, 8, false},
-                                      {12, 4, false}, {8, 4, false},   {56, 24, true}};
+                                      {12, 4, false}, {8, 4, false},   {56, 24, false}};
 
 // Decide the device dimensions from the caller's (see gar_hip_solver::padded).  GAR_HIP_PAD=0: never pad.
 void choose_padding(gar_hip_solver *s) {
@@ -740,10 +761,21 @@ int configure(gar_hip_solver *s) {
     s->tuple_doubles = 3 * (int64_t)nxb * nxb + 2 * nxb;
   }
   select_kernel(s);
-  if (!s->lds_error.empty() && !(s->wave_kernel || s->mfma_kernel || s->leg_bwd_kernel))
+  if (!s->lds_error.empty() && !(s->wave_kernel || s->mfma_kernel || s->leg_bwd_kernel || s->seg_bwd_kernel))
     return fail(GAR_HIP_ERR_UNSUPPORTED, s->lds_error);
   delete s->flay;
   s->flay = nullptr;
+  if (s->seg_bwd_kernel) { // scratch records of the plain kernels: the same knots, serial (nth = 0) layout
+    gar_hip_solver *f = new gar_hip_solver();
+    f->horizon = s->horizon;
+    f->batch = s->batch;
+    f->num_legs = 1;
+    f->nc0 = s->nc0;
+    f->dims5 = s->dims5;
+    s->flay = f;
+    if (int rc = build_layout(f))
+      return rc;
+  }
   if (s->fold) {
     gar_hip_solver *f = new gar_hip_solver();
     f->horizon = s->horizon;
@@ -1009,6 +1041,55 @@ int launch_backward(gar_hip_solver *s, double mueq) {
       G.only = s->d_status + s->batch + 4;
       hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(256), (size_t)s->lds.total * sizeof(double), s->stream, G);
     }
+    HIP_TRY(hipGetLastError());
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+    return GAR_HIP_OK;
+  }
+  if (s->seg_bwd_kernel) { // segment legs (gar_leg_seg.hpp): plain part, then the parameter recursion + tuples
+    const gar_hip_solver *f = s->flay;
+    const int N = s->horizon;
+    gar::MfmaParams M{};
+    M.prob = s->d_prob;
+    M.fac = s->d_fac2;
+    M.status = s->d_status;
+    M.slow = s->d_status + s->batch;
+    M.resume = s->d_status + s->batch + 4;
+    M.prob_stride = s->prob_doubles;
+    M.fac_stride = f->fac_doubles;
+    M.in_off0 = s->uni_in0;
+    M.in_rec = s->uni_in_rec;
+    M.in_offN = s->meta[N].in_off;
+    M.fac_rec = f->uni_fac_rec;
+    M.fac_offN = f->meta[N].fac_off;
+    M.horizon = N;
+    M.mueq = mueq;
+    const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+    hipLaunchKernelGGL(s->seg_bwd_kernel, grid, dim3(128), (size_t)s->seg_lds_doubles * sizeof(double), s->stream, M,
+                       s->num_legs, s->leg_begin);
+    gar::LegParamParams Q{};
+    Q.meta = s->d_meta;
+    Q.meta2 = s->d_meta2;
+    Q.prob = s->d_prob;
+    Q.fac2 = s->d_fac2;
+    Q.fac = s->d_fac;
+    Q.boundary = s->d_bound_local;
+    Q.status = s->d_status;
+    Q.prob_stride = s->prob_doubles;
+    Q.fac_stride = s->fac_doubles;
+    Q.fac2_stride = f->fac_doubles;
+    Q.boundary_stride = (long long)s->legs_per_rank * s->tuple_doubles;
+    Q.horizon = N;
+    Q.num_legs = s->num_legs;
+    Q.leg_begin = s->leg_begin;
+    Q.tuple_doubles = (int)s->tuple_doubles;
+    Q.nxb = s->nxb;
+    Q.nxM = s->dims5[0];
+    Q.nuM = s->dims5[1];
+    hipLaunchKernelGGL(gar::gar_leg_param_generic, grid, dim3(256), (size_t)s->seg_param_lds_doubles * sizeof(double),
+                       s->stream, Q);
     HIP_TRY(hipGetLastError());
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[1], s->stream));
@@ -1320,6 +1401,17 @@ int allocate(gar_hip_solver *s) {
     s->cscratch_doubles = (int64_t)(4 * nblk * bs + 4 * (size_t)nblk * s->nxb + 4);
     HIP_TRY(hipMalloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
     s->cond_lds_doubles = (int)(2 * bs + s->nxb + 2 + (s->nxb + 16) / 2 + 2);
+  }
+  if (s->seg_bwd_kernel) {
+    const gar_hip_solver *f = s->flay;
+    HIP_TRY(hipMalloc((void **)&s->d_fac2, sizeof(double) * (size_t)f->fac_doubles * B));
+    HIP_TRY(hipMemset(s->d_fac2, 0, sizeof(double) * (size_t)f->fac_doubles * B));
+    HIP_TRY(hipMalloc((void **)&s->d_meta2, sizeof(gar_stage_meta) * f->meta.size()));
+    HIP_TRY(hipMemcpy(s->d_meta2, f->meta.data(), sizeof(gar_stage_meta) * f->meta.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipFuncSetAttribute((const void *)s->seg_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->seg_lds_doubles * sizeof(double))));
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_leg_param_generic, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->seg_param_lds_doubles * sizeof(double))));
   }
   if (s->fold) {
     const gar_hip_solver *f = s->flay;
@@ -2293,7 +2385,7 @@ int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]) {
   GAR_GUARD(s);
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
-  if (!s->timing || !(s->mfma_kernel || s->wave_kernel || s->leg_bwd_kernel))
+  if (!s->timing || !(s->mfma_kernel || s->wave_kernel || s->leg_bwd_kernel || s->seg_bwd_kernel))
     return fail(GAR_HIP_ERR_UNSUPPORTED, "per-kernel timing is recorded for the specialised "
                                          "kernel family after gar_hip_set_timing(s, 1)");
   HIP_TRY(hipStreamSynchronize(s->stream));

@@ -593,3 +593,19 @@ def test_rejected_cycle_append_leaves_the_ring_intact(nx, nu):
     _, _, ref = pc.oracle_serial(prob, 1e-10)
     for A, B in zip(s.solution(0), ref):
         assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
+
+
+def test_wide_shape_in_leg_mode_segment_legs():
+    """ParallelRiccatiSolver on the Talos-walk LQ shape (56, 22) -- how the reference benchmarks it
+    (bench/talos-walk.cpp:102-127, bench/lqr.cpp:112-134) -- on the segment-leg family (gar_leg_seg.hpp): the
+    two-wave stage kernel over each leg's stage range from a zero value function behind the leg end, the parameter
+    part (Kth, Yth, Vxt, Vtt, vt) by the generic matrix recursion.  Solution, every stage's factors incl. the
+    leg-end records (yff, Aff, Yth zero like terminalSolve leaves them), collapsed K0 against the oracle's
+    leg-parallel solver; padded (56, 22) and native (56, 24); a batch."""
+    rng = np.random.default_rng(3)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(56), 7, 56, 22, mode="W")
+    par = pc.check_parallel(prob, 1e-10, 3, 1e-9, EMU)
+    assert par._impl.kernel_name == "pair_leg<56,24>" and par._impl.padded
+    probs = [synth.generate_lq_problem(70 + i, np.ones(56), 5, 56, 24, mode="W") for i in range(2)]
+    s = pc.check_batched(probs, 1e-10, 1e-9, EMU, num_legs=2)
+    assert s.kernel_name == "pair_leg<56,24>" and not s.padded

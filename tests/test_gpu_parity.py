@@ -671,8 +671,22 @@ def test_config4_talos_lq_shape():
                 assert s2.kernel_name == name
         finally:
             del os.environ["GAR_HIP_WIDE"]
-    # leg mode adds the parameter blocks (nth = 56): 318 KB of LDS in the generic leg kernels -- still refused
-    # loudly (GAR_HIP_ERR_UNSUPPORTED), not silently run elsewhere
-    from aligator_amd.gar import ParallelRiccatiSolver
-    with pytest.raises(RuntimeError, match="LDS"):
-        ParallelRiccatiSolver(prob.copy(), 5)
+    # PARALLEL mode, as the reference benchmarks this shape (bench/talos-walk.cpp:102-127, bench/lqr.cpp:112-134:
+    # LQSolverChoice::PARALLEL with 2-8 threads).  Round 3: segment legs (gar_leg_seg.hpp) -- the two-wave stage kernel
+    # over each leg's stages, the parameter part by the generic matrix recursion; before: refused (the generic
+    # leg kernels need 270 KB of LDS at nth = 56).  Full factors, K0 after collapseFeedback, at N = 275.
+    for legs in (2, 5, 8):
+        par = pc.check_parallel(prob, 1e-10, legs, 1e-8)
+        assert par._impl.kernel_name == "pair_leg<56,24>"
+    p2 = synth.generate_lq_problem(5601, np.ones(nx), 60, nx, nu, mode="F")
+    par = pc.check_parallel(p2, 1e-10, 4, 1e-6)
+    assert par._impl.kernel_name == "pair_leg<56,24>"
+    # and when the segment-leg family is switched off the generic leg kernels' need is still refused loudly
+    import os
+    os.environ["GAR_HIP_SEG_LEGS"] = "0"
+    try:
+        from aligator_amd.gar import ParallelRiccatiSolver
+        with pytest.raises(RuntimeError, match="LDS"):
+            ParallelRiccatiSolver(prob.copy(), 5)
+    finally:
+        del os.environ["GAR_HIP_SEG_LEGS"]
