@@ -1060,6 +1060,57 @@ __global__ void __launch_bounds__(256) gar_kkt_matrix(const double *knot, gar_kn
 // chain per stage and writes `out_pieces` pieces (the factor record).  What this kernel reaches is what HBM
 // sustains for the sweep's read/write mix and walk; no product path calls it.
 typedef double gar_double2 __attribute__((ext_vector_type(2)));
+// AHEAD = 2: the same walk with TWO records requested ahead of the one being consumed (what a deeper prefetch of
+// the knots would buy the sweep: roofline.stream_ceiling.two_ahead in the bench line)
+template <int IN_PL, int OUT_PL>
+__global__ void __launch_bounds__(64) gar_stream_sweep2(const gar_double2 *in, gar_double2 *out, double *sink,
+                                                        int nrec, int in_pieces, int out_pieces) {
+  const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
+  gar_double2 r0[IN_PL], r1[IN_PL], r2[IN_PL];
+  const gar_double2 *pin = in + (size_t)b * nrec * in_pieces;
+  gar_double2 *pout = out + (size_t)b * nrec * out_pieces;
+  auto load = [&](const gar_double2 *p, gar_double2 (&r)[IN_PL]) {
+#pragma unroll
+    for (int q = 0; q < IN_PL; ++q) {
+      const int e = 64 * q + lane;
+      r[q] = p[e < in_pieces ? e : in_pieces - 1];
+    }
+  };
+  auto consume = [&](const gar_double2 (&c)[IN_PL], int t, double &acc) {
+#pragma unroll
+    for (int q = 0; q < IN_PL; ++q)
+      acc += c[q].x * 1.0000001 + c[q].y;
+#pragma unroll 8
+    for (int i = 0; i < 72; ++i)
+      acc = __builtin_fma(acc, 0.999999, 1e-9);
+#pragma unroll
+    for (int q = 0; q < OUT_PL; ++q) {
+      const int e = 64 * q + lane;
+      if (e < out_pieces)
+        pout[(size_t)t * out_pieces + e] = gar_double2{acc, c[q < IN_PL ? q : 0].x};
+    }
+  };
+  double acc = 0.0;
+  int t = nrec - 1;
+  load(pin + (size_t)t * in_pieces, r0);
+  if (t >= 1)
+    load(pin + (size_t)(t - 1) * in_pieces, r1);
+  // three records rotate through r0 (consumed) <- r1 <- r2 (just requested); unrolled by three so that the
+  // rotation is a renaming, not register moves
+  while (t >= 0) {
+    if (t >= 2) load(pin + (size_t)(t - 2) * in_pieces, r2);
+    consume(r0, t, acc);
+    if (--t < 0) break;
+    if (t >= 2) load(pin + (size_t)(t - 2) * in_pieces, r0);
+    consume(r1, t, acc);
+    if (--t < 0) break;
+    if (t >= 2) load(pin + (size_t)(t - 2) * in_pieces, r1);
+    consume(r2, t, acc);
+    --t;
+  }
+  sink[(size_t)b * 64 + lane] = acc;
+}
+
 template <int IN_PL, int OUT_PL>
 __global__ void __launch_bounds__(64) gar_stream_sweep(const gar_double2 *in, gar_double2 *out, double *sink,
                                                        int nrec, int in_pieces, int out_pieces) {
@@ -1101,10 +1152,23 @@ __global__ void __launch_bounds__(64) gar_stream_sweep(const gar_double2 *in, ga
 // Measurement aid (bench.py, roofline.stream_ceiling.plain_copy): the plain grid-stride copy the guide's
 // "achievable" HBM figure refers to -- 16 B per lane, every byte read once and written once, all waves resident --
 // to put beside gar_stream_sweep (the sweep's own walk: one record in flight per wave).  No product path calls it.
+// (four independent nontemporal 16-byte loads in flight per lane, 64 workgroups per CU: the best of the variants
+// of scripts/ubench/copy_variants.cpp on this pool -- 6.2 TB/s where one load in flight and 8 workgroups per CU
+// give 5.1)
 __global__ void __launch_bounds__(256) gar_plain_copy(const gar_double2 *__restrict__ src, gar_double2 *__restrict__ dst,
                                                       long long n) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    gar_double2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = __builtin_nontemporal_load(&src[i + u * stride]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      __builtin_nontemporal_store(v[u], &dst[i + u * stride]);
+  }
+  for (; i < n; i += stride)
     dst[i] = src[i];
 }
 

@@ -1539,6 +1539,10 @@ const char *gar_hip_last_error(void) { return g_last_error.c_str(); }
 
 double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_bytes_per_stage,
                                  int64_t out_bytes_per_stage, int reps) {
+  // reps < 0: the walk with TWO records requested ahead (gar_stream_sweep2), |reps| repetitions
+  const bool reps_ahead2 = reps < 0;
+  if (reps < 0)
+    reps = -reps;
   // (north-star records fit the compiled piece counts: <= 32 x 64 x 16 B = 32 KB in, 28 KB out per stage)
   const int in_pieces = (int)((in_bytes_per_stage + 15) / 16), out_pieces = (int)((out_bytes_per_stage + 15) / 16);
   if (batch <= 0 || horizon <= 0 || in_pieces <= 0 || out_pieces <= 0 || in_pieces > 32 * 64 || out_pieces > 28 * 64 ||
@@ -1557,8 +1561,12 @@ double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_
       hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
     for (int r = 0; r < reps + 1; ++r) { // first launch: warm-up
       (void)hipEventRecord(e0, nullptr);
-      hipLaunchKernelGGL((gar::gar_stream_sweep<32, 28>), dim3((unsigned)batch), dim3(64), 0, nullptr, in, out, sink,
-                         horizon, in_pieces, out_pieces);
+      if (reps_ahead2)
+        hipLaunchKernelGGL((gar::gar_stream_sweep2<32, 28>), dim3((unsigned)batch), dim3(64), 0, nullptr, in, out, sink,
+                           horizon, in_pieces, out_pieces);
+      else
+        hipLaunchKernelGGL((gar::gar_stream_sweep<32, 28>), dim3((unsigned)batch), dim3(64), 0, nullptr, in, out, sink,
+                           horizon, in_pieces, out_pieces);
       (void)hipEventRecord(e1, nullptr);
       float ms = 0.f;
       if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
@@ -1596,7 +1604,7 @@ double gar_hip_copy_ceiling_ms(int device, int64_t bytes_moved, int reps) {
       hipEventCreate(&e1) == hipSuccess) {
     for (int r = 0; r < reps + 1; ++r) { // first launch: warm-up
       (void)hipEventRecord(e0, nullptr);
-      hipLaunchKernelGGL(gar::gar_plain_copy, dim3((unsigned)(cus * 8)), dim3(256), 0, nullptr, src, dst, n);
+      hipLaunchKernelGGL(gar::gar_plain_copy, dim3((unsigned)(cus * 64)), dim3(256), 0, nullptr, src, dst, n);
       (void)hipEventRecord(e1, nullptr);
       float ms = 0.f;
       if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {

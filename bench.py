@@ -410,9 +410,13 @@ def stream_ceiling(solver, device, batch, N, nx, nu, bwd_bytes, bwd_ms):
     out = {"ms": ms, "GBps": bwd_bytes * batch / (ms * 1e-3) / 1e9, "frac_of_peak": bwd_bytes * batch / (ms * 1e-3) / HBM_PEAK,
            "kernel_over_stream": bwd_ms / ms,
            "note": "a kernel that only moves the backward sweep's bytes (same waves, same walk), measured in this run"}
-    # ... and a PLAIN grid-stride 16 B/lane copy of the same number of bytes (all waves resident, half read half
-    # written), in the same process: what this box's HBM gives the kernel the guide's 6.3 TB/s describes.  The gap
-    # between the two is what the sweep's walk (one record in flight per wave, 54:46 read:write) costs.
+    # ... and a PLAIN grid-stride 16 B/lane copy of the same number of bytes (four nontemporal loads in flight per
+    # lane, 64 workgroups per CU: the best of scripts/ubench/copy_variants.cpp), in the same process: what this
+    # box's HBM gives the kernel the guide's 6.3 TB/s describes.  The gap between the two is what the sweep's walk
+    # (4 096 sequential streams, one record in flight per wave, 54:46 read:write) costs.
+    ms2 = solver._L.gar_hip_stream_ceiling_ms(int(device), int(batch), int(N), knot_b, fac_b, -3)
+    if ms2 > 0:   # the same walk with two knots requested ahead: what a deeper prefetch could buy the sweep
+        out["two_ahead"] = {"ms": ms2, "GBps": bwd_bytes * batch / (ms2 * 1e-3) / 1e9, "kernel_over_stream": bwd_ms / ms2}
     cms = solver._L.gar_hip_copy_ceiling_ms(int(device), int(bwd_bytes * batch), 3)
     if cms > 0:
         out["plain_copy"] = {"ms": cms, "GBps": bwd_bytes * batch / (cms * 1e-3) / 1e9,

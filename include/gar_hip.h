@@ -74,7 +74,8 @@ int gar_hip_device_count(void);
  * that `batch` one-wave-per-problem streams need for the BYTES of a serial-in-time backward sweep and nothing
  * else -- per stage in_bytes read (one knot ahead in flight), out_bytes written, a 72-FMA dependent chain -- i.e.
  * what this GPU's HBM sustains for the sweep's read/write mix and walk.  Allocates and frees its own buffers
- * (batch * horizon * (in + out) bytes); in_bytes <= 32 KiB, out_bytes <= 28 KiB.  Negative on error. */
+ * (batch * horizon * (in + out) bytes); in_bytes <= 32 KiB, out_bytes <= 28 KiB.  Negative on error.
+ * reps < 0: the same walk with TWO knots requested ahead of the one being consumed, |reps| repetitions. */
 double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_bytes_per_stage,
                                  int64_t out_bytes_per_stage, int reps);
 
