@@ -1128,6 +1128,10 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.mueq = mueq;
     M.init_closed = s->init_closed ? 1 : 0;
     M.ring0 = s->ring0;
+    {
+      const char *sa = std::getenv("GAR_HIP_SPD_ACCEPT");
+      M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
+    }
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->wave_kernel) {

@@ -51,6 +51,9 @@ struct MfmaParams {
   // MPC cycling (cycleAppend, proximal-riccati.hxx:79-86) as a RING: the records of the stages
   // t < horizon are never moved; logical stage t lives in slot (t + ring0) mod horizon
   int ring0;
+  // plain stage (gar_wave2.hpp): a positive definite Rhat keeps the unpivoted register LDL^T even where
+  // Bunch-Kaufman would interchange (wave_ldl_fast_neg_pre); 0: the reference's pivot rule literally
+  int spd_accept;
   __host__ __device__ long long slot(int t) const {
     const int p = t + ring0;
     return (ring0 != 0 && p >= horizon) ? p - horizon : p;

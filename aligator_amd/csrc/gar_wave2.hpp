@@ -310,24 +310,36 @@ template <int NU> __device__ __forceinline__ double ldl_bcast(double v, int n, i
 }
 // (nd_lds != nullptr: -1/d_k goes to LDS as it is produced -- it is wave-uniform -- instead of into nd[]:
 // 2 NU registers less while a wide factorisation runs)
+// spd_accept (the plain stage's Rhat only): a column that fails the first test is NOT examined further as long as
+// the pivot is positive; if every pivot of the factorisation turns out positive -- Rhat = R + B^T V' B is positive
+// definite on every convex stage -- the unpivoted LDL^T stands although Bunch-Kaufman would have interchanged:
+// Cholesky-type elimination of a positive definite matrix is backward stable without pivoting, so the gains agree
+// with the reference's pivoted factorisation to cond * eps.  A non-positive pivot anywhere returns 1: the stage then
+// runs the device Bunch-Kaufman, the reference's own rule (interchanges, 2x2 pivots).  On the reference's generator
+// at the north star 3.7 % of the stages used to take that 85 k-cycle path for interchanges that stability does not
+// need.  GAR_HIP_SPD_ACCEPT=0 follows the reference's pivot rule literally.
 template <int NU, int NDN = NU>
 __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], double (&nd)[NDN], bool &first_failed,
-                                                     double *nd_lds = nullptr) {
+                                                     double *nd_lds = nullptr, const bool spd_accept = false) {
   const double alpha = (1.0 + 4.123105625617661) / 8.0;
   int bad = 0;
   first_failed = false;
+  double minpiv = 1.0; // smallest pivot so far (wave-uniform); NaN-safe: the comparison below is !(x > 0)
 #pragma unroll
   for (int k = 0; k < NU; ++k) {
     const double akk = ldl_bcast<NU>(a[k], k, lane);
+    minpiv = !(akk > 0.0) ? -1.0 : minpiv;
     const unsigned long long nok = wave_ballot(!(fabs(akk) >= alpha * fabs(a[k])) || akk == 0.0);
     const unsigned long long from_k = ((1ull << NU) - 1ull) & ~((1ull << k) - 1ull);
     if (nok & from_k) { // wave-uniform, rare
       first_failed = true;
-      LdlRow<NU> R;
+      if (!spd_accept) {
+        LdlRow<NU> R;
 #pragma unroll
-      for (int j = 0; j < NU; ++j)
-        R.a[j] = a[j];
-      bad |= wave_bk_second_test<NU>(R, akk, k, lane);
+        for (int j = 0; j < NU; ++j)
+          R.a[j] = a[j];
+        bad |= wave_bk_second_test<NU>(R, akk, k, lane);
+      }
     }
     const double nd_k = -fast_rcp(akk);
     const double nlik = a[k] * nd_k; // -L(i,k)
@@ -340,6 +352,8 @@ __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], 
     else if (lane == 0)
       nd_lds[k] = nd_k;
   }
+  if (spd_accept && first_failed) // the unpivoted factorisation stands only if Rhat proved positive definite
+    bad |= __builtin_amdgcn_readfirstlane(minpiv > 0.0 ? 0 : 1);
   return bad;
 }
 
@@ -608,7 +622,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
     }
     verdict = wave_ldl_fast_neg_pre<NK, 1>(lane, a44, nd44, first_failed, nd44p);
   } else {
-    verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed);
+    verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed, nullptr, P.spd_accept != 0);
   }
   if (first_failed && lane == 0) { // diagnostics: stages that needed the second test / that really pivot
     atomicAdd(&P.slow[0], 1);

@@ -17,7 +17,7 @@ def main():
     budget = float(os.environ.get("SOAK_SECONDS", "150"))
     dense_share = float(os.environ.get("SOAK_DENSE", "0.25"))
     t0, n, fails, kinds, why = time.time(), 0, 0, {}, {}
-    for d in draws(os.environ.get("SOAK_SEED", "2026"), os.environ.get("SOAK_FOCUS")):
+    for d in draws(os.environ.get("SOAK_SEED", "2026"), os.environ.get("SOAK_FOCUS"), version=int(os.environ.get("SOAK_VERSION", "2"))):
         if time.time() - t0 >= budget:
             break
         nx, nu, nc, horz, mode, mu, legs, seed, prob = (d[k] for k in ("nx", "nu", "nc", "horz", "mode", "mu", "legs", "seed", "prob"))
@@ -34,7 +34,7 @@ def main():
                 pc.check_dense(prob, mu, tol if nc == 0 else 1e-5)
                 name, legs = "dense", 1
             elif legs == 1:
-                s, _, _ = pc.check_serial(prob, mu, tol, factors=(nc == 0 or mu > 1e-9))
+                s, _, _ = pc.check_serial(prob, mu, tol, factors=(nc == 0 or mu > 1e-9), conditioned=(nc > 0))
                 name = s.kernel_name
             else:
                 # constrained problems in leg mode: the condensed leg-boundary system inherits the 1/mu

@@ -62,15 +62,25 @@ def compare_factors(hip_datas, ora_solver, N, tol, names=("ff", "fb", "fth"),
             assert np.abs(km - b).max() <= max(tol, 1e-9) * max(1.0, np.abs(b).max()), (t, "kktMat")
 
 
-def check_serial(prob, mueq, tol, lib_path=None, theta=None, kkt_tol=None, factors=True):
+CONDITIONING_MARGIN = 10.0   # x what three independent CPU solves of the same problem disagree by
+
+
+def check_serial(prob, mueq, tol, lib_path=None, theta=None, kkt_tol=None, factors=True, conditioned=False):
+    """conditioned (constrained problems with a small mu; theta = None): each part of the solution is held to
+    max(tol, CONDITIONING_MARGIN x the disagreement of the oracle and LAPACK on the dense KKT matrix) -- see
+    conditioning_bound."""
     solver = ProximalRiccatiSolver(prob, lib_path=lib_path)
     assert solver.backward(mueq)
     sol = lqrInitializeSolution(prob)
     assert solver.forward(*sol, theta)
     _, osol, ref = oracle_serial(prob, mueq, theta)
     sc = scale_of(ref)
-    for A, B in zip(sol, ref):
-        assert maxdiff(A, B) <= tol * sc
+    tols = [tol] * 4
+    if conditioned and theta is None:
+        bound, _ = conditioning_bound(prob, mueq, ref)
+        tols = [max(tol, CONDITIONING_MARGIN * b) for b in bound]
+    for A, B, tl in zip(sol, ref, tols):
+        assert maxdiff(A, B) <= tl * sc
     if kkt_tol is not None:
         assert max(lqrComputeKktError(prob, *sol, mueq=mueq, theta=theta)) <= kkt_tol
     if factors:
@@ -138,8 +148,8 @@ def conditioning_bound(prob, mueq, ref=None):
 def check_parallel(prob, mueq, nthreads, tol, lib_path=None, max_refine=10, rounds=0, rng=None, conditioned=False,
                    report=None):
     """tests/gar/parallel.cpp:185-245 (parallel_solver_class).
-    conditioned: the tolerance of each part of the solution is max(tol, 4 x what the problem's conditioning
-    allows), measured on the problem itself (conditioning_bound, and the oracle's own leg-parallel vs serial
+    conditioned: the tolerance of each part of the solution is max(tol, CONDITIONING_MARGIN x what the problem's
+    conditioning allows), measured on the problem itself (conditioning_bound, and the oracle's own leg-parallel vs serial
     solutions) instead of a floor on mu in the caller.  report: a dict that receives every pairwise figure."""
     _, _, ref = oracle_serial(prob, mueq)
     pprob = prob.copy()
@@ -162,9 +172,10 @@ def check_parallel(prob, mueq, nthreads, tol, lib_path=None, max_refine=10, roun
         leg_vs_serial = [maxdiff(a, b) / sc for a, b in zip(osol, ref)]
         okkt = max(lqrComputeKktError(prob, *osol, mueq=mueq)) / sc
         if conditioned:
-            tols = [max(tol, 4 * b, 4 * l) for b, l in zip(bound, leg_vs_serial)]
-            ktol = max(tol, 4 * okkt)
-            ftol = max(ftol, 4 * max(bound), 4 * max(leg_vs_serial))
+            m = CONDITIONING_MARGIN
+            tols = [max(tol, m * b, m * l) for b, l in zip(bound, leg_vs_serial)]
+            ktol = max(tol, m * okkt)
+            ftol = max(ftol, m * max(bound), m * max(leg_vs_serial))
         if report is not None:
             pairs = {"hip_leg-oracle_leg": (sol, osol), "hip_leg-oracle_serial": (sol, ref), "hip_leg-lapack": (sol, lap),
                      "oracle_leg-oracle_serial": (osol, ref), "oracle_leg-lapack": (osol, lap),
@@ -181,11 +192,15 @@ def check_parallel(prob, mueq, nthreads, tol, lib_path=None, max_refine=10, roun
     b0, e0 = 0, (prob.horizon + 1) // nthreads
     assert pprob.stages[b0].nth == prob.stages[e0 - 1].nx2
     assert np.array_equal(pprob.stages[e0 - 1].Gx, pprob.stages[e0 - 1].A.T)
-    compare_factors(par.datas, opar, prob.horizon, ftol)
-    par.collapseFeedback()
-    opar.collapseFeedback()
-    K0, K0o = par.getFeedback(0), opar.datas(0).fb
-    assert np.abs(K0 - K0o).max() <= ftol * max(1.0, np.abs(K0o).max())
+    # (stage factors of constrained problems below mu ~ 1e-9: two Bunch-Kaufman runs on the same reduced KKT matrix,
+    # conditioned like 1/mu, differ block by block by more than the solution does -- the oracle and LAPACK do:
+    # the solution-level checks above stand alone there, as in check_serial's `factors` switch of the soak)
+    if not (conditioned and mueq <= 1e-9 and any(k.nc > 0 for k in prob.stages)):
+        compare_factors(par.datas, opar, prob.horizon, ftol)
+        par.collapseFeedback()
+        opar.collapseFeedback()
+        K0, K0o = par.getFeedback(0), opar.datas(0).fb
+        assert np.abs(K0 - K0o).max() <= ftol * max(1.0, np.abs(K0o).max())
     for _ in range(rounds):                                              # :238-244
         synth.randomly_modify_problem(rng, pprob)
         par.backward(mueq)
@@ -362,6 +377,7 @@ def check_second_bunch_kaufman_test(lib_path=None):
     pivot[2, 1] = pivot[1, 2] = 0.5                      # rowmax 2 < alpha * 4 / 1: interchange
     old = os.environ.get("GAR_HIP_BACKWARD")
     os.environ["GAR_HIP_BACKWARD"] = "wave"
+    old_spd = os.environ.get("GAR_HIP_SPD_ACCEPT")
     try:
         # 2x2 pivots on the plain stage's pivoting path: at column 0 with its partner next to it, and at column 1
         # with the partner two rows down (interchange 2 <-> 3)
@@ -369,14 +385,20 @@ def check_second_bunch_kaufman_test(lib_path=None):
         far = np.array([[10.0, 0.1, 0.1, 0.1], [0.1, 0.05, 0.2, 6.0], [0.1, 0.2, 8.0, 0.1], [0.1, 6.0, 0.1, 0.03]])
         assert (ora.BunchKaufman(two).pivots < 0).sum() == 2 and (ora.BunchKaufman(far).pivots < 0).sum() == 2
         assert ora.BunchKaufman(far).pivots[1] == -1 - 3          # partner row 3, moved next to the pivot
-        for Rm, want in ((keep, (horz, 0)), (pivot, (horz, horz)), (two, (horz, horz)), (far, (horz, horz))):
+        # spd: a positive definite Rhat keeps the unpivoted LDL^T even where Bunch-Kaufman interchanges (the default,
+        # wave_ldl_fast_neg_pre); "0": the reference's pivot rule literally.  `pivot` is positive definite, `two`
+        # and `far` are indefinite: they take the device Bunch-Kaufman either way.
+        assert np.linalg.eigvalsh(pivot).min() > 0 and np.linalg.eigvalsh(two).min() < 0 and np.linalg.eigvalsh(far).min() < 0
+        for spd, Rm, want in (("0", keep, (horz, 0)), ("0", pivot, (horz, horz)), ("0", two, (horz, horz)), ("0", far, (horz, horz)),
+                              ("1", keep, (horz, 0)), ("1", pivot, (horz, 0)), ("1", two, (horz, horz)), ("1", far, (horz, horz))):
+            os.environ["GAR_HIP_SPD_ACCEPT"] = spd
             prob = synth.generate_lq_problem(21, np.zeros(nx), horz, nx, nu, mode="W")
             for k in prob.stages[:-1]:
                 k.R[...] = Rm
                 k.S[...] = 0.0
                 k.B[...] = 0.0                           # Rhat = R at every stage
             piv = ora.BunchKaufman(Rm).pivots
-            assert np.array_equal(piv, np.arange(nu)) == (want[1] == 0), piv
+            assert np.array_equal(piv, np.arange(nu)) == (want[1] == 0 and not (spd == "1" and Rm is pivot)), piv
             s = BatchedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, batch=1, lib_path=lib_path)
             assert s.kernel_name == "wave<8,4>"
             s.upload([prob])
@@ -395,6 +417,10 @@ def check_second_bunch_kaufman_test(lib_path=None):
             del os.environ["GAR_HIP_BACKWARD"]
         else:
             os.environ["GAR_HIP_BACKWARD"] = old
+        if old_spd is None:
+            os.environ.pop("GAR_HIP_SPD_ACCEPT", None)
+        else:
+            os.environ["GAR_HIP_SPD_ACCEPT"] = old_spd
 
 
 def check_bulk_gains(prob, mueq, lib_path=None, num_legs=1):

@@ -11,7 +11,7 @@ SHAPES = [(36, 12, 0), (32, 12, 0), (16, 8, 0), (12, 8, 0), (12, 4, 0), (8, 4, 0
           (56, 22, 0), (56, 24, 0), (50, 20, 0)]  # the wide family (two waves per problem / one wave)
 
 
-def draws(soak_seed, focus=None, build=True):
+def draws(soak_seed, focus=None, build=True, version=1):
     """Generator over the soak's draws: dicts with nx, nu, nc, horz, mode, mu, legs, seed, backward, wide,
     dense_draw (the uniform the dense/Riccati choice compares with SOAK_DENSE) and `prob`."""
     rng = np.random.default_rng(int(soak_seed))
@@ -28,6 +28,8 @@ def draws(soak_seed, focus=None, build=True):
         # differ by cond * eps > 1e-6 from each other on EVERY kernel family, generic included)
         mu = 10.0 ** rng.uniform(-12 if nc == 0 else -10, -5)
         legs = 1 if (nx > 36 or rng.random() < (0.8 if nc > 0 else 0.4)) else int(rng.integers(2, max(3, min(9, horz // 2))))
+        if version >= 2 and nx > 36 and rng.random() < 0.3:   # (round 3: the wide shape in leg mode, gar_leg_seg.hpp;
+            legs = int(rng.integers(2, max(3, min(6, horz // 2))))   # version 1 keeps the draw sequence of the logged runs)
         seed = int(rng.integers(1 << 30))
         prob = synth.generate_lq_problem(np.random.default_rng(seed), rng.standard_normal(nx), horz, nx, nu, nc=nc, mode=mode)
         if nc > 0:
