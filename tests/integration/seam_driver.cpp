@@ -1,0 +1,157 @@
+// TEST INFRASTRUCTURE -- the drop-in seam executed with the REFERENCE's own types: the HipRiccatiSolver that
+// INTEGRATION.md prints (extracted verbatim into hip_riccati_binding.hpp by tests/test_integration_binding.py) is
+// compiled against /root/reference/include (over the Eigen-API stand-in oracle/ref_shim, as oracle/_ref is) and
+// driven through gar::RiccatiSolverBase<double>* exactly as SolverProxDDP drives linear_solver_
+// (solver-proxddp.hxx:208, 608-611, 619, 624-625, 631-632), next to the reference's own ProximalRiccatiSolver /
+// ParallelRiccatiSolver on the same LqrProblemTpl.  Linked with the wave-emulator build of the library on CPU.
+#define ALIGATOR_MULTITHREADING
+#include <sched.h>
+#define ALIGATOR_TRACY_SET_THREAD_NAME(x) delete[] (x)
+#include "aligator/gar/lqr-problem.hxx"
+#include "aligator/gar/riccati-kernel.hxx"
+#include "aligator/gar/proximal-riccati.hxx"
+#include "aligator/gar/parallel-solver.hxx"
+#include "hip_riccati_binding.hpp"
+
+#include <cstdio>
+#include <memory>
+#include <random>
+
+using namespace aligator;
+using Problem = gar::LqrProblemTpl<double>;
+using Knot = gar::LqrKnotTpl<double>;
+using Base = gar::RiccatiSolverBase<double>;
+using VectorXs = Eigen::Matrix<double, Eigen::Dynamic, 1>;
+
+static Problem make_problem(uint nx, uint nu, uint nc, uint N, unsigned seed) {
+  std::mt19937 rng(seed);
+  std::normal_distribution<double> n01(0.0, 1.0);
+  std::uniform_real_distribution<double> u11(-1.0, 1.0);
+  Problem::KnotVector knots;
+  for (uint t = 0; t <= N; ++t) {
+    const uint nut = t < N ? nu : 0;
+    Knot k(nx, nut, nc);
+    const uint nw = nx + nut;
+    Eigen::Matrix<double, -1, -1> G(nw, nw + 1);
+    for (Eigen::Index j = 0; j < G.cols(); ++j)
+      for (Eigen::Index i = 0; i < G.rows(); ++i)
+        G(i, j) = n01(rng);
+    Eigen::Matrix<double, -1, -1> W = G * G.transpose();
+    W *= 1.0 / double(nx);
+    k.Q = W.block(0, 0, nx, nx);
+    if (nut > 0) {
+      k.S = W.block(0, nx, nx, nut);
+      k.R = W.block(nx, nx, nut, nut);
+    }
+    for (uint i = 0; i < nx; ++i) {
+      k.q(i) = u11(rng);
+      k.f(i) = n01(rng);
+      for (uint j = 0; j < nx; ++j)
+        k.A(i, j) = (i == j ? 1.0 : 0.0) + 0.1 * u11(rng);
+      for (uint j = 0; j < nut; ++j)
+        k.B(i, j) = 0.5 * u11(rng);
+    }
+    for (uint j = 0; j < nut; ++j)
+      k.r(j) = u11(rng);
+    for (uint c = 0; c < nc; ++c) {
+      k.d(c) = u11(rng);
+      for (uint j = 0; j < nx; ++j)
+        k.C(c, j) = u11(rng);
+    }
+    knots.push_back(std::move(k));
+  }
+  Problem p(knots, long(nx));
+  p.G0.setIdentity();
+  p.G0 *= -1.0;
+  for (uint i = 0; i < nx; ++i)
+    p.g0(i) = u11(rng);
+  return p;
+}
+
+struct Sol {
+  std::vector<VectorXs> xs, us, vs, lbdas;
+  explicit Sol(const Problem &p) {
+    const int N = p.horizon();
+    lbdas.emplace_back(VectorXs::Zero(p.nc0()));
+    for (int t = 0; t <= N; ++t) {
+      const Knot &k = p.stages[size_t(t)];
+      xs.emplace_back(VectorXs::Zero(k.nx));
+      if (t < N)
+        us.emplace_back(VectorXs::Zero(k.nu));
+      vs.emplace_back(VectorXs::Zero(k.nc));
+      if (t < N)
+        lbdas.emplace_back(VectorXs::Zero(k.nx2));
+    }
+  }
+};
+static double diff(const std::vector<VectorXs> &a, const std::vector<VectorXs> &b) {
+  double m = 0;
+  for (size_t i = 0; i < a.size(); ++i)
+    for (Eigen::Index j = 0; j < a[i].size(); ++j)
+      m = std::max(m, std::abs(a[i](j) - b[i](j)));
+  return m;
+}
+
+// what SolverProxDDP does with linear_solver_ between two Newton iterations
+static double run(Base &solver, Problem &p, Sol &s, double mu, std::vector<double> &gains) {
+  solver.backward(mu);
+  solver.forward(s.xs, s.us, s.vs, s.lbdas);
+  solver.collapseFeedback();
+  gains.clear();
+  for (size_t t = 0; t + 1 < p.stages.size(); ++t) {
+    auto ff = solver.getFeedforward(t);
+    auto fb = solver.getFeedback(t);
+    for (Eigen::Index i = 0; i < ff.size(); ++i)
+      gains.push_back(ff(i));
+    for (Eigen::Index i = 0; i < fb.rows(); ++i)
+      for (Eigen::Index j = 0; j < fb.cols(); ++j)
+        gains.push_back(fb(i, j));
+  }
+  double scale = 1.0;
+  for (const auto &l : s.lbdas)
+    for (Eigen::Index j = 0; j < l.size(); ++j)
+      scale = std::max(scale, std::abs(l(j)));
+  return scale;
+}
+
+int main() {
+  int bad = 0;
+  struct Case { uint nx, nu, nc, N; int legs; double mu; const char *want; };
+  const Case cases[] = {{8, 4, 0, 12, 1, 1e-10, "<8,4>"},        {7, 3, 0, 9, 1, 1e-10, "<8,4>"}, // padded inside the C ABI
+                        {8, 4, 3, 10, 1, 1e-6, "generic"},       {12, 6, 0, 14, 3, 1e-10, "wave_leg<12,8>"},
+                        {8, 4, 2, 11, 2, 1e-6, "wave_leg<8,4>+fold"}};
+  for (const Case &c : cases) {
+    Problem pr = make_problem(c.nx, c.nu, c.nc, c.N, 7 + c.nx), ph = pr;
+    Sol sr(pr), sh(ph);
+    std::vector<double> gr, gh;
+    std::unique_ptr<Base> ref, hip;
+    if (c.legs == 1) {
+      ref = std::make_unique<gar::ProximalRiccatiSolver<double>>(pr);
+      hip = std::make_unique<gar::HipRiccatiSolver>(ph, 1);
+    } else { // both re-parameterise their problem in place (parallel-solver.hxx:51-82)
+      ref = std::make_unique<gar::ParallelRiccatiSolver<double>>(pr, uint(c.legs));
+      for (int i = 0; i + 1 < c.legs; ++i) {
+        const uint b = uint(i) * (c.N + 1) / uint(c.legs), e = uint(i + 1) * (c.N + 1) / uint(c.legs);
+        for (uint t = b; t < e; ++t)
+          ph.stages[t].addParameterization(ph.stages[e - 1].nx2);
+      }
+      hip = std::make_unique<gar::HipRiccatiSolver>(ph, c.legs);
+    }
+    const double scale = run(*ref, pr, sr, c.mu, gr);
+    run(*hip, ph, sh, c.mu, gh);
+    double dg = 0, gs = 1;
+    for (size_t i = 0; i < std::min(gr.size(), gh.size()); ++i) {
+      dg = std::max(dg, std::abs(gr[i] - gh[i]));
+      gs = std::max(gs, std::abs(gr[i]));
+    }
+    const double dx = diff(sr.xs, sh.xs), du = diff(sr.us, sh.us), dv = diff(sr.vs, sh.vs), dl = diff(sr.lbdas, sh.lbdas);
+    const char *name = gar_hip_kernel_name_of(*hip);
+    const bool ok = gr.size() == gh.size() && std::max(std::max(dx, du), std::max(dv, dl)) <= 1e-8 * scale && dg <= 1e-8 * gs &&
+                    std::string(name).find(c.want) != std::string::npos;
+    std::printf("nx=%u nu=%u nc=%u N=%u legs=%d kernel %-22s |x| %.1e |u| %.1e |v| %.1e |lbd| %.1e |gains| %.1e (rel %.1e)  %s\n", c.nx, c.nu,
+                c.nc, c.N, c.legs, name, dx, du, dv, dl, dg, dg / gs, ok ? "ok" : "MISMATCH");
+    bad += !ok;
+  }
+  std::printf(bad ? "%d case(s) FAILED\n" : "seam ok\n", bad);
+  return bad ? 1 : 0;
+}
