@@ -788,125 +788,6 @@ __device__ inline void wg_bk_solve_few(const WG &w, int n, const double *a, int 
 #undef GX
 }
 
-// Many right-hand sides, whole workgroup: threads are laid out (column c, row group g); at
-// substitution step j every thread updates its rows i > j of its column -- all (n-j-1) x ncols
-// elements move per barrier, instead of one thread grinding through a whole column alone.
-// Same operations, same order per element, as the one-thread-per-column path.
-template <int MODE>
-__device__ inline void wg_bk_solve_block(const WG &w, int n, const double *a, int lda,
-                                         const double *subdiag, const int *piv, double *x,
-                                         int xrs, int xcs, int ncols) {
-#define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
-#define GXC(i, c) x[(c) * xcs + (i) * xrs]
-  const int ngrp = w.nthr / ncols > 0 ? w.nthr / ncols : 1; // row groups per column
-  const int c0 = w.tid % ncols, g0 = w.tid / ncols;
-  const bool active = g0 < ngrp && w.tid < ngrp * ncols;
-  wg_bar(w);
-  for (int c = w.tid; c < ncols; c += w.nthr) { // forward interchanges (:458-468)
-    int k = 0;
-    while (k < n) {
-      int p = piv[k];
-      int row = k;
-      if (p < 0) {
-        p = -1 - p;
-        row = k + 1;
-        k += 2;
-      } else {
-        k += 1;
-      }
-      if (row != p) {
-        const double t = GXC(row, c);
-        GXC(row, c) = GXC(p, c);
-        GXC(p, c) = t;
-      }
-    }
-  }
-  for (int j = 0; j + 1 < n; ++j) { // unit-lower solve (:472)
-    wg_bar(w);
-    if (active) {
-      // four rows per round trip: the loads are issued together before the stores that follow
-      // (the compiler cannot prove that the store to x(i) does not alias the next loads)
-      const double xj = GXC(j, c0);
-      for (int i = j + 1 + g0; i < n; i += 4 * ngrp) {
-        double l[4], v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ii = i + q * ngrp;
-          l[q] = ii < n ? GA(ii, j) : 0.0;
-          v[q] = ii < n ? GXC(ii, c0) : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ii = i + q * ngrp;
-          if (ii < n)
-            GXC(ii, c0) = v[q] - l[q] * xj;
-        }
-      }
-    }
-  }
-  wg_bar(w);
-  for (int c = w.tid; c < ncols; c += w.nthr) { // inverse-D multiply (:474-502)
-    int k = 0;
-    while (k < n) {
-      if (piv[k] < 0) {
-        const double akp1k = subdiag[k], ak = GA(k, k), akp1 = GA(k + 1, k + 1);
-        const double xk = GXC(k, c), xkp1 = GXC(k + 1, c);
-        GXC(k, c) = xk * ak + xkp1 * akp1k;
-        GXC(k + 1, c) = xkp1 * akp1 + xk * akp1k;
-        k += 2;
-      } else {
-        GXC(k, c) *= GA(k, k);
-        k += 1;
-      }
-    }
-  }
-  for (int i = n - 1; i >= 1; --i) { // unit-upper (L^T) solve (:504)
-    wg_bar(w);
-    if (active) {
-      const double xi = GXC(i, c0);
-      for (int j = g0; j < i; j += 4 * ngrp) {
-        double l[4], v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int jj = j + q * ngrp;
-          l[q] = jj < i ? GA(i, jj) : 0.0;
-          v[q] = jj < i ? GXC(jj, c0) : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int jj = j + q * ngrp;
-          if (jj < i)
-            GXC(jj, c0) = v[q] - l[q] * xi;
-        }
-      }
-    }
-  }
-  wg_bar(w);
-  for (int c = w.tid; c < ncols; c += w.nthr) { // reverse interchanges (:506-517)
-    int k = n;
-    while (k > 0) {
-      k -= 1;
-      int p = piv[k];
-      if (p < 0) {
-        p = -1 - p;
-        if (k != p) {
-          const double t = GXC(k, c);
-          GXC(k, c) = GXC(p, c);
-          GXC(p, c) = t;
-        }
-        k -= 1;
-      } else if (k != p) {
-        const double t = GXC(k, c);
-        GXC(k, c) = GXC(p, c);
-        GXC(p, c) = t;
-      }
-    }
-  }
-  wg_bar(w);
-#undef GA
-#undef GXC
-}
-
 // Bunch-Kaufman solve of NCOLS (<= 48) right-hand sides by ONE wave with the triangular solves as
 // BLOCKED MFMA updates: X (N x NCOLS, row i at X[i*xrs + c]) is held in accumulator layout (tile
 // (ti, tj) register r = X(16ti + (lane>>4) + 4r, 16tj + (lane&15))); a k-step is a block of four
@@ -1063,6 +944,179 @@ __device__ inline void wave_bk_solve_mfma(const double *a, const double *subdiag
 #undef GA
 }
 
+// Many right-hand sides, whole workgroup, the triangular solves BLOCKED: a step finishes NB rows of X (their
+// NB x NB unit-triangular part by one thread per column), then the rows still open are updated with
+// X(open, :) -= L(open, blk) X(blk, :) on f64 MFMA tiles shared out over the waves -- 2 n / NB pairs of barriers
+// where the row-at-a-time substitution above needs 2 n, and a quarter of its LDS traffic.  Interchanges and the
+// (1x1 / 2x2) D^{-1} step exactly as bunchkaufman.hpp:451-518; the stored form keeps L(k+1, k) = 0 inside a 2x2
+// pivot, so the blocks need not respect pivot boundaries.  Sums are accumulated four products at a time (MFMA
+// order), not in the reference's dot-product order: equal to rounding.
+template <int MODE, int NB>
+__device__ __forceinline__ void ldl_block_update(const WG &w, const double *a, int lda, double *x, int xrs, int xcs,
+                                                 int ncols, int row0, int M, int p, int nb, bool transposed) {
+  // X(row0 + i, :) -= sum_k Lop(i, k) X(p + k, :),  Lop(i, k) = L(row0 + i, p + k)  [ L(p + k, row0 + i) transposed ]
+  if (M <= 0)
+    return;
+  const int tN = (ncols + 15) >> 4, nt = ((M + 15) >> 4) * tN;
+  const int li = w.lane & 15, lk = w.lane >> 4;
+  for (int t = w.wave; t < nt; t += w.nwaves) {
+    const int i0 = (t / tN) << 4, col = ((t % tN) << 4) + li;
+    const bool cok = col < ncols;
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + lk + 4 * r;
+      acc[r] = (row < M && cok) ? x[(row0 + row) * xrs + col * xcs] : 0.0;
+    }
+    const int ai = i0 + li;
+#pragma unroll
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+      const int k = k0 + lk;
+      double av = 0.0, bv = 0.0;
+      if (k < nb) {
+        if (ai < M)
+          av = -(transposed ? a[bk_idx<MODE>(p + k, row0 + ai, lda)] : a[bk_idx<MODE>(row0 + ai, p + k, lda)]);
+        if (cok)
+          bv = x[(p + k) * xrs + col * xcs];
+      }
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + lk + 4 * r;
+      if (row < M && cok)
+        x[(row0 + row) * xrs + col * xcs] = acc[r];
+    }
+  }
+}
+
+template <int MODE, int NB = 8>
+__device__ inline void wg_bk_solve_mfma(const WG &w, int n, const double *a, int lda, const double *subdiag,
+                                        const int *piv, double *x, int xrs, int xcs, int ncols) {
+#define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
+#define GXC(i, c) x[(c) * xcs + (i) * xrs]
+  wg_bar(w);
+  bool moved = false; // any interchange or 2x2 pivot?  (every wave looks at every entry: uniform)
+  for (int k = w.lane; k < n; k += 64)
+    moved |= piv[k] != k;
+  const bool pivoted = __ballot(moved) != 0ull;
+  if (pivoted) {
+    for (int c = w.tid; c < ncols; c += w.nthr) { // forward interchanges (:458-468)
+      int k = 0;
+      while (k < n) {
+        int p = piv[k];
+        int row = k;
+        if (p < 0) {
+          p = -1 - p;
+          row = k + 1;
+          k += 2;
+        } else {
+          k += 1;
+        }
+        if (row != p) {
+          const double t = GXC(row, c);
+          GXC(row, c) = GXC(p, c);
+          GXC(p, c) = t;
+        }
+      }
+    }
+    wg_bar(w);
+  }
+  for (int p = 0; p < n; p += NB) { // unit-lower solve (:472)
+    const int nb = n - p < NB ? n - p : NB;
+    for (int c = w.tid; c < ncols; c += w.nthr) {
+      double xv[NB];
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+        xv[r] = r < nb ? GXC(p + r, c) : 0.0;
+#pragma unroll
+      for (int r = 1; r < NB; ++r)
+        if (r < nb) {
+          double s = xv[r];
+#pragma unroll
+          for (int q = 0; q < r; ++q)
+            s -= GA(p + r, p + q) * xv[q];
+          xv[r] = s;
+          GXC(p + r, c) = s;
+        }
+    }
+    wg_bar(w);
+    ldl_block_update<MODE, NB>(w, a, lda, x, xrs, xcs, ncols, p + nb, n - p - nb, p, nb, false);
+    wg_bar(w);
+  }
+  if (pivoted) {
+    for (int c = w.tid; c < ncols; c += w.nthr) { // inverse-D multiply (:474-502)
+      int k = 0;
+      while (k < n) {
+        if (piv[k] < 0) {
+          const double akp1k = subdiag[k], ak = GA(k, k), akp1 = GA(k + 1, k + 1);
+          const double xk = GXC(k, c), xkp1 = GXC(k + 1, c);
+          GXC(k, c) = xk * ak + xkp1 * akp1k;
+          GXC(k + 1, c) = xkp1 * akp1 + xk * akp1k;
+          k += 2;
+        } else {
+          GXC(k, c) *= GA(k, k);
+          k += 1;
+        }
+      }
+    }
+  } else {
+    for (int e = w.tid; e < n * ncols; e += w.nthr) {
+      const int k = e / ncols, c = e - k * ncols;
+      GXC(k, c) *= GA(k, k);
+    }
+  }
+  wg_bar(w);
+  for (int p = ((n - 1) / NB) * NB; p >= 0; p -= NB) { // unit-upper (L^T) solve (:504)
+    const int nb = n - p < NB ? n - p : NB;
+    for (int c = w.tid; c < ncols; c += w.nthr) {
+      double xv[NB];
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+        xv[r] = r < nb ? GXC(p + r, c) : 0.0;
+#pragma unroll
+      for (int r = NB - 2; r >= 0; --r)
+        if (r < nb - 1) {
+          double s = xv[r];
+#pragma unroll
+          for (int q = r + 1; q < NB; ++q)
+            if (q < nb)
+              s -= GA(p + q, p + r) * xv[q];
+          xv[r] = s;
+          GXC(p + r, c) = s;
+        }
+    }
+    wg_bar(w);
+    ldl_block_update<MODE, NB>(w, a, lda, x, xrs, xcs, ncols, 0, p, p, nb, true);
+    wg_bar(w);
+  }
+  if (pivoted) {
+    for (int c = w.tid; c < ncols; c += w.nthr) { // reverse interchanges (:506-517)
+      int k = n;
+      while (k > 0) {
+        k -= 1;
+        int p = piv[k];
+        if (p < 0) {
+          p = -1 - p;
+          if (k != p) {
+            const double t = GXC(k, c);
+            GXC(k, c) = GXC(p, c);
+            GXC(p, c) = t;
+          }
+          k -= 1;
+        } else if (k != p) {
+          const double t = GXC(k, c);
+          GXC(k, c) = GXC(p, c);
+          GXC(p, c) = t;
+        }
+      }
+    }
+    wg_bar(w);
+  }
+#undef GA
+#undef GXC
+}
+
 template <int MODE = GAR_COLMAJOR>
 __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
                                    const double *subdiag, const int *piv, double *x, int xrs,
@@ -1091,8 +1145,8 @@ __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
     wg_bk_solve_few<MODE>(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
     return;
   }
-  if (!w.wave_scope && ncols >= 16 && ncols <= w.nthr) {
-    wg_bk_solve_block<MODE>(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
+  if (!w.wave_scope && ncols >= 16) {
+    wg_bk_solve_mfma<MODE>(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
     return;
   }
 #define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
@@ -1163,6 +1217,71 @@ __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
   wg_bar(w);
 #undef GA
 #undef GX
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// DEFINITE matrices (all pivots of one sign: Vxx > 0, Rhat > 0, the alternating-sign Schur complements of the
+// condensed leg-boundary system): blocked L D L^T WITHOUT pivoting.  A panel of 4 columns is factorised by wave 0
+// alone (lane = row: no workgroup barrier inside a panel), the trailing block takes A22 -= (L21 D) L21^T on f64
+// MFMA tiles from the whole workgroup.  Elimination of a definite matrix is backward stable without pivoting, so
+// the result agrees with Bunch-Kaufman's (which may still interchange on such a matrix) to cond * eps; the stored
+// form is Bunch-Kaufman's with piv[k] = k (unit-lower L below the diagonal, INVERSE pivots on it, subdiag = 0), so
+// wg_bk_solve and every consumer of a factorised block work unchanged.  Returns 0 when every pivot is finite,
+// nonzero and of the sign of the first one; otherwise 1 with `a` DESTROYED: the caller restores the block and
+// runs wg_bk_factor (the reference's rule).  n <= 64, column-major, wk: 4 n doubles of LDS, ctrl: >= 1 int.
+__device__ inline int wg_ldl_definite_factor(const WG &w, int n, double *a, int lda, double *subdiag, int *piv,
+                                             double *wk, int *ctrl) {
+  if (w.tid == 0)
+    ctrl[0] = 0;
+  __syncthreads();
+  if (n == 0)
+    return 0;
+  const bool positive = a[0] > 0.0;
+  for (int p = 0; p < n; p += 4) {
+    const int nb = n - p < 4 ? n - p : 4;
+    if (w.wave == 0) {
+      const int i = p + w.lane; // this lane's row
+      bool bad = false;
+      for (int c = 0; c < nb; ++c) {
+        const int k = p + c;
+        const double d = a[k + k * lda]; // wave-uniform
+        bad |= !(fabs(d) <= 1.7e308) || d == 0.0 || ((d > 0.0) != positive);
+        const double aik = (i > k && i < n) ? a[i + k * lda] : 0.0;
+        if (i > k && i < n)
+          wk[i + c * n] = aik; // (L D)(i, k)
+        wave_sync();
+        if (i == k)
+          a[k + k * lda] = 1.0 / d;
+        if (i > k && i < n) {
+          const double lik = aik / d;
+          a[i + k * lda] = lik;
+          for (int j = c + 1; j < nb; ++j) // rest of the panel: a(i, p+j) -= l(i, k) (L D)(p+j, k), rows i >= p+j
+            if (i >= p + j)
+              a[i + (p + j) * lda] -= lik * wk[(p + j) + c * n];
+        }
+        wave_sync();
+      }
+      if (bad && w.lane == 0)
+        ctrl[0] = 1;
+    }
+    __syncthreads();
+    if (ctrl[0])
+      return 1;
+    const int m = n - p - nb; // trailing block
+    if (m > 0) {
+      const MatV LD = colmajor(wk + (p + nb), n), L21 = colmajor(a + (p + nb) + p * lda, lda);
+      const MatV A22 = colmajor(a + (p + nb) + (p + nb) * lda, lda);
+      wg_gemm(w, m, m, nb, LD, L21.T(), A22, A22, -1.0);
+      __syncthreads();
+    }
+  }
+  for (int k = w.tid; k < n; k += w.nthr) {
+    piv[k] = k;
+    subdiag[k] = 0.0;
+  }
+  __syncthreads();
+  return 0;
 }
 
 } // namespace gar

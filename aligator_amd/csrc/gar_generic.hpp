@@ -893,7 +893,20 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
     for (int e = w.tid; e < n * n; e += w.nthr)
       blk[e] = facD[(long long)ib * bs + e];
     __syncthreads();
-    failed |= wg_bk_factor(w, n, blk, n, lsub, lpiv, ctrl);
+    // the Schur complements of this elimination are definite, of alternating sign (Vxx - Vxt S^-1 Vxt^T > 0,
+    // Vtt - S^-1 < 0, ...): blocked elimination without pivoting (ublk is free here: its panel workspace); a
+    // pivot of the wrong sign or a zero sends the block to the reference's Bunch-Kaufman
+    int indefinite = 1;
+    if (n >= 8 && n <= 64) {
+      indefinite = wg_ldl_definite_factor(w, n, blk, n, lsub, lpiv, ublk, ctrl);
+      if (indefinite) {
+        for (int e = w.tid; e < n * n; e += w.nthr)
+          blk[e] = facD[(long long)ib * bs + e];
+        __syncthreads();
+      }
+    }
+    if (indefinite)
+      failed |= wg_bk_factor(w, n, blk, n, lsub, lpiv, ctrl);
     for (int e = w.tid; e < n * n; e += w.nthr)
       facD[(long long)ib * bs + e] = blk[e];
     for (int e = w.tid; e < n; e += w.nthr) {

@@ -1064,6 +1064,10 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     M.fac_offN = f->meta[N].fac_off;
     M.horizon = N;
     M.mueq = mueq;
+    {
+      const char *sa = std::getenv("GAR_HIP_SPD_ACCEPT");
+      M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
+    }
     const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));

@@ -186,7 +186,23 @@ __global__ void __launch_bounds__(256) gar_leg_param_generic(LegParamParams P) {
       wg_gemm(w, nu, nth, nx2, B.T(), X, MatV{nullptr, 0, 0}, G, 1.0);
       __syncthreads();
       // Rhat = L D L^T (Bunch-Kaufman, the reference's factorisation); Kth = -Rhat^-1 Ghat_u  (:288-292)
-      failed |= wg_bk_factor(w, nu, Rh, nu, sub, piv, ctrl);
+      // (Rhat > 0 on a well-posed stage: blocked elimination without pivoting, workspace in VB, a copy of Rhat
+      // parked in Kt for the stage that is not -- that one goes through Bunch-Kaufman as in the reference)
+      int indefinite = 1;
+      if (nu >= 8 && nu <= 64 && 4 * nu <= nx2 * nu && nu * nu <= nu * nth) {
+        for (int e = w.tid; e < nu * nu; e += w.nthr)
+          Kt[e] = Rh[e];
+        __syncthreads();
+        indefinite = wg_ldl_definite_factor(w, nu, Rh, nu, sub, piv, VB, ctrl);
+        if (indefinite) {
+          for (int e = w.tid; e < nu * nu; e += w.nthr)
+            Rh[e] = Kt[e];
+          __syncthreads();
+        }
+      }
+      if (indefinite)
+        failed |= wg_bk_factor(w, nu, Rh, nu, sub, piv, ctrl);
+      __syncthreads();
       for (int e = w.tid; e < nu * nth; e += w.nthr)
         Kt[e] = -Gh[e];
       __syncthreads();

@@ -220,7 +220,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
     for (int j = 0; j < NU; ++j)
       a_row[j] = Mm[j * NU + frow];
     bool first_failed;
-    const int verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed);
+    const int verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed, nullptr, P.spd_accept != 0);
     if (lane < NU) {
 #pragma unroll
       for (int j = 0; j < NU; ++j)

@@ -1,0 +1,124 @@
+"""The workgroup-level L D L^T building blocks (aligator_amd/csrc/gar_device.hpp) on matrices chosen here:
+wg_ldl_definite_factor (blocked elimination without pivoting, used where the block is definite) against
+wg_bk_factor (the reference's Bunch-Kaufman, core/bunchkaufman.hpp:23-169), and the blocked MFMA substitution
+wg_bk_solve_mfma (:451-518) on factors with interchanges and 2x2 pivots.  Wave emulator here; the same
+translation unit is compiled with hipcc for the GPU run (tests/test_gpu_parity.py)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_emu():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
+    return ctypes.CDLL(os.path.join(HERE, "emu", "_build", "libgar_ldl_unit_emu.so"))
+
+
+def run_unit(lib, A, X, definite_first):
+    n, nc = A.shape[0], X.shape[1]
+    a = np.asfortranarray(A, dtype=np.float64).copy(order="F")
+    x = np.asfortranarray(X, dtype=np.float64).copy(order="F")
+    sub = np.zeros(n)
+    piv = np.zeros(n, dtype=np.int32)
+    info = np.zeros(2, dtype=np.int32)
+    dp = ctypes.POINTER(ctypes.c_double)
+    ip = ctypes.POINTER(ctypes.c_int)
+    rc = lib.gar_ldl_unit(n, nc, int(definite_first), a.ctypes.data_as(dp), x.ctypes.data_as(dp),
+                          sub.ctypes.data_as(dp), piv.ctypes.data_as(ip), info.ctypes.data_as(ip))
+    assert rc == 0
+    return a, x, sub, piv, info
+
+
+def spd(rng, n, cond=1e3):
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    return (q * np.geomspace(1.0, cond, n)) @ q.T
+
+
+def check_solution(A, X0, X, tol):
+    Afull = np.tril(A) + np.tril(A, -1).T
+    res = np.abs(Afull @ X - X0).max() / (np.abs(Afull).max() * np.abs(X).max() + np.abs(X0).max())
+    assert res <= tol, res
+
+
+CASES = [(8, 16), (12, 37), (24, 56), (36, 36), (44, 45), (56, 56), (57, 19), (64, 64), (30, 300)]
+
+
+@pytest.mark.parametrize("n,ncols", CASES)
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_definite_factor_matches_bunch_kaufman(n, ncols, sign, lib=None):
+    lib = lib or load_emu()
+    rng = np.random.default_rng(100 * n + ncols)
+    A = sign * spd(rng, n)
+    X0 = rng.standard_normal((n, ncols))
+    a1, x1, sub1, piv1, info1 = run_unit(lib, A, X0, True)
+    a2, x2, sub2, piv2, info2 = run_unit(lib, A, X0, False)
+    assert info1[0] == 0 and info1[1] == -1      # definite path taken, Bunch-Kaufman not run
+    assert info2[0] == -1 and info2[1] == 0
+    assert (piv1 == np.arange(n)).all() and (sub1 == 0).all()
+    check_solution(A, X0, x1, 1e-13)
+    check_solution(A, X0, x2, 1e-13)
+    assert np.abs(x1 - x2).max() <= 1e-10 * np.abs(x2).max()     # cond = 1e3
+    # the stored form: unit-lower L, inverse pivots on the diagonal
+    L = np.tril(a1, -1) + np.eye(n)
+    D = np.diag(1.0 / np.diag(a1))
+    assert np.abs(L @ D @ L.T - A).max() <= 1e-12 * np.abs(A).max()
+
+
+@pytest.mark.parametrize("n,ncols", [(12, 16), (44, 45), (56, 56), (64, 20)])
+def test_wrong_sign_pivot_sends_the_block_to_bunch_kaufman(n, ncols, lib=None):
+    lib = lib or load_emu()
+    rng = np.random.default_rng(n)
+    A = spd(rng, n)
+    k = n // 2
+    A[k:, k:] -= 2.0 * A[k:, k:]          # [[P, B], [B^T, -Q]]: quasi-definite, the pivots change sign at k
+    X0 = rng.standard_normal((n, ncols))
+    a1, x1, _, piv1, info1 = run_unit(lib, A, X0, True)
+    a2, x2, _, piv2, info2 = run_unit(lib, A, X0, False)
+    assert info1[0] == 1 and info1[1] == 0       # refused, then factorised by Bunch-Kaufman from the restored block
+    assert (a1 == a2).all() and (x1 == x2).all() and (piv1 == piv2).all()
+    check_solution(A, X0, x1, 1e-13)
+
+
+@pytest.mark.parametrize("n,ncols", [(16, 16), (44, 45), (56, 57), (116, 37)])
+def test_blocked_substitution_with_interchanges_and_2x2_pivots(n, ncols, lib=None):
+    """a KKT-like indefinite matrix with a zero block: Bunch-Kaufman must interchange and take 2x2 pivots"""
+    lib = lib or load_emu()
+    rng = np.random.default_rng(7 * n)
+    m = n // 3
+    A = np.zeros((n, n))
+    A[:n - m, :n - m] = spd(rng, n - m, 50.0)
+    A[:m, :m] = 0.0                                # zero leading block: the first columns fail the diagonal test
+    J = rng.standard_normal((m, n - m))
+    A[n - m:, :n - m] = J
+    A[:n - m, n - m:] = J.T
+    A[n - m:, n - m:] = -1e-3 * np.eye(m)
+    X0 = rng.standard_normal((n, ncols))
+    a, x, sub, piv, info = run_unit(lib, A, X0, False)
+    assert info[1] == 0
+    assert (piv < 0).any() and (piv[piv >= 0] != np.arange(n)[piv >= 0]).any()
+    ref = np.linalg.solve(A, X0)
+    assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max()
+    check_solution(A, X0, x, 1e-12)
+
+
+def load_gpu():
+    so = os.path.join(HERE, "unit", "_build", "libgar_ldl_unit.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-s", "-C", os.path.join(HERE, "unit")], check=True, capture_output=True)
+    return ctypes.CDLL(so)
+
+
+@pytest.mark.gpu
+def test_ldl_building_blocks_on_the_gpu():
+    lib = load_gpu()
+    for n, ncols in CASES:
+        for sign in (1.0, -1.0):
+            test_definite_factor_matches_bunch_kaufman(n, ncols, sign, lib=lib)
+    for n, ncols in [(12, 16), (44, 45), (56, 56), (64, 20)]:
+        test_wrong_sign_pivot_sends_the_block_to_bunch_kaufman(n, ncols, lib=lib)
+    for n, ncols in [(16, 16), (44, 45), (56, 57), (116, 37)]:
+        test_blocked_substitution_with_interchanges_and_2x2_pivots(n, ncols, lib=lib)

@@ -1,0 +1,92 @@
+// TEST-ONLY: the workgroup-level L D L^T building blocks of aligator_amd/csrc/gar_device.hpp behind a C entry
+// point, so that tests can drive them on a matrix of their choosing (definite, indefinite, with 2x2 pivots).
+// Built two ways from this one file: for the wave emulator (tests/emu, host threads) and with hipcc for gfx950.
+#include "gar_generic.hpp" // gar_smem, gar_device.hpp
+
+namespace {
+struct UnitParams {
+  double *A;  // n x n column-major: in the matrix (lower triangle read), out the factorised block
+  double *X;  // n x ncols column-major: in the right-hand sides, out the solution
+  double *sub;
+  int *piv;
+  int *info;  // [0] what the definite factorisation returned (-1: not run), [1] what Bunch-Kaufman returned (-1: not run)
+  int n, ncols, definite_first;
+};
+
+__global__ void __launch_bounds__(256) ldl_unit_kernel(UnitParams P) {
+  using namespace gar;
+  const WG w = wg_self();
+  const int n = P.n, nc = P.ncols;
+  double *a = gar_smem, *x = a + ((n * n + 1) & ~1), *wk = x + ((n * nc + 1) & ~1), *sub = wk + 4 * n + 2;
+  int *piv = (int *)(sub + n + (n & 1)), *ctrl = piv + n + 8;
+  for (int e = w.tid; e < n * n; e += w.nthr)
+    a[e] = P.A[e];
+  for (int e = w.tid; e < n * nc; e += w.nthr)
+    x[e] = P.X[e];
+  __syncthreads();
+  int r_def = -1, r_bk = -1;
+  if (P.definite_first) {
+    r_def = wg_ldl_definite_factor(w, n, a, n, sub, piv, wk, ctrl);
+    if (r_def) {
+      for (int e = w.tid; e < n * n; e += w.nthr)
+        a[e] = P.A[e];
+      __syncthreads();
+    }
+  }
+  if (r_def != 0)
+    r_bk = wg_bk_factor(w, n, a, n, sub, piv, ctrl);
+  wg_bk_solve(w, n, a, n, sub, piv, x, 1, n, nc);
+  for (int e = w.tid; e < n * n; e += w.nthr)
+    P.A[e] = a[e];
+  for (int e = w.tid; e < n * nc; e += w.nthr)
+    P.X[e] = x[e];
+  for (int e = w.tid; e < n; e += w.nthr) {
+    P.sub[e] = sub[e];
+    P.piv[e] = piv[e];
+  }
+  if (w.tid == 0) {
+    P.info[0] = r_def;
+    P.info[1] = r_bk;
+  }
+}
+} // namespace
+
+// host pointers in, host pointers out; returns 0 or a HIP error code
+extern "C" int gar_ldl_unit(int n, int ncols, int definite_first, double *A, double *X, double *sub, int *piv,
+                            int *info) {
+  UnitParams P{};
+  P.n = n;
+  P.ncols = ncols;
+  P.definite_first = definite_first;
+  const size_t bA = sizeof(double) * n * n, bX = sizeof(double) * n * ncols;
+#define TRY(e)                                                                                                         \
+  do {                                                                                                                 \
+    hipError_t err_ = (e);                                                                                             \
+    if (err_ != hipSuccess)                                                                                            \
+      return (int)err_ ? (int)err_ : -1;                                                                               \
+  } while (0)
+  TRY(hipMalloc((void **)&P.A, bA));
+  TRY(hipMalloc((void **)&P.X, bX ? bX : 8));
+  TRY(hipMalloc((void **)&P.sub, sizeof(double) * n));
+  TRY(hipMalloc((void **)&P.piv, sizeof(int) * n));
+  TRY(hipMalloc((void **)&P.info, sizeof(int) * 2));
+  TRY(hipMemcpy(P.A, A, bA, hipMemcpyHostToDevice));
+  TRY(hipMemcpy(P.X, X, bX, hipMemcpyHostToDevice));
+  const size_t lds = sizeof(double) * (size_t)(n * n + n * ncols + 6 * n + 64) + sizeof(int) * (size_t)(n + 32);
+  TRY(hipFuncSetAttribute((const void *)ldl_unit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ldl_unit_kernel, dim3(1), dim3(256), lds, (hipStream_t) nullptr, P);
+  TRY(hipGetLastError());
+  TRY(hipStreamSynchronize((hipStream_t) nullptr));
+  TRY(hipMemcpy(A, P.A, bA, hipMemcpyDeviceToHost));
+  TRY(hipMemcpy(X, P.X, bX, hipMemcpyDeviceToHost));
+  TRY(hipMemcpy(sub, P.sub, sizeof(double) * n, hipMemcpyDeviceToHost));
+  TRY(hipMemcpy(piv, P.piv, sizeof(int) * n, hipMemcpyDeviceToHost));
+  TRY(hipMemcpy(info, P.info, sizeof(int) * 2, hipMemcpyDeviceToHost));
+  hipFree(P.A);
+  hipFree(P.X);
+  hipFree(P.sub);
+  hipFree(P.piv);
+  hipFree(P.info);
+  return 0;
+#undef TRY
+}
