@@ -118,11 +118,19 @@ __device__ inline void wg_gemm(const WG &w, int M, int N, int K, MatV A, MatV B,
     }
     const int ai = i0 + li;
     const bool aok = ai < M, bok = col < N;
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      const int k = k0 + lk;
-      const double a = (aok && k < K) ? sgn * A(ai, k) : 0.0;
-      const double b = (bok && k < K) ? B(k, col) : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    // (the operands of four k-steps are requested together: one LDS / L2 round trip per 16 columns of A, not four)
+    for (int k0 = 0; k0 < K; k0 += 16) {
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + 4 * q + lk;
+        a[q] = (aok && k < K) ? sgn * A(ai, k) : 0.0;
+        b[q] = (bok && k < K) ? B(k, col) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (k0 + 4 * q < K)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -951,50 +959,76 @@ __device__ inline void wave_bk_solve_mfma(const double *a, const double *subdiag
 // (1x1 / 2x2) D^{-1} step exactly as bunchkaufman.hpp:451-518; the stored form keeps L(k+1, k) = 0 inside a 2x2
 // pivot, so the blocks need not respect pivot boundaries.  Sums are accumulated four products at a time (MFMA
 // order), not in the reference's dot-product order: equal to rounding.
-template <int MODE, int NB>
-__device__ __forceinline__ void ldl_block_update(const WG &w, const double *a, int lda, double *x, int xrs, int xcs,
-                                                 int ncols, int row0, int M, int p, int nb, bool transposed) {
+template <int MODE, int NB, bool COLX>
+__device__ __forceinline__ void ldl_block_update(const WG &w, const double *a, int lda, double *x, int xld, int ncols,
+                                                 int row0, int M, int p, int nb, bool transposed) {
   // X(row0 + i, :) -= sum_k Lop(i, k) X(p + k, :),  Lop(i, k) = L(row0 + i, p + k)  [ L(p + k, row0 + i) transposed ]
+  // X(i, c) at x[i + c xld] (COLX) or x[i xld + c].  A wave owns a 16-column strip of X (its NB rows of the
+  // finished block are fetched ONCE) and walks down the tile rows; with fewer strips than waves the tile rows are
+  // dealt out among the waves of a strip.  Every load is unconditional, from a clamped address: a branch per load
+  // would serialise the round trips.
   if (M <= 0)
     return;
-  const int tN = (ncols + 15) >> 4, nt = ((M + 15) >> 4) * tN;
+  const int tN = (ncols + 15) >> 4, tM = (M + 15) >> 4;
   const int li = w.lane & 15, lk = w.lane >> 4;
-  for (int t = w.wave; t < nt; t += w.nwaves) {
-    const int i0 = (t / tN) << 4, col = ((t % tN) << 4) + li;
+  int share = 1, strip0 = w.wave, part = 0; // waves per strip, first strip, this wave's part of the tile rows
+  if (tN < w.nwaves) {
+    share = w.nwaves / tN;
+    part = 0;
+    while (strip0 >= tN) {
+      strip0 -= tN;
+      ++part;
+    }
+    if (part >= share)
+      return;
+  }
+  const int sstep = tN < w.nwaves ? tN : w.nwaves;
+  for (int tj = strip0; tj < tN; tj += sstep) {
+    const int col = (tj << 4) + li;
     const bool cok = col < ncols;
-    double4_t acc;
+    const int colc = cok ? col : ncols - 1;
+    double *xc = COLX ? x + colc * xld : x + colc; // this lane's column
+    double bv[NB / 4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = i0 + lk + 4 * r;
-      acc[r] = (row < M && cok) ? x[(row0 + row) * xrs + col * xcs] : 0.0;
+    for (int q = 0; q < NB / 4; ++q) {
+      const int k = 4 * q + lk, kc = k < nb ? k : nb - 1;
+      const double v = COLX ? xc[p + kc] : xc[(p + kc) * xld];
+      bv[q] = (cok && k < nb) ? v : 0.0;
     }
-    const int ai = i0 + li;
+    for (int ti = part; ti < tM; ti += share) {
+      const int i0 = ti << 4;
+      double4_t acc;
+      int ra[4];
 #pragma unroll
-    for (int k0 = 0; k0 < NB; k0 += 4) {
-      const int k = k0 + lk;
-      double av = 0.0, bv = 0.0;
-      if (k < nb) {
-        if (ai < M)
-          av = -(transposed ? a[bk_idx<MODE>(p + k, row0 + ai, lda)] : a[bk_idx<MODE>(row0 + ai, p + k, lda)]);
-        if (cok)
-          bv = x[(p + k) * xrs + col * xcs];
+      for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r;
+        ra[r] = COLX ? row0 + (row < M ? row : M - 1) : (row0 + (row < M ? row : M - 1)) * xld;
+        acc[r] = xc[ra[r]];
       }
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
+      const int ai = i0 + li, aic = ai < M ? ai : M - 1;
+      double av[NB / 4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = i0 + lk + 4 * r;
-      if (row < M && cok)
-        x[(row0 + row) * xrs + col * xcs] = acc[r];
+      for (int q = 0; q < NB / 4; ++q) {
+        const int k = 4 * q + lk, kc = k < nb ? k : nb - 1;
+        const double l = transposed ? a[bk_idx<MODE>(p + kc, row0 + aic, lda)] : a[bk_idx<MODE>(row0 + aic, p + kc, lda)];
+        av[q] = (ai < M && k < nb) ? -l : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < NB / 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (i0 + lk + 4 * r < M && cok)
+          xc[ra[r]] = acc[r];
     }
   }
 }
 
-template <int MODE, int NB = 8>
-__device__ inline void wg_bk_solve_mfma(const WG &w, int n, const double *a, int lda, const double *subdiag,
-                                        const int *piv, double *x, int xrs, int xcs, int ncols) {
+template <int MODE, int NB, bool COLX>
+__device__ inline void wg_bk_solve_mfma_impl(const WG &w, int n, const double *a, int lda, const double *subdiag,
+                                             const int *piv, double *x, int xld, int ncols) {
 #define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
-#define GXC(i, c) x[(c) * xcs + (i) * xrs]
+#define GXC(i, c) x[COLX ? (c) * xld + (i) : (c) + (i) * xld]
   wg_bar(w);
   bool moved = false; // any interchange or 2x2 pivot?  (every wave looks at every entry: uniform)
   for (int k = w.lane; k < n; k += 64)
@@ -1024,24 +1058,39 @@ __device__ inline void wg_bk_solve_mfma(const WG &w, int n, const double *a, int
   }
   for (int p = 0; p < n; p += NB) { // unit-lower solve (:472)
     const int nb = n - p < NB ? n - p : NB;
-    for (int c = w.tid; c < ncols; c += w.nthr) {
-      double xv[NB];
-#pragma unroll
-      for (int r = 0; r < NB; ++r)
-        xv[r] = r < nb ? GXC(p + r, c) : 0.0;
+    if (w.tid < ncols) { // (the block of L and the rows of X are fetched before the first store: one round trip;
+      double lb[NB][NB]; //  unconditional loads from clamped addresses)
 #pragma unroll
       for (int r = 1; r < NB; ++r)
-        if (r < nb) {
+#pragma unroll
+        for (int q = 0; q < r; ++q)
+          lb[r][q] = GA(p + (r < nb ? r : 0), p + (r < nb ? q : 0)) * (r < nb ? 1.0 : 0.0);
+      for (int c = w.tid; c < ncols; c += w.nthr) {
+        double *xb = COLX ? x + c * xld + p : x + c + p * xld;
+        double xv[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+          xv[r] = COLX ? xb[r < nb ? r : 0] : xb[(r < nb ? r : 0) * xld];
+#pragma unroll
+        for (int r = 1; r < NB; ++r) {
           double s = xv[r];
 #pragma unroll
           for (int q = 0; q < r; ++q)
-            s -= GA(p + r, p + q) * xv[q];
+            s -= lb[r][q] * xv[q];
           xv[r] = s;
-          GXC(p + r, c) = s;
         }
+#pragma unroll
+        for (int r = 1; r < NB; ++r)
+          if (r < nb) {
+            if (COLX)
+              xb[r] = xv[r];
+            else
+              xb[r * xld] = xv[r];
+          }
+      }
     }
     wg_bar(w);
-    ldl_block_update<MODE, NB>(w, a, lda, x, xrs, xcs, ncols, p + nb, n - p - nb, p, nb, false);
+    ldl_block_update<MODE, NB, COLX>(w, a, lda, x, xld, ncols, p + nb, n - p - nb, p, nb, false);
     wg_bar(w);
   }
   if (pivoted) {
@@ -1060,34 +1109,53 @@ __device__ inline void wg_bk_solve_mfma(const WG &w, int n, const double *a, int
         }
       }
     }
-  } else {
-    for (int e = w.tid; e < n * ncols; e += w.nthr) {
-      const int k = e / ncols, c = e - k * ncols;
-      GXC(k, c) *= GA(k, k);
+  } else if (COLX) { // thread = row, columns one after the other: the pivot is read once, no division
+    for (int k = w.tid; k < n; k += w.nthr) {
+      const double dk = GA(k, k);
+      for (int c = 0; c < ncols; ++c)
+        x[c * xld + k] *= dk;
     }
+  } else { // thread = column
+    for (int c = w.tid; c < ncols; c += w.nthr)
+      for (int k = 0; k < n; ++k)
+        x[c + k * xld] *= GA(k, k);
   }
   wg_bar(w);
   for (int p = ((n - 1) / NB) * NB; p >= 0; p -= NB) { // unit-upper (L^T) solve (:504)
     const int nb = n - p < NB ? n - p : NB;
-    for (int c = w.tid; c < ncols; c += w.nthr) {
-      double xv[NB];
+    if (w.tid < ncols) {
+      double lb[NB][NB];
 #pragma unroll
-      for (int r = 0; r < NB; ++r)
-        xv[r] = r < nb ? GXC(p + r, c) : 0.0;
+      for (int q = 1; q < NB; ++q)
 #pragma unroll
-      for (int r = NB - 2; r >= 0; --r)
-        if (r < nb - 1) {
+        for (int r = 0; r < q; ++r)
+          lb[q][r] = GA(p + (q < nb ? q : 0), p + (q < nb ? r : 0)) * (q < nb ? 1.0 : 0.0);
+      for (int c = w.tid; c < ncols; c += w.nthr) {
+        double *xb = COLX ? x + c * xld + p : x + c + p * xld;
+        double xv[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+          xv[r] = COLX ? xb[r < nb ? r : 0] : xb[(r < nb ? r : 0) * xld];
+#pragma unroll
+        for (int r = NB - 2; r >= 0; --r) {
           double s = xv[r];
 #pragma unroll
           for (int q = r + 1; q < NB; ++q)
-            if (q < nb)
-              s -= GA(p + q, p + r) * xv[q];
+            s -= lb[q][r] * xv[q];
           xv[r] = s;
-          GXC(p + r, c) = s;
         }
+#pragma unroll
+        for (int r = 0; r < NB - 1; ++r)
+          if (r < nb - 1) {
+            if (COLX)
+              xb[r] = xv[r];
+            else
+              xb[r * xld] = xv[r];
+          }
+      }
     }
     wg_bar(w);
-    ldl_block_update<MODE, NB>(w, a, lda, x, xrs, xcs, ncols, 0, p, p, nb, true);
+    ldl_block_update<MODE, NB, COLX>(w, a, lda, x, xld, ncols, 0, p, p, nb, true);
     wg_bar(w);
   }
   if (pivoted) {
@@ -1115,6 +1183,16 @@ __device__ inline void wg_bk_solve_mfma(const WG &w, int n, const double *a, int
   }
 #undef GA
 #undef GXC
+}
+// X(i, c) at x[i xrs + c xcs]: one of the strides is 1 at every call site (column-major or row-major X); the two
+// layouts are compiled separately so that the unit stride folds into the instructions' immediate offsets
+template <int MODE, int NB = 8>
+__device__ inline void wg_bk_solve_mfma(const WG &w, int n, const double *a, int lda, const double *subdiag,
+                                        const int *piv, double *x, int xrs, int xcs, int ncols) {
+  if (xrs == 1)
+    wg_bk_solve_mfma_impl<MODE, NB, true>(w, n, a, lda, subdiag, piv, x, xcs, ncols);
+  else
+    wg_bk_solve_mfma_impl<MODE, NB, false>(w, n, a, lda, subdiag, piv, x, xrs, ncols);
 }
 
 template <int MODE = GAR_COLMAJOR>
@@ -1145,7 +1223,7 @@ __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
     wg_bk_solve_few<MODE>(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
     return;
   }
-  if (!w.wave_scope && ncols >= 16) {
+  if (!w.wave_scope && ncols >= 16 && (xrs == 1 || xcs == 1)) {
     wg_bk_solve_mfma<MODE>(w, n, a, lda, subdiag, piv, x, xrs, xcs, ncols);
     return;
   }
@@ -1222,57 +1300,102 @@ __device__ inline void wg_bk_solve(const WG &w, int n, const double *a, int lda,
 
 // ---------------------------------------------------------------------------------------------------------------
 // DEFINITE matrices (all pivots of one sign: Vxx > 0, Rhat > 0, the alternating-sign Schur complements of the
-// condensed leg-boundary system): blocked L D L^T WITHOUT pivoting.  A panel of 4 columns is factorised by wave 0
-// alone (lane = row: no workgroup barrier inside a panel), the trailing block takes A22 -= (L21 D) L21^T on f64
-// MFMA tiles from the whole workgroup.  Elimination of a definite matrix is backward stable without pivoting, so
-// the result agrees with Bunch-Kaufman's (which may still interchange on such a matrix) to cond * eps; the stored
-// form is Bunch-Kaufman's with piv[k] = k (unit-lower L below the diagonal, INVERSE pivots on it, subdiag = 0), so
-// wg_bk_solve and every consumer of a factorised block work unchanged.  Returns 0 when every pivot is finite,
-// nonzero and of the sign of the first one; otherwise 1 with `a` DESTROYED: the caller restores the block and
-// runs wg_bk_factor (the reference's rule).  n <= 64, column-major, wk: 4 n doubles of LDS, ctrl: >= 1 int.
+// condensed leg-boundary system): blocked L D L^T WITHOUT pivoting.  A panel of NBF columns is factorised by wave 0
+// alone IN REGISTERS (lane = row; the pivot and the multipliers of a column reach the other lanes by v_readlane:
+// no LDS round trip, no barrier inside a panel), the lower tiles of the trailing block take
+// A22 -= (L21 D) L21^T on f64 MFMA from the whole workgroup.  Elimination of a definite matrix is backward stable
+// without pivoting, so the result agrees with Bunch-Kaufman's (which may still interchange on such a matrix) to
+// cond * eps; the stored form is Bunch-Kaufman's with piv[k] = k (unit-lower L below the diagonal, INVERSE pivots
+// on it, subdiag = 0), so wg_bk_solve and every consumer of a factorised block work unchanged.  Only the lower
+// triangle is read or written.  Returns 0 when every pivot is finite, nonzero and of the sign of the first one;
+// otherwise 1 with `a` DESTROYED: the caller restores the block and runs wg_bk_factor (the reference's rule).
+// n <= 64, column-major, wk: NBF n doubles of LDS (GAR_LDL_PANEL = NBF), ctrl: >= 1 int.
+#define GAR_LDL_PANEL 8
 __device__ inline int wg_ldl_definite_factor(const WG &w, int n, double *a, int lda, double *subdiag, int *piv,
                                              double *wk, int *ctrl) {
+  constexpr int NBF = GAR_LDL_PANEL;
   if (w.tid == 0)
     ctrl[0] = 0;
   __syncthreads();
   if (n == 0)
     return 0;
   const bool positive = a[0] > 0.0;
-  for (int p = 0; p < n; p += 4) {
-    const int nb = n - p < 4 ? n - p : 4;
+  const int li = w.lane & 15, lk = w.lane >> 4;
+  for (int p = 0; p < n; p += NBF) {
+    const int nb = n - p < NBF ? n - p : NBF;
     if (w.wave == 0) {
-      const int i = p + w.lane; // this lane's row
-      bool bad = false;
-      for (int c = 0; c < nb; ++c) {
-        const int k = p + c;
-        const double d = a[k + k * lda]; // wave-uniform
-        bad |= !(fabs(d) <= 1.7e308) || d == 0.0 || ((d > 0.0) != positive);
-        const double aik = (i > k && i < n) ? a[i + k * lda] : 0.0;
-        if (i > k && i < n)
-          wk[i + c * n] = aik; // (L D)(i, k)
-        wave_sync();
-        if (i == k)
-          a[k + k * lda] = 1.0 / d;
-        if (i > k && i < n) {
-          const double lik = aik / d;
-          a[i + k * lda] = lik;
-          for (int j = c + 1; j < nb; ++j) // rest of the panel: a(i, p+j) -= l(i, k) (L D)(p+j, k), rows i >= p+j
-            if (i >= p + j)
-              a[i + (p + j) * lda] -= lik * wk[(p + j) + c * n];
-        }
-        wave_sync();
+      const int l = w.lane, i = p + l; // this lane's row
+      double v[NBF], ld[NBF];
+      const int ic = i < n ? i : n - 1; // (unconditional loads from clamped addresses; only the lower triangle counts)
+#pragma unroll
+      for (int c = 0; c < NBF; ++c) {
+        const double t = a[ic + (p + (c < nb ? c : 0)) * lda];
+        v[c] = (c < nb && l >= c && i < n) ? t : 0.0;
       }
-      if (bad && w.lane == 0)
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < NBF; ++c)
+        if (c < nb) {
+          const double d = bk_bcast(v[c], c);
+          bad |= !(fabs(d) <= 1.7e308) || d == 0.0 || ((d > 0.0) != positive);
+          const double rd = 1.0 / d;
+          ld[c] = l > c ? v[c] : 0.0; // (L D)(i, k)
+          const double lik = ld[c] * rd;
+          v[c] = l == c ? rd : (l > c ? lik : v[c]);
+#pragma unroll
+          for (int j = c + 1; j < NBF; ++j)
+            if (j < nb) { // rest of the panel: a(i, p+j) -= l(i, k) (L D)(p+j, k), rows i >= p+j
+              const double ldj = bk_bcast(ld[c], j);
+              if (l >= j)
+                v[j] -= lik * ldj;
+            }
+        }
+#pragma unroll
+      for (int c = 0; c < NBF; ++c)
+        if (c < nb && l >= c && i < n) {
+          a[i + (p + c) * lda] = v[c];
+          if (l >= nb)
+            wk[i + c * n] = ld[c];
+        }
+      if (bad && l == 0)
         ctrl[0] = 1;
     }
     __syncthreads();
     if (ctrl[0])
       return 1;
-    const int m = n - p - nb; // trailing block
+    const int m = n - p - nb, r0 = p + nb; // trailing block: rows / columns r0 ..
     if (m > 0) {
-      const MatV LD = colmajor(wk + (p + nb), n), L21 = colmajor(a + (p + nb) + p * lda, lda);
-      const MatV A22 = colmajor(a + (p + nb) + (p + nb) * lda, lda);
-      wg_gemm(w, m, m, nb, LD, L21.T(), A22, A22, -1.0);
+      const int tM = (m + 15) >> 4, nt = tM * (tM + 1) / 2;
+      for (int t = w.wave; t < nt; t += w.nwaves) {
+        int ti = 0, rest = t; // lower tiles, row by row: (0,0) (1,0) (1,1) (2,0) ...
+        while (rest > ti) {
+          rest -= ti + 1;
+          ++ti;
+        }
+        const int i0 = ti << 4, col = (rest << 4) + li, ai = i0 + li;
+        double4_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + lk + 4 * r;
+          acc[r] = (row < m && col < m) ? a[(r0 + row) + (r0 + col) * lda] : 0.0;
+        }
+        double av[NBF / 4], bv[NBF / 4];
+#pragma unroll
+        for (int q = 0; q < NBF / 4; ++q) {
+          const int k = 4 * q + lk;
+          av[q] = (ai < m && k < nb) ? -wk[(r0 + ai) + k * n] : 0.0;          // -(L D)(row, k)
+          bv[q] = (col < m && k < nb) ? a[(r0 + col) + (p + k) * lda] : 0.0;  // L(col, k)
+        }
+#pragma unroll
+        for (int q = 0; q < NBF / 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + lk + 4 * r;
+          if (row < m && col < m && row >= col)
+            a[(r0 + row) + (r0 + col) * lda] = acc[r];
+        }
+      }
       __syncthreads();
     }
   }

@@ -831,7 +831,7 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
   double *info = err + 2 * nblk * nxb;
   double *sol = P.csol + (long long)b * nblk * nxb;
   const double *prob = P.prob + (long long)b * P.prob_stride;
-  double *blk = sm, *ublk = sm + bs, *lsub = sm + 2 * bs;
+  double *blk = sm, *ublk = sm + bs, *lsub = sm + 2 * bs + nxb; // ublk: n x (r + 1)
   int *lpiv = (int *)(lsub + nxb + (nxb & 1));
   int *ctrl = lpiv + nxb + 8;
   // block i has dimension dim(i): nc0 for i == 0, else nxb  (rhsDims_, :68-73)
@@ -913,20 +913,25 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
       fsub[ib * nxb + e] = lsub[e];
       fpiv[ib * nxb + e] = lpiv[e];
     }
-    wg_bk_solve(w, n, blk, n, lsub, lpiv, sol + ib * nxb, 1, 0, 1);
-    if (i < 0)
+    if (i < 0) {
+      wg_bk_solve(w, n, blk, n, lsub, lpiv, sol + ib * nxb, 1, 0, 1);
       break;
+    }
     const int r = DIM(i);
     MatV Bi = colmajor(super + (long long)i * bs, r); // r x n
-    // rhs[i] -= B rhs[i+1]
-    wg_gemv(w, r, n, Bi, sol + ib * nxb, 1, sol + i * nxb, 1, sol + i * nxb, 1, -1.0);
-    // U[i] <- D^{-1} U[i]  (n x r), through LDS
+    // [U[i] | rhs[i+1]] <- D^{-1} [U[i] | rhs[i+1]]  (n x (r + 1)): one blocked substitution for both, through LDS
     for (int e = w.tid; e < n * r; e += w.nthr)
       ublk[e] = U[(long long)i * bs + e];
+    for (int e = w.tid; e < n; e += w.nthr)
+      ublk[n * r + e] = sol[ib * nxb + e];
     __syncthreads();
-    wg_bk_solve(w, n, blk, n, lsub, lpiv, ublk, 1, n, r);
+    wg_bk_solve(w, n, blk, n, lsub, lpiv, ublk, 1, n, r + 1);
     for (int e = w.tid; e < n * r; e += w.nthr)
       U[(long long)i * bs + e] = ublk[e];
+    for (int e = w.tid; e < n; e += w.nthr)
+      sol[ib * nxb + e] = ublk[n * r + e];
+    // rhs[i] -= B rhs[i+1]
+    wg_gemv(w, r, n, Bi, ublk + n * r, 1, sol + i * nxb, 1, sol + i * nxb, 1, -1.0);
     // facD[i] -= B U[i]
     wg_gemm(w, r, r, n, Bi, colmajor(ublk, n), colmajor(facD + (long long)i * bs, r),
             colmajor(facD + (long long)i * bs, r), -1.0);

@@ -1408,7 +1408,7 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipMalloc((void **)&s->d_csol, sizeof(double) * (size_t)nblk * s->nxb * B));
     s->cscratch_doubles = (int64_t)(4 * nblk * bs + 4 * (size_t)nblk * s->nxb + 4);
     HIP_TRY(hipMalloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
-    s->cond_lds_doubles = (int)(2 * bs + s->nxb + 2 + (s->nxb + 16) / 2 + 2);
+    s->cond_lds_doubles = (int)(2 * bs + 2 * s->nxb + 2 + (s->nxb + 16) / 2 + 2);
   }
   if (s->seg_bwd_kernel) {
     const gar_hip_solver *f = s->flay;

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) gar_leg_param_generic(LegParamParams P) {
       // (Rhat > 0 on a well-posed stage: blocked elimination without pivoting, workspace in VB, a copy of Rhat
       // parked in Kt for the stage that is not -- that one goes through Bunch-Kaufman as in the reference)
       int indefinite = 1;
-      if (nu >= 8 && nu <= 64 && 4 * nu <= nx2 * nu && nu * nu <= nu * nth) {
+      if (nu >= 8 && nu <= 64 && GAR_LDL_PANEL * nu <= nx2 * nu && nu * nu <= nu * nth) {
         for (int e = w.tid; e < nu * nu; e += w.nthr)
           Kt[e] = Rh[e];
         __syncthreads();

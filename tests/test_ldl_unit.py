@@ -18,16 +18,16 @@ def load_emu():
     return ctypes.CDLL(os.path.join(HERE, "emu", "_build", "libgar_ldl_unit_emu.so"))
 
 
-def run_unit(lib, A, X, definite_first):
+def run_unit(lib, A, X, definite_first, x_rowmajor=False):
     n, nc = A.shape[0], X.shape[1]
     a = np.asfortranarray(A, dtype=np.float64).copy(order="F")
-    x = np.asfortranarray(X, dtype=np.float64).copy(order="F")
+    x = np.array(X, dtype=np.float64, order="C" if x_rowmajor else "F")
     sub = np.zeros(n)
     piv = np.zeros(n, dtype=np.int32)
-    info = np.zeros(2, dtype=np.int32)
+    info = np.zeros(4, dtype=np.int32)
     dp = ctypes.POINTER(ctypes.c_double)
     ip = ctypes.POINTER(ctypes.c_int)
-    rc = lib.gar_ldl_unit(n, nc, int(definite_first), a.ctypes.data_as(dp), x.ctypes.data_as(dp),
+    rc = lib.gar_ldl_unit(n, nc, int(definite_first), int(x_rowmajor), a.ctypes.data_as(dp), x.ctypes.data_as(dp),
                           sub.ctypes.data_as(dp), piv.ctypes.data_as(ip), info.ctypes.data_as(ip))
     assert rc == 0
     return a, x, sub, piv, info
@@ -55,7 +55,7 @@ def test_definite_factor_matches_bunch_kaufman(n, ncols, sign, lib=None):
     A = sign * spd(rng, n)
     X0 = rng.standard_normal((n, ncols))
     a1, x1, sub1, piv1, info1 = run_unit(lib, A, X0, True)
-    a2, x2, sub2, piv2, info2 = run_unit(lib, A, X0, False)
+    a2, x2, sub2, piv2, info2 = run_unit(lib, A, X0, False, x_rowmajor=True)   # (and the other layout of X)
     assert info1[0] == 0 and info1[1] == -1      # definite path taken, Bunch-Kaufman not run
     assert info2[0] == -1 and info2[1] == 0
     assert (piv1 == np.arange(n)).all() and (sub1 == 0).all()
@@ -98,7 +98,8 @@ def test_blocked_substitution_with_interchanges_and_2x2_pivots(n, ncols, lib=Non
     A[n - m:, n - m:] = -1e-3 * np.eye(m)
     X0 = rng.standard_normal((n, ncols))
     a, x, sub, piv, info = run_unit(lib, A, X0, False)
-    assert info[1] == 0
+    xr = run_unit(lib, A, X0, False, x_rowmajor=True)[1]
+    assert info[1] == 0 and np.abs(xr - x).max() <= 1e-12 * np.abs(x).max()
     assert (piv < 0).any() and (piv[piv >= 0] != np.arange(n)[piv >= 0]).any()
     ref = np.linalg.solve(A, X0)
     assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max()
@@ -122,3 +123,24 @@ def test_ldl_building_blocks_on_the_gpu():
         test_wrong_sign_pivot_sends_the_block_to_bunch_kaufman(n, ncols, lib=lib)
     for n, ncols in [(16, 16), (44, 45), (56, 57), (116, 37)]:
         test_blocked_substitution_with_interchanges_and_2x2_pivots(n, ncols, lib=lib)
+
+
+@pytest.mark.gpu
+def test_ldl_building_block_cycles_are_reported():
+    """not a pass/fail on speed: prints the cycle counts DESIGN.md quotes (pytest -s)"""
+    lib = load_gpu()
+    rng = np.random.default_rng(1)
+    for n, ncols in [(24, 56), (44, 45), (56, 56), (56, 1), (116, 37)]:
+        A = spd(rng, n) if n <= 64 else None
+        if A is None:
+            A = spd(rng, n)
+        X0 = rng.standard_normal((n, ncols))
+        rows = []
+        for definite in ((True, False) if n <= 64 else (False,)):
+            best = None
+            for _ in range(3):
+                info = run_unit(lib, A, X0, definite)[4]
+                best = info[2:4] if best is None else np.minimum(best, info[2:4])
+            rows.append(("definite" if definite else "bunch-kaufman", int(best[0]), int(best[1])))
+        print(f"n={n} ncols={ncols}: " + "; ".join(f"{k}: factor {f} solve {s_} cycles" for k, f, s_ in rows))
+        assert all(f > 0 for _, f, _ in rows)

@@ -9,15 +9,16 @@ struct UnitParams {
   double *X;  // n x ncols column-major: in the right-hand sides, out the solution
   double *sub;
   int *piv;
-  int *info;  // [0] what the definite factorisation returned (-1: not run), [1] what Bunch-Kaufman returned (-1: not run)
-  int n, ncols, definite_first;
+  int *info;  // [0] what the definite factorisation returned (-1: not run), [1] what Bunch-Kaufman returned (-1: not run),
+              // [2] cycles of the factorisation, [3] cycles of the solve (0 on the emulator)
+  int n, ncols, definite_first, x_rowmajor; // X: n x ncols column-major, or row-major when x_rowmajor
 };
 
 __global__ void __launch_bounds__(256) ldl_unit_kernel(UnitParams P) {
   using namespace gar;
   const WG w = wg_self();
   const int n = P.n, nc = P.ncols;
-  double *a = gar_smem, *x = a + ((n * n + 1) & ~1), *wk = x + ((n * nc + 1) & ~1), *sub = wk + 4 * n + 2;
+  double *a = gar_smem, *x = a + ((n * n + 1) & ~1), *wk = x + ((n * nc + 1) & ~1), *sub = wk + GAR_LDL_PANEL * n + 2;
   int *piv = (int *)(sub + n + (n & 1)), *ctrl = piv + n + 8;
   for (int e = w.tid; e < n * n; e += w.nthr)
     a[e] = P.A[e];
@@ -25,6 +26,7 @@ __global__ void __launch_bounds__(256) ldl_unit_kernel(UnitParams P) {
     x[e] = P.X[e];
   __syncthreads();
   int r_def = -1, r_bk = -1;
+  const long long c0 = clock64();
   if (P.definite_first) {
     r_def = wg_ldl_definite_factor(w, n, a, n, sub, piv, wk, ctrl);
     if (r_def) {
@@ -35,7 +37,12 @@ __global__ void __launch_bounds__(256) ldl_unit_kernel(UnitParams P) {
   }
   if (r_def != 0)
     r_bk = wg_bk_factor(w, n, a, n, sub, piv, ctrl);
-  wg_bk_solve(w, n, a, n, sub, piv, x, 1, n, nc);
+  const long long c1 = clock64();
+  if (P.x_rowmajor)
+    wg_bk_solve(w, n, a, n, sub, piv, x, nc, 1, nc);
+  else
+    wg_bk_solve(w, n, a, n, sub, piv, x, 1, n, nc);
+  const long long c2 = clock64();
   for (int e = w.tid; e < n * n; e += w.nthr)
     P.A[e] = a[e];
   for (int e = w.tid; e < n * nc; e += w.nthr)
@@ -47,17 +54,20 @@ __global__ void __launch_bounds__(256) ldl_unit_kernel(UnitParams P) {
   if (w.tid == 0) {
     P.info[0] = r_def;
     P.info[1] = r_bk;
+    P.info[2] = (int)(c1 - c0);
+    P.info[3] = (int)(c2 - c1);
   }
 }
 } // namespace
 
 // host pointers in, host pointers out; returns 0 or a HIP error code
-extern "C" int gar_ldl_unit(int n, int ncols, int definite_first, double *A, double *X, double *sub, int *piv,
+extern "C" int gar_ldl_unit(int n, int ncols, int definite_first, int x_rowmajor, double *A, double *X, double *sub, int *piv,
                             int *info) {
   UnitParams P{};
   P.n = n;
   P.ncols = ncols;
   P.definite_first = definite_first;
+  P.x_rowmajor = x_rowmajor;
   const size_t bA = sizeof(double) * n * n, bX = sizeof(double) * n * ncols;
 #define TRY(e)                                                                                                         \
   do {                                                                                                                 \
@@ -69,10 +79,10 @@ extern "C" int gar_ldl_unit(int n, int ncols, int definite_first, double *A, dou
   TRY(hipMalloc((void **)&P.X, bX ? bX : 8));
   TRY(hipMalloc((void **)&P.sub, sizeof(double) * n));
   TRY(hipMalloc((void **)&P.piv, sizeof(int) * n));
-  TRY(hipMalloc((void **)&P.info, sizeof(int) * 2));
+  TRY(hipMalloc((void **)&P.info, sizeof(int) * 4));
   TRY(hipMemcpy(P.A, A, bA, hipMemcpyHostToDevice));
   TRY(hipMemcpy(P.X, X, bX, hipMemcpyHostToDevice));
-  const size_t lds = sizeof(double) * (size_t)(n * n + n * ncols + 6 * n + 64) + sizeof(int) * (size_t)(n + 32);
+  const size_t lds = sizeof(double) * (size_t)(n * n + n * ncols + (GAR_LDL_PANEL + 2) * n + 64) + sizeof(int) * (size_t)(n + 32);
   TRY(hipFuncSetAttribute((const void *)ldl_unit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(ldl_unit_kernel, dim3(1), dim3(256), lds, (hipStream_t) nullptr, P);
   TRY(hipGetLastError());
@@ -81,7 +91,7 @@ extern "C" int gar_ldl_unit(int n, int ncols, int definite_first, double *A, dou
   TRY(hipMemcpy(X, P.X, bX, hipMemcpyDeviceToHost));
   TRY(hipMemcpy(sub, P.sub, sizeof(double) * n, hipMemcpyDeviceToHost));
   TRY(hipMemcpy(piv, P.piv, sizeof(int) * n, hipMemcpyDeviceToHost));
-  TRY(hipMemcpy(info, P.info, sizeof(int) * 2, hipMemcpyDeviceToHost));
+  TRY(hipMemcpy(info, P.info, sizeof(int) * 4, hipMemcpyDeviceToHost));
   hipFree(P.A);
   hipFree(P.X);
   hipFree(P.sub);
