@@ -1060,11 +1060,19 @@ __device__ inline void wg_bk_solve_mfma_impl(const WG &w, int n, const double *a
     const int nb = n - p < NB ? n - p : NB;
     if (w.tid < ncols) { // (the block of L and the rows of X are fetched before the first store: one round trip;
       double lb[NB][NB]; //  unconditional loads from clamped addresses)
+      if (nb == NB) {
 #pragma unroll
-      for (int r = 1; r < NB; ++r)
+        for (int r = 1; r < NB; ++r)
 #pragma unroll
-        for (int q = 0; q < r; ++q)
-          lb[r][q] = GA(p + (r < nb ? r : 0), p + (r < nb ? q : 0)) * (r < nb ? 1.0 : 0.0);
+          for (int q = 0; q < r; ++q)
+            lb[r][q] = GA(p + r, p + q);
+      } else {
+#pragma unroll
+        for (int r = 1; r < NB; ++r)
+#pragma unroll
+          for (int q = 0; q < r; ++q)
+            lb[r][q] = GA(p + (r < nb ? r : 0), p + (r < nb ? q : 0)) * (r < nb ? 1.0 : 0.0);
+      }
       for (int c = w.tid; c < ncols; c += w.nthr) {
         double *xb = COLX ? x + c * xld + p : x + c + p * xld;
         double xv[NB];
@@ -1125,11 +1133,19 @@ __device__ inline void wg_bk_solve_mfma_impl(const WG &w, int n, const double *a
     const int nb = n - p < NB ? n - p : NB;
     if (w.tid < ncols) {
       double lb[NB][NB];
+      if (nb == NB) {
 #pragma unroll
-      for (int q = 1; q < NB; ++q)
+        for (int q = 1; q < NB; ++q)
 #pragma unroll
-        for (int r = 0; r < q; ++r)
-          lb[q][r] = GA(p + (q < nb ? q : 0), p + (q < nb ? r : 0)) * (q < nb ? 1.0 : 0.0);
+          for (int r = 0; r < q; ++r)
+            lb[q][r] = GA(p + q, p + r);
+      } else {
+#pragma unroll
+        for (int q = 1; q < NB; ++q)
+#pragma unroll
+          for (int r = 0; r < q; ++r)
+            lb[q][r] = GA(p + (q < nb ? q : 0), p + (q < nb ? r : 0)) * (q < nb ? 1.0 : 0.0);
+      }
       for (int c = w.tid; c < ncols; c += w.nthr) {
         double *xb = COLX ? x + c * xld + p : x + c + p * xld;
         double xv[NB];
@@ -1186,7 +1202,10 @@ __device__ inline void wg_bk_solve_mfma_impl(const WG &w, int n, const double *a
 }
 // X(i, c) at x[i xrs + c xcs]: one of the strides is 1 at every call site (column-major or row-major X); the two
 // layouts are compiled separately so that the unit stride folds into the instructions' immediate offsets
-template <int MODE, int NB = 8>
+#ifndef GAR_SOLVE_NB
+#define GAR_SOLVE_NB 8
+#endif
+template <int MODE, int NB = GAR_SOLVE_NB>
 __device__ inline void wg_bk_solve_mfma(const WG &w, int n, const double *a, int lda, const double *subdiag,
                                         const int *piv, double *x, int xrs, int xcs, int ncols) {
   if (xrs == 1)

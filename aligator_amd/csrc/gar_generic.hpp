@@ -809,7 +809,24 @@ __device__ __forceinline__ const double *cond_tuple(const CondensedParams &P, in
 }
 
 // LDS: blk[nxb*nxb] ublk[nxb*nxb] sub[nxb] piv/ctrl
+// (debug build -DGAR_CTRACE: cycles per phase of workgroup 0, read with gar_hip_debug_ctrace -- scripts/ctrace_condensed.py)
+#ifdef GAR_CTRACE
+__device__ long long g_ctrace[16];
+#define CT(id)                                                                                                         \
+  {                                                                                                                    \
+    __syncthreads();                                                                                                   \
+    const long long now_ = clock64();                                                                                  \
+    if (w.tid == 0 && blockIdx.x == 0)                                                                                 \
+      g_ctrace[id] += now_ - tprev;                                                                                    \
+    tprev = now_;                                                                                                      \
+  }
+#else
+#define CT(id)
+#endif
 __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) {
+#ifdef GAR_CTRACE
+  long long tprev = clock64();
+#endif
   const WG w = wg_self();
   double *sm = gar_smem;
   const int b = (int)blockIdx.x;
@@ -831,21 +848,21 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
   double *info = err + 2 * nblk * nxb;
   double *sol = P.csol + (long long)b * nblk * nxb;
   const double *prob = P.prob + (long long)b * P.prob_stride;
-  double *blk = sm, *ublk = sm + bs, *lsub = sm + 2 * bs + nxb; // ublk: n x (r + 1)
+  // LDS: blk (n x (n + 1)), ublk (n x (r + 1); >= 9 nxb doubles for the slices of the back-substitution), bsup (r x n)
+  double *blk = sm, *ublk = blk + bs + nxb, *bsup = ublk + bs + nxb, *lsub = bsup + bs;
   int *lpiv = (int *)(lsub + nxb + (nxb & 1));
   int *ctrl = lpiv + nxb + 8;
   // block i has dimension dim(i): nc0 for i == 0, else nxb  (rhsDims_, :68-73)
 #define DIM(i) ((i) == 0 ? P.nc0 : nxb)
 
-  // ---- assembleCondensedSystem (parallel-solver.hxx:85-129), blocks stored
-  // column-major with leading dimension DIM(row block)
-  for (int e = w.tid; e < nblk * bs; e += w.nthr) {
-    diag[e] = 0.0;
-    super[e] = 0.0;
-  }
-  __syncthreads();
+  CT(0)
+  // ---- assembleCondensedSystem (parallel-solver.hxx:85-129), blocks stored column-major with leading dimension
+  // DIM(row block).  Every block that is read later is written exactly once (diag, super and rhs stay as they are:
+  // the refinement's residual is taken against them); facD and U are produced by the elimination itself.
   {
     const int nc0 = P.nc0, nx0 = P.nx0;
+    for (int e = w.tid; e < nc0 * nc0; e += w.nthr)
+      diag[e] = 0.0;
     for (int e = w.tid; e < nc0 * nx0; e += w.nthr) // super[0] = G0 (nc0 x nx0)
       super[e] = prob[P.G0_off + e];
     for (int e = w.tid; e < nc0; e += w.nthr)
@@ -853,46 +870,45 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
   }
   for (int leg = 0; leg < P.num_legs; ++leg) {
     const double *tup = cond_tuple(P, b, leg);
-    // diag[2 leg + 1] = Vxx(leg) ; rhs[2 leg + 1] = -vx(leg)
-    for (int e = w.tid; e < bs; e += w.nthr)
-      diag[(long long)(2 * leg + 1) * bs + e] = tup[e];
-    for (int e = w.tid; e < nxb; e += w.nthr)
-      rhs[(2 * leg + 1) * nxb + e] = -tup[3 * bs + e];
-    if (leg + 1 < P.num_legs) {
-      // super[2 leg + 1] = Vxt(leg); diag[2 leg + 2] = Vtt(leg); super[2 leg + 2] = -I
-      for (int e = w.tid; e < bs; e += w.nthr) {
-        super[(long long)(2 * leg + 1) * bs + e] = tup[bs + e];
-        diag[(long long)(2 * leg + 2) * bs + e] = tup[2 * bs + e];
-        const int j = e / nxb, i = e - j * nxb;
-        super[(long long)(2 * leg + 2) * bs + e] = (i == j) ? -1.0 : 0.0;
+    const bool inner = leg + 1 < P.num_legs;
+    double *d1 = diag + (long long)(2 * leg + 1) * bs, *s1 = super + (long long)(2 * leg + 1) * bs;
+    // diag[2 leg + 1] = Vxx(leg); super[2 leg + 1] = Vxt(leg); diag[2 leg + 2] = Vtt(leg); super[2 leg + 2] = -I is
+    // never stored: the elimination, the residual and the refinement step apply it as what it is
+#pragma unroll 4
+    for (int e = w.tid; e < bs; e += w.nthr) {
+      d1[e] = tup[e];
+      if (inner) {
+        s1[e] = tup[bs + e];
+        d1[bs + e] = tup[2 * bs + e];
       }
-      for (int e = w.tid; e < nxb; e += w.nthr)
+    }
+    for (int e = w.tid; e < nxb; e += w.nthr) { // rhs[2 leg + 1] = -vx(leg), rhs[2 leg + 2] = -vt(leg)
+      rhs[(2 * leg + 1) * nxb + e] = -tup[3 * bs + e];
+      if (inner)
         rhs[(2 * leg + 2) * nxb + e] = -tup[3 * bs + nxb + e];
     }
   }
   __syncthreads();
-  for (int e = w.tid; e < nblk * nxb; e += w.nthr)
-    sol[e] = rhs[e];
-  for (int e = w.tid; e < nblk * bs; e += w.nthr)
-    facD[e] = diag[e];
-  // U[i] = sub[i] = super[i]^T : DIM(i+1) x DIM(i)
-  for (int i = 0; i < N; ++i) {
-    const int r = DIM(i), c = DIM(i + 1);
-    for (int e = w.tid; e < r * c; e += w.nthr) {
-      const int bb = e / r, a = e - bb * r; // super(a, bb)
-      U[(long long)i * bs + a * c + bb] = super[(long long)i * bs + e];
-    }
-  }
-  __syncthreads();
 
+  CT(1)
   int failed = 0;
-  // ---- symmetricBlockTridiagSolve, up-looking (block-tridiagonal.hpp:82-138)
+  // ---- symmetricBlockTridiagSolve, up-looking (block-tridiagonal.hpp:82-138).  The block being eliminated lives
+  // in LDS together with its right-hand side: blk = [facD[ib] | rhs[ib]] (n x (n + 1)); eliminating it leaves
+  // [facD[i] | rhs[i]] = [diag[i] | rhs[i]] - super[i] D^{-1} [super[i]^T | rhs[ib]] in the same place.
+  {
+    const int n = DIM(N);
+    for (int e = w.tid; e < n * n; e += w.nthr)
+      blk[e] = diag[(long long)N * bs + e];
+    for (int e = w.tid; e < n; e += w.nthr)
+      blk[n * n + e] = rhs[N * nxb + e];
+    __syncthreads();
+  }
   for (int i = N - 1; i >= -1; --i) {
     const int ib = i + 1, n = DIM(ib);
-    // factor facD[ib] in LDS
+    // the unfactorised block, for the factorisation that has to start over
     for (int e = w.tid; e < n * n; e += w.nthr)
-      blk[e] = facD[(long long)ib * bs + e];
-    __syncthreads();
+      facD[(long long)ib * bs + e] = blk[e];
+    CT(2)
     // the Schur complements of this elimination are definite, of alternating sign (Vxx - Vxt S^-1 Vxt^T > 0,
     // Vtt - S^-1 < 0, ...): blocked elimination without pivoting (ublk is free here: its panel workspace); a
     // pivot of the wrong sign or a zero sends the block to the reference's Bunch-Kaufman
@@ -907,6 +923,7 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
     }
     if (indefinite)
       failed |= wg_bk_factor(w, n, blk, n, lsub, lpiv, ctrl);
+    CT(3)
     for (int e = w.tid; e < n * n; e += w.nthr)
       facD[(long long)ib * bs + e] = blk[e];
     for (int e = w.tid; e < n; e += w.nthr) {
@@ -914,73 +931,147 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
       fpiv[ib * nxb + e] = lpiv[e];
     }
     if (i < 0) {
-      wg_bk_solve(w, n, blk, n, lsub, lpiv, sol + ib * nxb, 1, 0, 1);
+      wg_bk_solve(w, n, blk, n, lsub, lpiv, blk + n * n, 1, 0, 1);
+      for (int e = w.tid; e < n; e += w.nthr)
+        sol[e] = blk[n * n + e];
       break;
     }
     const int r = DIM(i);
-    MatV Bi = colmajor(super + (long long)i * bs, r); // r x n
-    // [U[i] | rhs[i+1]] <- D^{-1} [U[i] | rhs[i+1]]  (n x (r + 1)): one blocked substitution for both, through LDS
-    for (int e = w.tid; e < n * r; e += w.nthr)
-      ublk[e] = U[(long long)i * bs + e];
+    const bool minus_identity = i >= 2 && (i & 1) == 0; // super[2 leg + 2] = -I
+    const double *Bg = super + (long long)i * bs;        // r x n
+    // ublk = [super[i]^T | rhs[ib]]  (n x (r + 1)), then <- D^{-1} ublk: one blocked substitution for both
+    if (minus_identity) {
+      for (int e = w.tid; e < n * r; e += w.nthr)
+        ublk[e] = (e / n == e % n) ? -1.0 : 0.0;
+    } else {
+      for (int e = w.tid; e < n * r; e += w.nthr) { // (read along the columns of super: coalesced)
+        const int a = e % r, bb = e / r;            // super(a, bb)
+        const double v = Bg[e];
+        ublk[a * n + bb] = v;
+        bsup[e] = v;
+      }
+    }
     for (int e = w.tid; e < n; e += w.nthr)
-      ublk[n * r + e] = sol[ib * nxb + e];
+      ublk[n * r + e] = blk[n * n + e];
     __syncthreads();
+    CT(4)
     wg_bk_solve(w, n, blk, n, lsub, lpiv, ublk, 1, n, r + 1);
+    CT(5)
     for (int e = w.tid; e < n * r; e += w.nthr)
       U[(long long)i * bs + e] = ublk[e];
     for (int e = w.tid; e < n; e += w.nthr)
       sol[ib * nxb + e] = ublk[n * r + e];
-    // rhs[i] -= B rhs[i+1]
-    wg_gemv(w, r, n, Bi, ublk + n * r, 1, sol + i * nxb, 1, sol + i * nxb, 1, -1.0);
-    // facD[i] -= B U[i]
-    wg_gemm(w, r, r, n, Bi, colmajor(ublk, n), colmajor(facD + (long long)i * bs, r),
-            colmajor(facD + (long long)i * bs, r), -1.0);
+    CT(6)
+    // [facD[i] | rhs[i]] = [diag[i] | rhs[i]] - super[i] ublk, into blk (r x (r + 1))
+    if (minus_identity) { // (r == n)
+      for (int e = w.tid; e < r * r; e += w.nthr)
+        blk[e] = diag[(long long)i * bs + e] + ublk[e];
+      for (int e = w.tid; e < r; e += w.nthr)
+        blk[r * r + e] = rhs[i * nxb + e] + ublk[n * r + e];
+    } else {
+      for (int e = w.tid; e < r * r; e += w.nthr)
+        blk[e] = diag[(long long)i * bs + e];
+      for (int e = w.tid; e < r; e += w.nthr)
+        blk[r * r + e] = rhs[i * nxb + e];
+      __syncthreads();
+      CT(7)
+      wg_gemm(w, r, r + 1, n, colmajor(bsup, r), colmajor(ublk, n), colmajor(blk, r), colmajor(blk, r), -1.0);
+    }
     __syncthreads();
+    CT(8)
   }
-  for (int i = 0; i < N; ++i) { // :131-134
+  __syncthreads();
+  CT(9)
+  // :131-134  sol[i + 1] -= U[i] sol[i]; the products are cut into K-slices over the whole workgroup
+  for (int i = 0; i < N; ++i) {
     const int r = DIM(i), n = DIM(i + 1);
-    wg_gemv(w, n, r, colmajor(U + (long long)i * bs, n), sol + i * nxb, 1, sol + (i + 1) * nxb, 1,
-            sol + (i + 1) * nxb, 1, -1.0);
+    double *xin = ublk, *part = ublk + nxb; // sol[i] in LDS, partial sums
+    for (int e = w.tid; e < r; e += w.nthr)
+      xin[e] = sol[i * nxb + e];
+    __syncthreads();
+    const int slices = n > 0 && w.nthr / n >= 1 ? (w.nthr / n > 8 ? 8 : w.nthr / n) : 1;
+    if (n > 0 && w.tid < n * slices) {
+      const int sl = w.tid / n, row = w.tid - sl * n;
+      const double *Ug = U + (long long)i * bs + row;
+      double acc = 0.0;
+#pragma unroll 8
+      for (int k = sl; k < r; k += slices)
+        acc += Ug[(long long)k * n] * xin[k];
+      part[sl * n + row] = acc;
+    }
+    __syncthreads();
+    for (int row = w.tid; row < n; row += w.nthr) {
+      double acc = 0.0;
+      for (int sl = 0; sl < slices; ++sl)
+        acc += part[sl * n + row];
+      sol[(i + 1) * nxb + row] -= acc;
+    }
     __syncthreads();
   }
 
+  CT(10)
   // ---- iterative refinement (parallel-solver.hxx:184-202, with the residual
   // computed from the true right-hand side; see DESIGN.md "refinement")
   int steps = 0;
   double resdl = 0.0;
   for (int it = 0; it < P.max_refinement; ++it) {
-    // err = rhs - A sol   (blockTridiagMatMul, :52-75)
+    // err = rhs - A sol   (blockTridiagMatMul, :52-75); sol is read from LDS when it fits, the -I blocks of the
+    // super-diagonal are applied as such, and the infinity norm is reduced as the rows are produced
+    const bool xs_lds = nblk * nxb <= 3 * bs + 2 * nxb;
+    const double *xs = sol;
+    if (xs_lds) {
+      for (int e = w.tid; e < nblk * nxb; e += w.nthr)
+        sm[e] = sol[e];
+      xs = sm;
+      __syncthreads();
+    }
+    double mx = 0.0;
     for (int e = w.tid; e < nblk * nxb; e += w.nthr) {
       const int i = e / nxb, a = e - i * nxb;
       const int n = DIM(i);
       double s = 0.0;
       if (a < n) {
         s = rhs[e];
-        const double *Dg = diag + (long long)i * bs;
+        const double *Dg = diag + (long long)i * bs + a, *xi = xs + i * nxb;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
         for (int k = 0; k < n; ++k)
-          s -= Dg[k * n + a] * sol[i * nxb + k];
+          s0 += Dg[k * n] * xi[k];
         if (i > 0) { // sub[i-1] = super[i-1]^T
           const int r = DIM(i - 1);
-          const double *Bp = super + (long long)(i - 1) * bs;
-          for (int k = 0; k < r; ++k)
-            s -= Bp[a * r + k] * sol[(i - 1) * nxb + k];
+          if (i - 1 >= 2 && ((i - 1) & 1) == 0) { // super[i-1] = -I
+            s1 -= xs[(i - 1) * nxb + a];
+          } else {
+            const double *Bp = super + (long long)(i - 1) * bs + a * r, *xp = xs + (i - 1) * nxb;
+#pragma unroll 8
+            for (int k = 0; k < r; ++k)
+              s1 += Bp[k] * xp[k];
+          }
         }
         if (i < N) {
           const int c = DIM(i + 1);
-          const double *Bn = super + (long long)i * bs;
-          for (int k = 0; k < c; ++k)
-            s -= Bn[k * n + a] * sol[(i + 1) * nxb + k];
+          if (i >= 2 && (i & 1) == 0) { // super[i] = -I
+            s1 -= xs[(i + 1) * nxb + a];
+          } else {
+            const double *Bn = super + (long long)i * bs + a, *xn = xs + (i + 1) * nxb;
+#pragma unroll 8
+            for (int k = 0; k < c; ++k)
+              s1 += Bn[k * n] * xn[k];
+          }
         }
+        s -= s0 + s1;
       }
       err[e] = s;
+      const double v = fabs(s);
+      mx = fmax(mx, v == v ? v : 1.8e308 * 10.0); // (a NaN counts as +inf)
     }
+    mx = wave_max_f64(mx);
+    __syncthreads(); // (sol's copy in LDS has been read by everyone)
+    if (w.lane == 0)
+      lsub[w.wave] = mx;
     __syncthreads();
-    // infinity norm (all threads redundantly; tiny)
-    double mx = 0.0;
-    for (int e = 0; e < nblk * nxb; ++e) {
-      const double v = fabs(err[e]);
-      mx = (v > mx || v != v) ? v : mx;
-    }
+    for (int q = 0; q < w.nwaves; ++q)
+      mx = fmax(mx, lsub[q]);
     resdl = mx;
     if (resdl <= P.threshold)
       break;
@@ -993,8 +1084,14 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
       if (i < 0)
         break;
       const int r = DIM(i);
-      wg_gemv(w, r, n, colmajor(super + (long long)i * bs, r), err + ib * nxb, 1, err + i * nxb, 1,
-              err + i * nxb, 1, -1.0);
+      if (i >= 2 && (i & 1) == 0) { // super[i] = -I
+        __syncthreads();
+        for (int e = w.tid; e < r; e += w.nthr)
+          err[i * nxb + e] += err[ib * nxb + e];
+      } else {
+        wg_gemv(w, r, n, colmajor(super + (long long)i * bs, r), err + ib * nxb, 1, err + i * nxb, 1,
+                err + i * nxb, 1, -1.0);
+      }
     }
     for (int i = 0; i < N; ++i) {
       const int r = DIM(i), n = DIM(i + 1);
@@ -1008,6 +1105,7 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
     steps = it + 1;
     __syncthreads();
   }
+  CT(11)
   if (w.tid == 0) {
     info[0] = resdl;
     info[1] = (double)steps;

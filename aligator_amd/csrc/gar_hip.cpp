@@ -1408,7 +1408,7 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipMalloc((void **)&s->d_csol, sizeof(double) * (size_t)nblk * s->nxb * B));
     s->cscratch_doubles = (int64_t)(4 * nblk * bs + 4 * (size_t)nblk * s->nxb + 4);
     HIP_TRY(hipMalloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
-    s->cond_lds_doubles = (int)(2 * bs + 2 * s->nxb + 2 + (s->nxb + 16) / 2 + 2);
+    s->cond_lds_doubles = (int)(3 * bs + 4 * s->nxb + 2 + (s->nxb + 16) / 2 + 2 + (s->nxb < 9 ? 9 * s->nxb : 0));
   }
   if (s->seg_bwd_kernel) {
     const gar_hip_solver *f = s->flay;
@@ -2570,6 +2570,14 @@ int gar_hip_set_condensed_backward_ok(gar_hip_solver *s, double omega) {
   return GAR_HIP_OK;
 }
 
+#ifdef GAR_CTRACE
+extern "C" int gar_hip_debug_ctrace(long long *out) {
+  long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_ctrace), sizeof(z)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_ctrace), z, sizeof(z)) != hipSuccess) return 2;
+  return 0;
+}
+#endif
 int gar_hip_condensed_backward_error(gar_hip_solver *s, int b, double *out) {
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
