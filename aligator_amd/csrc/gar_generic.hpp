@@ -647,11 +647,32 @@ __global__ void __launch_bounds__(256) gar_update_lq(UpdateParams P) {
   }
 }
 
+// One K-slice of a dot product: sum over k = q, q + 4, q + 8, ... < K of a[k astride] x[k], sixteen products per
+// round trip, every load unconditional from a clamped address (a branch per load would serialise the round trips).
+__device__ __forceinline__ double gar_sliced_dot(const double *a, int astride, const double *x, int K, int q) {
+  double s = 0.0;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    double av[16], xv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = k0 + q + 4 * j, kc = k < K ? k : K - 1;
+      av[j] = a[(long long)kc * astride];
+      xv[j] = x[kc];
+      av[j] = k < K ? av[j] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      s += av[j] * xv[j];
+  }
+  return s;
+}
+
+#define GAR_FORWARD_THREADS 1024
 // ---------------------------------------------------------------------------
 // forward: x0/lbd0 from kkt0 (serial) or the condensed solution (legs), then
 // the closed-loop roll-out.  LDS: x (nxM), xn (nxM), theta (nthM).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gar_forward_generic(GenericParams P) {
+__global__ void __launch_bounds__(GAR_FORWARD_THREADS) gar_forward_generic(GenericParams P) {
   const WG w = wg_self();
   double *sm = gar_smem;
   const int leg = (int)blockIdx.x + P.leg_begin;
@@ -667,12 +688,10 @@ __global__ void __launch_bounds__(256) gar_forward_generic(GenericParams P) {
   double *xn = sm + P.lds.fxn; // next state
   double *th = sm + P.lds.fth; // theta
   bool have_theta = false;
-  int nth_used = 0;
   if (P.num_legs == 1) { // computeInitial (riccati-kernel.hxx:195-207)
     const int nx = m0.nx, nc0 = P.nc0, n0 = nx + nc0, nth = m0.nth;
     const double *io = P.init + (long long)b * P.init_stride;
     have_theta = (P.theta != nullptr) && nth > 0;
-    nth_used = nth;
     if (have_theta)
       for (int e = w.tid; e < nth; e += w.nthr)
         th[e] = P.theta[(long long)b * nth + e];
@@ -703,68 +722,86 @@ __global__ void __launch_bounds__(256) gar_forward_generic(GenericParams P) {
     }
     if (leg < P.num_legs - 1) { // theta = lbdas[end] (:234-236)
       have_theta = true;
-      nth_used = m0.nth;
-      for (int e = w.tid; e < nth_used; e += w.nthr)
+      for (int e = w.tid; e < m0.nth; e += w.nthr)
         th[e] = cs[(2 * (leg + 1)) * nxb + e];
     }
   }
   __syncthreads();
 
-  for (int t = t_beg; t < t_end; ++t) {
+  // ---- the state chain (riccati-kernel.hxx:343-365, the rows of x'):  x_{t+1} = yff + Aff x_t (+ Yth th).
+  // It is the only sequential part of the roll-out.  Thread (row, slice) = (tid / 4, tid % 4) takes every fourth
+  // column of its row, all its loads in flight at once; the four slices meet through two lane shuffles.
+  const int srow = w.tid >> 2, sq = w.tid & 3, srows = w.nthr >> 2;
+  for (int t = t_beg; t + 1 < t_end; ++t) {
     const gar_stage_meta m = P.meta[t];
-    const int nx = m.nx, nu = m.nu, nc = m.nc, nx2 = m.nx2, nth = m.nth;
-    const int nk = nu + nc, nr = nk + nx2;
-    const gar_factor_offsets fo = gar_factor_layout(nx, nu, nc, nx2, nth);
+    const int nx = m.nx, nx2 = m.nx2, nth = m.nth, nk = m.nu + m.nc;
+    const gar_factor_offsets fo = gar_factor_layout(nx, m.nu, m.nc, nx2, nth);
     const double *rec = fac + m.fac_off;
-    const bool last = (t == t_end - 1);
     const bool use_th = have_theta && nth > 0;
-    // u = kff + K x (+Kth th); v = zff + Z x (+Zth th); x' = yff + Aff x (+Yth th)
-    const int rows = last ? nk : nr;
-    for (int i = w.tid; i < rows; i += w.nthr) {
-      double s = rec[fo.ff + i];
-      const double *row = rec + fo.fb + (long long)i * nx;
-      double a = 0.0;
-      for (int k = 0; k < nx; ++k)
-        a += row[k] * x[k];
-      s += a;
-      if (use_th) {
-        const double *rt = rec + fo.fth + (long long)i * nth;
-        double a2 = 0.0;
-        for (int k = 0; k < nth; ++k)
-          a2 += rt[k] * th[k];
-        s += a2;
-      }
-      if (i < nu)
-        sol[m.u_off + i] = s;
-      else if (i < nk)
-        sol[m.v_off + (i - nu)] = s;
-      else
-        xn[i - nk] = s;
-    }
-    if (last)
-      break;
-    __syncthreads();
-    // lbd' = vx' + Vxx' x' (+ Vxt' th)  (:369-374)
     const gar_stage_meta mn = P.meta[t + 1];
-    const gar_factor_offsets fn = gar_factor_layout(mn.nx, mn.nu, mn.nc, mn.nx2, mn.nth);
-    const double *recn = fac + mn.fac_off;
-    for (int i = w.tid; i < nx2; i += w.nthr) {
-      double s = recn[fn.vx + i];
-      double a = 0.0;
-      for (int k = 0; k < nx2; ++k)
-        a += recn[fn.Vxx + (long long)k * nx2 + i] * xn[k];
-      s += a;
-      if (use_th) {
-        double a2 = 0.0;
-        for (int k = 0; k < nth; ++k)
-          a2 += recn[fn.Vxt + (long long)k * nx2 + i] * th[k];
-        s += a2;
+    for (int i0 = 0; i0 < nx2; i0 += srows) {
+      const int i = i0 + srow, ic = i < nx2 ? i : nx2 - 1;
+      double sum = gar_sliced_dot(rec + fo.fb + (long long)(nk + ic) * nx, 1, x, nx, sq);
+      if (use_th)
+        sum += gar_sliced_dot(rec + fo.fth + (long long)(nk + ic) * nth, 1, th, nth, sq);
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      if (sq == 0 && i < nx2) {
+        const double v = sum + rec[fo.ff + nk + i];
+        xn[i] = v;
+        sol[mn.x_off + i] = v;
       }
-      sol[mn.l_off + i] = s;
-      sol[mn.x_off + i] = xn[i];
-      x[i] = xn[i];
     }
     __syncthreads();
+    double *tmp = x;
+    x = xn;
+    xn = tmp;
+  }
+  __syncthreads();
+  // ---- everything else is a function of the states just computed and independent from stage to stage:
+  //   u = kff + K x (+ Kth th),  v = zff + Z x (+ Zth th)          (:343-365, rows of u and v)
+  //   lbd' = vx' + Vxx' x' (+ Vxt' th)                               (:369-374)
+  // A wave takes the stages t = t_beg + wave, + nwaves, ...; 16 rows per pass, lane (row, slice) = (lane / 4, lane % 4).
+  {
+    const int lrow = w.lane >> 2, lq = w.lane & 3;
+    for (int t = t_beg + w.wave; t < t_end; t += w.nwaves) {
+      const gar_stage_meta m = P.meta[t];
+      const int nx = m.nx, nu = m.nu, nx2 = m.nx2, nth = m.nth, nk = m.nu + m.nc;
+      const gar_factor_offsets fo = gar_factor_layout(nx, nu, m.nc, nx2, nth);
+      const double *rec = fac + m.fac_off;
+      const bool use_th = have_theta && nth > 0;
+      const double *xt = sol + m.x_off;
+      for (int i0 = 0; i0 < nk; i0 += 16) {
+        const int i = i0 + lrow, ic = i < nk ? i : nk - 1;
+        double sum = gar_sliced_dot(rec + fo.fb + (long long)ic * nx, 1, xt, nx, lq);
+        if (use_th)
+          sum += gar_sliced_dot(rec + fo.fth + (long long)ic * nth, 1, th, nth, lq);
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        if (lq == 0 && i < nk) {
+          const double v = sum + rec[fo.ff + i];
+          if (i < nu)
+            sol[m.u_off + i] = v;
+          else
+            sol[m.v_off + (i - nu)] = v;
+        }
+      }
+      if (t + 1 < t_end) {
+        const gar_stage_meta mn = P.meta[t + 1];
+        const gar_factor_offsets fn = gar_factor_layout(mn.nx, mn.nu, mn.nc, mn.nx2, mn.nth);
+        const double *recn = fac + mn.fac_off, *xt1 = sol + mn.x_off;
+        for (int i0 = 0; i0 < nx2; i0 += 16) {
+          const int i = i0 + lrow, ic = i < nx2 ? i : nx2 - 1;
+          double sum = gar_sliced_dot(recn + fn.Vxx + ic, nx2, xt1, nx2, lq);
+          if (use_th)
+            sum += gar_sliced_dot(recn + fn.Vxt + ic, nx2, th, nth, lq);
+          sum += __shfl_xor(sum, 1);
+          sum += __shfl_xor(sum, 2);
+          if (lq == 0 && i < nx2)
+            sol[mn.l_off + i] = sum + recn[fn.vx + i];
+        }
+      }
+    }
   }
 }
 

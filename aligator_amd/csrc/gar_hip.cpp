@@ -1190,7 +1190,7 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
                          s->stream, make_fold_params(s));
       gar::GenericParams G = make_params(s, 0.0);
       G.only = s->d_status + s->batch + 4;
-      hipLaunchKernelGGL(gar::gar_forward_generic, dim3((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch), dim3(256),
+      hipLaunchKernelGGL(gar::gar_forward_generic, dim3((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch), dim3(GAR_FORWARD_THREADS),
                          (size_t)s->lds.ftotal * sizeof(double), s->stream, G);
     }
     HIP_TRY(hipGetLastError());
@@ -1234,7 +1234,7 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
   const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
   if (s->timing)
     HIP_TRY(hipEventRecord(s->ev[3], s->stream));
-  hipLaunchKernelGGL(gar::gar_forward_generic, grid, dim3(256),
+  hipLaunchKernelGGL(gar::gar_forward_generic, grid, dim3(GAR_FORWARD_THREADS),
                      (size_t)s->lds.ftotal * sizeof(double), s->stream, P);
   HIP_TRY(hipGetLastError());
   if (s->timing)
