@@ -58,6 +58,7 @@ struct GenericParams {
   LdsPlan lds;
   DensePlan dense;
   const int *only; // folded solvers (gar_fold.hpp): sweep only the problems with only[b] != 0 (null: all)
+  int vxx_packed;  // the factor records keep the lower triangle of Vxx, packed (gar_layout.h: gar_sym_index)
 };
 
 extern __shared__ double gar_smem[];
@@ -72,7 +73,7 @@ extern __shared__ double gar_smem[];
 __device__ inline int initial_stage_ptr(const WG &w, const GenericParams &P, int b, int nx, int nth,
                                         const double *V0p, const double *v0, const double *Vxt0p,
                                         const double *Vtt0, const double *vt0, double *k0mat,
-                                        double *k0rhs, double *k0sub, int *piv0, int *ctrl0) {
+                                        double *k0rhs, double *k0sub, int *piv0, int *ctrl0, int v0_packed = 0) {
   const double *prob = P.prob + (long long)b * P.prob_stride;
   int failed = 0;
   const int nc0 = P.nc0, n0 = nx + nc0;
@@ -84,7 +85,7 @@ __device__ inline int initial_stage_ptr(const WG &w, const GenericParams &P, int
     const int j = e / n0, i = e - j * n0;
     double v = 0.0;
     if (j < nx)
-      v = (i < nx) ? V0p[j * nx + i] : G0[j * nc0 + (i - nx)];
+      v = (i < nx) ? V0p[gar_sym_index(v0_packed, nx, i, j)] : G0[j * nc0 + (i - nx)];
     else if (i < nx)
       v = G0[i * nc0 + (j - nx)];
     K0(i, j) = v;
@@ -442,7 +443,7 @@ __global__ void __launch_bounds__(256) gar_initial_generic(GenericParams P) {
   const gar_factor_offsets fo = gar_factor_layout(m0.nx, m0.nu, m0.nc, m0.nx2, m0.nth);
   const double *rec = P.fac + (long long)b * P.fac_stride + m0.fac_off;
   for (int e = w.tid; e < m0.nx * m0.nx; e += w.nthr)
-    sm[L.V[0] + e] = rec[fo.Vxx + e];
+    sm[L.V[0] + e] = rec[fo.Vxx + gar_sym_index(P.vxx_packed, m0.nx, e % m0.nx, e / m0.nx)];
   for (int e = w.tid; e < m0.nx; e += w.nthr)
     sm[L.v[0] + e] = rec[fo.vx + e];
   for (int e = w.tid; e < m0.nx * m0.nth; e += w.nthr)
@@ -494,7 +495,7 @@ __global__ void __launch_bounds__(64) gar_initial_wave(GenericParams P) {
       wave_sync();
       double acc = rec[fo.vx + ix];
       for (int k = 0; k < nx; ++k)
-        acc += rec[fo.Vxx + (long long)k * nx + ix] * xs[k]; // Vxx0 symmetric: row ix
+        acc += rec[fo.Vxx + gar_sym_index(P.vxx_packed, nx, ix, k)] * xs[k]; // Vxx0 symmetric: row ix
       double *io = P.init + (long long)b * P.init_stride;
       if (w.lane < nx) {
         io[w.lane] = x0;
@@ -507,7 +508,7 @@ __global__ void __launch_bounds__(64) gar_initial_wave(GenericParams P) {
   int *piv0 = (int *)(k0sub + n0 + (n0 & 1));
   const int failed = initial_stage_ptr(w, P, b, m0.nx, nth, rec + fo.Vxx, rec + fo.vx, rec + fo.Vxt,
                                        rec + fo.Vtt, rec + fo.vt, k0mat, k0rhs, k0sub, piv0,
-                                       piv0 + n0);
+                                       piv0 + n0, P.vxx_packed);
   if (failed && w.tid == 0)
     atomicOr(&P.status[b], failed);
 }
@@ -1179,7 +1180,8 @@ __global__ void gar_collapse_feedback(const gar_stage_meta *meta, double *fac,
 // knot and stage t+1's Vxx (symmetrised from its lower triangle, as the consuming stage does, :216).
 // One workgroup; Vn == nullptr: no value-function term (terminal knot, last knot of a leg).
 __global__ void __launch_bounds__(256) gar_kkt_matrix(const double *knot, gar_knot_offsets ko, const double *Vn,
-                                                      int nx2, int nu, int nc, double mueq, double *out) {
+                                                      int nx2, int nu, int nc, double mueq, double *out,
+                                                      int vn_packed) {
   const int nk = nu + nc;
   for (int e = (int)threadIdx.x; e < nk * nk; e += (int)blockDim.x) {
     const int j = e / nk, i = e - j * nk;
@@ -1191,7 +1193,7 @@ __global__ void __launch_bounds__(256) gar_kkt_matrix(const double *knot, gar_kn
         for (int l = 0; l < nx2; ++l) {
           double w = 0.0; // (Vxx' B)(l, j)
           for (int k = 0; k < nx2; ++k)
-            w = __builtin_fma(k >= l ? Vn[l * nx2 + k] : Vn[k * nx2 + l], knot[ko.B + j * nx2 + k], w);
+            w = __builtin_fma(Vn[gar_sym_index(vn_packed, nx2, k >= l ? k : l, k >= l ? l : k)], knot[ko.B + j * nx2 + k], w);
           acc = __builtin_fma(knot[ko.B + i * nx2 + l], w, acc);
         }
         v += acc;

@@ -185,6 +185,7 @@ struct gar_hip_solver {
   int wave_lds_doubles = 0, waves_per_block = 1;
   int wave_block_threads = 64; // 128: two waves per problem (gar_wave_pair.hpp)
   bool fb_t2 = false;      // factor records keep fb / fth in the fbT2 device order (gar_mfma.hpp)
+  bool vxx_packed = false; // ... and the lower triangle of Vxx, packed (gar_layout.h: the serial one-wave family)
   std::string lds_error;   // the generic kernels do not fit a CU's LDS (fatal unless a specialised family serves the shape)
   bool wave_fused_init = false;
   bool init_closed = true; // closed-form initial stage when G0 = +-I (GAR_HIP_INIT=bk: always factorise)
@@ -622,6 +623,7 @@ void select_kernel(gar_hip_solver *s) {
   s->wave_fused_init = false;
   s->wave_block_threads = 64;
   s->fb_t2 = false;
+  s->vxx_packed = false;
   {
     const char *ik = std::getenv("GAR_HIP_INIT");
     s->init_closed = !(ik && std::string(ik) == "bk");
@@ -659,6 +661,7 @@ void select_kernel(gar_hip_solver *s) {
     if (nx == 36 && nu == 12 && nc == 32) bind_cstr<36, 12, 32>(s);
     else if (nx == 16 && nu == 8 && nc == 8) bind_cstr<16, 8, 8>(s);
     else if (nx == 8 && nu == 4 && nc == 4) bind_cstr<8, 4, 4>(s);
+    s->vxx_packed = s->fb_t2; // (serial one-wave family: gar_layout.h)
     return;
   }
   if (nx == 36 && nu == 12) bind_mfma<36, 12>(s);
@@ -668,6 +671,7 @@ void select_kernel(gar_hip_solver *s) {
   else if (nx == 12 && nu == 4) bind_mfma<12, 4>(s);
   else if (nx == 8 && nu == 4) bind_mfma<8, 4>(s);
   else if (nx == 56 && nu == 24) bind_wide<56, 24>(s);
+  s->vxx_packed = s->fb_t2; // the serial one-wave family keeps the lower triangle of Vxx, packed (gar_layout.h)
 }
 
 // (nx, nu) shapes with kernels of their own (bind_mfma / bind_leg / bind_wide / bind_seg_leg above)
@@ -824,6 +828,7 @@ gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
   P.lds = s->lds;
   P.dense = s->dense_lds;
   P.init_closed = s->init_closed ? 1 : 0;
+  P.vxx_packed = s->vxx_packed ? 1 : 0;
   return P;
 }
 
@@ -2207,7 +2212,14 @@ static int get_value_dev(gar_hip_solver *s, int b, int t, double *Vxx, double *v
   const gar_stage_meta &m = s->meta[t];
   const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, s->dense ? 2 * m.nx2 : m.nx2, m.nth);
   const double *rec = s->d_fac + (int64_t)b * s->fac_doubles + m.fac_off;
-  int rc = d2h(s, Vxx, rec + o.Vxx, (int64_t)m.nx * m.nx);
+  std::vector<double> packed; // the serial one-wave family keeps the lower triangle, packed (gar_layout.h)
+  int rc = 0;
+  if (s->vxx_packed && Vxx) {
+    packed.resize((size_t)gar_sym_packed_doubles(m.nx));
+    rc = d2h(s, packed.data(), rec + o.Vxx, (int64_t)packed.size());
+  } else {
+    rc = d2h(s, Vxx, rec + o.Vxx, (int64_t)m.nx * m.nx);
+  }
   rc |= d2h(s, vx, rec + o.vx, m.nx);
   rc |= d2h(s, Vxt, rec + o.Vxt, (int64_t)m.nx * m.nth);
   rc |= d2h(s, Vtt, rec + o.Vtt, (int64_t)m.nth * m.nth);
@@ -2215,6 +2227,10 @@ static int get_value_dev(gar_hip_solver *s, int b, int t, double *Vxx, double *v
   if (rc)
     return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (!packed.empty())
+    for (int j = 0; j < m.nx; ++j)
+      for (int i = 0; i < m.nx; ++i)
+        Vxx[(size_t)j * m.nx + i] = packed[(size_t)gar_sym_index(1, m.nx, i, j)];
   return GAR_HIP_OK;
 }
 
@@ -2250,7 +2266,7 @@ static int get_kkt_dev(gar_hip_solver *s, int b, int t, double mueq, double *out
     Vn = s->d_fac + (int64_t)b * s->fac_doubles + mn.fac_off + fn.Vxx;
   }
   hipLaunchKernelGGL(gar::gar_kkt_matrix, dim3(1), dim3(256), 0, s->stream, knot, ko, Vn, m.nx2, m.nu, m.nc, mueq,
-                     s->d_kkt);
+                     s->d_kkt, s->vxx_packed ? 1 : 0);
   HIP_TRY(hipGetLastError());
   if (int rc = d2h(s, out, s->d_kkt, (int64_t)nk * nk))
     return rc;

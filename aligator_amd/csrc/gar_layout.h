@@ -97,6 +97,22 @@ GAR_HD static inline gar_knot_offsets gar_knot_layout(int nx, int nu, int nc, in
   return o;
 }
 
+// ---- packed storage of a symmetric block ---------------------------------------------------------------------
+// The one-wave-per-problem serial kernels (gar_wave*.hpp, gar_mfma.hpp: the solvers whose roll-out is
+// gar_forward_mfma) keep only the LOWER TRIANGLE of Vxx in the Vxx block of their factor records, in rectangular
+// packed order: the block's first nx (nx + 1) / 2 doubles are nx / 2 "super-columns" of nx + 1 doubles, super-column
+// c holding column c's rows c .. nx-1 followed by column nx-1-c's rows nx-1-c .. nx-1 (nx even).  The rest of the
+// block is not touched: the sweep writes, and the roll-out reads, 5.3 KB instead of 10.4 KB per stage at nx = 36.
+// Every other family stores the full column-major matrix.  gar_hip_get_value unpacks.
+//   element (i, j) of the block, either order:
+GAR_HD static inline int gar_sym_index(int packed, int n, int i, int j) {
+  if (!packed)
+    return j * n + i;
+  const int a = i >= j ? i : j, b = i >= j ? j : i; // a >= b
+  return 2 * b < n ? b * (n + 1) + (a - b) : (n - 1 - b) * (n + 1) + (b + 1) + (a - b);
+}
+GAR_HD static inline int gar_sym_packed_doubles(int n) { return n * (n + 1) / 2; }
+
 // offsets inside a factor record
 typedef struct gar_factor_offsets {
   int32_t ff, fb, fth, Vxx, vx, Vxt, Vtt, vt, total;

@@ -298,7 +298,8 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       const int j = e / NX, i = e - j * NX; // column-major element (i, j)
       const double v = (i >= j) ? rec[C::tQ + e] : rec[C::tQ + i * NX + j];
       V[i * PK + j] = v; // symmetrised from lower, as the consumer stage does (:216)
-      out[C::tVxx + e] = v;
+      if (i >= j)
+        out[C::tVxx + gar_sym_index(1, NX, i, j)] = v; // (packed lower triangle: gar_layout.h)
     }
     for (int e = tid; e < NX; e += 256) {
       const double v = rec[C::tq + e];
@@ -442,9 +443,10 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       GAR_MARK(7)
       __syncthreads(); // C: V, vn, Ft[next] complete
       GAR_MARK(8)
-      for (int e = tid; e < NX * NX; e += 192) { // Vxx -> HBM (column-major, symmetric)
+      for (int e = tid; e < NX * NX; e += 192) { // Vxx -> HBM (packed lower triangle: gar_layout.h)
         const int j = e / NX, i = e - j * NX;
-        out[C::fVxx + e] = V[i * PK + j];
+        if (i >= j)
+          out[C::fVxx + gar_sym_index(1, NX, i, j)] = V[i * PK + j];
       }
       GAR_MARK(9)
     }
@@ -630,6 +632,49 @@ struct MfmaFwdParams {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// Vxx -> HBM, 16 B per lane.  PACK (the serial family with the gar_forward_mfma roll-out): the LOWER TRIANGLE of V
+// (LDS, pitch NX), rectangular packed (gar_layout.h: gar_sym_index) -- half the bytes of the full block,
+// contiguous.  Otherwise (the wide shapes, whose roll-out reads the full block): V as it is, linear.
+template <int NX, bool PACK> struct VxxOut {
+  static_assert(!PACK || NX % 4 == 0, "packed Vxx: nx (nx + 1) / 2 must be even (16-byte stores)");
+  static constexpr int NP2 = PACK ? NX * (NX + 1) / 4 : NX * NX / 2; // 16-byte pairs
+  static constexpr int NCH = (NP2 + 63) / 64;                        // pairs per lane
+  __device__ static __forceinline__ int lds_of(int p) { // LDS offset of packed element p
+    const int c = p / (NX + 1), k = p - c * (NX + 1);
+    const bool first = k < NX - c;
+    const int j = first ? c : NX - 1 - c;
+    const int i = first ? c + k : j + k - (NX - c);
+    return i * NX + j;
+  }
+  __device__ static __forceinline__ double2_t read(const double *V, int q, int lane) { // chunk q of this lane
+    const int e = 64 * q + lane, ec = (64 * q + 63 < NP2 || e < NP2) ? e : NP2 - 1;
+    double2_t v;
+    if constexpr (PACK) {
+      v.x = V[lds_of(2 * ec)];
+      v.y = V[lds_of(2 * ec + 1)];
+    } else {
+      v = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
+    }
+    return v;
+  }
+  __device__ static __forceinline__ void write(double *dst, int q, int lane, double2_t v) {
+    const int e = 64 * q + lane;
+    if (64 * q + 63 < NP2 || e < NP2)
+      *reinterpret_cast<double2_t *>(&dst[2 * e]) = v;
+  }
+};
+template <int NX, bool PACK = true> __device__ __forceinline__ void wave_flush_vxx(const double *V, double *dst, int lane) {
+  using VO = VxxOut<NX, PACK>;
+  double2_t vbuf[VO::NCH];
+#pragma unroll
+  for (int q = 0; q < VO::NCH; ++q) // all the LDS reads first (one latency), then the stores
+    vbuf[q] = VO::read(V, q, lane);
+#pragma unroll
+  for (int q = 0; q < VO::NCH; ++q)
+    VO::write(dst, q, lane, vbuf[q]);
+}
+
+
 // one stage's gains in registers: [K; Aff] row r (fbT2: 16 B per lane), Vxx' row iv, ff, vx';
 // constrained stages: row NU + lane of [K; Z; Aff] (a Z row) in a second slot
 template <int NX, int NC = 0> struct FwdStage {
@@ -660,18 +705,16 @@ __device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *f
       S.gz[m] = *reinterpret_cast<const double2_t *>(rec + C::fFB + m * 2 * NW + 2 * rz);
     S.ffz = rec[C::fFF + rz];
   }
-  // Vxx' is symmetric: row iv = its lower-triangle part (column j, row iv, coalesced over the lanes iv >= j)
-  // followed by the part of COLUMN iv below the diagonal (this lane's own contiguous run) -- only the lower
-  // triangle of the record is read
-#ifndef GAR_FWD_FULL_VXX
+  // Vxx' is symmetric and its record holds the lower triangle, rectangular packed (gar_layout.h: gar_sym_index):
+  // row iv = elements (iv, j) for j <= iv (consecutive lanes, consecutive addresses) and (j, iv) for j > iv
+  {
+    const int lowbase = 2 * iv < NX ? iv * NX : (NX - 1 - iv) * (NX + 1) + 1; // (j, iv), j > iv: lowbase + j
 #pragma unroll
-  for (int j = 0; j < NX; ++j)
-    S.vrow[j] = recn[oVn + (iv >= j ? j * NX + iv : iv * NX + j)];
-#else
-#pragma unroll
-  for (int j = 0; j < NX; ++j)
-    S.vrow[j] = recn[oVn + j * NX + iv]; // Vxx' symmetric: column j, row iv
-#endif
+    for (int j = 0; j < NX; ++j) {
+      const int cj = 2 * j < NX ? j * (NX + 1) - j : (NX - 1 - j) * (NX + 1) + (j + 1) - j; // (iv, j), iv >= j: cj + iv
+      S.vrow[j] = recn[oVn + (iv >= j ? cj + iv : lowbase + j)];
+    }
+  }
   S.ff = rec[C::fFF + r];
   S.vxn = recn[ovn + iv];
 }

@@ -497,7 +497,7 @@ __device__ __attribute__((noinline)) int wave_kkt_factor_solve(double *Mm, doubl
 //         system [Rhat D^T; D -mu I] [K; Z] = -[Shat^T; C] is assembled in LDS and factorised by the
 //         wave-scope Bunch-Kaufman (it is indefinite: there is no unpivoted fast path);
 //         Vxx += C^T Z, vx += C^T zff; ff = [kff; zff; yff], fb = [K; Z; Aff].
-template <int NX, int NU, int MODE = 0, int PAR = 0, int NC = 0>
+template <int NX, int NU, int MODE = 0, int PAR = 0, int NC = 0, bool PACKV = false>
 __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, const double *prob,
                                            double *fac, int t, int lane,
                                            const WaveLane<NX, NU, NC> &L, WaveStage<NX, NU> &S,
@@ -1178,9 +1178,12 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   // ---- knot t-1: its Hessian tiles replace H
   wave_load_b<NX, NU>(recn, L, S);
   GAR_WMARK(9)
-  // ---- Vxx -> HBM (column-major, symmetric), 16 B per lane -----------------------
+  // ---- Vxx -> HBM, 16 B per lane: column-major and symmetric, or (PACKV: the serial family, gar_layout.h) the
+  // packed lower triangle
   static_assert(PK == NX, "V is stored exactly as the Vxx record");
-  {
+  if constexpr (PACKV) {
+    wave_flush_vxx<NX, true>(V, out + oVxx, lane);
+  } else {
     constexpr int NCH = (NX * NX / 2 + 63) / 64;
     double2_t vbuf[NCH];
 #pragma unroll
@@ -1265,7 +1268,7 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
     const double *rn = fac + P.slot(tstart + 1) * P.fac_rec;
     for (int e = lane; e < NX * NX; e += 64) {
       const int j = e / NX, i = e - j * NX;
-      V[i * PK + j] = rn[M::fVxx + e];
+      V[i * PK + j] = rn[M::fVxx + gar_sym_index(M::WIDE ? 0 : 1, NX, i, j)]; // (packed lower triangle: gar_layout.h)
     }
     if (lane < NX)
       vn[lane] = rn[M::fvx + lane];
@@ -1278,7 +1281,10 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
       for (int k = 0; k < NC; ++k) // (C^T Z)(i, j), Z = C / mu
         v = __builtin_fma(rec[M::tC + i * NC + k], rec[M::tC + j * NC + k] / P.mueq, v);
       V[i * PK + j] = v; // symmetrised from lower, as the consumer stage does (:216)
-      out[M::tVxx + e] = v;
+      if (M::WIDE)
+        out[M::tVxx + e] = v;
+      else if (i >= j)
+        out[M::tVxx + gar_sym_index(1, NX, i, j)] = v; // (packed lower triangle: gar_layout.h)
     }
     if (lane < NX) {
       double v = rec[M::tq + lane];
@@ -1309,7 +1315,7 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
       if constexpr (PHASE == 2) {
         if (lane == 0)
           atomicAdd(&P.slow[3], 1);
-        wave_stage<NX, NU, 0, 0, NC>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+        wave_stage<NX, NU, 0, 0, NC, true>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
       } else {
         if (PHASE == 1 && lane == 0)
           atomicAdd(&P.slow[2], 1);
@@ -1332,7 +1338,7 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
   }
   if constexpr (PHASE < 2) {
     if (N > 0)
-      wave_flush_vxx<NX>(V, vflush, lane);
+      wave_flush_vxx<NX, !M::WIDE>(V, vflush, lane);
   }
   // ---- initial stage (proximal-riccati.hxx:42-60), fused: kkt0 = [Vxx0 G0^T; G0 0] is
   // Bunch-Kaufman-factorised by this wave right away (packed lower triangle in LDS, read from

@@ -357,24 +357,6 @@ __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], 
   return bad;
 }
 
-// Vxx (the symmetric content of V in LDS) -> HBM, 16 B per lane, linear
-template <int NX> __device__ __forceinline__ void wave_flush_vxx(const double *V, double *dst, int lane) {
-  constexpr int NCH = (NX * NX / 2 + 63) / 64;
-  double2_t vbuf[NCH];
-#pragma unroll
-  for (int q = 0; q < NCH; ++q) {
-    const int e = 64 * q + lane;
-    const int ec = (64 * q + 63 < NX * NX / 2) ? e : (e < NX * NX / 2 ? e : NX * NX / 2 - 1);
-    vbuf[q] = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
-  }
-#pragma unroll
-  for (int q = 0; q < NCH; ++q) {
-    const int e = 64 * q + lane;
-    if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
-      *reinterpret_cast<double2_t *>(&dst[2 * e]) = vbuf[q];
-  }
-}
-
 // A memory instruction issued right behind a v_mfma_f64_16x16x4 costs ~8 cycles of the wave's time
 // instead of ~20 (the MFMA holds the VALU for 64 cycles; LDS and memory instructions of the same
 // wave keep issuing: scripts/ubench/overlap.cpp).  The compiler's scheduler clusters memory
@@ -480,24 +462,18 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   double Bop[TX][KU]; // B of this knot as the A operand of Aff = A + B K: B[16ti+li][4s'+lk]
   double Bop4[KU];    // REM4: B[NX-4+i4][4s'+k4], the A operand of the 4x4x4 blocks
   // ---- memory work slotted behind the MFMAs of the tile columns tj < cR (list A) ----------------
-  constexpr int NCH = (NX * NX / 2 + 63) / 64;
+  using VO = VxxOut<NX, !WIDE>;
+  constexpr int NCH = VO::NCH;
   constexpr int nA_flush = NCH + 2, nA_rows = NU, nA_bop = TX * KU + (C::REM4 ? KU : 0);
   constexpr int nA = nA_flush + nA_rows + nA_bop;
   double2_t vbuf[NCH];
   const int frow = lane < NU ? lane : NU - 1;
   auto slotA = [&](int i) { // i: compile-time after unrolling
     if (i < nA_flush) {     // the previous stage's Vxx -> HBM: LDS read of chunk i, store of chunk i-2
-      if (i < NCH) {
-        const int e = 64 * i + lane;
-        const int ec = (64 * i + 63 < NX * NX / 2) ? e : (e < NX * NX / 2 ? e : NX * NX / 2 - 1);
-        vbuf[i < NCH ? i : 0] = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
-      }
-      if (i >= 2) {
-        const int q = i - 2;
-        const int e = 64 * q + lane;
-        if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
-          *reinterpret_cast<double2_t *>(&vflush[2 * e]) = vbuf[q < NCH ? q : 0];
-      }
+      if (i < NCH)
+        vbuf[i < NCH ? i : 0] = VO::read(V, i, lane);
+      if (i >= 2)
+        VO::write(vflush, i - 2, lane, vbuf[i - 2 < NCH ? i - 2 : 0]);
     } else if (i < nA_flush + nA_rows) { // Rhat, lane = row
       const int j = i - nA_flush;
       a_row[j < NU ? j : 0] = Mm[j * NU + frow];

@@ -421,17 +421,13 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   GAR_PMARK(11)
   __syncthreads(); // (4) V, vx complete
   GAR_PMARK(12)
-  // ---- Vxx -> HBM (column-major, symmetric), 16 B per lane, the chunks alternate between the waves ----
+  // ---- Vxx -> HBM, 16 B per lane, the chunks alternate between the waves: column-major and symmetric for the wide
+  // shapes, the packed lower triangle (gar_layout.h) where the roll-out is gar_forward_mfma ----
   {
-    constexpr int NCH = (NX * NX / 2 + 63) / 64;
+    using VO = VxxOut<NX, !WIDE>;
 #pragma unroll
-    for (int q = W; q < NCH; q += 2) {
-      const int e = 64 * q + lane;
-      const int ec = (64 * q + 63 < NX * NX / 2) ? e : (e < NX * NX / 2 ? e : NX * NX / 2 - 1);
-      const double2_t v = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
-      if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
-        *reinterpret_cast<double2_t *>(&out[oVxx + 2 * e]) = v;
-    }
+    for (int q = W; q < VO::NCH; q += 2)
+      VO::write(out + oVxx, q, lane, VO::read(V, q, lane));
   }
 }
 
@@ -461,7 +457,10 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
       const int j = e / NX, i = e - j * NX;
       const double v = (i >= j) ? rec[M::tQ + e] : rec[M::tQ + i * NX + j];
       V[i * PK + j] = v;
-      out[M::tVxx + e] = v;
+      if (M::WIDE)
+        out[M::tVxx + e] = v;
+      else if (i >= j)
+        out[M::tVxx + gar_sym_index(1, NX, i, j)] = v; // (packed lower triangle: gar_layout.h)
     }
     if (tid < NX) {
       const double v = rec[M::tq + tid];
