@@ -661,7 +661,7 @@ void select_kernel(gar_hip_solver *s) {
     if (nx == 36 && nu == 12 && nc == 32) bind_cstr<36, 12, 32>(s);
     else if (nx == 16 && nu == 8 && nc == 8) bind_cstr<16, 8, 8>(s);
     else if (nx == 8 && nu == 4 && nc == 4) bind_cstr<8, 4, 4>(s);
-    s->vxx_packed = s->fb_t2; // (serial one-wave family: gar_layout.h)
+    s->vxx_packed = GAR_VXX_PACKED && s->fb_t2; // (serial one-wave family: gar_layout.h)
     return;
   }
   if (nx == 36 && nu == 12) bind_mfma<36, 12>(s);
@@ -671,7 +671,7 @@ void select_kernel(gar_hip_solver *s) {
   else if (nx == 12 && nu == 4) bind_mfma<12, 4>(s);
   else if (nx == 8 && nu == 4) bind_mfma<8, 4>(s);
   else if (nx == 56 && nu == 24) bind_wide<56, 24>(s);
-  s->vxx_packed = s->fb_t2; // the serial one-wave family keeps the lower triangle of Vxx, packed (gar_layout.h)
+  s->vxx_packed = GAR_VXX_PACKED && s->fb_t2; // the serial one-wave family keeps the lower triangle of Vxx, packed (gar_layout.h)
 }
 
 // (nx, nu) shapes with kernels of their own (bind_mfma / bind_leg / bind_wide / bind_seg_leg above)

@@ -104,6 +104,10 @@ GAR_HD static inline gar_knot_offsets gar_knot_layout(int nx, int nu, int nc, in
 // c holding column c's rows c .. nx-1 followed by column nx-1-c's rows nx-1-c .. nx-1 (nx even).  The rest of the
 // block is not touched: the sweep writes, and the roll-out reads, 5.3 KB instead of 10.4 KB per stage at nx = 36.
 // Every other family stores the full column-major matrix.  gar_hip_get_value unpacks.
+// (-DGAR_VXX_PACKED=0 builds the library with full blocks everywhere: the A/B of scripts/ab_vxx_packed.sh)
+#ifndef GAR_VXX_PACKED
+#define GAR_VXX_PACKED 1
+#endif
 //   element (i, j) of the block, either order:
 GAR_HD static inline int gar_sym_index(int packed, int n, int i, int j) {
   if (!packed)

@@ -298,7 +298,9 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       const int j = e / NX, i = e - j * NX; // column-major element (i, j)
       const double v = (i >= j) ? rec[C::tQ + e] : rec[C::tQ + i * NX + j];
       V[i * PK + j] = v; // symmetrised from lower, as the consumer stage does (:216)
-      if (i >= j)
+      if (!GAR_VXX_PACKED)
+        out[C::tVxx + e] = v;
+      else if (i >= j)
         out[C::tVxx + gar_sym_index(1, NX, i, j)] = v; // (packed lower triangle: gar_layout.h)
     }
     for (int e = tid; e < NX; e += 256) {
@@ -445,7 +447,9 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       GAR_MARK(8)
       for (int e = tid; e < NX * NX; e += 192) { // Vxx -> HBM (packed lower triangle: gar_layout.h)
         const int j = e / NX, i = e - j * NX;
-        if (i >= j)
+        if (!GAR_VXX_PACKED)
+          out[C::fVxx + e] = V[i * PK + j];
+        else if (i >= j)
           out[C::fVxx + gar_sym_index(1, NX, i, j)] = V[i * PK + j];
       }
       GAR_MARK(9)
@@ -707,13 +711,18 @@ __device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *f
   }
   // Vxx' is symmetric and its record holds the lower triangle, rectangular packed (gar_layout.h: gar_sym_index):
   // row iv = elements (iv, j) for j <= iv (consecutive lanes, consecutive addresses) and (j, iv) for j > iv
-  {
+  if (GAR_VXX_PACKED) {
     const int lowbase = 2 * iv < NX ? iv * NX : (NX - 1 - iv) * (NX + 1) + 1; // (j, iv), j > iv: lowbase + j
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const int cj = 2 * j < NX ? j * (NX + 1) - j : (NX - 1 - j) * (NX + 1) + (j + 1) - j; // (iv, j), iv >= j: cj + iv
       S.vrow[j] = recn[oVn + (iv >= j ? cj + iv : lowbase + j)];
     }
+  }
+  if (!GAR_VXX_PACKED) { // full block: lower triangle only (column j, row iv for j <= iv; this lane's own column below)
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      S.vrow[j] = recn[oVn + (iv >= j ? j * NX + iv : iv * NX + j)];
   }
   S.ff = rec[C::fFF + r];
   S.vxn = recn[ovn + iv];

@@ -1268,7 +1268,7 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
     const double *rn = fac + P.slot(tstart + 1) * P.fac_rec;
     for (int e = lane; e < NX * NX; e += 64) {
       const int j = e / NX, i = e - j * NX;
-      V[i * PK + j] = rn[M::fVxx + gar_sym_index(M::WIDE ? 0 : 1, NX, i, j)]; // (packed lower triangle: gar_layout.h)
+      V[i * PK + j] = rn[M::fVxx + gar_sym_index(GAR_VXX_PACKED && !M::WIDE, NX, i, j)]; // (packed lower triangle: gar_layout.h)
     }
     if (lane < NX)
       vn[lane] = rn[M::fvx + lane];
@@ -1281,7 +1281,7 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
       for (int k = 0; k < NC; ++k) // (C^T Z)(i, j), Z = C / mu
         v = __builtin_fma(rec[M::tC + i * NC + k], rec[M::tC + j * NC + k] / P.mueq, v);
       V[i * PK + j] = v; // symmetrised from lower, as the consumer stage does (:216)
-      if (M::WIDE)
+      if (M::WIDE || !GAR_VXX_PACKED)
         out[M::tVxx + e] = v;
       else if (i >= j)
         out[M::tVxx + gar_sym_index(1, NX, i, j)] = v; // (packed lower triangle: gar_layout.h)
@@ -1315,7 +1315,7 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
       if constexpr (PHASE == 2) {
         if (lane == 0)
           atomicAdd(&P.slow[3], 1);
-        wave_stage<NX, NU, 0, 0, NC, true>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
+        wave_stage<NX, NU, 0, 0, NC, GAR_VXX_PACKED != 0>(P, sm, prob, fac, t, lane, L, S, failed, tracing);
       } else {
         if (PHASE == 1 && lane == 0)
           atomicAdd(&P.slow[2], 1);
@@ -1338,7 +1338,7 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
   }
   if constexpr (PHASE < 2) {
     if (N > 0)
-      wave_flush_vxx<NX, !M::WIDE>(V, vflush, lane);
+      wave_flush_vxx<NX, GAR_VXX_PACKED && !M::WIDE>(V, vflush, lane);
   }
   // ---- initial stage (proximal-riccati.hxx:42-60), fused: kkt0 = [Vxx0 G0^T; G0 0] is
   // Bunch-Kaufman-factorised by this wave right away (packed lower triangle in LDS, read from

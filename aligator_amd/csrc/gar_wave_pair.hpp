@@ -424,7 +424,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   // ---- Vxx -> HBM, 16 B per lane, the chunks alternate between the waves: column-major and symmetric for the wide
   // shapes, the packed lower triangle (gar_layout.h) where the roll-out is gar_forward_mfma ----
   {
-    using VO = VxxOut<NX, !WIDE>;
+    using VO = VxxOut<NX, GAR_VXX_PACKED && !WIDE>;
 #pragma unroll
     for (int q = W; q < VO::NCH; q += 2)
       VO::write(out + oVxx, q, lane, VO::read(V, q, lane));
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
       const int j = e / NX, i = e - j * NX;
       const double v = (i >= j) ? rec[M::tQ + e] : rec[M::tQ + i * NX + j];
       V[i * PK + j] = v;
-      if (M::WIDE)
+      if (M::WIDE || !GAR_VXX_PACKED)
         out[M::tVxx + e] = v;
       else if (i >= j)
         out[M::tVxx + gar_sym_index(1, NX, i, j)] = v; // (packed lower triangle: gar_layout.h)

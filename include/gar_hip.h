@@ -165,6 +165,9 @@ int gar_hip_commit(gar_hip_solver *s);
  * device-resident producers (the updateLQSubproblem replacement, SURVEY 8f1, or
  * a synthetic generator) can write knots in place. */
 double *gar_hip_device_problems(gar_hip_solver *s);
+/* (factors: the solver's own device format -- csrc/gar_layout.h.  The specialised families keep fb / fth in the fbT2
+ * order and, the serial one-wave family, the symmetric Vxx as its packed lower triangle (gar_sym_index): read them
+ * through gar_hip_get_gains / gar_hip_get_value / gar_hip_fetch_results, which convert.) */
 double *gar_hip_device_factors(gar_hip_solver *s);
 double *gar_hip_device_solutions(gar_hip_solver *s);
 /* The DEVICE side of the records behind those pointers (and behind gar_hip_upload_packed_device): identical to the
