@@ -177,6 +177,7 @@ struct gar_hip_solver {
   // specialised backward kernel (gar_mfma.hpp), null = generic
   void (*mfma_kernel)(gar::MfmaParams) = nullptr;
   void (*mfma_fwd_kernel)(gar::MfmaFwdParams) = nullptr;
+  size_t mfma_fwd_lds_bytes = 0; // gar_forward_mfma: the packed Vxx' of a stage goes through LDS
   int mfma_lds_doubles = 0;
   // one-wave-per-problem backward kernel (gar_wave.hpp), preferred when bound
   void (*wave_kernel)(gar::MfmaParams, int) = nullptr;
@@ -448,6 +449,7 @@ replan:
 template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   s->mfma_kernel = gar::gar_backward_mfma<NX, NU>;
   s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU>;
+  s->mfma_fwd_lds_bytes = GAR_VXX_PACKED ? sizeof(double) * (size_t)gar_sym_packed_doubles(NX) : 0;
   s->fb_t2 = true;
   s->mfma_lds_doubles = gar::MfmaCfg<NX, NU>::total;
   s->kernel_name = "mfma<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
@@ -594,6 +596,7 @@ template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
   s->wave_coupled_kernel = gar::gar_backward_wave_coupled<NX, NU, NC>;
   s->wave_bk_kernel = gar::gar_backward_wave_bk<NX, NU, NC>;
   s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU, NC>;
+  s->mfma_fwd_lds_bytes = GAR_VXX_PACKED ? sizeof(double) * (size_t)gar_sym_packed_doubles(NX) : 0;
   s->fb_t2 = true;
   const int with_init = gar::WaveCfg<NX, NU, NC>::total_with_init(s->nc0);
   s->wave_fused_init = (size_t)with_init * sizeof(double) <= 64 * 1024 && s->nth0 == 0;
@@ -617,6 +620,7 @@ void select_kernel(gar_hip_solver *s) {
   s->cyc_recover_kernel = nullptr;
   s->mfma_kernel = nullptr;
   s->mfma_fwd_kernel = nullptr;
+  s->mfma_fwd_lds_bytes = 0;
   s->wave_kernel = nullptr;
   s->wave_coupled_kernel = nullptr;
   s->wave_bk_kernel = nullptr;
@@ -1222,7 +1226,7 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
     F.ring0 = s->ring0;
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[3], s->stream));
-    hipLaunchKernelGGL(s->mfma_fwd_kernel, dim3((unsigned)s->batch), dim3(64), 0, s->stream, F);
+    hipLaunchKernelGGL(s->mfma_fwd_kernel, dim3((unsigned)s->batch), dim3(64), s->mfma_fwd_lds_bytes, s->stream, F);
     HIP_TRY(hipGetLastError());
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[4], s->stream));

@@ -684,7 +684,11 @@ template <int NX, bool PACK = true> __device__ __forceinline__ void wave_flush_v
 template <int NX, int NC = 0> struct FwdStage {
   double2_t g[NX / 2];
   double2_t gz[NC > 0 ? NX / 2 : 1];
-  double vrow[NX];
+  // Vxx' of the next stage.  Packed records (gar_layout.h): this lane's 16-byte pieces of the packed lower triangle,
+  // fetched linearly (whole lines, 6 requests per lane at nx = 36) -- they go through LDS to become rows in
+  // fwd_step.  Full records (-DGAR_VXX_PACKED=0): row iv itself, gathered from the lower triangle.
+  double2_t vp[GAR_VXX_PACKED ? VxxOut<NX, true>::NCH : 1];
+  double vrow[GAR_VXX_PACKED ? 1 : NX];
   double ff, vxn, ffz;
 };
 
@@ -709,20 +713,17 @@ __device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *f
       S.gz[m] = *reinterpret_cast<const double2_t *>(rec + C::fFB + m * 2 * NW + 2 * rz);
     S.ffz = rec[C::fFF + rz];
   }
-  // Vxx' is symmetric and its record holds the lower triangle, rectangular packed (gar_layout.h: gar_sym_index):
-  // row iv = elements (iv, j) for j <= iv (consecutive lanes, consecutive addresses) and (j, iv) for j > iv
   if (GAR_VXX_PACKED) {
-    const int lowbase = 2 * iv < NX ? iv * NX : (NX - 1 - iv) * (NX + 1) + 1; // (j, iv), j > iv: lowbase + j
+    using VO = VxxOut<NX, true>;
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      const int cj = 2 * j < NX ? j * (NX + 1) - j : (NX - 1 - j) * (NX + 1) + (j + 1) - j; // (iv, j), iv >= j: cj + iv
-      S.vrow[j] = recn[oVn + (iv >= j ? cj + iv : lowbase + j)];
+    for (int q = 0; q < VO::NCH; ++q) {
+      const int e = 64 * q + lane, ec = (64 * q + 63 < VO::NP2 || e < VO::NP2) ? e : VO::NP2 - 1;
+      S.vp[GAR_VXX_PACKED ? q : 0] = *reinterpret_cast<const double2_t *>(recn + oVn + 2 * ec);
     }
-  }
-  if (!GAR_VXX_PACKED) { // full block: lower triangle only (column j, row iv for j <= iv; this lane's own column below)
+  } else { // full block: lower triangle only (column j, row iv for j <= iv; this lane's own column below)
 #pragma unroll
     for (int j = 0; j < NX; ++j)
-      S.vrow[j] = recn[oVn + (iv >= j ? j * NX + iv : iv * NX + j)];
+      S.vrow[GAR_VXX_PACKED ? 0 : j] = recn[oVn + (iv >= j ? j * NX + iv : iv * NX + j)];
   }
   S.ff = rec[C::fFF + r];
   S.vxn = recn[ovn + iv];
@@ -730,9 +731,20 @@ __device__ __forceinline__ void fwd_load(const MfmaFwdParams &P, const double *f
 
 template <int NX, int NU, int NC = 0>
 __device__ __forceinline__ double fwd_step(const MfmaFwdParams &P, double *sol, int t, int lane,
-                                           double xs, const FwdStage<NX, NC> &S) {
+                                           double xs, const FwdStage<NX, NC> &S, double *vb, int iv) {
   using C = MfmaCfg<NX, NU, NC>;
   constexpr int NW = C::NW;
+  if (GAR_VXX_PACKED) { // the packed triangle of Vxx' -> LDS (the rows are read back after the products below)
+    using VO = VxxOut<NX, true>;
+    wave_sync(); // (the previous stage's row reads are done)
+#pragma unroll
+    for (int q = 0; q < VO::NCH; ++q) {
+      const int e = 64 * q + lane;
+      if (64 * q + 63 < VO::NP2 || e < VO::NP2)
+        *reinterpret_cast<double2_t *>(&vb[2 * e]) = S.vp[GAR_VXX_PACKED ? q : 0];
+    }
+    wave_sync();
+  }
   // u = kff + K x ; x' = yff + Aff x   (:334-336, :360-361); two accumulators
   double acc = S.ff, acc1 = 0.0;
 #pragma unroll
@@ -757,10 +769,27 @@ __device__ __forceinline__ double fwd_step(const MfmaFwdParams &P, double *sol, 
   }
   // lbd' = vx' + Vxx' x'  (:369-371); x'_j sits in lane NU + j
   double lam = S.vxn, lam1 = 0.0;
+  if (GAR_VXX_PACKED) {
+    // row iv of the symmetric matrix from its packed lower triangle (gar_sym_index): elements (iv, j), j <= iv, at
+    // cj + iv (consecutive lanes, consecutive addresses); (j, iv), j > iv, at lowbase + j
+    const int lowbase = 2 * iv < NX ? iv * NX : (NX - 1 - iv) * (NX + 1) + 1;
+    double vr[NX];
 #pragma unroll
-  for (int j = 0; j < NX; j += 2) {
-    lam = __builtin_fma(S.vrow[j], lane_bcast(acc, NU + j), lam);
-    lam1 = __builtin_fma(S.vrow[j + 1], lane_bcast(acc, NU + j + 1), lam1);
+    for (int j = 0; j < NX; ++j) {
+      const int cj = 2 * j < NX ? j * NX : (NX - 1 - j) * (NX + 1) + 1;
+      vr[j] = vb[iv >= j ? cj + iv : lowbase + j];
+    }
+#pragma unroll
+    for (int j = 0; j < NX; j += 2) {
+      lam = __builtin_fma(vr[j], lane_bcast(acc, NU + j), lam);
+      lam1 = __builtin_fma(vr[j + 1], lane_bcast(acc, NU + j + 1), lam1);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NX; j += 2) {
+      lam = __builtin_fma(S.vrow[GAR_VXX_PACKED ? 0 : j], lane_bcast(acc, NU + j), lam);
+      lam1 = __builtin_fma(S.vrow[GAR_VXX_PACKED ? 0 : j + 1], lane_bcast(acc, NU + j + 1), lam1);
+    }
   }
   lam += lam1;
   if (lane < NX)
@@ -786,6 +815,7 @@ __global__ void __launch_bounds__(64) gar_forward_mfma(MfmaFwdParams P) {
   const int iv = lane < NX ? lane : NX - 1; // row of Vxx'
   // the state lives in lanes NU .. NW-1 (where x' = yff + Aff x is produced)
   const int ix = (lane >= NU && lane < NW) ? lane - NU : 0;
+  double *vb = gar_smem; // nx (nx + 1) / 2 doubles of dynamic LDS (packed Vxx records: gar_forward_mfma_lds_bytes)
   FwdStage<NX, NC> SA, SB;
   fwd_load<NX, NU, NC>(P, fac, 0, r, iv, lane, SA);
   double xs = io[ix]; // x0 from the initial-stage solve (kkt0.ff)
@@ -796,12 +826,12 @@ __global__ void __launch_bounds__(64) gar_forward_mfma(MfmaFwdParams P) {
   int t = 0;
   for (; t + 1 < N; t += 2) {
     fwd_load<NX, NU, NC>(P, fac, t + 1, r, iv, lane, SB);
-    xs = fwd_step<NX, NU, NC>(P, sol, t, lane, xs, SA);
+    xs = fwd_step<NX, NU, NC>(P, sol, t, lane, xs, SA, vb, iv);
     fwd_load<NX, NU, NC>(P, fac, t + 2, r, iv, lane, SA);
-    xs = fwd_step<NX, NU, NC>(P, sol, t + 1, lane, xs, SB);
+    xs = fwd_step<NX, NU, NC>(P, sol, t + 1, lane, xs, SB, vb, iv);
   }
   if (t < N)
-    xs = fwd_step<NX, NU, NC>(P, sol, t, lane, xs, SA);
+    xs = fwd_step<NX, NU, NC>(P, sol, t, lane, xs, SA, vb, iv);
   if (NC > 0) { // terminal knot: v_N = zff + Z x_N (its record keeps the generic row-major layout)
     const double *recN = fac + P.fac_offN;
     const int i = lane < NC ? lane : NC - 1;
