@@ -639,8 +639,9 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // Vxx -> HBM, 16 B per lane.  PACK (the serial family with the gar_forward_mfma roll-out): the LOWER TRIANGLE of V
 // (LDS, pitch NX), rectangular packed (gar_layout.h: gar_sym_index) -- half the bytes of the full block,
 // contiguous.  Otherwise (the wide shapes, whose roll-out reads the full block): V as it is, linear.
-template <int NX, bool PACK> struct VxxOut {
+template <int NX, bool PACK, int PK = NX> struct VxxOut { // PK: pitch of V in LDS
   static_assert(!PACK || NX % 4 == 0, "packed Vxx: nx (nx + 1) / 2 must be even (16-byte stores)");
+  static_assert(NX % 2 == 0 && PK % 2 == 0, "16-byte pieces stay inside a column");
   static constexpr int NP2 = PACK ? NX * (NX + 1) / 4 : NX * NX / 2; // 16-byte pairs
   static constexpr int NCH = (NP2 + 63) / 64;                        // pairs per lane
   __device__ static __forceinline__ int lds_of(int p) { // LDS offset of packed element p
@@ -648,7 +649,7 @@ template <int NX, bool PACK> struct VxxOut {
     const bool first = k < NX - c;
     const int j = first ? c : NX - 1 - c;
     const int i = first ? c + k : j + k - (NX - c);
-    return i * NX + j;
+    return i * PK + j;
   }
   __device__ static __forceinline__ double2_t read(const double *V, int q, int lane) { // chunk q of this lane
     const int e = 64 * q + lane, ec = (64 * q + 63 < NP2 || e < NP2) ? e : NP2 - 1;
@@ -656,8 +657,11 @@ template <int NX, bool PACK> struct VxxOut {
     if constexpr (PACK) {
       v.x = V[lds_of(2 * ec)];
       v.y = V[lds_of(2 * ec + 1)];
-    } else {
+    } else if constexpr (PK == NX) {
       v = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
+    } else { // column (2 ec) / NX of the record = column of V, rows 2 ec % NX, + 1
+      const int col = (2 * ec) / NX, row = 2 * ec - col * NX;
+      v = *reinterpret_cast<const double2_t *>(&V[col * PK + row]);
     }
     return v;
   }
@@ -667,8 +671,9 @@ template <int NX, bool PACK> struct VxxOut {
       *reinterpret_cast<double2_t *>(&dst[2 * e]) = v;
   }
 };
-template <int NX, bool PACK = true> __device__ __forceinline__ void wave_flush_vxx(const double *V, double *dst, int lane) {
-  using VO = VxxOut<NX, PACK>;
+template <int NX, bool PACK = true, int PK = NX>
+__device__ __forceinline__ void wave_flush_vxx(const double *V, double *dst, int lane) {
+  using VO = VxxOut<NX, PACK, PK>;
   double2_t vbuf[VO::NCH];
 #pragma unroll
   for (int q = 0; q < VO::NCH; ++q) // all the LDS reads first (one latency), then the stores
@@ -678,9 +683,6 @@ template <int NX, bool PACK = true> __device__ __forceinline__ void wave_flush_v
     VO::write(dst, q, lane, vbuf[q]);
 }
 
-
-// one stage's gains in registers: [K; Aff] row r (fbT2: 16 B per lane), Vxx' row iv, ff, vx';
-// constrained stages: row NU + lane of [K; Z; Aff] (a Z row) in a second slot
 template <int NX, int NC = 0> struct FwdStage {
   double2_t g[NX / 2];
   double2_t gz[NC > 0 ? NX / 2 : 1];

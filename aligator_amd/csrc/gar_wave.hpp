@@ -57,9 +57,15 @@ template <int NX, int NU, int NC = 0> struct WaveCfg {
 #else
   static constexpr bool REM4 = (NX % 16 == 4) && (KST == 1);
 #endif
-  // V is kept unpadded (pitch NX): it then IS the column-major Vxx record, so the copy to HBM is
-  // linear; the 2-way bank conflicts this costs the operand reads are invisible beside 64-cycle MFMAs
-  static constexpr int PK = NX, PG = M::PG;
+  // Pitch of V in LDS: NX (unpadded).  Its MFMA operand reads V[(16 t + li) * PK + 4 s + lk] are 2-way bank conflicts
+  // (lanes li and li + 8); a pitch of NX + 2 makes them conflict-free ((PK li + lk) mod 32 is then a bijection) and
+  // is supported (-DGAR_V_PITCH_PAD=1: every flush is a gather with the pitch) -- measured in an A/B on one box,
+  // alternating launches: backward 11.25 ms padded against 11.07 ms unpadded (scripts/ab_vxx_packed.py): the
+  // conflicts hide behind the 64-cycle MFMAs they feed.  Not used.
+#ifndef GAR_V_PITCH_PAD
+#define GAR_V_PITCH_PAD 0
+#endif
+  static constexpr int PK = (GAR_V_PITCH_PAD && NX % 4 == 0) ? NX + 2 : NX, PG = M::PG;
   // tile row / register of H holding Shat^T row u = 4s' + lk (rows NX + u)
   __host__ __device__ static constexpr int shTile(int s) { return (NX + 4 * s) >> 4; }
   __host__ __device__ static constexpr int shReg(int s) { return ((NX + 4 * s) & 15) >> 2; }
@@ -1180,25 +1186,7 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
   GAR_WMARK(9)
   // ---- Vxx -> HBM, 16 B per lane: column-major and symmetric, or (PACKV: the serial family, gar_layout.h) the
   // packed lower triangle
-  static_assert(PK == NX, "V is stored exactly as the Vxx record");
-  if constexpr (PACKV) {
-    wave_flush_vxx<NX, true>(V, out + oVxx, lane);
-  } else {
-    constexpr int NCH = (NX * NX / 2 + 63) / 64;
-    double2_t vbuf[NCH];
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) { // all the LDS reads first (one latency), then the stores
-      const int e = 64 * q + lane;
-      const int ec = (64 * q + 63 < NX * NX / 2) ? e : (e < NX * NX / 2 ? e : NX * NX / 2 - 1);
-      vbuf[q] = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
-    }
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-      const int e = 64 * q + lane;
-      if (64 * q + 63 < NX * NX / 2 || e < NX * NX / 2)
-        *reinterpret_cast<double2_t *>(&out[oVxx + 2 * e]) = vbuf[q];
-    }
-  }
+  wave_flush_vxx<NX, PACKV, PK>(V, out + oVxx, lane);
   GAR_WMARK(10)
 #undef GAR_WMARK
 }
@@ -1338,7 +1326,7 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
   }
   if constexpr (PHASE < 2) {
     if (N > 0)
-      wave_flush_vxx<NX, GAR_VXX_PACKED && !M::WIDE>(V, vflush, lane);
+      wave_flush_vxx<NX, GAR_VXX_PACKED && !M::WIDE, PK>(V, vflush, lane);
   }
   // ---- initial stage (proximal-riccati.hxx:42-60), fused: kkt0 = [Vxx0 G0^T; G0 0] is
   // Bunch-Kaufman-factorised by this wave right away (packed lower triangle in LDS, read from

@@ -462,7 +462,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   double Bop[TX][KU]; // B of this knot as the A operand of Aff = A + B K: B[16ti+li][4s'+lk]
   double Bop4[KU];    // REM4: B[NX-4+i4][4s'+k4], the A operand of the 4x4x4 blocks
   // ---- memory work slotted behind the MFMAs of the tile columns tj < cR (list A) ----------------
-  using VO = VxxOut<NX, GAR_VXX_PACKED && !WIDE>;
+  using VO = VxxOut<NX, GAR_VXX_PACKED && !WIDE, PK>;
   constexpr int NCH = VO::NCH;
   constexpr int nA_flush = NCH + 2, nA_rows = NU, nA_bop = TX * KU + (C::REM4 ? KU : 0);
   constexpr int nA = nA_flush + nA_rows + nA_bop;

@@ -424,7 +424,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   // ---- Vxx -> HBM, 16 B per lane, the chunks alternate between the waves: column-major and symmetric for the wide
   // shapes, the packed lower triangle (gar_layout.h) where the roll-out is gar_forward_mfma ----
   {
-    using VO = VxxOut<NX, GAR_VXX_PACKED && !WIDE>;
+    using VO = VxxOut<NX, GAR_VXX_PACKED && !WIDE, PK>;
 #pragma unroll
     for (int q = W; q < VO::NCH; q += 2)
       VO::write(out + oVxx, q, lane, VO::read(V, q, lane));

@@ -12,6 +12,8 @@ nx, nu, N, batch = 36, 12, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
 libs = {"packed": os.path.join(ROOT, "aligator_amd", "libgar_hip.so"),
         "full": os.path.join(ROOT, "aligator_amd", "libgar_hip_vxxfull.so")}
+if len(sys.argv) > 2:   # any two builds: name=path name=path
+    libs = {a.split("=")[0]: os.path.join(ROOT, "aligator_amd", a.split("=")[1]) for a in sys.argv[2:]}
 solvers = {}
 for name, path in libs.items():
     s = BatchedRiccatiSolver(dims, nx, batch=batch, num_legs=1, device=0, lib_path=path)
@@ -34,5 +36,5 @@ for name, t in times.items():
           f"=> {batch / np.median(a.sum(1)) * 1e3:.0f} sweeps/s")
 # same answers
 x = [solvers[k].solution(0) for k in solvers]
-print("max |packed - full| over the solution of problem 0:",
+print("max difference between the two builds over the solution of problem 0:",
       max(float(np.abs(a - b).max()) for A, B in zip(*x) for a, b in zip(A, B) if a.size))
