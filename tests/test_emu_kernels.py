@@ -609,3 +609,44 @@ def test_wide_shape_in_leg_mode_segment_legs():
     probs = [synth.generate_lq_problem(70 + i, np.ones(56), 5, 56, 24, mode="W") for i in range(2)]
     s = pc.check_batched(probs, 1e-10, 1e-9, EMU, num_legs=2)
     assert s.kernel_name == "pair_leg<56,24>" and not s.padded
+
+
+def test_serial_family_keeps_vxx_as_its_packed_lower_triangle():
+    """The record format csrc/gar_layout.h documents (gar_sym_index): in the serial one-wave family the Vxx block of
+    a factor record holds the lower triangle, rectangular packed, in its first nx (nx + 1) / 2 doubles and nothing
+    else of the block is written -- read here straight from the (emulated) device record and compared with what
+    gar_hip_get_value unpacks; every stage incl. the terminal one, and after a cycleAppend (records move whole)."""
+    import ctypes as C
+    from aligator_amd.gar import BatchedRiccatiSolver
+    nx, nu, N = 12, 4, 5
+    prob = synth.generate_lq_problem(77, np.ones(nx), N, nx, nu, mode="W")
+    s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, lib_path=EMU)
+    assert s.kernel_name in ("wave<12,4>", "mfma<12,4>")
+    s.upload([prob])
+    fac = s.device_pointers()[1]
+    raw = (C.c_double * s.device_factors_doubles).from_address(fac)
+    np.frombuffer(raw, dtype=np.float64)[:] = -7.0          # sentinel: what the sweep does not write stays
+    s.backward(1e-10)
+    buf = np.frombuffer(raw, dtype=np.float64)
+
+    def sym_index(n, i, j):                                  # gar_layout.h: gar_sym_index(1, n, i, j)
+        a, b = max(i, j), min(i, j)
+        return b * (n + 1) + (a - b) if 2 * b < n else (n - 1 - b) * (n + 1) + (b + 1) + (a - b)
+
+    assert sorted(sym_index(nx, i, j) for j in range(nx) for i in range(j, nx)) == list(range(nx * (nx + 1) // 2))
+    for t in range(N + 1):
+        off = (C.c_int64 * 6)()
+        s._check(s._L.gar_hip_stage_offsets(s.handle, t, off))
+        nu_t = nu if t < N else 0
+        o_vxx = off[1] + (nu_t + nx) + (nu_t + nx) * nx      # ff | fb | Vxx (gar_factor_layout, nc = nth = 0)
+        Vxx = np.zeros((nx, nx), order="F")
+        vx = np.zeros(nx)
+        s._check(s._L.gar_hip_get_value(s.handle, 0, t, Vxx.ctypes.data_as(C.POINTER(C.c_double)),
+                                        vx.ctypes.data_as(C.POINTER(C.c_double)), None, None, None))
+        assert np.abs(Vxx - Vxx.T).max() == 0.0 and np.abs(Vxx).max() > 0
+        block = buf[o_vxx:o_vxx + nx * nx]
+        for j in range(nx):
+            for i in range(j, nx):
+                assert block[sym_index(nx, i, j)] == Vxx[i, j]
+        assert (block[nx * (nx + 1) // 2:] == -7.0).all()    # the other half of the block is never touched
+    s.close()
