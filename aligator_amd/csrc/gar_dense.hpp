@@ -147,7 +147,10 @@ __global__ void __launch_bounds__(256) gar_backward_dense(GenericParams P) {
     wg_bar(w);
     // 1. factorise  2. solve (:115, :142-144)
     if (n > 0) {
-      failed |= wg_bk_factor<GAR_PACKED_LOWER>(w, n, Kmat, n, sub, piv, ctrl);
+      if (P.dense.wk >= 0 && n >= 24 && n <= 128) // panel-blocked: pivot search by one wave, MFMA trailing updates
+        failed |= wg_bk_factor_blocked<GAR_PACKED_LOWER>(w, n, Kmat, n, sub, piv, ctrl, sm + P.dense.wk);
+      else
+        failed |= wg_bk_factor<GAR_PACKED_LOWER>(w, n, Kmat, n, sub, piv, ctrl);
       wg_bk_solve<GAR_PACKED_LOWER>(w, n, Kmat, n, sub, piv, Rm, rld, 1, rld);
     }
     // gains to the factor record (the reference's storage orders: fb, ft row-major)

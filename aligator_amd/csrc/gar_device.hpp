@@ -1426,4 +1426,309 @@ __device__ inline int wg_ldl_definite_factor(const WG &w, int n, double *a, int 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// BLOCKED Bunch-Kaufman, n <= 128 (core/bunchkaufman.hpp:172-344 is the reference's blocked path; LAPACK's dlasyf
+// is the scheme): the same pivot rule and the same stored form as wg_bk_factor, with the trailing matrix updated
+// once per PANEL instead of once per column.
+//   panel   wave 0 alone, lane l owns rows l and l + 64, everything in LDS, wave barriers only.  Column k is brought
+//           up to date on demand, w = A(k:, k) - L(k:, panel) W(k, panel)^T (W = L D: the columns as they were when
+//           they were eliminated); the pivot search looks at w (and, when the diagonal fails the first test, at the
+//           candidate column brought up to date the same way); interchanges swap rows of the stored A, of EVERY
+//           column of L to the left (so that no pass over L is left for the end) and of W; the pivot column(s) are
+//           scaled into L, kept unscaled in W.
+//   update  all waves: A22 -= L21 W21^T on the lower tiles, f64 MFMA (K = panel width <= 8).
+// Sums are dot products here and a sequence of rank-1 updates in the unblocked code: the factors agree to rounding
+// -- and a pivot decision can differ where two candidates tie to rounding (either is a valid Bunch-Kaufman step).
+// wk: n x GAR_BK_PANEL doubles of LDS.  Returns 0, or 1 on an exactly-zero pivot column.  Ends with a barrier.
+#define GAR_BK_PANEL 8
+template <int MODE = GAR_COLMAJOR>
+__device__ inline int wg_bk_factor_blocked(const WG &w, int n, double *a, int lda, double *subdiag, int *piv, int *ctrl,
+                                           double *wk) {
+#define GA(i, j) a[bk_idx<MODE>((i), (j), lda)]
+#define WK(i, c) wk[(i) + (c) * n]
+  constexpr int NBP = GAR_BK_PANEL;
+  const double alpha = (1.0 + 4.123105625617661) / 8.0; // (1+sqrt(17))/8
+  if (w.tid == 0) {
+    ctrl[0] = 0; // next column
+    ctrl[1] = 0; // columns of W filled by the panel just finished
+    ctrl[2] = 0; // info
+  }
+  __syncthreads();
+  const int li = w.lane & 15, lk = w.lane >> 4;
+  int k = 0;
+  while (k < n) {
+    const int p = k; // first column of this panel
+    if (w.wave == 0) {
+      const int l = w.lane;
+      int kw = 0, info = 0;
+      while (k < n && kw < NBP - 1) {
+        // ---- column k brought up to date: wv[q] = row l + 64 q of w (rows >= k)
+        // (every operand of the panel-wide dot products is requested before the first is used: unconditional loads
+        // from clamped addresses, selected afterwards)
+        double wv[2], w2[2], lrow[2][NBP - 1];
+        {
+          double wrow[NBP - 1], a0[2];
+#pragma unroll
+          for (int c = 0; c < NBP - 1; ++c)
+            wrow[c] = WK(k, c < kw ? c : 0);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int i = l + 64 * q;
+            const int ic = (i >= k && i < n) ? i : k;
+            a0[q] = GA(ic, k);
+#pragma unroll
+            for (int c = 0; c < NBP - 1; ++c)
+              lrow[q][c] = GA(ic, p + (c < kw ? c : 0)); // this lane's rows of the panel's L: used again below
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int i = l + 64 * q;
+            double s = a0[q];
+#pragma unroll
+            for (int c = 0; c < NBP - 1; ++c)
+              s -= c < kw ? lrow[q][c] * wrow[c] : 0.0;
+            wv[q] = (i >= k && i < n) ? s : 0.0;
+          }
+        }
+        // ---- pivot search (bunchkaufman.hpp:46-83)
+        const double wkk = bk_bcast(k < 64 ? wv[0] : wv[1], k & 63);
+        const double abs_akk = fabs(wkk);
+        double bv = -1.0;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int i = l + 64 * q;
+          if (i > k && i < n && fabs(wv[q]) > bv) {
+            bv = fabs(wv[q]);
+            bi = i;
+          }
+        }
+        double colmax = wave_max_f64(bv);
+        int imax = k + 1;
+        if (colmax < 0.0) {
+          colmax = 0.0;
+        } else { // first row attaining it (the reference's strict ">" scan)
+          unsigned long long hit = __ballot(bv == colmax);
+          imax = 0x7fffffff;
+          while (hit) {
+            const int src = (int)__builtin_ctzll(hit);
+            const int cand = __builtin_amdgcn_readlane(bi, src);
+            imax = cand < imax ? cand : imax;
+            hit &= hit - 1;
+          }
+        }
+        int k_step = 1, kp = k;
+        bool use_w2 = false; // the pivot column (kp = imax, 1x1) / the second pivot column (2x2) is w2
+        if (fmax(abs_akk, colmax) == 0.0) {
+          info = 1;
+        } else if (!(abs_akk >= colmax * alpha)) {
+          // the candidate column imax of the symmetric trailing matrix, brought up to date
+          double wrow[NBP - 1];
+#pragma unroll
+          for (int c = 0; c < NBP - 1; ++c)
+            wrow[c] = WK(imax, c < kw ? c : 0);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int i = l + 64 * q;
+            const bool in = i >= k && i < n;
+            const int ic = in ? i : k;
+            double s = GA(ic >= imax ? ic : imax, ic >= imax ? imax : ic);
+#pragma unroll
+            for (int c = 0; c < NBP - 1; ++c)
+              s -= c < kw ? lrow[q][c] * wrow[c] : 0.0;
+            w2[q] = in ? s : 0.0;
+          }
+          double rv = 0.0;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int i = l + 64 * q;
+            if (i >= k && i < n && i != imax)
+              rv = fmax(rv, fabs(w2[q]));
+          }
+          const double rowmax = wave_max_f64(rv);
+          const double abs_aii = fabs(bk_bcast(imax < 64 ? w2[0] : w2[1], imax & 63));
+          if (abs_akk >= (alpha * colmax) * (colmax / rowmax)) {
+            kp = k;
+          } else if (abs_aii >= alpha * rowmax) {
+            kp = imax;
+            use_w2 = true;
+          } else {
+            kp = imax;
+            k_step = 2;
+            use_w2 = true;
+          }
+        }
+        if (info) { // NumericalIssue: keep the remaining pivots in range and stop
+          for (int i = k + l; i < n; i += 64)
+            piv[i] = i;
+          break;
+        }
+        if (k_step == 1 && use_w2) { // the pivot column is column imax
+          wv[0] = w2[0];
+          wv[1] = w2[1];
+        }
+        const int kk = k + k_step - 1;
+        if (kp != kk) { // ---- symmetric interchange of kk and kp (:86-102), lazily updated storage
+          wave_sync();
+          // the stored (not yet updated) column kk moves to where row / column kp lives
+          for (int i = kk + 1 + l; i < n; i += 64) {
+            if (i < kp)
+              GA(kp, i) = GA(i, kk);
+            else if (i > kp)
+              GA(i, kp) = GA(i, kk);
+          }
+          if (l == 0)
+            GA(kp, kp) = GA(kk, kk);
+          // rows kk and kp of every column of L to the left, and of W
+          for (int c = l; c < k; c += 64) {
+            const double t = GA(kk, c);
+            GA(kk, c) = GA(kp, c);
+            GA(kp, c) = t;
+          }
+          if (l < kw) {
+            const double t = WK(kk, l);
+            WK(kk, l) = WK(kp, l);
+            WK(kp, l) = t;
+          }
+          // ... and of the working columns
+          {
+            const double akk0 = bk_bcast(kk < 64 ? wv[0] : wv[1], kk & 63), akp0 = bk_bcast(kp < 64 ? wv[0] : wv[1], kp & 63);
+            if (l == (kk & 63))
+              wv[kk >> 6] = akp0;
+            if (l == (kp & 63))
+              wv[kp >> 6] = akk0;
+            if (k_step == 2) {
+              const double bkk0 = bk_bcast(kk < 64 ? w2[0] : w2[1], kk & 63), bkp0 = bk_bcast(kp < 64 ? w2[0] : w2[1], kp & 63);
+              if (l == (kk & 63))
+                w2[kk >> 6] = bkp0;
+              if (l == (kp & 63))
+                w2[kp >> 6] = bkk0;
+            }
+          }
+          wave_sync();
+        }
+        // ---- the pivot column(s): L into A, the unscaled columns into W
+        if (k_step == 1) { // :104-121
+          const double d = bk_bcast(k < 64 ? wv[0] : wv[1], k & 63);
+          const double d11 = 1.0 / d;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int i = l + 64 * q;
+            if (i >= k && i < n) {
+              WK(i, kw) = wv[q];
+              GA(i, k) = i == k ? d11 : wv[q] * d11;
+            }
+          }
+          if (l == 0)
+            piv[k] = kp;
+          kw += 1;
+        } else { // 2x2 pivot, :122-149: columns k (wv) and k + 1 (w2)
+          const double akk = bk_bcast(k < 64 ? wv[0] : wv[1], k & 63);
+          const double ak1k = bk_bcast(k + 1 < 64 ? wv[0] : wv[1], (k + 1) & 63);
+          const double ak1k1 = bk_bcast(k + 1 < 64 ? w2[0] : w2[1], (k + 1) & 63);
+          const double d21_abs = fabs(ak1k), d21_inv = 1.0 / d21_abs;
+          const double d11 = d21_inv * ak1k1, d22 = d21_inv * akk;
+          const double t = 1.0 / ((d11 * d22) - 1.0), d = t * d21_inv, d21 = ak1k * d21_inv;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int i = l + 64 * q;
+            if (i >= k && i < n) {
+              WK(i, kw) = wv[q];
+              WK(i, kw + 1) = i > k ? w2[q] : ak1k; // (row k of column k + 1: the symmetric element)
+              if (i > k + 1) {
+                GA(i, k) = ((wv[q] * d11) - (w2[q] * d21)) * d;
+                GA(i, k + 1) = ((w2[q] * d22) - (wv[q] * d21)) * d;
+              }
+            }
+          }
+          if (l == 0) { // the inverse of the 2x2 block, as wg_bk_factor stores it
+            GA(k, k) = d11 * d;
+            GA(k + 1, k) = -d21 * d;
+            GA(k + 1, k + 1) = d22 * d;
+            piv[k] = -1 - kp;
+            piv[k + 1] = -1 - kp;
+          }
+          kw += 2;
+        }
+        k += k_step;
+        wave_sync();
+      }
+      if (l == 0) {
+        ctrl[0] = info ? n : k;
+        ctrl[1] = kw;
+        ctrl[2] |= info;
+      }
+    }
+    __syncthreads();
+    k = ctrl[0];
+    const int kw = ctrl[1];
+    if (ctrl[2])
+      break;
+    // ---- trailing update: A(i, j) -= sum_c L(i, p + c) W(j, c), i >= j >= k, lower tiles
+    const int m = n - k;
+    if (m > 0 && kw > 0) {
+      const int tM = (m + 15) >> 4, nt = tM * (tM + 1) / 2;
+      for (int t = w.wave; t < nt; t += w.nwaves) {
+        int ti = 0, rest = t;
+        while (rest > ti) {
+          rest -= ti + 1;
+          ++ti;
+        }
+        const int i0 = ti << 4, col = (rest << 4) + li, ai = i0 + li;
+        const int colc = col < m ? col : m - 1, aic = ai < m ? ai : m - 1;
+        double4_t acc;
+        int rows[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + lk + 4 * r;
+          rows[r] = row < m ? row : m - 1;
+          const int hi = rows[r] >= colc ? rows[r] : colc, lo = rows[r] >= colc ? colc : rows[r];
+          acc[r] = GA(k + hi, k + lo);
+        }
+        double av[NBP / 4], bv[NBP / 4];
+#pragma unroll
+        for (int q = 0; q < NBP / 4; ++q) {
+          const int c = 4 * q + lk, cc = c < kw ? c : kw - 1;
+          const double lv = GA(k + aic, p + cc), wvv = WK(k + colc, cc);
+          av[q] = (ai < m && c < kw) ? -lv : 0.0;
+          bv[q] = (col < m && c < kw) ? wvv : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < NBP / 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + lk + 4 * r;
+          if (row < m && col < m && row >= col)
+            GA(k + row, k + col) = acc[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int info = ctrl[2];
+  __syncthreads();
+  // subdiag extraction (:393-404); the rows of L were interchanged as the pivots were chosen
+  for (int kq = w.tid; kq < n; kq += w.nthr)
+    subdiag[kq] = 0.0;
+  __syncthreads();
+  if (w.tid == 0) { // pairs are rare; a serial pass keeps the pairing unambiguous
+    int kq = 0;
+    while (kq < n) {
+      if (piv[kq] < 0) {
+        subdiag[kq] = GA(kq + 1, kq);
+        subdiag[kq + 1] = 0.0;
+        GA(kq + 1, kq) = 0.0;
+        kq += 2;
+      } else {
+        kq += 1;
+      }
+    }
+  }
+  __syncthreads();
+  return info;
+#undef GA
+#undef WK
+}
+
 } // namespace gar

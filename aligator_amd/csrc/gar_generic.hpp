@@ -28,6 +28,7 @@ struct LdsPlan {
   int V[2], v[2], Vxt[2], Vtt[2], vt[2];
   int lean; // 1: one buffer for the parameter blocks too; stage t reads Vxt', Vtt', vt' from stage t+1's record
   int H, h, F, fv, P, vp, CD, dd, Gu, Guh, Gv, M, msub, piv, G, Yth, yff;
+  int bkw; // panel workspace of the blocked Bunch-Kaufman (nk x GAR_BK_PANEL), -1: none (nk > 128)
   int k0mat, k0rhs, k0sub, k0piv; // initial-stage KKT (aliases the stage buffers)
   int total;                      // doubles (backward kernel)
   int fx, fxn, fth, ftotal;       // forward kernel: x, x', theta
@@ -36,6 +37,7 @@ struct LdsPlan {
 // LDS of the stage-dense kernels (gar_dense.hpp): KKT matrix, right-hand sides, subdiagonal, pivots
 struct DensePlan {
   int K, R, sub, piv, total;
+  int wk; // panel workspace of the blocked Bunch-Kaufman (n x GAR_BK_PANEL), -1: none (n > 128 or no room)
 };
 
 struct GenericParams {
@@ -312,7 +314,12 @@ __global__ void __launch_bounds__(256) gar_backward_generic(GenericParams P) {
       }
       __syncthreads();
     } else {
-      failed |= wg_bk_factor(w, nk, Mk.p, nk, sm + L.msub, piv, ctrl);
+      // (from 24 columns on the panel-blocked factorisation pays: one wave runs the pivot search, the trailing matrix
+      // is updated once per panel on MFMA tiles)
+      if (L.bkw >= 0 && nk >= 24 && nk <= 128)
+        failed |= wg_bk_factor_blocked(w, nk, Mk.p, nk, sm + L.msub, piv, ctrl, sm + L.bkw);
+      else
+        failed |= wg_bk_factor(w, nk, Mk.p, nk, sm + L.msub, piv, ctrl);
       wg_bk_solve(w, nk, Mk.p, nk, sm + L.msub, piv, G.p, gld, 1, gld);
     }
 

@@ -399,6 +399,12 @@ replan:
   L.k0sub = take(n0);
   L.k0piv = take(264);
   L.total = std::max(stage_end, p);
+  // panel workspace of the blocked Bunch-Kaufman, behind everything -- where there is room for it
+  L.bkw = -1;
+  if (nkM <= 128 && (size_t)(L.total + align2(nkM * GAR_BK_PANEL)) * sizeof(double) <= 160 * 1024) {
+    L.bkw = L.total;
+    L.total += align2(nkM * GAR_BK_PANEL);
+  }
   if (!L.lean && nthM > 0 && (size_t)L.total * sizeof(double) > 160 * 1024) {
     L.lean = 1; // one generation of the parameter blocks in LDS, the other read back from the records
     goto replan;
@@ -421,6 +427,9 @@ replan:
     D.R = take(nM * rldM);
     D.sub = take(nM);
     D.piv = take(264);
+    D.wk = -1;
+    if (nM <= 128 && (int64_t)(p + nM * GAR_BK_PANEL) * 8 <= 160 * 1024)
+      D.wk = take(nM * GAR_BK_PANEL);
     const int stage_total = p;
     p = 0; // the initial stage reuses the buffer from its start (gar_backward_dense)
     take(n0 * n0);

@@ -18,7 +18,7 @@ def load_emu():
     return ctypes.CDLL(os.path.join(HERE, "emu", "_build", "libgar_ldl_unit_emu.so"))
 
 
-def run_unit(lib, A, X, definite_first, x_rowmajor=False):
+def run_unit(lib, A, X, definite_first, x_rowmajor=False, blocked=0):
     n, nc = A.shape[0], X.shape[1]
     a = np.asfortranarray(A, dtype=np.float64).copy(order="F")
     x = np.array(X, dtype=np.float64, order="C" if x_rowmajor else "F")
@@ -27,7 +27,7 @@ def run_unit(lib, A, X, definite_first, x_rowmajor=False):
     info = np.zeros(4, dtype=np.int32)
     dp = ctypes.POINTER(ctypes.c_double)
     ip = ctypes.POINTER(ctypes.c_int)
-    rc = lib.gar_ldl_unit(n, nc, int(definite_first), int(x_rowmajor), a.ctypes.data_as(dp), x.ctypes.data_as(dp),
+    rc = lib.gar_ldl_unit(n, nc, int(definite_first), int(x_rowmajor), int(blocked), a.ctypes.data_as(dp), x.ctypes.data_as(dp),
                           sub.ctypes.data_as(dp), piv.ctypes.data_as(ip), info.ctypes.data_as(ip))
     assert rc == 0
     return a, x, sub, piv, info
@@ -123,6 +123,9 @@ def test_ldl_building_blocks_on_the_gpu():
         test_wrong_sign_pivot_sends_the_block_to_bunch_kaufman(n, ncols, lib=lib)
     for n, ncols in [(16, 16), (44, 45), (56, 57), (116, 37)]:
         test_blocked_substitution_with_interchanges_and_2x2_pivots(n, ncols, lib=lib)
+    for n, ncols, kind in [(44, 45, "kkt"), (72, 20, "kkt"), (116, 37, "dense-stage"), (128, 16, "random")]:
+        for packed in (False, True):
+            test_blocked_bunch_kaufman_matches_the_unblocked_one(n, ncols, kind, packed, lib=lib)
 
 
 @pytest.mark.gpu
@@ -144,3 +147,88 @@ def test_ldl_building_block_cycles_are_reported():
             rows.append(("definite" if definite else "bunch-kaufman", int(best[0]), int(best[1])))
         print(f"n={n} ncols={ncols}: " + "; ".join(f"{k}: factor {f} solve {s_} cycles" for k, f, s_ in rows))
         assert all(f > 0 for _, f, _ in rows)
+    for n, ncols, kind in [(44, 45, "kkt"), (72, 1, "kkt"), (116, 37, "dense-stage")]:
+        A = indefinite(np.random.default_rng(3), n, kind)
+        X0 = rng.standard_normal((n, ncols))
+        rows = []
+        for name, blocked in (("column at a time", 0), ("blocked", 1), ("blocked, packed", 2)):
+            best = None
+            for _ in range(3):
+                info = run_unit(lib, A, X0, False, blocked=blocked)[4]
+                best = info[2:4] if best is None else np.minimum(best, info[2:4])
+            rows.append((name, int(best[0]), int(best[1])))
+        print(f"indefinite n={n} ({kind}): " + "; ".join(f"{k}: factor {f} solve {s_} cycles" for k, f, s_ in rows))
+
+
+def indefinite(rng, n, kind):
+    if kind == "kkt":                       # [[H, J^T], [J, -eps I]] with a zero leading block in H
+        m = n // 3
+        A = np.zeros((n, n))
+        A[:n - m, :n - m] = spd(rng, n - m, 50.0)
+        A[:m, :m] = 0.0
+        J = rng.standard_normal((m, n - m))
+        A[n - m:, :n - m] = J
+        A[:n - m, n - m:] = J.T
+        A[n - m:, n - m:] = -1e-3 * np.eye(m)
+        return A
+    if kind == "random":                    # dense symmetric indefinite
+        B = rng.standard_normal((n, n))
+        return B + B.T
+    if kind == "dense-stage":               # the stage-dense solver's matrix (csrc/gar_dense.hpp), nu, nc, nx
+        nu, nc = n // 8, n // 4
+        nx = (n - nu - nc) // 2
+        n2 = nu + nc + 2 * nx
+        A = np.zeros((n, n))
+        A[:nu, :nu] = spd(rng, nu, 10.0)
+        D = rng.standard_normal((nc, nu)); Bm = rng.standard_normal((nx, nu))
+        A[nu:nu + nc, :nu] = D; A[:nu, nu:nu + nc] = D.T
+        A[nu:nu + nc, nu:nu + nc] = -1e-8 * np.eye(nc)
+        o2, o3 = nu + nc, nu + nc + nx
+        A[o2:o3, :nu] = Bm; A[:nu, o2:o3] = Bm.T
+        A[o3:o3 + nx, o2:o3] = -np.eye(nx); A[o2:o3, o3:o3 + nx] = -np.eye(nx)
+        A[o3:o3 + nx, o3:o3 + nx] = spd(rng, nx, 100.0)
+        for i in range(n2, n):
+            A[i, i] = 1.0 + i
+        return A
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("n,ncols,kind", [(9, 3, "random"), (16, 16, "kkt"), (44, 45, "kkt"), (44, 37, "random"),
+                                          (72, 1, "random"), (72, 20, "kkt"), (116, 37, "dense-stage"),
+                                          (128, 16, "random"), (100, 5, "kkt")])
+@pytest.mark.parametrize("packed", [False, True])
+def test_blocked_bunch_kaufman_matches_the_unblocked_one(n, ncols, kind, packed, lib=None):
+    """wg_bk_factor_blocked (panel by one wave, MFMA trailing update) against wg_bk_factor (column at a time): the
+    same pivots, factors equal to rounding, the same solution"""
+    lib = lib or load_emu()
+    rng = np.random.default_rng(1000 * n + ncols)
+    A = indefinite(rng, n, kind)
+    X0 = rng.standard_normal((n, ncols))
+    a1, x1, sub1, piv1, info1 = run_unit(lib, A, X0, False, blocked=2 if packed else 1)
+    a2, x2, sub2, piv2, info2 = run_unit(lib, A, X0, False, blocked=0)
+    assert info1[1] == 0 and info2[1] == 0
+    assert (piv1 == piv2).all(), (piv1, piv2)
+    if kind != "random" or n > 9:
+        assert (piv1 < 0).any() or (piv1 != np.arange(n)).any()      # the case does pivot
+    L1, L2 = np.tril(a1), np.tril(a2)
+    tol = max(1e-9, 50 * np.linalg.cond(A) * np.finfo(float).eps)   # the two orders of summation: cond * eps apart
+    assert np.abs(L1 - L2).max() <= tol * max(1.0, np.abs(L2).max())
+    assert np.abs(sub1 - sub2).max() <= tol * max(1.0, np.abs(sub2).max())
+    ref = np.linalg.solve(A, X0)
+    scale = np.abs(ref).max()
+    assert np.abs(x1 - ref).max() <= 10 * tol * scale and np.abs(x1 - x2).max() <= 10 * tol * scale
+    assert np.abs(x1 - ref).max() <= 3 * max(np.abs(x2 - ref).max(), 1e-12 * scale)   # as accurate as the unblocked one
+    check_solution(A, X0, x1, 1e-11)
+
+
+def test_blocked_bunch_kaufman_reports_a_zero_column():
+    lib = load_emu()
+    rng = np.random.default_rng(5)
+    A = indefinite(rng, 20, "random")
+    A[7:, 7:] = 0.0                          # after seven steps... not necessarily zero: make the WHOLE matrix zero from a column on
+    A[:, :] = 0.0
+    A[:3, :3] = spd(rng, 3)
+    X0 = rng.standard_normal((20, 4))
+    for blocked in (0, 1):
+        info = run_unit(lib, A, X0, False, blocked=blocked)[4]
+        assert info[1] == 1                  # NumericalIssue (bunchkaufman.hpp:58-59)
