@@ -164,27 +164,23 @@ __global__ void __launch_bounds__(256) gar_backward_dense(GenericParams P) {
       else
         fr[fo.fth + i * nth + (c - 1 - nx)] = v;
     }
-    // 3. value function (:150-171 ; terminal :81-97).  R(i, c) = Rm[i * rld + c].
-    for (int e = w.tid; e < nx * (nx + 1); e += w.nthr) {
-      const int j = e / nx, i = e - j * nx; // column j < nx: Pxx(:, j); column nx: px
-      const int c = (j < nx) ? 1 + j : 0;
-      double s = (j < nx) ? k[ko.Q + e] : k[ko.q + i];
-      const double *Si = k + ko.S + i, *Ci = k + ko.C + i * nc, *Ai = k + ko.A + i * nx2;
-#pragma unroll 4
-      for (int r = 0; r < nu; ++r)
-        s += Si[r * nx] * RR(r, c); // S K
-#pragma unroll 4
-      for (int r = 0; r < nc; ++r)
-        s += Ci[r] * RR(o1 + r, c); // C^T Z
+    // 3. value function (:150-171 ; terminal :81-97).  R(i, c) = Rm[i * rld + c]:
+    //   [px | Pxx] = [q | Q] + S [kff | K] + C^T [zff | Z] (+ A^T [lff | L])      on f64 MFMA tiles (wg_gemm), the
+    // left factors read from the knot record in place (S column-major; C^T, A^T as transposed views), accumulating
+    // in the factor record: a tile is read back by the thread that wrote it, so the three products need no barrier
+    {
+      const MatV Pxx = colmajor(fr + fo.Vxx, nx), px = colmajor(fr + fo.vx, nx);
+      const MatV Sm = colmajor(const_cast<double *>(k) + ko.S, nx);
+      const MatV Ct = MatV{const_cast<double *>(k) + ko.C, nc, 1}, At = MatV{const_cast<double *>(k) + ko.A, nx2, 1};
+      const MatV Rg = rowmajor(Rm, rld); // rows: u (nu), v (nc), lambda' (nx2), x' (nx2); columns: ff | fb | ft
+      wg_gemm(w, nx, nx, nu, Sm, Rg.sub(0, 1), colmajor(const_cast<double *>(k) + ko.Q, nx), Pxx, 1.0);
+      wg_gemm(w, nx, 1, nu, Sm, Rg.sub(0, 0), colmajor(const_cast<double *>(k) + ko.q, nx), px, 1.0);
+      wg_gemm(w, nx, nx, nc, Ct, Rg.sub(o1, 1), Pxx, Pxx, 1.0);
+      wg_gemm(w, nx, 1, nc, Ct, Rg.sub(o1, 0), px, px, 1.0);
       if (!term) {
-#pragma unroll 4
-        for (int r = 0; r < nx2; ++r)
-          s += Ai[r] * RR(o2 + r, c); // A^T L
+        wg_gemm(w, nx, nx, nx2, At, Rg.sub(o2, 1), Pxx, Pxx, 1.0);
+        wg_gemm(w, nx, 1, nx2, At, Rg.sub(o2, 0), px, px, 1.0);
       }
-      if (j < nx)
-        fr[fo.Vxx + e] = s;
-      else
-        fr[fo.vx + i] = s;
     }
     if (nth > 0) {
       const bool stored = (m.flags & GAR_KNOT_HAS_PARAM) != 0;
