@@ -107,25 +107,42 @@ __device__ inline void wg_gemm(const WG &w, int M, int N, int K, MatV A, MatV B,
   const int tN = (N + 15) >> 4;
   const int nt = ((M + 15) >> 4) * tN;
   const int li = w.lane & 15, lk = w.lane >> 4;
+  int ti = 0, tj = w.wave; // tile (ti, tj) of this wave: t = ti tN + tj, advanced without divisions
+  while (tj >= tN) {
+    tj -= tN;
+    ++ti;
+  }
   for (int t = w.wave; t < nt; t += w.nwaves) {
-    const int i0 = (t / tN) << 4, j0 = (t % tN) << 4;
+    const int i0 = ti << 4, j0 = tj << 4;
     const int col = j0 + li;
+    // Every load is unconditional, from a clamped address, and selected afterwards: a conditional load is a branch
+    // (the compiler may not speculate it), and a branch per operand serialises the round trips.
+    const int colc = col < N ? col : N - 1;
     double4_t acc;
+    if (C0.p != nullptr) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = i0 + lk + 4 * r;
-      acc[r] = (C0.p != nullptr && row < M && col < N) ? C0(row, col) : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r;
+        acc[r] = C0(row < M ? row : M - 1, colc);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[r] = 0.0;
     }
-    const int ai = i0 + li;
+    const int ai = i0 + li, aic = ai < M ? ai : M - 1;
     const bool aok = ai < M, bok = col < N;
+    const double *ap = &A(aic, 0), *bp = &B(0, colc);
     // (the operands of four k-steps are requested together: one LDS / L2 round trip per 16 columns of A, not four)
     for (int k0 = 0; k0 < K; k0 += 16) {
       double a[4], b[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int k = k0 + 4 * q + lk;
-        a[q] = (aok && k < K) ? sgn * A(ai, k) : 0.0;
-        b[q] = (bok && k < K) ? B(k, col) : 0.0;
+        const int k = k0 + 4 * q + lk, kc = k < K ? k : K - 1;
+        a[q] = ap[kc * A.cs];
+        b[q] = bp[kc * B.rs];
+        a[q] = (aok && k < K) ? sgn * a[q] : 0.0;
+        b[q] = (bok && k < K) ? b[q] : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -137,6 +154,11 @@ __device__ inline void wg_gemm(const WG &w, int M, int N, int K, MatV A, MatV B,
       const int row = i0 + lk + 4 * r;
       if (row < M && col < N)
         D(row, col) = acc[r];
+    }
+    tj += w.nwaves; // next tile of this wave
+    while (tj >= tN) {
+      tj -= tN;
+      ++ti;
     }
   }
 }

@@ -868,7 +868,12 @@ __device__ long long g_ctrace[16];
 #else
 #define CT(id)
 #endif
-__global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) {
+// (GAR_CONDENSED_THREADS threads: 16 waves share the copies, the tiles of the products and the strips of the
+// substitutions; the panel factorisation stays one wave's work)
+#ifndef GAR_CONDENSED_THREADS
+#define GAR_CONDENSED_THREADS 1024
+#endif
+__global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(CondensedParams P) {
 #ifdef GAR_CTRACE
   long long tprev = clock64();
 #endif
@@ -1113,10 +1118,11 @@ __global__ void __launch_bounds__(256) gar_condensed_generic(CondensedParams P) 
     mx = wave_max_f64(mx);
     __syncthreads(); // (sol's copy in LDS has been read by everyone)
     if (w.lane == 0)
-      lsub[w.wave] = mx;
+      sm[w.wave] = mx; // (the copy of sol in LDS is dead)
     __syncthreads();
     for (int q = 0; q < w.nwaves; ++q)
-      mx = fmax(mx, lsub[q]);
+      mx = fmax(mx, sm[q]);
+    __syncthreads();
     resdl = mx;
     if (resdl <= P.threshold)
       break;

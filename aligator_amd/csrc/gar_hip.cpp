@@ -1110,7 +1110,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     Q.nxb = s->nxb;
     Q.nxM = s->dims5[0];
     Q.nuM = s->dims5[1];
-    hipLaunchKernelGGL(gar::gar_leg_param_generic, grid, dim3(256), (size_t)s->seg_param_lds_doubles * sizeof(double),
+    hipLaunchKernelGGL(gar::gar_leg_param_generic, grid, dim3(GAR_LEG_PARAM_THREADS), (size_t)s->seg_param_lds_doubles * sizeof(double),
                        s->stream, Q);
     HIP_TRY(hipGetLastError());
     if (s->timing)
@@ -1324,7 +1324,7 @@ int launch_condensed(gar_hip_solver *s) {
     hipLaunchKernelGGL(s->cond_wave_kernel, dim3((unsigned)s->batch), dim3(64),
                        (size_t)s->cond_wave_lds_doubles * sizeof(double), s->stream, C);
   else
-    hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(256),
+    hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
                        (size_t)s->cond_lds_doubles * sizeof(double), s->stream, C);
   HIP_TRY(hipGetLastError());
   if (s->timing) // leg mode: the "initial stage" slot of the timing API is the condensed solve
@@ -2604,6 +2604,12 @@ extern "C" int gar_hip_debug_ctrace(long long *out) {
   long long z[16] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_ctrace), sizeof(z)) != hipSuccess) return 1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_ctrace), z, sizeof(z)) != hipSuccess) return 2;
+  return 0;
+}
+extern "C" int gar_hip_debug_ptrace(long long *out) {
+  long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_ptrace), sizeof(z)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_ptrace), z, sizeof(z)) != hipSuccess) return 2;
   return 0;
 }
 #endif

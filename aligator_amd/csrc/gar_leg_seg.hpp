@@ -109,8 +109,30 @@ __host__ __device__ inline int leg_param_lds_doubles(int nx, int nu) {
   return 4 * a2(nx * nx) + 3 * a2(nx * nu) + a2(nu * nx) + a2(nu * nu) + 2 * a2(nu) + 3 * a2(nx) + 64;
 }
 
-// grid (local legs, batch) x 256
-__global__ void __launch_bounds__(256) gar_leg_param_generic(LegParamParams P) {
+// (debug build -DGAR_CTRACE: cycles per phase of workgroup (0, 0), read with gar_hip_debug_ptrace)
+#ifdef GAR_CTRACE
+__device__ long long g_ptrace[16];
+#define PT(id)                                                                                                         \
+  {                                                                                                                    \
+    __syncthreads();                                                                                                   \
+    const long long now_ = clock64();                                                                                  \
+    if (w.tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)                                                              \
+      g_ptrace[id] += now_ - tprev;                                                                                    \
+    tprev = now_;                                                                                                      \
+  }
+#else
+#define PT(id)
+#endif
+// grid (local legs, batch) x GAR_LEG_PARAM_THREADS
+// (GAR_LEG_PARAM_THREADS threads: the copies between HBM and LDS and the tiles of the products spread over 8 waves;
+// the panel factorisation and the in-block substitutions stay one wave's work)
+#ifndef GAR_LEG_PARAM_THREADS
+#define GAR_LEG_PARAM_THREADS 1024
+#endif
+__global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_generic(LegParamParams P) {
+#ifdef GAR_CTRACE
+  long long tprev = clock64();
+#endif
   const WG w = wg_self();
   double *sm = gar_smem;
   const int leg = (int)blockIdx.x + P.leg_begin, b = (int)blockIdx.y;
@@ -158,6 +180,7 @@ __global__ void __launch_bounds__(256) gar_leg_param_generic(LegParamParams P) {
       const double *knot = prob + m.in_off;
       const double *src = fac2 + P.meta2[t].fac_off;
       double *dst = fac + m.fac_off;
+      PT(0)
       // operands: B (nx2 x nu, column-major), Aff (rows nu.. of the row-major fb), yff, R; V' staged in Xn
       for (int e = w.tid; e < nx2 * nu; e += w.nthr)
         Bm[e] = knot[ko.B + e];
@@ -176,6 +199,7 @@ __global__ void __launch_bounds__(256) gar_leg_param_generic(LegParamParams P) {
         }
       }
       __syncthreads();
+      PT(1)
       const MatV B = colmajor(Bm, nx2), X = colmajor(Xt, nx2), G = rowmajor(Gh, nth), K = rowmajor(Kt, nth);
       if (!leg_end) { // Rhat = R + B^T (V' B)  (:221, :225)
         wg_gemm(w, nx2, nu, nx2, colmajor(Xn, nx2), B, MatV{nullptr, 0, 0}, colmajor(VB, nx2), 1.0);
@@ -185,6 +209,7 @@ __global__ void __launch_bounds__(256) gar_leg_param_generic(LegParamParams P) {
       // Ghat_u = B^T Vxt'  (:286-287)
       wg_gemm(w, nu, nth, nx2, B.T(), X, MatV{nullptr, 0, 0}, G, 1.0);
       __syncthreads();
+      PT(2)
       // Rhat = L D L^T (Bunch-Kaufman, the reference's factorisation); Kth = -Rhat^-1 Ghat_u  (:288-292)
       // (Rhat > 0 on a well-posed stage: blocked elimination without pivoting, workspace in VB, a copy of Rhat
       // parked in Kt for the stage that is not -- that one goes through Bunch-Kaufman as in the reference)
@@ -203,11 +228,13 @@ __global__ void __launch_bounds__(256) gar_leg_param_generic(LegParamParams P) {
       if (indefinite)
         failed |= wg_bk_factor(w, nu, Rh, nu, sub, piv, ctrl);
       __syncthreads();
+      PT(3)
       for (int e = w.tid; e < nu * nth; e += w.nthr)
         Kt[e] = -Gh[e];
       __syncthreads();
       wg_bk_solve(w, nu, Rh, nu, sub, piv, Kt, nth, 1, nth);
       __syncthreads();
+      PT(4)
       // Vxt = Aff^T Vxt'  (:305-306; at the leg end Aff^T I = A^T + K^T B^T, :186),  Vtt += Ghat_u^T Kth  (:308-310),
       // vt += Vxt'^T yff  (:301), Yth = B Kth  (:295) straight into the record
       wg_gemm(w, nx, nth, nx2, rowmajor(Af, nx).T(), X, MatV{nullptr, 0, 0}, colmajor(Xn, nx), 1.0);
@@ -216,6 +243,7 @@ __global__ void __launch_bounds__(256) gar_leg_param_generic(LegParamParams P) {
       if (!leg_end)
         wg_gemm(w, nx2, nth, nu, B, K, MatV{nullptr, 0, 0}, rowmajor(dst + fo.fth + nu * nth, nth), 1.0);
       __syncthreads();
+      PT(5)
       // the caller-visible record: ff | fb | fth | Vxx | vx | Vxt | Vtt | vt  (gar_layout.h)
       for (int e = w.tid; e < nr; e += w.nthr)
         dst[fo.ff + e] = (leg_end && e >= nu) ? 0.0 : src[f2.ff + e];
@@ -237,6 +265,7 @@ __global__ void __launch_bounds__(256) gar_leg_param_generic(LegParamParams P) {
         vt[e] = vtn[e];
       }
       __syncthreads();
+      PT(6)
       double *tmp = Xt;
       Xt = Xn;
       Xn = tmp;
