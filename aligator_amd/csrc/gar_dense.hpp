@@ -28,7 +28,12 @@
 
 namespace gar {
 
-__global__ void __launch_bounds__(256) gar_backward_dense(GenericParams P) {
+// (GAR_DENSE_THREADS threads: assembly, trailing updates, substitution strips and the value-function products spread
+// over 16 waves; the panel of the factorisation stays one wave's work)
+#ifndef GAR_DENSE_THREADS
+#define GAR_DENSE_THREADS 1024
+#endif
+__global__ void __launch_bounds__(GAR_DENSE_THREADS) gar_backward_dense(GenericParams P) {
   const WG w = wg_self();
   double *sm = gar_smem;
   const int b = (int)blockIdx.x;

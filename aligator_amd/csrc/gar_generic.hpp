@@ -141,7 +141,11 @@ __device__ inline int initial_stage(const WG &w, const GenericParams &P, int b, 
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gar_backward_generic(GenericParams P) {
+// (GAR_BACKWARD_THREADS threads per (leg, problem): copies, product tiles and substitution strips spread over 16 waves)
+#ifndef GAR_BACKWARD_THREADS
+#define GAR_BACKWARD_THREADS 1024
+#endif
+__global__ void __launch_bounds__(GAR_BACKWARD_THREADS) gar_backward_generic(GenericParams P) {
   const WG w = wg_self();
   double *sm = gar_smem;
   const int leg = (int)blockIdx.x + P.leg_begin;

@@ -1057,7 +1057,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     if (s->fold) { // ... and are swept by the generic leg kernels (every other problem: an early exit)
       gar::GenericParams G = make_params(s, mueq);
       G.only = s->d_status + s->batch + 4;
-      hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(256), (size_t)s->lds.total * sizeof(double), s->stream, G);
+      hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(GAR_BACKWARD_THREADS), (size_t)s->lds.total * sizeof(double), s->stream, G);
     }
     HIP_TRY(hipGetLastError());
     if (s->timing)
@@ -1119,7 +1119,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
   }
   gar::GenericParams P = make_params(s, mueq);
   if (s->dense) {
-    hipLaunchKernelGGL(gar::gar_backward_dense, dim3((unsigned)s->batch), dim3(256),
+    hipLaunchKernelGGL(gar::gar_backward_dense, dim3((unsigned)s->batch), dim3(GAR_DENSE_THREADS),
                        (size_t)s->dense_lds.total * sizeof(double), s->stream, P);
     HIP_TRY(hipGetLastError());
     return GAR_HIP_OK;
@@ -1189,7 +1189,7 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     return GAR_HIP_OK;
   }
   const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
-  hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(256),
+  hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(GAR_BACKWARD_THREADS),
                      (size_t)s->lds.total * sizeof(double), s->stream, P);
   HIP_TRY(hipGetLastError());
   return GAR_HIP_OK;
