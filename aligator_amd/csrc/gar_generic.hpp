@@ -845,6 +845,8 @@ struct CondensedParams {
   double threshold;
   long long *trace; // debug: cycle stamps of two elimination steps of problem 0 (or null)
   int gated;        // 1: skip the problems whose cyclic-reduction residual (scratch info[0]) met the threshold
+  int reduced;      // 1: the chain runs on the REDUCED system (the leg states eliminated leg-parallel beforehand:
+                    //    gar_condensed_leg_eliminate / gar_condensed_leg_states below)
   // scratch layout (doubles, per problem): nblk = 2*num_legs, bs = nxb*nxb
   //   diag[nblk][bs] super[nblk][bs] facD[nblk][bs] U[nblk][bs]
   //   fsub[nblk][nxb] rhs[nblk][nxb] err[nblk][nxb] fpiv[nblk][nxb] (ints in doubles)
@@ -855,6 +857,178 @@ __device__ __forceinline__ const double *cond_tuple(const CondensedParams &P, in
   // owner of a leg under the floor partition r J / W (equals leg / legs_per_rank when W divides J)
   const int rank = ((leg + 1) * P.world - 1) / P.num_legs, ll = leg - rank * P.num_legs / P.world;
   return P.ball + (((long long)rank * P.batch + b) * P.legs_per_rank + ll) * P.tuple_doubles;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The condensed system with the leg STATES eliminated first, leg-parallel.  Unknowns (lbd0 | x_0, th_0, x_1, th_1,
+// ..., x_{J-1}); the rows of x_l couple only to its neighbours:
+//     Vxx_l x_l + Vxt_l th_l - th_{l-1} = -vx_l        (l = 0: G0^T lbd0 in place of -th_{-1}; l = J-1: no th_l)
+// so x_l = z_l + P_l th_{l-1} - Y_l th_l with P_l = Vxx_l^{-1}, Y_l = P_l Vxt_l, z_l = -P_l vx_l: one factorisation and
+// one substitution of [I | Vxt | -vx] per leg, all legs at once (gar_condensed_leg_eliminate, grid (J, batch)).
+// What is left is a block-tridiagonal system in (lbd0, th_0 .. th_{J-2}) -- J blocks instead of 2 J:
+//     diag(th_l) = Vtt_l - Vxt_l^T Y_l - P_{l+1},  off(th_l, th_{l+1}) = Y_{l+1},  rhs = -vt_l - Vxt_l^T z_l + z_{l+1}
+//     diag(lbd0) = -G0 P_0 G0^T,  off(lbd0, th_0) = -G0 Y_0,  rhs = -g0 - G0 z_0
+// solved by the chain below in `reduced` mode (same elimination, refinement and residual code, half the sequential
+// steps), after which the states follow leg-parallel together with the residual of THEIR rows
+// (gar_condensed_leg_states).  The reference eliminates the 2 J blocks in order (block-tridiagonal.hpp:82-138); this
+// is the same system in another elimination order: its result is checked like the cyclic reduction's -- the chain
+// kernel on the full system runs `gated` afterwards and re-solves in the reference's order what misses the
+// residual threshold / the backward-error bound (or whose Vxx_l would not factorise).
+// Scratch (beyond the chain's first J blocks): P_l = diag[J + l], Y_l = super[J + l], W_l = Vxt_l^T Y_l = facD[J + l],
+// z_l = rhs[J + l], c_l = Vxt_l^T z_l = fsub[J + l]; the reduced solution lives in err[J ..].
+// ---------------------------------------------------------------------------------------------------------------
+// (GAR_CONDENSED_THREADS threads: 16 waves share the copies, the tiles of the products and the strips of the
+// substitutions; the panel factorisation stays one wave's work)
+#ifndef GAR_CONDENSED_THREADS
+#define GAR_CONDENSED_THREADS 1024
+#endif
+__device__ __forceinline__ double gar_inf() { return __longlong_as_double(0x7ff0000000000000ll); }
+__device__ __forceinline__ void gar_atomic_max_nonneg(double *addr, double v) { // v >= 0 (or NaN -> +inf)
+  if (!(v == v))
+    v = gar_inf();
+  atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// LDS: X (bs) | R (nxb x (2 nxb + 1)) | wk (GAR_LDL_PANEL nxb) | sub (nxb) | piv, ctrl
+__host__ __device__ inline int gar_condensed_leg_lds_doubles(int nxb) {
+  return nxb * nxb + nxb * (2 * nxb + 1) + 1 + GAR_LDL_PANEL * nxb + nxb + 2 + (nxb + 48) / 2 + 2;
+}
+__global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_leg_eliminate(CondensedParams P) {
+  const WG w = wg_self();
+  double *sm = gar_smem;
+  const int leg = (int)blockIdx.x, b = (int)blockIdx.y, J = P.num_legs;
+  const int n = P.nxb, bs = n * n, nblk = 2 * J;
+  const bool inner = leg + 1 < J;
+  double *S = P.scratch + (long long)b * P.scratch_stride;
+  double *diag = S, *super = diag + (long long)nblk * bs, *facD = super + (long long)nblk * bs;
+  double *fsub = facD + 2ll * nblk * bs, *rhs = fsub + nblk * n;
+  double *Pg = diag + (long long)(J + leg) * bs, *Yg = super + (long long)(J + leg) * bs, *Wg = facD + (long long)(J + leg) * bs;
+  double *zg = rhs + (J + leg) * n, *cg = fsub + (J + leg) * n;
+  const double *tup = cond_tuple(P, b, leg);
+  const int ncol = n + (inner ? n : 0) + 1; // [I | Vxt | -vx]
+  double *X = sm, *R = X + bs, *wk = R + ((n * (2 * n + 1) + 1) & ~1), *sub = wk + GAR_LDL_PANEL * n;
+  int *piv = (int *)(sub + n + (n & 1)), *ctrl = piv + n + 8;
+  for (int e = w.tid; e < bs; e += w.nthr) {
+    X[e] = tup[e];
+    R[e] = (e / n == e % n) ? 1.0 : 0.0;
+    if (inner)
+      R[bs + e] = tup[bs + e];
+  }
+  for (int e = w.tid; e < n; e += w.nthr)
+    R[(ncol - 1) * n + e] = -tup[3 * bs + e];
+  __syncthreads();
+  int bad = 1;
+  if (n >= 8 && n <= 64) {
+    bad = wg_ldl_definite_factor(w, n, X, n, sub, piv, wk, ctrl);
+    if (bad) {
+      for (int e = w.tid; e < bs; e += w.nthr)
+        X[e] = tup[e];
+      __syncthreads();
+    }
+  }
+  if (bad)
+    bad = wg_bk_factor(w, n, X, n, sub, piv, ctrl);
+  wg_bk_solve(w, n, X, n, sub, piv, R, 1, n, ncol);
+  if (bad) { // a Vxx that would not factorise: poison z_l -- the residual gate then hands the problem to the full chain
+    for (int e = w.tid; e < n; e += w.nthr)
+      R[(ncol - 1) * n + e] = __longlong_as_double(0x7ff8000000000000ll);
+    __syncthreads();
+  }
+  for (int e = w.tid; e < bs; e += w.nthr) {
+    Pg[e] = R[e];
+    if (inner)
+      Yg[e] = R[bs + e];
+  }
+  for (int e = w.tid; e < n; e += w.nthr)
+    zg[e] = R[(ncol - 1) * n + e];
+  if (inner) { // [W | c] = Vxt^T [Y | z]
+    const MatV Vxt = colmajor(const_cast<double *>(tup) + bs, n);
+    wg_gemm(w, n, n, n, Vxt.T(), colmajor(R + bs, n), MatV{nullptr, 0, 0}, colmajor(Wg, n), 1.0);
+    wg_gemm(w, n, 1, n, Vxt.T(), colmajor(R + (ncol - 1) * n, n), MatV{nullptr, 0, 0}, colmajor(cg, n), 1.0);
+  }
+}
+
+// x_l from the reduced solution, and the residual / scale of the rows of x_l (everything the reduced chain did not
+// check itself), accumulated into info[0] / info[2] over the legs.  grid (J, batch) x 256.
+__global__ void __launch_bounds__(256) gar_condensed_leg_states(CondensedParams P) {
+  const WG w = wg_self();
+  double *sm = gar_smem; // thp (n) | thn (n) | x (n)
+  const int leg = (int)blockIdx.x, b = (int)blockIdx.y, J = P.num_legs;
+  const int n = P.nxb, bs = n * n, nblk = 2 * J;
+  const bool inner = leg + 1 < J;
+  double *S = P.scratch + (long long)b * P.scratch_stride;
+  double *diag = S, *super = diag + (long long)nblk * bs;
+  double *fsub = super + 3ll * nblk * bs, *rhs = fsub + nblk * n, *err = rhs + nblk * n;
+  double *info = rhs + 3ll * nblk * n;
+  const double *Pg = diag + (long long)(J + leg) * bs, *Yg = super + (long long)(J + leg) * bs, *zg = rhs + (J + leg) * n;
+  const double *rsol = err + J * n; // (lbd0, th_0 .. th_{J-2})
+  double *sol = P.csol + (long long)b * nblk * n;
+  const double *tup = cond_tuple(P, b, leg);
+  const double *G0 = P.prob + (long long)b * P.prob_stride + P.G0_off;
+  double *thp = sm, *thn = sm + n, *x = sm + 2 * n;
+  const int nc0 = P.nc0;
+  // the reduced solution goes to its places in the full one: lbd0 -> block 0, th_l -> block 2 l + 2
+  if (leg == 0)
+    for (int e = w.tid; e < nc0; e += w.nthr)
+      sol[e] = rsol[e];
+  if (inner)
+    for (int e = w.tid; e < n; e += w.nthr)
+      sol[(2 * leg + 2) * n + e] = rsol[(leg + 1) * n + e];
+  // thp = the left neighbour's contribution to the rows of x_l:  +th_{l-1}, or -G0^T lbd0 for the first leg
+  for (int e = w.tid; e < n; e += w.nthr) {
+    double v = 0.0;
+    if (leg > 0) {
+      v = rsol[leg * n + e];
+    } else {
+      for (int k = 0; k < nc0; ++k)
+        v -= G0[e * nc0 + k] * rsol[k]; // G0 (nc0 x nx0) column-major: G0^T(e, k) = G0[k + e nc0]
+    }
+    thp[e] = v;
+    thn[e] = inner ? rsol[(leg + 1) * n + e] : 0.0;
+  }
+  __syncthreads();
+  const int srow = w.tid >> 2, sq = w.tid & 3, srows = w.nthr >> 2;
+  for (int i0 = 0; i0 < n; i0 += srows) { // x = z + P thp - Y thn   (P, Y symmetric resp. general: rows read strided)
+    const int i = i0 + srow, ic = i < n ? i : n - 1;
+    double sum = gar_sliced_dot(Pg + ic, n, thp, n, sq);
+    if (inner)
+      sum -= gar_sliced_dot(Yg + ic, n, thn, n, sq);
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (sq == 0 && i < n) {
+      const double v = zg[i] + sum;
+      x[i] = v;
+      sol[(2 * leg + 1) * n + i] = v;
+    }
+  }
+  __syncthreads();
+  // residual of the rows of x_l:  -vx - Vxx x - Vxt thn + thp, and their scale |vx| + |Vxx| |x| + |Vxt| |thn| + |thp|
+  double rmax = 0.0, smax = 0.0;
+  for (int i0 = 0; i0 < n; i0 += srows) {
+    const int i = i0 + srow, ic = i < n ? i : n - 1;
+    double r = 0.0, a = 0.0;
+    for (int k = sq; k < n; k += 4) {
+      const double vxx = tup[(long long)k * n + ic], vxt = inner ? tup[bs + (long long)k * n + ic] : 0.0;
+      r += vxx * x[k] + vxt * thn[k];
+      a += fabs(vxx) * fabs(x[k]) + fabs(vxt) * fabs(thn[k]);
+    }
+    r += __shfl_xor(r, 1);
+    r += __shfl_xor(r, 2);
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    if (sq == 0 && i < n) {
+      const double vx = tup[3 * bs + i];
+      const double res = fabs(-vx - r + thp[i]);
+      rmax = fmax(rmax, res == res ? res : gar_inf());
+      smax = fmax(smax, fabs(vx) + a + fabs(thp[i]));
+    }
+  }
+  rmax = wave_max_f64(rmax);
+  smax = wave_max_f64(smax);
+  if (w.lane == 0) {
+    gar_atomic_max_nonneg(&info[0], rmax);
+    gar_atomic_max_nonneg(&info[2], smax);
+  }
 }
 
 // LDS: blk[nxb*nxb] ublk[nxb*nxb] sub[nxb] piv/ctrl
@@ -872,11 +1046,6 @@ __device__ long long g_ctrace[16];
 #else
 #define CT(id)
 #endif
-// (GAR_CONDENSED_THREADS threads: 16 waves share the copies, the tiles of the products and the strips of the
-// substitutions; the panel factorisation stays one wave's work)
-#ifndef GAR_CONDENSED_THREADS
-#define GAR_CONDENSED_THREADS 1024
-#endif
 __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(CondensedParams P) {
 #ifdef GAR_CTRACE
   long long tprev = clock64();
@@ -884,23 +1053,34 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(C
   const WG w = wg_self();
   double *sm = gar_smem;
   const int b = (int)blockIdx.x;
-  const int nxb = P.nxb, bs = nxb * nxb, nblk = 2 * P.num_legs, N = nblk - 1;
-  if (P.gated) { // already solved to the residual threshold by the cyclic-reduction kernels?
-    const double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * bs + 4ll * nblk * nxb;
+  // nblkS: blocks of the FULL system (the scratch arrays' pitch); nblk: blocks of the system this launch solves --
+  // the full one, or (P.reduced) the one in (lbd0, th_0 .. th_{J-2}) left by gar_condensed_leg_eliminate
+  const int nxb = P.nxb, bs = nxb * nxb, nblkS = 2 * P.num_legs, nblk = P.reduced ? P.num_legs : nblkS, N = nblk - 1;
+  const bool alt = !P.reduced; // the full system's super-diagonal alternates Vxt, -I
+  if (P.gated) { // already solved to the residual threshold by the cyclic-reduction / reduced-system kernels?
+    const double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblkS * bs + 4ll * nblkS * nxb;
     // (refinement disabled: the cyclic-reduction result stands -- unless a block inverse failed
     // outright, which poisons the residual with +inf)
+    double *inf_w = P.scratch + (long long)b * P.scratch_stride + 4ll * nblkS * bs + 4ll * nblkS * nxb;
     if (inf[0] <= P.threshold || (P.max_refinement == 0 && inf[0] <= 1.79e308) ||
-        (inf[0] <= 1.79e308 && inf[0] <= P.backward_ok * inf[2])) // (see gar_cyclic_recover)
+        (inf[0] <= 1.79e308 && inf[0] <= P.backward_ok * inf[2])) { // (see gar_cyclic_recover)
+      if (w.tid == 0)
+        inf_w[3] = 0.0; // the pre-solver's result stands (gar_hip_condensed_resolved)
       return;
+    }
+    if (w.tid == 0)
+      inf_w[3] = 1.0; // re-solved here, in the reference's order
+  } else if (w.tid == 0 && !P.reduced) {
+    (P.scratch + (long long)b * P.scratch_stride + 4ll * nblkS * bs + 4ll * nblkS * nxb)[3] = 0.0;
   }
   double *S = P.scratch + (long long)b * P.scratch_stride;
-  double *diag = S, *super = diag + (long long)nblk * bs, *facD = super + (long long)nblk * bs;
-  double *U = facD + (long long)nblk * bs;
-  double *fsub = U + (long long)nblk * bs;
-  double *rhs = fsub + nblk * nxb, *err = rhs + nblk * nxb;
-  int *fpiv = (int *)(err + nblk * nxb);
-  double *info = err + 2 * nblk * nxb;
-  double *sol = P.csol + (long long)b * nblk * nxb;
+  double *diag = S, *super = diag + (long long)nblkS * bs, *facD = super + (long long)nblkS * bs;
+  double *U = facD + (long long)nblkS * bs;
+  double *fsub = U + (long long)nblkS * bs;
+  double *rhs = fsub + nblkS * nxb, *err = rhs + nblkS * nxb;
+  int *fpiv = (int *)(err + nblkS * nxb);
+  double *info = err + 2 * nblkS * nxb;
+  double *sol = P.reduced ? err + P.num_legs * nxb : P.csol + (long long)b * nblkS * nxb;
   const double *prob = P.prob + (long long)b * P.prob_stride;
   // LDS: blk (n x (n + 1)), ublk (n x (r + 1); >= 9 nxb doubles for the slices of the back-substitution), bsup (r x n)
   double *blk = sm, *ublk = blk + bs + nxb, *bsup = ublk + bs + nxb, *lsub = bsup + bs;
@@ -910,6 +1090,36 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(C
 #define DIM(i) ((i) == 0 ? P.nc0 : nxb)
 
   CT(0)
+  if (P.reduced) {
+    // ---- the reduced system from what gar_condensed_leg_eliminate left (see there): P_l = diag[J + l],
+    // Y_l = super[J + l], W_l = facD[J + l], z_l = rhs[J + l], c_l = fsub[J + l]
+    const int J = P.num_legs, nc0 = P.nc0, nx0 = P.nx0;
+    const MatV G0 = colmajor(const_cast<double *>(prob) + P.G0_off, nc0);
+    double *GP = blk; // G0 P_0 (nc0 x nx0), in LDS
+    wg_gemm(w, nc0, nx0, nx0, G0, colmajor(diag + (long long)J * bs, nxb), MatV{nullptr, 0, 0}, colmajor(GP, nc0), 1.0);
+    __syncthreads();
+    wg_gemm(w, nc0, nc0, nx0, colmajor(GP, nc0), G0.T(), MatV{nullptr, 0, 0}, colmajor(diag, nc0), -1.0);
+    wg_gemm(w, nc0, nx0, nx0, G0, colmajor(super + (long long)J * bs, nxb), MatV{nullptr, 0, 0}, colmajor(super, nc0), -1.0);
+    wg_gemm(w, nc0, 1, nx0, G0, colmajor(rhs + J * nxb, nxb), MatV{nullptr, 0, 0}, colmajor(rhs, nc0), -1.0);
+    __syncthreads();
+    for (int e = w.tid; e < nc0; e += w.nthr)
+      rhs[e] -= prob[P.g0_off + e]; // rhs[0] = -g0 - G0 z_0
+    for (int l = 0; l + 1 < J; ++l) {
+      const double *tup = cond_tuple(P, b, l);
+      const int i = l + 1;
+      const double *Wl = facD + (long long)(J + l) * bs, *Pn = diag + (long long)(J + l + 1) * bs;
+      const double *Yn = super + (long long)(J + l + 1) * bs;
+#pragma unroll 4
+      for (int e = w.tid; e < bs; e += w.nthr) {
+        diag[(long long)i * bs + e] = tup[2 * bs + e] - Wl[e] - Pn[e];
+        if (i < N)
+          super[(long long)i * bs + e] = Yn[e];
+      }
+      for (int e = w.tid; e < nxb; e += w.nthr)
+        rhs[i * nxb + e] = -tup[3 * bs + nxb + e] - fsub[(J + l) * nxb + e] + rhs[(J + l + 1) * nxb + e];
+    }
+    __syncthreads();
+  } else {
   // ---- assembleCondensedSystem (parallel-solver.hxx:85-129), blocks stored column-major with leading dimension
   // DIM(row block).  Every block that is read later is written exactly once (diag, super and rhs stay as they are:
   // the refinement's residual is taken against them); facD and U are produced by the elimination itself.
@@ -943,6 +1153,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(C
     }
   }
   __syncthreads();
+  }
 
   CT(1)
   int failed = 0;
@@ -991,7 +1202,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(C
       break;
     }
     const int r = DIM(i);
-    const bool minus_identity = i >= 2 && (i & 1) == 0; // super[2 leg + 2] = -I
+    const bool minus_identity = alt && i >= 2 && (i & 1) == 0; // super[2 leg + 2] = -I
     const double *Bg = super + (long long)i * bs;        // r x n
     // ublk = [super[i]^T | rhs[ib]]  (n x (r + 1)), then <- D^{-1} ublk: one blocked substitution for both
     if (minus_identity) {
@@ -1093,7 +1304,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(C
           s0 += Dg[k * n] * xi[k];
         if (i > 0) { // sub[i-1] = super[i-1]^T
           const int r = DIM(i - 1);
-          if (i - 1 >= 2 && ((i - 1) & 1) == 0) { // super[i-1] = -I
+          if (alt && i - 1 >= 2 && ((i - 1) & 1) == 0) { // super[i-1] = -I
             s1 -= xs[(i - 1) * nxb + a];
           } else {
             const double *Bp = super + (long long)(i - 1) * bs + a * r, *xp = xs + (i - 1) * nxb;
@@ -1104,7 +1315,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(C
         }
         if (i < N) {
           const int c = DIM(i + 1);
-          if (i >= 2 && (i & 1) == 0) { // super[i] = -I
+          if (alt && i >= 2 && (i & 1) == 0) { // super[i] = -I
             s1 -= xs[(i + 1) * nxb + a];
           } else {
             const double *Bn = super + (long long)i * bs + a, *xn = xs + (i + 1) * nxb;
@@ -1117,7 +1328,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(C
       }
       err[e] = s;
       const double v = fabs(s);
-      mx = fmax(mx, v == v ? v : 1.8e308 * 10.0); // (a NaN counts as +inf)
+      mx = fmax(mx, v == v ? v : gar_inf()); // (a NaN counts as +inf)
     }
     mx = wave_max_f64(mx);
     __syncthreads(); // (sol's copy in LDS has been read by everyone)
@@ -1139,7 +1350,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(C
       if (i < 0)
         break;
       const int r = DIM(i);
-      if (i >= 2 && (i & 1) == 0) { // super[i] = -I
+      if (alt && i >= 2 && (i & 1) == 0) { // super[i] = -I
         __syncthreads();
         for (int e = w.tid; e < r; e += w.nthr)
           err[i * nxb + e] += err[ib * nxb + e];
@@ -1162,10 +1373,15 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_generic(C
   }
   CT(11)
   if (w.tid == 0) {
-    info[0] = resdl;
     info[1] = (double)steps;
-    if (failed)
-      atomicOr(&P.status[b], 4);
+    if (P.reduced) { // gar_condensed_leg_states adds the rows of the states; a failure here goes to the full chain
+      info[0] = failed ? gar_inf() : resdl;
+      info[2] = 0.0;
+    } else {
+      info[0] = resdl;
+      if (failed)
+        atomicOr(&P.status[b], 4);
+    }
   }
 #undef DIM
 }

@@ -158,6 +158,7 @@ struct gar_hip_solver {
   int legs_per_rank = 0;
   double cond_threshold = 1e-10; // parallel-solver.hpp:92
   double cond_backward_ok = GAR_CONDENSED_BACKWARD_OK; // gar_hip_set_condensed_backward_ok
+  bool cond_reduced = false; // generic condensed solve: leg states eliminated leg-parallel first (GAR_HIP_CONDENSED_REDUCED=0: off)
   int max_refinement = 5;        // parallel-solver.hpp:94
   // host staging
   double *h_prob = nullptr; // pinned, batch * prob_doubles (when small enough)
@@ -1320,12 +1321,27 @@ int launch_condensed(gar_hip_solver *s) {
     HIP_TRY(hipGetLastError());
     C.gated = 1; // the chain kernel (with refinement) re-solves only what missed the threshold
   }
-  if (s->cond_wave_kernel)
+  if (s->cond_wave_kernel) {
     hipLaunchKernelGGL(s->cond_wave_kernel, dim3((unsigned)s->batch), dim3(64),
                        (size_t)s->cond_wave_lds_doubles * sizeof(double), s->stream, C);
-  else
+  } else {
+    if (!C.gated && s->cond_reduced) {
+      // the leg states eliminated leg-parallel, the chain on the J remaining blocks, the states back leg-parallel
+      // (gar_generic.hpp: gar_condensed_leg_eliminate); the full chain then runs gated, like behind cyclic reduction
+      const dim3 grid((unsigned)s->num_legs, (unsigned)s->batch);
+      hipLaunchKernelGGL(gar::gar_condensed_leg_eliminate, grid, dim3(GAR_CONDENSED_THREADS),
+                         (size_t)gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double), s->stream, C);
+      gar::CondensedParams R = C;
+      R.reduced = 1;
+      hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
+                         (size_t)s->cond_lds_doubles * sizeof(double), s->stream, R);
+      hipLaunchKernelGGL(gar::gar_condensed_leg_states, grid, dim3(256), (size_t)(3 * s->nxb + 2) * sizeof(double),
+                         s->stream, C);
+      C.gated = 1;
+    }
     hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
                        (size_t)s->cond_lds_doubles * sizeof(double), s->stream, C);
+  }
   HIP_TRY(hipGetLastError());
   if (s->timing) // leg mode: the "initial stage" slot of the timing API is the condensed solve
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
@@ -1427,6 +1443,11 @@ int allocate(gar_hip_solver *s) {
     s->cscratch_doubles = (int64_t)(4 * nblk * bs + 4 * (size_t)nblk * s->nxb + 4);
     HIP_TRY(hipMalloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
     s->cond_lds_doubles = (int)(3 * bs + 4 * s->nxb + 2 + (s->nxb + 16) / 2 + 2 + (s->nxb < 9 ? 9 * s->nxb : 0));
+    {
+      const char *cr = std::getenv("GAR_HIP_CONDENSED_REDUCED");
+      s->cond_reduced = !(cr && cr[0] == '0') && s->nx0 == s->nxb &&
+                        (size_t)gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double) <= 160 * 1024;
+    }
   }
   if (s->seg_bwd_kernel) {
     const gar_hip_solver *f = s->flay;
@@ -1509,6 +1530,10 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_generic,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->cond_lds_doubles * sizeof(double))));
+  if (s->num_legs > 1 && s->cond_reduced)
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_leg_eliminate,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double))));
   return GAR_HIP_OK;
 }
 
@@ -2613,6 +2638,22 @@ extern "C" int gar_hip_debug_ptrace(long long *out) {
   return 0;
 }
 #endif
+int gar_hip_condensed_resolved(gar_hip_solver *s, int b, int *out) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  if (s->num_legs < 2 || !out)
+    return fail(GAR_HIP_ERR_ARG, "condensed info needs leg mode");
+  const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
+  const double *info = s->d_cscratch + (int64_t)b * s->cscratch_doubles + 4 * nblk * bs + 4 * nblk * s->nxb;
+  double v = 0.0;
+  if (int rc = d2h(s, &v, info + 3, 1))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *out = v != 0.0 ? 1 : 0;
+  return GAR_HIP_OK;
+}
+
 int gar_hip_condensed_backward_error(gar_hip_solver *s, int b, double *out) {
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))

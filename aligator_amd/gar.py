@@ -351,6 +351,13 @@ class BatchedRiccatiSolver:
         self._check(self._L.gar_hip_condensed_backward_error(self._h, int(b), out))
         return float(out[0])
 
+    def condensed_resolved(self, b: int = 0) -> bool:
+        """True when the fast condensed solve of problem b (cyclic reduction / leg-parallel state elimination)
+        missed its residual check and the system was solved again in the reference's order."""
+        out = C.c_int(0)
+        self._check(self._L.gar_hip_condensed_resolved(self._h, int(b), C.byref(out)))
+        return bool(out.value)
+
     def collapse_feedback(self):
         self._factors_cache = {}
         self._check(self._L.gar_hip_collapse_feedback(self._h))

@@ -248,6 +248,11 @@ int gar_hip_condensed_info(gar_hip_solver *s, int b, double out[2]);
  * absolute threshold (parallel-solver.hpp:92) is out of reach of any fp64 solver -- the reference then spends its
  * maxRefinementSteps without effect (parallel-solver.hxx:184-202).  0 when the elimination chain solved instead. */
 int gar_hip_condensed_backward_error(gar_hip_solver *s, int b, double *out);
+/* The condensed system is first solved by a fast elimination order -- block cyclic reduction (specialised leg
+ * families) or, on the any-dimension path, with the leg states eliminated leg-parallel and the chain run on the
+ * J remaining blocks -- and checked by its residual; *out = 1 when the last solve of problem b missed the check and
+ * was redone in the reference's order (block-tridiagonal.hpp:82-138 with refinement), 0 when the fast result stood. */
+int gar_hip_condensed_resolved(gar_hip_solver *s, int b, int *out);
 /* the omega bound above (default 1e-12); 0: only the reference's absolute threshold counts */
 int gar_hip_set_condensed_backward_ok(gar_hip_solver *s, double omega);
 

@@ -650,3 +650,40 @@ def test_serial_family_keeps_vxx_as_its_packed_lower_triangle():
                 assert block[sym_index(nx, i, j)] == Vxx[i, j]
         assert (block[nx * (nx + 1) // 2:] == -7.0).all()    # the other half of the block is never touched
     s.close()
+
+
+@pytest.mark.parametrize("nx,nu,horz,legs", [(10, 4, 12, 2), (10, 4, 13, 3), (20, 7, 23, 5), (9, 3, 16, 8)])
+def test_generic_condensed_solve_with_the_leg_states_eliminated_first(monkeypatch, nx, nu, horz, legs):
+    """The any-dimension leg path: gar_condensed_leg_eliminate (one factorisation and substitution per leg, all
+    legs at once), the chain on the J remaining blocks, gar_condensed_leg_states -- against the oracle's
+    leg-parallel solver, and against the same solver with the reduction switched off (the reference's elimination
+    order on all 2 J blocks).  The fast result must STAND (gar_hip_condensed_resolved = 0); with a residual
+    threshold no solver can meet and the backward-error gate off it must be redone in the reference's order."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    monkeypatch.setenv("GAR_HIP_PAD", "0")
+    monkeypatch.setenv("GAR_HIP_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(100 * nx + legs)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+    par = pc.check_parallel(prob, 1e-10, legs, 1e-9, EMU)
+    assert par._impl.kernel_name == "generic" and not par._impl.condensed_resolved(0)
+    dims = [k.dims for k in prob.stages]
+    sols = {}
+    for reduced in ("1", "0"):
+        monkeypatch.setenv("GAR_HIP_CONDENSED_REDUCED", reduced)
+        s = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=legs, lib_path=EMU)
+        s.upload([prob])
+        s.backward(1e-10)
+        s.forward()
+        sols[reduced] = s.solution(0)
+        assert not s.condensed_resolved(0)
+        if reduced == "1":   # an unreachable threshold, no backward-error pass: the full chain has to redo it
+            s.set_refinement(1e-300, 2, backward_ok=0.0)
+            s.backward(1e-10)
+            s.forward()
+            assert s.condensed_resolved(0)
+            again = s.solution(0)
+            sc = max(1.0, max(float(np.abs(v).max()) for v in again[3]))
+            assert max(float(np.abs(a - b).max()) for A, B in zip(again, sols["1"]) for a, b in zip(A, B) if a.size) <= 1e-10 * sc
+        s.close()
+    sc = max(1.0, max(float(np.abs(v).max()) for v in sols["0"][3]))
+    assert max(float(np.abs(a - b).max()) for A, B in zip(sols["1"], sols["0"]) for a, b in zip(A, B) if a.size) <= 1e-10 * sc
