@@ -354,7 +354,10 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       }
       wg_bar(w);
     } else {
-    const bool par_search = (n - k - 1) >= 16 && n >= 2 * w.nwaves;
+    // (rows are dealt one per thread: only the first pw = ceil(n / 64) waves can hold any -- they alone park results in
+    // `subdiag`, 3 pw <= n entries whatever the size of the workgroup)
+    const int pw = ((n + 63) >> 6) < w.nwaves ? ((n + 63) >> 6) : w.nwaves;
+    const bool par_search = (n - k - 1) >= 16 && n >= 3 * pw;
     if (par_search) {
       double bv = -1.0;
       int bi = 0x7fffffff;
@@ -383,7 +386,7 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
           }
         }
       }
-      if (w.lane == 0) {
+      if (w.lane == 0 && w.wave < pw) {
         subdiag[2 * w.wave] = bv;
         subdiag[2 * w.wave + 1] = (double)bi;
       }
@@ -394,7 +397,7 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
       // of up to n elements by thread 0.
       double colmax = subdiag[0];
       int imax = (int)subdiag[1];
-      for (int q = 1; q < w.nwaves; ++q) {
+      for (int q = 1; q < pw; ++q) {
         const double v = subdiag[2 * q];
         const int iq = (int)subdiag[2 * q + 1];
         if (v > colmax || (v == colmax && iq < imax)) {
@@ -421,12 +424,12 @@ __device__ inline int wg_bk_factor(const WG &w, int n, double *a, int lda, doubl
             rv = fmax(rv, fabs(GA(i, imax)));
         }
         rv = wave_max_f64(rv);
-        if (w.lane == 0)
-          subdiag[2 * w.nwaves + w.wave] = rv; // n >= 17 > 3 nwaves here
+        if (w.lane == 0 && w.wave < pw)
+          subdiag[2 * pw + w.wave] = rv; // (3 pw <= n)
         wg_bar(w);
-        double rowmax = subdiag[2 * w.nwaves];
-        for (int q = 1; q < w.nwaves; ++q)
-          rowmax = fmax(rowmax, subdiag[2 * w.nwaves + q]);
+        double rowmax = subdiag[2 * pw];
+        for (int q = 1; q < pw; ++q)
+          rowmax = fmax(rowmax, subdiag[2 * pw + q]);
         if (abs_akk >= (alpha * colmax) * (colmax / rowmax)) {
           kp = k;
         } else if (abs_aii >= alpha * rowmax) {

@@ -952,7 +952,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_leg_elimi
 // check itself), accumulated into info[0] / info[2] over the legs.  grid (J, batch) x 256.
 __global__ void __launch_bounds__(256) gar_condensed_leg_states(CondensedParams P) {
   const WG w = wg_self();
-  double *sm = gar_smem; // thp (n) | thn (n) | x (n)
+  double *sm = gar_smem; // thp (n) | thn (n) | x (n) | x_{l+1} (n) | th_{l+1} (n)
   const int leg = (int)blockIdx.x, b = (int)blockIdx.y, J = P.num_legs;
   const int n = P.nxb, bs = n * n, nblk = 2 * J;
   const bool inner = leg + 1 < J;
@@ -1021,6 +1021,60 @@ __global__ void __launch_bounds__(256) gar_condensed_leg_states(CondensedParams 
       const double res = fabs(-vx - r + thp[i]);
       rmax = fmax(rmax, res == res ? res : gar_inf());
       smax = fmax(smax, fabs(vx) + a + fabs(thp[i]));
+    }
+  }
+  // ... and of the rows of th_l, of the FULL system (the reduced system was formed from P, Y, W in floating point: its
+  // own residual does not see what forming it lost):  -vt_l - Vxt_l^T x_l - Vtt_l th_l + x_{l+1}, with x_{l+1}
+  // recomputed here (its own workgroup writes it); and of the rows of lbd0: -g0 - G0 x_0
+  if (inner) {
+    double *xn = sm + 3 * n, *thnn = sm + 4 * n;
+    const bool inner2 = leg + 2 < J;
+    const double *Pn = Pg + bs, *Yn = Yg + bs, *zn = zg + n; // leg + 1
+    for (int e = w.tid; e < n; e += w.nthr)
+      thnn[e] = inner2 ? rsol[(leg + 2) * n + e] : 0.0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += srows) {
+      const int i = i0 + srow, ic = i < n ? i : n - 1;
+      double sum = gar_sliced_dot(Pn + ic, n, thn, n, sq);
+      if (inner2)
+        sum -= gar_sliced_dot(Yn + ic, n, thnn, n, sq);
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      if (sq == 0 && i < n)
+        xn[i] = zn[i] + sum;
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += srows) {
+      const int i = i0 + srow, ic = i < n ? i : n - 1;
+      double r = 0.0, a = 0.0;
+      for (int k = sq; k < n; k += 4) {
+        const double vxt = tup[bs + (long long)ic * n + k], vtt = tup[2 * bs + (long long)k * n + ic]; // Vxt(k, i), Vtt(i, k)
+        r += vxt * x[k] + vtt * thn[k];
+        a += fabs(vxt) * fabs(x[k]) + fabs(vtt) * fabs(thn[k]);
+      }
+      r += __shfl_xor(r, 1);
+      r += __shfl_xor(r, 2);
+      a += __shfl_xor(a, 1);
+      a += __shfl_xor(a, 2);
+      if (sq == 0 && i < n) {
+        const double vt = tup[3 * bs + n + i];
+        const double res = fabs(-vt - r + xn[i]);
+        rmax = fmax(rmax, res == res ? res : gar_inf());
+        smax = fmax(smax, fabs(vt) + a + fabs(xn[i]));
+      }
+    }
+  }
+  if (leg == 0) {
+    const double *g0 = P.prob + (long long)b * P.prob_stride + P.g0_off;
+    for (int i = w.tid; i < nc0; i += w.nthr) {
+      double r = 0.0, a = 0.0;
+      for (int k = 0; k < n; ++k) {
+        r += G0[i + k * nc0] * x[k];
+        a += fabs(G0[i + k * nc0]) * fabs(x[k]);
+      }
+      const double res = fabs(-g0[i] - r);
+      rmax = fmax(rmax, res == res ? res : gar_inf());
+      smax = fmax(smax, fabs(g0[i]) + a);
     }
   }
   rmax = wave_max_f64(rmax);

@@ -1335,7 +1335,7 @@ int launch_condensed(gar_hip_solver *s) {
       R.reduced = 1;
       hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
                          (size_t)s->cond_lds_doubles * sizeof(double), s->stream, R);
-      hipLaunchKernelGGL(gar::gar_condensed_leg_states, grid, dim3(256), (size_t)(3 * s->nxb + 2) * sizeof(double),
+      hipLaunchKernelGGL(gar::gar_condensed_leg_states, grid, dim3(256), (size_t)(5 * s->nxb + 2) * sizeof(double),
                          s->stream, C);
       C.gated = 1;
     }

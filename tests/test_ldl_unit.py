@@ -18,7 +18,7 @@ def load_emu():
     return ctypes.CDLL(os.path.join(HERE, "emu", "_build", "libgar_ldl_unit_emu.so"))
 
 
-def run_unit(lib, A, X, definite_first, x_rowmajor=False, blocked=0):
+def run_unit(lib, A, X, definite_first, x_rowmajor=False, blocked=0, threads=256):
     n, nc = A.shape[0], X.shape[1]
     a = np.asfortranarray(A, dtype=np.float64).copy(order="F")
     x = np.array(X, dtype=np.float64, order="C" if x_rowmajor else "F")
@@ -27,7 +27,7 @@ def run_unit(lib, A, X, definite_first, x_rowmajor=False, blocked=0):
     info = np.zeros(4, dtype=np.int32)
     dp = ctypes.POINTER(ctypes.c_double)
     ip = ctypes.POINTER(ctypes.c_int)
-    rc = lib.gar_ldl_unit(n, nc, int(definite_first), int(x_rowmajor), int(blocked), a.ctypes.data_as(dp), x.ctypes.data_as(dp),
+    rc = lib.gar_ldl_unit(n, nc, int(definite_first), int(x_rowmajor), int(blocked), int(threads), a.ctypes.data_as(dp), x.ctypes.data_as(dp),
                           sub.ctypes.data_as(dp), piv.ctypes.data_as(ip), info.ctypes.data_as(ip))
     assert rc == 0
     return a, x, sub, piv, info
@@ -126,6 +126,8 @@ def test_ldl_building_blocks_on_the_gpu():
     for n, ncols, kind in [(44, 45, "kkt"), (72, 20, "kkt"), (116, 37, "dense-stage"), (128, 16, "random")]:
         for packed in (False, True):
             test_blocked_bunch_kaufman_matches_the_unblocked_one(n, ncols, kind, packed, lib=lib)
+    for n, ncols, kind in [(44, 45, "kkt"), (116, 37, "dense-stage"), (56, 57, "kkt")]:
+        test_workgroup_size_does_not_change_the_factorisation(n, ncols, kind, lib=lib)
 
 
 @pytest.mark.gpu
@@ -232,3 +234,27 @@ def test_blocked_bunch_kaufman_reports_a_zero_column():
     for blocked in (0, 1):
         info = run_unit(lib, A, X0, False, blocked=blocked)[4]
         assert info[1] == 1                  # NumericalIssue (bunchkaufman.hpp:58-59)
+
+
+@pytest.mark.parametrize("n,ncols,kind", [(44, 45, "kkt"), (40, 16, "random"), (116, 37, "dense-stage"), (56, 57, "kkt")])
+def test_workgroup_size_does_not_change_the_factorisation(n, ncols, kind, lib=None):
+    """The kernels that call these routines run on 256- and on 1 024-thread workgroups: the column-at-a-time
+    Bunch-Kaufman parks per-wave partial results of its pivot search in `subdiag` (n doubles) -- with 16 waves only
+    the waves that can hold a row may do so (a 44 x 44 block has room for 14 entries, not 48)."""
+    lib = lib or load_emu()
+    rng = np.random.default_rng(n)
+    A = indefinite(rng, n, kind)
+    X0 = rng.standard_normal((n, ncols))
+    for blocked in (0, 1):
+        a1, x1, sub1, piv1, info1 = run_unit(lib, A, X0, False, blocked=blocked, threads=256)
+        a2, x2, sub2, piv2, info2 = run_unit(lib, A, X0, False, blocked=blocked, threads=1024)
+        assert info1[1] == 0 and info2[1] == 0
+        assert (piv1 == piv2).all()
+        assert (np.tril(a1) == np.tril(a2)).all() and (sub1 == sub2).all()
+        scale = np.abs(x1).max()
+        assert np.abs(x1 - x2).max() <= 1e-12 * scale     # (the substitution's tiles are dealt out differently)
+    if n <= 64:
+        A = spd(rng, n)
+        r1 = run_unit(lib, A, X0, True, threads=256)
+        r2 = run_unit(lib, A, X0, True, threads=1024)
+        assert r1[4][0] == 0 and r2[4][0] == 0 and (np.tril(r1[0]) == np.tril(r2[0])).all()

@@ -15,7 +15,7 @@ struct UnitParams {
   int blocked;                              // 1: wg_bk_factor_blocked, 2: the same on the PACKED lower triangle
 };
 
-__global__ void __launch_bounds__(256) ldl_unit_kernel(UnitParams P) {
+__global__ void __launch_bounds__(1024) ldl_unit_kernel(UnitParams P) {
   using namespace gar;
   const WG w = wg_self();
   const int n = P.n, nc = P.ncols;
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) ldl_unit_kernel(UnitParams P) {
 } // namespace
 
 // host pointers in, host pointers out; returns 0 or a HIP error code
-extern "C" int gar_ldl_unit(int n, int ncols, int definite_first, int x_rowmajor, int blocked, double *A, double *X, double *sub, int *piv,
+extern "C" int gar_ldl_unit(int n, int ncols, int definite_first, int x_rowmajor, int blocked, int threads, double *A, double *X, double *sub, int *piv,
                             int *info) {
   UnitParams P{};
   P.n = n;
@@ -104,7 +104,7 @@ extern "C" int gar_ldl_unit(int n, int ncols, int definite_first, int x_rowmajor
   TRY(hipMemcpy(P.X, X, bX, hipMemcpyHostToDevice));
   const size_t lds = sizeof(double) * (size_t)(n * n + n * ncols + (GAR_LDL_PANEL + 2) * n + 64) + sizeof(int) * (size_t)(n + 48);
   TRY(hipFuncSetAttribute((const void *)ldl_unit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(ldl_unit_kernel, dim3(1), dim3(256), lds, (hipStream_t) nullptr, P);
+  hipLaunchKernelGGL(ldl_unit_kernel, dim3(1), dim3(threads > 0 ? threads : 256), lds, (hipStream_t) nullptr, P);
   TRY(hipGetLastError());
   TRY(hipStreamSynchronize((hipStream_t) nullptr));
   TRY(hipMemcpy(A, P.A, bA, hipMemcpyDeviceToHost));
