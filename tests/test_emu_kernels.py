@@ -687,3 +687,20 @@ def test_generic_condensed_solve_with_the_leg_states_eliminated_first(monkeypatc
         s.close()
     sc = max(1.0, max(float(np.abs(v).max()) for v in sols["0"][3]))
     assert max(float(np.abs(a - b).max()) for A, B in zip(sols["1"], sols["0"]) for a, b in zip(A, B) if a.size) <= 1e-10 * sc
+
+
+@pytest.mark.parametrize("nx,nu,nc,horz,legs", [(10, 8, 20, 6, 1), (10, 8, 20, 9, 3), (6, 6, 40, 4, 1)])
+def test_generic_constrained_stage_on_the_blocked_bunch_kaufman(monkeypatch, nx, nu, nc, horz, legs):
+    """The any-dimension backward kernel with a coupled constrained stage of nu + nc >= 24: its reduced KKT matrix
+    [Rhat D^T; D -mu I] goes through wg_bk_factor_blocked (panel by one wave, MFMA trailing updates) on a
+    1 024-thread workgroup -- serial and in leg mode, against the oracle (every factor block)."""
+    monkeypatch.setenv("GAR_HIP_PAD", "0")
+    monkeypatch.setenv("GAR_HIP_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(7 * nc + legs)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nc=nc, mode="W")
+    if legs == 1:
+        solver, _, _ = pc.check_serial(prob, 1e-6, 1e-8, EMU, conditioned=True)
+        assert solver.kernel_name == "generic"
+    else:
+        par = pc.check_parallel(prob, 1e-6, legs, 1e-8, EMU, conditioned=True)
+        assert par._impl.kernel_name == "generic"
