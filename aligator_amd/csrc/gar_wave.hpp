@@ -59,9 +59,11 @@ template <int NX, int NU, int NC = 0> struct WaveCfg {
 #endif
   // Pitch of V in LDS: NX (unpadded).  Its MFMA operand reads V[(16 t + li) * PK + 4 s + lk] are 2-way bank conflicts
   // (lanes li and li + 8); a pitch of NX + 2 makes them conflict-free ((PK li + lk) mod 32 is then a bijection) and
-  // is supported (-DGAR_V_PITCH_PAD=1: every flush is a gather with the pitch) -- measured in an A/B on one box,
-  // alternating launches: backward 11.25 ms padded against 11.07 ms unpadded (scripts/ab_vxx_packed.py): the
-  // conflicts hide behind the 64-cycle MFMAs they feed.  Not used.
+  // is supported (-DGAR_V_PITCH_PAD=1: every flush is a gather with the pitch) -- measured: SQ_LDS_BANK_CONFLICT
+  // falls from 8.1 % to 4.3 % of the wave cycles (45 % -> 30 % of the LDS-active cycles) and SQ_WAVE_CYCLES does not
+  // move (-0.3 %; profiles/r03_sq_lds_pitch.log); A/B on one box, alternating launches: backward 11.25 ms padded
+  // against 11.07 ms unpadded (scripts/ab_vxx_packed.py).  The conflicts hide behind the 64-cycle MFMAs they feed.
+  // Not used.
 #ifndef GAR_V_PITCH_PAD
 #define GAR_V_PITCH_PAD 0
 #endif
