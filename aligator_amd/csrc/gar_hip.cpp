@@ -132,6 +132,8 @@ struct gar_hip_solver {
   bool fold = false, fold_expanded = false, coupled_known = false;
   gar_hip_solver *flay = nullptr;
   double *d_prob2 = nullptr, *d_fac2 = nullptr;
+  double *d_tgain = nullptr; // segment legs: T_t = Rhat_t^{-1} B_t^T per stage (gar_leg_param_prepare)
+  int64_t tgain_doubles = 0;  // per problem
   gar_stage_meta *d_meta2 = nullptr;
   double fold_mueq = 0.0;
   std::vector<int> h_coupled;
@@ -1111,6 +1113,12 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     Q.nxb = s->nxb;
     Q.nxM = s->dims5[0];
     Q.nuM = s->dims5[1];
+    Q.tgain = s->d_tgain;
+    Q.tgain_stride = s->tgain_doubles;
+    Q.local_legs = s->leg_end - s->leg_begin;
+    // T_t = Rhat_t^{-1} B_t^T of every stage of the non-final legs at once, then the recursion (products only)
+    hipLaunchKernelGGL(gar::gar_leg_param_prepare, dim3((unsigned)N, (unsigned)s->batch), dim3(256),
+                       (size_t)gar::leg_prepare_lds_doubles(s->dims5[0], s->dims5[1]) * sizeof(double), s->stream, Q);
     hipLaunchKernelGGL(gar::gar_leg_param_generic, grid, dim3(GAR_LEG_PARAM_THREADS), (size_t)s->seg_param_lds_doubles * sizeof(double),
                        s->stream, Q);
     HIP_TRY(hipGetLastError());
@@ -1385,6 +1393,8 @@ void free_device(gar_hip_solver *s) {
 
   (void)hipFree(s->d_prob2);
   (void)hipFree(s->d_fac2);
+  (void)hipFree(s->d_tgain);
+  s->d_tgain = nullptr;
   (void)hipFree(s->d_meta2);
   s->d_prob2 = s->d_fac2 = nullptr;
   s->d_meta2 = nullptr;
@@ -1459,6 +1469,10 @@ int allocate(gar_hip_solver *s) {
                                 (int)(s->seg_lds_doubles * sizeof(double))));
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_leg_param_generic, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->seg_param_lds_doubles * sizeof(double))));
+    s->tgain_doubles = (int64_t)(s->horizon + 1) * s->dims5[0] * s->dims5[1];
+    HIP_TRY(hipMalloc((void **)&s->d_tgain, sizeof(double) * (size_t)s->tgain_doubles * B));
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_leg_param_prepare, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(gar::leg_prepare_lds_doubles(s->dims5[0], s->dims5[1]) * sizeof(double))));
   }
   if (s->fold) {
     const gar_hip_solver *f = s->flay;

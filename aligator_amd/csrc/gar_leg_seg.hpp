@@ -102,11 +102,96 @@ struct LegParamParams {
   long long prob_stride, fac_stride, fac2_stride, boundary_stride;
   int horizon, num_legs, leg_begin, tuple_doubles, nxb;
   int nxM, nuM; // largest nx, nu (LDS carve)
+  double *tgain;          // [problem][stage][nuM x nxM]: T_t = Rhat_t^{-1} B_t^T (gar_leg_param_prepare)
+  long long tgain_stride; // doubles per problem
+  int local_legs;
 };
 
-__host__ __device__ inline int leg_param_lds_doubles(int nx, int nu) {
+__host__ __device__ inline int leg_param_lds_doubles(int nx, int nu) { // the recursion: Xa Xb Tt Af | Bm Tm Gh Kt | vt vtn yf
   auto a2 = [](int x) { return (x + 1) & ~1; };
-  return 4 * a2(nx * nx) + 3 * a2(nx * nu) + a2(nu * nx) + a2(nu * nu) + 2 * a2(nu) + 3 * a2(nx) + 64;
+  return 4 * a2(nx * nx) + 4 * a2(nx * nu) + 3 * a2(nx) + 64;
+}
+__host__ __device__ inline int leg_prepare_lds_doubles(int nx, int nu) { // V' | Bm VB Tm | Rh | wk | sub piv ctrl
+  auto a2 = [](int x) { return (x + 1) & ~1; };
+  return a2(nx * nx) + 3 * a2(nx * nu) + 2 * a2(nu * nu) + a2(GAR_LDL_PANEL * nu) + 2 * a2(nu) + 64;
+}
+
+// What the parameter recursion needs of Rhat_t = R_t + B_t^T V'_{t+1} B_t is the operator T_t = Rhat_t^{-1} B_t^T
+// (Kth = -T_t Vxt', a product) -- and T_t does not depend on the recursion's state: every stage of every non-final
+// leg at once, one workgroup each (grid (stages, batch) x 256).  The factorisation and the substitution leave the
+// sequential path this way.  V'_{t+1} is the plain kernel's Vxx of stage t + 1 (zero behind a leg end).
+__global__ void __launch_bounds__(256) gar_leg_param_prepare(LegParamParams P) {
+  const WG w = wg_self();
+  double *sm = gar_smem;
+  const int t = (int)blockIdx.x, b = (int)blockIdx.y;
+  int leg = P.leg_begin, t_beg = 0, t_end = 0;
+  for (; leg < P.leg_begin + P.local_legs; ++leg) { // the leg of stage t (among this rank's)
+    gar_get_work(P.horizon, leg, P.num_legs, &t_beg, &t_end);
+    if (t >= t_beg && t < t_end)
+      break;
+  }
+  if (leg >= P.leg_begin + P.local_legs || leg == P.num_legs - 1)
+    return;
+  const bool leg_end = (t == t_end - 1);
+  const double *prob = P.prob + (long long)b * P.prob_stride;
+  const double *fac2 = P.fac2 + (long long)b * P.fac2_stride;
+  const gar_stage_meta m = P.meta[t];
+  const int nx = m.nx, nu = m.nu, nx2 = m.nx2;
+  (void)nx;
+  auto a2 = [](int x) { return (x + 1) & ~1; };
+  const int nxM = P.nxM, nuM = P.nuM;
+  double *p = sm;
+  auto take = [&](int n) { double *o = p; p += a2(n); return o; };
+  double *Vn = take(nxM * nxM), *Bm = take(nxM * nuM), *VB = take(nxM * nuM), *Tm = take(nxM * nuM);
+  double *Rh = take(nuM * nuM), *Rc = take(nuM * nuM), *wk = take(GAR_LDL_PANEL * nuM), *sub = take(nuM);
+  int *piv = (int *)take(nuM), *ctrl = (int *)take(16);
+  const gar_knot_offsets ko = gar_knot_layout(m.nx, nu, 0, nx2, 0);
+  const double *knot = prob + m.in_off;
+  for (int e = w.tid; e < nx2 * nu; e += w.nthr) {
+    const double v = knot[ko.B + e];
+    Bm[e] = v;
+    Tm[(e / nx2) * nx2 + (e % nx2)] = v; // B^T (nu x nx2, row-major) = B column-major, as it is
+  }
+  for (int e = w.tid; e < nu * nu; e += w.nthr)
+    Rh[e] = knot[ko.R + e];
+  if (!leg_end) { // V' symmetrised from its lower triangle as the consuming stage does (:216)
+    const gar_stage_meta mn = P.meta[t + 1];
+    const double *Vg = fac2 + P.meta2[t + 1].fac_off + gar_factor_layout(mn.nx, mn.nu, 0, mn.nx2, 0).Vxx;
+    for (int e = w.tid; e < nx2 * nx2; e += w.nthr) {
+      const int j = e / nx2, i = e - j * nx2;
+      Vn[e] = (i >= j) ? Vg[e] : Vg[i * nx2 + j];
+    }
+  }
+  __syncthreads();
+  const MatV B = colmajor(Bm, nx2);
+  if (!leg_end) { // Rhat = R + B^T (V' B)  (:221, :225)
+    wg_gemm(w, nx2, nu, nx2, colmajor(Vn, nx2), B, MatV{nullptr, 0, 0}, colmajor(VB, nx2), 1.0);
+    __syncthreads();
+    wg_gemm(w, nu, nu, nx2, B.T(), colmajor(VB, nx2), colmajor(Rh, nu), colmajor(Rh, nu), 1.0);
+    __syncthreads();
+  }
+  // Rhat > 0 on a well-posed stage: blocked elimination without pivoting; otherwise Bunch-Kaufman as in the reference
+  int failed = 0, indefinite = 1;
+  if (nu >= 8 && nu <= 64) {
+    for (int e = w.tid; e < nu * nu; e += w.nthr)
+      Rc[e] = Rh[e];
+    __syncthreads();
+    indefinite = wg_ldl_definite_factor(w, nu, Rh, nu, sub, piv, wk, ctrl);
+    if (indefinite) {
+      for (int e = w.tid; e < nu * nu; e += w.nthr)
+        Rh[e] = Rc[e];
+      __syncthreads();
+    }
+  }
+  if (indefinite)
+    failed |= wg_bk_factor(w, nu, Rh, nu, sub, piv, ctrl);
+  __syncthreads();
+  wg_bk_solve(w, nu, Rh, nu, sub, piv, Tm, nx2, 1, nx2); // T = Rhat^{-1} B^T, rows of nx2
+  double *Tg = P.tgain + (long long)b * P.tgain_stride + (long long)t * nuM * nxM;
+  for (int e = w.tid; e < nu * nx2; e += w.nthr)
+    Tg[e] = Tm[e];
+  if (failed && w.tid == 0)
+    atomicOr(&P.status[b], failed);
 }
 
 // (debug build -DGAR_CTRACE: cycles per phase of workgroup (0, 0), read with gar_hip_debug_ptrace)
@@ -147,11 +232,10 @@ __global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_generic(L
   double *p = sm;
   auto take = [&](int n) { double *o = p; p += a2(n); return o; };
   double *Xa = take(nxM * nxM), *Xb = take(nxM * nxM), *Tt = take(nxM * nxM), *Af = take(nxM * nxM);
-  double *Bm = take(nxM * nuM), *VB = take(nxM * nuM), *Gh = take(nuM * nxM), *Kt = take(nuM * nxM);
-  double *Rh = take(nuM * nuM), *sub = take(nuM), *vt = take(nxM), *vtn = take(nxM), *yf = take(nxM);
-  int *piv = (int *)take(nuM), *ctrl = (int *)take(16);
-  double *Xt = Xa, *Xn = Xb; // Vxt' (current) and the buffer the new Vxt / the staged V' go to
-  int failed = 0;
+  double *Bm = take(nxM * nuM), *Tm = take(nxM * nuM), *Gh = take(nuM * nxM), *Kt = take(nuM * nxM);
+  double *vt = take(nxM), *vtn = take(nxM), *yf = take(nxM);
+  double *Xt = Xa, *Xn = Xb; // Vxt' (current) and the buffer the new Vxt goes to
+  const int failed = 0;      // (the factorisations are gar_leg_param_prepare's)
 
   if (last_leg) { // unparameterised records: the scratch layout's, at the caller-visible offsets
     for (int t = t_beg; t < t_end; ++t) {
@@ -181,65 +265,30 @@ __global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_generic(L
       const double *src = fac2 + P.meta2[t].fac_off;
       double *dst = fac + m.fac_off;
       PT(0)
-      // operands: B (nx2 x nu, column-major), Aff (rows nu.. of the row-major fb), yff, R; V' staged in Xn
-      for (int e = w.tid; e < nx2 * nu; e += w.nthr)
+      // operands: B (nx2 x nu, column-major), Aff (rows nu.. of the row-major fb), yff, T = Rhat^{-1} B^T (prepared)
+      const double *Tg = P.tgain + (long long)b * P.tgain_stride + (long long)t * nuM * nxM;
+      for (int e = w.tid; e < nx2 * nu; e += w.nthr) {
         Bm[e] = knot[ko.B + e];
+        Tm[e] = Tg[e];
+      }
       for (int e = w.tid; e < nx2 * nx; e += w.nthr)
         Af[e] = src[f2.fb + nu * nx + e];
       for (int e = w.tid; e < nx2; e += w.nthr)
         yf[e] = src[f2.ff + nu + e];
-      for (int e = w.tid; e < nu * nu; e += w.nthr)
-        Rh[e] = knot[ko.R + e];
-      if (!leg_end) { // V' = Vxx of stage t+1, symmetrised from its lower triangle as the consuming stage does (:216)
-        const gar_stage_meta mn = P.meta[t + 1];
-        const double *Vn = fac2 + P.meta2[t + 1].fac_off + gar_factor_layout(mn.nx, mn.nu, 0, mn.nx2, 0).Vxx;
-        for (int e = w.tid; e < nx2 * nx2; e += w.nthr) {
-          const int j = e / nx2, i = e - j * nx2;
-          Xn[e] = (i >= j) ? Vn[e] : Vn[i * nx2 + j];
-        }
-      }
       __syncthreads();
       PT(1)
       const MatV B = colmajor(Bm, nx2), X = colmajor(Xt, nx2), G = rowmajor(Gh, nth), K = rowmajor(Kt, nth);
-      if (!leg_end) { // Rhat = R + B^T (V' B)  (:221, :225)
-        wg_gemm(w, nx2, nu, nx2, colmajor(Xn, nx2), B, MatV{nullptr, 0, 0}, colmajor(VB, nx2), 1.0);
-        __syncthreads();
-        wg_gemm(w, nu, nu, nx2, B.T(), colmajor(VB, nx2), colmajor(Rh, nu), colmajor(Rh, nu), 1.0);
-      }
-      // Ghat_u = B^T Vxt'  (:286-287)
+      // everything that is a function of Vxt' alone, in one phase:
+      //   Ghat_u = B^T Vxt' (:286-287),  Kth = -Rhat^{-1} Ghat_u = -T Vxt' (:288-292),  Vxt = Aff^T Vxt' (:305-306; at the
+      //   leg end Aff^T I = A^T + K^T B^T, :186),  vt += Vxt'^T yff (:301)
       wg_gemm(w, nu, nth, nx2, B.T(), X, MatV{nullptr, 0, 0}, G, 1.0);
-      __syncthreads();
-      PT(2)
-      // Rhat = L D L^T (Bunch-Kaufman, the reference's factorisation); Kth = -Rhat^-1 Ghat_u  (:288-292)
-      // (Rhat > 0 on a well-posed stage: blocked elimination without pivoting, workspace in VB, a copy of Rhat
-      // parked in Kt for the stage that is not -- that one goes through Bunch-Kaufman as in the reference)
-      int indefinite = 1;
-      if (nu >= 8 && nu <= 64 && GAR_LDL_PANEL * nu <= nx2 * nu && nu * nu <= nu * nth) {
-        for (int e = w.tid; e < nu * nu; e += w.nthr)
-          Kt[e] = Rh[e];
-        __syncthreads();
-        indefinite = wg_ldl_definite_factor(w, nu, Rh, nu, sub, piv, VB, ctrl);
-        if (indefinite) {
-          for (int e = w.tid; e < nu * nu; e += w.nthr)
-            Rh[e] = Kt[e];
-          __syncthreads();
-        }
-      }
-      if (indefinite)
-        failed |= wg_bk_factor(w, nu, Rh, nu, sub, piv, ctrl);
-      __syncthreads();
-      PT(3)
-      for (int e = w.tid; e < nu * nth; e += w.nthr)
-        Kt[e] = -Gh[e];
-      __syncthreads();
-      wg_bk_solve(w, nu, Rh, nu, sub, piv, Kt, nth, 1, nth);
+      wg_gemm(w, nu, nth, nx2, rowmajor(Tm, nx2), X, MatV{nullptr, 0, 0}, K, -1.0);
+      wg_gemm(w, nx, nth, nx2, rowmajor(Af, nx).T(), X, MatV{nullptr, 0, 0}, colmajor(Xn, nx), 1.0);
+      wg_gemm(w, nth, 1, nx2, X.T(), colmajor(yf, nx2), colmajor(vt, nth), colmajor(vtn, nth), 1.0);
       __syncthreads();
       PT(4)
-      // Vxt = Aff^T Vxt'  (:305-306; at the leg end Aff^T I = A^T + K^T B^T, :186),  Vtt += Ghat_u^T Kth  (:308-310),
-      // vt += Vxt'^T yff  (:301), Yth = B Kth  (:295) straight into the record
-      wg_gemm(w, nx, nth, nx2, rowmajor(Af, nx).T(), X, MatV{nullptr, 0, 0}, colmajor(Xn, nx), 1.0);
+      // Vtt += Ghat_u^T Kth  (:308-310),  Yth = B Kth  (:295) straight into the record
       wg_gemm(w, nth, nth, nu, G.T(), K, colmajor(Tt, nth), colmajor(Tt, nth), 1.0);
-      wg_gemv(w, nth, nx2, X.T(), yf, 1, vt, 1, vtn, 1, 1.0);
       if (!leg_end)
         wg_gemm(w, nx2, nth, nu, B, K, MatV{nullptr, 0, 0}, rowmajor(dst + fo.fth + nu * nth, nth), 1.0);
       __syncthreads();
