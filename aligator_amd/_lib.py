@@ -70,6 +70,7 @@ SIGNATURES = {
     "gar_hip_condensed_info": (C.c_int, [C.c_void_p, C.c_int, _PD]),
     "gar_hip_condensed_backward_error": (C.c_int, [C.c_void_p, C.c_int, _PD]),
     "gar_hip_condensed_resolved": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "gar_hip_condensed_solver_name": (C.c_char_p, [C.c_void_p]),
     "gar_hip_set_condensed_backward_ok": (C.c_int, [C.c_void_p, C.c_double]),
     "gar_hip_get_solution": (C.c_int, [C.c_void_p, C.c_int, _PD, _PD, _PD, _PD]),
     "gar_hip_get_gains": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _PD, _PD, _PD]),

@@ -22,6 +22,7 @@
 #include "gar_wave_leg.hpp"
 #include "gar_wave_pair.hpp"
 #include "gar_cyclic.hpp"
+#include "gar_condensed_cr.hpp"
 #include "gar_dense.hpp"
 #include "gar_fold.hpp"
 #include "gar_leg_seg.hpp"
@@ -161,6 +162,8 @@ struct gar_hip_solver {
   double cond_threshold = 1e-10; // parallel-solver.hpp:92
   double cond_backward_ok = GAR_CONDENSED_BACKWARD_OK; // gar_hip_set_condensed_backward_ok
   bool cond_reduced = false; // generic condensed solve: leg states eliminated leg-parallel first (GAR_HIP_CONDENSED_REDUCED=0: off)
+  bool cond_cr = false;      // ... and the J remaining blocks by block cyclic reduction, a workgroup per block and level
+                             // (gar_condensed_cr.hpp; GAR_HIP_CONDENSED_CR=0: the one-workgroup chain, =<k>: from k legs on)
   int max_refinement = 5;        // parallel-solver.hpp:94
   // host staging
   double *h_prob = nullptr; // pinned, batch * prob_doubles (when small enough)
@@ -1339,10 +1342,26 @@ int launch_condensed(gar_hip_solver *s) {
       const dim3 grid((unsigned)s->num_legs, (unsigned)s->batch);
       hipLaunchKernelGGL(gar::gar_condensed_leg_eliminate, grid, dim3(GAR_CONDENSED_THREADS),
                          (size_t)gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double), s->stream, C);
-      gar::CondensedParams R = C;
-      R.reduced = 1;
-      hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
-                         (size_t)s->cond_lds_doubles * sizeof(double), s->stream, R);
+      if (s->cond_cr) {
+        // the J remaining blocks by block cyclic reduction: a workgroup per block and level (gar_condensed_cr.hpp)
+        const int J = s->num_legs;
+        const size_t blk_bytes = (size_t)s->nxb * s->nxb * sizeof(double);
+        hipLaunchKernelGGL(gar::gar_condensed_cr_assemble, grid, dim3(256), blk_bytes, s->stream, C);
+        for (int h = 1; h < J; h *= 2) {
+          hipLaunchKernelGGL(gar::gar_condensed_cr_eliminate, dim3((unsigned)((J - 1 + h) / (2 * h)), (unsigned)s->batch),
+                             dim3(GAR_CONDENSED_THREADS),
+                             (size_t)gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double), s->stream, C, h);
+          hipLaunchKernelGGL(gar::gar_condensed_cr_update, dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch),
+                             dim3(GAR_CONDENSED_THREADS), blk_bytes, s->stream, C, h);
+        }
+        hipLaunchKernelGGL(gar::gar_condensed_cr_back, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
+                           (size_t)gar::gar_condensed_cr_back_lds_doubles(s->nxb, J) * sizeof(double), s->stream, C);
+      } else {
+        gar::CondensedParams R = C;
+        R.reduced = 1;
+        hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
+                           (size_t)s->cond_lds_doubles * sizeof(double), s->stream, R);
+      }
       hipLaunchKernelGGL(gar::gar_condensed_leg_states, grid, dim3(256), (size_t)(5 * s->nxb + 2) * sizeof(double),
                          s->stream, C);
       C.gated = 1;
@@ -1457,6 +1476,11 @@ int allocate(gar_hip_solver *s) {
       const char *cr = std::getenv("GAR_HIP_CONDENSED_REDUCED");
       s->cond_reduced = !(cr && cr[0] == '0') && s->nx0 == s->nxb &&
                         (size_t)gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double) <= 160 * 1024;
+      // cyclic reduction of the reduced system: log2 J dependent steps instead of J; below 4 legs the chain is as short
+      const char *cc = std::getenv("GAR_HIP_CONDENSED_CR");
+      const int cr_min = cc && cc[0] ? std::atoi(cc) : 4;
+      s->cond_cr = s->cond_reduced && cr_min >= 1 && s->num_legs >= std::max(cr_min, 2) && s->nc0 <= s->nxb &&
+                   (size_t)gar::gar_condensed_cr_back_lds_doubles(s->nxb, s->num_legs) * sizeof(double) <= 160 * 1024;
     }
   }
   if (s->seg_bwd_kernel) {
@@ -1548,6 +1572,17 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_leg_eliminate,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double))));
+  if (s->num_legs > 1 && s->cond_cr) {
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_cr_eliminate,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double))));
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_cr_update, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)s->nxb * s->nxb * sizeof(double))));
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_cr_assemble, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)s->nxb * s->nxb * sizeof(double))));
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_cr_back, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(gar::gar_condensed_cr_back_lds_doubles(s->nxb, s->num_legs) * sizeof(double))));
+  }
   return GAR_HIP_OK;
 }
 
@@ -1830,6 +1865,18 @@ int gar_hip_batch(const gar_hip_solver *s) { return s ? s->batch : 0; }
 int gar_hip_horizon(const gar_hip_solver *s) { return s ? s->horizon : -1; }
 const char *gar_hip_kernel_name(const gar_hip_solver *s) {
   return s ? s->kernel_name.c_str() : "";
+}
+
+const char *gar_hip_condensed_solver_name(const gar_hip_solver *s) {
+  if (!s || s->num_legs < 2)
+    return "";
+  if (s->cyc_setup_kernel)
+    return "cyclic"; // gar_cyclic.hpp (specialised leg families), the wave-scope chain gated behind it
+  if (s->cond_wave_kernel)
+    return "chain";
+  if (s->cond_reduced)
+    return s->cond_cr ? "reduced+cyclic" : "reduced+chain"; // gar_generic.hpp / gar_condensed_cr.hpp
+  return "generic-chain";
 }
 
 int gar_hip_stage_offsets(const gar_hip_solver *s, int t, int64_t out[6]) {

@@ -358,6 +358,11 @@ class BatchedRiccatiSolver:
         self._check(self._L.gar_hip_condensed_resolved(self._h, int(b), C.byref(out)))
         return bool(out.value)
 
+    @property
+    def condensed_solver_name(self) -> str:
+        """Which fast solver the condensed system goes through before the gated chain (gar_hip.h)."""
+        return self._L.gar_hip_condensed_solver_name(self._h).decode()
+
     def collapse_feedback(self):
         self._factors_cache = {}
         self._check(self._L.gar_hip_collapse_feedback(self._h))

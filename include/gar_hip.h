@@ -253,6 +253,16 @@ int gar_hip_condensed_backward_error(gar_hip_solver *s, int b, double *out);
  * J remaining blocks -- and checked by its residual; *out = 1 when the last solve of problem b missed the check and
  * was redone in the reference's order (block-tridiagonal.hpp:82-138 with refinement), 0 when the fast result stood. */
 int gar_hip_condensed_resolved(gar_hip_solver *s, int b, int *out);
+/* which fast solver the condensed system of this (leg-mode) solver goes through before the gated chain:
+ *   "cyclic"         block cyclic reduction, one wave per block (specialised leg families);
+ *   "chain"          the wave-scope elimination chain in the reference's order (GAR_HIP_CONDENSED=chain);
+ *   "reduced+cyclic" any-dimension path: leg states eliminated leg-parallel, the J remaining blocks by block cyclic
+ *                    reduction on a workgroup per block and level (log2 J dependent steps; from 4 legs on;
+ *                    GAR_HIP_CONDENSED_CR=0 switches it off, =<k> moves the threshold to k legs);
+ *   "reduced+chain"  ... the J remaining blocks by the one-workgroup chain;
+ *   "generic-chain"  the 2 J blocks in the reference's order (block-tridiagonal.hpp:82-138) only.
+ * "" on a solver without legs. */
+const char *gar_hip_condensed_solver_name(const gar_hip_solver *s);
 /* the omega bound above (default 1e-12); 0: only the reference's absolute threshold counts */
 int gar_hip_set_condensed_backward_ok(gar_hip_solver *s, double omega);
 

@@ -689,6 +689,70 @@ def test_generic_condensed_solve_with_the_leg_states_eliminated_first(monkeypatc
     assert max(float(np.abs(a - b).max()) for A, B in zip(sols["1"], sols["0"]) for a, b in zip(A, B) if a.size) <= 1e-10 * sc
 
 
+@pytest.mark.parametrize("nx,nu,horz,legs,nc0", [(20, 7, 23, 5, None), (9, 3, 16, 8, None), (6, 2, 27, 13, None),
+                                                  (10, 4, 19, 4, 3), (10, 4, 14, 7, 0), (12, 5, 34, 16, None)])
+def test_generic_condensed_solve_by_block_cyclic_reduction(monkeypatch, nx, nu, horz, legs, nc0):
+    """gar_condensed_cr.hpp: with the leg states gone the J remaining blocks are reduced level by level, a workgroup
+    per block and level (log2 J dependent steps; any J, not only powers of two; block 0 of dimension nc0 < nx or 0;
+    blocks below 8 rows on Bunch-Kaufman).  Against the serial oracle, against the one-workgroup chain on the same
+    reduced system (GAR_HIP_CONDENSED_CR=0) and -- with a threshold no solver meets -- redone by the gated full chain."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    from aligator_amd.lqr import LqrProblem
+    monkeypatch.setenv("GAR_HIP_PAD", "0")
+    monkeypatch.setenv("GAR_HIP_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(1000 * nx + legs)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+    if nc0 is not None:
+        prob = LqrProblem(prob.stages, nc0)
+        prob.G0[...] = rng.standard_normal((nc0, nx))
+        prob.g0[...] = rng.standard_normal(nc0)
+    _, _, ref = pc.oracle_serial(prob, 1e-10)
+    dims = [k.dims for k in prob.stages]
+    sols = {}
+    for cr in ("1", "0"):
+        monkeypatch.setenv("GAR_HIP_CONDENSED_CR", cr)
+        s = BatchedRiccatiSolver(dims, prob.nc0, batch=1, num_legs=legs, lib_path=EMU)
+        assert s.kernel_name == "generic"
+        assert s.condensed_solver_name == ("reduced+cyclic" if cr == "1" else "reduced+chain")
+        s.upload([prob])
+        assert s.backward(1e-10) and s.forward()
+        sols[cr] = s.solution(0)
+        assert not s.condensed_resolved(0)
+        resid, steps = s.condensed_info(0)
+        assert resid <= 1e-9 * pc.scale_of(ref)
+        for A, B in zip(sols[cr], ref):
+            assert pc.maxdiff(A, B) <= 1e-9 * pc.scale_of(ref)
+        if cr == "1":
+            s.set_refinement(1e-300, 2, backward_ok=0.0)
+            assert s.backward(1e-10) and s.forward()
+            assert s.condensed_resolved(0)
+            for A, B in zip(s.solution(0), sols["1"]):
+                assert pc.maxdiff(A, B) <= 1e-10 * pc.scale_of(ref)
+        s.close()
+    for A, B in zip(sols["1"], sols["0"]):
+        assert pc.maxdiff(A, B) <= 1e-10 * pc.scale_of(ref)
+    monkeypatch.delenv("GAR_HIP_CONDENSED_CR")
+    s = BatchedRiccatiSolver(dims, prob.nc0, batch=1, num_legs=legs, lib_path=EMU)   # default: from 4 legs on
+    assert s.condensed_solver_name == "reduced+cyclic"
+    s.close()
+    s = BatchedRiccatiSolver(dims, prob.nc0, batch=1, num_legs=3, lib_path=EMU)
+    assert s.condensed_solver_name == "reduced+chain"
+    s.close()
+
+
+def test_generic_condensed_cyclic_reduction_on_a_batch(monkeypatch):
+    """A batch through the level kernels (grid (blocks of the level, batch)): every problem against its own oracle."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    monkeypatch.setenv("GAR_HIP_PAD", "0")
+    monkeypatch.setenv("GAR_HIP_FORCE_GENERIC", "1")
+    nx, nu, horz, legs = 9, 4, 17, 6
+    probs = [synth.generate_lq_problem(300 + i, np.random.default_rng(i).standard_normal(nx), horz, nx, nu, mode="W")
+             for i in range(3)]
+    s = pc.check_batched(probs, 1e-10, 1e-9, EMU, num_legs=legs)
+    assert s.condensed_solver_name == "reduced+cyclic"
+    assert not any(s.condensed_resolved(b) for b in range(3))
+
+
 @pytest.mark.parametrize("nx,nu,nc,horz,legs", [(10, 8, 20, 6, 1), (10, 8, 20, 9, 3), (6, 6, 40, 4, 1)])
 def test_generic_constrained_stage_on_the_blocked_bunch_kaufman(monkeypatch, nx, nu, nc, horz, legs):
     """The any-dimension backward kernel with a coupled constrained stage of nu + nc >= 24: its reduced KKT matrix

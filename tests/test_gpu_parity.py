@@ -696,9 +696,11 @@ def test_config4_talos_lq_shape():
     # LQSolverChoice::PARALLEL with 2-8 threads).  Round 3: segment legs (gar_leg_seg.hpp) -- the two-wave stage kernel
     # over each leg's stages, the parameter part by the generic matrix recursion; before: refused (the generic
     # leg kernels need 270 KB of LDS at nth = 56).  Full factors, K0 after collapseFeedback, at N = 275.
-    for legs in (2, 5, 8):
+    for legs in (2, 5, 8, 16):
         par = pc.check_parallel(prob, 1e-10, legs, 1e-8)
         assert par._impl.kernel_name == "pair_leg<56,24>"
+        # from 4 legs on the reduced condensed system is solved by block cyclic reduction (gar_condensed_cr.hpp)
+        assert par._impl.condensed_solver_name == ("reduced+cyclic" if legs >= 4 else "reduced+chain")
     p2 = synth.generate_lq_problem(5601, np.ones(nx), 60, nx, nu, mode="F")
     par = pc.check_parallel(p2, 1e-10, 4, 1e-6)
     assert par._impl.kernel_name == "pair_leg<56,24>"
