@@ -11,6 +11,8 @@ ref = None
 # (legs, GAR_HIP_CONDENSED_CR): from 4 legs on the reduced condensed system goes through block cyclic reduction
 # (gar_condensed_cr.hpp); "0" = the one-workgroup chain on the same reduced system, for the A/B on one box
 runs = [(1, None), (2, None)] + [(J, cr) for J in (4, 5, 8, 16, 34, 68) for cr in ("0", None)]
+if os.environ.get("LEGS"):   # one configuration (for rocprofv3 --kernel-trace --stats: scripts/prof_wide_legs.sh)
+    runs = [(int(os.environ["LEGS"]), None)]
 for legs, cr in runs:
     if cr is None:
         os.environ.pop("GAR_HIP_CONDENSED_CR", None)
