@@ -31,6 +31,24 @@
 
 namespace gar {
 
+// (debug build -DGAR_CTRACE: cycles per phase of workgroup (0, 0) of each kernel, accumulated over the launches since
+// the last read with gar_hip_debug_crtrace -- scripts/ctrace_condensed_cr.py)
+#ifdef GAR_CTRACE
+__device__ long long g_crtrace[16];
+#define CRT0() long long tprev = clock64();
+#define CRT(id)                                                                                                        \
+  {                                                                                                                    \
+    __syncthreads();                                                                                                   \
+    const long long now_ = clock64();                                                                                  \
+    if (w.tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)                                                              \
+      g_crtrace[id] += now_ - tprev;                                                                                   \
+    tprev = now_;                                                                                                      \
+  }
+#else
+#define CRT0()
+#define CRT(id)
+#endif
+
 struct CrScratch {
   double *diag, *super, *facD, *U, *fsub, *rhs, *err, *info;
   __device__ CrScratch(const CondensedParams &P, int b) {
@@ -48,9 +66,10 @@ struct CrScratch {
 };
 
 // ---- the reduced system, one workgroup per block (the chain kernel assembles it serially) ---------------------
-// grid (J, batch) x 256; LDS: nc0 x n doubles (block 0 only)
-__global__ void __launch_bounds__(256) gar_condensed_cr_assemble(CondensedParams P) {
+// grid (J, batch) x GAR_CONDENSED_THREADS (block 0 is three products: a tile per wave); LDS: nc0 x n doubles
+__global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_assemble(CondensedParams P) {
   const WG w = wg_self();
+  CRT0()
   const int i = (int)blockIdx.x, b = (int)blockIdx.y, J = P.num_legs;
   const int n = P.nxb, bs = n * n, nc0 = P.nc0;
   const CrScratch X(P, b);
@@ -63,12 +82,16 @@ __global__ void __launch_bounds__(256) gar_condensed_cr_assemble(CondensedParams
     __syncthreads();
     wg_gemm(w, nc0, nc0, n, colmajor(GP, nc0), G0.T(), MatV{nullptr, 0, 0}, colmajor(X.diag, nc0), -1.0);
     wg_gemm(w, nc0, n, n, G0, colmajor(X.super + (long long)J * bs, n), MatV{nullptr, 0, 0}, colmajor(X.super, nc0), -1.0);
-    for (int e = w.tid; e < nc0; e += w.nthr) { // (a handful of rows: one thread each)
-      double s = 0.0;
-      for (int k = 0; k < n; ++k)
-        s += G0(e, k) * X.rhs[J * n + k];
-      X.rhs[e] = -prob[P.g0_off + e] - s;
+    const int srow = w.tid >> 2, sq = w.tid & 3, srows = w.nthr >> 2;
+    for (int i0 = 0; i0 < nc0; i0 += srows) { // rhs = -g0 - G0 z_0: four threads per row
+      const int e = i0 + srow, ec = e < nc0 ? e : nc0 - 1;
+      double sum = gar_sliced_dot(prob + P.G0_off + ec, nc0, X.rhs + J * n, n, sq);
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      if (sq == 0 && e < nc0)
+        X.rhs[e] = -prob[P.g0_off + e] - sum;
     }
+    CRT(12)
     return;
   }
   // block i = th_l, l = i - 1:  diag = Vtt_l - W_l - P_{l+1},  off(th_l, th_{l+1}) = Y_{l+1},
@@ -93,6 +116,7 @@ __global__ void __launch_bounds__(256) gar_condensed_cr_assemble(CondensedParams
 // grid (number of odd multiples of h below J, batch) x GAR_CONDENSED_THREADS; LDS as gar_condensed_leg_eliminate
 __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_eliminate(CondensedParams P, int h) {
   const WG w = wg_self();
+  CRT0()
   double *sm = gar_smem;
   const int j = (2 * (int)blockIdx.x + 1) * h, b = (int)blockIdx.y, J = P.num_legs;
   if (j >= J)
@@ -118,6 +142,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_elimin
   for (int e = w.tid; e < n; e += w.nthr)
     R[(ncol - 1) * n + e] = Xs.rhs[j * n + e];
   __syncthreads();
+  CRT(0)
   int bad = 1;
   if (n >= 8 && n <= 64) {
     bad = wg_ldl_definite_factor(w, n, X, n, sub, piv, wk, ctrl);
@@ -129,8 +154,10 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_elimin
   }
   if (bad)
     bad = wg_bk_factor(w, n, X, n, sub, piv, ctrl);
+  CRT(1)
   wg_bk_solve(w, n, X, n, sub, piv, R, 1, n, ncol);
   __syncthreads();
+  CRT(2)
   double *Aj = Xs.U + (long long)j * bs, *Bj = Xs.U + (long long)(J + j) * bs, *yj = Xs.fsub + j * n;
   for (int e = w.tid; e < rl * n; e += w.nthr)
     Aj[e] = R[e];
@@ -139,12 +166,20 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_elimin
       Bj[e] = R[rl * n + e];
   for (int e = w.tid; e < n; e += w.nthr) // a block that would not factorise: NaN reaches the residual gate
     yj[e] = bad ? __longlong_as_double(0x7ff8000000000000ll) : R[(ncol - 1) * n + e];
+  CRT(3)
 }
 
 // ---- (B) the survivors of level h fold their neighbours in ----------------------------------------------------
-// grid (number of multiples of 2h below J, batch) x GAR_CONDENSED_THREADS; LDS: n x n doubles
-__global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_update(CondensedParams P, int h) {
+// grid (number of multiples of 2h below J, batch) x GAR_CONDENSED_THREADS.  staged: the operands of a side (C, A or B
+// of the neighbour, y) are brought into LDS with every load in flight at once and the products read them there -- a
+// product whose operands sit in global memory pays a round trip per 16 columns of K and tile.  LDS: 4 n x n + n
+// doubles (staged; the host decides by what fits a CU), else n x n.
+__host__ __device__ inline int gar_condensed_cr_update_lds_doubles(int nxb, int staged) {
+  return staged ? 4 * nxb * nxb + nxb + 2 : nxb * nxb;
+}
+__global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_update(CondensedParams P, int h, int staged) {
   const WG w = wg_self();
+  CRT0()
   const int i = 2 * h * (int)blockIdx.x, b = (int)blockIdx.y, J = P.num_legs;
   if (i >= J)
     return;
@@ -153,24 +188,81 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_update
   const CrScratch X(P, b);
   double *Si = X.diag + (long long)i * bs, *Ci = X.super + (long long)i * bs, *ri = X.rhs + i * n;
   double *tmp = gar_smem; // the new coupling C_i (r x n) until every product has read the old one
+  double *Lc = tmp + bs, *La = Lc + bs, *Lb = La + bs, *Ly = Lb + bs; // (staged only)
   const int jr = i + h, jl = i - h;
   if (jr < J) {
-    const MatV C = colmajor(Ci, r);
     const bool again = jr + h < J; // i keeps a right neighbour at the next level
-    wg_gemm(w, r, r, n, C, colmajor(X.U + (long long)jr * bs, n), colmajor(Si, r), colmajor(Si, r), -1.0);
-    wg_gemm(w, r, 1, n, C, colmajor(X.fsub + jr * n, n), colmajor(ri, r), colmajor(ri, r), -1.0);
+    double *Ag = X.U + (long long)jr * bs, *Bg = X.U + (long long)(J + jr) * bs, *yg = X.fsub + jr * n;
+    MatV C = colmajor(Ci, r), A = colmajor(Ag, n), B = colmajor(Bg, n), y = colmajor(yg, n);
+    if (staged) {
+#pragma unroll 4
+      for (int e = w.tid; e < bs; e += w.nthr) {
+        if (e < r * n) {
+          Lc[e] = Ci[e];
+          La[e] = Ag[e];
+        }
+        if (again)
+          Lb[e] = Bg[e];
+      }
+      for (int e = w.tid; e < n; e += w.nthr)
+        Ly[e] = yg[e];
+      __syncthreads();
+      C = colmajor(Lc, r), A = colmajor(La, n), B = colmajor(Lb, n), y = colmajor(Ly, n);
+    }
+    wg_gemm(w, r, r, n, C, A, colmajor(Si, r), colmajor(Si, r), -1.0);
+    wg_gemm(w, r, 1, n, C, y, colmajor(ri, r), colmajor(ri, r), -1.0);
     if (again)
-      wg_gemm(w, r, n, n, C, colmajor(X.U + (long long)(J + jr) * bs, n), MatV{nullptr, 0, 0}, colmajor(tmp, r), -1.0);
+      wg_gemm(w, r, n, n, C, B, MatV{nullptr, 0, 0}, colmajor(tmp, r), -1.0);
     __syncthreads();
     if (again)
       for (int e = w.tid; e < r * n; e += w.nthr)
         Ci[e] = tmp[e];
   }
+  CRT(4)
   if (jl >= 0) { // (i >= 2h: r == n; C_{jl} is n x n)
-    const MatV Ct = colmajor(X.super + (long long)jl * bs, n).T();
-    wg_gemm(w, n, n, n, Ct, colmajor(X.U + (long long)(J + jl) * bs, n), colmajor(Si, n), colmajor(Si, n), -1.0);
-    wg_gemm(w, n, 1, n, Ct, colmajor(X.fsub + jl * n, n), colmajor(ri, n), colmajor(ri, n), -1.0);
+    double *Cg = X.super + (long long)jl * bs, *Bg = X.U + (long long)(J + jl) * bs, *yg = X.fsub + jl * n;
+    MatV Ct = colmajor(Cg, n).T(), B = colmajor(Bg, n), y = colmajor(yg, n);
+    if (staged) {
+#pragma unroll 4
+      for (int e = w.tid; e < bs; e += w.nthr) {
+        Lc[e] = Cg[e];
+        Lb[e] = Bg[e];
+      }
+      for (int e = w.tid; e < n; e += w.nthr)
+        Ly[e] = yg[e];
+      __syncthreads();
+      Ct = colmajor(Lc, n).T(), B = colmajor(Lb, n), y = colmajor(Ly, n);
+    }
+    wg_gemm(w, n, n, n, Ct, B, colmajor(Si, n), colmajor(Si, n), -1.0);
+    wg_gemm(w, n, 1, n, Ct, y, colmajor(ri, n), colmajor(ri, n), -1.0);
   }
+  CRT(5)
+}
+
+// slice q of  sum_k a[k astride] x[k] (k < Ka) + sum_k b[k astride] y[k] (k < Kb): every load issued before the first
+// product (gar_sliced_dot twice is two dependent round trips); Ka, Kb may be 0 (a, b must still point at memory)
+__device__ __forceinline__ double gar_sliced_dot2(const double *a, const double *x, int Ka, const double *b, const double *y,
+                                                  int Kb, int astride, int q) {
+  double s = 0.0;
+  const int K = Ka > Kb ? Ka : Kb;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    double av[16], bv[16], xv[16], yv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = k0 + q + 4 * j;
+      const int ka = k < Ka ? k : (Ka > 0 ? Ka - 1 : 0), kb = k < Kb ? k : (Kb > 0 ? Kb - 1 : 0);
+      av[j] = a[(long long)ka * astride];
+      bv[j] = b[(long long)kb * astride];
+      xv[j] = x[ka];
+      yv[j] = y[kb];
+      av[j] = k < Ka ? av[j] : 0.0;
+      bv[j] = k < Kb ? bv[j] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      s += av[j] * xv[j] + bv[j] * yv[j];
+  }
+  return s;
 }
 
 // ---- the top block and the back-substitution, one workgroup per problem ---------------------------------------
@@ -180,6 +272,7 @@ __host__ __device__ inline int gar_condensed_cr_back_lds_doubles(int nxb, int J)
 }
 __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_back(CondensedParams P) {
   const WG w = wg_self();
+  CRT0()
   double *sm = gar_smem;
   const int b = (int)blockIdx.x, J = P.num_legs;
   const int n = P.nxb, bs = n * n, n0 = P.nc0;
@@ -194,6 +287,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_back(C
     for (int e = w.tid; e < n0; e += w.nthr)
       rb[e] = Xs.rhs[e];
     __syncthreads();
+    CRT(7)
     bad = 1;
     if (n0 >= 8 && n0 <= 64) {
       bad = wg_ldl_definite_factor(w, n0, X, n0, sub, piv, wk, ctrl);
@@ -205,8 +299,10 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_back(C
     }
     if (bad)
       bad = wg_bk_factor(w, n0, X, n0, sub, piv, ctrl);
+    CRT(8)
     wg_bk_solve(w, n0, X, n0, sub, piv, rb, 1, 0, 1);
     __syncthreads();
+    CRT(9)
   }
   for (int e = w.tid; e < n; e += w.nthr)
     z[e] = e < n0 ? (bad ? __longlong_as_double(0x7ff8000000000000ll) : rb[e]) : 0.0;
@@ -220,17 +316,19 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_back(C
     for (int i0 = 0; i0 < rows; i0 += srows) {
       const int idx = i0 + srow, ic = idx < rows ? idx : rows - 1;
       const int q = ic / n, row = ic - q * n, j = (2 * q + 1) * h;
-      const int rl = (j - h == 0) ? n0 : n;
-      double sum = gar_sliced_dot(Xs.U + (long long)j * bs + row, n, z + (j - h) * n, rl, sq);
-      if (j + h < J)
-        sum += gar_sliced_dot(Xs.U + (long long)(J + j) * bs + row, n, z + (j + h) * n, n, sq);
+      const int rl = (j - h == 0) ? n0 : n, rr = (j + h < J) ? n : 0;
+      // (y_j and both rows requested before anything is consumed: one round trip per level, not three)
+      const double yj = Xs.fsub[j * n + row];
+      double sum = gar_sliced_dot2(Xs.U + (long long)j * bs + row, z + (j - h) * n, rl,
+                                   Xs.U + (long long)(J + j) * bs + row, z + (rr ? j + h : j) * n, rr, n, sq);
       sum += __shfl_xor(sum, 1);
       sum += __shfl_xor(sum, 2);
       if (sq == 0 && idx < rows)
-        z[j * n + row] = Xs.fsub[j * n + row] - sum;
+        z[j * n + row] = yj - sum;
     }
     __syncthreads();
   }
+  CRT(10)
   double *sol = Xs.err + J * n; // (lbd0, th_0 .. th_{J-2}): where gar_condensed_leg_states reads it
   for (int e = w.tid; e < J * n; e += w.nthr)
     sol[e] = z[e];
@@ -239,6 +337,7 @@ __global__ void __launch_bounds__(GAR_CONDENSED_THREADS) gar_condensed_cr_back(C
     Xs.info[1] = 0.0;
     Xs.info[2] = 0.0;
   }
+  CRT(11)
 }
 
 } // namespace gar

@@ -1346,13 +1346,16 @@ int launch_condensed(gar_hip_solver *s) {
         // the J remaining blocks by block cyclic reduction: a workgroup per block and level (gar_condensed_cr.hpp)
         const int J = s->num_legs;
         const size_t blk_bytes = (size_t)s->nxb * s->nxb * sizeof(double);
-        hipLaunchKernelGGL(gar::gar_condensed_cr_assemble, grid, dim3(256), blk_bytes, s->stream, C);
+        // (the products of a level read their operands from LDS when four blocks fit a CU)
+        const int staged = (size_t)gar::gar_condensed_cr_update_lds_doubles(s->nxb, 1) * sizeof(double) <= 160 * 1024;
+        const size_t upd_bytes = (size_t)gar::gar_condensed_cr_update_lds_doubles(s->nxb, staged) * sizeof(double);
+        hipLaunchKernelGGL(gar::gar_condensed_cr_assemble, grid, dim3(GAR_CONDENSED_THREADS), blk_bytes, s->stream, C);
         for (int h = 1; h < J; h *= 2) {
           hipLaunchKernelGGL(gar::gar_condensed_cr_eliminate, dim3((unsigned)((J - 1 + h) / (2 * h)), (unsigned)s->batch),
                              dim3(GAR_CONDENSED_THREADS),
                              (size_t)gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double), s->stream, C, h);
           hipLaunchKernelGGL(gar::gar_condensed_cr_update, dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch),
-                             dim3(GAR_CONDENSED_THREADS), blk_bytes, s->stream, C, h);
+                             dim3(GAR_CONDENSED_THREADS), upd_bytes, s->stream, C, h, staged);
         }
         hipLaunchKernelGGL(gar::gar_condensed_cr_back, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
                            (size_t)gar::gar_condensed_cr_back_lds_doubles(s->nxb, J) * sizeof(double), s->stream, C);
@@ -1577,7 +1580,8 @@ int allocate(gar_hip_solver *s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double))));
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_cr_update, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)s->nxb * s->nxb * sizeof(double))));
+                                (int)std::min<size_t>(160 * 1024, (size_t)gar::gar_condensed_cr_update_lds_doubles(s->nxb, 1) *
+                                                                      sizeof(double))));
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_cr_assemble, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)((size_t)s->nxb * s->nxb * sizeof(double))));
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_condensed_cr_back, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2690,6 +2694,12 @@ extern "C" int gar_hip_debug_ctrace(long long *out) {
   long long z[16] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_ctrace), sizeof(z)) != hipSuccess) return 1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_ctrace), z, sizeof(z)) != hipSuccess) return 2;
+  return 0;
+}
+extern "C" int gar_hip_debug_crtrace(long long *out) {
+  long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_crtrace), sizeof(z)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_crtrace), z, sizeof(z)) != hipSuccess) return 2;
   return 0;
 }
 extern "C" int gar_hip_debug_ptrace(long long *out) {
