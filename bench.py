@@ -406,6 +406,34 @@ def secondary_shapes(device, batch=1024):
                     "backward_frac_of_hbm_roofline": 8 * (knot + fac) * N * batch / (kb / reps * 1e-3) / HBM_PEAK,
                     "max_rel_err_vs_oracle": err, "max_kkt_rel": kkt}
         s.close()
+        if nc == 0:
+            # ... and the way the reference itself benchmarks this shape: ONE problem, LQSolverChoice::PARALLEL
+            # (bench/talos-walk.cpp:102-127, bench/lqr.cpp:112-134) -- latency of one backward + forward sweep in leg
+            # mode against the serial kernel on the same problem, the leg-mode solution against the serial oracle's
+            # (tests/gar/parallel.cpp:211-235) in the same run
+            prob = probs[(batch - 1) % 2]   # (the problem `ref` and `scale` above belong to)
+            lat = {}
+            for legs in (1, 34):
+                s1 = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs, device=device)
+                s1.upload([prob])
+                for _ in range(2):
+                    s1.backward_async(mu); s1.forward_async()
+                s1.sync()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    s1.backward_async(mu); s1.forward_async()
+                s1.sync()
+                lat[legs] = (time.perf_counter() - t0) / 10 * 1e3
+                if legs > 1:
+                    sol = s1.solution(0)
+                    perr = max(float(np.abs(a - c).max()) for A, B in zip(sol, ref) for a, c in zip(A, B) if a.size) / scale
+                    out[key]["parallel_mode_one_problem"] = {
+                        "legs": legs, "kernel": s1.kernel_name, "condensed_solver": s1.condensed_solver_name,
+                        "condensed_redone_by_the_chain": bool(s1.condensed_resolved(0)),
+                        "ms_per_sweep": lat[legs], "serial_ms_per_sweep": lat[1],
+                        "max_rel_err_vs_serial_oracle": perr,
+                        "max_kkt_rel": max(lqrComputeKktError(prob, *sol, mueq=mu)) / scale}
+                s1.close()
     return out
 
 

@@ -256,6 +256,8 @@ public:
     return fb;
   }
   const char *kernelName() const { return gar_hip_kernel_name(h_); }
+  /// leg mode: the fast solver of the condensed system ("cyclic", "reduced+cyclic", ...; gar_hip.h)
+  const char *condensedSolverName() const { return gar_hip_condensed_solver_name(h_); }
 
 protected:
   HipSolver(LqrProblem &problem, int num_legs, int device, bool dense = false)
