@@ -54,6 +54,20 @@ if mode == "horizon":
         f = s.impl.factor(t_own, 0)
         if f.nu > 0:
             assert np.abs(np.diag(f.kktMat)).max() > 0.0
+    # the any-dimension leg kernels over two ranks: the gathered tuples go through the leg-parallel state elimination
+    # and the block cyclic reduction of the reduced condensed system (gar_condensed_cr.hpp), redundantly on every rank
+    os.environ["GAR_HIP_FORCE_GENERIC"] = "1"
+    os.environ["GAR_HIP_PAD"] = "0"
+    for legs in (5, 6):
+        s = ShardedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, legs, batch=1,
+                                 lib_path=emu, on_device=False)
+        assert s.impl.kernel_name == "generic" and s.impl.condensed_solver_name == "reduced+cyclic"
+        s.impl.upload([prob])
+        s.backward(mueq)
+        s.forward()
+        sol = s.gather_solution(0)
+        assert_matches(sol, gold, 1e-8)
+        assert not s.impl.condensed_resolved(0)
     print(f"rank {rank}: horizon sharding ok")
 else:
     # batch sharding (bench.py --gpus N): each rank sweeps its own problems; the only
