@@ -131,14 +131,24 @@ def spawn_ranks(args):
     n = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if n < args.gpus and not args.same_device:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {n} HIP device(s) visible")
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    rc = 1
+    for attempt in range(3):
+        # the rendezvous store listens on EVERY local address: probe the port there, not on 127.0.0.1 alone (a port
+        # free on loopback can be held on another address: EADDRINUSE); a launch that dies at once is tried again
+        with socket.socket() as so:
+            so.bind(("", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        t0 = time.perf_counter()
+        rc = subprocess.run(cmd, env=env).returncode
+        if rc == 0 or time.perf_counter() - t0 > 45.0:
+            break
+        print(f"bench.py: launch on port {port} failed within {time.perf_counter() - t0:.0f} s (rc {rc}); "
+              f"{'trying another port' if attempt < 2 else 'giving up'}", file=sys.stderr)
+    raise SystemExit(rc)
 
 
 def algorithmic_bytes(N, nx, nu):
@@ -536,11 +546,8 @@ def main():
     if world > 1 or args.mode == "horizon":
         import torch.distributed as dist
         if world == 1 and "MASTER_ADDR" not in os.environ:  # --mode horizon on one GPU: a 1-rank group
-            import socket
-            with socket.socket() as so:
-                so.bind(("127.0.0.1", 0))
-                port = so.getsockname()[1]
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+            # (an in-process store: a one-rank group needs no rendezvous socket, so no port can be in use)
+            dist.init_process_group("nccl", store=dist.HashStore(), world_size=1, rank=0,
                                     device_id=torch.device("cuda", local_rank))
         elif args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -690,7 +690,8 @@ def test_generic_condensed_solve_with_the_leg_states_eliminated_first(monkeypatc
 
 
 @pytest.mark.parametrize("nx,nu,horz,legs,nc0", [(20, 7, 23, 5, None), (9, 3, 16, 8, None), (6, 2, 27, 13, None),
-                                                  (10, 4, 19, 4, 3), (10, 4, 14, 7, 0), (12, 5, 34, 16, None)])
+                                                  (10, 4, 19, 4, 3), (10, 4, 14, 7, 0), (12, 5, 34, 16, None),
+                                                  (9, 3, 9, 2, None), (9, 3, 10, 3, None)])
 def test_generic_condensed_solve_by_block_cyclic_reduction(monkeypatch, nx, nu, horz, legs, nc0):
     """gar_condensed_cr.hpp: with the leg states gone the J remaining blocks are reduced level by level, a workgroup
     per block and level (log2 J dependent steps; any J, not only powers of two; block 0 of dimension nc0 < nx or 0;
@@ -733,7 +734,7 @@ def test_generic_condensed_solve_by_block_cyclic_reduction(monkeypatch, nx, nu, 
         assert pc.maxdiff(A, B) <= 1e-10 * pc.scale_of(ref)
     monkeypatch.delenv("GAR_HIP_CONDENSED_CR")
     s = BatchedRiccatiSolver(dims, prob.nc0, batch=1, num_legs=legs, lib_path=EMU)   # default: from 4 legs on
-    assert s.condensed_solver_name == "reduced+cyclic"
+    assert s.condensed_solver_name == ("reduced+cyclic" if legs >= 4 else "reduced+chain")
     s.close()
     s = BatchedRiccatiSolver(dims, prob.nc0, batch=1, num_legs=3, lib_path=EMU)
     assert s.condensed_solver_name == "reduced+chain"

@@ -381,7 +381,7 @@ def test_sharded_solver_single_rank_rccl():
     from aligator_amd.sharded import ShardedRiccatiSolver
     from aligator_amd.gar import lqrComputeKktError
     with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
+        s.bind(("", 0))   # (the rendezvous store listens on every local address)
         port = s.getsockname()[1]
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
@@ -502,7 +502,7 @@ def test_bench_two_ranks_on_one_gpu():
     sharing this box's only GPU (gloo barrier): whole-job value = all ranks' sweeps / max time."""
     import socket
     with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
+        s.bind(("", 0))   # (the rendezvous store listens on every local address)
         port = s.getsockname()[1]
     d = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                      "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
@@ -566,7 +566,7 @@ def test_bench_horizon_mode_two_ranks_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
+        s.bind(("", 0))   # (the rendezvous store listens on every local address)
         port = s.getsockname()[1]
     d = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                      "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",

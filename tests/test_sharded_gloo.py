@@ -86,7 +86,7 @@ dist.destroy_process_group()
 
 def _free_port():
     with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
+        s.bind(("", 0))   # (the rendezvous store listens on every local address)
         return s.getsockname()[1]
 
 
