@@ -375,17 +375,13 @@ def test_sharded_solver_single_rank_rccl():
     """aligator_amd.sharded on the real device path: torch views of the library's device
     buffers, all_gather_into_tensor over RCCL (world_size 1 is all a 1-GPU box offers; the
     2-rank flow is covered on CPU by tests/test_sharded_gloo.py)."""
-    import socket
     import torch
     import torch.distributed as dist
     from aligator_amd.sharded import ShardedRiccatiSolver
     from aligator_amd.gar import lqrComputeKktError
-    with socket.socket() as s:
-        s.bind(("", 0))   # (the rendezvous store listens on every local address)
-        port = s.getsockname()[1]
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
-                            device_id=torch.device("cuda", 0))
+    # (a one-rank group needs no rendezvous socket: an in-process store, so no port can be in use)
+    dist.init_process_group("nccl", store=dist.HashStore(), world_size=1, rank=0, device_id=torch.device("cuda", 0))
     try:
         for (nx, nu) in ((12, 6), (36, 12)):  # generic leg kernels ; wave-leg kernels + cyclic reduction
             prob = synth.generate_lq_problem(32, np.zeros(nx), 255, nx, nu, mode="W")
@@ -455,11 +451,22 @@ def test_constrained_wave_kernels_bunch_kaufman_pivoting():
 
 
 def _bench_line(cmd):
+    """cmd: the argument list, or a function of a port probed free on every local address (launches through
+    torch.distributed.run: a rendezvous that finds the port taken after all is tried again on another one)."""
     import json
+    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable] + cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    for attempt in range(3):
+        argv = cmd
+        if callable(cmd):
+            with socket.socket() as s:
+                s.bind(("", 0))
+                argv = cmd(s.getsockname()[1])
+        r = subprocess.run([sys.executable] + argv, cwd=root, capture_output=True, text=True, timeout=900)
+        if r.returncode == 0 or not callable(cmd) or "address already in use" not in (r.stdout + r.stderr):
+            break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout            # ONE JSON line on rank 0
@@ -500,13 +507,9 @@ def test_bench_contract_single_gpu():
 def test_bench_two_ranks_on_one_gpu():
     """The N > 1 launch line of the driver (torch.distributed.run, one rank per GPU) with two ranks
     sharing this box's only GPU (gloo barrier): whole-job value = all ranks' sweeps / max time."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("", 0))   # (the rendezvous store listens on every local address)
-        port = s.getsockname()[1]
-    d = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                     "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
-                     "--steps", "2", "--warmup", "1", "--batch", "128", "--backend", "gloo", "--same-device"])
+    d = _bench_line(lambda port: ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                                  "--steps", "2", "--warmup", "1", "--batch", "128", "--backend", "gloo", "--same-device"])
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d and "parallel_in_time" not in d
     assert abs(d["value"] - 2 * 128 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
 
@@ -561,16 +564,12 @@ def test_bench_horizon_mode_one_rank_rccl():
 
 def test_bench_horizon_mode_two_ranks_rccl():
     """The same with a real 2-rank RCCL all-gather; skipped on a 1-GPU box."""
-    import socket
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
-    with socket.socket() as s:
-        s.bind(("", 0))   # (the rendezvous store listens on every local address)
-        port = s.getsockname()[1]
-    d = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                     "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
-                     "--mode", "horizon"])
+    d = _bench_line(lambda port: ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                                  "--mode", "horizon"])
     hs = d["horizon_sharded"]
     assert d["n_gpus"] == 2 and hs["legs_per_rank"] == 128 and hs["max_rel_diff_vs_serial_on_rank0_stages"] < 1e-9
 
