@@ -61,6 +61,10 @@ def lib():
         L.ref_dense_forward.argtypes = [C.c_void_p, C.c_void_p, _PD, _PD, _PD, _PD, _PD]
         L.ref_dense_factor.argtypes = [C.c_void_p, C.c_int, C.c_int, _PD]
         L.ref_dense_initial.argtypes = [C.c_void_p, C.c_int, _PD]
+        L.ref_problem_cycle.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        for nm in ("ref_serial_cycle_append", "ref_parallel_cycle_append", "ref_dense_cycle_append"):
+            getattr(L, nm).argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_kkt_error.argtypes = [C.c_void_p, _PD, _PD, _PD, _PD, C.c_double, _PD, _PD]
         L.ref_bk_compute.argtypes = [C.c_int, _PD, _PD, _PD, C.POINTER(C.c_int)]
         L.ref_bk_solve.argtypes = [C.c_int, _PD, C.c_int, _PD]
         L.ref_block_tridiag_solve.argtypes = [C.c_int, C.POINTER(C.c_int), _PD, _PD, _PD, _PD, C.c_int]
@@ -98,6 +102,19 @@ class Problem:
             lib().ref_problem_free(self._h)
         except Exception:
             pass
+
+    def cycle(self, knot):
+        """The caller's side of an MPC cycle (solvers/proxddp/workspace.hxx:122-126): rotate_vec_left(stages, 0, 1),
+        a fresh knot of `knot`'s dimensions in the last-but-one slot, filled with its blocks."""
+        L = lib()
+        d = np.ascontiguousarray(knot.dims, dtype=np.int32)
+        L.ref_problem_cycle(self._h, d.ctypes.data_as(C.POINTER(C.c_int)))
+        blocks = [_f(getattr(knot, nm)) for nm in _BLOCKS]
+        L.ref_problem_set_knot(self._h, self.N - 1, *[_p(b) for b in blocks])
+        nd = self.dims.copy()
+        nd[:self.N - 1] = self.dims[1:self.N]
+        nd[self.N - 1] = d
+        self.dims = nd
 
     def sizes(self):
         d = self.dims
@@ -162,6 +179,12 @@ class ProximalRiccatiSolver(_SolverBase):
     def nth(self, t):
         return int(self.problem.dims[t, 4])
 
+    def cycleAppend(self):
+        """ProximalRiccatiSolver::cycleAppend (proximal-riccati.hxx:79-86) on the problem's last-but-one knot, as
+        solver-proxddp.hxx:208 calls it (after Problem.cycle)."""
+        if lib().ref_serial_cycle_append(self._h, self.problem._h):
+            raise RuntimeError(lib().ref_last_error().decode())
+
     def backward(self, mueq: float) -> bool:
         rc = lib().ref_serial_backward(self._h, float(mueq))
         if rc < 0:
@@ -213,6 +236,12 @@ class ParallelRiccatiSolver(_SolverBase):
                 return 0 if i == J - 1 else int(self.problem.dims[e - 1, 3])
         raise IndexError(t)
 
+    def cycleAppend(self):
+        """ParallelRiccatiSolver::cycleAppend (parallel-solver.hxx:246-258): drops every parameterisation and
+        initialises again (the problem's dims change under it: re-read them with Problem.refresh_nth)."""
+        if lib().ref_parallel_cycle_append(self._h, self.problem._h):
+            raise RuntimeError(lib().ref_last_error().decode())
+
     def set_refinement(self, thr, steps):
         lib().ref_parallel_set_refinement(self._h, float(thr), int(steps))
 
@@ -250,6 +279,11 @@ class RiccatiSolverDense:
         except Exception:
             pass
 
+    def cycleAppend(self):
+        """RiccatiSolverDense::cycleAppend (dense-riccati.hxx:118-146)."""
+        if lib().ref_dense_cycle_append(self._h, self.problem._h):
+            raise RuntimeError(lib().ref_last_error().decode())
+
     def backward(self, mueq: float) -> bool:
         rc = lib().ref_dense_backward(self._h, float(mueq))
         if rc < 0:
@@ -286,6 +320,19 @@ class RiccatiSolverDense:
                 lib().ref_dense_initial(self._h, what, _p(a))
             out.append(np.ascontiguousarray(a))
         return out
+
+
+def kkt_error(problem: Problem, xs, us, vs, lbdas, mueq, theta=None):
+    """aligator::gar::lqrComputeKktError (gar/utils.hxx:88-182): (dynErr, cstErr, dualErr)."""
+    cat = lambda v: np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in v])
+                                         if len(v) else np.zeros(0))
+    X, U, V, Lm = cat(xs), cat(us), cat(vs), cat(lbdas)
+    th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+    out = np.zeros(3)
+    if lib().ref_kkt_error(problem._h, _p(X), _p(U), _p(V), _p(Lm), float(mueq), _p(th) if th is not None else None,
+                           _p(out)):
+        raise RuntimeError(lib().ref_last_error().decode())
+    return tuple(out)
 
 
 def bk_compute(A):

@@ -9,6 +9,9 @@
 //   aligator::gar::RiccatiSolverDense                         (gar/dense-riccati.hpp, .hxx -> dense-kernel.hpp)
 //   aligator::BunchKaufman                                    (core/bunchkaufman.hpp)
 //   aligator::gar::symmetricBlockTridiagSolve                 (gar/block-tridiagonal.hpp)
+//   aligator::gar::lqrComputeKktError                         (gar/utils.hpp, .hxx)
+//   aligator::rotate_vec_left + the solvers' cycleAppend      (utils/mpc-util.hpp; the MPC cycle of
+//                                                              solvers/proxddp/workspace.hxx:122-126)
 #define ALIGATOR_MULTITHREADING
 #include <sched.h>
 #ifndef ALIGATOR_TRACY_SET_THREAD_NAME
@@ -20,6 +23,8 @@
 #include "aligator/gar/parallel-solver.hxx"
 #include "aligator/gar/block-tridiagonal.hpp"
 #include "aligator/gar/dense-riccati.hxx"
+#include "aligator/gar/utils.hxx"
+#include "aligator/utils/mpc-util.hpp"
 
 #include <cstring>
 #include <memory>
@@ -270,6 +275,77 @@ void ref_dense_initial(void *sp, int what, double *out) {
   case 2: put(s->thGrad, out); break;
   case 3: put(s->thHess, out); break;
   default: break;
+  }
+}
+
+// ---- the MPC cycle as WorkspaceTpl::cycleAppend drives it (solvers/proxddp/workspace.hxx:122-126,
+// solver-proxddp.hxx:208): rotate the knots left keeping the terminal one, a fresh knot in the last-but-one slot
+// (filled by the caller through ref_problem_set_knot), then the solver's own cycleAppend on that knot -----------------
+void ref_problem_cycle(void *pp, const int *d5) {
+  auto *p = static_cast<Problem *>(pp);
+  const size_t N = size_t(p->horizon());
+  rotate_vec_left(p->stages, 0, 1);
+  p->stages[N - 1] = Knot(uint(d5[0]), uint(d5[1]), uint(d5[2]), uint(d5[3]), uint(d5[4]));
+}
+int ref_serial_cycle_append(void *s, void *pp) {
+  auto *p = static_cast<Problem *>(pp);
+  try {
+    static_cast<Serial *>(s)->cycleAppend(p->stages[size_t(p->horizon()) - 1]);
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int ref_parallel_cycle_append(void *s, void *pp) {
+  auto *p = static_cast<Problem *>(pp);
+  try {
+    static_cast<Parallel *>(s)->cycleAppend(p->stages[size_t(p->horizon()) - 1]);
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int ref_dense_cycle_append(void *s, void *pp) {
+  auto *p = static_cast<Problem *>(pp);
+  try {
+    static_cast<DenseSolver *>(s)->cycleAppend(p->stages[size_t(p->horizon()) - 1]);
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// ---- lqrComputeKktError (gar/utils.hxx:88-182) on packed trajectories; out = {dynErr, cstErr, dualErr} ---------------
+int ref_kkt_error(void *pp, const double *xs, const double *us, const double *vs, const double *lbdas, double mueq,
+                  const double *theta, double out[3]) {
+  const Problem &p = *static_cast<Problem *>(pp);
+  Sol sol(p);
+  auto fill = [](std::vector<VectorXs> &v, const double *in) {
+    for (auto &x : v)
+      for (Eigen::Index i = 0; i < x.size(); ++i)
+        x(i) = *in++;
+  };
+  fill(sol.xs, xs); fill(sol.us, us); fill(sol.vs, vs); fill(sol.lbdas, lbdas);
+  if (sol.us.size() < sol.xs.size()) // the function indexes us[t] up to t = N only when knot.nu > 0
+    sol.us.emplace_back(VectorXs::Zero(0));
+  try {
+    std::array<double, 3> e;
+    if (theta && p.ntheta() > 0) {
+      VectorXs th(Eigen::Index(p.ntheta()));
+      get(th, theta);
+      std::optional<typename math_types<double>::ConstVectorRef> opt{std::in_place, th};
+      e = gar::lqrComputeKktError<double>(p, sol.xs, sol.us, sol.vs, sol.lbdas, mueq, opt, false);
+    } else {
+      e = gar::lqrComputeKktError<double>(p, sol.xs, sol.us, sol.vs, sol.lbdas, mueq, std::nullopt, false);
+    }
+    out[0] = e[0]; out[1] = e[1]; out[2] = e[2];
+    return 0;
+  } catch (const std::exception &ex) {
+    g_err = ex.what();
+    return -1;
   }
 }
 

@@ -201,3 +201,168 @@ def test_stage_dense_solver_oracle_equals_reference_code():
         for a, b in zip(rs.initial(), (o.kkt0_ff, o.kkt0_fth, o.thGrad, o.thHess)):
             if a.size:
                 assert np.abs(a - np.asarray(b).reshape(a.shape)).max() <= tol * max(1.0, np.abs(b).max())
+
+
+# ---- rows a10 / f4 (cycleAppend) and a17 (lqrComputeKktError) against the reference's own code ----------------------
+def _rotate(prob, new):
+    """The caller's side of an MPC cycle (solvers/proxddp/workspace.hxx:122-126)."""
+    N = prob.horizon
+    prob.stages[:N] = prob.stages[1:N] + [new]
+
+
+@pytest.mark.parametrize("nx,nu,nc", [(8, 4, 0), (6, 3, 2)])
+def test_mpc_cycle_reference_code_vs_oracle_and_kernels(oracle, nx, nu, nc):
+    """ProximalRiccatiSolver::cycleAppend (proximal-riccati.hxx:79-86) driven the way WorkspaceTpl::cycleAppend and
+    solver-proxddp.hxx:208 drive it, on the reference's compiled code: after each cycle (more cycles than stages)
+      reference(cycled) == reference(fresh solver on the rotated problem)   -- what the contract of the call is,
+      reference(cycled) == oracle on the rotated problem                    -- the oracle's pin,
+      reference(cycled) == the kernel sources on the emulator through the C ABI's ring (gar_hip_cycle_append),
+    solution and every stage's gains and value function; and right after cycleAppend, before the next backward, the
+    rotated factors: stage t holds what stage t+1 held, the last-but-one factor is re-created (zero gains), thGrad / thHess
+    are zero."""
+    import os
+    import subprocess
+    from aligator_amd.gar import ProximalRiccatiSolver
+    here = os.path.dirname(os.path.abspath(__file__))
+    emu = os.path.join(here, "emu", "_build", "libgar_hip_emu.so")
+    subprocess.run(["make", "-s", "-C", os.path.join(here, "emu")], check=True)
+    rng = np.random.default_rng(5 + nx)
+    horz, mu, tol = 5, 1e-8, 1e-10
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nc=nc, mode="W")
+    rp = ref.Problem(prob)
+    rs = ref.ProximalRiccatiSolver(rp)
+    ks = ProximalRiccatiSolver(prob, lib_path=emu)
+    assert rs.backward(mu) and ks.backward(mu)
+    rs.forward()
+    for c in range(horz + 2):
+        before = [rs.datas(t) for t in range(horz + 1)]
+        new = synth.generate_knot(rng, nx, nu, nc=nc, mode="W")
+        _rotate(prob, new)
+        rp.cycle(new)
+        rs.cycleAppend()
+        ks.cycleAppend(new)
+        for t in range(horz - 1):                                  # rotate_vec_left(datas, 0, 1)
+            for nm in ("ff", "fb", "Vxx", "vx"):
+                assert np.array_equal(getattr(rs.datas(t), nm), getattr(before[t + 1], nm)), (c, t, nm)
+        for nm in ("ff", "fb"):                                    # StageFactor re-created: its constructor zeroes the
+            assert not getattr(rs.datas(horz - 1), nm).any(), (c, nm)   # gains (riccati-kernel.hxx:46-49), NOT Vxx / vx
+        for nm in ("ff", "fb", "Vxx", "vx"):                       # (CostToGo's leaves them uninitialised, .hpp:43-52)
+            assert np.array_equal(getattr(rs.datas(horz), nm), getattr(before[horz], nm))
+        assert not any(a.any() for a in rs.initial()[1:])          # thGrad, thHess (and kkt0.mat) zeroed
+        assert rs.backward(mu) and ks.backward(mu)
+        rsol = rs.forward()
+        ksol = lqrInitializeSolution(prob)
+        assert ks.forward(*ksol)
+        fresh = ref.ProximalRiccatiSolver(ref.Problem(prob))
+        assert fresh.backward(mu)
+        fsol = fresh.forward()
+        _, osol, oref = pc.oracle_serial(prob, mu)
+        sc = pc.scale_of(oref)
+        for a, f, o, k in zip(rsol, fsol, oref, ksol):
+            assert pc.maxdiff(a, f) == 0.0, c                      # same code, same data: bitwise
+            assert pc.maxdiff(a, o) <= tol * sc, c
+            assert pc.maxdiff(a, k) <= 1e-9 * sc, c
+        for t in range(horz + 1):
+            r, o, k = rs.datas(t), osol.datas(t), ks.datas[t]
+            for nm in ("ff", "fb", "Vxx", "vx"):
+                a = getattr(r, nm)
+                if not a.size:
+                    continue
+                b = getattr(o, nm)
+                kk = getattr(k, nm) if nm in ("ff", "fb") else getattr(k.vm, nm)
+                assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (c, t, nm)
+                assert np.abs(a - np.asarray(kk).reshape(a.shape)).max() <= 1e-9 * max(1.0, np.abs(a).max()), (c, t, nm)
+
+
+def test_parallel_cycle_reference_code_vs_oracle(oracle):
+    """ParallelRiccatiSolver::cycleAppend (parallel-solver.hxx:246-258: drop every parameterisation, initialise
+    again) on the reference's compiled code: the cycled solver equals the oracle's leg-parallel solve of the rotated
+    problem."""
+    rng = np.random.default_rng(23)
+    nx, nu, horz, legs, mu = 8, 4, 11, 3, 1e-9
+    prob = synth.generate_lq_problem(rng, np.zeros(nx), horz, nx, nu, mode="W")
+    rp = ref.Problem(prob)
+    rpar = ref.ParallelRiccatiSolver(rp, legs)
+    assert rpar.backward(mu)
+    rpar.forward()
+    for c in range(3):
+        new = synth.generate_knot(rng, nx, nu, mode="W")
+        _rotate(prob, new)
+        rp.cycle(new)
+        rpar.cycleAppend()
+        assert rpar.backward(mu)
+        rsol = rpar.forward()
+        opar = oracle.ParallelRiccatiSolver(pc.to_oracle(prob), legs)
+        opar.backward(mu)
+        osol = lqrInitializeSolution(prob)
+        opar.forward(*osol)
+        sc = pc.scale_of(osol)
+        for a, b in zip(rsol, osol):
+            assert pc.maxdiff(a, b) <= 1e-10 * sc, c
+
+
+def test_kkt_error_equals_reference_code(oracle):
+    """lqrComputeKktError (gar/utils.hxx:88-182) compiled from the reference against the two host mirrors' restatement
+    (aligator_amd/lqr.py, numpy) and the oracle's (oracle/gar_oracle.c), on trajectories that are NOT solutions (every
+    term of every residual is non-zero), with and without theta, constrained and not, nu = 0 at the terminal knot."""
+    from aligator_amd.lqr import lqrComputeKktError
+    rng = np.random.default_rng(31)
+    par, theta = _parametric()
+    for prob, th, mu in ((synth.generate_lq_problem(rng, rng.standard_normal(8), 9, 8, 4, mode="F"), None, 1e-7),
+                         (_constrained(6, 3, 4, 7, 11), None, 1e-3),
+                         (par, theta, 1e-5),
+                         (synth.short_horizon_problem(8), None, 0.0)):
+        sol = lqrInitializeSolution(prob)
+        for group in sol:
+            for a in group:
+                a[...] = rng.standard_normal(a.shape)
+        r = ref.kkt_error(ref.Problem(prob), *sol, mu, th)
+        mine = lqrComputeKktError(prob, *sol, mueq=mu, theta=th)
+        theirs = oracle.lqr_kkt_error(pc.to_oracle(prob), *sol, mu, th)
+        assert min(r) > 1e-3 or prob.stages[0].nc == 0            # the comparison is not 0 == 0
+        for a, b, c in zip(r, mine, theirs):
+            assert abs(a - b) <= 1e-13 * max(1.0, abs(a)), (r, mine)
+            assert abs(a - c) <= 1e-13 * max(1.0, abs(a)), (r, theirs)
+
+
+def test_dense_cycle_reference_code_vs_oracle_and_kernels():
+    """RiccatiSolverDense::cycleAppend (dense-riccati.hxx:118-146) on the reference's compiled code, cycled more
+    often than there are stages: equal to the numpy restatement solving the rotated problem afresh and to the dense
+    kernels on the emulator through the C ABI's ring."""
+    import os
+    import subprocess
+    from oracle.dense_riccati import RiccatiSolverDense as OracleDense
+    from aligator_amd.gar import RiccatiSolverDense
+    here = os.path.dirname(os.path.abspath(__file__))
+    emu = os.path.join(here, "emu", "_build", "libgar_hip_emu.so")
+    subprocess.run(["make", "-s", "-C", os.path.join(here, "emu")], check=True)
+    rng = np.random.default_rng(41)
+    nx, nu, horz, mu = 6, 3, 4, 1e-9
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+    rp = ref.Problem(prob)
+    rs = ref.RiccatiSolverDense(rp)
+    ks = RiccatiSolverDense(prob, lib_path=emu)
+    assert rs.backward(mu) and ks.backward(mu)
+    rs.forward()
+    for c in range(horz + 2):
+        new = synth.generate_knot(rng, nx, nu, mode="W")
+        _rotate(prob, new)
+        rp.cycle(new)
+        rs.cycleAppend()
+        ks.cycleAppend(new)
+        assert rs.backward(mu) and ks.backward(mu)
+        rsol = rs.forward()
+        ksol = lqrInitializeSolution(prob)
+        assert ks.forward(*ksol)
+        o = OracleDense(prob, terminal_leading_block=False)
+        o.backward(mu)
+        osol = lqrInitializeSolution(prob)
+        o.forward(*osol)
+        sc = pc.scale_of(osol)
+        for a, b, k in zip(rsol, osol, ksol):
+            assert pc.maxdiff(a, b) <= 1e-10 * sc, c
+            assert pc.maxdiff(a, k) <= 1e-9 * sc, c
+        for t in range(horz + 1):
+            f = rs.datas(t)
+            for a, b in ((f.Pxx, o.Pxx[t]), (f.px, o.px[t])):
+                assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), (c, t)
