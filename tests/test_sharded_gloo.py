@@ -1,6 +1,6 @@
-"""The N > 1 path on CPU: world_size = 2, backend gloo, 127.0.0.1.
+"""The N > 1 path on CPU: world_size = 2 and 3, backend gloo, 127.0.0.1.
 
-Two processes run the REAL sharded flow of aligator_amd.sharded
+Two (three) processes run the REAL sharded flow of aligator_amd.sharded
 (gar_hip_solver_create_sharded -> backward_legs -> all_gather of the boundary
 tuples -> condensed solve -> forward_legs) with the kernel sources executing on
 the wave emulator (tests/emu: test-only build, host memory), and bench.py's batch
@@ -35,7 +35,9 @@ if mode == "horizon":
     from aligator_amd.sharded import ShardedRiccatiSolver
     from test_golden import load_fixture, assert_matches
     prob, mueq, _, gold = load_fixture(os.path.join(sys.argv[1], "tests", "golden", "parallel_shape_nx8_N17.npz"))
-    for legs in (2, 3, 4, 5, 6):          # odd leg counts: an UNEVEN split over the two ranks (1 + 2, 2 + 3)
+    for legs in (2, 3, 4, 5, 6):          # odd leg counts: an UNEVEN split over the ranks (1 + 2, 2 + 3; 1 + 2 + 2, ...)
+        if legs < world:                   # 1 <= W <= J (gar_hip_solver_create_ranked)
+            continue
         s = ShardedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, legs, batch=1,
                                  lib_path=emu, on_device=False)
         s.impl.upload([prob])
@@ -44,11 +46,11 @@ if mode == "horizon":
         sol = s.gather_solution(0)
         assert_matches(sol, gold, 1e-8)
         assert max(lqrComputeKktError(prob, *sol, mueq=mueq)) <= 1e-8
-        # this rank really only computed its own stages: legs [r J / 2, (r+1) J / 2) of get_work(17, ., J)
+        # this rank really only computed its own stages: legs [r J / W, (r+1) J / W) of get_work(17, ., J)
         lo, hi = s.stage_range
-        cut = (legs // 2) * 18 // legs
-        assert (lo, hi) == ((0, cut) if rank == 0 else (cut, 18)), (lo, hi, cut)
-        assert s.leg_range == ((0, legs // 2) if rank == 0 else (legs // 2, legs))
+        l0, l1 = rank * legs // world, (rank + 1) * legs // world
+        assert s.leg_range == (l0, l1), (s.leg_range, l0, l1)
+        assert (lo, hi) == (l0 * 18 // legs, l1 * 18 // legs), (lo, hi, l0, l1)
         # datas[t].kktMat of a sharded solver is formed from THIS sweep's mueq (ADVICE r2)
         t_own = lo
         f = s.impl.factor(t_own, 0)
@@ -58,7 +60,7 @@ if mode == "horizon":
     # and the block cyclic reduction of the reduced condensed system (gar_condensed_cr.hpp), redundantly on every rank
     os.environ["GAR_HIP_FORCE_GENERIC"] = "1"
     os.environ["GAR_HIP_PAD"] = "0"
-    for legs in (5, 6):
+    for legs in (5, 6) if world == 2 else (5,):
         s = ShardedRiccatiSolver([k.dims for k in prob.stages], prob.nc0, legs, batch=1,
                                  lib_path=emu, on_device=False)
         assert s.impl.kernel_name == "generic" and s.impl.condensed_solver_name == "reduced+cyclic"
@@ -95,14 +97,13 @@ def build_emu():
     subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu")], check=True)
 
 
-@pytest.mark.parametrize("mode", ["horizon", "batch"])
-def test_two_ranks_gloo(tmp_path, mode):
+def _run_ranks(tmp_path, mode, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT, EMU, mode], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -110,3 +111,14 @@ def test_two_ranks_gloo(tmp_path, mode):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
         assert "ok" in out
+
+
+@pytest.mark.parametrize("mode", ["horizon", "batch"])
+def test_two_ranks_gloo(tmp_path, mode):
+    _run_ranks(tmp_path, mode, 2)
+
+
+def test_three_ranks_gloo_horizon(tmp_path):
+    """An odd world: legs 3 (one per rank), 4, 5, 6 over three ranks -- per-rank counts 1+1+2, 1+2+2, 2+2+2 -- through
+    the chunked all-gather of gar_hip_solver_create_ranked's layout; the any-dimension leg kernels at 5 legs."""
+    _run_ranks(tmp_path, "horizon", 3)
