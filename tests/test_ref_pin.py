@@ -274,31 +274,61 @@ def test_mpc_cycle_reference_code_vs_oracle_and_kernels(oracle, nx, nu, nc):
                 assert np.abs(a - np.asarray(kk).reshape(a.shape)).max() <= 1e-9 * max(1.0, np.abs(a).max()), (c, t, nm)
 
 
-def test_parallel_cycle_reference_code_vs_oracle(oracle):
+@pytest.mark.parametrize("nx,nu,nc,kernel", [(8, 4, 0, "wave_leg<8,4>"), (6, 3, 0, "wave_leg<8,4>"), (8, 4, 3, None)])
+def test_parallel_cycle_reference_code_vs_oracle_and_kernels(oracle, nx, nu, nc, kernel):
     """ParallelRiccatiSolver::cycleAppend (parallel-solver.hxx:246-258: drop every parameterisation, initialise
     again) on the reference's compiled code: the cycled solver equals the oracle's leg-parallel solve of the rotated
-    problem."""
-    rng = np.random.default_rng(23)
-    nx, nu, horz, legs, mu = 8, 4, 11, 3, 1e-9
-    prob = synth.generate_lq_problem(rng, np.zeros(nx), horz, nx, nu, mode="W")
+    problem, the product's host mirror on the emulator (which re-parameterises the caller's problem the same way),
+    and the RAW C ABI's gar_hip_cycle_append in leg mode ("just reinitialise everything": buffers rebuilt, the whole
+    problem uploaded again) -- a shape with its own leg kernels, one padded inside the library, one with constraints
+    folded onto them."""
+    import os
+    import subprocess
+    from aligator_amd.gar import BatchedRiccatiSolver, ParallelRiccatiSolver
+    here = os.path.dirname(os.path.abspath(__file__))
+    emu = os.path.join(here, "emu", "_build", "libgar_hip_emu.so")
+    subprocess.run(["make", "-s", "-C", os.path.join(here, "emu")], check=True)
+    rng = np.random.default_rng(23 + nx + nc)
+    horz, legs, mu = 11, 3, 1e-7 if nc else 1e-9
+    tol = 1e-8 if nc else 1e-10
+    prob = synth.generate_lq_problem(rng, np.zeros(nx), horz, nx, nu, nc=nc, mode="W")
+    plain = prob.copy()                                            # never parameterised: what the raw ABI is given
     rp = ref.Problem(prob)
     rpar = ref.ParallelRiccatiSolver(rp, legs)
-    assert rpar.backward(mu)
+    kprob = prob.copy()
+    kpar = ParallelRiccatiSolver(kprob, legs, lib_path=emu)
+    if kernel:
+        assert kpar._impl.kernel_name == kernel
+    raw = BatchedRiccatiSolver([k.dims for k in plain.stages], plain.nc0, 1, legs, lib_path=emu)
+    raw.upload([plain])
+    assert rpar.backward(mu) and kpar.backward(mu) and raw.backward(mu)
     rpar.forward()
     for c in range(3):
-        new = synth.generate_knot(rng, nx, nu, mode="W")
-        _rotate(prob, new)
+        new = synth.generate_knot(rng, nx, nu, nc=nc, mode="W")
+        for p in (prob, kprob, plain):
+            _rotate(p, new.copy())
         rp.cycle(new)
         rpar.cycleAppend()
-        assert rpar.backward(mu)
+        kpar.cycleAppend(new)
+        raw.cycle_append(new.dims)                                 # the C entry point itself, leg mode
+        raw.upload([plain])
+        assert rpar.backward(mu) and kpar.backward(mu) and raw.backward(mu)
         rsol = rpar.forward()
-        opar = oracle.ParallelRiccatiSolver(pc.to_oracle(prob), legs)
+        ksol = lqrInitializeSolution(plain)
+        assert kpar.forward(*ksol)
+        assert raw.forward()
+        opar = oracle.ParallelRiccatiSolver(pc.to_oracle(plain.copy()), legs)
         opar.backward(mu)
-        osol = lqrInitializeSolution(prob)
+        osol = lqrInitializeSolution(plain)
         opar.forward(*osol)
         sc = pc.scale_of(osol)
-        for a, b in zip(rsol, osol):
-            assert pc.maxdiff(a, b) <= 1e-10 * sc, c
+        for a, b, k, w in zip(rsol, osol, ksol, raw.solution(0)):
+            assert pc.maxdiff(a, b) <= tol * sc, c
+            assert pc.maxdiff(a, k) <= 10 * tol * sc, c
+            assert pc.maxdiff(a, w) <= 10 * tol * sc, c
+        # the reference re-parameterised the rotated problem: the same knots carry nth = nx in the mirror's problem
+        for t in range(horz + 1):
+            assert kprob.stages[t].nth == rpar.nth(t), (c, t)
 
 
 def test_kkt_error_equals_reference_code(oracle):
