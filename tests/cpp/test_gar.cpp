@@ -343,6 +343,37 @@ static void mpc_cycle() {
   std::printf("  kernel %s, %u cycles\n", solver.kernelName(), horz + 2);
 }
 
+// ParallelRiccatiSolver::cycleAppend (parallel-solver.hxx:246-258: "just reinitialise everything"): in leg mode the
+// C ABI rebuilds its layout and buffers; the next sweep must solve the caller's rotated problem like the serial solver
+static void mpc_cycle_parallel() {
+  std::printf("mpc_cycle_parallel\n");
+  std::mt19937 rng(9);
+  const uint nx = 8, nu = 4, horz = 11, legs = 3;
+  auto prob = generate_problem(rng, VectorXs(nx, 0.0), horz, nx, nu);
+  ParallelRiccatiSolver solver{prob, legs};
+  const double mu = 1e-10;
+  solver.backward(mu);
+  for (uint c = 0; c < 3; ++c) {
+    LqrKnot knot = generate_knot(rng, nx, nu);
+    for (uint t = 0; t + 1 < horz; ++t)
+      prob.stages[t] = prob.stages[t + 1];
+    prob.stages[horz - 1] = knot;
+    solver.cycleAppend(knot);
+    solver.backward(mu);
+    auto [xs, us, vs, lbdas] = lqrInitializeSolution(prob);
+    solver.forward(xs, us, vs, lbdas);
+    KktError err = lqrComputeKktError(prob, xs, us, vs, lbdas, mu);
+    REQUIRE(err.max <= 1e-9);
+    ProximalRiccatiSolver serial{prob};
+    serial.backward(mu);
+    auto [xs2, us2, vs2, lbdas2] = lqrInitializeSolution(prob);
+    serial.forward(xs2, us2, vs2, lbdas2);
+    REQUIRE(maxdiff(xs, xs2) <= 1e-9);
+    REQUIRE(maxdiff(us, us2) <= 1e-9);
+  }
+  std::printf("  kernel %s, 3 cycles\n", solver.kernelName());
+}
+
 static void error_behaviour() {
   std::printf("error_behaviour\n");
   std::mt19937 rng(3);
@@ -389,6 +420,7 @@ int main() {
       parallel_solver_class(th);
   dense_solver();
   mpc_cycle();
+  mpc_cycle_parallel();
   padded_shape(12, 6, "12,8");
   padded_shape(10, 3, "12,4");
   raw_c_abi_wide_shape();
