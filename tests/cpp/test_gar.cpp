@@ -352,6 +352,7 @@ static void mpc_cycle_parallel() {
   auto prob = generate_problem(rng, VectorXs(nx, 0.0), horz, nx, nu);
   ParallelRiccatiSolver solver{prob, legs};
   const double mu = 1e-10;
+  double worst = 0.0;
   solver.backward(mu);
   for (uint c = 0; c < 3; ++c) {
     LqrKnot knot = generate_knot(rng, nx, nu);
@@ -370,8 +371,9 @@ static void mpc_cycle_parallel() {
     serial.forward(xs2, us2, vs2, lbdas2);
     REQUIRE(maxdiff(xs, xs2) <= 1e-9);
     REQUIRE(maxdiff(us, us2) <= 1e-9);
+    worst = std::max({worst, err.max, maxdiff(xs, xs2), maxdiff(us, us2)});
   }
-  std::printf("  kernel %s, 3 cycles\n", solver.kernelName());
+  std::printf("  kernel %s, 3 cycles, kkt / |x_par - x_serial| <= %.2e\n", solver.kernelName(), worst);
 }
 
 static void error_behaviour() {
