@@ -91,6 +91,11 @@ SIGNATURES = {
     "gar_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "gar_hip_last_kernel_ms": (C.c_int, [C.c_void_p, _PD]),
     "gar_hip_cycle_append": (C.c_int, [C.c_void_p, _PI32]),
+    "gar_hip_multi_create": (C.c_void_p, [C.c_int, C.POINTER(C.c_int), C.c_int, _PI32, C.c_int, C.c_int, C.c_int]),
+    "gar_hip_num_devices": (C.c_int, [C.c_void_p]),
+    "gar_hip_stage_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "gar_hip_multi_exchange_name": (C.c_char_p, [C.c_void_p]),
+    "gar_hip_debug_alloc_count": (C.c_longlong, []),
 }
 
 

@@ -562,10 +562,11 @@ __global__ void __launch_bounds__(256) gar_rotate_records(double *base, long lon
 __global__ void __launch_bounds__(256) gar_gather_gains(const gar_stage_meta *meta, const double *fac,
                                                         double *ff_all, double *fb_all,
                                                         const long long *goff, int horizon, int t2, int dense,
-                                                        int unx, int unu) {
+                                                        int unx, int unu, int t0) {
   // unx > 0: the solver is padded (gar_hip.cpp, gar_hip_solver::padded) -- the caller's arrays hold the rows of the
   // real controls [0, unu) and states [nu, nu + unx) and the first unx columns only; goff are the caller's offsets
-  const int t = (int)blockIdx.x;
+  // t0: first stage of the range gathered (one process, several devices: each device gathers its own stages)
+  const int t = t0 + (int)blockIdx.x;
   const gar_stage_meta m = meta[t];
   const int nx2r = dense ? 2 * m.nx2 : m.nx2;
   const gar_factor_offsets o = gar_factor_layout(m.nx, m.nu, m.nc, nx2r, m.nth);

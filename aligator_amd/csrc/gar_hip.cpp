@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,20 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 inline int align2(int x) { return (x + 1) & ~1; }
+
+// Every device / pinned-host allocation of the library goes through these two and is counted
+// (gar_hip_debug_alloc_count): the reference runs backward / forward under ALIGATOR_NOMALLOC_SCOPED
+// (gar/proximal-riccati.hxx:35, tests/nomalloc.cpp); tests/test_nomalloc.py asserts the same here -- the count
+// does not move across repeated backward + forward calls.
+std::atomic<long long> g_alloc_count{0};
+inline hipError_t gar_dev_malloc(void **p, size_t bytes) {
+  g_alloc_count.fetch_add(1, std::memory_order_relaxed);
+  return hipMalloc(p, bytes);
+}
+inline hipError_t gar_host_malloc(void **p, size_t bytes, unsigned flags) {
+  g_alloc_count.fetch_add(1, std::memory_order_relaxed);
+  return hipHostMalloc(p, bytes, flags);
+}
 
 // Tracing hooks (the reference brackets the same places with Tracy zones: backwardImpl
 // riccati-kernel.hxx:108, "factor_initial" proximal-riccati.hxx:43, forwardImpl riccati-kernel.hxx:320,
@@ -101,10 +116,21 @@ struct DeviceGuard {
   DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 #define GAR_GUARD(s) DeviceGuard guard_((s) ? (s)->device : -1)
+// one process, several devices (gar_multi.hpp): the handle owns one ranked solver per device and serves every
+// entry point by routing to them
+#define GAR_MULTI(s, expr)                                                                                             \
+  do {                                                                                                                 \
+    if ((s) && (s)->multi)                                                                                             \
+      return (expr);                                                                                                   \
+  } while (0)
 
 } // namespace
 
+struct gar_multi;
+
 struct gar_hip_solver {
+  // gar_hip_multi_create: this object holds the layout only (no device memory); `multi` owns the per-device solvers
+  gar_multi *multi = nullptr;
   int device = 0, horizon = 0, nc0 = 0, batch = 0;
   int num_legs = 1, leg_begin = 0, leg_end = 1;
   int world = 1, rank = 0; // horizon sharding: this solver owns legs [rank J / W, (rank + 1) J / W)
@@ -1442,38 +1468,38 @@ void free_device(gar_hip_solver *s) {
 
 int allocate(gar_hip_solver *s) {
   const size_t B = (size_t)s->batch;
-  HIP_TRY(hipMalloc((void **)&s->d_meta, sizeof(gar_stage_meta) * s->meta.size()));
+  HIP_TRY(gar_dev_malloc((void **)&s->d_meta, sizeof(gar_stage_meta) * s->meta.size()));
   HIP_TRY(hipMemcpy(s->d_meta, s->meta.data(), sizeof(gar_stage_meta) * s->meta.size(),
                     hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void **)&s->d_prob, sizeof(double) * (size_t)s->prob_doubles * B));
+  HIP_TRY(gar_dev_malloc((void **)&s->d_prob, sizeof(double) * (size_t)s->prob_doubles * B));
   HIP_TRY(hipMemset(s->d_prob, 0, sizeof(double) * (size_t)s->prob_doubles * B));
-  HIP_TRY(hipMalloc((void **)&s->d_fac, sizeof(double) * (size_t)s->fac_doubles * B));
+  HIP_TRY(gar_dev_malloc((void **)&s->d_fac, sizeof(double) * (size_t)s->fac_doubles * B));
   HIP_TRY(hipMemset(s->d_fac, 0, sizeof(double) * (size_t)s->fac_doubles * B));
-  HIP_TRY(hipMalloc((void **)&s->d_sol, sizeof(double) * (size_t)s->sol_doubles * B));
+  HIP_TRY(gar_dev_malloc((void **)&s->d_sol, sizeof(double) * (size_t)s->sol_doubles * B));
   HIP_TRY(hipMemset(s->d_sol, 0, sizeof(double) * (size_t)s->sol_doubles * B));
-  HIP_TRY(hipMalloc((void **)&s->d_init, sizeof(double) * (size_t)s->init_doubles * B));
+  HIP_TRY(gar_dev_malloc((void **)&s->d_init, sizeof(double) * (size_t)s->init_doubles * B));
   HIP_TRY(hipMemset(s->d_init, 0, sizeof(double) * (size_t)s->init_doubles * B));
-  HIP_TRY(hipMalloc((void **)&s->d_theta, sizeof(double) * (size_t)std::max(s->nth0, 1) * B));
+  HIP_TRY(gar_dev_malloc((void **)&s->d_theta, sizeof(double) * (size_t)std::max(s->nth0, 1) * B));
   // per-problem failure flags, then the four slow-path counters (MfmaParams::slow), then MfmaParams::resume
-  HIP_TRY(hipMalloc((void **)&s->d_status, sizeof(int) * (2 * B + 4)));
+  HIP_TRY(gar_dev_malloc((void **)&s->d_status, sizeof(int) * (2 * B + 4)));
   HIP_TRY(hipMemset(s->d_status, 0, sizeof(int) * (2 * B + 4)));
   if (s->num_legs > 1) {
     const int chunk = s->legs_per_rank; // >= this rank's own leg count; equal-sized chunks for the all-gather
     const int nblk = 2 * s->num_legs;
     const size_t bs = (size_t)s->nxb * s->nxb;
-    HIP_TRY(hipMalloc((void **)&s->d_bound_local, sizeof(double) * s->tuple_doubles * chunk * B));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_bound_local, sizeof(double) * s->tuple_doubles * chunk * B));
     HIP_TRY(hipMemset(s->d_bound_local, 0, sizeof(double) * s->tuple_doubles * chunk * B));
     if (s->world == 1) {
       s->d_bound_all = s->d_bound_local;
       s->bound_all_owned = false;
     } else {
-      HIP_TRY(hipMalloc((void **)&s->d_bound_all,
+      HIP_TRY(gar_dev_malloc((void **)&s->d_bound_all,
                         sizeof(double) * s->tuple_doubles * chunk * s->world * B));
       s->bound_all_owned = true;
     }
-    HIP_TRY(hipMalloc((void **)&s->d_csol, sizeof(double) * (size_t)nblk * s->nxb * B));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_csol, sizeof(double) * (size_t)nblk * s->nxb * B));
     s->cscratch_doubles = (int64_t)(4 * nblk * bs + 4 * (size_t)nblk * s->nxb + 4);
-    HIP_TRY(hipMalloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
     s->cond_lds_doubles = (int)(3 * bs + 4 * s->nxb + 2 + (s->nxb + 16) / 2 + 2 + (s->nxb < 9 ? 9 * s->nxb : 0));
     {
       const char *cr = std::getenv("GAR_HIP_CONDENSED_REDUCED");
@@ -1488,32 +1514,32 @@ int allocate(gar_hip_solver *s) {
   }
   if (s->seg_bwd_kernel) {
     const gar_hip_solver *f = s->flay;
-    HIP_TRY(hipMalloc((void **)&s->d_fac2, sizeof(double) * (size_t)f->fac_doubles * B));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_fac2, sizeof(double) * (size_t)f->fac_doubles * B));
     HIP_TRY(hipMemset(s->d_fac2, 0, sizeof(double) * (size_t)f->fac_doubles * B));
-    HIP_TRY(hipMalloc((void **)&s->d_meta2, sizeof(gar_stage_meta) * f->meta.size()));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_meta2, sizeof(gar_stage_meta) * f->meta.size()));
     HIP_TRY(hipMemcpy(s->d_meta2, f->meta.data(), sizeof(gar_stage_meta) * f->meta.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute((const void *)s->seg_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->seg_lds_doubles * sizeof(double))));
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_leg_param_generic, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->seg_param_lds_doubles * sizeof(double))));
     s->tgain_doubles = (int64_t)(s->horizon + 1) * s->dims5[0] * s->dims5[1];
-    HIP_TRY(hipMalloc((void **)&s->d_tgain, sizeof(double) * (size_t)s->tgain_doubles * B));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_tgain, sizeof(double) * (size_t)s->tgain_doubles * B));
     HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_leg_param_prepare, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(gar::leg_prepare_lds_doubles(s->dims5[0], s->dims5[1]) * sizeof(double))));
   }
   if (s->fold) {
     const gar_hip_solver *f = s->flay;
-    HIP_TRY(hipMalloc((void **)&s->d_prob2, sizeof(double) * (size_t)f->prob_doubles * B));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_prob2, sizeof(double) * (size_t)f->prob_doubles * B));
     HIP_TRY(hipMemset(s->d_prob2, 0, sizeof(double) * (size_t)f->prob_doubles * B));
-    HIP_TRY(hipMalloc((void **)&s->d_fac2, sizeof(double) * (size_t)f->fac_doubles * B));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_fac2, sizeof(double) * (size_t)f->fac_doubles * B));
     HIP_TRY(hipMemset(s->d_fac2, 0, sizeof(double) * (size_t)f->fac_doubles * B));
-    HIP_TRY(hipMalloc((void **)&s->d_meta2, sizeof(gar_stage_meta) * f->meta.size()));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_meta2, sizeof(gar_stage_meta) * f->meta.size()));
     HIP_TRY(hipMemcpy(s->d_meta2, f->meta.data(), sizeof(gar_stage_meta) * f->meta.size(), hipMemcpyHostToDevice));
   }
   s->fold_expanded = s->coupled_known = false;
   const size_t staging = sizeof(double) * (size_t)s->prob_doubles * B;
   if (staging <= ((size_t)1 << 30)) {
-    HIP_TRY(hipHostMalloc((void **)&s->h_prob, staging, hipHostMallocDefault));
+    HIP_TRY(gar_host_malloc((void **)&s->h_prob, staging, hipHostMallocDefault));
     std::memset(s->h_prob, 0, staging);
     s->staged = true;
   }
@@ -1636,6 +1662,9 @@ void strip_solution_rec(const gar_hip_solver *s, const double *dev, double *rec)
 }
 } // namespace
 
+static int fetch_results_impl(gar_hip_solver *s, int b, int what, int t_lo, int t_hi, double *gains_base, bool sync);
+#include "gar_multi.hpp"
+
 extern "C" {
 
 const char *gar_hip_version(void) { return "gar-hip 0.1 (gfx950)"; }
@@ -1660,8 +1689,8 @@ double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_
   hipEvent_t e0 = nullptr, e1 = nullptr;
   double best = -1.0;
   const size_t nin = (size_t)batch * horizon * in_pieces * 16, nout = (size_t)batch * horizon * out_pieces * 16;
-  if (hipMalloc((void **)&in, nin) == hipSuccess && hipMalloc((void **)&out, nout) == hipSuccess &&
-      hipMalloc((void **)&sink, (size_t)batch * 64 * 8) == hipSuccess && hipMemset(in, 0, nin) == hipSuccess &&
+  if (gar_dev_malloc((void **)&in, nin) == hipSuccess && gar_dev_malloc((void **)&out, nout) == hipSuccess &&
+      gar_dev_malloc((void **)&sink, (size_t)batch * 64 * 8) == hipSuccess && hipMemset(in, 0, nin) == hipSuccess &&
       hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
     for (int r = 0; r < reps + 1; ++r) { // first launch: warm-up
       (void)hipEventRecord(e0, nullptr);
@@ -1703,7 +1732,7 @@ double gar_hip_copy_ceiling_ms(int device, int64_t bytes_moved, int reps) {
   double best = -1.0;
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-  if (hipMalloc((void **)&src, (size_t)n * 16) == hipSuccess && hipMalloc((void **)&dst, (size_t)n * 16) == hipSuccess &&
+  if (gar_dev_malloc((void **)&src, (size_t)n * 16) == hipSuccess && gar_dev_malloc((void **)&dst, (size_t)n * 16) == hipSuccess &&
       hipMemset(src, 0, (size_t)n * 16) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
       hipEventCreate(&e1) == hipSuccess) {
     for (int r = 0; r < reps + 1; ++r) { // first launch: warm-up
@@ -1831,6 +1860,10 @@ gar_hip_solver *gar_hip_solver_create(int device, int horizon, const int32_t *di
 void gar_hip_solver_destroy(gar_hip_solver *s) {
   if (!s)
     return;
+  if (s->multi) {
+    multi_destroy(s);
+    return;
+  }
   GAR_GUARD(s);
   (void)hipStreamSynchronize(s->stream);
   free_device(s);
@@ -1848,6 +1881,7 @@ int gar_hip_set_stream(gar_hip_solver *s, void *hip_stream) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  GAR_MULTI(s, fail(GAR_HIP_ERR_UNSUPPORTED, "a multi-device solver runs on one stream per device, its own"));
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
   return GAR_HIP_OK;
@@ -1857,6 +1891,7 @@ int gar_hip_sync(gar_hip_solver *s) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  GAR_MULTI(s, multi_sync(s));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return GAR_HIP_OK;
 }
@@ -1874,6 +1909,7 @@ const char *gar_hip_kernel_name(const gar_hip_solver *s) {
 const char *gar_hip_condensed_solver_name(const gar_hip_solver *s) {
   if (!s || s->num_legs < 2)
     return "";
+  GAR_MULTI(s, gar_hip_condensed_solver_name(s->multi->subs[0]));
   if (s->cyc_setup_kernel)
     return "cyclic"; // gar_cyclic.hpp (specialised leg families), the wave-scope chain gated behind it
   if (s->cond_wave_kernel)
@@ -1948,6 +1984,7 @@ static int set_init_dev(gar_hip_solver *s, int b, const double *G0, const double
 
 int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packed) {
   GAR_GUARD(s);
+  GAR_MULTI(s, multi_upload_packed(s, b0, nb, packed));
   if (!s || !packed || b0 < 0 || nb < 0 || b0 + nb > s->batch)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_packed: bad argument");
   if (s->padded) { // the caller's records: knot by knot through the padding path
@@ -1984,6 +2021,7 @@ int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packe
 
 int gar_hip_upload_packed_device(gar_hip_solver *s, int b0, int nb, const double *packed_dev) {
   GAR_GUARD(s);
+  GAR_MULTI(s, fail(GAR_HIP_ERR_UNSUPPORTED, "device-resident upload into a multi-device solver: the records live on several devices"));
   if (!s || !packed_dev || b0 < 0 || nb < 0 || b0 + nb > s->batch)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_packed_device: bad argument");
   if (int rc = commit(s)) // staged host data first, then the device copy wins
@@ -1999,11 +2037,14 @@ int gar_hip_commit(gar_hip_solver *s) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  GAR_MULTI(s, multi_all(s, [](gar_hip_solver *q) { return gar_hip_commit(q); }));
   return commit(s);
 }
 
 double *gar_hip_device_problems(gar_hip_solver *s) { return s ? s->d_prob : nullptr; }
 double *gar_hip_device_factors(gar_hip_solver *s) {
+  if (s && s->multi) // (the records live on several devices)
+    return nullptr;
   if (s && s->fold) { // the caller-visible records of a folded solver are formed on request
     GAR_GUARD(s);
     (void)ensure_expanded(s);
@@ -2016,6 +2057,7 @@ int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  GAR_MULTI(s, multi_backward_legs(s, mueq));
   if (int rc = commit(s))
     return rc;
   HIP_TRY(hipMemsetAsync(s->d_status, 0, sizeof(int) * ((size_t)s->batch + 4 + (s->fold ? (size_t)s->batch : 0)), s->stream));
@@ -2026,6 +2068,7 @@ int gar_hip_condensed_solve_async(gar_hip_solver *s) {
   GAR_GUARD(s);
   if (!s || s->num_legs < 2)
     return fail(GAR_HIP_ERR_ARG, "condensed solve needs leg mode");
+  GAR_MULTI(s, multi_exchange_and_condensed(s)); // the boundary exchange happens HERE, inside the library
   return launch_condensed(s);
 }
 
@@ -2033,6 +2076,7 @@ int gar_hip_forward_legs_async(gar_hip_solver *s) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  GAR_MULTI(s, multi_forward(s));
   return launch_forward(s, nullptr);
 }
 
@@ -2040,6 +2084,7 @@ int gar_hip_backward_async(gar_hip_solver *s, double mueq) {
   GAR_GUARD(s);
   if (int rc = gar_hip_backward_legs_async(s, mueq))
     return rc;
+  GAR_MULTI(s, multi_exchange_and_condensed(s));
   if (s->num_legs > 1) {
     if (s->world > 1)
       return fail(GAR_HIP_ERR_ARG, "sharded solver: exchange boundaries, then call "
@@ -2053,6 +2098,7 @@ int gar_hip_num_failed(gar_hip_solver *s) {
   GAR_GUARD(s);
   if (!s)
     return 0;
+  GAR_MULTI(s, multi_num_failed(s));
   std::vector<int> st((size_t)s->batch);
   if (hipMemcpyAsync(st.data(), s->d_status, sizeof(int) * st.size(), hipMemcpyDeviceToHost,
                      s->stream) != hipSuccess ||
@@ -2067,6 +2113,7 @@ int gar_hip_num_failed(gar_hip_solver *s) {
 
 int gar_hip_slow_path_stages(gar_hip_solver *s, int64_t out[2]) {
   GAR_GUARD(s);
+  GAR_MULTI(s, multi_counters(s, out, gar_hip_slow_path_stages));
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
   int c[2] = {0, 0};
@@ -2079,6 +2126,7 @@ int gar_hip_slow_path_stages(gar_hip_solver *s, int64_t out[2]) {
 
 int gar_hip_constrained_bk_stages(gar_hip_solver *s, int64_t out[2]) {
   GAR_GUARD(s);
+  GAR_MULTI(s, multi_counters(s, out, gar_hip_constrained_bk_stages));
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
   int c[2] = {0, 0};
@@ -2107,6 +2155,7 @@ int gar_hip_forward_async(gar_hip_solver *s, const double *theta_device) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  GAR_MULTI(s, multi_forward(s));
   return launch_forward(s, theta_device);
 }
 
@@ -2114,6 +2163,11 @@ int gar_hip_forward(gar_hip_solver *s, const double *theta) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  if (s->multi) {
+    if (int rc = multi_forward(s))
+      return rc;
+    return multi_sync(s);
+  }
   const double *th = nullptr;
   if (theta && s->nth0 > 0 && s->num_legs == 1) {
     HIP_TRY(hipMemcpyAsync(s->d_theta, theta, sizeof(double) * (size_t)s->nth0 * s->batch,
@@ -2135,6 +2189,7 @@ int gar_hip_set_refinement(gar_hip_solver *s, double thr, int max_steps) {
     return fail(GAR_HIP_ERR_ARG, "bad refinement settings");
   s->cond_threshold = thr;
   s->max_refinement = max_steps;
+  GAR_MULTI(s, multi_all(s, [&](gar_hip_solver *q) { return gar_hip_set_refinement(q, thr, max_steps); }));
   return GAR_HIP_OK;
 }
 
@@ -2142,6 +2197,7 @@ int gar_hip_condensed_info(gar_hip_solver *s, int b, double out[2]) {
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
+  GAR_MULTI(s, gar_hip_condensed_info(s->multi->subs[0], b, out)); // (solved redundantly on every device)
   if (s->num_legs < 2 || !out)
     return fail(GAR_HIP_ERR_ARG, "condensed info needs leg mode");
   const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
@@ -2231,8 +2287,10 @@ int gar_hip_gains_offsets(const gar_hip_solver *s, int t, int64_t out[2]) {
   return GAR_HIP_OK;
 }
 
-int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
-  GAR_GUARD(s);
+// [t_lo, t_hi): the stages whose gains are gathered and copied (the whole horizon for a one-device solver; its own
+// stages for each device of a multi-device solver, gar_multi.hpp); gains_base: the host buffer [.. | ff_all | fb_all]
+// the gains land in (null: the solver's own); sync = false leaves the copies in flight on the solver's stream
+static int fetch_results_impl(gar_hip_solver *s, int b, int what, int t_lo, int t_hi, double *gains_base, bool sync) {
   if (int rc = check_bt(s, b, 0))
     return rc;
   // the caller's records (under padding: the real rows / columns only); the device solution record is staged
@@ -2244,11 +2302,11 @@ int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
     // all three or none: a partial failure must not leave h_results set with the device buffers missing
     double *h = nullptr, *dg = nullptr;
     long long *dgo = nullptr;
-    hipError_t e = hipHostMalloc((void **)&h, sizeof(double) * (nsol + ngain + nscratch), hipHostMallocDefault);
+    hipError_t e = gar_host_malloc((void **)&h, sizeof(double) * (nsol + ngain + nscratch), hipHostMallocDefault);
     if (e == hipSuccess)
-      e = hipMalloc((void **)&dg, sizeof(double) * std::max<size_t>(ngain, 1));
+      e = gar_dev_malloc((void **)&dg, sizeof(double) * std::max<size_t>(ngain, 1));
     if (e == hipSuccess)
-      e = hipMalloc((void **)&dgo, sizeof(long long) * u->gain_off.size());
+      e = gar_dev_malloc((void **)&dgo, sizeof(long long) * u->gain_off.size());
     if (e == hipSuccess)
       e = hipMemcpyAsync(dgo, u->gain_off.data(), sizeof(long long) * u->gain_off.size(), hipMemcpyHostToDevice,
                          s->stream);
@@ -2263,25 +2321,46 @@ int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
     s->d_gains = dg;
     s->d_gain_off = dgo;
   }
-  if (what & 2) { // device-side gather (fbT2 -> row-major, dummy rows / columns dropped), then ONE device-to-host copy
+  if ((what & 2) && t_hi > t_lo) { // device-side gather (fbT2 -> row-major, dummy rows / columns dropped), then ONE device-to-host copy
     if (int rc = ensure_expanded(s))
       return rc;
     const bool t2 = records_t2(s, b);
-    hipLaunchKernelGGL(gar::gar_gather_gains, dim3((unsigned)(s->horizon + 1)), dim3(256), 0, s->stream,
+    hipLaunchKernelGGL(gar::gar_gather_gains, dim3((unsigned)(t_hi - t_lo)), dim3(256), 0, s->stream,
                        s->d_meta, s->d_fac + (int64_t)b * s->fac_doubles, s->d_gains,
                        s->d_gains + u->ff_all_doubles, s->d_gain_off, s->horizon, t2 ? 1 : 0,
-                       s->dense ? 1 : 0, s->padded ? s->unx : 0, s->padded ? s->unu : 0);
+                       s->dense ? 1 : 0, s->padded ? s->unx : 0, s->padded ? s->unu : 0, t_lo);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(s->h_results + nsol, s->d_gains, sizeof(double) * ngain, hipMemcpyDeviceToHost,
-                           s->stream));
+    double *hg = (gains_base ? gains_base : s->h_results) + nsol;
+    if (t_lo == 0 && t_hi == s->horizon + 1) {
+      HIP_TRY(hipMemcpyAsync(hg, s->d_gains, sizeof(double) * ngain, hipMemcpyDeviceToHost, s->stream));
+    } else { // the two slices of this stage range
+      const std::vector<long long> &go = u->gain_off;
+      const long long f0 = go[2 * (size_t)t_lo], f1 = t_hi <= s->horizon ? go[2 * (size_t)t_hi] : u->ff_all_doubles;
+      const long long b0 = go[2 * (size_t)t_lo + 1], b1 = t_hi <= s->horizon ? go[2 * (size_t)t_hi + 1] : u->fb_all_doubles;
+      if (f1 > f0)
+        HIP_TRY(hipMemcpyAsync(hg + f0, s->d_gains + f0, sizeof(double) * (size_t)(f1 - f0), hipMemcpyDeviceToHost, s->stream));
+      if (b1 > b0)
+        HIP_TRY(hipMemcpyAsync(hg + u->ff_all_doubles + b0, s->d_gains + u->ff_all_doubles + b0,
+                               sizeof(double) * (size_t)(b1 - b0), hipMemcpyDeviceToHost, s->stream));
+    }
   }
   if (what & 1)
     HIP_TRY(hipMemcpyAsync(s->h_results + (s->padded ? nsol + ngain : 0), s->d_sol + (int64_t)b * s->sol_doubles,
                            sizeof(double) * (size_t)s->sol_doubles, hipMemcpyDeviceToHost, s->stream));
+  if (!sync)
+    return GAR_HIP_OK;
   HIP_TRY(hipStreamSynchronize(s->stream));
   if ((what & 1) && s->padded)
     strip_solution_rec(s, s->h_results + nsol + ngain, s->h_results);
   return GAR_HIP_OK;
+}
+
+int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  GAR_MULTI(s, multi_fetch_results(s, b, what));
+  return fetch_results_impl(s, b, what, 0, s->horizon + 1, nullptr, true);
 }
 
 const double *gar_hip_host_results(gar_hip_solver *s, int64_t offs[3]) {
@@ -2293,6 +2372,8 @@ const double *gar_hip_host_results(gar_hip_solver *s, int64_t offs[3]) {
     offs[1] = u->sol_doubles;
     offs[2] = u->sol_doubles + u->ff_all_doubles;
   }
+  if (s->multi)
+    return s->multi->h_results;
   return s->h_results;
 }
 
@@ -2300,10 +2381,11 @@ int gar_hip_get_gains_all(gar_hip_solver *s, int b, double *ff_all, double *fb_a
   if (int rc = gar_hip_fetch_results(s, b, 2))
     return rc;
   const gar_hip_solver *u = s->ulay ? s->ulay : s;
+  const double *h = gar_hip_host_results(s, nullptr);
   if (ff_all)
-    std::memcpy(ff_all, s->h_results + u->sol_doubles, sizeof(double) * (size_t)u->ff_all_doubles);
+    std::memcpy(ff_all, h + u->sol_doubles, sizeof(double) * (size_t)u->ff_all_doubles);
   if (fb_all)
-    std::memcpy(fb_all, s->h_results + u->sol_doubles + u->ff_all_doubles,
+    std::memcpy(fb_all, h + u->sol_doubles + u->ff_all_doubles,
                 sizeof(double) * (size_t)u->fb_all_doubles);
   return GAR_HIP_OK;
 }
@@ -2352,7 +2434,7 @@ static int get_kkt_dev(gar_hip_solver *s, int b, int t, double mueq, double *out
     if (s->d_kkt)
       (void)hipFree(s->d_kkt);
     s->d_kkt = nullptr;
-    HIP_TRY(hipMalloc((void **)&s->d_kkt, sizeof(double) * (size_t)nk * nk));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_kkt, sizeof(double) * (size_t)nk * nk));
     s->kkt_doubles = (int64_t)nk * nk;
   }
   if (commit(s) != GAR_HIP_OK)
@@ -2395,9 +2477,10 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  GAR_MULTI(s, gar_hip_debug_trace(s->multi->subs[0], enable, out));
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (enable && !s->d_trace) {
-    HIP_TRY(hipMalloc((void **)&s->d_trace, sizeof(long long) * 64));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_trace, sizeof(long long) * 64));
     HIP_TRY(hipMemset(s->d_trace, 0, sizeof(long long) * 64));
   }
   if (out && s->d_trace)
@@ -2426,13 +2509,14 @@ int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_d
   GAR_GUARD(s);
   if (!s || !deriv_dev)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_update_lq_subproblem_device: bad argument");
+  GAR_MULTI(s, fail(GAR_HIP_ERR_UNSUPPORTED, "device-resident LQ assembly on a multi-device solver: one derivative buffer per device would be needed"));
   if (s->padded)
     return fail(GAR_HIP_ERR_UNSUPPORTED, "device-resident LQ assembly on a padded solver: the derivative records would "
                                          "have to carry the dummy states / controls (GAR_HIP_PAD=0 keeps the caller's shape)");
   if (int rc = commit(s)) // pending host staging first; later host writes flush only their own ranges
     return rc;
   if (!s->d_deriv_off) {
-    HIP_TRY(hipMalloc((void **)&s->d_deriv_off, sizeof(long long) * s->deriv_off.size()));
+    HIP_TRY(gar_dev_malloc((void **)&s->d_deriv_off, sizeof(long long) * s->deriv_off.size()));
     HIP_TRY(hipMemcpy(s->d_deriv_off, s->deriv_off.data(), sizeof(long long) * s->deriv_off.size(),
                       hipMemcpyHostToDevice));
   }
@@ -2461,6 +2545,7 @@ int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_d
 
 int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed) {
   GAR_GUARD(s);
+  GAR_MULTI(s, multi_download_packed(s, b0, nb, packed));
   if (!s || !packed || b0 < 0 || nb < 0 || b0 + nb > s->batch)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_download_packed: bad argument");
   if (int rc = commit(s))
@@ -2508,6 +2593,7 @@ int gar_hip_set_timing(gar_hip_solver *s, int enable) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  GAR_MULTI(s, multi_all(s, [&](gar_hip_solver *q) { return gar_hip_set_timing(q, enable); }));
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (enable && !s->ev[0])
     for (auto &e : s->ev)
@@ -2518,6 +2604,7 @@ int gar_hip_set_timing(gar_hip_solver *s, int enable) {
 
 int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]) {
   GAR_GUARD(s);
+  GAR_MULTI(s, multi_last_kernel_ms(s, out));
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
   if (!s->timing || !(s->mfma_kernel || s->wave_kernel || s->leg_bwd_kernel || s->seg_bwd_kernel))
@@ -2538,6 +2625,7 @@ int gar_hip_collapse_feedback(gar_hip_solver *s) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  GAR_MULTI(s, gar_hip_collapse_feedback(s->multi->subs[0])); // stage 0 lives on the first device
   if (s->num_legs < 2 || s->leg_begin != 0)
     return GAR_HIP_OK; // no-op except Parallel (riccati-base.hpp:33)
   if (s->fold) { // the wave-leg family's own records (then re-expanded on request); flagged problems: generic records
@@ -2561,6 +2649,7 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
   GAR_GUARD(s);
   if (!s || !d)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
+  GAR_MULTI(s, multi_cycle_append(s, d));
   const int N = s->horizon;
   if (N < 1)
     return GAR_HIP_OK;
@@ -2645,6 +2734,7 @@ int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, t))
     return rc;
+  GAR_MULTI(s, gar_hip_upload_stage(multi_owner(s, t), b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma));
   if (!s->padded)
     return upload_stage_dev(s, b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma);
   const gar_stage_meta &m = s->meta[t];
@@ -2663,6 +2753,7 @@ int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
+  GAR_MULTI(s, multi_set_init(s, b, G0, g0));
   if (!s->padded)
     return set_init_dev(s, b, G0, g0);
   if (s->user_nc0 > 0 && (!G0 || !g0))
@@ -2686,6 +2777,7 @@ int gar_hip_set_condensed_backward_ok(gar_hip_solver *s, double omega) {
   if (!s || !(omega >= 0.0))
     return fail(GAR_HIP_ERR_ARG, "bad backward-error bound");
   s->cond_backward_ok = omega;
+  GAR_MULTI(s, multi_all(s, [&](gar_hip_solver *q) { return gar_hip_set_condensed_backward_ok(q, omega); }));
   return GAR_HIP_OK;
 }
 
@@ -2713,6 +2805,7 @@ int gar_hip_condensed_resolved(gar_hip_solver *s, int b, int *out) {
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
+  GAR_MULTI(s, gar_hip_condensed_resolved(s->multi->subs[0], b, out));
   if (s->num_legs < 2 || !out)
     return fail(GAR_HIP_ERR_ARG, "condensed info needs leg mode");
   const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
@@ -2729,6 +2822,7 @@ int gar_hip_condensed_backward_error(gar_hip_solver *s, int b, double *out) {
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
+  GAR_MULTI(s, gar_hip_condensed_backward_error(s->multi->subs[0], b, out));
   if (s->num_legs < 2 || !out)
     return fail(GAR_HIP_ERR_ARG, "condensed info needs leg mode");
   const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
@@ -2745,6 +2839,7 @@ int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, doubl
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
+  GAR_MULTI(s, multi_get_solution(s, b, xs, us, vs, lbdas));
   if (!s->padded)
     return get_solution_dev(s, b, xs, us, vs, lbdas);
   std::vector<double> rec((size_t)s->sol_doubles);
@@ -2759,6 +2854,7 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, t))
     return rc;
+  GAR_MULTI(s, gar_hip_get_gains(multi_owner(s, t), b, t, ff, fb, fth));
   if (!s->padded)
     return get_gains_dev(s, b, t, ff, fb, fth);
   const gar_stage_meta &m = s->meta[t];
@@ -2786,6 +2882,7 @@ int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, 
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, t))
     return rc;
+  GAR_MULTI(s, gar_hip_get_value(multi_owner(s, t), b, t, Vxx, vx, Vxt, Vtt, vt));
   if (!s->padded)
     return get_value_dev(s, b, t, Vxx, vx, Vxt, Vtt, vt);
   const gar_stage_meta &m = s->meta[t];
@@ -2815,6 +2912,7 @@ int gar_hip_get_kkt(gar_hip_solver *s, int b, int t, double mueq, double *out) {
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, t))
     return rc;
+  GAR_MULTI(s, gar_hip_get_kkt(multi_owner(s, t), b, t, mueq, out));
   if (!s->padded)
     return get_kkt_dev(s, b, t, mueq, out);
   if (!out)
@@ -2836,6 +2934,7 @@ int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff, double *kkt0_
   GAR_GUARD(s);
   if (int rc = check_bt(s, b, 0))
     return rc;
+  GAR_MULTI(s, gar_hip_get_initial(s->multi->subs[0], b, kkt0_ff, kkt0_fth, thGrad, thHess));
   if (!s->padded)
     return get_initial_dev(s, b, kkt0_ff, kkt0_fth, thGrad, thHess);
   const int n0 = s->n0, NT = s->nth0, NX = s->pnx, nx = s->unx, nt = NT > 0 ? nx : 0, n0u = nx + s->user_nc0;
@@ -2869,6 +2968,25 @@ int gar_hip_device_stage_layout(const gar_hip_solver *s, int t, int64_t out[11])
   out[5] = m.in_off; out[6] = m.fac_off; out[7] = m.x_off; out[8] = m.u_off; out[9] = m.v_off; out[10] = m.l_off;
   return GAR_HIP_OK;
 }
+
+gar_hip_solver *gar_hip_multi_create(int ndev, const int *dev_ids, int horizon, const int32_t *dims5, int nc0, int batch,
+                                     int num_legs) {
+  return multi_create(ndev, dev_ids, horizon, dims5, nc0, batch, num_legs);
+}
+
+int gar_hip_num_devices(const gar_hip_solver *s) { return !s ? 0 : (s->multi ? (int)s->multi->subs.size() : 1); }
+
+int gar_hip_stage_device(const gar_hip_solver *s, int t) {
+  if (int rc = check_bt(s, 0, t))
+    return rc;
+  return s->multi ? s->multi->subs[(size_t)s->multi->owner[(size_t)t]]->device : s->device;
+}
+
+const char *gar_hip_multi_exchange_name(const gar_hip_solver *s) {
+  return (s && s->multi) ? (s->multi->pull ? "pull" : "copy") : "";
+}
+
+long long gar_hip_debug_alloc_count(void) { return g_alloc_count.load(std::memory_order_relaxed); }
 
 int gar_hip_device_sizes(const gar_hip_solver *s, int64_t out[8]) {
   if (!s || !out)

@@ -75,11 +75,13 @@ class BatchedRiccatiSolver:
     ProximalRiccatiSolver algorithm, >= 2 the ParallelRiccatiSolver one.  Kernel selection and padding onto a
     specialised shape happen inside the C ABI (include/gar_hip.h, gar_hip_solver_create): everything here speaks
     the caller's dimensions; `device_dims` / `device_layout()` report the device records (device-resident producers).
-    rank_of: (rank, world) -- horizon sharding, this solver owns legs [rank J / W, (rank+1) J / W).
+    rank_of: (rank, world) -- horizon sharding, one process per GPU: this solver owns legs [rank J / W, (rank+1) J / W).
+    devices: a list of device ids -- horizon sharding inside THIS process (gar_hip_multi_create): device r owns legs
+    [r J / W, (r+1) J / W), the boundary exchange happens inside backward(); the same device may be named more than once.
     """
 
     def __init__(self, dims, nc0: int, batch: int = 1, num_legs: int = 1, device: int = 0,
-                 rank_of=None, lib_path: Optional[str] = None, dense: bool = False):
+                 rank_of=None, lib_path: Optional[str] = None, dense: bool = False, devices=None):
         self._L = _lib.load(lib_path)
         self.dense = bool(dense)   # RiccatiSolverDense's algorithm (csrc/gar_dense.hpp): serial in time
         if self.dense:
@@ -89,10 +91,17 @@ class BatchedRiccatiSolver:
         self.horizon = self.dims.shape[0] - 1
         self.batch, self.num_legs = int(batch), int(num_legs)
         rank, world = rank_of if rank_of is not None else (0, 1)
+        self.devices = [int(d) for d in devices] if devices is not None else None
         if self.dense:
             self._h = self._L.gar_hip_solver_create_dense(
                 int(device), self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
                 self.nc0, self.batch)
+        elif self.devices is not None:
+            assert rank_of is None, "devices= shards inside this process; rank_of= is one process per GPU"
+            ids = (C.c_int * len(self.devices))(*self.devices)
+            self._h = self._L.gar_hip_multi_create(
+                len(self.devices), ids, self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
+                self.nc0, self.batch, self.num_legs)
         else:
             self._h = self._L.gar_hip_solver_create_ranked(
                 int(device), self.horizon, self.dims.ctypes.data_as(C.POINTER(C.c_int32)),
@@ -501,11 +510,11 @@ class RiccatiSolverBase:
 
 
 class _HipSolver(RiccatiSolverBase):
-    def __init__(self, problem: LqrProblem, num_legs: int, device: int, lib_path):
+    def __init__(self, problem: LqrProblem, num_legs: int, device: int, lib_path, devices=None):
         self.problem_ = problem  # non-owning, re-read on every backward()
         dims = [k.dims for k in problem.stages]
         self._num_legs = num_legs
-        self._device, self._lib_path = device, lib_path
+        self._device, self._lib_path, self._devices = device, lib_path, devices
         self._make(dims)
 
     _dense = False
@@ -514,7 +523,8 @@ class _HipSolver(RiccatiSolverBase):
         if self._num_legs > 1:
             dims = [(nx, nu, nc, nx2, 0) for (nx, nu, nc, nx2, _) in dims]
         self._impl = BatchedRiccatiSolver(dims, self.problem_.nc0, 1, self._num_legs,
-                                          self._device, lib_path=self._lib_path, dense=self._dense)
+                                          self._device, lib_path=self._lib_path, dense=self._dense,
+                                          devices=self._devices)
 
     class _Datas:
         def __init__(self, impl):
@@ -630,7 +640,9 @@ class ParallelRiccatiSolver(_HipSolver):
     The device records keep this parameterisation implicit.
     """
 
-    def __init__(self, problem: LqrProblem, num_threads: int, device: int = 0, lib_path=None):
+    def __init__(self, problem: LqrProblem, num_threads: int, device: int = 0, lib_path=None, devices=None):
+        """devices: a list of device ids -- the legs are split over these devices inside this one object
+        (include/gar_hip.h, gar_hip_multi_create): `linear_solver_` stays ONE RiccatiSolverBase."""
         if num_threads < 2:
             raise RuntimeError(f"(ParallelRiccatiSolver) numThreads ({num_threads}) should be "
                                "greater than or equal to 2.")  # parallel-solver.hxx:42-46
@@ -638,7 +650,7 @@ class ParallelRiccatiSolver(_HipSolver):
         self.condensedThreshold = 1e-10   # parallel-solver.hpp:92
         self.maxRefinementSteps = 5       # parallel-solver.hpp:94
         self._parameterize(problem)
-        super().__init__(problem, self.numThreads_, device, lib_path)
+        super().__init__(problem, self.numThreads_, device, lib_path, devices=devices)
 
     def getNumThreads(self) -> int:
         return self.numThreads_

@@ -70,6 +70,10 @@ typedef struct gar_hip_solver gar_hip_solver;
 const char *gar_hip_version(void);
 const char *gar_hip_last_error(void);
 int gar_hip_device_count(void);
+/* Device and pinned-host allocations the library has made so far in this process.  The reference runs backward /
+ * forward under ALIGATOR_NOMALLOC_SCOPED (gar/proximal-riccati.hxx:35, tests/nomalloc.cpp); the same contract here:
+ * the count does not move across gar_hip_backward / gar_hip_forward (tests/test_nomalloc.py). */
+long long gar_hip_debug_alloc_count(void);
 /* Measurement aid, no reference counterpart (bench.py's roofline.stream_ceiling): milliseconds (best of `reps`)
  * that `batch` one-wave-per-problem streams need for the BYTES of a serial-in-time backward sweep and nothing
  * else -- per stage in_bytes read (one knot ahead in flight), out_bytes written, a 72-FMA dependent chain -- i.e.
@@ -114,6 +118,28 @@ gar_hip_solver *gar_hip_solver_create_ranked(int device, int horizon, const int3
 gar_hip_solver *gar_hip_solver_create_sharded(int device, int horizon,
                                               const int32_t *dims5, int nc0, int batch,
                                               int num_legs, int leg_begin, int leg_end);
+/* ONE process, SEVERAL devices: ParallelRiccatiSolver(problem, num_legs) semantics with the legs split over the `ndev`
+ * devices dev_ids[0..ndev) -- device r owns legs [r J / ndev, (r+1) J / ndev), get_work over devices
+ * (gar/parallel-solver.hxx:23-28) -- behind the SAME handle type, so that the one RiccatiSolverBase object
+ * SolverProxDDP holds (solvers/proxddp/solver-proxddp.hpp:56,181) shards its horizon over the GPUs of the node
+ * without a process per GPU.  The boundary exchange the reference performs as the barrier closing its OpenMP region
+ * (parallel-solver.hxx:150-169) happens INSIDE gar_hip_backward: every device sweeps its legs on its own stream,
+ * then reads the other devices' boundary tuples (3 nx^2 + 2 nx doubles per leg) -- one gather kernel over
+ * peer-mapped buffers (xGMI) when every pair of devices has peer access, hipMemcpyPeerAsync otherwise
+ * (GAR_HIP_MULTI_EXCHANGE=copy forces it; gar_hip_multi_exchange_name tells) -- ordered by HIP events, no host
+ * synchronisation, and solves the condensed system redundantly.  Every entry point of this header then serves the
+ * handle: uploads and per-stage getters go to the stage's device, G0 / g0 and settings to all, the solution and the
+ * bulk read-back are merged (each device copies only its own stages, all devices at once).  Entry points that take
+ * or return DEVICE pointers (gar_hip_device_*, gar_hip_upload_packed_device, gar_hip_update_lq_subproblem_device,
+ * gar_hip_set_stream) answer GAR_HIP_ERR_UNSUPPORTED / NULL.  dev_ids may name the same device more than once
+ * (several ranked solvers sharing one GPU: how the path is tested on a one-GPU box).  ndev == 1 returns the plain
+ * solver of gar_hip_solver_create (num_legs == 1: serial in time); ndev >= 2 needs num_legs >= ndev.  ndev <= 16. */
+gar_hip_solver *gar_hip_multi_create(int ndev, const int *dev_ids, int horizon, const int32_t *dims5, int nc0,
+                                     int batch, int num_legs);
+/* devices behind the handle (1 for every other constructor); the device that holds stage t; "pull" / "copy" / "" */
+int gar_hip_num_devices(const gar_hip_solver *s);
+int gar_hip_stage_device(const gar_hip_solver *s, int t);
+const char *gar_hip_multi_exchange_name(const gar_hip_solver *s);
 /* RiccatiSolverDense(problem): serial in time, any dimensions.  backward() factorises the whole
  * (nu+nc+2*nx2)^2 stage matrix (gar/dense-kernel.hpp:100-172); gar_hip_get_gains then returns
  * ff (nu+nc+2*nx2) and fb (nu+nc+2*nx2, nx) row-major = block rows [K; Z; L; Y] as

@@ -260,7 +260,8 @@ public:
   const char *condensedSolverName() const { return gar_hip_condensed_solver_name(h_); }
 
 protected:
-  HipSolver(LqrProblem &problem, int num_legs, int device, bool dense = false)
+  // devices: more than one id = the legs split over these devices inside this one object (gar_hip_multi_create)
+  HipSolver(LqrProblem &problem, int num_legs, int device, bool dense = false, const std::vector<int> &devices = {})
       : problem_(&problem), dense_(dense) {
     const int N = problem.horizon();
     std::vector<int32_t> dims5;
@@ -269,7 +270,8 @@ protected:
       dims5.insert(dims5.end(), d, d + 5);
     }
     h_ = dense ? gar_hip_solver_create_dense(device, N, dims5.data(), (int)problem.nc0(), 1)
-               : gar_hip_solver_create(device, N, dims5.data(), (int)problem.nc0(), 1, num_legs);
+         : devices.empty() ? gar_hip_solver_create(device, N, dims5.data(), (int)problem.nc0(), 1, num_legs)
+                           : gar_hip_multi_create((int)devices.size(), devices.data(), N, dims5.data(), (int)problem.nc0(), 1, num_legs);
     if (!h_)
       throw std::runtime_error(gar_hip_last_error());
   }
@@ -351,6 +353,12 @@ class ParallelRiccatiSolver : public detail::HipSolver {
 public:
   ParallelRiccatiSolver(LqrProblem &problem, const uint num_threads, int device = 0)
       : HipSolver(problem, check_threads(num_threads), device), numThreads_(num_threads) {}
+  /// the legs split over `devices` (device ids) inside this one object: one process, the boundary exchange inside
+  /// backward() (include/gar_hip.h, gar_hip_multi_create)
+  ParallelRiccatiSolver(LqrProblem &problem, const uint num_threads, const std::vector<int> &devices)
+      : HipSolver(problem, check_threads(num_threads), devices.empty() ? 0 : devices[0], false, devices),
+        numThreads_(num_threads) {}
+  int numDevices() const { return gar_hip_num_devices(h_); }
   bool backward(const double mueq) override {
     check(gar_hip_set_refinement(h_, condensedThreshold, (int)maxRefinementSteps));
     gains_valid_ = false;

@@ -33,7 +33,8 @@ typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 typedef struct emu_stream_t *hipStream_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
-constexpr unsigned hipStreamNonBlocking = 1, hipHostMallocDefault = 0;
+constexpr unsigned hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipEventDisableTiming = 2;
+constexpr hipError_t hipErrorPeerAccessAlreadyEnabled = 704;
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 
 namespace emu {
@@ -206,7 +207,13 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 typedef struct emu_event_t *hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)std::malloc(1); return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return 0; }
+// (launches run to completion before they return: every event is complete when it is waited for)
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { std::memmove(d, s, n); return 0; }
+inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = std::getenv("GAR_EMU_NO_PEER") ? 0 : 1; return 0; }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }

@@ -1,5 +1,5 @@
-// TEST INFRASTRUCTURE -- the drop-in seam executed with the REFERENCE's own types: the HipRiccatiSolver that
-// INTEGRATION.md prints (extracted verbatim into hip_riccati_binding.hpp by tests/test_integration_binding.py) is
+// TEST INFRASTRUCTURE -- the drop-in seam executed with the REFERENCE's own types: the HipRiccatiSolver this
+// repository ships as include/aligator/gar/hip-riccati.hpp (the file a maintainer adds to aligator) is
 // compiled against /root/reference/include (over the Eigen-API stand-in oracle/ref_shim, as oracle/_ref is) and
 // driven through gar::RiccatiSolverBase<double>* exactly as SolverProxDDP drives linear_solver_
 // (solver-proxddp.hxx:208, 608-611, 619, 624-625, 631-632), next to the reference's own ProximalRiccatiSolver /
@@ -11,7 +11,7 @@
 #include "aligator/gar/riccati-kernel.hxx"
 #include "aligator/gar/proximal-riccati.hxx"
 #include "aligator/gar/parallel-solver.hxx"
-#include "hip_riccati_binding.hpp"
+#include "aligator/gar/hip-riccati.hpp" // this repository's include/, next to the reference's include/aligator/gar
 
 #include <cstdio>
 #include <memory>
@@ -114,12 +114,18 @@ static double run(Base &solver, Problem &p, Sol &s, double mu, std::vector<doubl
   return scale;
 }
 
+extern "C" void emu_set_device_count(int n); // the emulator build's virtual devices (tests/emu/emu_runtime.cpp)
+
 int main() {
   int bad = 0;
-  struct Case { uint nx, nu, nc, N; int legs; double mu; const char *want; };
-  const Case cases[] = {{8, 4, 0, 12, 1, 1e-10, "<8,4>"},        {7, 3, 0, 9, 1, 1e-10, "<8,4>"}, // padded inside the C ABI
-                        {8, 4, 3, 10, 1, 1e-6, "generic"},       {12, 6, 0, 14, 3, 1e-10, "wave_leg<12,8>"},
-                        {8, 4, 2, 11, 2, 1e-6, "wave_leg<8,4>+fold"}};
+  emu_set_device_count(3);
+  // ndev > 1: the legs split over that many devices behind the ONE RiccatiSolverBase object (gar_hip_multi_create)
+  struct Case { uint nx, nu, nc, N; int legs; double mu; const char *want; int ndev; };
+  const Case cases[] = {{8, 4, 0, 12, 1, 1e-10, "<8,4>", 1},        {7, 3, 0, 9, 1, 1e-10, "<8,4>", 1}, // padded inside the C ABI
+                        {8, 4, 3, 10, 1, 1e-6, "generic", 1},       {12, 6, 0, 14, 3, 1e-10, "wave_leg<12,8>", 1},
+                        {8, 4, 2, 11, 2, 1e-6, "wave_leg<8,4>+fold", 1},
+                        {12, 6, 0, 14, 3, 1e-10, "wave_leg<12,8>", 3}, {8, 4, 0, 17, 5, 1e-10, "wave_leg<8,4>", 2},
+                        {5, 2, 1, 11, 4, 1e-6, "generic", 3}};
   for (const Case &c : cases) {
     Problem pr = make_problem(c.nx, c.nu, c.nc, c.N, 7 + c.nx), ph = pr;
     Sol sr(pr), sh(ph);
@@ -135,7 +141,14 @@ int main() {
         for (uint t = b; t < e; ++t)
           ph.stages[t].addParameterization(ph.stages[e - 1].nx2);
       }
-      hip = std::make_unique<gar::HipRiccatiSolver>(ph, c.legs);
+      if (c.ndev == 1) {
+        hip = std::make_unique<gar::HipRiccatiSolver>(ph, c.legs);
+      } else {
+        std::vector<int> devs;
+        for (int d = 0; d < c.ndev; ++d)
+          devs.push_back(d);
+        hip = std::make_unique<gar::HipRiccatiSolver>(ph, c.legs, devs);
+      }
     }
     const double scale = run(*ref, pr, sr, c.mu, gr);
     run(*hip, ph, sh, c.mu, gh);
@@ -145,11 +158,12 @@ int main() {
       gs = std::max(gs, std::abs(gr[i]));
     }
     const double dx = diff(sr.xs, sh.xs), du = diff(sr.us, sh.us), dv = diff(sr.vs, sh.vs), dl = diff(sr.lbdas, sh.lbdas);
-    const char *name = gar_hip_kernel_name_of(*hip);
-    const bool ok = gr.size() == gh.size() && std::max(std::max(dx, du), std::max(dv, dl)) <= 1e-8 * scale && dg <= 1e-8 * gs &&
+    const auto &hs = static_cast<gar::HipRiccatiSolver &>(*hip);
+    const char *name = hs.kernelName();
+    const bool ok = hs.numDevices() == c.ndev && gr.size() == gh.size() && std::max(std::max(dx, du), std::max(dv, dl)) <= 1e-8 * scale && dg <= 1e-8 * gs &&
                     std::string(name).find(c.want) != std::string::npos;
-    std::printf("nx=%u nu=%u nc=%u N=%u legs=%d kernel %-22s |x| %.1e |u| %.1e |v| %.1e |lbd| %.1e |gains| %.1e (rel %.1e)  %s\n", c.nx, c.nu,
-                c.nc, c.N, c.legs, name, dx, du, dv, dl, dg, dg / gs, ok ? "ok" : "MISMATCH");
+    std::printf("nx=%u nu=%u nc=%u N=%u legs=%d devices=%d kernel %-22s |x| %.1e |u| %.1e |v| %.1e |lbd| %.1e |gains| %.1e (rel %.1e)  %s\n", c.nx, c.nu,
+                c.nc, c.N, c.legs, c.ndev, name, dx, du, dv, dl, dg, dg / gs, ok ? "ok" : "MISMATCH");
     bad += !ok;
   }
   std::printf(bad ? "%d case(s) FAILED\n" : "seam ok\n", bad);

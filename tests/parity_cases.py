@@ -146,14 +146,15 @@ def conditioning_bound(prob, mueq, ref=None):
 
 
 def check_parallel(prob, mueq, nthreads, tol, lib_path=None, max_refine=10, rounds=0, rng=None, conditioned=False,
-                   report=None):
+                   report=None, devices=None):
     """tests/gar/parallel.cpp:185-245 (parallel_solver_class).
     conditioned: the tolerance of each part of the solution is max(tol, CONDITIONING_MARGIN x what the problem's
     conditioning allows), measured on the problem itself (conditioning_bound, and the oracle's own leg-parallel vs serial
     solutions) instead of a floor on mu in the caller.  report: a dict that receives every pairwise figure."""
     _, _, ref = oracle_serial(prob, mueq)
     pprob = prob.copy()
-    par = ParallelRiccatiSolver(pprob, nthreads, lib_path=lib_path)
+    # devices: the legs split over several devices inside the one solver object (gar_hip_multi_create)
+    par = ParallelRiccatiSolver(pprob, nthreads, lib_path=lib_path, devices=devices)
     par.maxRefinementSteps = max_refine
     sol = lqrInitializeSolution(pprob)
     assert par.backward(mueq)
@@ -423,11 +424,11 @@ def check_second_bunch_kaufman_test(lib_path=None):
             os.environ["GAR_HIP_SPD_ACCEPT"] = old_spd
 
 
-def check_bulk_gains(prob, mueq, lib_path=None, num_legs=1):
+def check_bulk_gains(prob, mueq, lib_path=None, num_legs=1, devices=None):
     """gar_hip_fetch_results / gar_hip_get_gains_all against the per-stage gar_hip_get_gains and the
     per-part gar_hip_get_solution: bitwise the same numbers, one copy instead of 3 (N+1) + 4."""
     dims = [k.dims for k in prob.stages]
-    s = BatchedRiccatiSolver(dims, prob.nc0, batch=2, num_legs=num_legs, lib_path=lib_path)
+    s = BatchedRiccatiSolver(dims, prob.nc0, batch=2, num_legs=num_legs, lib_path=lib_path, devices=devices)
     s.upload([prob, prob])
     assert s.backward(mueq) and s.forward()
     if num_legs > 1:
