@@ -362,6 +362,55 @@ def horizon_sharded(args, world, rank, device, dist, N=2048, legs=256, reps=10):
     return out
 
 
+def horizon_single_process(args, N=2048, legs=256, reps=10):
+    """BASELINE.json configs[3] from the seam the reference calls: ONE process, ONE solver object
+    (include/gar_hip.h, gar_hip_multi_create -- what `HipRiccatiSolver(problem, num_legs, devices)` holds behind
+    `SolverProxDDP::linear_solver_`), its legs split over `--gpus` devices; the boundary exchange happens inside
+    backward() (csrc/gar_multi.hpp: peer gather kernel or hipMemcpyPeerAsync, ordered by HIP events).  No torchrun,
+    no torch.distributed.  --same-device: every sub-solver on cuda:0 (how a one-GPU box exercises the path)."""
+    from aligator_amd import synth
+    nx, nu, mueq = 36, 12, 1e-14
+    W = args.gpus
+    if not args.same_device and torch.cuda.device_count() < W:
+        raise SystemExit(f"bench.py --single-process --gpus {W}: only {torch.cuda.device_count()} device(s) visible")
+    devices = [0] * W if args.same_device else list(range(W))
+    prob = synth.generate_lq_problem(4242, np.zeros(nx), N, nx, nu, mode=args.generator)
+    dims = [k.dims for k in prob.stages]
+    s = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=legs, devices=devices)
+    s.upload([prob])
+    for _ in range(2):
+        s.backward_async(mueq)
+        s.forward_async()
+    s.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        s.backward_async(mueq)
+        s.forward_async()
+    s.sync()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    assert s.backward(mueq) and s.forward()   # the checked form: raises if any stage on any device failed
+    resid, steps = s.condensed_info(0)
+    out = {"workload": f"one problem, N={N} nx={nx} nu={nu} fp64 (BASELINE.json configs[3]), horizon sharded, ONE process",
+           "devices": devices, "legs": legs, "ms_per_sweep": ms,
+           "exchange": s._L.gar_hip_multi_exchange_name(s.handle).decode() or "none (one device)",
+           "boundary_bytes_read_per_device": 8 * (3 * nx * nx + 2 * nx) * legs,
+           "condensed_residual": resid, "refinement_steps": steps, "kernel": s.kernel_name, "host_syncs_per_sweep": 0}
+    ref = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=1, device=devices[0])
+    ref.upload([prob])
+    ref.backward(mueq)
+    ref.forward()
+    a, b = s.solution(0), ref.solution(0)
+    scale = max(1.0, max(float(np.abs(v).max()) for v in b[3]))
+    out["max_rel_diff_vs_serial"] = max(float(np.abs(x - y).max()) for A, B in zip(a, b) for x, y in zip(A, B) if x.size) / scale
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ref.backward_async(mueq)
+        ref.forward_async()
+    ref.sync()
+    out["serial_one_device_ms_per_sweep"] = (time.perf_counter() - t0) / reps * 1e3
+    return out
+
+
 def secondary_shapes(device, batch=1024):
     """Two more shapes of the same hot path, outside the timed region (rank 0, one GPU), so that the round's
     bench record carries them: the reference's OWN gar benchmark shape (bench/gar-riccati.cpp:19-22: nx=36,
@@ -522,6 +571,9 @@ def main():
                     help="process-group backend for the timing barrier (gloo + --same-device lets two "
                          "ranks share one GPU to exercise the N>1 path on a 1-GPU box)")
     ap.add_argument("--same-device", action="store_true", help="testing: every rank uses cuda:0")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--mode horizon without torchrun: ONE process, ONE solver object whose legs are split over "
+                         "--gpus devices (gar_hip_multi_create), the boundary exchange inside the library")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto: roofline.traffic from rocprofv3 counter passes run inside this bench (rank 0, one GPU) "
                          "when rocprofv3 is on PATH, the committed profiles/pmc_traffic.json otherwise; off: the file")
@@ -530,6 +582,24 @@ def main():
 
     if args.pmc_child:
         return pmc_child(args)
+    if args.single_process:
+        if args.mode != "horizon":
+            raise SystemExit("--single-process belongs to --mode horizon (the batch axis needs no exchange)")
+        if int(os.environ.get("RANK", "0")) != 0:
+            return  # launched under torchrun all the same: rank 0 drives every device, the others have nothing to do
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the backend has no CPU path")
+        hs = horizon_single_process(args)
+        big = horizon_single_process(args, N=16384, legs=512, reps=5)
+        print(json.dumps({
+            "metric": "Riccati sweeps/sec (bwd+fwd), ONE problem N=2048 nx=36 nu=12, horizon sharded",
+            "value": 1e3 / hs["ms_per_sweep"], "unit": "sweeps/s", "n_gpus": args.gpus, "steps": 10, "warmup": 2,
+            "ms_per_step": hs["ms_per_sweep"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": f"synthetic (generator {args.generator})",
+            "config": {"workload": hs["workload"],
+                       "parallelism": f"horizon-sharded x{args.gpus} inside one process, one in-library boundary gather per sweep"},
+            "horizon_sharded": hs, "horizon_sharded_N16384": big}))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))

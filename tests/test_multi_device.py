@@ -208,3 +208,27 @@ def test_gpu_multi_device_three_way_uneven_and_padded():
         sc = pc.scale_of(ref)
         for a, b in zip(many.solution(0), ref):
             assert pc.maxdiff(a, b) <= 1e-8 * sc
+
+
+@pytest.mark.gpu
+def test_gpu_bench_horizon_single_process():
+    """`python bench.py --mode horizon --single-process --gpus 2`: the configs[3] line from ONE process without
+    torchrun (two sub-solvers share this box's GPU); more GPUs than visible fails loudly."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, "bench.py", "--mode", "horizon", "--single-process", "--gpus", "2", "--same-device"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    hs = d["horizon_sharded"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and hs["devices"] == [0, 0] and hs["exchange"] == "pull"
+    assert hs["max_rel_diff_vs_serial"] < 1e-9 and d["horizon_sharded_N16384"]["max_rel_diff_vs_serial"] < 1e-9
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, "bench.py", "--mode", "horizon", "--single-process", "--gpus", str(n + 1)],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible" in (r.stdout + r.stderr)
