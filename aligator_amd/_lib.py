@@ -77,6 +77,7 @@ SIGNATURES = {
     "gar_hip_gains_doubles": (C.c_int, [C.c_void_p, _PI64]),
     "gar_hip_gains_offsets": (C.c_int, [C.c_void_p, C.c_int, _PI64]),
     "gar_hip_fetch_results": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gar_hip_prefetch_gains": (C.c_int, [C.c_void_p, C.c_int]),
     "gar_hip_host_results": (C.c_void_p, [C.c_void_p, _PI64]),
     "gar_hip_get_gains_all": (C.c_int, [C.c_void_p, C.c_int, _PD, _PD]),
     "gar_hip_get_value": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _PD, _PD, _PD, _PD, _PD]),

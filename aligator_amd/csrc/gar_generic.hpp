@@ -660,6 +660,94 @@ __global__ void __launch_bounds__(256) gar_update_lq(UpdateParams P) {
   }
 }
 
+// The same on a PADDED solver (gar_hip.cpp, gar_hip_solver::padded): the derivative records speak the CALLER's
+// dimensions (unx, unu; uniform, unconstrained -- what a padded solver is), the knot records the device's (NX, NU).
+// Real rows / columns: the reference's sums in the reference's order, as above; the dummy controls get R = I, S = 0,
+// B = 0, r = 0, the dummy states Q = I, A = 0, f = 0, q = 0 and the extra rows [0 -I] x0 = 0 of the initial
+// constraint -- exactly what gar_hip_upload_stage / gar_hip_set_init write.  deriv_off / d_G0 / d_g0 / d_iH: the
+// CALLER's derivative layout; unc0 rows of the caller's G0.
+__global__ void __launch_bounds__(256) gar_update_lq_padded(UpdateParams P, int unx, int unu, int unc0) {
+  const int t = (int)blockIdx.x, b = (int)blockIdx.y, tid = (int)threadIdx.x;
+  const gar_stage_meta m = P.meta[t];
+  const int NX = m.nx, NU = m.nu; // device; nc = 0, nx2 = NX
+  const bool term = (t == P.horizon);
+  const int nu = term ? 0 : unu;
+  const gar_knot_offsets KO = gar_knot_layout(NX, NU, 0, NX, 0), ko = gar_knot_layout(unx, nu, 0, unx, 0);
+  const gar_deriv_offsets dof = gar_deriv_layout(unx, nu, 0, unx);
+  const double *dv = P.deriv + (long long)b * P.deriv_stride;
+  const double *d = dv + P.deriv_off[t];
+  double *k = P.prob + (long long)b * P.prob_stride + m.in_off;
+  const bool exact = P.hess_exact && !term;
+  for (int e = tid; e < NX * NX; e += 256) { // Q
+    const int j = e / NX, i = e - j * NX;
+    double v = i == j ? 1.0 : 0.0;
+    if (i < unx && j < unx) {
+      const int s = j * unx + i;
+      v = d[ko.Q + s];
+      if (i == j)
+        v += P.preg;
+      if (exact)
+        v += d[dof.Hxx + s];
+      if (t == 0)
+        v += dv[P.d_iH + s];
+    }
+    k[KO.Q + e] = v;
+  }
+  for (int e = tid; e < NX; e += 256) // q
+    k[KO.q + e] = e < unx ? d[ko.q + e] + d[dof.lxc + e] : 0.0;
+  if (!term) {
+    for (int e = tid; e < NX * NU; e += 256) { // S
+      const int j = e / NX, i = e - j * NX;
+      double v = 0.0;
+      if (i < unx && j < nu) {
+        const int s = j * unx + i;
+        v = exact ? d[ko.S + s] + d[dof.Hxu + s] : d[ko.S + s];
+      }
+      k[KO.S + e] = v;
+    }
+    for (int e = tid; e < NU * NU; e += 256) { // R
+      const int j = e / NU, i = e - j * NU;
+      double v = i == j ? 1.0 : 0.0;
+      if (i < nu && j < nu) {
+        const int s = j * nu + i;
+        v = d[ko.R + s];
+        if (i == j)
+          v += P.preg;
+        if (exact)
+          v += d[dof.Huu + s];
+      }
+      k[KO.R + e] = v;
+    }
+    for (int e = tid; e < NU; e += 256) // r
+      k[KO.r + e] = e < nu ? d[ko.r + e] + d[dof.luc + e] : 0.0;
+    for (int e = tid; e < NX * NX; e += 256) { // A
+      const int j = e / NX, i = e - j * NX;
+      k[KO.A + e] = (i < unx && j < unx) ? d[ko.A + j * unx + i] : 0.0;
+    }
+    for (int e = tid; e < NX * NU; e += 256) { // B
+      const int j = e / NX, i = e - j * NX;
+      k[KO.B + e] = (i < unx && j < nu) ? d[ko.B + j * unx + i] : 0.0;
+    }
+    for (int e = tid; e < NX; e += 256) // f
+      k[KO.f + e] = e < unx ? d[ko.f + e] : 0.0;
+  }
+  if (t == 0) { // [G0 0; 0 -I], [g0; 0]
+    double *pb = P.prob + (long long)b * P.prob_stride;
+    const int nc0 = P.nc0; // device rows = unc0 + (NX - unx)
+    for (int e = tid; e < nc0 * NX; e += 256) {
+      const int j = e / nc0, i = e - j * nc0;
+      double v = 0.0;
+      if (i < unc0 && j < unx)
+        v = dv[P.d_G0 + j * unc0 + i];
+      else if (i >= unc0 && j >= unx && i - unc0 == j - unx)
+        v = -1.0;
+      pb[P.G0_off + e] = v;
+    }
+    for (int e = tid; e < nc0; e += 256)
+      pb[P.g0_off + e] = e < unc0 ? dv[P.d_g0 + e] : 0.0;
+  }
+}
+
 // One K-slice of a dot product: sum over k = q, q + 4, q + 8, ... < K of a[k astride] x[k], sixteen products per
 // round trip, every load unconditional from a clamped address (a branch per load would serialise the round trips).
 __device__ __forceinline__ double gar_sliced_dot(const double *a, int astride, const double *x, int K, int q) {

@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -194,6 +197,7 @@ struct gar_hip_solver {
   // host staging
   double *h_prob = nullptr; // pinned, batch * prob_doubles (when small enough)
   bool staged = false, dirty = false;
+  bool stage_nt = false; // pack with non-temporal stores (problems of >= 12 MiB; GAR_HIP_STAGE_NT=0/1 overrides)
   // what the host wrote into the staging area since the last flush: per problem, a sorted list of
   // disjoint [lo, hi) ranges (doubles).  commit() copies exactly these, so knots a device-resident
   // producer wrote in place (gar_hip_device_problems) survive a later set_init / upload_stage
@@ -253,6 +257,12 @@ struct gar_hip_solver {
   double *d_gains = nullptr, *h_results = nullptr;
   bool timing = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // gar_hip_prefetch_gains: the bulk read-back of the gains started right behind the backward sweep on a second
+  // stream, so that it overlaps the forward sweep and the solution read-back
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_main = nullptr, ev_pref = nullptr;
+  int pref_b = -1;             // problem whose gains are in flight / in h_results (-1: none)
+  bool pref_collapsed = false; // collapseFeedback ran since: stage 0's gains are fetched again
 };
 
 namespace {
@@ -877,6 +887,13 @@ gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
   return P;
 }
 
+// non-temporal stores (stage_copy) are weakly ordered: make them globally visible before a DMA engine reads them
+inline void stage_fence() {
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+  _mm_sfence();
+#endif
+}
+
 void mark_dirty(gar_hip_solver *s, int b, int64_t lo, int64_t hi) {
   auto &iv = s->dirty_iv[(size_t)b];
   // the common pattern is "append right after the last range" (knot after knot): O(1); gaps of
@@ -903,6 +920,7 @@ void mark_dirty(gar_hip_solver *s, int b, int64_t lo, int64_t hi) {
 int commit(gar_hip_solver *s) {
   if (!(s->staged && s->dirty))
     return GAR_HIP_OK;
+  stage_fence();
   const int64_t P = s->prob_doubles;
   // whole problems, back to back: one copy per run of fully rewritten problems
   int b = 0;
@@ -939,28 +957,61 @@ int commit(gar_hip_solver *s) {
   return GAR_HIP_OK;
 }
 
+// Host copy into the pinned staging area with non-temporal stores: the destination is written once and next read by
+// the DMA engine, so it should not be pulled into (read-for-ownership) nor left in the caches of the packing core --
+// a third less memory traffic than memcpy's cached stores on the 19 MB of a (56, 22), N = 256 problem (measured on
+// the GPU box's host: 920 -> 560 us).  Only for problems that do not fit the last-level cache next to their source
+// (gar_hip_solver::stage_nt): the 7.6 MB of the north-star problem pack at cache speed with plain stores (150 us
+// against 440 us with non-temporal ones).
+inline void stage_copy(double *dst, const double *src, size_t n, bool nt) {
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+  if (nt && n >= 512) {
+    size_t i = 0;
+    if (reinterpret_cast<uintptr_t>(dst) & 15) // 8-byte aligned at least: one scalar brings it to 16
+      dst[i] = src[i], ++i;
+    for (; i + 8 <= n; i += 8) {
+      const __m128d a = _mm_loadu_pd(src + i), b = _mm_loadu_pd(src + i + 2), c = _mm_loadu_pd(src + i + 4),
+                    d = _mm_loadu_pd(src + i + 6);
+      _mm_stream_pd(dst + i, a);
+      _mm_stream_pd(dst + i + 2, b);
+      _mm_stream_pd(dst + i + 4, c);
+      _mm_stream_pd(dst + i + 6, d);
+    }
+    for (; i < n; ++i)
+      dst[i] = src[i];
+    return;
+  }
+#endif
+  std::memcpy(dst, src, sizeof(double) * n);
+}
+
+// pipeline the upload: once the range being appended to has grown past 1 MiB it goes out
+// (asynchronously, pinned -> HBM) while the caller packs the next knots -- one Newton
+// iteration's 7.6 MB of knots then costs max(host packing, PCIe), not their sum
+int flush_if_grown(gar_hip_solver *s, int b) {
+  auto &iv = s->dirty_iv[(size_t)b];
+  if (!iv.empty() && iv.back().second - iv.back().first >= (int64_t)(1 << 17)) {
+    stage_fence();
+    const int64_t lo = iv.back().first, hi = std::min(iv.back().second, s->prob_doubles);
+    HIP_TRY(hipMemcpyAsync(s->d_prob + (int64_t)b * s->prob_doubles + lo,
+                           s->h_prob + (int64_t)b * s->prob_doubles + lo,
+                           sizeof(double) * (size_t)(hi - lo), hipMemcpyHostToDevice, s->stream));
+    iv.pop_back();
+  }
+  return GAR_HIP_OK;
+}
+
 int write_block(gar_hip_solver *s, int b, int64_t off, const double *src, int64_t n) {
   if (n <= 0)
     return GAR_HIP_OK;
   if (s->staged) {
     double *dst = s->h_prob + (int64_t)b * s->prob_doubles + off;
     if (src)
-      std::memcpy(dst, src, sizeof(double) * (size_t)n);
+      stage_copy(dst, src, (size_t)n, s->stage_nt);
     else
       std::memset(dst, 0, sizeof(double) * (size_t)n);
     mark_dirty(s, b, off, off + n);
-    // pipeline the upload: once the range being appended to has grown past 1 MiB it goes out
-    // (asynchronously, pinned -> HBM) while the caller packs the next knots -- one Newton
-    // iteration's 7.6 MB of knots then costs max(host packing, PCIe), not their sum
-    auto &iv = s->dirty_iv[(size_t)b];
-    if (iv.back().second - iv.back().first >= (int64_t)(1 << 17)) {
-      const int64_t lo = iv.back().first, hi = std::min(iv.back().second, s->prob_doubles);
-      HIP_TRY(hipMemcpyAsync(s->d_prob + (int64_t)b * s->prob_doubles + lo,
-                             s->h_prob + (int64_t)b * s->prob_doubles + lo,
-                             sizeof(double) * (size_t)(hi - lo), hipMemcpyHostToDevice, s->stream));
-      iv.pop_back();
-    }
-    return GAR_HIP_OK;
+    return flush_if_grown(s, b);
   }
   double *dst = s->d_prob + (int64_t)b * s->prob_doubles + off;
   if (src)
@@ -1542,6 +1593,8 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(gar_host_malloc((void **)&s->h_prob, staging, hipHostMallocDefault));
     std::memset(s->h_prob, 0, staging);
     s->staged = true;
+    const char *nt = std::getenv("GAR_HIP_STAGE_NT");
+    s->stage_nt = nt && nt[0] ? nt[0] == '1' : sizeof(double) * (size_t)s->prob_doubles >= ((size_t)12 << 20);
   }
   s->dirty_iv.assign(B, {});
   s->dirty = false;
@@ -1872,6 +1925,12 @@ void gar_hip_solver_destroy(gar_hip_solver *s) {
   for (auto &e : s->ev)
     if (e)
       (void)hipEventDestroy(e);
+  if (s->aux_stream) {
+    (void)hipStreamSynchronize(s->aux_stream);
+    (void)hipStreamDestroy(s->aux_stream);
+    (void)hipEventDestroy(s->ev_main);
+    (void)hipEventDestroy(s->ev_pref);
+  }
   delete s->ulay;
   delete s->flay;
   delete s;
@@ -2058,6 +2117,10 @@ int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   GAR_MULTI(s, multi_backward_legs(s, mueq));
+  if (s->ev_pref) { // a read-back of the previous sweep's gains may still be in flight on the second stream
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_pref, 0));
+    s->pref_b = -1;
+  }
   if (int rc = commit(s))
     return rc;
   HIP_TRY(hipMemsetAsync(s->d_status, 0, sizeof(int) * ((size_t)s->batch + 4 + (s->fold ? (size_t)s->batch : 0)), s->stream));
@@ -2321,6 +2384,16 @@ static int fetch_results_impl(gar_hip_solver *s, int b, int what, int t_lo, int 
     s->d_gains = dg;
     s->d_gain_off = dgo;
   }
+  if ((what & 2) && s->pref_b == b && !gains_base && t_lo == 0 && t_hi == s->horizon + 1) {
+    // the gains are already on their way (gar_hip_prefetch_gains): wait for them; what collapseFeedback changed
+    // since -- stage 0 -- comes again
+    HIP_TRY(hipEventSynchronize(s->ev_pref));
+    s->pref_b = -1;
+    if (!s->pref_collapsed)
+      what &= ~2;
+    else
+      t_hi = 1;
+  }
   if ((what & 2) && t_hi > t_lo) { // device-side gather (fbT2 -> row-major, dummy rows / columns dropped), then ONE device-to-host copy
     if (int rc = ensure_expanded(s))
       return rc;
@@ -2361,6 +2434,36 @@ int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
     return rc;
   GAR_MULTI(s, multi_fetch_results(s, b, what));
   return fetch_results_impl(s, b, what, 0, s->horizon + 1, nullptr, true);
+}
+
+int gar_hip_prefetch_gains(gar_hip_solver *s, int b) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  // (multi-device and folded solvers: the ordinary fetch does the work -- their read-back has host-side steps)
+  if (s->multi || s->fold)
+    return GAR_HIP_OK;
+  if (int rc = fetch_results_impl(s, b, 0, 0, 0, nullptr, false)) // the buffers, on first use
+    return rc;
+  if (!s->aux_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_pref, hipEventDisableTiming));
+  }
+  const gar_hip_solver *u = s->ulay ? s->ulay : s;
+  const size_t nsol = (size_t)u->sol_doubles, ngain = (size_t)(u->ff_all_doubles + u->fb_all_doubles);
+  HIP_TRY(hipEventRecord(s->ev_main, s->stream));
+  HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_main, 0));
+  hipLaunchKernelGGL(gar::gar_gather_gains, dim3((unsigned)(s->horizon + 1)), dim3(256), 0, s->aux_stream, s->d_meta,
+                     s->d_fac + (int64_t)b * s->fac_doubles, s->d_gains, s->d_gains + u->ff_all_doubles, s->d_gain_off,
+                     s->horizon, records_t2(s, b) ? 1 : 0, s->dense ? 1 : 0, s->padded ? s->unx : 0,
+                     s->padded ? s->unu : 0, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->h_results + nsol, s->d_gains, sizeof(double) * ngain, hipMemcpyDeviceToHost, s->aux_stream));
+  HIP_TRY(hipEventRecord(s->ev_pref, s->aux_stream));
+  s->pref_b = b;
+  s->pref_collapsed = false;
+  return GAR_HIP_OK;
 }
 
 const double *gar_hip_host_results(gar_hip_solver *s, int64_t offs[3]) {
@@ -2492,15 +2595,17 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]) {
   return GAR_HIP_OK;
 }
 
-int64_t gar_hip_deriv_doubles(const gar_hip_solver *s) { return s ? s->deriv_doubles : 0; }
+// (the derivative records speak the CALLER's dimensions: under padding the layout is the caller-facing one, `ulay`)
+int64_t gar_hip_deriv_doubles(const gar_hip_solver *s) { return s ? (s->ulay ? s->ulay->deriv_doubles : s->deriv_doubles) : 0; }
 
 int gar_hip_deriv_offsets(const gar_hip_solver *s, int t, int64_t out[4]) {
   if (int rc = check_bt(s, 0, t))
     return rc;
-  out[0] = s->deriv_off[t];
-  out[1] = s->d_G0;
-  out[2] = s->d_g0;
-  out[3] = s->d_iH;
+  const gar_hip_solver *u = s->ulay ? s->ulay : s;
+  out[0] = u->deriv_off[t];
+  out[1] = u->d_G0;
+  out[2] = u->d_g0;
+  out[3] = u->d_iH;
   return GAR_HIP_OK;
 }
 
@@ -2510,35 +2615,36 @@ int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_d
   if (!s || !deriv_dev)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_update_lq_subproblem_device: bad argument");
   GAR_MULTI(s, fail(GAR_HIP_ERR_UNSUPPORTED, "device-resident LQ assembly on a multi-device solver: one derivative buffer per device would be needed"));
-  if (s->padded)
-    return fail(GAR_HIP_ERR_UNSUPPORTED, "device-resident LQ assembly on a padded solver: the derivative records would "
-                                         "have to carry the dummy states / controls (GAR_HIP_PAD=0 keeps the caller's shape)");
   if (int rc = commit(s)) // pending host staging first; later host writes flush only their own ranges
     return rc;
+  const gar_hip_solver *u = s->ulay ? s->ulay : s; // the layout of the derivative buffer: the caller's dimensions
   if (!s->d_deriv_off) {
-    HIP_TRY(gar_dev_malloc((void **)&s->d_deriv_off, sizeof(long long) * s->deriv_off.size()));
-    HIP_TRY(hipMemcpy(s->d_deriv_off, s->deriv_off.data(), sizeof(long long) * s->deriv_off.size(),
+    HIP_TRY(gar_dev_malloc((void **)&s->d_deriv_off, sizeof(long long) * u->deriv_off.size()));
+    HIP_TRY(hipMemcpy(s->d_deriv_off, u->deriv_off.data(), sizeof(long long) * u->deriv_off.size(),
                       hipMemcpyHostToDevice));
   }
   gar::UpdateParams U{};
   U.meta = s->d_meta;
   U.deriv = deriv_dev;
   U.prob = s->d_prob;
-  U.deriv_stride = s->deriv_doubles;
+  U.deriv_stride = u->deriv_doubles;
   U.prob_stride = s->prob_doubles;
   U.G0_off = s->G0_off;
   U.g0_off = s->g0_off;
   U.deriv_off = s->d_deriv_off;
-  U.d_G0 = s->d_G0;
-  U.d_g0 = s->d_g0;
-  U.d_iH = s->d_iH;
+  U.d_G0 = u->d_G0;
+  U.d_g0 = u->d_g0;
+  U.d_iH = u->d_iH;
   U.horizon = s->horizon;
   U.nc0 = s->nc0;
   U.nx0 = s->nx0;
   U.hess_exact = hess_exact;
   U.preg = preg;
-  hipLaunchKernelGGL(gar::gar_update_lq, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch),
-                     dim3(256), 0, s->stream, U);
+  const dim3 grid((unsigned)(s->horizon + 1), (unsigned)s->batch);
+  if (s->padded) // the caller's records scattered into the padded knots, dummy rows / columns written (gar_generic.hpp)
+    hipLaunchKernelGGL(gar::gar_update_lq_padded, grid, dim3(256), 0, s->stream, U, s->unx, s->unu, s->user_nc0);
+  else
+    hipLaunchKernelGGL(gar::gar_update_lq, grid, dim3(256), 0, s->stream, U);
   HIP_TRY(hipGetLastError());
   return GAR_HIP_OK;
 }
@@ -2626,6 +2732,7 @@ int gar_hip_collapse_feedback(gar_hip_solver *s) {
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   GAR_MULTI(s, gar_hip_collapse_feedback(s->multi->subs[0])); // stage 0 lives on the first device
+  s->pref_collapsed = true;
   if (s->num_legs < 2 || s->leg_begin != 0)
     return GAR_HIP_OK; // no-op except Parallel (riccati-base.hpp:33)
   if (s->fold) { // the wave-leg family's own records (then re-expanded on request); flagged problems: generic records
@@ -2650,6 +2757,9 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
   if (!s || !d)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
   GAR_MULTI(s, multi_cycle_append(s, d));
+  if (s->ev_pref)
+    HIP_TRY(hipEventSynchronize(s->ev_pref));
+  s->pref_b = -1;
   const int N = s->horizon;
   if (N < 1)
     return GAR_HIP_OK;
@@ -2741,6 +2851,39 @@ int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const
   const int nx = s->unx, nu = m.nu > 0 ? s->unu : 0, NX = m.nx, NU = m.nu;
   if (!Q || !q || !A || !f || (nu > 0 && (!S || !R || !r || !B)))
     return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_stage: null block");
+  if (s->staged) {
+    // straight into the pinned staging record, one pass: real rows / columns copied column by column, the dummy
+    // ones written beside them (no intermediate padded copy of the blocks); then the knot is one dirty range
+    const gar_knot_offsets o = gar_knot_layout(NX, NU, 0, NX, 0);
+    double *rec = s->h_prob + (int64_t)b * s->prob_doubles + m.in_off;
+    const bool nt = s->stage_nt;
+    auto put = [rec, nt](int64_t off, const double *src, int r, int c, int R, int C, double diag) {
+      double *dst = rec + off;
+      if (r == R) { // same column pitch (e.g. (56, 22) -> (56, 24): only controls are added): the real columns in one go
+        stage_copy(dst, src, (size_t)r * (size_t)c, nt);
+      } else {
+        for (int j = 0; j < c; ++j) {
+          std::memcpy(dst + (size_t)j * R, src + (size_t)j * r, sizeof(double) * (size_t)r);
+          std::memset(dst + (size_t)j * R + r, 0, sizeof(double) * (size_t)(R - r));
+        }
+      }
+      if (C > c)
+        std::memset(dst + (size_t)c * R, 0, sizeof(double) * (size_t)R * (size_t)(C - c));
+      if (diag != 0.0)
+        for (int i = std::min(r, c); i < std::min(R, C); ++i)
+          dst[(size_t)i * R + i] = diag;
+    };
+    put(o.Q, Q, nx, nx, NX, NX, 1.0);
+    put(o.S, S, nx, nu, NX, NU, 0.0);
+    put(o.R, R, nu, nu, NU, NU, 1.0);
+    put(o.q, q, nx, 1, NX, 1, 0.0);
+    put(o.r, r, nu, 1, NU, 1, 0.0);
+    put(o.A, A, nx, nx, NX, NX, 0.0);
+    put(o.B, B, nx, nu, NX, NU, 0.0);
+    put(o.f, f, nx, 1, NX, 1, 0.0);
+    mark_dirty(s, b, m.in_off, m.in_off + gar_knot_doubles(NX, NU, 0, NX, 0));
+    return flush_if_grown(s, b);
+  }
   thread_local std::vector<double> bQ, bS, bR, bq, br, bA, bB, bf;
   return upload_stage_dev(s, b, t, padded_block(bQ, Q, nx, nx, NX, NX, 1.0), padded_block(bS, S, nx, nu, NX, NU, 0.0),
                           padded_block(bR, R, nu, nu, NU, NU, 1.0), padded_block(bq, q, nx, 1, NX, 1, 0.0),

@@ -264,9 +264,8 @@ class BatchedRiccatiSolver:
 
     def pack_derivs(self, derivs, init) -> np.ndarray:
         """One problem's derivative buffer (csrc/gar_layout.h, gar_deriv_layout): header
-        G0 | g0 | init Hxx, then one record per stage in DERIV_BLOCKS order."""
-        if self.padded:
-            raise NotImplementedError("derivative records of a padded solver")
+        G0 | g0 | init Hxx, then one record per stage in DERIV_BLOCKS order -- in the CALLER's dimensions, also when
+        the library padded the shape (the device kernel scatters into the padded knots)."""
         buf = np.zeros(self.deriv_doubles)
         off = np.zeros(4, dtype=np.int64)
         for t, d in enumerate(derivs):

@@ -56,7 +56,8 @@ public:
     if (rc == GAR_HIP_ERR_FACTOR)                       // riccati-kernel.hxx:239-241
       ALIGATOR_RUNTIME_ERROR("Failed stage LDL factorization");
     check(rc);
-    fetch_gains();                                      // ff/fb views stay valid until next backward
+    check(gar_hip_prefetch_gains(h_, 0));               // the gains start travelling now, under forward()
+    gains_stale_ = true;                                // waited for once, on first use (after collapseFeedback, :619)
     return true;
   }
 
@@ -76,9 +77,11 @@ public:
     check(gar_hip_cycle_append(h_, d));
     map_gains();                                        // dimensions of the last-but-one stage may differ
   }
-  void collapseFeedback() override { check(gar_hip_collapse_feedback(h_)); fetch_gains(); }
-  VectorRef getFeedforward(size_t i) override { return ff_[i]; }
-  RowMatrixRef getFeedback(size_t i) override { return fb_[i]; }   // row-major [K; Z; Aff]
+  void collapseFeedback() override { check(gar_hip_collapse_feedback(h_)); gains_stale_ = true; }
+  // views into solver-owned host memory, valid until the next backward / cycleAppend (the reference's contract);
+  // every stage's ff / fb comes over in ONE gather + ONE device-to-host copy, when the caller first asks
+  VectorRef getFeedforward(size_t i) override { fetch_gains(); return ff_[i]; }
+  RowMatrixRef getFeedback(size_t i) override { fetch_gains(); return fb_[i]; }   // row-major [K; Z; Aff]
   const char *kernelName() const { return gar_hip_kernel_name(h_); }  // the family that runs (padding is the library's business)
   int numDevices() const { return gar_hip_num_devices(h_); }
 
@@ -115,7 +118,11 @@ private:
     }
   }
   // every stage's ff / fb: one device-side gather, ONE D2H, one synchronisation (per device, concurrently)
-  void fetch_gains() { check(gar_hip_fetch_results(h_, 0, /*gains*/ 2)); }
+  void fetch_gains() {
+    if (!gains_stale_) return;
+    check(gar_hip_fetch_results(h_, 0, /*gains*/ 2));
+    gains_stale_ = false;
+  }
   static void check(int rc) { if (rc != GAR_HIP_OK) ALIGATOR_RUNTIME_ERROR(gar_hip_last_error()); }
   static const double *scatter(const double *p, std::vector<VectorXs> &out, size_t total) {
     const double *q = p;
@@ -125,6 +132,7 @@ private:
   Problem *problem_; int num_legs_; std::vector<int> devices_; gar_hip_solver *h_ = nullptr;
   size_t nxs_ = 0, nus_ = 0, nvs_ = 0, nls_ = 0;        // doubles per part of the packed solution
   std::vector<VectorMap> ff_; std::vector<RowMatrixMap> fb_;
+  bool gains_stale_ = false;
 };
 
 } // namespace aligator::gar

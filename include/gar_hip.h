@@ -218,7 +218,10 @@ int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed);
  * hess_exact != 0, stage 0 gets the initial condition's Hessian).  Asynchronous on the solver's
  * stream: follow with gar_hip_backward_async.  out[0] of gar_hip_deriv_offsets = offset of stage
  * t's record, out[1..3] = offsets of G0, g0, init Hxx inside one problem's derivative buffer.
- * Not available on a padded solver (GAR_HIP_ERR_UNSUPPORTED; GAR_HIP_PAD=0 keeps the caller's shape). */
+ * The derivative records ALWAYS speak the caller's dimensions: on a padded solver ((56, 22) -> (56, 24), (12, 6) ->
+ * (12, 8), (4, 2) -> (8, 4), ...) the kernel scatters the real rows / columns into the padded knots and writes the
+ * dummy ones (R = I, S = 0, B = 0, r = 0; Q = I, A = 0, f = 0; [0 -I] x0 = 0), as gar_hip_upload_stage does.
+ * Not available on a multi-device solver (GAR_HIP_ERR_UNSUPPORTED). */
 int64_t gar_hip_deriv_doubles(const gar_hip_solver *s);
 int gar_hip_deriv_offsets(const gar_hip_solver *s, int t, int64_t out[4]);
 int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_dev, double preg,
@@ -314,7 +317,13 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb,
  *                           ff_all and of fb_all inside it.  The subclass maps its getFeedforward /
  *                           getFeedback views straight onto it ("views into solver-owned host
  *                           memory, valid until the next backward", as in the reference).
- *   gar_hip_get_gains_all   fetch + copy into caller-owned arrays (either may be NULL) */
+ *   gar_hip_get_gains_all   fetch + copy into caller-owned arrays (either may be NULL)
+ *   gar_hip_prefetch_gains  optional, right after gar_hip_backward: starts the gather and the copy of problem b's
+ *                           gains on a second stream, so that they overlap the forward sweep and the solution
+ *                           read-back; the next gar_hip_fetch_results(s, b, 2) then only waits for them (and fetches
+ *                           stage 0 again if gar_hip_collapse_feedback ran in between).  The host buffer must not be
+ *                           read for gains before that fetch.  A no-op on multi-device and folded solvers. */
+int gar_hip_prefetch_gains(gar_hip_solver *s, int b);
 int gar_hip_gains_doubles(const gar_hip_solver *s, int64_t out[2]);
 int gar_hip_gains_offsets(const gar_hip_solver *s, int t, int64_t out[2]);
 int gar_hip_fetch_results(gar_hip_solver *s, int b, int what);

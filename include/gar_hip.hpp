@@ -328,7 +328,8 @@ public:
   bool backward(const double mueq) override {
     gains_valid_ = false;
     upload();
-    check(gar_hip_backward(h_, mueq)); // GAR_HIP_ERR_FACTOR -> "Failed stage LDL factorization"
+    check(gar_hip_backward(h_, mueq));
+    check(gar_hip_prefetch_gains(h_, 0)); // the gains start travelling now, under forward() // GAR_HIP_ERR_FACTOR -> "Failed stage LDL factorization"
     return true;
   }
 };
@@ -344,6 +345,7 @@ public:
     gains_valid_ = false;
     upload();
     check(gar_hip_backward(h_, mueq));
+    check(gar_hip_prefetch_gains(h_, 0)); // the gains start travelling now, under forward()
     return true;
   }
 };
@@ -364,6 +366,7 @@ public:
     gains_valid_ = false;
     upload();
     check(gar_hip_backward(h_, mueq));
+    check(gar_hip_prefetch_gains(h_, 0)); // the gains start travelling now, under forward()
     return true;
   }
   void collapseFeedback() override {

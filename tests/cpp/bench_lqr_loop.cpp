@@ -20,12 +20,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "gar_hip.hpp"
+#ifndef SEAM_NO_ORACLE
 extern "C" {
 #include "../../oracle/gar_oracle.h"
 }
+#endif
 
 using namespace aligator_hip::gar;
 using clk = std::chrono::steady_clock;
@@ -68,6 +71,7 @@ static void update_lq_subproblem(LqrProblem &p, int iter) {
   }
 }
 
+#ifndef SEAM_NO_ORACLE
 static ora_problem *to_oracle(const LqrProblem &p) {
   const int N = p.horizon();
   std::vector<int> d5;
@@ -95,6 +99,95 @@ static void sync_oracle(const LqrProblem &p, ora_problem *o) { // the oracle re-
       std::copy(k.B.data(), k.B.data() + k.nx2 * k.nu, q.B);
     }
   }
+}
+
+#endif
+
+// ---- the same iteration, phase by phase (the `seam` object of bench.py's line) -------------------------------------
+// The call sequence of include/aligator/gar/hip-riccati.hpp (the binding a maintainer adds to aligator), written
+// out over the C ABI with a host clock around every call.  Gains are consumed the way solver-proxddp.hxx:619-632
+// consumes them: copied, stage by stage, from the solver-owned views into the caller's own storage.
+struct SeamPhases {
+  double pack = 0, backward = 0, forward = 0, sol = 0, collapse = 0, gains = 0, consume = 0, total = 0; // us, host clock
+  double dev_bwd = 0, dev_cond = 0, dev_fwd = 0;                                                        // ms, HIP events
+  double h2d_bytes = 0, d2h_bytes = 0;
+};
+static SeamPhases time_phases(LqrProblem &p, int num_legs, int iters, double mu, std::string *kernel) {
+  const int N = p.horizon();
+  std::vector<int32_t> dims5;
+  for (const LqrKnot &k : p.stages) {
+    const int32_t d[5] = {(int)k.nx, (int)k.nu, (int)k.nc, (int)k.nx2, 0};
+    dims5.insert(dims5.end(), d, d + 5);
+  }
+  gar_hip_solver *h = gar_hip_solver_create(0, N, dims5.data(), (int)p.nc0(), 1, num_legs);
+  if (!h)
+    throw std::runtime_error(gar_hip_last_error());
+  *kernel = gar_hip_kernel_name(h);
+  auto check = [](int rc) {
+    if (rc != GAR_HIP_OK)
+      throw std::runtime_error(gar_hip_last_error());
+  };
+  check(gar_hip_fetch_results(h, 0, 0));
+  check(gar_hip_set_timing(h, 1));
+  int64_t offs[3], gd[2];
+  const double *base = gar_hip_host_results(h, offs);
+  check(gar_hip_gains_doubles(h, gd));
+  std::vector<double> my_gains((size_t)(gd[0] + gd[1])), my_sol((size_t)gar_hip_solution_doubles(h));
+  SeamPhases best;
+  best.total = 1e30;
+  auto us_since = [](clk::time_point t0) { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
+  for (int it = 0; it < iters + 2; ++it) {
+    update_lq_subproblem(p, it);
+    SeamPhases ph;
+    const auto t0 = clk::now();
+    auto t = t0;
+    for (int s = 0; s <= N; ++s) {
+      const LqrKnot &k = p.stages[(size_t)s];
+      check(gar_hip_upload_stage(h, 0, s, k.Q.data(), k.S.data(), k.R.data(), k.q.data(), k.r.data(), k.A.data(), k.B.data(),
+                                 k.f.data(), k.C.data(), k.D.data(), k.d.data(), nullptr, nullptr, nullptr, nullptr, nullptr));
+    }
+    check(gar_hip_set_init(h, 0, p.G0.data(), p.g0.data()));
+    ph.pack = us_since(t);
+    t = clk::now();
+    check(gar_hip_backward(h, mu));
+    check(gar_hip_prefetch_gains(h, 0)); // (the binding's backward(): the gains start travelling under forward())
+    ph.backward = us_since(t);
+    t = clk::now();
+    check(gar_hip_forward(h, nullptr));
+    ph.forward = us_since(t);
+    t = clk::now();
+    check(gar_hip_fetch_results(h, 0, 1));
+    std::copy(base + offs[0], base + offs[0] + (int64_t)my_sol.size(), my_sol.begin());
+    ph.sol = us_since(t);
+    t = clk::now();
+    check(gar_hip_collapse_feedback(h));
+    ph.collapse = us_since(t);
+    t = clk::now();
+    check(gar_hip_fetch_results(h, 0, 2));
+    ph.gains = us_since(t);
+    t = clk::now();
+    std::copy(base + offs[1], base + offs[1] + (int64_t)my_gains.size(), my_gains.begin());
+    ph.consume = us_since(t);
+    ph.total = us_since(t0);
+    double km[3];
+    check(gar_hip_last_kernel_ms(h, km));
+    ph.dev_bwd = km[0], ph.dev_cond = km[1], ph.dev_fwd = km[2];
+    if (it >= 2 && ph.total < best.total)
+      best = ph;
+  }
+  best.h2d_bytes = 8.0 * (double)gar_hip_problem_doubles(h);
+  best.d2h_bytes = 8.0 * (double)(my_gains.size() + my_sol.size());
+  gar_hip_solver_destroy(h);
+  return best;
+}
+static void print_phases_json(const char *name, const SeamPhases &q, const std::string &kernel, int legs, bool last) {
+  std::printf("\"%s\": {\"kernel\": \"%s\", \"legs\": %d, \"us_per_newton_iteration\": %.1f, \"host_us\": {\"pack_into_pinned_staging\": %.1f, "
+              "\"backward_incl_h2d_tail_and_status_sync\": %.1f, \"forward\": %.1f, \"solution_d2h_and_scatter\": %.1f, "
+              "\"collapse_feedback\": %.1f, \"gains_gather_and_d2h\": %.1f, \"gains_consumed_by_caller\": %.1f}, "
+              "\"device_ms\": {\"backward_sweep\": %.4f, \"condensed_or_initial\": %.4f, \"forward_sweep\": %.4f}, "
+              "\"h2d_bytes\": %.0f, \"d2h_bytes\": %.0f}%s",
+              name, kernel.c_str(), legs, q.total, q.pack, q.backward, q.forward, q.sol, q.collapse, q.gains, q.consume, q.dev_bwd,
+              q.dev_cond, q.dev_fwd, q.h2d_bytes, q.d2h_bytes, last ? "" : ", ");
 }
 
 template <class Solver> static double time_loop(Solver &solver, LqrProblem &p, int iters, double mu, double *checksum) {
@@ -132,16 +225,35 @@ int main(int argc, char **argv) {
     std::printf("bench_lqr_loop: no HIP device (the backend has no CPU fallback)\n");
     return 77;
   }
-  const int N = argc > 1 ? std::atoi(argv[1]) : 256, iters = 20;
+  const bool json = argc > 1 && std::string(argv[1]) == "--json";
+  const int N = (!json && argc > 1) ? std::atoi(argv[1]) : 256, iters = 20;
   const double mu = 1e-10; // bench/lqr.cpp: mu_init = 1e-10
   struct Shape { int dim, nu; const char *what; };
   const Shape shapes[] = {{36, 12, "north star (36, 12)"}, {56, 22, "bench/lqr.cpp (56, 22)"}};
+  if (json) { // one JSON object: per shape, serial and N/8 legs, phase by phase
+    std::printf("{\"workload\": \"one Newton iteration of bench/lqr.cpp's ProxDDP loop through the RiccatiSolverBase seam "
+                "(upload of %d knots, backward, forward, collapseFeedback, every stage's gains), N=%d, one problem\", ", N + 1, N);
+    for (size_t i = 0; i < 2; ++i) {
+      const Shape &sh = shapes[i];
+      LqrProblem p = define_problem(N, sh.dim, sh.nu, 42), pp = define_problem(N, sh.dim, sh.nu, 42);
+      std::string k1, k2;
+      const SeamPhases a = time_phases(p, 1, iters, mu, &k1), b = time_phases(pp, N / 8, iters, mu, &k2);
+      std::printf("\"nx%d_nu%d\": {", sh.dim, sh.nu);
+      print_phases_json("serial", a, k1, 1, false);
+      print_phases_json("legs", b, k2, N / 8, true);
+      std::printf("}%s", i == 0 ? ", " : "");
+    }
+    std::printf("}\n");
+    return 0;
+  }
   for (const Shape &sh : shapes) {
     LqrProblem p = define_problem(N, sh.dim, sh.nu, 42);
+    double ora_us = 0.0;
+#ifndef SEAM_NO_ORACLE
     // the oracle, one thread (the reference's BM_lqr_prox<SERIAL> role)
     ora_problem *op = to_oracle(p);
     ora_prox_solver *os = ora_prox_new(op);
-    double ora_us = 1e30;
+    ora_us = 1e30;
     for (int it = 0; it < 5; ++it) {
       update_lq_subproblem(p, it);
       const auto t0 = clk::now();
@@ -153,6 +265,7 @@ int main(int argc, char **argv) {
     }
     ora_prox_free(os);
     ora_problem_free(op);
+#endif
     double cs = 0.0, cp = 0.0;
     {
       ProximalRiccatiSolver s(p);

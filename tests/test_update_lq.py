@@ -83,24 +83,40 @@ def emu_lib():
     return EMU
 
 
+@pytest.mark.parametrize("pad", ["0", "1"])
 @pytest.mark.parametrize("dims,nc0,batch,preg,exact", CASES)
-def test_update_lq_on_emulator(emu_lib, monkeypatch, dims, nc0, batch, preg, exact):
-    monkeypatch.setenv("GAR_HIP_PAD", "0")   # derivative records speak the device's dimensions: keep the caller's
+def test_update_lq_on_emulator(emu_lib, monkeypatch, dims, nc0, batch, preg, exact, pad):
+    # pad = 1: (4, 2) runs padded onto the (8, 4) family -- the derivative records keep the CALLER's dimensions, the
+    # kernel scatters into the padded knots and writes the dummy rows / columns (gar_update_lq_padded)
+    monkeypatch.setenv("GAR_HIP_PAD", pad)
     run_case(emu_lib, dims, nc0, batch, preg, exact, device=False)
 
 
-def test_update_lq_is_refused_on_a_padded_solver(emu_lib):
+# shapes the library pads inside the C ABI: BASELINE configs[0] (4, 2), configs[2] (12, 6), the Talos walk's (56, 22)
+PADDED = [([(4, 2, 0, 4, 0)] * 5 + [(4, 0, 0, 4, 0)], 4, 2, 1e-3, True, "<8,4>"),
+          ([(12, 6, 0, 12, 0)] * 4 + [(12, 0, 0, 12, 0)], 12, 2, 1e-6, True, "<12,8>"),
+          ([(10, 3, 0, 10, 0)] * 3 + [(10, 0, 0, 10, 0)], 7, 1, 0.0, False, "<12,4>"),
+          ([(56, 22, 0, 56, 0)] * 3 + [(56, 0, 0, 56, 0)], 56, 1, 1e-8, True, "pair<56,24>")]
+
+
+@pytest.mark.parametrize("dims,nc0,batch,preg,exact,family", PADDED)
+def test_update_lq_on_a_padded_solver(emu_lib, dims, nc0, batch, preg, exact, family):
     from aligator_amd.gar import BatchedRiccatiSolver
-    dims = CASES[0][0]
-    s = BatchedRiccatiSolver(dims, 4, batch=1, lib_path=emu_lib)
-    assert s.padded and s.kernel_name in ("mfma<8,4>", "wave<8,4>")
-    with pytest.raises(RuntimeError, match="padded"):
-        s.update_lq_subproblem_device(1, 0.0, False)
+    s = BatchedRiccatiSolver(dims, nc0, batch=1, lib_path=emu_lib)
+    assert s.padded and family in s.kernel_name, s.kernel_name
+    run_case(emu_lib, dims, nc0, batch, preg, exact, device=False)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims,nc0,batch,preg,exact",
-                         CASES + [([(36, 12, 0, 36, 0)] * 16 + [(36, 0, 0, 36, 0)], 36, 4, 1e-8, True)])
-def test_update_lq_on_gpu(monkeypatch, dims, nc0, batch, preg, exact):
+                         CASES + [([(36, 12, 0, 36, 0)] * 16 + [(36, 0, 0, 36, 0)], 36, 4, 1e-8, True)] +
+                         [c[:5] for c in PADDED] + [([(56, 22, 0, 56, 0)] * 32 + [(56, 0, 0, 56, 0)], 56, 3, 1e-8, True)])
+def test_update_lq_on_gpu(dims, nc0, batch, preg, exact):
+    run_case(None, dims, nc0, batch, preg, exact, device=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,nc0,batch,preg,exact", CASES)
+def test_update_lq_on_gpu_unpadded(monkeypatch, dims, nc0, batch, preg, exact):
     monkeypatch.setenv("GAR_HIP_PAD", "0")
     run_case(None, dims, nc0, batch, preg, exact, device=True)
