@@ -64,7 +64,10 @@ __global__ void __launch_bounds__(256) gar_fold_constraints(FoldParams P) {
     }
     dst[e] = v;
   }
-  int bad = 0;
+  // mu not strictly positive (or so small that C / mu overflows): the fold divides by it -- such a problem goes
+  // to the generic leg kernels like one with D != 0, whose Bunch-Kaufman meets the singular [Rhat 0; 0 -mu I] and
+  // reports the failed stage as the reference does (riccati-kernel.hxx:239-241)
+  int bad = (nc > 0 && !(mu >= 1e-290)) ? 1 : 0;
   for (int e = tid; e < nc * nu; e += 256)
     bad |= (src[ko.D + e] != 0.0);
   if (bad)

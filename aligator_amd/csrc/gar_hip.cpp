@@ -782,10 +782,30 @@ void choose_padding(gar_hip_solver *s) {
   s->nc0 = s->user_nc0 + (bx - nx); // the dummy states are pinned by extra rows of the initial constraint
 }
 
+int configure_padded_or_not(gar_hip_solver *s);
+
 // Everything that can be decided and validated WITHOUT touching device memory: padding, both layouts, the LDS
 // plan, leg-mode geometry, the kernel family.  create and cycle_append (on a trial object) share it.
 int configure(gar_hip_solver *s) {
   choose_padding(s);
+  for (;;) {
+    const int rc = configure_padded_or_not(s);
+    // Padded onto a specialised shape, but no kernel of that family binds (leg mode with a leg of fewer than two
+    // knots, GAR_HIP_SEG_LEGS=0, parameter LDS beyond a CU, ...): the any-dimension kernels would then sweep the
+    // PADDED shape -- several times the work and LDS of the caller's own, possibly beyond what fits.  Redo the
+    // configuration on the caller's dimensions.
+    if (s->padded && (rc != GAR_HIP_OK || !(s->wave_kernel || s->mfma_kernel || s->leg_bwd_kernel || s->seg_bwd_kernel))) {
+      s->dims5 = s->user_dims5;
+      s->nc0 = s->user_nc0;
+      s->padded = false;
+      s->unx = s->unu = s->pnx = s->pnu = 0;
+      continue;
+    }
+    return rc;
+  }
+}
+
+int configure_padded_or_not(gar_hip_solver *s) {
   if (int rc = build_layout(s))
     return rc;
   if (int rc = plan_lds(s))
@@ -1551,6 +1571,9 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(gar_dev_malloc((void **)&s->d_csol, sizeof(double) * (size_t)nblk * s->nxb * B));
     s->cscratch_doubles = (int64_t)(4 * nblk * bs + 4 * (size_t)nblk * s->nxb + 4);
     HIP_TRY(gar_dev_malloc((void **)&s->d_cscratch, sizeof(double) * (size_t)s->cscratch_doubles * B));
+    // (the info slots behind the blocks -- residual, steps, scale, resolved -- are read by the gar_hip_condensed_*
+    // getters: defined before the first solve)
+    HIP_TRY(hipMemset(s->d_cscratch, 0, sizeof(double) * (size_t)s->cscratch_doubles * B));
     s->cond_lds_doubles = (int)(3 * bs + 4 * s->nxb + 2 + (s->nxb + 16) / 2 + 2 + (s->nxb < 9 ? 9 * s->nxb : 0));
     {
       const char *cr = std::getenv("GAR_HIP_CONDENSED_REDUCED");

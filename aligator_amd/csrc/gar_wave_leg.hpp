@@ -669,12 +669,19 @@ __global__ void __launch_bounds__(64, 1) gar_condensed_wave(CondensedParams P) {
   const int b = (int)blockIdx.x;
   const int nblk = 2 * P.num_legs, N = nblk - 1;
   if (P.gated) { // the cyclic-reduction solve of this problem met the residual threshold?
-    const double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * NX * NX + 4ll * nblk * NX;
+    double *inf = P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * NX * NX + 4ll * nblk * NX;
     // (refinement disabled: the cyclic-reduction result stands -- unless a block inverse failed
     // outright, which poisons the residual with +inf)
     if (inf[0] <= P.threshold || (P.max_refinement == 0 && inf[0] <= 1.79e308) ||
-        (inf[0] <= 1.79e308 && inf[0] <= P.backward_ok * inf[2])) // (see gar_cyclic_recover)
+        (inf[0] <= 1.79e308 && inf[0] <= P.backward_ok * inf[2])) { // (see gar_cyclic_recover)
+      if (lane == 0)
+        inf[3] = 0.0; // the cyclic-reduction result stands (gar_hip_condensed_resolved)
       return;
+    }
+    if (lane == 0)
+      inf[3] = 1.0; // re-solved here, in the reference's order
+  } else if (lane == 0) {
+    (P.scratch + (long long)b * P.scratch_stride + 4ll * nblk * NX * NX + 4ll * nblk * NX)[3] = 0.0;
   }
   const WG w1 = wave_self();
   double *sm = gar_smem;

@@ -411,6 +411,107 @@ def horizon_single_process(args, N=2048, legs=256, reps=10):
     return out
 
 
+def batch_scan(args, device, stream, N, nx, nu, mueq, main_batch, main_value, reps=5):
+    """the headline workload at Bsz in {1, 256, 1024} (and `--batch`, the timed region itself): sweeps/s
+    of the serial-in-time solver (num_legs = 1, what `value` is quoted on) and, for ONE problem, of the
+    parallel-in-time solver with N/8 legs -- the configuration a caller with a single problem would pick."""
+    dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
+    out = {}
+    for B in (1, 256, 1024):
+        if B >= main_batch:
+            continue
+        row = {}
+        for legs in ((1, max(2, N // 8)) if B == 1 else (1,)):
+            s = BatchedRiccatiSolver(dims, nx, batch=B, num_legs=legs, device=device)
+            s.set_stream(stream.cuda_stream)
+            synth_device.fill_problems(s, seed=777, mode=args.generator, keep=())
+            for _ in range(2):
+                s.backward_async(mueq)
+                s.forward_async()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                s.backward_async(mueq)
+                s.forward_async()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            key = "serial" if legs == 1 else f"legs{legs}"
+            row[key] = {"sweeps_per_s": B / dt, "ms_per_step": dt * 1e3, "kernel": s.kernel_name}
+            s.close()
+        out[str(B)] = row
+    out[str(main_batch)] = {"serial": {"sweeps_per_s": main_value, "note": "the timed region of this line"}}
+    return out
+
+
+def config3(args, device, stream, reps=10):
+    """BASELINE.json configs[2] / SURVEY 8(d) "Config 3": ONE problem, N = 1024, nx = 12, nu = 6 (padded inside the C
+    ABI onto the (12, 8) family), ParallelRiccatiSolver semantics with legs in {2, ..., 64}, mu = 1e-9, up to 10
+    refinement steps (tests/gar/parallel.cpp:185-245), beside the serial-in-time solver; every configuration's
+    solution against the serial ORACLE's (relative to the largest multiplier) and the reference's residual
+    lqrComputeKktError, the reference's bar being 1e-7 (parallel.cpp:221, 234-235)."""
+    from aligator_amd import synth
+    from aligator_amd.gar import lqrComputeKktError
+    from oracle import oracle as ora
+    N, nx, nu, mueq = 1024, 12, 6, 1e-9
+    prob = synth.generate_lq_problem(33, np.zeros(nx), N, nx, nu, mode="W")
+    dims = [k.dims for k in prob.stages]
+    osol = ora.ProximalRiccatiSolver(ora.Problem.from_knots(prob.stages, prob.G0, prob.g0))
+    osol.backward(mueq)
+    from aligator_amd.gar import lqrInitializeSolution
+    ref = lqrInitializeSolution(prob)
+    osol.forward(*ref)
+    scale = max(1.0, max(float(np.abs(v).max()) for part in ref for v in part if v.size))
+    out = {"workload": f"one problem, N={N} nx={nx} nu={nu} fp64, mu={mueq} (BASELINE.json configs[2])", "legs": {}}
+    for legs in (1, 2, 4, 8, 16, 32, 64):
+        s = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=legs, device=device)
+        s.set_stream(stream.cuda_stream)
+        if legs > 1:
+            s.set_refinement(1e-10, 10)
+        s.upload([prob])
+        for _ in range(2):
+            s.backward_async(mueq)
+            s.forward_async()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s.backward_async(mueq)
+            s.forward_async()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        sol = s.solution(0)
+        err = max(float(np.abs(a - b).max()) for A, B in zip(sol, ref) for a, b in zip(A, B) if a.size) / scale
+        kkt = max(lqrComputeKktError(prob, *sol, mueq=mueq)) / scale
+        row = {"ms_per_sweep": ms, "kernel": s.kernel_name, "max_rel_err_vs_serial_oracle": err, "max_kkt_rel": kkt,
+               "failed_factorisations": s.num_failed()}
+        if legs > 1:
+            resid, steps = s.condensed_info(0)
+            row.update({"condensed_solver": s.condensed_solver_name, "condensed_residual": resid, "refinement_steps": steps})
+            out["legs"][str(legs)] = row
+        else:
+            out["serial"] = row
+        s.close()
+    best = min(out["legs"], key=lambda k: out["legs"][k]["ms_per_sweep"])
+    out["best_legs"] = int(best)
+    out["speedup_vs_serial"] = out["serial"]["ms_per_sweep"] / out["legs"][best]["ms_per_sweep"]
+    return out
+
+
+def seam():
+    """One Newton iteration of bench/lqr.cpp's ProxDDP loop through the RiccatiSolverBase seam, phase by phase --
+    tests/cpp/bench_lqr_loop.cpp built without its oracle leg (tests/cpp/_build/seam_bench, made by
+    __graft_entry__.build()): the call sequence of include/aligator/gar/hip-riccati.hpp over the C ABI, (36, 12) and
+    bench/lqr.cpp's / the Talos walk's (56, 22), N = 256, serial and N/8 legs.  None when the binary is absent."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "seam_bench")
+    if not os.path.exists(exe):
+        return {"skipped": "tests/cpp/_build/seam_bench not built"}
+    try:
+        r = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=240)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001  (a secondary figure must not take the line down)
+        return {"skipped": f"{type(e).__name__}: {e}"}
+
+
 def secondary_shapes(device, batch=1024):
     """Two more shapes of the same hot path, outside the timed region (rank 0, one GPU), so that the round's
     bench record carries them: the reference's OWN gar benchmark shape (bench/gar-riccati.cpp:19-22: nx=36,
@@ -784,6 +885,9 @@ def main():
             out["horizon_sharded"] = hs
         if world == 1 and not args.no_extras:
             out["secondary_shapes"] = secondary_shapes(local_rank)
+            out["batch_scan"] = batch_scan(args, local_rank, stream, N, nx, nu, mueq, args.batch, sweeps / elapsed)
+            out["config3"] = config3(args, local_rank, stream)
+            out["seam"] = seam()
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, nx, nu, N, mueq)
         print(json.dumps(out))

@@ -769,3 +769,51 @@ def test_generic_constrained_stage_on_the_blocked_bunch_kaufman(monkeypatch, nx,
     else:
         par = pc.check_parallel(prob, 1e-6, legs, 1e-8, EMU, conditioned=True)
         assert par._impl.kernel_name == "generic"
+
+
+@pytest.mark.parametrize("condensed", ["cyclic", "chain"])
+def test_condensed_resolved_is_defined_on_the_specialised_leg_families(monkeypatch, condensed):
+    """gar_hip_condensed_resolved on a wave_leg family: the gated wave-scope chain behind block cyclic
+    reduction writes the flag -- 0 when the fast result stood (also before any solve: the scratch is zeroed at
+    allocation), 1 when an unreachable threshold with the backward-error gate off forces the re-solve in the
+    reference's order -- and the re-solved result equals the fast one."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    if condensed == "chain":
+        monkeypatch.setenv("GAR_HIP_CONDENSED", "chain")
+    nx, nu, horz, legs = 8, 4, 13, 3
+    prob = synth.generate_lq_problem(11, np.zeros(nx), horz, nx, nu, mode="W")
+    s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=2, num_legs=legs, lib_path=EMU)
+    assert s.kernel_name == "wave_leg<8,4>" and s.condensed_solver_name == condensed
+    assert not s.condensed_resolved(0) and not s.condensed_resolved(1)   # defined before the first solve
+    s.upload([prob, prob])
+    assert s.backward(1e-10) and s.forward()
+    fast = s.solution(1)
+    assert not s.condensed_resolved(0) and not s.condensed_resolved(1)
+    if condensed == "cyclic":
+        s.set_refinement(1e-300, 2, backward_ok=0.0)
+        assert s.backward(1e-10) and s.forward()
+        assert s.condensed_resolved(0) and s.condensed_resolved(1)
+        again = s.solution(1)
+        sc = max(1.0, max(float(np.abs(v).max()) for v in again[3]))
+        assert max(float(np.abs(a - b).max()) for A, B in zip(again, fast) for a, b in zip(A, B) if a.size) <= 1e-10 * sc
+
+
+def test_padding_is_dropped_when_no_specialised_kernel_binds(monkeypatch):
+    """a leg-mode problem whose (nx, nu) would be padded onto a specialised shape but whose legs the
+    specialised leg kernels do not serve (a leg of one knot) must run the any-dimension kernels on ITS OWN
+    dimensions, not on the padded ones."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    nx, nu, horz, legs = 10, 3, 5, 4                      # 6 knots over 4 legs: legs of one knot
+    dims = [(nx, nu, 0, nx, 0)] * horz + [(nx, 0, 0, nx, 0)]
+    s = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=legs, lib_path=EMU)
+    assert s.kernel_name == "generic" and not s.padded and tuple(s.device_dims[0][:2]) == (nx, nu)
+    s.close()
+    serial = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=1, lib_path=EMU)
+    assert serial.padded and "<12,4>" in serial.kernel_name   # the serial solver of the same shape IS padded
+    serial.close()
+    longer = BatchedRiccatiSolver([(nx, nu, 0, nx, 0)] * 11 + [(nx, 0, 0, nx, 0)], nx, batch=1, num_legs=3, lib_path=EMU)
+    assert longer.padded and longer.kernel_name == "wave_leg<12,4>"
+    longer.close()
+    rng = np.random.default_rng(8)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+    pc.check_parallel(prob, 1e-10, legs, 1e-8, EMU)
