@@ -16,6 +16,9 @@
 
 namespace gar {
 
+// the ONE dynamic-LDS region of every kernel (each translation unit declares it; its size is the launch's)
+extern __shared__ double gar_smem[];
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // strided view: element (i,j) at p[i*rs + j*cs]

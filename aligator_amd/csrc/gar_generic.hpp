@@ -63,7 +63,7 @@ struct GenericParams {
   int vxx_packed;  // the factor records keep the lower triangle of Vxx, packed (gar_layout.h: gar_sym_index)
 };
 
-extern __shared__ double gar_smem[];
+// (gar_smem, the one dynamic-LDS region: declared in gar_device.hpp)
 
 
 // ---------------------------------------------------------------------------
@@ -602,6 +602,7 @@ struct UpdateParams {
   long long d_G0, d_g0, d_iH;
   int horizon, nc0, nx0, hess_exact;
   double preg;
+  int qr_packed; // knots t < horizon keep Q and R as packed lower triangles (gar_layout.h)
 };
 
 __global__ void __launch_bounds__(256) gar_update_lq(UpdateParams P) {
@@ -615,6 +616,7 @@ __global__ void __launch_bounds__(256) gar_update_lq(UpdateParams P) {
   double *k = P.prob + (long long)b * P.prob_stride + m.in_off;
   const bool term = (t == P.horizon);
   const bool exact = P.hess_exact && !term;
+  const bool pk = P.qr_packed && !term;
   for (int e = tid; e < nx * nx; e += 256) { // Q (:763, :768, :773, :804)
     const int j = e / nx, i = e - j * nx;
     double v = d[ko.Q + e];
@@ -624,7 +626,10 @@ __global__ void __launch_bounds__(256) gar_update_lq(UpdateParams P) {
       v += d[dof.Hxx + e];
     if (t == 0)
       v += dv[P.d_iH + e];
-    k[ko.Q + e] = v;
+    if (!pk)
+      k[ko.Q + e] = v;
+    else if (i >= j)
+      k[ko.Q + gar_lower_index(nx, i, j)] = v;
   }
   for (int e = tid; e < nx; e += 256) // q (:766, :783)
     k[ko.q + e] = d[ko.q + e] + d[dof.lxc + e];
@@ -642,7 +647,10 @@ __global__ void __launch_bounds__(256) gar_update_lq(UpdateParams P) {
         v += P.preg;
       if (exact)
         v += d[dof.Huu + e];
-      k[ko.R + e] = v;
+      if (!pk)
+        k[ko.R + e] = v;
+      else if (i >= j)
+        k[ko.R + gar_lower_index(nu, i, j)] = v;
     }
     for (int e = tid; e < nu; e += 256) // r (:767, :784)
       k[ko.r + e] = d[ko.r + e] + d[dof.luc + e];
@@ -678,6 +686,7 @@ __global__ void __launch_bounds__(256) gar_update_lq_padded(UpdateParams P, int 
   const double *d = dv + P.deriv_off[t];
   double *k = P.prob + (long long)b * P.prob_stride + m.in_off;
   const bool exact = P.hess_exact && !term;
+  const bool pk = P.qr_packed && !term;
   for (int e = tid; e < NX * NX; e += 256) { // Q
     const int j = e / NX, i = e - j * NX;
     double v = i == j ? 1.0 : 0.0;
@@ -691,7 +700,10 @@ __global__ void __launch_bounds__(256) gar_update_lq_padded(UpdateParams P, int 
       if (t == 0)
         v += dv[P.d_iH + s];
     }
-    k[KO.Q + e] = v;
+    if (!pk)
+      k[KO.Q + e] = v;
+    else if (i >= j)
+      k[KO.Q + gar_lower_index(NX, i, j)] = v;
   }
   for (int e = tid; e < NX; e += 256) // q
     k[KO.q + e] = e < unx ? d[ko.q + e] + d[dof.lxc + e] : 0.0;
@@ -716,7 +728,10 @@ __global__ void __launch_bounds__(256) gar_update_lq_padded(UpdateParams P, int 
         if (exact)
           v += d[dof.Huu + s];
       }
-      k[KO.R + e] = v;
+      if (!pk)
+        k[KO.R + e] = v;
+      else if (i >= j)
+        k[KO.R + gar_lower_index(NU, i, j)] = v;
     }
     for (int e = tid; e < NU; e += 256) // r
       k[KO.r + e] = e < nu ? d[ko.r + e] + d[dof.luc + e] : 0.0;
@@ -1557,13 +1572,14 @@ __global__ void gar_collapse_feedback(const gar_stage_meta *meta, double *fac,
 // One workgroup; Vn == nullptr: no value-function term (terminal knot, last knot of a leg).
 __global__ void __launch_bounds__(256) gar_kkt_matrix(const double *knot, gar_knot_offsets ko, const double *Vn,
                                                       int nx2, int nu, int nc, double mueq, double *out,
-                                                      int vn_packed) {
+                                                      int vn_packed, int r_packed) {
   const int nk = nu + nc;
   for (int e = (int)threadIdx.x; e < nk * nk; e += (int)blockDim.x) {
     const int j = e / nk, i = e - j * nk;
     double v;
     if (i < nu && j < nu) {
-      v = knot[ko.R + j * nu + i];
+      // (r_packed: the knot keeps R as its packed lower triangle, gar_layout.h)
+      v = r_packed ? knot[ko.R + gar_lower_index(nu, i >= j ? i : j, i >= j ? j : i)] : knot[ko.R + j * nu + i];
       if (Vn != nullptr) {
         double acc = 0.0;
         for (int l = 0; l < nx2; ++l) {

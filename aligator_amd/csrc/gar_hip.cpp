@@ -31,6 +31,12 @@
 #include "gar_fold.hpp"
 #include "gar_leg_seg.hpp"
 
+namespace gar { // instantiated in gar_wave_sweep.cpp (its own translation unit, its own code-generation flags)
+#define GAR_SWEEP_EXTERN(NX, NU) extern template __global__ void gar_backward_wave<NX, NU, 0>(MfmaParams, int);
+GAR_SWEEP_SHAPES(GAR_SWEEP_EXTERN)
+#undef GAR_SWEEP_EXTERN
+} // namespace gar
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -223,6 +229,7 @@ struct gar_hip_solver {
   int wave_block_threads = 64; // 128: two waves per problem (gar_wave_pair.hpp)
   bool fb_t2 = false;      // factor records keep fb / fth in the fbT2 device order (gar_mfma.hpp)
   bool vxx_packed = false; // ... and the lower triangle of Vxx, packed (gar_layout.h: the serial one-wave family)
+  bool qr_packed = false;  // knots t < N keep Q and R as packed lower triangles (gar_layout.h: the headline sweep)
   std::string lds_error;   // the generic kernels do not fit a CU's LDS (fatal unless a specialised family serves the shape)
   bool wave_fused_init = false;
   bool init_closed = true; // closed-form initial stage when G0 = +-I (GAR_HIP_INIT=bk: always factorise)
@@ -533,6 +540,7 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
     s->wave_lds_doubles = s->wave_fused_init ? with_init : gar::WaveCfg<NX, NU>::total;
     s->waves_per_block = 1; // one 64-thread workgroup per problem (constant LDS base)
     s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
+    s->qr_packed = GAR_QR_PACKED != 0; // the sweep reads only the lower triangles of Q and R (gar_layout.h)
   }
 }
 
@@ -679,6 +687,7 @@ void select_kernel(gar_hip_solver *s) {
   s->wave_block_threads = 64;
   s->fb_t2 = false;
   s->vxx_packed = false;
+  s->qr_packed = false;
   {
     const char *ik = std::getenv("GAR_HIP_INIT");
     s->init_closed = !(ik && std::string(ik) == "bk");
@@ -1003,6 +1012,24 @@ inline void stage_copy(double *dst, const double *src, size_t n, bool nt) {
   }
 #endif
   std::memcpy(dst, src, sizeof(double) * n);
+}
+
+// Lower triangle of an r x r column-major block `src` (null: zeros), packed (gar_layout.h: gar_lower_index) as
+// the lower triangle of an R x R block, R >= r, with `diag` on the diagonal beyond r: `dst` gets R (R + 1) / 2 doubles
+inline void pack_lower(double *dst, const double *src, int r, int R, double diag) {
+  for (int j = 0; j < R; ++j) {
+    double *col = dst + gar_lower_index(R, j, j);
+    const int n = R - j;
+    if (j < r && src) {
+      std::memcpy(col, src + (size_t)j * r + j, sizeof(double) * (size_t)(r - j));
+      if (R > r)
+        std::memset(col + (r - j), 0, sizeof(double) * (size_t)(R - r));
+    } else {
+      std::memset(col, 0, sizeof(double) * (size_t)n);
+      if (j >= r)
+        col[0] = diag;
+    }
+  }
 }
 
 // pipeline the upload: once the range being appended to has grown past 1 MiB it goes out
@@ -1708,6 +1735,13 @@ const double *padded_block(std::vector<double> &buf, const double *src, int r, i
       buf[(size_t)i * R + i] = diag;
   return buf.data();
 }
+// the leading r x r part of a symmetric R x R block stored as its packed lower triangle (gar_layout.h), as a full
+// column-major r x r block (both triangles)
+void unpack_lower(double *dst, const double *src, int r, int R) {
+  for (int j = 0; j < r; ++j)
+    for (int i = j; i < r; ++i)
+      dst[(size_t)j * r + i] = dst[(size_t)i * r + j] = src[gar_lower_index(R, i, j)];
+}
 // rows [0, unu) and [NU, NU + unx) of a gain block with NU + NX (+...) rows: the real controls and states
 inline int gain_row(const gar_hip_solver *s, int r, int nu_dev) {
   const int unu = nu_dev > 0 ? s->unu : 0;
@@ -2035,9 +2069,19 @@ static int upload_stage_dev(gar_hip_solver *s, int b, int t, const double *Q, co
   if (!Q || !q || !A || !f || (nu > 0 && (!S || !R || !r || !B)))
     return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_stage: null block");
   int rc = 0;
-  rc |= write_block(s, b, base + o.Q, Q, (int64_t)nx * nx);
+  if (s->qr_packed && t < s->horizon) { // Q, R: their lower triangles, packed, in the first n (n + 1) / 2 doubles of the block
+    thread_local std::vector<double> pq, pr;
+    pq.resize((size_t)nx * (nx + 1) / 2);
+    pr.resize((size_t)nu * (nu + 1) / 2);
+    pack_lower(pq.data(), Q, nx, nx, 0.0);
+    pack_lower(pr.data(), R, nu, nu, 0.0);
+    rc |= write_block(s, b, base + o.Q, pq.data(), (int64_t)pq.size());
+    rc |= write_block(s, b, base + o.R, pr.data(), (int64_t)pr.size());
+  } else {
+    rc |= write_block(s, b, base + o.Q, Q, (int64_t)nx * nx);
+    rc |= write_block(s, b, base + o.R, R, (int64_t)nu * nu);
+  }
   rc |= write_block(s, b, base + o.S, S, (int64_t)nx * nu);
-  rc |= write_block(s, b, base + o.R, R, (int64_t)nu * nu);
   rc |= write_block(s, b, base + o.q, q, nx);
   rc |= write_block(s, b, base + o.r, r, nu);
   rc |= write_block(s, b, base + o.A, A, (int64_t)nx2 * nx);
@@ -2069,8 +2113,8 @@ int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packe
   GAR_MULTI(s, multi_upload_packed(s, b0, nb, packed));
   if (!s || !packed || b0 < 0 || nb < 0 || b0 + nb > s->batch)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_packed: bad argument");
-  if (s->padded) { // the caller's records: knot by knot through the padding path
-    const gar_hip_solver *u = s->ulay;
+  if (s->padded || s->qr_packed) { // the caller's records: knot by knot through the padding / packing path
+    const gar_hip_solver *u = s->ulay ? s->ulay : s;
     for (int b = b0; b < b0 + nb; ++b) {
       const double *rec = packed + (int64_t)(b - b0) * u->prob_doubles;
       for (int t = 0; t <= s->horizon; ++t) {
@@ -2577,7 +2621,7 @@ static int get_kkt_dev(gar_hip_solver *s, int b, int t, double mueq, double *out
     Vn = s->d_fac + (int64_t)b * s->fac_doubles + mn.fac_off + fn.Vxx;
   }
   hipLaunchKernelGGL(gar::gar_kkt_matrix, dim3(1), dim3(256), 0, s->stream, knot, ko, Vn, m.nx2, m.nu, m.nc, mueq,
-                     s->d_kkt, s->vxx_packed ? 1 : 0);
+                     s->d_kkt, s->vxx_packed ? 1 : 0, (s->qr_packed && t < s->horizon) ? 1 : 0);
   HIP_TRY(hipGetLastError());
   if (int rc = d2h(s, out, s->d_kkt, (int64_t)nk * nk))
     return rc;
@@ -2663,6 +2707,7 @@ int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_d
   U.nx0 = s->nx0;
   U.hess_exact = hess_exact;
   U.preg = preg;
+  U.qr_packed = s->qr_packed ? 1 : 0;
   const dim3 grid((unsigned)(s->horizon + 1), (unsigned)s->batch);
   if (s->padded) // the caller's records scattered into the padded knots, dummy rows / columns written (gar_generic.hpp)
     hipLaunchKernelGGL(gar::gar_update_lq_padded, grid, dim3(256), 0, s->stream, U, s->unx, s->unu, s->user_nc0);
@@ -2699,9 +2744,14 @@ int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed) {
         const gar_knot_offsets o = gar_knot_layout(m.nx, m.nu, 0, m.nx2, 0), O = gar_knot_layout(M.nx, M.nu, 0, M.nx2, 0);
         double *k = rec + m.in_off;
         const double *K = dev.data() + M.in_off;
-        take(k + o.Q, K + O.Q, m.nx, m.nx, M.nx);
+        if (s->qr_packed && t < s->horizon) {
+          unpack_lower(k + o.Q, K + O.Q, m.nx, M.nx);
+          unpack_lower(k + o.R, K + O.R, m.nu, M.nu);
+        } else {
+          take(k + o.Q, K + O.Q, m.nx, m.nx, M.nx);
+          take(k + o.R, K + O.R, m.nu, m.nu, M.nu);
+        }
         take(k + o.S, K + O.S, m.nx, m.nu, M.nx);
-        take(k + o.R, K + O.R, m.nu, m.nu, M.nu);
         take(k + o.q, K + O.q, m.nx, 1, M.nx);
         take(k + o.r, K + O.r, m.nu, 1, M.nu);
         take(k + o.A, K + O.A, m.nx2, m.nx, M.nx2);
@@ -2715,6 +2765,19 @@ int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed) {
                          sizeof(double) * (size_t)s->prob_doubles * nb, hipMemcpyDeviceToHost,
                          s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->qr_packed) { // the device keeps the lower triangles of Q and R, packed: the full symmetric blocks back
+    std::vector<double> tmp;
+    for (int k = 0; k < nb; ++k)
+      for (int t = 0; t < s->horizon; ++t) {
+        const gar_stage_meta &m = s->meta[t];
+        const gar_knot_offsets o = gar_knot_layout(m.nx, m.nu, m.nc, m.nx2, 0);
+        double *rec = packed + (int64_t)k * s->prob_doubles + m.in_off;
+        for (const auto &blk : {std::make_pair(o.Q, m.nx), std::make_pair(o.R, m.nu)}) {
+          tmp.assign(rec + blk.first, rec + blk.first + (size_t)blk.second * (blk.second + 1) / 2);
+          unpack_lower(rec + blk.first, tmp.data(), blk.second, blk.second);
+        }
+      }
+  }
   return GAR_HIP_OK;
 }
 
@@ -2896,9 +2959,14 @@ int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const
         for (int i = std::min(r, c); i < std::min(R, C); ++i)
           dst[(size_t)i * R + i] = diag;
     };
-    put(o.Q, Q, nx, nx, NX, NX, 1.0);
+    if (s->qr_packed && t < s->horizon) {
+      pack_lower(rec + o.Q, Q, nx, NX, 1.0);
+      pack_lower(rec + o.R, R, nu, NU, 1.0);
+    } else {
+      put(o.Q, Q, nx, nx, NX, NX, 1.0);
+      put(o.R, R, nu, nu, NU, NU, 1.0);
+    }
     put(o.S, S, nx, nu, NX, NU, 0.0);
-    put(o.R, R, nu, nu, NU, NU, 1.0);
     put(o.q, q, nx, 1, NX, 1, 0.0);
     put(o.r, r, nu, 1, NU, 1, 0.0);
     put(o.A, A, nx, nx, NX, NX, 0.0);
@@ -3158,7 +3226,7 @@ int gar_hip_device_sizes(const gar_hip_solver *s, int64_t out[8]) {
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
   out[0] = s->prob_doubles; out[1] = s->fac_doubles; out[2] = s->sol_doubles; out[3] = s->nc0;
-  out[4] = s->G0_off; out[5] = s->g0_off; out[6] = s->padded ? 1 : 0; out[7] = s->init_doubles;
+  out[4] = s->G0_off; out[5] = s->g0_off; out[6] = (s->padded ? 1 : 0) | (s->qr_packed ? 2 : 0); out[7] = s->init_doubles;
   return GAR_HIP_OK;
 }
 

@@ -117,6 +117,22 @@ GAR_HD static inline int gar_sym_index(int packed, int n, int i, int j) {
 }
 GAR_HD static inline int gar_sym_packed_doubles(int n) { return n * (n + 1) / 2; }
 
+// The input side of the same idea (round 4): the headline one-wave-per-problem sweep gar_backward_wave<NX, NU>
+// (unconstrained, serial in time, batch > CUs) only ever uses the LOWER triangle of Q and R -- Vxx is symmetrised
+// from its lower triangle by the consuming stage (riccati-kernel.hxx:216), the reduced KKT matrix from its own
+// (:232), so the upper triangles of Q-hat and R-hat are never formed.  Its knot records keep Q and R as their
+// lower triangles in LAPACK "L" packed order (column after column, column j holding rows j .. n-1) in the FIRST
+// n (n + 1) / 2 doubles of the Q / R block; the rest of the block is not touched, offsets and record pitch are
+// unchanged.  The sweep reads 23.9 KB instead of 29.5 KB per knot at (36, 12).  The terminal knot stays full.
+// gar_hip_upload_stage / gar_hip_upload_packed / gar_hip_update_lq_subproblem_device pack, gar_hip_download_packed
+// and gar_hip_get_kkt unpack; gar_hip_device_sizes reports the format to device-resident producers.
+// (-DGAR_QR_PACKED=0: full blocks everywhere, the A/B of scripts/ab_vxx_packed.py)
+#ifndef GAR_QR_PACKED
+#define GAR_QR_PACKED 1
+#endif
+//   element (i, j), i >= j, of an n x n block
+GAR_HD static inline int gar_lower_index(int n, int i, int j) { return i + ((2 * n - j - 1) * j) / 2; }
+
 // offsets inside a factor record
 typedef struct gar_factor_offsets {
   int32_t ff, fb, fth, Vxx, vx, Vxt, Vtt, vt, total;

@@ -153,6 +153,7 @@ template <int NX, int NU, int NC = 0> struct WaveLane {
   // element (16ti+lk+4r, 16tj+li) of [Q S;S^T R] at its NATURAL position (no mirroring:
   // the strictly-upper part of a diagonal tile only feeds results that are never used)
   unsigned hcx0, hcxX[C::TW];    // rows < NX: Q[lk][li] ; column tiles reaching past NX
+  unsigned hcq[C::TW];           // QP (Q, R as packed lower triangles, gar_layout.h): rows < NX of column tile tj
   unsigned hcu0, hcuX[C::TW][C::KU]; // rows NX+4s'+lk: S^T[lk][li] ; tiles reaching past NX
   unsigned bop0, bopX;           // B[li][lk] ; overhanging last row tile
   unsigned bop4;                 // B[NX-4+(lane&3)][lane>>4]: A operand of the 4x4x4 blocks
@@ -162,7 +163,11 @@ template <int NX, int NU, int NC = 0> struct WaveLane {
   __host__ __device__ static constexpr bool x_in(int t) { return 16 * t + 15 < NX; }
 };
 
-template <int NX, int NU, int NC>
+// QP: the knot records keep Q and R as packed lower triangles (gar_layout.h: gar_lower_index).  Element (i, j) sits
+// at i + g(j), g(j) = (2n - j - 1) j / 2: one lane offset per column tile, the row goes to the immediate.  The
+// strictly-upper lanes of a diagonal tile then read some other element of the block -- they only feed results that
+// are never used, as with the full blocks.
+template <int NX, int NU, int NC, bool QP = false>
 __device__ __forceinline__ void wave_lane_init(WaveLane<NX, NU, NC> &L, int lane) {
   using C = WaveCfg<NX, NU, NC>;
   using M = MfmaCfg<NX, NU, NC>;
@@ -179,11 +184,14 @@ __device__ __forceinline__ void wave_lane_init(WaveLane<NX, NU, NC> &L, int lane
     const int col = (16 * tj + li) < C::NW ? (16 * tj + li) : C::NW - 1;
     // x rows (row = lk + const): Q(row, col) = kQ + col*NX + row ; S(row, col-NX) = kS + (col-NX)*NX + row
     L.hcxX[tj] = 8u * (unsigned)((col < NX ? M::kQ + col * NX : M::kS + (col - NX) * NX) + lk);
+    L.hcq[tj] = 8u * (unsigned)((col < NX ? M::kQ + ((2 * NX - col - 1) * col) / 2 : M::kS + (col - NX) * NX) + lk);
     // u rows (row = NX + u, u = 4s' + lk): S^T(u, col) = kS + u*NX + col ; R(u, col-NX) = kR + (col-NX)*NU + u
 #pragma unroll
     for (int sp = 0; sp < C::KU; ++sp) {
       const int u = 4 * sp + lk;
-      L.hcuX[tj][sp] = 8u * (unsigned)(col < NX ? M::kS + u * NX + col : M::kR + (col - NX) * NU + u);
+      L.hcuX[tj][sp] = 8u * (unsigned)(col < NX ? M::kS + u * NX + col
+                                                  : (QP ? M::kR + ((2 * NU - (col - NX) - 1) * (col - NX)) / 2 + u
+                                                        : M::kR + (col - NX) * NU + u));
     }
   }
   L.bop0 = 8u * (unsigned)(M::kB + lk * NX + li);
@@ -217,7 +225,7 @@ __device__ __forceinline__ void wave_load_a(const double *rec, const LANE &L, Wa
   S.qri = ldg_b(rec, 0, L.qri);
 }
 // part B: the Hessian tiles (first needed by H's accumulation) and B as the A operand of Aff
-template <int NX, int NU, class LANE>
+template <int NX, int NU, class LANE, bool QP = false>
 __device__ __forceinline__ void wave_load_b(const double *rec, const LANE &L, WaveStage<NX, NU> &S) {
   using C = WaveCfg<NX, NU>;
 #pragma unroll
@@ -228,8 +236,9 @@ __device__ __forceinline__ void wave_load_b(const double *rec, const LANE &L, Wa
       for (int r = 0; r < 4; ++r) {
         const int row0 = 16 * ti + 4 * r; // + lk
         if (row0 + 3 < NX)
-          S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, 16 * tj * NX + row0, L.hcx0)
-                                                       : ldg_b(rec, row0, L.hcxX[tj]);
+          S.Hc[ti][tj][r] = QP ? ldg_b(rec, row0, L.hcq[tj])
+                               : (WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, 16 * tj * NX + row0, L.hcx0)
+                                                             : ldg_b(rec, row0, L.hcxX[tj]));
         else if (row0 >= NX && row0 + 3 < C::NW)
           S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj)
                                 ? ldg_b(rec, (row0 - NX) * NX + 16 * tj, L.hcu0)
@@ -1242,12 +1251,14 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
     if (tstart < 0)
       return;
   }
+  // Q, R of the knots as packed lower triangles (gar_layout.h): the plain unconstrained one-wave sweep
+  constexpr bool QP = GAR_QR_PACKED && NC == 0 && !M::WIDE;
   WaveLane<NX, NU, NC> L;
-  wave_lane_init<NX, NU>(L, lane);
+  wave_lane_init<NX, NU, NC, QP>(L, lane);
   WaveStage<NX, NU> S;
   if (N > 0) {
     wave_load_a<NX, NU>(prob + P.in_off0 + P.slot(tstart) * P.in_rec, L, S);
-    wave_load_b<NX, NU>(prob + P.in_off0 + P.slot(tstart) * P.in_rec, L, S);
+    wave_load_b<NX, NU, WaveLane<NX, NU, NC>, QP>(prob + P.in_off0 + P.slot(tstart) * P.in_rec, L, S);
   }
 
   // ---- terminal knot (terminalSolve, nu = 0, :146-149, :175-178): Z = C/mu, zff = d/mu,
@@ -1408,6 +1419,9 @@ template <int NX, int NU, int NC = 0>
 __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int batch) {
   gar_backward_wave_body<NX, NU, NC, 0>(P, batch);
 }
+// The plain unconstrained shapes are instantiated ONCE, in gar_wave_sweep.cpp (a translation unit of its own: see
+// there); every other translation unit sees them as extern templates.
+#define GAR_SWEEP_SHAPES(X) X(36, 12) X(32, 12) X(16, 8) X(12, 8) X(12, 4) X(8, 4)
 // constrained sweeps, second and third kernel of the chain (see gar_backward_wave_body)
 template <int NX, int NU, int NC>
 __global__ void __launch_bounds__(64, 1) gar_backward_wave_coupled(MfmaParams P, int batch) {

@@ -143,7 +143,9 @@ class BatchedRiccatiSolver:
         self.device_dims = dl[:, :5].astype(np.int32)
         self.device_stage_offsets = dl[:, 5:].copy()   # knot, factor, x, u, v, lbda
         self.device_problem_doubles, self.device_factors_doubles, self.device_solution_doubles = (int(v) for v in ds[:3])
-        self.device_nc0, self.device_G0_off, self.device_g0_off, self.padded = int(ds[3]), int(ds[4]), int(ds[5]), bool(ds[6])
+        self.device_nc0, self.device_G0_off, self.device_g0_off, self.padded = int(ds[3]), int(ds[4]), int(ds[5]), bool(int(ds[6]) & 1)
+        # the device knots t < N keep Q and R as packed lower triangles (csrc/gar_layout.h: the headline sweep's records)
+        self.qr_packed = bool(int(ds[6]) & 2)
         self._factors_cache = {}
         self._mueq = None   # of the last backward (datas[t].kktMat is formed on request)
 
@@ -199,6 +201,27 @@ class BatchedRiccatiSolver:
                     continue
                 buf[p:p + n] = _f64(getattr(k, name)).ravel(order="F")
                 p += n
+        return buf
+
+    def pack_device(self, problem: LqrProblem) -> np.ndarray:
+        """One problem in the DEVICE's record format, for producers that write knots in place
+        (gar_hip_device_problems / gar_hip_upload_packed_device): pack(), then -- when the solver keeps the lower
+        triangles of Q and R packed (`qr_packed`, csrc/gar_layout.h) -- those blocks of every knot t < N repacked."""
+        if self.padded:
+            raise NotImplementedError("device records of a padded solver: ask device_dims / device_stage_offsets")
+        buf = self.pack(problem)
+        if not self.qr_packed:
+            return buf
+        for t in range(self.horizon):
+            nx, nu = int(self.dims[t, 0]), int(self.dims[t, 1])
+            p = int(self.stage_offsets[t, 0])
+            for off, n in ((p, nx), (p + nx * nx + nx * nu, nu)):   # Q, then (behind S) R
+                full = buf[off:off + n * n].reshape(n, n, order="F").copy()
+                buf[off:off + n * n] = 0.0
+                k = off
+                for j in range(n):
+                    buf[k:k + n - j] = full[j:, j]
+                    k += n - j
         return buf
 
     def unpack(self, buf: np.ndarray) -> LqrProblem:

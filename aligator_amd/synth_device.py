@@ -87,7 +87,15 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
 
         def padv(v, R):
             return torch.nn.functional.pad(v, (0, R - v.shape[-1]))
-        stage = torch.cat([_colmajor(pad(Q, NX, NX, 1.0)), _colmajor(pad(S, NX, NU)), _colmajor(pad(R, NU, NU, 1.0)),
+        def sym_block(m, n):
+            """The device's Q / R block: full column-major, or (solver.qr_packed, csrc/gar_layout.h) the lower
+            triangle packed column after column in the first n (n + 1) / 2 doubles, the rest of the block untouched."""
+            if not getattr(solver, "qr_packed", False):
+                return _colmajor(m)
+            iu = torch.triu_indices(n, n, device=dev)           # (r, c), r <= c, ordered by r then c ...
+            low = m[..., iu[1], iu[0]]                           # ... = column r of the lower triangle, rows c >= r
+            return torch.nn.functional.pad(low, (0, n * n - low.shape[-1]))
+        stage = torch.cat([sym_block(pad(Q, NX, NX, 1.0), NX), _colmajor(pad(S, NX, NU)), sym_block(pad(R, NU, NU, 1.0), NU),
                            padv(randu(nb, N, nx), NX), padv(randu(nb, N, nu), NU), _colmajor(pad(A, NX, NX)),
                            _colmajor(pad(B, NX, NU)), padv(randn(nb, N, nx), NX)], dim=-1)
         assert stage.shape[-1] <= rec
@@ -114,6 +122,6 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
 def download_problem(solver, b: int) -> LqrProblem:
     """Host LqrProblem (the caller's dimensions) of a sampled problem."""
     k = b % solver.batch
-    if solver.padded:   # the library strips the dummy rows / columns: gar_hip_download_packed
+    if solver.padded or getattr(solver, "qr_packed", False):   # the library converts: gar_hip_download_packed
         return solver.unpack(solver.download_packed(k, 1))
     return solver.unpack(solver._host_samples[k])

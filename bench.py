@@ -67,7 +67,7 @@ def pmc_traffic_in_run(args, N, nx, nu, timeout=240):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
-    knot_b = 8 * (2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu)
+    knot_b = 8 * knot_doubles_read(nx, nu)
     fac_b = 8 * ((nu + nx) * (nx + 1) + nx * (nx + 1) // 2 + nx)   # what pmc_child asks the streaming kernel to write
     known = {"FETCH_SIZE": float(args.batch) * N * (-(-knot_b // 16) * 16), "WRITE_SIZE": float(args.batch) * N * (-(-fac_b // 16) * 16)}
     got, detail = {}, {}
@@ -118,7 +118,7 @@ def pmc_child(args):
         solver.backward_async(1e-14)
         solver.forward_async()
     solver.sync()
-    knot_b = 8 * (2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu)
+    knot_b = 8 * knot_doubles_read(nx, nu, solver.qr_packed)
     fac_b = 8 * ((nu + nx) * (nx + 1) + nx * (nx + 1) // 2 + nx)   # (packed Vxx: moved_bytes)
     solver.close()
     ms = solver._L.gar_hip_stream_ceiling_ms(0, int(args.batch), int(N), knot_b, fac_b, 1)
@@ -161,11 +161,19 @@ def algorithmic_bytes(N, nx, nu):
     return bwd, fwd
 
 
-def moved_bytes(N, nx, nu):
+def knot_doubles_read(nx, nu, qr_packed=True):
+    """Doubles of a knot record the backward sweep reads: everything, or (csrc/gar_layout.h, `qr_packed`: the headline
+    one-wave sweep's records keep Q and R as their packed lower triangles) 2 988 instead of 3 684 at (36, 12)."""
+    sym = (nx * (nx + 1) // 2 + nu * (nu + 1) // 2) if qr_packed else (nx * nx + nu * nu)
+    return sym + nx * nx + 2 * nx * nu + 2 * nx + nu
+
+
+def moved_bytes(N, nx, nu, qr_packed=True):
     """What the serial one-wave kernels actually move per sweep: the factor record keeps the symmetric Vxx as its
     lower triangle, packed (csrc/gar_layout.h: gar_sym_index) -- nx (nx + 1) / 2 doubles instead of nx^2, written by
-    the backward sweep and read by the forward sweep."""
-    knot = 2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu
+    the backward sweep and read by the forward sweep -- and (round 4, `qr_packed`) the knot records keep Q and R as
+    their packed lower triangles: the upper triangles never influence a result (riccati-kernel.hxx:216, :232)."""
+    knot = knot_doubles_read(nx, nu, qr_packed)
     fac = (nu + nx) * nx + (nu + nx) + nx * (nx + 1) // 2 + nx        # 2478 at (36, 12)
     fwd_out = 2 * nx + nu
     return 8 * (knot + fac) * N, 8 * (fac + fwd_out) * N
@@ -599,7 +607,7 @@ def secondary_shapes(device, batch=1024):
 
 def stream_ceiling(solver, device, batch, N, nx, nu, bwd_bytes, bwd_ms):
     """bwd_bytes: the bytes the backward sweep MOVES per problem (moved_bytes), which is what these kernels move."""
-    knot_b = 8 * (2 * nx * nx + 2 * nx * nu + nu * nu + 2 * nx + nu)
+    knot_b = 8 * knot_doubles_read(nx, nu, solver.qr_packed)
     fac_b = 8 * ((nu + nx) * (nx + 1) + nx * (nx + 1) // 2 + nx)
     if knot_b > 32 * 1024 or fac_b > 28 * 1024:
         return None
@@ -608,7 +616,7 @@ def stream_ceiling(solver, device, batch, N, nx, nu, bwd_bytes, bwd_ms):
         return None
     out = {"ms": ms, "GBps": bwd_bytes * batch / (ms * 1e-3) / 1e9, "frac_of_peak": bwd_bytes * batch / (ms * 1e-3) / HBM_PEAK,
            "kernel_over_stream": bwd_ms / ms,
-           "note": "a kernel that only moves the bytes the backward sweep moves (same waves, same walk; packed Vxx), "
+           "note": "a kernel that only moves the bytes the backward sweep moves (same waves, same walk; packed Vxx, packed lower Q / R), "
                    "measured in this run"}
     # ... and a PLAIN grid-stride 16 B/lane copy of the same number of bytes (four nontemporal loads in flight per
     # lane, 64 workgroups per CU: the best of scripts/ubench/copy_variants.cpp), in the same process: what this
@@ -825,7 +833,7 @@ def main():
     if rank == 0:
         sweeps = args.batch * world * args.steps
         bwd_b, fwd_b = algorithmic_bytes(N, nx, nu)
-        bwd_mv, fwd_mv = moved_bytes(N, nx, nu)
+        bwd_mv, fwd_mv = moved_bytes(N, nx, nu, solver.qr_packed)
         achieved = bwd_b * args.batch / (bwd_ms * 1e-3)
         out = {
             "metric": "Riccati sweeps/sec (bwd+fwd), N=256 nx=36 nu=12",

@@ -202,7 +202,12 @@ double *gar_hip_device_solutions(gar_hip_solver *s);
  *                                offset, out[6] = factor record offset, out[7..10] = x,u,v,lbda offsets
  *   gar_hip_device_sizes         out[0..2] = doubles of one device problem / factor set / solution record,
  *                                out[3] = rows of the device G0 (nc0 + dummy states), out[4..5] = offsets of G0, g0,
- *                                out[6] = 1 if padded, out[7] = doubles of one initial-stage record */
+ *                                out[6] = flags: bit 0 = padded; bit 1 = the knots t < horizon keep Q and R as
+ *                                their LOWER TRIANGLES, packed column after column (LAPACK "L" order) in the first
+ *                                n (n + 1) / 2 doubles of the Q / R block, the rest of the block unused
+ *                                (csrc/gar_layout.h: the headline one-wave sweep reads 19 % fewer bytes per knot;
+ *                                every host entry point converts, only in-place device producers need to know),
+ *                                out[7] = doubles of one initial-stage record */
 int gar_hip_device_stage_layout(const gar_hip_solver *s, int t, int64_t out[11]);
 int gar_hip_device_sizes(const gar_hip_solver *s, int64_t out[8]);
 

@@ -36,5 +36,5 @@ for name, t in times.items():
           f"=> {batch / np.median(a.sum(1)) * 1e3:.0f} sweeps/s")
 # same answers
 x = [solvers[k].solution(0) for k in solvers]
-print("max difference between the two builds over the solution of problem 0:",
-      max(float(np.abs(a - b).max()) for A, B in zip(*x) for a, b in zip(A, B) if a.size))
+print("max difference between the builds over the solution of problem 0:",
+      max(float(np.abs(a - b).max()) for y in x[1:] for A, B in zip(x[0], y) for a, b in zip(A, B) if a.size))

@@ -468,7 +468,7 @@ def test_device_written_knots_survive_host_set_init():
     probs = [synth.generate_lq_problem(50 + i, np.ones(nx), N, nx, nu, mode="W") for i in range(2)]
     dims = [k.dims for k in probs[0].stages]
     s = BatchedRiccatiSolver(dims, nx, batch=2, lib_path=EMU)
-    packed = np.concatenate([s.pack(p) for p in probs])
+    packed = np.concatenate([s.pack_device(p) for p in probs])                  # the DEVICE's record format
     ctypes.memmove(s.device_pointers()[0], packed.ctypes.data, packed.nbytes)   # "device" write in place
     x0 = np.full(nx, 0.5)
     for b, p in enumerate(probs):
