@@ -444,7 +444,10 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   constexpr int cR = NX >> 4; // first tile column holding control columns: Rhat needs tj >= cR
   // V' as the A operand of P = V'F: the same registers serve every tile column (the wide shapes
   // have no registers to spare for that: they read the operands from LDS at every use)
-  constexpr bool PRELOAD_V = !WIDE;
+#ifndef GAR_PRELOAD_V
+#define GAR_PRELOAD_V 1
+#endif
+  constexpr bool PRELOAD_V = !WIDE && GAR_PRELOAD_V;
   double Vop[PRELOAD_V ? (TXF > 0 ? TXF : 1) : 1][PRELOAD_V ? KS : 1], Vop4[PRELOAD_V ? KS : 1];
   if (PRELOAD_V) {
 #pragma unroll

@@ -21,12 +21,12 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from .lqr import (BLOCK_NAMES, LqrKnot, LqrProblem, block_shapes,
-                  lqrComputeKktError, lqrInitializeSolution, lqrNumRows)
+from .lqr import (BLOCK_NAMES, BunchKaufman, LqrKnot, LqrProblem, block_shapes, lqrComputeKktError,
+                  lqrCreateSparseMatrix, lqrInitializeSolution, lqrNumRows)
 
 __all__ = ["LqrKnot", "LqrProblem", "RiccatiSolverBase", "ProximalRiccatiSolver",
            "ParallelRiccatiSolver", "RiccatiSolverDense", "BatchedRiccatiSolver", "lqrInitializeSolution",
-           "lqrComputeKktError", "lqrNumRows", "get_work"]
+           "lqrComputeKktError", "lqrCreateSparseMatrix", "lqrNumRows", "BunchKaufman", "get_work"]
 
 _PD = C.POINTER(C.c_double)
 GAR_HIP_ERR_FACTOR = -4
@@ -63,9 +63,27 @@ class _FactorView:
             self._kkt = self._kkt_fn()
         return self._kkt
 
+    @property
+    def kktChol(self):
+        """StageFactor::kktChol (expose-prox-riccati.cpp:31): the Bunch-Kaufman factorisation of kktMat, formed on the
+        host on request (the device sweeps factorise in registers / LDS and keep only the gains)."""
+        from .lqr import BunchKaufman
+        return BunchKaufman(self.kktMat)
+
 
 class _Kkt0View:
-    __slots__ = ("ff", "fth")
+    """ProximalRiccatiSolver::kkt0 (proximal-riccati.hpp:40-43; expose-prox-riccati.cpp:48-52): ff, fth, and -- on
+    request, from stage 0's value function and the problem's G0 -- mat = [Vxx0 G0^T; G0 0] and its factorisation."""
+    __slots__ = ("ff", "fth", "_mat_fn")
+
+    @property
+    def mat(self):
+        return self._mat_fn()
+
+    @property
+    def chol(self):
+        from .lqr import BunchKaufman
+        return BunchKaufman(self.mat)
 
 
 class BatchedRiccatiSolver:
@@ -605,6 +623,16 @@ class ProximalRiccatiSolver(_HipSolver):
     def kkt0(self):
         k = _Kkt0View()
         k.ff, k.fth, _, _ = self._impl.initial(0)
+
+        def mat():   # [Vxx0 G0^T; G0 0] (proximal-riccati.hxx:44-47), the lower triangle being what is factorised
+            V, G0 = self._impl.factor(0).vm.Vxx, np.asarray(self.problem_.G0)
+            n, m = V.shape[0], G0.shape[0]
+            M = np.zeros((n + m, n + m), order="F")
+            M[:n, :n] = V
+            M[n:, :n] = G0
+            M[:n, n:] = G0.T
+            return M
+        k._mat_fn = mat
         return k
 
     @property
@@ -638,6 +666,16 @@ class RiccatiSolverDense(_HipSolver):
     def kkt0(self):
         k = _Kkt0View()
         k.ff, k.fth, _, _ = self._impl.initial(0)
+
+        def mat():   # [Vxx0 G0^T; G0 0] (proximal-riccati.hxx:44-47), the lower triangle being what is factorised
+            V, G0 = self._impl.factor(0).vm.Vxx, np.asarray(self.problem_.G0)
+            n, m = V.shape[0], G0.shape[0]
+            M = np.zeros((n + m, n + m), order="F")
+            M[:n, :n] = V
+            M[n:, :n] = G0
+            M[:n, n:] = G0.T
+            return M
+        k._mat_fn = mat
         return k
 
     @property

@@ -8,6 +8,8 @@ Mirrors the reference's `aligator.gar` scripting surface
 * ``lqrInitializeSolution`` <- gar/utils.hpp:114-142
 * ``lqrComputeKktError``    <- gar/utils.hxx:88-182
 * ``lqrNumRows``            <- gar/utils.hpp:65-77
+* ``lqrCreateSparseMatrix`` <- gar/utils.hxx:8-86 (bindings/python/src/gar/expose-utils.cpp:26-37)
+* ``BunchKaufman``          <- core/bunchkaufman.hpp (what StageFactor.kktChol / kkt0.chol expose)
 
 Every block is a column-major (Fortran-order) float64 numpy array with the
 same name and shape as in the reference, so packing into the device record
@@ -216,3 +218,166 @@ def lqrComputeKktError(problem: LqrProblem, xs, us, vs, lbdas, mueq: float = 0.0
         dual_err = max(dual_err, inf(gx), inf(gu))
         cst_err = max(cst_err, inf(cst))
     return dyn_err, cst_err, dual_err
+
+
+def lqrCreateSparseMatrix(problem: LqrProblem, mueq: float, update: bool = False):
+    """-> (mat, rhs): the global KKT matrix of the LQ problem as a scipy.sparse CSC matrix and its right-hand side,
+    laid out exactly as the reference's gar::lqrCreateSparseMatrix (gar/utils.hxx:8-86; Python:
+    expose-utils.cpp:26-37): unknowns [lbda0; x0 u0 v0; lbda1; x1 u1 v1; ...], row block of a knot [q; r; d], then f;
+    the coupling of x_{t+1} with lbda_{t+1} is written as +I like the reference does (:75-80 -- the residual
+    convention of lqrComputeKktError and of the reference's dense test builder is -I).
+    `update` (re-use of an existing sparsity pattern) changes nothing here: the matrix is rebuilt."""
+    import scipy.sparse as sp
+    n = lqrNumRows(problem)
+    N = problem.horizon
+    rows, cols, vals = [], [], []
+
+    def put(i0, j0, blk):
+        blk = np.asarray(blk)
+        if blk.size:
+            ii, jj = np.nonzero(np.ones(blk.shape, dtype=bool))
+            rows.append(ii + i0)
+            cols.append(jj + j0)
+            vals.append(blk[ii, jj])
+
+    rhs = np.zeros(n)
+    nc0 = problem.nc0
+    rhs[:nc0] = problem.g0
+    put(0, nc0, problem.G0)
+    put(nc0, 0, problem.G0.T)
+    idx = nc0
+    for t, k in enumerate(problem.stages):
+        nk = k.nx + k.nu + k.nc
+        rhs[idx:idx + k.nx] = k.q
+        rhs[idx + k.nx:idx + k.nx + k.nu] = k.r
+        rhs[idx + k.nx + k.nu:idx + nk] = k.d
+        i0, i1 = idx + k.nx, idx + k.nx + k.nu
+        i2 = i1 + k.nc
+        put(idx, idx, k.Q)
+        put(i0, idx, k.S.T)
+        put(idx, i0, k.S)
+        put(i0, i0, k.R)
+        put(i1, idx, k.C)
+        put(idx, i1, k.C.T)
+        put(i1, i0, k.D)
+        put(i0, i1, k.D.T)
+        put(i1, i1, -mueq * np.eye(k.nc))
+        if t != N:
+            rhs[idx + nk:idx + nk + k.nx2] = k.f
+            put(i2, idx, k.A)
+            put(idx, i2, k.A.T)
+            put(i2, i0, k.B)
+            put(i0, i2, k.B.T)
+            i3 = i2 + k.nx2
+            put(i2, i3, np.eye(k.nx2))
+            put(i3, i2, np.eye(k.nx2))
+            idx += nk + k.nx2
+    mat = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)) \
+        if vals else sp.csc_matrix((n, n))
+    return mat, rhs
+
+
+class BunchKaufman:
+    """L D L^T of a symmetric (possibly indefinite) matrix with Bunch-Kaufman partial pivoting, LOWER triangle --
+    the factorisation behind StageFactor.kktChol and kkt0.chol (core/bunchkaufman.hpp; the textbook algorithm of
+    LAPACK's dsytf2 with uplo = 'L', alpha = (1 + sqrt 17) / 8).  A host-side mirror of what the reference's Python
+    module exposes for inspection; the device sweeps factorise in registers / LDS and do not keep this object.
+
+    `pivots` follows the reference: pivots[k] = p (0-based) for a 1x1 pivot with rows k and p interchanged,
+    pivots[k] = pivots[k+1] = -1 - p for a 2x2 pivot with rows k+1 and p interchanged (bunchkaufman.hpp:155-161).
+    `matrixLDLT` holds the unit-lower factor below the block diagonal and D's blocks on it (D itself; the reference
+    stores the blocks' inverses).  Only the lower triangle of the input is read."""
+
+    def __init__(self, A=None):
+        self.pivots = np.zeros(0, dtype=np.int64)
+        self.matrixLDLT = np.zeros((0, 0))
+        self.info = True
+        if A is not None:
+            self.compute(A)
+
+    def compute(self, A):
+        a = np.tril(np.array(A, dtype=np.float64, order="F", copy=True))
+        n = a.shape[0]
+        a = a + np.tril(a, -1).T          # work on the full symmetric matrix: the updates stay one-liners
+        piv = np.zeros(n, dtype=np.int64)
+        alpha = (1.0 + np.sqrt(17.0)) / 8.0
+        self.info = True
+        k = 0
+        while k < n:
+            step = 1
+            akk = abs(a[k, k])
+            if k + 1 < n:
+                imax = k + 1 + int(np.argmax(np.abs(a[k + 1:, k])))
+                colmax = abs(a[imax, k])
+            else:
+                imax, colmax = k, 0.0
+            if max(akk, colmax) == 0.0:
+                self.info = False
+                break
+            if akk >= alpha * colmax:
+                kp = k
+            else:
+                rowmax = max(np.abs(a[imax, k:imax]).max(initial=0.0), np.abs(a[imax + 1:, imax]).max(initial=0.0))
+                if akk >= (alpha * colmax) * (colmax / rowmax):
+                    kp = k
+                elif abs(a[imax, imax]) >= alpha * rowmax:
+                    kp = imax
+                else:
+                    kp, step = imax, 2
+            kk = k + step - 1
+            if kp != kk:                   # symmetric interchange of rows / columns kk and kp of the ACTIVE block
+                sub = a[k:, k:]            # (the columns of L already computed are not touched: solve() interleaves)
+                sub[[kk - k, kp - k], :] = sub[[kp - k, kk - k], :]
+                sub[:, [kk - k, kp - k]] = sub[:, [kp - k, kk - k]]
+            if step == 1:
+                d = a[k, k]
+                l = a[k + 1:, k] / d
+                a[k + 1:, k + 1:] -= np.outer(l, a[k + 1:, k])
+                a[k + 1:, k] = l
+                a[k, k + 1:] = l
+                piv[k] = kp
+            else:
+                D = a[k:k + 2, k:k + 2].copy()
+                W = np.linalg.solve(D, a[k:k + 2, k + 2:]).T     # L's two columns
+                a[k + 2:, k + 2:] -= W @ a[k:k + 2, k + 2:]
+                a[k + 2:, k:k + 2] = W
+                a[k:k + 2, k + 2:] = W.T
+                piv[k] = piv[k + 1] = -1 - kp
+            k += step
+        self.pivots = piv
+        self.matrixLDLT = np.tril(a)
+        return self
+
+    def _blocks(self):
+        n, k = len(self.pivots), 0
+        while k < n:
+            step = 2 if self.pivots[k] < 0 else 1
+            yield k, step
+            k += step
+
+    def solve(self, B):
+        """x with A x = B (the caller's A, before any interchange)."""
+        x = np.array(B, dtype=np.float64, copy=True)
+        one = x.ndim == 1
+        if one:
+            x = x[:, None]
+        a, n = self.matrixLDLT, len(self.pivots)
+        for k, step in self._blocks():            # P, then L^{-1}, block column by block column
+            kk = k + step - 1
+            kp = int(self.pivots[k]) if step == 1 else -1 - int(self.pivots[k])
+            if kp != kk:
+                x[[kk, kp]] = x[[kp, kk]]
+            x[k + step:] -= a[k + step:, k:k + step] @ x[k:k + step]
+        for k, step in self._blocks():            # D^{-1}
+            if step == 1:
+                x[k] /= a[k, k]
+            else:
+                D = np.array([[a[k, k], a[k + 1, k]], [a[k + 1, k], a[k + 1, k + 1]]])
+                x[k:k + 2] = np.linalg.solve(D, x[k:k + 2])
+        for k, step in reversed(list(self._blocks())):   # L^{-T}, then P^T
+            x[k:k + step] -= a[k + step:, k:k + step].T @ x[k + step:]
+            kk = k + step - 1
+            kp = int(self.pivots[k]) if step == 1 else -1 - int(self.pivots[k])
+            if kp != kk:
+                x[[kk, kp]] = x[[kp, kk]]
+        return x[:, 0] if one else x
