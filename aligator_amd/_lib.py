@@ -55,6 +55,7 @@ SIGNATURES = {
     "gar_hip_device_sizes": (C.c_int, [C.c_void_p, _PI64]),
     "gar_hip_backward": (C.c_int, [C.c_void_p, C.c_double]),
     "gar_hip_backward_async": (C.c_int, [C.c_void_p, C.c_double]),
+    "gar_hip_backward_blocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _PD, _PD, C.c_double]),
     "gar_hip_forward": (C.c_int, [C.c_void_p, _PD]),
     "gar_hip_forward_async": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gar_hip_num_failed": (C.c_int, [C.c_void_p]),

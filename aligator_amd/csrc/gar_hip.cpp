@@ -1168,12 +1168,22 @@ inline bool records_t2(const gar_hip_solver *s, int b) {
   return s->fb_t2 && !(s->fold && s->coupled_known && s->h_coupled[(size_t)b] != 0);
 }
 
-int launch_backward(gar_hip_solver *s, double mueq) {
+// [l0, l1): the legs swept by this call (default: every leg of this solver; gar_hip_backward_blocks sweeps them in
+// chunks, as their knots arrive).  The kernels index legs as blockIdx.x + leg_begin and the tuples as blockIdx.x:
+// a chunk is the same launch with leg_begin = l0 and the tuple buffer advanced to leg l0's slot.
+int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
   RoctxRange range_(s->num_legs > 1 ? "gar::parallel_backward" : "gar::backwardImpl+factor_initial");
+  const bool chunk = l0 >= 0;
+  if (!chunk)
+    l0 = s->leg_begin, l1 = s->leg_end;
+  const bool first = l0 == s->leg_begin, last = l1 == s->leg_end;
+  const long long tup_shift = (long long)(l0 - s->leg_begin) * s->tuple_doubles;
   if (s->leg_bwd_kernel) {
     gar::LegParams Q = make_leg_params(s);
-    const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
-    if (s->timing)
+    Q.leg_begin = l0;
+    Q.boundary += tup_shift;
+    const dim3 grid((unsigned)(l1 - l0), (unsigned)s->batch);
+    if (s->timing && first)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->fold) { // knots with nc > 0: fold C, d into Q, q (gar_fold.hpp); problems with D != 0 get flagged
       s->fold_mueq = mueq;
@@ -1187,10 +1197,13 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     if (s->fold) { // ... and are swept by the generic leg kernels (every other problem: an early exit)
       gar::GenericParams G = make_params(s, mueq);
       G.only = s->d_status + s->batch + 4;
+      G.leg_begin = l0;
+      G.local_legs = l1 - l0;
+      G.boundary += tup_shift;
       hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(GAR_BACKWARD_THREADS), (size_t)s->lds.total * sizeof(double), s->stream, G);
     }
     HIP_TRY(hipGetLastError());
-    if (s->timing)
+    if (s->timing && last)
       HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     return GAR_HIP_OK;
   }
@@ -1216,18 +1229,18 @@ int launch_backward(gar_hip_solver *s, double mueq) {
       const char *sa = std::getenv("GAR_HIP_SPD_ACCEPT");
       M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
     }
-    const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
-    if (s->timing)
+    const dim3 grid((unsigned)(l1 - l0), (unsigned)s->batch);
+    if (s->timing && first)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     hipLaunchKernelGGL(s->seg_bwd_kernel, grid, dim3(128), (size_t)s->seg_lds_doubles * sizeof(double), s->stream, M,
-                       s->num_legs, s->leg_begin);
+                       s->num_legs, l0);
     gar::LegParamParams Q{};
     Q.meta = s->d_meta;
     Q.meta2 = s->d_meta2;
     Q.prob = s->d_prob;
     Q.fac2 = s->d_fac2;
     Q.fac = s->d_fac;
-    Q.boundary = s->d_bound_local;
+    Q.boundary = s->d_bound_local + tup_shift;
     Q.status = s->d_status;
     Q.prob_stride = s->prob_doubles;
     Q.fac_stride = s->fac_doubles;
@@ -1235,21 +1248,21 @@ int launch_backward(gar_hip_solver *s, double mueq) {
     Q.boundary_stride = (long long)s->legs_per_rank * s->tuple_doubles;
     Q.horizon = N;
     Q.num_legs = s->num_legs;
-    Q.leg_begin = s->leg_begin;
+    Q.leg_begin = l0;
     Q.tuple_doubles = (int)s->tuple_doubles;
     Q.nxb = s->nxb;
     Q.nxM = s->dims5[0];
     Q.nuM = s->dims5[1];
     Q.tgain = s->d_tgain;
     Q.tgain_stride = s->tgain_doubles;
-    Q.local_legs = s->leg_end - s->leg_begin;
+    Q.local_legs = l1 - l0;
     // T_t = Rhat_t^{-1} B_t^T of every stage of the non-final legs at once, then the recursion (products only)
     hipLaunchKernelGGL(gar::gar_leg_param_prepare, dim3((unsigned)N, (unsigned)s->batch), dim3(256),
                        (size_t)gar::leg_prepare_lds_doubles(s->dims5[0], s->dims5[1]) * sizeof(double), s->stream, Q);
     hipLaunchKernelGGL(gar::gar_leg_param_generic, grid, dim3(GAR_LEG_PARAM_THREADS), (size_t)s->seg_param_lds_doubles * sizeof(double),
                        s->stream, Q);
     HIP_TRY(hipGetLastError());
-    if (s->timing)
+    if (s->timing && last)
       HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     return GAR_HIP_OK;
   }
@@ -1324,7 +1337,11 @@ int launch_backward(gar_hip_solver *s, double mueq) {
       HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     return GAR_HIP_OK;
   }
-  const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
+  const dim3 grid((unsigned)(l1 - l0), (unsigned)s->batch);
+  P.leg_begin = l0;
+  P.local_legs = l1 - l0;
+  if (P.boundary)
+    P.boundary += tup_shift;
   hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(GAR_BACKWARD_THREADS),
                      (size_t)s->lds.total * sizeof(double), s->stream, P);
   HIP_TRY(hipGetLastError());
@@ -2222,6 +2239,35 @@ int gar_hip_backward_async(gar_hip_solver *s, double mueq) {
     return launch_condensed(s);
   }
   return GAR_HIP_OK;
+}
+
+// The caller's whole problem and backward(mueq) in ONE call (what the binding's backward() has in hand): the
+// sequence gar_hip_upload_stage x (N+1), gar_hip_set_init, gar_hip_backward behind one crossing of the ABI (the
+// staged knots go out in 1 MiB pieces while the next ones are packed, gar_hip_upload_stage).
+int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, const double *G0, const double *g0,
+                            double mueq) {
+  GAR_GUARD(s);
+  if (!s || !blocks)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_backward_blocks: bad argument");
+  if (s->batch != 1)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_backward_blocks serves one problem (batch = 1): use gar_hip_upload_stage / "
+                                 "gar_hip_upload_packed + gar_hip_backward for a batch");
+  const int N = s->horizon;
+  auto upload = [&](int t) {
+    const double *const *k = blocks + 16 * (size_t)t;
+    return gar_hip_upload_stage(s, 0, t, k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9], k[10], k[11], k[12],
+                                k[13], k[14], k[15]);
+  };
+  // (Measured and not kept, round 4: sweeping the legs chunk by chunk as their knots arrive, copies on a stream of
+  // their own -- the sweep of a chunk takes as long as the sweep of all legs, a leg being a sequential chain over its
+  // stages, so the critical path stays packing + one leg + condensed solve; chunks on one stream add their sweeps:
+  // (56, 22), 32 legs: 2.35 -> 2.95 ms per Newton iteration.)
+  for (int t = 0; t <= N; ++t)
+    if (int rc = upload(t))
+      return rc;
+  if (int rc = gar_hip_set_init(s, 0, G0, g0))
+    return rc;
+  return gar_hip_backward(s, mueq);
 }
 
 int gar_hip_num_failed(gar_hip_solver *s) {

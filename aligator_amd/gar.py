@@ -357,6 +357,25 @@ class BatchedRiccatiSolver:
         self._check(self._L.gar_hip_forward(self._h, th))
         return True
 
+    def backward_blocks(self, problem: LqrProblem, mueq: float) -> bool:
+        """gar_hip_backward_blocks: the caller's whole problem (batch = 1) and backward(mueq) in one call."""
+        self._factors_cache = {}
+        self._mueq = float(mueq)
+        keep, ptrs = [], (C.c_void_p * (16 * (self.horizon + 1)))()
+        for t, k in enumerate(problem.stages):
+            stored = self.num_legs == 1 and k.nth > 0
+            for i, name in enumerate(BLOCK_NAMES):
+                a = getattr(k, name)
+                if a.size == 0 or (i >= 11 and not stored):
+                    ptrs[16 * t + i] = None
+                    continue
+                a = _f64(a)
+                keep.append(a)
+                ptrs[16 * t + i] = a.ctypes.data
+        G0, g0 = _f64(problem.G0), _f64(problem.g0)
+        self._check(self._L.gar_hip_backward_blocks(self._h, ptrs, _ptr(G0), _ptr(g0), float(mueq)))
+        return True
+
     def backward_async(self, mueq: float):
         self._factors_cache = {}
         self._mueq = float(mueq)
@@ -733,9 +752,10 @@ class ParallelRiccatiSolver(_HipSolver):
             k.Gu[...] = k.B.T
             k.Gth[...] = 0.0
             k.gamma[...] = k.f
-        self._upload()
         self._impl.set_refinement(self.condensedThreshold, self.maxRefinementSteps)
-        return self._impl.backward(mueq)
+        if p.horizon != self._impl.horizon:
+            raise ValueError("problem horizon changed; create a new solver")
+        return self._impl.backward_blocks(p, mueq)   # upload + sweep in one call
 
     def forward(self, xs, us, vs, lbdas, theta=None) -> bool:
         return super().forward(xs, us, vs, lbdas, None)  # theta ignored (:209-212)

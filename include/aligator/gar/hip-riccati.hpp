@@ -15,6 +15,7 @@
 #include "aligator/gar/lqr-problem.hpp"
 #include "aligator/utils/exceptions.hpp"
 #include <gar_hip.h>   // this repository: include/gar_hip.h
+#include <algorithm>
 #include <vector>
 
 namespace aligator::gar {
@@ -43,16 +44,17 @@ public:
     // the reference re-reads the caller's problem on every call (proximal-riccati.hxx:37):
     // 16 memcpy's per knot into the library's pinned staging area (of the device that owns the stage), ONE
     // host-to-device copy per device in gar_hip_backward
+    // -- handed over in ONE call (gar_hip_backward_blocks)
     const auto &st = problem_->stages;
-    for (int t = 0; t < (int)st.size(); ++t) {
+    blocks_.resize(16 * st.size());
+    for (size_t t = 0; t < st.size(); ++t) {
       const Knot &k = st[t];
-      check(gar_hip_upload_stage(h_, 0, t, k.Q.data(), k.S.data(), k.R.data(), k.q.data(),
-                                 k.r.data(), k.A.data(), k.B.data(), k.f.data(), k.C.data(),
-                                 k.D.data(), k.d.data(), k.Gth.data(), k.Gx.data(), k.Gu.data(),
-                                 k.Gv.data(), k.gamma.data()));
+      const double *b[16] = {k.Q.data(), k.S.data(), k.R.data(), k.q.data(), k.r.data(), k.A.data(), k.B.data(), k.f.data(),
+                             k.C.data(), k.D.data(), k.d.data(), k.Gth.data(), k.Gx.data(), k.Gu.data(), k.Gv.data(),
+                             k.gamma.data()};
+      std::copy(b, b + 16, blocks_.begin() + 16 * t);
     }
-    check(gar_hip_set_init(h_, 0, problem_->G0.data(), problem_->g0.data()));
-    const int rc = gar_hip_backward(h_, mueq);
+    const int rc = gar_hip_backward_blocks(h_, blocks_.data(), problem_->G0.data(), problem_->g0.data(), mueq);
     if (rc == GAR_HIP_ERR_FACTOR)                       // riccati-kernel.hxx:239-241
       ALIGATOR_RUNTIME_ERROR("Failed stage LDL factorization");
     check(rc);
@@ -132,6 +134,7 @@ private:
   Problem *problem_; int num_legs_; std::vector<int> devices_; gar_hip_solver *h_ = nullptr;
   size_t nxs_ = 0, nus_ = 0, nvs_ = 0, nls_ = 0;        // doubles per part of the packed solution
   std::vector<VectorMap> ff_; std::vector<RowMatrixMap> fb_;
+  std::vector<const double *> blocks_;                  // the 16 block pointers of every knot, rebuilt per backward
   bool gains_stale_ = false;
 };
 

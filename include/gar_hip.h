@@ -241,6 +241,12 @@ int gar_hip_backward_async(gar_hip_solver *s, double mueq);
  * Results stay in HBM; fetch with gar_hip_get_solution. */
 int gar_hip_forward(gar_hip_solver *s, const double *theta);
 int gar_hip_forward_async(gar_hip_solver *s, const double *theta_device);
+/* The binding's backward(mueq) in ONE call: the caller's whole problem (batch = 1) -- blocks[16 t + k], k = 0..15 in
+ * the argument order of gar_hip_upload_stage (Q S R q r A B f C D d Gth Gx Gu Gv gamma; same NULL rules), G0, g0 --
+ * re-read as the reference does on every backward (proximal-riccati.hxx:37), then the sweep: gar_hip_upload_stage x
+ * (N+1) + gar_hip_set_init + gar_hip_backward behind one crossing of the ABI. */
+int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, const double *G0, const double *g0,
+                            double mueq);
 /* number of problems whose backward reported a failed factorisation */
 int gar_hip_num_failed(gar_hip_solver *s);
 

@@ -275,7 +275,20 @@ protected:
     if (!h_)
       throw std::runtime_error(gar_hip_last_error());
   }
-  // the reference re-reads the caller's problem on every backward (proximal-riccati.hxx:37)
+  // the reference re-reads the caller's problem on every backward (proximal-riccati.hxx:37): the whole problem and
+  // backward(mueq) in one call (gar_hip_backward_blocks)
+  void backward_blocks(double mueq) const {
+    const auto &st = problem_->stages;
+    blocks_.resize(16 * st.size());
+    for (size_t t = 0; t < st.size(); ++t) {
+      const LqrKnot &k = st[t];
+      const double *b[16] = {k.Q.data(), k.S.data(), k.R.data(), k.q.data(), k.r.data(), k.A.data(), k.B.data(), k.f.data(),
+                             k.C.data(), k.D.data(), k.d.data(), k.Gth.data(), k.Gx.data(), k.Gu.data(), k.Gv.data(),
+                             k.gamma.data()};
+      std::copy(b, b + 16, blocks_.begin() + 16 * t);
+    }
+    check(gar_hip_backward_blocks(h_, blocks_.data(), problem_->G0.data(), problem_->g0.data(), mueq));
+  }
   void upload() const {
     const auto &st = problem_->stages;
     for (int t = 0; t < (int)st.size(); ++t) {
@@ -315,6 +328,7 @@ protected:
   LqrProblem *problem_;
   bool dense_ = false; // RiccatiSolverDense: nu+nc+2*nx2 gain rows
   mutable bool gains_valid_ = false;
+  mutable std::vector<const double *> blocks_;
   gar_hip_solver *h_ = nullptr;
 };
 
@@ -364,8 +378,7 @@ public:
   bool backward(const double mueq) override {
     check(gar_hip_set_refinement(h_, condensedThreshold, (int)maxRefinementSteps));
     gains_valid_ = false;
-    upload();
-    check(gar_hip_backward(h_, mueq));
+    backward_blocks(mueq);
     check(gar_hip_prefetch_gains(h_, 0)); // the gains start travelling now, under forward()
     return true;
   }

@@ -133,6 +133,7 @@ static SeamPhases time_phases(LqrProblem &p, int num_legs, int iters, double mu,
   const double *base = gar_hip_host_results(h, offs);
   check(gar_hip_gains_doubles(h, gd));
   std::vector<double> my_gains((size_t)(gd[0] + gd[1])), my_sol((size_t)gar_hip_solution_doubles(h));
+  std::vector<const double *> blocks(16 * (size_t)(N + 1));
   SeamPhases best;
   best.total = 1e30;
   auto us_since = [](clk::time_point t0) { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
@@ -143,13 +144,13 @@ static SeamPhases time_phases(LqrProblem &p, int num_legs, int iters, double mu,
     auto t = t0;
     for (int s = 0; s <= N; ++s) {
       const LqrKnot &k = p.stages[(size_t)s];
-      check(gar_hip_upload_stage(h, 0, s, k.Q.data(), k.S.data(), k.R.data(), k.q.data(), k.r.data(), k.A.data(), k.B.data(),
-                                 k.f.data(), k.C.data(), k.D.data(), k.d.data(), nullptr, nullptr, nullptr, nullptr, nullptr));
+      const double *b16[16] = {k.Q.data(), k.S.data(), k.R.data(), k.q.data(), k.r.data(), k.A.data(), k.B.data(), k.f.data(),
+                               k.C.data(), k.D.data(), k.d.data(), nullptr, nullptr, nullptr, nullptr, nullptr};
+      std::copy(b16, b16 + 16, blocks.begin() + 16 * (size_t)s);
     }
-    check(gar_hip_set_init(h, 0, p.G0.data(), p.g0.data()));
     ph.pack = us_since(t);
     t = clk::now();
-    check(gar_hip_backward(h, mu));
+    check(gar_hip_backward_blocks(h, blocks.data(), p.G0.data(), p.g0.data(), mu)); // upload + sweep, one call
     check(gar_hip_prefetch_gains(h, 0)); // (the binding's backward(): the gains start travelling under forward())
     ph.backward = us_since(t);
     t = clk::now();
@@ -181,8 +182,8 @@ static SeamPhases time_phases(LqrProblem &p, int num_legs, int iters, double mu,
   return best;
 }
 static void print_phases_json(const char *name, const SeamPhases &q, const std::string &kernel, int legs, bool last) {
-  std::printf("\"%s\": {\"kernel\": \"%s\", \"legs\": %d, \"us_per_newton_iteration\": %.1f, \"host_us\": {\"pack_into_pinned_staging\": %.1f, "
-              "\"backward_incl_h2d_tail_and_status_sync\": %.1f, \"forward\": %.1f, \"solution_d2h_and_scatter\": %.1f, "
+  std::printf("\"%s\": {\"kernel\": \"%s\", \"legs\": %d, \"us_per_newton_iteration\": %.1f, \"host_us\": {\"block_pointer_table\": %.1f, "
+              "\"backward_blocks_pack_h2d_sweep_status_sync\": %.1f, \"forward\": %.1f, \"solution_d2h_and_scatter\": %.1f, "
               "\"collapse_feedback\": %.1f, \"gains_gather_and_d2h\": %.1f, \"gains_consumed_by_caller\": %.1f}, "
               "\"device_ms\": {\"backward_sweep\": %.4f, \"condensed_or_initial\": %.4f, \"forward_sweep\": %.4f}, "
               "\"h2d_bytes\": %.0f, \"d2h_bytes\": %.0f}%s",
