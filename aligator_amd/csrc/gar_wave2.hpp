@@ -47,13 +47,10 @@ __device__ __forceinline__ void wave_lds_order() {
 // the only DPP control CDNA's double-precision ALU accepts) -- no SGPR round trip, no
 // VALU-writes-SGPR wait states: a v_readlane broadcast of a double is two instructions plus an
 // s_nop before its first use.  N must be a constant after unrolling.
+// (the CPU emulator of tests/emu implements the same instruction: ONE source path)
 template <int N> __device__ __forceinline__ double row_bcast_c(double v, int lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
   (void)lane;
   return __builtin_amdgcn_mov_dpp(v, 0x150 + N, 0xF, 0xF, true);
-#else
-  return __shfl(v, (lane & 48) | N);
-#endif
 }
 __device__ __forceinline__ double row_bcast(double v, int n, int lane) {
   switch (n) {
@@ -202,7 +199,6 @@ __device__ __forceinline__ void ldl_solve_mfma4_packed(const double *Lp, const d
 // sum over the four 16-lane rows of the wave, in every lane: two v_permlane{16,32}_swap exchanges on
 // the VALU (gfx950) instead of two ds_bpermute round trips through the LDS crossbar
 __device__ __forceinline__ double rows_sum(double a, int lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
   typedef unsigned uint2v __attribute__((ext_vector_type(2)));
   (void)lane;
   unsigned lo = (unsigned)__double2loint(a), hi = (unsigned)__double2hiint(a);
@@ -214,11 +210,6 @@ __device__ __forceinline__ double rows_sum(double a, int lane) {
   l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
   h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
   return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-#else
-  a += __shfl_xor(a, 16);
-  a += __shfl_xor(a, 32);
-  return a;
-#endif
 }
 
 // Reduce-scatter over the four 16-lane rows: every lane holds partial sums p0..p3 (one per
@@ -227,7 +218,6 @@ __device__ __forceinline__ double rows_sum(double a, int lane) {
 // three swaps + three adds per double instead of one all-reduce (two swaps, two copies, two adds)
 // per destination and a select.
 __device__ __forceinline__ double rows_reduce_scatter(double p0, double p1, double p2, double p3, int lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
   typedef unsigned uint2v __attribute__((ext_vector_type(2)));
   (void)lane;
   // halves: lower rows {0,1} keep p0 / p1 and send p2 / p3, upper rows the other way round
@@ -241,15 +231,6 @@ __device__ __forceinline__ double rows_reduce_scatter(double p0, double p1, doub
   const uint2v l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(s02), (unsigned)__double2loint(s13), false, false);
   const uint2v h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(s02), (unsigned)__double2hiint(s13), false, false);
   return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-#else
-  const int g = lane >> 4;
-  // step 1: the partner row g^2 sends what this half wants
-  const double ra = __shfl_xor((g & 2) ? p0 : p2, 32), rb = __shfl_xor((g & 2) ? p1 : p3, 32);
-  const double s_a = ((g & 2) ? p2 : p0) + ra, s_b = ((g & 2) ? p3 : p1) + rb;
-  // step 2: the partner row g^1
-  const double mine = (g & 1) ? s_b : s_a, give = (g & 1) ? s_a : s_b;
-  return mine + __shfl_xor(give, 16);
-#endif
 }
 
 // the register LDL^T of wave_ldl_fast_neg on rows already in registers (a[j] = Rhat(row, j))
@@ -291,11 +272,7 @@ __device__ __attribute__((noinline)) int wave_bk_second_test(LdlRow<NU> R, doubl
 }
 
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) {
-#if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_ballot_w64(p); // the v_cmp result itself (HIP's __ballot goes through an int)
-#else
-  return __ballot(p);
-#endif
 }
 // The register LDL^T of wave_ldl_fast_neg on rows already in registers (a[j] = Rhat(row, j)), under
 // the COMPLETE pivot rule: a column that fails the first test is checked out of line against the

@@ -163,6 +163,38 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
   W.bar.arrive_and_wait();
   return r;
 }
+// v_mov_b64_dpp row_newbcast:N (ctrl 0x150 + N): every lane reads lane N of its own 16-lane row
+inline double __builtin_amdgcn_mov_dpp(double v, int ctrl, int row_mask, int bank_mask, bool) {
+  emu::WaveCtx &W = emu::wave();
+  const int lane = threadIdx.x & 63;
+  W.a[lane] = v;
+  W.bar.arrive_and_wait();
+  double r = v;
+  if (ctrl >= 0x150 && ctrl <= 0x15f && ((row_mask >> (lane >> 4)) & 1) && ((bank_mask >> ((lane & 15) >> 2)) & 1))
+    r = W.a[(lane & 48) | (ctrl - 0x150)];
+  W.bar.arrive_and_wait();
+  return r;
+}
+// v_permlane16_swap / v_permlane32_swap (gfx950), semantics probed on the hardware (scripts/ubench/swap_probe.cpp):
+// vdst's odd rows (upper half) are exchanged with src0's even rows (lower half).  Result [0] = new vdst, [1] = new src0.
+typedef unsigned emu_uint2 __attribute__((ext_vector_type(2)));
+inline emu_uint2 emu_permlane_swap(unsigned vdst, unsigned src0, int span) { // span 16: rows, 32: halves
+  emu::WaveCtx &W = emu::wave();
+  const int lane = threadIdx.x & 63;
+  W.a[lane] = (double)vdst; // exact for 32-bit values
+  W.b[lane] = (double)src0;
+  W.bar.arrive_and_wait();
+  const bool upper = (lane & span) != 0;
+  emu_uint2 r;
+  r[0] = upper ? (unsigned)W.b[lane - span] : vdst;
+  r[1] = upper ? src0 : (unsigned)W.a[lane + span];
+  W.bar.arrive_and_wait();
+  return r;
+}
+inline emu_uint2 __builtin_amdgcn_permlane16_swap(unsigned vdst, unsigned src0, bool, bool) { return emu_permlane_swap(vdst, src0, 16); }
+inline emu_uint2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src0, bool, bool) { return emu_permlane_swap(vdst, src0, 32); }
+inline unsigned long long __ballot(int pred);
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return __ballot(p ? 1 : 0); }
 inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
 inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 inline double __hiloint2double(int hi, int lo) {
