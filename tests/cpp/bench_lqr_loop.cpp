@@ -227,6 +227,7 @@ int main(int argc, char **argv) {
     return 77;
   }
   const bool json = argc > 1 && std::string(argv[1]) == "--json";
+  const int json_legs = (json && argc > 2) ? std::atoi(argv[2]) : 0; // --json [legs]: the leg count (default N / 8)
   const int N = (!json && argc > 1) ? std::atoi(argv[1]) : 256, iters = 20;
   const double mu = 1e-10; // bench/lqr.cpp: mu_init = 1e-10
   struct Shape { int dim, nu; const char *what; };
@@ -238,10 +239,11 @@ int main(int argc, char **argv) {
       const Shape &sh = shapes[i];
       LqrProblem p = define_problem(N, sh.dim, sh.nu, 42), pp = define_problem(N, sh.dim, sh.nu, 42);
       std::string k1, k2;
-      const SeamPhases a = time_phases(p, 1, iters, mu, &k1), b = time_phases(pp, N / 8, iters, mu, &k2);
+      const int legs = json_legs > 1 ? json_legs : N / 8;
+      const SeamPhases a = time_phases(p, 1, iters, mu, &k1), b = time_phases(pp, legs, iters, mu, &k2);
       std::printf("\"nx%d_nu%d\": {", sh.dim, sh.nu);
       print_phases_json("serial", a, k1, 1, false);
-      print_phases_json("legs", b, k2, N / 8, true);
+      print_phases_json("legs", b, k2, legs, true);
       std::printf("}%s", i == 0 ? ", " : "");
     }
     std::printf("}\n");
