@@ -662,6 +662,7 @@ template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
   s->wave_lds_doubles = s->wave_fused_init ? with_init : gar::WaveCfg<NX, NU, NC>::total;
   s->waves_per_block = 1;
   s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + "," + std::to_string(NC) + ">";
+  s->qr_packed = GAR_QR_PACKED != 0; // the chain's three kernels read only the lower triangles of Q and R (gar_layout.h)
 }
 
 void select_kernel(gar_hip_solver *s) {
@@ -2135,11 +2136,13 @@ int gar_hip_upload_packed(gar_hip_solver *s, int b0, int nb, const double *packe
     for (int b = b0; b < b0 + nb; ++b) {
       const double *rec = packed + (int64_t)(b - b0) * u->prob_doubles;
       for (int t = 0; t <= s->horizon; ++t) {
+        // (a padded solver is unconstrained and unparameterised; one that only packs Q / R may carry both)
         const gar_stage_meta &m = u->meta[t];
-        const gar_knot_offsets o = gar_knot_layout(m.nx, m.nu, 0, m.nx2, 0);
+        const int nth_st = (m.flags & GAR_KNOT_HAS_PARAM) ? m.nth : 0;
+        const gar_knot_offsets o = gar_knot_layout(m.nx, m.nu, m.nc, m.nx2, nth_st);
         const double *k = rec + m.in_off;
         if (int rc = gar_hip_upload_stage(s, b, t, k + o.Q, k + o.S, k + o.R, k + o.q, k + o.r, k + o.A, k + o.B, k + o.f,
-                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))
+                                          k + o.C, k + o.D, k + o.d, k + o.Gth, k + o.Gx, k + o.Gu, k + o.Gv, k + o.gamma))
           return rc;
       }
       if (int rc = gar_hip_set_init(s, b, rec + u->G0_off, rec + u->g0_off))

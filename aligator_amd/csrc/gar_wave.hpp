@@ -1192,8 +1192,9 @@ __device__ __forceinline__ void wave_stage(const MfmaParams &P, double *sm, cons
         }
       }
   wave_sync();
-  // ---- knot t-1: its Hessian tiles replace H
-  wave_load_b<NX, NU>(recn, L, S);
+  // ---- knot t-1: its Hessian tiles replace H  (NC > 0 is the serial constrained chain, whose records keep Q and R
+  // as packed lower triangles like the plain sweep's: gar_layout.h; the leg kernels run this stage with NC = 0)
+  wave_load_b<NX, NU, WaveLane<NX, NU, NC>, (GAR_QR_PACKED && NC > 0 && !MfmaCfg<NX, NU, NC>::WIDE)>(recn, L, S);
   GAR_WMARK(9)
   // ---- Vxx -> HBM, 16 B per lane: column-major and symmetric, or (PACKV: the serial family, gar_layout.h) the
   // packed lower triangle
@@ -1251,8 +1252,8 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
     if (tstart < 0)
       return;
   }
-  // Q, R of the knots as packed lower triangles (gar_layout.h): the plain unconstrained one-wave sweep
-  constexpr bool QP = GAR_QR_PACKED && NC == 0 && !M::WIDE;
+  // Q, R of the knots as packed lower triangles (gar_layout.h): the one-wave serial sweeps
+  constexpr bool QP = GAR_QR_PACKED && !M::WIDE; // (the constrained chain NC > 0 too)
   WaveLane<NX, NU, NC> L;
   wave_lane_init<NX, NU, NC, QP>(L, lane);
   WaveStage<NX, NU> S;

@@ -1059,7 +1059,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   wave_sync();
   GAR_WMARK(14)
   // ---- knot t-1: its Hessian tiles replace H
-  wave_load_b<NX, NU, WaveLane<NX, NU, NC>, (GAR_QR_PACKED && NC == 0 && !WIDE)>(recn, L, S);
+  wave_load_b<NX, NU, WaveLane<NX, NU, NC>, (GAR_QR_PACKED && !WIDE)>(recn, L, S);
   GAR_WMARK(9)
   // ---- Vxx -> HBM is left to the next stage (list A) / to the caller after the last one -----------
   vflush = out + oVxx;

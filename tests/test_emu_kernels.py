@@ -817,3 +817,17 @@ def test_padding_is_dropped_when_no_specialised_kernel_binds(monkeypatch):
     rng = np.random.default_rng(8)
     prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
     pc.check_parallel(prob, 1e-10, legs, 1e-8, EMU)
+
+
+def test_packed_upload_of_constrained_and_parameterised_problems_on_packed_triangle_records():
+    """gar_hip_upload_packed on solvers whose records keep Q, R as packed lower triangles (round 4) goes knot by knot:
+    constrained knots (C, D, d) and user parameters must travel too (a GPU-only test found them dropped)."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    rng = np.random.default_rng(21)
+    for nx, nu, nc, nth, horz, mu in ((8, 4, 4, 0, 5, 1e-6), (16, 8, 8, 0, 3, 1e-6)):
+        probs = [synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nc=nc, nth=nth, mode="W") for _ in range(2)]
+        s = pc.check_batched(probs, mu, 1e-8, EMU)
+        assert s.qr_packed and f"<{nx},{nu},{nc}>" in s.kernel_name
+        back = s.download_packed()
+        want = np.concatenate([s.pack(p) for p in probs])
+        assert np.array_equal(back, want)
