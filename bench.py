@@ -746,6 +746,11 @@ def main():
         dist.destroy_process_group()
         return
 
+    # The Newton-iteration seam (host data, one problem) is measured FIRST, before this process allocates anything
+    # large: for seconds after a process has freed tens of GB of HBM the driver's scrubbing of that memory keeps the
+    # copy engines busy and every host<->device copy of the seam runs several times slower (measured: 0.92 -> 2.0 ms
+    # and 2.3 -> 4.9 ms right after a 57 GB process, back to 0.92 / 2.3 twenty seconds later).
+    seam_line = seam() if (world == 1 and rank == 0 and not args.no_extras) else None
     N, nx, nu, mueq = args.horizon, args.nx, args.nu, 1e-14
     dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
     solver = BatchedRiccatiSolver(dims, nx, batch=args.batch, num_legs=1, device=local_rank)
@@ -895,7 +900,7 @@ def main():
             out["secondary_shapes"] = secondary_shapes(local_rank)
             out["batch_scan"] = batch_scan(args, local_rank, stream, N, nx, nu, mueq, args.batch, sweeps / elapsed)
             out["config3"] = config3(args, local_rank, stream)
-            out["seam"] = seam()
+            out["seam"] = seam_line
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, nx, nu, N, mueq)
         print(json.dumps(out))
