@@ -284,7 +284,7 @@ int gar_hip_set_refinement(gar_hip_solver *s, double condensed_threshold, int ma
 int gar_hip_condensed_info(gar_hip_solver *s, int b, double out[2]);
 /* Block cyclic reduction of the condensed system (specialised leg families): the backward error
  * omega = max_i |r_i| / max_i (|rhs_i| + sum_j |K_ij| |s_j|) of its solution.  The solve stands when the reference's
- * absolute residual threshold is met OR omega <= 1e-12: with value functions of order 1/mu (constrained knots) the
+ * absolute residual threshold is met OR omega <= 1e-13: with value functions of order 1/mu (constrained knots) the
  * absolute threshold (parallel-solver.hpp:92) is out of reach of any fp64 solver -- the reference then spends its
  * maxRefinementSteps without effect (parallel-solver.hxx:184-202).  0 when the elimination chain solved instead. */
 int gar_hip_condensed_backward_error(gar_hip_solver *s, int b, double *out);
@@ -303,7 +303,8 @@ int gar_hip_condensed_resolved(gar_hip_solver *s, int b, int *out);
  *   "generic-chain"  the 2 J blocks in the reference's order (block-tridiagonal.hpp:82-138) only.
  * "" on a solver without legs. */
 const char *gar_hip_condensed_solver_name(const gar_hip_solver *s);
-/* the omega bound above (default 1e-12); 0: only the reference's absolute threshold counts */
+/* the omega bound above (default 1e-13; 1e-12 until round 4: a soak draw with omega = 9.4e-13 kept multipliers 150 x
+ * farther from LAPACK than any CPU solver, the forward error being cond * omega); 0: only the reference's absolute threshold counts */
 int gar_hip_set_condensed_backward_ok(gar_hip_solver *s, double omega);
 
 /* ---- results (HBM -> host) ------------------------------------------------ */
