@@ -831,3 +831,27 @@ def test_packed_upload_of_constrained_and_parameterised_problems_on_packed_trian
         back = s.download_packed()
         want = np.concatenate([s.pack(p) for p in probs])
         assert np.array_equal(back, want)
+
+
+def test_backward_blocks_is_the_upload_and_backward_sequence():
+    """gar_hip_backward_blocks (the binding's backward() in one ABI call): same bits as gar_hip_upload_stage x (N+1) +
+    gar_hip_set_init + gar_hip_backward, serial and leg mode, a padded shape; refused on a batch."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    rng = np.random.default_rng(31)
+    for nx, nu, horz, legs in ((8, 4, 9, 1), (8, 4, 11, 3), (6, 3, 8, 2)):
+        prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, mode="W")
+        dims = [k.dims for k in prob.stages]
+        a = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=legs, lib_path=EMU)
+        b = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=legs, lib_path=EMU)
+        for t, k in enumerate(prob.stages):
+            a.upload_knot(0, t, k)
+        a.set_init(0, prob.G0, prob.g0)
+        assert a.backward(1e-10) and a.forward()
+        assert b.backward_blocks(prob, 1e-10) and b.forward()
+        for A, B in zip(a.solution(0), b.solution(0)):
+            for x, y in zip(A, B):
+                assert np.array_equal(x, y)
+        assert np.array_equal(a.download_packed(), b.download_packed())
+    two = BatchedRiccatiSolver(dims, nx, batch=2, lib_path=EMU)
+    with pytest.raises(RuntimeError, match="batch"):
+        two.backward_blocks(prob, 1e-10)
