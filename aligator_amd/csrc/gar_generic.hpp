@@ -551,6 +551,13 @@ __global__ void __launch_bounds__(256) gar_rotate_records(double *base, long lon
   a[(long long)(nrec - 1) * rec] = 0.0;
 }
 
+// A small record straight into pinned host memory, by the kernel's own stores: it does not queue on the copy
+// engine behind a large device-to-host copy that is in flight (the solution next to the gains' read-back).
+__global__ void __launch_bounds__(256) gar_store_to_host(double *dst_host, const double *src, long long n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(src[e], dst_host + e);
+}
+
 // ---------------------------------------------------------------------------
 // Bulk read-back of the gains (the loop of SolverProxDDPTpl::computeDirection that copies
 // getFeedforward(i) / getFeedback(i) of every stage, solver-proxddp.hxx:620-632): ff and fb of all

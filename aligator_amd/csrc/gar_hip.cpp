@@ -269,6 +269,11 @@ struct gar_hip_solver {
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_main = nullptr, ev_pref = nullptr;
   int pref_b = -1;             // problem whose gains are in flight / in h_results (-1: none)
+  // gar_hip_backward_blocks on a problem without parameter: the roll-out and the solution's copy are enqueued BEHIND the
+  // sweep before the host waits for the status word, so that gar_hip_forward / the solution fetch find them done
+  int *h_status = nullptr;     // pinned
+  hipEvent_t ev_status = nullptr, ev_sol = nullptr;
+  bool eager_fwd = false;      // d_sol and h_results hold the roll-out of the last sweep (theta = none)
   bool pref_collapsed = false; // collapseFeedback ran since: stage 0's gains are fetched again
 };
 
@@ -1791,6 +1796,7 @@ void strip_solution_rec(const gar_hip_solver *s, const double *dev, double *rec)
 } // namespace
 
 static int fetch_results_impl(gar_hip_solver *s, int b, int what, int t_lo, int t_hi, double *gains_base, bool sync);
+static int prefetch_impl(gar_hip_solver *s, int b);
 #include "gar_multi.hpp"
 
 extern "C" {
@@ -2006,6 +2012,11 @@ void gar_hip_solver_destroy(gar_hip_solver *s) {
     (void)hipEventDestroy(s->ev_main);
     (void)hipEventDestroy(s->ev_pref);
   }
+  if (s->h_status) {
+    (void)hipHostFree(s->h_status);
+    (void)hipEventDestroy(s->ev_status);
+    (void)hipEventDestroy(s->ev_sol);
+  }
   delete s->ulay;
   delete s->flay;
   delete s;
@@ -2204,6 +2215,7 @@ int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   GAR_MULTI(s, multi_backward_legs(s, mueq));
+  s->eager_fwd = false;
   if (s->ev_pref) { // a read-back of the previous sweep's gains may still be in flight on the second stream
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_pref, 0));
     s->pref_b = -1;
@@ -2270,7 +2282,52 @@ int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, cons
       return rc;
   if (int rc = gar_hip_set_init(s, 0, G0, g0))
     return rc;
-  return gar_hip_backward(s, mueq);
+  // Without a parameter the roll-out depends on nothing the caller still has to say: it is enqueued right behind the
+  // sweep, with the solution's copy and the gains' read-back (second stream), BEFORE the host waits for the status
+  // word -- the device runs sweep, roll-out and copies back to back instead of waiting for the host between them.
+  // gar_hip_forward / gar_hip_prefetch_gains / the solution fetch then find their work done.
+  static const bool eager_on = [] { const char *e = std::getenv("GAR_HIP_EAGER"); return !(e && e[0] == '0'); }();
+  const bool eager = eager_on && !s->multi && !s->fold && !s->dense && (s->nth0 == 0 || s->num_legs > 1) && s->world == 1;
+  if (!eager)
+    return gar_hip_backward(s, mueq);
+  if (int rc = gar_hip_backward_async(s, mueq))
+    return rc;
+  if (!s->h_status) {
+    HIP_TRY(gar_host_malloc((void **)&s->h_status, sizeof(int) * (size_t)s->batch, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_status, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_sol, hipEventDisableTiming));
+  }
+  HIP_TRY(hipMemcpyAsync(s->h_status, s->d_status, sizeof(int) * (size_t)s->batch, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipEventRecord(s->ev_status, s->stream));
+  if (int rc = prefetch_impl(s, 0)) // (allocates the read-back buffers on first use)
+    return rc;
+  if (int rc = launch_forward(s, nullptr))
+    return rc;
+  {
+    const gar_hip_solver *u = s->ulay ? s->ulay : s;
+    const size_t nsol = (size_t)u->sol_doubles, ngain = (size_t)(u->ff_all_doubles + u->fb_all_doubles);
+    // by a kernel's own stores into the pinned buffer: the copy engine is busy with the gains (3.7 / 9.4 MB) and a
+    // hipMemcpyAsync would queue behind them
+    static const bool by_kernel = [] { const char *e = std::getenv("GAR_HIP_EAGER_DMA"); return !(e && e[0] == '1'); }();
+    double *dst = s->h_results + (s->padded ? nsol + ngain : 0);
+    if (by_kernel) {
+      const unsigned nblk = (unsigned)std::min<int64_t>((s->sol_doubles + 255) / 256, 256);
+      hipLaunchKernelGGL(gar::gar_store_to_host, dim3(nblk), dim3(256), 0, s->stream, dst, s->d_sol, (long long)s->sol_doubles);
+      HIP_TRY(hipGetLastError());
+    } else {
+      HIP_TRY(hipMemcpyAsync(dst, s->d_sol, sizeof(double) * (size_t)s->sol_doubles, hipMemcpyDeviceToHost, s->stream));
+    }
+  }
+  HIP_TRY(hipEventRecord(s->ev_sol, s->stream));
+  HIP_TRY(hipEventSynchronize(s->ev_status));
+  int nf = 0;
+  for (int b = 0; b < s->batch; ++b)
+    nf += (s->h_status[b] != 0);
+  s->last_failed = nf;
+  if (nf > 0)
+    return fail(GAR_HIP_ERR_FACTOR, "Failed stage LDL factorization (" + std::to_string(nf) + " problem(s))");
+  s->eager_fwd = true;
+  return GAR_HIP_OK;
 }
 
 int gar_hip_num_failed(gar_hip_solver *s) {
@@ -2346,6 +2403,10 @@ int gar_hip_forward(gar_hip_solver *s, const double *theta) {
     if (int rc = multi_forward(s))
       return rc;
     return multi_sync(s);
+  }
+  if (s->eager_fwd) { // enqueued behind the sweep by gar_hip_backward_blocks (no parameter: theta has no say)
+    HIP_TRY(hipEventSynchronize(s->ev_sol));
+    return GAR_HIP_OK;
   }
   const double *th = nullptr;
   if (theta && s->nth0 > 0 && s->num_legs == 1) {
@@ -2533,32 +2594,24 @@ static int fetch_results_impl(gar_hip_solver *s, int b, int what, int t_lo, int 
                                sizeof(double) * (size_t)(b1 - b0), hipMemcpyDeviceToHost, s->stream));
     }
   }
-  if (what & 1)
+  const bool sol_there = (what & 1) && s->eager_fwd && b == 0; // copied behind the eager roll-out (gar_hip_backward_blocks)
+  if ((what & 1) && !sol_there)
     HIP_TRY(hipMemcpyAsync(s->h_results + (s->padded ? nsol + ngain : 0), s->d_sol + (int64_t)b * s->sol_doubles,
                            sizeof(double) * (size_t)s->sol_doubles, hipMemcpyDeviceToHost, s->stream));
   if (!sync)
     return GAR_HIP_OK;
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (sol_there && what == 1)
+    HIP_TRY(hipEventSynchronize(s->ev_sol));
+  else
+    HIP_TRY(hipStreamSynchronize(s->stream));
   if ((what & 1) && s->padded)
     strip_solution_rec(s, s->h_results + nsol + ngain, s->h_results);
   return GAR_HIP_OK;
 }
 
-int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
-  GAR_MULTI(s, multi_fetch_results(s, b, what));
-  return fetch_results_impl(s, b, what, 0, s->horizon + 1, nullptr, true);
-}
-
-int gar_hip_prefetch_gains(gar_hip_solver *s, int b) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
-  // (multi-device and folded solvers: the ordinary fetch does the work -- their read-back has host-side steps)
-  if (s->multi || s->fold)
-    return GAR_HIP_OK;
+// every stage's gains of problem b: gather + ONE device-to-host copy on the second stream, behind what the main
+// stream holds now
+static int prefetch_impl(gar_hip_solver *s, int b) {
   if (int rc = fetch_results_impl(s, b, 0, 0, 0, nullptr, false)) // the buffers, on first use
     return rc;
   if (!s->aux_stream) {
@@ -2580,6 +2633,26 @@ int gar_hip_prefetch_gains(gar_hip_solver *s, int b) {
   s->pref_b = b;
   s->pref_collapsed = false;
   return GAR_HIP_OK;
+}
+
+int gar_hip_fetch_results(gar_hip_solver *s, int b, int what) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  GAR_MULTI(s, multi_fetch_results(s, b, what));
+  return fetch_results_impl(s, b, what, 0, s->horizon + 1, nullptr, true);
+}
+
+int gar_hip_prefetch_gains(gar_hip_solver *s, int b) {
+  GAR_GUARD(s);
+  if (int rc = check_bt(s, b, 0))
+    return rc;
+  // (multi-device and folded solvers: the ordinary fetch does the work -- their read-back has host-side steps)
+  if (s->multi || s->fold)
+    return GAR_HIP_OK;
+  if (s->eager_fwd && s->pref_b == b && !s->pref_collapsed)
+    return GAR_HIP_OK; // gar_hip_backward_blocks started it already
+  return prefetch_impl(s, b);
 }
 
 const double *gar_hip_host_results(gar_hip_solver *s, int64_t offs[3]) {
@@ -2868,6 +2941,7 @@ int gar_hip_collapse_feedback(gar_hip_solver *s) {
     return fail(GAR_HIP_ERR_ARG, "null solver");
   GAR_MULTI(s, gar_hip_collapse_feedback(s->multi->subs[0])); // stage 0 lives on the first device
   s->pref_collapsed = true;
+  s->eager_fwd = false; // a roll-out after this call is a new one
   if (s->num_legs < 2 || s->leg_begin != 0)
     return GAR_HIP_OK; // no-op except Parallel (riccati-base.hpp:33)
   if (s->fold) { // the wave-leg family's own records (then re-expanded on request); flagged problems: generic records
@@ -2895,6 +2969,7 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
   if (s->ev_pref)
     HIP_TRY(hipEventSynchronize(s->ev_pref));
   s->pref_b = -1;
+  s->eager_fwd = false;
   const int N = s->horizon;
   if (N < 1)
     return GAR_HIP_OK;

@@ -244,7 +244,13 @@ int gar_hip_forward_async(gar_hip_solver *s, const double *theta_device);
 /* The binding's backward(mueq) in ONE call: the caller's whole problem (batch = 1) -- blocks[16 t + k], k = 0..15 in
  * the argument order of gar_hip_upload_stage (Q S R q r A B f C D d Gth Gx Gu Gv gamma; same NULL rules), G0, g0 --
  * re-read as the reference does on every backward (proximal-riccati.hxx:37), then the sweep: gar_hip_upload_stage x
- * (N+1) + gar_hip_set_init + gar_hip_backward behind one crossing of the ABI. */
+ * (N+1) + gar_hip_set_init + gar_hip_backward behind one crossing of the ABI.
+ * On a problem without parameter (nth = 0, or leg mode, where theta has no say) on one device the roll-out, the
+ * solution's copy into the pinned result buffer (by the kernel's own stores: the copy engine carries the gains) and
+ * the gains' read-back are enqueued right behind the sweep, BEFORE the host waits for the status word: the device
+ * runs them back to back, and the gar_hip_forward / gar_hip_prefetch_gains / gar_hip_fetch_results(solution) calls
+ * that follow find their work done (same results; the next backward, gar_hip_collapse_feedback or
+ * gar_hip_cycle_append ends that state).  GAR_HIP_EAGER=0 switches it off. */
 int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, const double *G0, const double *g0,
                             double mueq);
 /* number of problems whose backward reported a failed factorisation */

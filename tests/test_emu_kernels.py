@@ -852,6 +852,29 @@ def test_backward_blocks_is_the_upload_and_backward_sequence():
             for x, y in zip(A, B):
                 assert np.array_equal(x, y)
         assert np.array_equal(a.download_packed(), b.download_packed())
+        # the roll-out gar_hip_backward_blocks enqueues behind the sweep (no parameter) is what forward() / the bulk
+        # read-back hand out: same bits as the plain sequence, also when asked twice, after collapseFeedback, and
+        # after the NEXT sweep on changed data (nothing stale survives a backward)
+        for x, y in zip(a.fetch_results(0), b.fetch_results(0)):
+            assert np.array_equal(x, y)
+        assert b.forward()
+        for x, y in zip(a.fetch_results(0), b.fetch_results(0)):
+            assert np.array_equal(x, y)
+        a.collapse_feedback(), b.collapse_feedback()
+        assert a.forward() and b.forward()
+        for x, y in zip(a.fetch_results(0), b.fetch_results(0)):
+            assert np.array_equal(x, y)
+        before = [x.copy() for x in b.fetch_results(0)]
+        for k in prob.stages:
+            k.q[:] = rng.standard_normal(k.q.shape)
+        for t, k in enumerate(prob.stages):
+            a.upload_knot(0, t, k)
+        assert a.backward(1e-10) and a.forward()
+        assert b.backward_blocks(prob, 1e-10) and b.forward()
+        after = b.fetch_results(0)
+        assert not np.array_equal(before[0], after[0])
+        for x, y in zip(a.fetch_results(0), after):
+            assert np.array_equal(x, y)
     two = BatchedRiccatiSolver(dims, nx, batch=2, lib_path=EMU)
     with pytest.raises(RuntimeError, match="batch"):
         two.backward_blocks(prob, 1e-10)
