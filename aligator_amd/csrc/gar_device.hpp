@@ -51,6 +51,32 @@ __device__ __forceinline__ void wg_bar(const WG &w) {
   else
     __syncthreads();
 }
+// workgroup barrier that orders LDS traffic only: global loads and stores in flight STAY in flight across it (a
+// __syncthreads waits for vmcnt(0) -- every outstanding store's acknowledgement -- on each side)
+__device__ __forceinline__ void wg_lds_bar() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// put(e, get(e)) for e < n over the group, EIGHT loads in flight per thread before the first store (a plain
+// `for (e...) dst[e] = src[e]` compiles to load -> wait -> store per iteration)
+template <class Get, class Put>
+__device__ __forceinline__ void wg_move8(const WG &w, int n, Get get, Put put) {
+  for (int e0 = w.tid; e0 < n; e0 += 8 * w.nthr) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = e0 + q * w.nthr;
+      v[q] = get(e < n ? e : n - 1);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = e0 + q * w.nthr;
+      if (e < n)
+        put(e, v[q]);
+    }
+  }
+}
 // Maximum of a double over the wave, in every lane.  Six DPP stages (row_shr 1, 2, 4, 8, then
 // row_bcast 15 and 31) reduce into lane 63, v_readlane broadcasts it: ~150 cycles.  The same
 // reduction through __shfl_xor costs 12 ds_bpermute round trips (the LDS crossbar, ~100 cycles

@@ -164,12 +164,10 @@ struct gar_hip_solver {
   // plain part of every leg by that kernel into scratch records (flay: the same knots, nth = 0; d_fac2), the
   // parameter part by the generic matrix recursion, which writes the caller-visible records and the tuples
   void (*seg_bwd_kernel)(gar::MfmaParams, int, int) = nullptr;
-  int seg_lds_doubles = 0, seg_param_lds_doubles = 0;
+  int seg_lds_doubles = 0;
   bool fold = false, fold_expanded = false, coupled_known = false;
   gar_hip_solver *flay = nullptr;
   double *d_prob2 = nullptr, *d_fac2 = nullptr;
-  double *d_tgain = nullptr; // segment legs: T_t = Rhat_t^{-1} B_t^T per stage (gar_leg_param_prepare)
-  int64_t tgain_doubles = 0;  // per problem
   gar_stage_meta *d_meta2 = nullptr;
   double fold_mueq = 0.0;
   std::vector<int> h_coupled;
@@ -607,7 +605,6 @@ template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
 template <int NX, int NU> void bind_seg_leg(gar_hip_solver *s) {
   s->seg_bwd_kernel = gar::gar_backward_pair_leg<NX, NU>;
   s->seg_lds_doubles = gar::PairCfg<NX, NU>::total;
-  s->seg_param_lds_doubles = gar::leg_param_lds_doubles(NX, NU);
   s->fb_t2 = false; // row-major fb: the generic roll-out, condensed solve and collapse serve the family
   s->kernel_name = "pair_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
 }
@@ -647,7 +644,7 @@ void select_leg_kernel(gar_hip_solver *s) {
   else if (nx == 8 && nu == 4) bind_leg<8, 4>(s);
   else if (nx == 56 && nu == 24 && !any_nc) {
     const char *sg = std::getenv("GAR_HIP_SEG_LEGS");
-    if (!(sg && sg[0] == '0') && (size_t)gar::leg_param_lds_doubles(56, 24) * sizeof(double) <= 160 * 1024)
+    if (!(sg && sg[0] == '0') && (size_t)gar::leg_stage_lds_doubles(56, 24) * sizeof(double) <= 160 * 1024)
       bind_seg_leg<56, 24>(s);
   }
   s->fold = any_nc && s->leg_bwd_kernel != nullptr;
@@ -1259,14 +1256,15 @@ int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
     Q.nxb = s->nxb;
     Q.nxM = s->dims5[0];
     Q.nuM = s->dims5[1];
-    Q.tgain = s->d_tgain;
-    Q.tgain_stride = s->tgain_doubles;
     Q.local_legs = l1 - l0;
-    // T_t = Rhat_t^{-1} B_t^T of every stage of the non-final legs at once, then the recursion (products only)
-    hipLaunchKernelGGL(gar::gar_leg_param_prepare, dim3((unsigned)N, (unsigned)s->batch), dim3(256),
-                       (size_t)gar::leg_prepare_lds_doubles(s->dims5[0], s->dims5[1]) * sizeof(double), s->stream, Q);
-    hipLaunchKernelGGL(gar::gar_leg_param_generic, grid, dim3(GAR_LEG_PARAM_THREADS), (size_t)s->seg_param_lds_doubles * sizeof(double),
-                       s->stream, Q);
+    // the chain of Vxt alone per leg; everything else of every stage at once; the running sums and the tuples
+    {
+      hipLaunchKernelGGL(gar::gar_leg_param_chain, grid, dim3(GAR_LEG_PARAM_THREADS),
+                         (size_t)gar::leg_chain_lds_doubles(s->dims5[0]) * sizeof(double), s->stream, Q);
+      hipLaunchKernelGGL(gar::gar_leg_param_stage, dim3((unsigned)N + 1, (unsigned)s->batch), dim3(GAR_LEG_STAGE_THREADS),
+                         (size_t)gar::leg_stage_lds_doubles(s->dims5[0], s->dims5[1]) * sizeof(double), s->stream, Q);
+      hipLaunchKernelGGL(gar::gar_leg_param_finish, grid, dim3(1024), 0, s->stream, Q);
+    }
     HIP_TRY(hipGetLastError());
     if (s->timing && last)
       HIP_TRY(hipEventRecord(s->ev[1], s->stream));
@@ -1562,8 +1560,6 @@ void free_device(gar_hip_solver *s) {
 
   (void)hipFree(s->d_prob2);
   (void)hipFree(s->d_fac2);
-  (void)hipFree(s->d_tgain);
-  s->d_tgain = nullptr;
   (void)hipFree(s->d_meta2);
   s->d_prob2 = s->d_fac2 = nullptr;
   s->d_meta2 = nullptr;
@@ -1644,12 +1640,10 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipMemcpy(s->d_meta2, f->meta.data(), sizeof(gar_stage_meta) * f->meta.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute((const void *)s->seg_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(s->seg_lds_doubles * sizeof(double))));
-    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_leg_param_generic, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(s->seg_param_lds_doubles * sizeof(double))));
-    s->tgain_doubles = (int64_t)(s->horizon + 1) * s->dims5[0] * s->dims5[1];
-    HIP_TRY(gar_dev_malloc((void **)&s->d_tgain, sizeof(double) * (size_t)s->tgain_doubles * B));
-    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_leg_param_prepare, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(gar::leg_prepare_lds_doubles(s->dims5[0], s->dims5[1]) * sizeof(double))));
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_leg_param_chain, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(gar::leg_chain_lds_doubles(s->dims5[0]) * sizeof(double))));
+    HIP_TRY(hipFuncSetAttribute((const void *)gar::gar_leg_param_stage, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(gar::leg_stage_lds_doubles(s->dims5[0], s->dims5[1]) * sizeof(double))));
   }
   if (s->fold) {
     const gar_hip_solver *f = s->flay;
@@ -3150,12 +3144,6 @@ extern "C" int gar_hip_debug_crtrace(long long *out) {
   long long z[16] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_crtrace), sizeof(z)) != hipSuccess) return 1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_crtrace), z, sizeof(z)) != hipSuccess) return 2;
-  return 0;
-}
-extern "C" int gar_hip_debug_ptrace(long long *out) {
-  long long z[16] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_ptrace), sizeof(z)) != hipSuccess) return 1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_ptrace), z, sizeof(z)) != hipSuccess) return 2;
   return 0;
 }
 #endif

@@ -16,10 +16,10 @@
 //         Ghat_u = B^T Vxt',  Kth = -Rhat^-1 Ghat_u,  Yth = B Kth,
 //         Vxt = Aff^T Vxt',   Vtt = Vtt' + Ghat_u^T Kth,  vt = vt' + Vxt'^T yff
 //       started from Vxt' = I, Vtt' = 0, vt' = 0 -- which reproduces (1)'s parameter outputs at the leg end.
-//       gar_leg_param_generic runs it for ANY dimensions (one workgroup per (leg, problem), blocks in LDS, f64
-//       MFMA through wg_gemm, the workgroup Bunch-Kaufman of gar_device.hpp on Rhat -- the reference's own
-//       factorisation), after the plain kernel of the same launch sequence, and writes the caller-visible
-//       records (fth = [Kth; Yth], Vxt, Vtt, vt beside the copied ff, fb, Vxx, vx) and the leg's boundary tuple.
+//       The gar_leg_param_* kernels below run it for ANY dimensions (blocks in LDS, f64 MFMA through wg_gemm, the
+//       workgroup LDL^T / Bunch-Kaufman of gar_device.hpp on Rhat -- the reference's own factorisation), after the
+//       plain kernel of the same launch sequence, and write the caller-visible records (fth = [Kth; Yth], Vxt,
+//       Vtt, vt beside the copied ff, fb, Vxx, vx) and the leg's boundary tuple.
 // Like terminalSolve, the leg-end record keeps yff, Aff and Yth at zero (:130-193 never writes them).
 #pragma once
 #include "gar_device.hpp"
@@ -102,25 +102,127 @@ struct LegParamParams {
   long long prob_stride, fac_stride, fac2_stride, boundary_stride;
   int horizon, num_legs, leg_begin, tuple_doubles, nxb;
   int nxM, nuM; // largest nx, nu (LDS carve)
-  double *tgain;          // [problem][stage][nuM x nxM]: T_t = Rhat_t^{-1} B_t^T (gar_leg_param_prepare)
-  long long tgain_stride; // doubles per problem
   int local_legs;
 };
 
-__host__ __device__ inline int leg_param_lds_doubles(int nx, int nu) { // the recursion: Xa Xb Tt Af | Bm Tm Gh Kt | vt vtn yf
-  auto a2 = [](int x) { return (x + 1) & ~1; };
-  return 4 * a2(nx * nx) + 4 * a2(nx * nu) + 3 * a2(nx) + 64;
-}
-__host__ __device__ inline int leg_prepare_lds_doubles(int nx, int nu) { // V' | Bm VB Tm | Rh | wk | sub piv ctrl
+__host__ __device__ inline int leg_prepare_lds_doubles(int nx, int nu) { // V' | Bm VB Tm | Rh Rc | wk | sub piv ctrl (the front of gar_leg_param_stage's carve)
   auto a2 = [](int x) { return (x + 1) & ~1; };
   return a2(nx * nx) + 3 * a2(nx * nu) + 2 * a2(nu * nu) + a2(GAR_LDL_PANEL * nu) + 2 * a2(nu) + 64;
 }
 
-// What the parameter recursion needs of Rhat_t = R_t + B_t^T V'_{t+1} B_t is the operator T_t = Rhat_t^{-1} B_t^T
-// (Kth = -T_t Vxt', a product) -- and T_t does not depend on the recursion's state: every stage of every non-final
-// leg at once, one workgroup each (grid (stages, batch) x 256).  The factorisation and the substitution leave the
-// sequential path this way.  V'_{t+1} is the plain kernel's Vxx of stage t + 1 (zero behind a leg end).
-__global__ void __launch_bounds__(256) gar_leg_param_prepare(LegParamParams P) {
+#ifndef GAR_LEG_PARAM_THREADS
+#define GAR_LEG_PARAM_THREADS 1024
+#endif
+// ---- (2) the parameter part, split by what is sequential ---------------------------------------------------------
+// Of the recursion above only  Vxt_t = Aff_t^T Vxt_{t+1}  chains the stages of a leg; everything else of stage t is a
+// function of Vxt_{t+1} (and of that stage's own operands), and Vtt / vt are running sums of per-stage increments:
+//   (2a) gar_leg_param_chain   one workgroup per (leg, problem): the chain of products alone, Vxt of every stage
+//                              written to its record (a stage: one 56 x 56 x 56 product, its operand prefetched);
+//   (2b) gar_leg_param_stage   one workgroup per (STAGE, problem), all stages at once: Rhat_t = R + B^T V' B, its
+//                              factorisation, T = Rhat^{-1} B^T, then
+//                              Ghat_u = B^T Vxt', Kth = -T Vxt', Yth = B Kth, the increments Ghat_u^T Kth and
+//                              Vxt'^T yff, and the caller-visible record;
+//   (2c) gar_leg_param_finish  one workgroup per (leg, problem): Vtt, vt summed from the leg end down (elementwise,
+//                              a thread per element), the boundary tuple.
+// The sequential path of a leg of 8 stages drops from 8 x (4 products + record traffic) to 8 products.
+__host__ __device__ inline int leg_chain_lds_doubles(int nx) {
+  auto a2 = [](int x) { return (x + 1) & ~1; };
+  return 3 * a2(nx * nx) + 64;
+}
+__host__ __device__ inline int leg_stage_lds_doubles(int nx, int nu) { // leg_prepare's carve + Gh Kt | yf
+  auto a2 = [](int x) { return (x + 1) & ~1; };
+  return leg_prepare_lds_doubles(nx, nu) + 2 * a2(nx * nu) + a2(nx);
+}
+
+__global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_chain(LegParamParams P) {
+  const WG w = wg_self();
+  double *sm = gar_smem;
+  const int leg = (int)blockIdx.x + P.leg_begin, b = (int)blockIdx.y;
+  if (leg == P.num_legs - 1)
+    return;
+  int t_beg, t_end;
+  gar_get_work(P.horizon, leg, P.num_legs, &t_beg, &t_end);
+  const double *fac2 = P.fac2 + (long long)b * P.fac2_stride;
+  double *fac = P.fac + (long long)b * P.fac_stride;
+  auto a2 = [](int x) { return (x + 1) & ~1; };
+  const int nxM = P.nxM;
+  double *Xt = sm, *Xn = Xt + a2(nxM * nxM), *Af = Xn + a2(nxM * nxM);
+  const int nth = P.meta[t_end - 1].nx2;
+  constexpr int PRE = 4; // the next stage's Aff in flight under the product (registers), up to PRE x nthr doubles
+  double pre[PRE];
+  // the stage descriptors run TWO stages ahead of the product (a descriptor read, then the operand reads it addresses,
+  // are two dependent round trips to memory: neither may sit on the chain)
+  struct Desc {
+    int nx, nu, nx2;
+    long long aff, vxt; // offsets of Aff (scratch records) and of Vxt (caller-visible records)
+  };
+  auto desc = [&](int t) {
+    const gar_stage_meta m = P.meta[t < t_beg ? t_beg : t];
+    Desc d;
+    d.nx = m.nx, d.nu = m.nu, d.nx2 = m.nx2;
+    d.aff = P.meta2[t < t_beg ? t_beg : t].fac_off + gar_factor_layout(m.nx, m.nu, 0, m.nx2, 0).fb + m.nu * m.nx;
+    d.vxt = m.fac_off + gar_factor_layout(m.nx, m.nu, 0, m.nx2, nth).Vxt;
+    return d;
+  };
+  Desc cur = desc(t_end - 1), nxt = desc(t_end - 2);
+  {
+    const double *a = fac2 + cur.aff;
+    wg_move8(w, cur.nx2 * cur.nx, [&](int e) { return a[e]; }, [&](int e, double v) { Af[e] = v; });
+    for (int e = w.tid; e < nth * nth; e += w.nthr)
+      Xt[e] = ((e / nth) == (e % nth)) ? 1.0 : 0.0;
+  }
+  // (the barriers order LDS only: the record stores of one stage and the operand loads of the next stay in flight)
+  for (int t = t_end - 1; t >= t_beg; --t) {
+    const int nx = cur.nx, nx2 = cur.nx2;
+    wg_lds_bar(); // Af, Xt complete
+    const Desc nnv = desc(t - 2);
+    const int ncnt = nxt.nx2 * nxt.nx;
+    const double *na = fac2 + nxt.aff;
+    if (t > t_beg) {
+#pragma unroll
+      for (int q = 0; q < PRE; ++q) {
+        const int e = w.tid + q * w.nthr;
+        pre[q] = na[e < ncnt ? e : ncnt - 1];
+      }
+    }
+    // Vxt = Aff^T Vxt'  (:305-306; at the leg end Aff^T I = A^T + K^T B^T, :186)
+    wg_gemm(w, nx, nth, nx2, rowmajor(Af, nx).T(), colmajor(Xt, nx2), MatV{nullptr, 0, 0}, colmajor(Xn, nx), 1.0);
+    wg_lds_bar();
+    // first everything that WAITS for loads -- the next operand into LDS, the descriptor two stages ahead into scalar
+    // registers -- then the record stores: gfx9 counts loads and stores on one in-order counter, so a wait for a load
+    // issued behind a store is a wait for that store's acknowledgement too
+    if (t > t_beg) {
+#pragma unroll
+      for (int q = 0; q < PRE; ++q) {
+        const int e = w.tid + q * w.nthr;
+        if (e < ncnt)
+          Af[e] = pre[q];
+      }
+      for (int e = w.tid + PRE * w.nthr; e < ncnt; e += w.nthr)
+        Af[e] = na[e];
+    }
+    Desc nn;
+    nn.nx = __builtin_amdgcn_readfirstlane(nnv.nx), nn.nu = __builtin_amdgcn_readfirstlane(nnv.nu);
+    nn.nx2 = __builtin_amdgcn_readfirstlane(nnv.nx2);
+    nn.aff = ((long long)__builtin_amdgcn_readfirstlane((int)(nnv.aff >> 32)) << 32) |
+             (unsigned)__builtin_amdgcn_readfirstlane((int)nnv.aff);
+    nn.vxt = ((long long)__builtin_amdgcn_readfirstlane((int)(nnv.vxt >> 32)) << 32) |
+             (unsigned)__builtin_amdgcn_readfirstlane((int)nnv.vxt);
+    double *dst = fac + cur.vxt;
+    wg_move8(w, nx * nth, [&](int e) { return Xn[e]; }, [&](int e, double v) { dst[e] = v; });
+    double *tmp = Xt;
+    Xt = Xn;
+    Xn = tmp;
+    cur = nxt;
+    nxt = nn;
+  }
+}
+
+#ifndef GAR_LEG_STAGE_THREADS
+#define GAR_LEG_STAGE_THREADS 512
+#endif
+// grid (N + 1, batch) x GAR_LEG_STAGE_THREADS
+__global__ void __launch_bounds__(GAR_LEG_STAGE_THREADS) gar_leg_param_stage(LegParamParams P) {
   const WG w = wg_self();
   double *sm = gar_smem;
   const int t = (int)blockIdx.x, b = (int)blockIdx.y;
@@ -130,14 +232,22 @@ __global__ void __launch_bounds__(256) gar_leg_param_prepare(LegParamParams P) {
     if (t >= t_beg && t < t_end)
       break;
   }
-  if (leg >= P.leg_begin + P.local_legs || leg == P.num_legs - 1)
+  if (leg >= P.leg_begin + P.local_legs)
     return;
-  const bool leg_end = (t == t_end - 1);
   const double *prob = P.prob + (long long)b * P.prob_stride;
   const double *fac2 = P.fac2 + (long long)b * P.fac2_stride;
+  double *fac = P.fac + (long long)b * P.fac_stride;
   const gar_stage_meta m = P.meta[t];
-  const int nx = m.nx, nu = m.nu, nx2 = m.nx2;
-  (void)nx;
+  const int nx = m.nx, nu = m.nu, nx2 = m.nx2, nr = nu + nx2;
+  const double *src = fac2 + P.meta2[t].fac_off;
+  double *dst = fac + m.fac_off;
+  if (leg == P.num_legs - 1) { // unparameterised records: the scratch layout's, at the caller-visible offsets
+    const int n = (int)gar_factor_doubles(m.nx, m.nu, m.nc, m.nx2, 0);
+    wg_move8(w, n, [&](int e) { return src[e]; }, [&](int e, double v) { dst[e] = v; });
+    return;
+  }
+  const bool leg_end = (t == t_end - 1);
+  const int nth = P.meta[t_end - 1].nx2; // the parameter: the next leg's first costate
   auto a2 = [](int x) { return (x + 1) & ~1; };
   const int nxM = P.nxM, nuM = P.nuM;
   double *p = sm;
@@ -145,23 +255,30 @@ __global__ void __launch_bounds__(256) gar_leg_param_prepare(LegParamParams P) {
   double *Vn = take(nxM * nxM), *Bm = take(nxM * nuM), *VB = take(nxM * nuM), *Tm = take(nxM * nuM);
   double *Rh = take(nuM * nuM), *Rc = take(nuM * nuM), *wk = take(GAR_LDL_PANEL * nuM), *sub = take(nuM);
   int *piv = (int *)take(nuM), *ctrl = (int *)take(16);
+  double *Gh = take(nuM * nxM), *Kt = take(nuM * nxM), *yf = take(nxM);
   const gar_knot_offsets ko = gar_knot_layout(m.nx, nu, 0, nx2, 0);
+  const gar_factor_offsets f2 = gar_factor_layout(nx, nu, 0, nx2, 0), fo = gar_factor_layout(nx, nu, 0, nx2, nth);
   const double *knot = prob + m.in_off;
-  for (int e = w.tid; e < nx2 * nu; e += w.nthr) {
-    const double v = knot[ko.B + e];
+  wg_move8(w, nx2 * nu, [&](int e) { return knot[ko.B + e]; }, [&](int e, double v) {
     Bm[e] = v;
-    Tm[(e / nx2) * nx2 + (e % nx2)] = v; // B^T (nu x nx2, row-major) = B column-major, as it is
-  }
-  for (int e = w.tid; e < nu * nu; e += w.nthr)
-    Rh[e] = knot[ko.R + e];
+    Tm[e] = v; // B^T (nu x nx2, row-major) = B column-major, as it is
+  });
+  wg_move8(w, nu * nu, [&](int e) { return knot[ko.R + e]; }, [&](int e, double v) { Rh[e] = v; });
+  for (int e = w.tid; e < nx2; e += w.nthr)
+    yf[e] = src[f2.ff + nu + e];
   if (!leg_end) { // V' symmetrised from its lower triangle as the consuming stage does (:216)
     const gar_stage_meta mn = P.meta[t + 1];
     const double *Vg = fac2 + P.meta2[t + 1].fac_off + gar_factor_layout(mn.nx, mn.nu, 0, mn.nx2, 0).Vxx;
-    for (int e = w.tid; e < nx2 * nx2; e += w.nthr) {
+    wg_move8(w, nx2 * nx2, [&](int e) {
       const int j = e / nx2, i = e - j * nx2;
-      Vn[e] = (i >= j) ? Vg[e] : Vg[i * nx2 + j];
-    }
+      return (i >= j) ? Vg[e] : Vg[i * nx2 + j]; }, [&](int e, double v) { Vn[e] = v; });
   }
+  // the plain part of the caller-visible record, ff | fb | Vxx | vx, while the operands arrive (leg end: yff, Aff zero)
+  for (int e = w.tid; e < nr; e += w.nthr)
+    dst[fo.ff + e] = (leg_end && e >= nu) ? 0.0 : src[f2.ff + e];
+  wg_move8(w, nr * nx, [&](int e) { return src[f2.fb + e]; },
+           [&](int e, double v) { dst[fo.fb + e] = (leg_end && e >= nu * nx) ? 0.0 : v; });
+  wg_move8(w, nx * nx + nx, [&](int e) { return src[f2.Vxx + e]; }, [&](int e, double v) { dst[fo.Vxx + e] = v; }); // Vxx | vx
   __syncthreads();
   const MatV B = colmajor(Bm, nx2);
   if (!leg_end) { // Rhat = R + B^T (V' B)  (:221, :225)
@@ -169,6 +286,15 @@ __global__ void __launch_bounds__(256) gar_leg_param_prepare(LegParamParams P) {
     __syncthreads();
     wg_gemm(w, nu, nu, nx2, B.T(), colmajor(VB, nx2), colmajor(Rh, nu), colmajor(Rh, nu), 1.0);
     __syncthreads();
+  }
+  // Vxt' of this stage (the chain kernel's record of stage t + 1; the identity behind the leg end) takes V's place
+  if (leg_end) {
+    for (int e = w.tid; e < nx2 * nth; e += w.nthr)
+      Vn[e] = ((e / nx2) == (e % nx2)) ? 1.0 : 0.0;
+  } else {
+    const gar_stage_meta mn = P.meta[t + 1];
+    const double *Xg = fac + mn.fac_off + gar_factor_layout(mn.nx, mn.nu, 0, mn.nx2, nth).Vxt;
+    wg_move8(w, nx2 * nth, [&](int e) { return Xg[e]; }, [&](int e, double v) { Vn[e] = v; });
   }
   // Rhat > 0 on a well-posed stage: blocked elimination without pivoting; otherwise Bunch-Kaufman as in the reference
   int failed = 0, indefinite = 1;
@@ -187,163 +313,81 @@ __global__ void __launch_bounds__(256) gar_leg_param_prepare(LegParamParams P) {
     failed |= wg_bk_factor(w, nu, Rh, nu, sub, piv, ctrl);
   __syncthreads();
   wg_bk_solve(w, nu, Rh, nu, sub, piv, Tm, nx2, 1, nx2); // T = Rhat^{-1} B^T, rows of nx2
-  double *Tg = P.tgain + (long long)b * P.tgain_stride + (long long)t * nuM * nxM;
-  for (int e = w.tid; e < nu * nx2; e += w.nthr)
-    Tg[e] = Tm[e];
+  __syncthreads();
+  const MatV X = colmajor(Vn, nx2), G = rowmajor(Gh, nth), K = rowmajor(Kt, nth);
+  // Ghat_u = B^T Vxt' (:286-287),  Kth = -Rhat^{-1} Ghat_u = -T Vxt' (:288-292)
+  wg_gemm(w, nu, nth, nx2, B.T(), X, MatV{nullptr, 0, 0}, G, 1.0);
+  wg_gemm(w, nu, nth, nx2, rowmajor(Tm, nx2), X, MatV{nullptr, 0, 0}, K, -1.0);
+  __syncthreads();
+  // the increments of the running sums (gar_leg_param_finish adds them up): Ghat_u^T Kth (:308-310), Vxt'^T yff (:301);
+  // Yth = B Kth (:295) -- straight into the record
+  wg_gemm(w, nth, nth, nu, G.T(), K, MatV{nullptr, 0, 0}, colmajor(dst + fo.Vtt, nth), 1.0);
+  wg_gemm(w, nth, 1, nx2, X.T(), colmajor(yf, nx2), MatV{nullptr, 0, 0}, colmajor(dst + fo.vt, nth), 1.0);
+  if (!leg_end)
+    wg_gemm(w, nx2, nth, nu, B, K, MatV{nullptr, 0, 0}, rowmajor(dst + fo.fth + nu * nth, nth), 1.0);
+  // fth = [Kth; Yth]  (Vxt: the chain kernel's; Vtt, vt: the increments, summed by gar_leg_param_finish)
+  for (int e = w.tid; e < nu * nth; e += w.nthr)
+    dst[fo.fth + e] = Kt[e];
+  if (leg_end)
+    for (int e = w.tid; e < nx2 * nth; e += w.nthr)
+      dst[fo.fth + nu * nth + e] = 0.0;
   if (failed && w.tid == 0)
     atomicOr(&P.status[b], failed);
 }
 
-// (debug build -DGAR_CTRACE: cycles per phase of workgroup (0, 0), read with gar_hip_debug_ptrace)
-#ifdef GAR_CTRACE
-__device__ long long g_ptrace[16];
-#define PT(id)                                                                                                         \
-  {                                                                                                                    \
-    __syncthreads();                                                                                                   \
-    const long long now_ = clock64();                                                                                  \
-    if (w.tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)                                                              \
-      g_ptrace[id] += now_ - tprev;                                                                                    \
-    tprev = now_;                                                                                                      \
-  }
-#else
-#define PT(id)
-#endif
-// grid (local legs, batch) x GAR_LEG_PARAM_THREADS
-// (GAR_LEG_PARAM_THREADS threads: the copies between HBM and LDS and the tiles of the products spread over 8 waves;
-// the panel factorisation and the in-block substitutions stay one wave's work)
-#ifndef GAR_LEG_PARAM_THREADS
-#define GAR_LEG_PARAM_THREADS 1024
-#endif
-__global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_generic(LegParamParams P) {
-#ifdef GAR_CTRACE
-  long long tprev = clock64();
-#endif
+// grid (local legs, batch) x 1024
+__global__ void __launch_bounds__(1024) gar_leg_param_finish(LegParamParams P) {
   const WG w = wg_self();
-  double *sm = gar_smem;
   const int leg = (int)blockIdx.x + P.leg_begin, b = (int)blockIdx.y;
   int t_beg, t_end;
   gar_get_work(P.horizon, leg, P.num_legs, &t_beg, &t_end);
   const bool last_leg = (leg == P.num_legs - 1);
-  const double *prob = P.prob + (long long)b * P.prob_stride;
-  const double *fac2 = P.fac2 + (long long)b * P.fac2_stride;
   double *fac = P.fac + (long long)b * P.fac_stride;
-  auto a2 = [](int x) { return (x + 1) & ~1; };
-  const int nxM = P.nxM, nuM = P.nuM;
-  double *p = sm;
-  auto take = [&](int n) { double *o = p; p += a2(n); return o; };
-  double *Xa = take(nxM * nxM), *Xb = take(nxM * nxM), *Tt = take(nxM * nxM), *Af = take(nxM * nxM);
-  double *Bm = take(nxM * nuM), *Tm = take(nxM * nuM), *Gh = take(nuM * nxM), *Kt = take(nuM * nxM);
-  double *vt = take(nxM), *vtn = take(nxM), *yf = take(nxM);
-  double *Xt = Xa, *Xn = Xb; // Vxt' (current) and the buffer the new Vxt goes to
-  const int failed = 0;      // (the factorisations are gar_leg_param_prepare's)
-
-  if (last_leg) { // unparameterised records: the scratch layout's, at the caller-visible offsets
-    for (int t = t_beg; t < t_end; ++t) {
-      const gar_stage_meta m = P.meta[t];
-      const int n = (int)gar_factor_doubles(m.nx, m.nu, m.nc, m.nx2, 0);
-      const double *src = fac2 + P.meta2[t].fac_off;
-      double *dst = fac + m.fac_off;
-      for (int e = w.tid; e < n; e += w.nthr)
-        dst[e] = src[e];
-    }
-  } else {
-    const int nth = P.meta[t_end - 1].nx2; // the parameter: the next leg's first costate
-    for (int e = w.tid; e < nth * nth; e += w.nthr) {
-      Xt[e] = ((e / nth) == (e % nth)) ? 1.0 : 0.0;
-      Tt[e] = 0.0;
-    }
-    for (int e = w.tid; e < nth; e += w.nthr)
-      vt[e] = 0.0;
-    __syncthreads();
-    for (int t = t_end - 1; t >= t_beg; --t) {
-      const gar_stage_meta m = P.meta[t];
-      const int nx = m.nx, nu = m.nu, nx2 = m.nx2, nr = nu + nx2;
-      const bool leg_end = (t == t_end - 1);
-      const gar_knot_offsets ko = gar_knot_layout(nx, nu, 0, nx2, 0);
-      const gar_factor_offsets f2 = gar_factor_layout(nx, nu, 0, nx2, 0), fo = gar_factor_layout(nx, nu, 0, nx2, nth);
-      const double *knot = prob + m.in_off;
-      const double *src = fac2 + P.meta2[t].fac_off;
-      double *dst = fac + m.fac_off;
-      PT(0)
-      // operands: B (nx2 x nu, column-major), Aff (rows nu.. of the row-major fb), yff, T = Rhat^{-1} B^T (prepared)
-      const double *Tg = P.tgain + (long long)b * P.tgain_stride + (long long)t * nuM * nxM;
-      for (int e = w.tid; e < nx2 * nu; e += w.nthr) {
-        Bm[e] = knot[ko.B + e];
-        Tm[e] = Tg[e];
+  const gar_stage_meta m0 = P.meta[t_beg];
+  const int nxb = P.nxb, bs = nxb * nxb, nx = m0.nx, nth = last_leg ? 0 : P.meta[t_end - 1].nx2;
+  double *tup = P.boundary + (long long)b * P.boundary_stride + (long long)blockIdx.x * P.tuple_doubles;
+  const gar_factor_offsets fo0 = gar_factor_layout(m0.nx, m0.nu, m0.nc, m0.nx2, nth);
+  const double *rec = fac + m0.fac_off;
+  // the boundary tuple of this leg: (Vxx | Vxt | Vtt | vx | vt) of its first stage, blocks of nxb;
+  // every element of the tuple is written exactly once
+  wg_move8(w, 2 * bs, [&](int e) {
+    const bool second = e >= bs;
+    const int ee = second ? e - bs : e, j = ee / nxb, i = ee - j * nxb;
+    const bool real = i < nx && j < (second ? nth : nx);
+    return real ? rec[(second ? fo0.Vxt : fo0.Vxx) + j * nx + i] : 0.0; }, [&](int e, double v) { tup[e] = v; });
+  for (int e = w.tid; e < nxb; e += w.nthr)
+    tup[3 * bs + e] = e < nx ? rec[fo0.vx + e] : 0.0;
+  for (int e = w.tid + 3 * bs + 2 * nxb; e < P.tuple_doubles; e += w.nthr)
+    tup[e] = 0.0;
+  // Vtt_t = Vtt_{t+1} + Ghat_u^T Kth, vt_t = vt_{t+1} + Vxt'^T yff from the leg end down: elementwise, in place, the
+  // increments of up to CH stages loaded before the first sum is stored
+  constexpr int CH = 8;
+  for (int e = w.tid; e < bs + nxb; e += w.nthr) {
+    const bool mat = e < bs;
+    const int j = mat ? e / nxb : 0, i = mat ? e - j * nxb : e - bs;
+    const bool real = i < nth && (!mat || j < nth);
+    double acc = 0.0;
+    if (real)
+      for (int t1 = t_end - 1; t1 >= t_beg; t1 -= CH) {
+        double v[CH];
+        double *q[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int t = (t1 - c >= t_beg) ? t1 - c : t_beg;
+          const gar_stage_meta m = P.meta[t];
+          const gar_factor_offsets fo = gar_factor_layout(m.nx, m.nu, 0, m.nx2, nth);
+          q[c] = fac + m.fac_off + (mat ? fo.Vtt + j * nth + i : fo.vt + i);
+          v[c] = *q[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          if (t1 - c >= t_beg) {
+            acc = acc + v[c];
+            *q[c] = acc;
+          }
       }
-      for (int e = w.tid; e < nx2 * nx; e += w.nthr)
-        Af[e] = src[f2.fb + nu * nx + e];
-      for (int e = w.tid; e < nx2; e += w.nthr)
-        yf[e] = src[f2.ff + nu + e];
-      __syncthreads();
-      PT(1)
-      const MatV B = colmajor(Bm, nx2), X = colmajor(Xt, nx2), G = rowmajor(Gh, nth), K = rowmajor(Kt, nth);
-      // everything that is a function of Vxt' alone, in one phase:
-      //   Ghat_u = B^T Vxt' (:286-287),  Kth = -Rhat^{-1} Ghat_u = -T Vxt' (:288-292),  Vxt = Aff^T Vxt' (:305-306; at the
-      //   leg end Aff^T I = A^T + K^T B^T, :186),  vt += Vxt'^T yff (:301)
-      wg_gemm(w, nu, nth, nx2, B.T(), X, MatV{nullptr, 0, 0}, G, 1.0);
-      wg_gemm(w, nu, nth, nx2, rowmajor(Tm, nx2), X, MatV{nullptr, 0, 0}, K, -1.0);
-      wg_gemm(w, nx, nth, nx2, rowmajor(Af, nx).T(), X, MatV{nullptr, 0, 0}, colmajor(Xn, nx), 1.0);
-      wg_gemm(w, nth, 1, nx2, X.T(), colmajor(yf, nx2), colmajor(vt, nth), colmajor(vtn, nth), 1.0);
-      __syncthreads();
-      PT(4)
-      // Vtt += Ghat_u^T Kth  (:308-310),  Yth = B Kth  (:295) straight into the record
-      wg_gemm(w, nth, nth, nu, G.T(), K, colmajor(Tt, nth), colmajor(Tt, nth), 1.0);
-      if (!leg_end)
-        wg_gemm(w, nx2, nth, nu, B, K, MatV{nullptr, 0, 0}, rowmajor(dst + fo.fth + nu * nth, nth), 1.0);
-      __syncthreads();
-      PT(5)
-      // the caller-visible record: ff | fb | fth | Vxx | vx | Vxt | Vtt | vt  (gar_layout.h)
-      for (int e = w.tid; e < nr; e += w.nthr)
-        dst[fo.ff + e] = (leg_end && e >= nu) ? 0.0 : src[f2.ff + e];
-      for (int e = w.tid; e < nr * nx; e += w.nthr)
-        dst[fo.fb + e] = (leg_end && e >= nu * nx) ? 0.0 : src[f2.fb + e];
-      for (int e = w.tid; e < nu * nth; e += w.nthr)
-        dst[fo.fth + e] = Kt[e];
-      if (leg_end)
-        for (int e = w.tid; e < nx2 * nth; e += w.nthr)
-          dst[fo.fth + nu * nth + e] = 0.0;
-      for (int e = w.tid; e < nx * nx + nx; e += w.nthr)
-        dst[fo.Vxx + e] = src[f2.Vxx + e]; // Vxx | vx, contiguous in both layouts
-      for (int e = w.tid; e < nx * nth; e += w.nthr)
-        dst[fo.Vxt + e] = Xn[e];
-      for (int e = w.tid; e < nth * nth; e += w.nthr)
-        dst[fo.Vtt + e] = Tt[e];
-      for (int e = w.tid; e < nth; e += w.nthr) {
-        dst[fo.vt + e] = vtn[e];
-        vt[e] = vtn[e];
-      }
-      __syncthreads();
-      PT(6)
-      double *tmp = Xt;
-      Xt = Xn;
-      Xn = tmp;
-    }
+    tup[(mat ? 2 * bs : 3 * bs + nxb - bs) + e] = acc;
   }
-  __syncthreads();
-  // the boundary tuple of this leg: (Vxx | Vxt | Vtt | vx | vt) of its first stage, blocks of nxb
-  {
-    const gar_stage_meta m = P.meta[t_beg];
-    const int nxb = P.nxb, bs = nxb * nxb, nx = m.nx, nth = last_leg ? 0 : m.nth;
-    const gar_factor_offsets fo = gar_factor_layout(m.nx, m.nu, m.nc, m.nx2, nth);
-    const double *rec = fac + m.fac_off;
-    double *tup = P.boundary + (long long)b * P.boundary_stride + (long long)blockIdx.x * P.tuple_doubles;
-    for (int e = w.tid; e < P.tuple_doubles; e += w.nthr)
-      tup[e] = 0.0;
-    __syncthreads();
-    for (int e = w.tid; e < nx * nx; e += w.nthr)
-      tup[(e / nx) * nxb + (e % nx)] = rec[fo.Vxx + e];
-    for (int e = w.tid; e < nx * nth; e += w.nthr)
-      tup[bs + (e / nx) * nxb + (e % nx)] = rec[fo.Vxt + e];
-    for (int e = w.tid; e < nth * nth; e += w.nthr)
-      tup[2 * bs + (e / nth) * nxb + (e % nth)] = rec[fo.Vtt + e];
-    for (int e = w.tid; e < nx; e += w.nthr)
-      tup[3 * bs + e] = rec[fo.vx + e];
-    for (int e = w.tid; e < nth; e += w.nthr)
-      tup[3 * bs + nxb + e] = rec[fo.vt + e];
-  }
-  if (failed && w.tid == 0)
-    atomicOr(&P.status[b], failed);
 }
 
 } // namespace gar

@@ -23,8 +23,4 @@ for legs in (8, 16):
     s.backward_async(1e-10); s.forward_async(); s.sync()
     lib.gar_hip_debug_ctrace(out)
     print(f"legs={legs}: total {sum(out)} cycles;", {n: int(out[i]) for i, n in enumerate(names)}, flush=True)
-    pt = (C.c_longlong * 16)()
-    lib.gar_hip_debug_ptrace(pt)
-    pn = ["meta", "operand loads", "V'B, Rhat, Ghat products", "factorisation", "substitution", "Vxt, Vtt, vt, Yth products", "record stores"]
-    print(f"   parameter recursion of leg 0 (both sweeps since the last read): total {sum(pt)};", {n: int(pt[i]) for i, n in enumerate(pn)}, flush=True)
     s.close()

@@ -204,7 +204,8 @@ inline double __hiloint2double(int hi, int lo) {
 inline void __builtin_amdgcn_wave_barrier() {
   emu::wave().bar.arrive_and_wait();
 }
-#define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
+#define __builtin_amdgcn_fence(order, ...) std::atomic_thread_fence(std::memory_order_seq_cst)
+inline void __builtin_amdgcn_s_barrier() { emu::block->bar.arrive_and_wait(); }
 inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 inline long long clock64() { return 0; }
