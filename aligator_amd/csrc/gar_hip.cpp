@@ -1791,6 +1791,10 @@ void strip_solution_rec(const gar_hip_solver *s, const double *dev, double *rec)
 
 static int fetch_results_impl(gar_hip_solver *s, int b, int what, int t_lo, int t_hi, double *gains_base, bool sync);
 static int prefetch_impl(gar_hip_solver *s, int b);
+static int upload_stage_impl(gar_hip_solver *s, int b, int t, const double *Q, const double *S, const double *R,
+                             const double *q, const double *r, const double *A, const double *B, const double *f,
+                             const double *C, const double *D, const double *d, const double *Gth, const double *Gx,
+                             const double *Gu, const double *Gv, const double *gamma);
 #include "gar_multi.hpp"
 
 extern "C" {
@@ -2092,33 +2096,59 @@ static int upload_stage_dev(gar_hip_solver *s, int b, int t, const double *Q, co
   if (!Q || !q || !A || !f || (nu > 0 && (!S || !R || !r || !B)))
     return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_stage: null block");
   int rc = 0;
+  // staged: the blocks are copied into the pinned record and the KNOT becomes one dirty range (the holes the packed
+  // triangles of Q and R leave inside their blocks included: block-by-block ranges would not merge, and a problem
+  // would go out as two small copies per knot instead of 1 MiB pieces)
+  auto put = [&](int64_t off, const double *src, int64_t n) {
+    if (n <= 0)
+      return;
+    if (!s->staged) {
+      rc |= write_block(s, b, off, src, n);
+      return;
+    }
+    double *dst = s->h_prob + (int64_t)b * s->prob_doubles + off;
+    if (src)
+      stage_copy(dst, src, (size_t)n, s->stage_nt);
+    else
+      std::memset(dst, 0, sizeof(double) * (size_t)n);
+  };
   if (s->qr_packed && t < s->horizon) { // Q, R: their lower triangles, packed, in the first n (n + 1) / 2 doubles of the block
-    thread_local std::vector<double> pq, pr;
-    pq.resize((size_t)nx * (nx + 1) / 2);
-    pr.resize((size_t)nu * (nu + 1) / 2);
-    pack_lower(pq.data(), Q, nx, nx, 0.0);
-    pack_lower(pr.data(), R, nu, nu, 0.0);
-    rc |= write_block(s, b, base + o.Q, pq.data(), (int64_t)pq.size());
-    rc |= write_block(s, b, base + o.R, pr.data(), (int64_t)pr.size());
+    if (s->staged) {
+      double *rec = s->h_prob + (int64_t)b * s->prob_doubles + base;
+      pack_lower(rec + o.Q, Q, nx, nx, 0.0);
+      pack_lower(rec + o.R, R, nu, nu, 0.0);
+    } else {
+      thread_local std::vector<double> pq, pr;
+      pq.resize((size_t)nx * (nx + 1) / 2);
+      pr.resize((size_t)nu * (nu + 1) / 2);
+      pack_lower(pq.data(), Q, nx, nx, 0.0);
+      pack_lower(pr.data(), R, nu, nu, 0.0);
+      put(base + o.Q, pq.data(), (int64_t)pq.size());
+      put(base + o.R, pr.data(), (int64_t)pr.size());
+    }
   } else {
-    rc |= write_block(s, b, base + o.Q, Q, (int64_t)nx * nx);
-    rc |= write_block(s, b, base + o.R, R, (int64_t)nu * nu);
+    put(base + o.Q, Q, (int64_t)nx * nx);
+    put(base + o.R, R, (int64_t)nu * nu);
   }
-  rc |= write_block(s, b, base + o.S, S, (int64_t)nx * nu);
-  rc |= write_block(s, b, base + o.q, q, nx);
-  rc |= write_block(s, b, base + o.r, r, nu);
-  rc |= write_block(s, b, base + o.A, A, (int64_t)nx2 * nx);
-  rc |= write_block(s, b, base + o.B, B, (int64_t)nx2 * nu);
-  rc |= write_block(s, b, base + o.f, f, nx2);
-  rc |= write_block(s, b, base + o.C, C, (int64_t)nc * nx);
-  rc |= write_block(s, b, base + o.D, D, (int64_t)nc * nu);
-  rc |= write_block(s, b, base + o.d, d, nc);
+  put(base + o.S, S, (int64_t)nx * nu);
+  put(base + o.q, q, nx);
+  put(base + o.r, r, nu);
+  put(base + o.A, A, (int64_t)nx2 * nx);
+  put(base + o.B, B, (int64_t)nx2 * nu);
+  put(base + o.f, f, nx2);
+  put(base + o.C, C, (int64_t)nc * nx);
+  put(base + o.D, D, (int64_t)nc * nu);
+  put(base + o.d, d, nc);
   if (nth_st > 0) {
-    rc |= write_block(s, b, base + o.Gth, Gth, (int64_t)nth_st * nth_st);
-    rc |= write_block(s, b, base + o.Gx, Gx, (int64_t)nx * nth_st);
-    rc |= write_block(s, b, base + o.Gu, Gu, (int64_t)nu * nth_st);
-    rc |= write_block(s, b, base + o.Gv, Gv, (int64_t)nc * nth_st);
-    rc |= write_block(s, b, base + o.gamma, gamma, nth_st);
+    put(base + o.Gth, Gth, (int64_t)nth_st * nth_st);
+    put(base + o.Gx, Gx, (int64_t)nx * nth_st);
+    put(base + o.Gu, Gu, (int64_t)nu * nth_st);
+    put(base + o.Gv, Gv, (int64_t)nc * nth_st);
+    put(base + o.gamma, gamma, nth_st);
+  }
+  if (s->staged) {
+    mark_dirty(s, b, base, base + gar_knot_doubles(nx, nu, nc, nx2, nth_st));
+    return flush_if_grown(s, b);
   }
   return rc ? GAR_HIP_ERR_DEVICE : GAR_HIP_OK;
 }
@@ -2271,6 +2301,9 @@ int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, cons
   // their own -- the sweep of a chunk takes as long as the sweep of all legs, a leg being a sequential chain over its
   // stages, so the critical path stays packing + one leg + condensed solve; chunks on one stream add their sweeps:
   // (56, 22), 32 legs: 2.35 -> 2.95 ms per Newton iteration.)
+  // (Measured and not kept, round 4: a second host thread packing alternate 1 MiB chunks of a >= 12 MiB problem --
+  // (56, 22), 32 legs: 1.53-1.57 -> 1.50 ms for this call, the link and the host's memory system are the bound, not
+  // the packing core; profiles/r04_seam_two_packing_threads_not_kept.json.)
   for (int t = 0; t <= N; ++t)
     if (int rc = upload(t))
       return rc;
@@ -2551,6 +2584,7 @@ static int fetch_results_impl(gar_hip_solver *s, int b, int what, int t_lo, int 
       (void)hipFree(dgo);
       return fail(GAR_HIP_ERR_DEVICE, std::string("gar_hip_fetch_results: ") + hipGetErrorString(e));
     }
+    std::memset(h, 0, sizeof(double) * (nsol + ngain + nscratch)); // (alignment padding inside the records reads as zero)
     s->h_results = h;
     s->d_gains = dg;
     s->d_gain_off = dgo;
@@ -3049,6 +3083,13 @@ int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const
   if (int rc = check_bt(s, b, t))
     return rc;
   GAR_MULTI(s, gar_hip_upload_stage(multi_owner(s, t), b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma));
+  return upload_stage_impl(s, b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma);
+}
+
+static int upload_stage_impl(gar_hip_solver *s, int b, int t, const double *Q, const double *S, const double *R,
+                             const double *q, const double *r, const double *A, const double *B, const double *f,
+                             const double *C, const double *D, const double *d, const double *Gth, const double *Gx,
+                             const double *Gu, const double *Gv, const double *gamma) {
   if (!s->padded)
     return upload_stage_dev(s, b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma);
   const gar_stage_meta &m = s->meta[t];

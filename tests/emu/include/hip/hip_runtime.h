@@ -227,7 +227,8 @@ inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return 0; }
-inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return 0; }
+inline long long &emu_memcpy_async_calls() { static long long n = 0; return n; } // (tests count the copies a call sequence issues)
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { ++emu_memcpy_async_calls(); std::memmove(d, s, n); return 0; }
 inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 inline hipError_t hipMemset2DAsync(void *d, size_t pitch, int v, size_t w, size_t h, hipStream_t) {

@@ -611,6 +611,25 @@ def test_wide_shape_in_leg_mode_segment_legs():
     assert s.kernel_name == "pair_leg<56,24>" and not s.padded
 
 
+def test_staged_problem_goes_out_in_few_copies():
+    """One Newton iteration's re-read of the problem (gar_hip_backward_blocks) leaves the pinned staging area in
+    1 MiB pieces: a knot is ONE dirty range also when Q and R are kept as packed lower triangles (the holes inside
+    their blocks travel along) -- counted on the emulator's hipMemcpyAsync: a handful of copies per call, not two
+    per knot (round 4 found 2 N + 3 of them behind the packed triangles)."""
+    import ctypes as C
+    from aligator_amd.gar import BatchedRiccatiSolver
+    lib = C.CDLL(EMU)
+    lib.emu_memcpy_async_count.restype = C.c_longlong
+    for nx, nu, N, legs in ((36, 12, 48, 1), (8, 4, 64, 4), (10, 3, 40, 1)):
+        prob = synth.generate_lq_problem(3, np.zeros(nx), N, nx, nu, mode="W")
+        s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs, lib_path=EMU)
+        assert s.backward_blocks(prob, 1e-10)
+        c0 = lib.emu_memcpy_async_count()
+        assert s.backward_blocks(prob, 1e-10)
+        assert lib.emu_memcpy_async_count() - c0 <= 8, (nx, nu, N)
+        s.close()
+
+
 def test_serial_family_keeps_vxx_as_its_packed_lower_triangle():
     """The record format csrc/gar_layout.h documents (gar_sym_index): in the serial one-wave family the Vxx block of
     a factor record holds the lower triangle, rectangular packed, in its first nx (nx + 1) / 2 doubles and nothing
