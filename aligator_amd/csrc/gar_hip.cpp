@@ -3181,6 +3181,12 @@ extern "C" int gar_hip_debug_ctrace(long long *out) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_ctrace), z, sizeof(z)) != hipSuccess) return 2;
   return 0;
 }
+extern "C" int gar_hip_debug_ptrace(long long *out) {
+  long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_ptrace), sizeof(z)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_ptrace), z, sizeof(z)) != hipSuccess) return 2;
+  return 0;
+}
 extern "C" int gar_hip_debug_crtrace(long long *out) {
   long long z[16] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_crtrace), sizeof(z)) != hipSuccess) return 1;

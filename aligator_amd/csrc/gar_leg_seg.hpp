@@ -117,7 +117,11 @@ __host__ __device__ inline int leg_prepare_lds_doubles(int nx, int nu) { // V' |
 // Of the recursion above only  Vxt_t = Aff_t^T Vxt_{t+1}  chains the stages of a leg; everything else of stage t is a
 // function of Vxt_{t+1} (and of that stage's own operands), and Vtt / vt are running sums of per-stage increments:
 //   (2a) gar_leg_param_chain   one workgroup per (leg, problem): the chain of products alone, Vxt of every stage
-//                              written to its record (a stage: one 56 x 56 x 56 product, its operand prefetched);
+//                              written to its record (a stage: one 56 x 56 x 56 product, its operand prefetched;
+//                              traced, scripts/ctrace_leg_chain.py: 15-16 k cycles per stage, 7 k of them the product on
+//                              wave 0 + 2.7 k waiting for the other 15 -- 14 MFMAs per wave, four waves per SIMD: the
+//                              masking and address arithmetic of the any-dimension wg_gemm shares the issue port with the
+//                              MFMAs; an odd LDS pitch for Vxt', fewer waves, operands fetched a group ahead: no effect);
 //   (2b) gar_leg_param_stage   one workgroup per (STAGE, problem), all stages at once: Rhat_t = R + B^T V' B, its
 //                              factorisation, T = Rhat^{-1} B^T, then
 //                              Ghat_u = B^T Vxt', Kth = -T Vxt', Yth = B Kth, the increments Ghat_u^T Kth and
@@ -134,7 +138,22 @@ __host__ __device__ inline int leg_stage_lds_doubles(int nx, int nu) { // leg_pr
   return leg_prepare_lds_doubles(nx, nu) + 2 * a2(nx * nu) + a2(nx);
 }
 
+#ifdef GAR_CTRACE
+__device__ long long g_ptrace[16];
+#define CHT(id)                                                                                                        \
+  {                                                                                                                    \
+    const long long now_ = clock64();                                                                                  \
+    if (w.tid == 0 && blockIdx.x == 1 && blockIdx.y == 0)                                                              \
+      g_ptrace[id] += now_ - tprev;                                                                                    \
+    tprev = now_;                                                                                                      \
+  }
+#else
+#define CHT(id)
+#endif
 __global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_chain(LegParamParams P) {
+#ifdef GAR_CTRACE
+  long long tprev = clock64();
+#endif
   const WG w = wg_self();
   double *sm = gar_smem;
   const int leg = (int)blockIdx.x + P.leg_begin, b = (int)blockIdx.y;
@@ -174,7 +193,9 @@ __global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_chain(Leg
   // (the barriers order LDS only: the record stores of one stage and the operand loads of the next stay in flight)
   for (int t = t_end - 1; t >= t_beg; --t) {
     const int nx = cur.nx, nx2 = cur.nx2;
+    CHT(0)
     wg_lds_bar(); // Af, Xt complete
+    CHT(1)
     const Desc nnv = desc(t - 2);
     const int ncnt = nxt.nx2 * nxt.nx;
     const double *na = fac2 + nxt.aff;
@@ -185,9 +206,12 @@ __global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_chain(Leg
         pre[q] = na[e < ncnt ? e : ncnt - 1];
       }
     }
+    CHT(2)
     // Vxt = Aff^T Vxt'  (:305-306; at the leg end Aff^T I = A^T + K^T B^T, :186)
     wg_gemm(w, nx, nth, nx2, rowmajor(Af, nx).T(), colmajor(Xt, nx2), MatV{nullptr, 0, 0}, colmajor(Xn, nx), 1.0);
+    CHT(3)
     wg_lds_bar();
+    CHT(4)
     // first everything that WAITS for loads -- the next operand into LDS, the descriptor two stages ahead into scalar
     // registers -- then the record stores: gfx9 counts loads and stores on one in-order counter, so a wait for a load
     // issued behind a store is a wait for that store's acknowledgement too
@@ -201,6 +225,7 @@ __global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_chain(Leg
       for (int e = w.tid + PRE * w.nthr; e < ncnt; e += w.nthr)
         Af[e] = na[e];
     }
+    CHT(5)
     Desc nn;
     nn.nx = __builtin_amdgcn_readfirstlane(nnv.nx), nn.nu = __builtin_amdgcn_readfirstlane(nnv.nu);
     nn.nx2 = __builtin_amdgcn_readfirstlane(nnv.nx2);
@@ -208,8 +233,10 @@ __global__ void __launch_bounds__(GAR_LEG_PARAM_THREADS) gar_leg_param_chain(Leg
              (unsigned)__builtin_amdgcn_readfirstlane((int)nnv.aff);
     nn.vxt = ((long long)__builtin_amdgcn_readfirstlane((int)(nnv.vxt >> 32)) << 32) |
              (unsigned)__builtin_amdgcn_readfirstlane((int)nnv.vxt);
+    CHT(6)
     double *dst = fac + cur.vxt;
     wg_move8(w, nx * nth, [&](int e) { return Xn[e]; }, [&](int e, double v) { dst[e] = v; });
+    CHT(7)
     double *tmp = Xt;
     Xt = Xn;
     Xn = tmp;
