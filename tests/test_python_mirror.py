@@ -109,3 +109,61 @@ def test_kkt_chol_and_kkt0_views_on_the_emulator():
     x_l = k0.chol.solve(-np.concatenate([v0, prob.g0]))       # proximal-riccati.hxx:44-52
     assert np.abs(x_l - k0.ff).max() <= 1e-9 * max(1.0, np.abs(k0.ff).max())
     assert np.array_equal(np.tril(M[:nx, :nx]), np.tril(V0))
+
+
+def test_compat_shim_serves_aligator_gar():
+    """compat/aligator: `import aligator.gar` answered by aligator_amd (opt-in, for scripts written against the
+    reference's bindings).  The submodule carries every top-level name bindings/python/src/gar/expose-*.cpp registers
+    (scanned from the reference when it is present), the classes ARE the mirror's, and a script in the reference's
+    idiom -- LqrKnot / LqrProblem / ProximalRiccatiSolver(problem).backward(mu) / forward(xs, us, vs, lbdas) /
+    lqrComputeKktError -- runs through it (on the emulator library here)."""
+    import re
+    import sys
+    root = os.path.dirname(HERE)
+    code = f"""
+import numpy as np
+import aligator
+from aligator import gar
+import aligator.gar as gar2
+import aligator_amd.gar as mirror
+assert gar is gar2 and gar.ProximalRiccatiSolver is mirror.ProximalRiccatiSolver
+nx, nu, N = 8, 4, 6
+rng = np.random.default_rng(1)
+knots = []
+for t in range(N + 1):
+    k = gar.LqrKnot(nx, nu if t < N else 0, 0)
+    k.Q[:] = np.eye(nx) * 2.0
+    k.q[:] = rng.standard_normal(nx)
+    if t < N:
+        k.R[:] = np.eye(nu)
+        k.r[:] = rng.standard_normal(nu)
+        k.A[:] = np.eye(nx) + 0.1 * rng.standard_normal((nx, nx))
+        k.B[:] = rng.standard_normal((nx, nu))
+        k.f[:] = 0.1 * rng.standard_normal(nx)
+    knots.append(k)
+prob = gar.LqrProblem(knots, nx)
+prob.G0[:] = -np.eye(nx)
+prob.g0[:] = rng.standard_normal(nx)
+solver = gar.ProximalRiccatiSolver(prob, lib_path={EMU!r})
+xs, us, vs, lbdas = gar.lqrInitializeSolution(prob)
+assert solver.backward(1e-12) and solver.forward(xs, us, vs, lbdas)
+err = gar.lqrComputeKktError(prob, xs, us, vs, lbdas, 1e-12, None, False)
+assert max(err) < 1e-9, err
+print("NAMES", " ".join(sorted(gar.__all__)))
+"""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "compat")]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = set(out.stdout.split("NAMES", 1)[1].split())
+    expected = {"LqrKnot", "LqrProblem", "RiccatiSolverBase", "ProximalRiccatiSolver", "ParallelRiccatiSolver",
+                "RiccatiSolverDense", "lqrComputeKktError", "lqrCreateSparseMatrix", "lqrInitializeSolution"}
+    assert expected <= names
+    ref = "/root/reference/bindings/python/src/gar"
+    if os.path.isdir(ref):  # what the reference registers at the top level of its gar module
+        found = set()
+        for fn in os.listdir(ref):
+            src = open(os.path.join(ref, fn)).read()
+            found |= set(re.findall(r'bp::def\(\s*"(\w+)"', src))
+            found |= set(re.findall(r'bp::class_<[^;]*?>\s*\(\s*"(\w+)"', src, re.S))
+        top = {n for n in found if n in expected or n.startswith(("lqr", "Riccati", "Proximal", "Parallel", "Lqr"))}
+        assert top <= names, top - names
