@@ -2317,8 +2317,16 @@ int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, cons
   const bool eager = eager_on && !s->multi && !s->fold && !s->dense && (s->nth0 == 0 || s->num_legs > 1) && s->world == 1;
   if (!eager)
     return gar_hip_backward(s, mueq);
-  if (int rc = gar_hip_backward_async(s, mueq))
+  if (int rc = gar_hip_backward_legs_async(s, mueq))
     return rc;
+  if (s->num_legs > 1) {
+    // the gains are final once the leg sweeps are (the condensed solve reads the boundary tuples and writes the
+    // boundary solution): their read-back starts HERE, under the condensed solve, not behind it
+    if (int rc = prefetch_impl(s, 0)) // (allocates the read-back buffers on first use)
+      return rc;
+    if (int rc = launch_condensed(s))
+      return rc;
+  }
   if (!s->h_status) {
     HIP_TRY(gar_host_malloc((void **)&s->h_status, sizeof(int) * (size_t)s->batch, hipHostMallocDefault));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_status, hipEventDisableTiming));
@@ -2326,8 +2334,9 @@ int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, cons
   }
   HIP_TRY(hipMemcpyAsync(s->h_status, s->d_status, sizeof(int) * (size_t)s->batch, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipEventRecord(s->ev_status, s->stream));
-  if (int rc = prefetch_impl(s, 0)) // (allocates the read-back buffers on first use)
-    return rc;
+  if (s->num_legs == 1)
+    if (int rc = prefetch_impl(s, 0))
+      return rc;
   if (int rc = launch_forward(s, nullptr))
     return rc;
   {

@@ -247,7 +247,8 @@ int gar_hip_forward_async(gar_hip_solver *s, const double *theta_device);
  * (N+1) + gar_hip_set_init + gar_hip_backward behind one crossing of the ABI.
  * On a problem without parameter (nth = 0, or leg mode, where theta has no say) on one device the roll-out, the
  * solution's copy into the pinned result buffer (by the kernel's own stores: the copy engine carries the gains) and
- * the gains' read-back are enqueued right behind the sweep, BEFORE the host waits for the status word: the device
+ * the gains' read-back (in leg mode already behind the leg sweeps, under the condensed solve) are enqueued right
+ * behind the sweep, BEFORE the host waits for the status word: the device
  * runs them back to back, and the gar_hip_forward / gar_hip_prefetch_gains / gar_hip_fetch_results(solution) calls
  * that follow find their work done (same results; the next backward, gar_hip_collapse_feedback or
  * gar_hip_cycle_append ends that state).  GAR_HIP_EAGER=0 switches it off. */
