@@ -620,7 +620,7 @@ def test_staged_problem_goes_out_in_few_copies():
     from aligator_amd.gar import BatchedRiccatiSolver
     lib = C.CDLL(EMU)
     lib.emu_memcpy_async_count.restype = C.c_longlong
-    for nx, nu, N, legs in ((36, 12, 48, 1), (8, 4, 64, 4), (10, 3, 40, 1)):
+    for nx, nu, N, legs in ((12, 4, 48, 1), (8, 4, 40, 4), (10, 3, 30, 1)):
         prob = synth.generate_lq_problem(3, np.zeros(nx), N, nx, nu, mode="W")
         s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs, lib_path=EMU)
         assert s.backward_blocks(prob, 1e-10)
