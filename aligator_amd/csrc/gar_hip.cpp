@@ -2994,8 +2994,7 @@ int gar_hip_collapse_feedback(gar_hip_solver *s) {
                        (long long)s->fac_doubles, s->batch, (const int *)nullptr, 0);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  return GAR_HIP_OK;
+  return GAR_HIP_OK; // (asynchronous: whoever reads the gains next is ordered behind it on the stream)
 }
 
 int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {

@@ -359,6 +359,9 @@ int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx,
 /* kkt0.ff (nx0+nc0), kkt0.fth ((nx0+nc0) x nth ROW-major), thGrad, thHess */
 int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff,
                         double *kkt0_fth, double *thGrad, double *thHess);
+/* collapseFeedback (riccati-base.hpp:33; no-op except in leg mode): enqueued on the solver's stream, not waited
+ * for -- every getter and fetch of this library is ordered behind it; a caller reading gar_hip_device_factors() from
+ * another stream synchronises with gar_hip_sync first. */
 int gar_hip_collapse_feedback(gar_hip_solver *s);
 /* Debug aid (no reference counterpart): with enable != 0 the specialised backward
  * kernel stamps s_memtime at its phase boundaries for one stage of problem 0,
