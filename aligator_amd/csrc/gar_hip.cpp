@@ -2343,16 +2343,11 @@ int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, cons
     const gar_hip_solver *u = s->ulay ? s->ulay : s;
     const size_t nsol = (size_t)u->sol_doubles, ngain = (size_t)(u->ff_all_doubles + u->fb_all_doubles);
     // by a kernel's own stores into the pinned buffer: the copy engine is busy with the gains (3.7 / 9.4 MB) and a
-    // hipMemcpyAsync would queue behind them
-    static const bool by_kernel = [] { const char *e = std::getenv("GAR_HIP_EAGER_DMA"); return !(e && e[0] == '1'); }();
+    // hipMemcpyAsync would queue behind them (measured: profiles/r04_seam_eager_rollout_ab.json)
     double *dst = s->h_results + (s->padded ? nsol + ngain : 0);
-    if (by_kernel) {
-      const unsigned nblk = (unsigned)std::min<int64_t>((s->sol_doubles + 255) / 256, 256);
-      hipLaunchKernelGGL(gar::gar_store_to_host, dim3(nblk), dim3(256), 0, s->stream, dst, s->d_sol, (long long)s->sol_doubles);
-      HIP_TRY(hipGetLastError());
-    } else {
-      HIP_TRY(hipMemcpyAsync(dst, s->d_sol, sizeof(double) * (size_t)s->sol_doubles, hipMemcpyDeviceToHost, s->stream));
-    }
+    const unsigned nblk = (unsigned)std::min<int64_t>((s->sol_doubles + 255) / 256, 256);
+    hipLaunchKernelGGL(gar::gar_store_to_host, dim3(nblk), dim3(256), 0, s->stream, dst, s->d_sol, (long long)s->sol_doubles);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(s->ev_sol, s->stream));
   HIP_TRY(hipEventSynchronize(s->ev_status));
