@@ -164,6 +164,7 @@ struct gar_hip_solver {
   // plain part of every leg by that kernel into scratch records (flay: the same knots, nth = 0; d_fac2), the
   // parameter part by the generic matrix recursion, which writes the caller-visible records and the tuples
   void (*seg_bwd_kernel)(gar::MfmaParams, int, int) = nullptr;
+  void (*seg_fwd_kernel)(gar::GenericParams) = nullptr; // its roll-out (gar_forward_wide_leg), leg mode
   int seg_lds_doubles = 0;
   bool fold = false, fold_expanded = false, coupled_known = false;
   gar_hip_solver *flay = nullptr;
@@ -604,6 +605,7 @@ template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
 // the wide shape in leg mode: segment legs (gar_leg_seg.hpp) on the two-wave stage kernel
 template <int NX, int NU> void bind_seg_leg(gar_hip_solver *s) {
   s->seg_bwd_kernel = gar::gar_backward_pair_leg<NX, NU>;
+  s->seg_fwd_kernel = gar::gar_forward_wide_leg<NX, NU>;
   s->seg_lds_doubles = gar::PairCfg<NX, NU>::total;
   s->fb_t2 = false; // row-major fb: the generic roll-out, condensed solve and collapse serve the family
   s->kernel_name = "pair_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
@@ -670,6 +672,7 @@ template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
 void select_kernel(gar_hip_solver *s) {
   s->fold = false;
   s->seg_bwd_kernel = nullptr;
+  s->seg_fwd_kernel = nullptr;
   s->leg_bwd_kernel = nullptr;
   s->leg_tuple_kernel = nullptr;
   s->leg_fwd_kernel = nullptr;
@@ -1409,8 +1412,11 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
   const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
   if (s->timing)
     HIP_TRY(hipEventRecord(s->ev[3], s->stream));
-  hipLaunchKernelGGL(gar::gar_forward_generic, grid, dim3(GAR_FORWARD_THREADS),
-                     (size_t)s->lds.ftotal * sizeof(double), s->stream, P);
+  if (s->seg_bwd_kernel && s->seg_fwd_kernel && s->num_legs > 1) // segment legs: a wave per (leg, problem)
+    hipLaunchKernelGGL(s->seg_fwd_kernel, grid, dim3(64), 0, s->stream, P);
+  else
+    hipLaunchKernelGGL(gar::gar_forward_generic, grid, dim3(GAR_FORWARD_THREADS),
+                       (size_t)s->lds.ftotal * sizeof(double), s->stream, P);
   HIP_TRY(hipGetLastError());
   if (s->timing)
     HIP_TRY(hipEventRecord(s->ev[4], s->stream));

@@ -417,4 +417,139 @@ __global__ void __launch_bounds__(1024) gar_leg_param_finish(LegParamParams P) {
   }
 }
 
+// ---- (3) the roll-out of the segment legs: one wave per (leg, problem), lane = row ------------------------------
+// forwardImpl over one leg (riccati-kernel.hxx:314-377 under parallel-solver.hxx:209-243) in gar_forward_wide's
+// scheme -- lane r < NU owns row r of K and Kth, lane r < NX row r of Aff, Yth, Vxx' and Vxt' (fb, fth ROW-major: a
+// row is 448 contiguous bytes; Vxx' symmetric: its row is its column; Vxt' column-major: one coalesced load per
+// column), the state and the parameter broadcast from the lanes that hold them:
+//   u = kff + K x + Kth th,   x' = yff + Aff x + Yth th,   lbd' = vx' + Vxx' x' + Vxt' th
+// with x, lbd at the leg's first stage and th (the next leg's first costate) from the condensed solution.  Replaces
+// the any-dimension roll-out on this family (74 -> 54 us per sweep at N = 256, 32 legs: a lone wave draws its 230 KB
+// per stage at about 35 GB/s).
+// one stage of the roll-out: (MORE) x_{t+1}, lbd_{t+1}, then u_t.  A lane's six rows are 336 doubles -- more than
+// the register file holds -- so the order is pinned: the rows of the state chain (Aff, Yth) and of the costate
+// (Vxx', Vxt') are requested first, the rows of the controls (K, Kth) into the registers the chain releases
+template <int NX, int NU, bool LAST, bool MORE>
+__device__ __forceinline__ void wide_leg_stage(const GenericParams &P, const double *fac, double *sol, int t, int lane,
+                                               double &xs, double th) {
+  constexpr int NTH = LAST ? 0 : NX;
+  const int iA = lane < NX ? lane : NX - 1, iK = lane < NU ? lane : NU - 1;
+  const gar_stage_meta m = P.meta[t];
+  const int nu = m.nu; // (0 at the terminal knot)
+  const gar_factor_offsets fo = gar_factor_layout(NX, nu, 0, m.nx2, NTH);
+  const double *rec = fac + m.fac_off;
+  const gar_stage_meta mn = P.meta[MORE ? t + 1 : t];
+  const gar_factor_offsets fn = gar_factor_layout(NX, mn.nu, 0, mn.nx2, NTH);
+  const double *recn = fac + mn.fac_off;
+  const double x_in = xs;
+  const bool has_u = nu > 0;
+  double2_t kro[NX / 2], kth[LAST ? 1 : NX / 2];
+  auto load_k = [&] {
+    const double *kp = rec + fo.fb + (long long)iK * NX, *ktp = rec + fo.fth + (long long)iK * NX;
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      kro[q] = *reinterpret_cast<const double2_t *>(kp + 2 * q);
+      if (!LAST)
+        kth[q] = *reinterpret_cast<const double2_t *>(ktp + 2 * q);
+    }
+  };
+  if (MORE) {
+    double2_t aff[NX / 2], yth[LAST ? 1 : NX / 2], vrow[NX / 2];
+    double vxt[LAST ? 1 : NX];
+    const double *ap = rec + fo.fb + (long long)(nu + iA) * NX, *ytp = rec + fo.fth + (long long)(nu + iA) * NX;
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      aff[q] = *reinterpret_cast<const double2_t *>(ap + 2 * q);
+      if (!LAST)
+        yth[q] = *reinterpret_cast<const double2_t *>(ytp + 2 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q)
+      vrow[q] = *reinterpret_cast<const double2_t *>(recn + fn.Vxx + (long long)iA * NX + 2 * q);
+    if (!LAST) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j)
+        vxt[j] = recn[fn.Vxt + (long long)j * NX + iA];
+    }
+    const double yff = rec[fo.ff + nu + iA], vxn = recn[fn.vx + iA];
+    __builtin_amdgcn_sched_barrier(0);
+    double x0 = yff, x1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      x0 = __builtin_fma(aff[q].x, lane_bcast(x_in, 2 * q), x0);
+      x1 = __builtin_fma(aff[q].y, lane_bcast(x_in, 2 * q + 1), x1);
+      if (!LAST) {
+        x0 = __builtin_fma(yth[q].x, lane_bcast(th, 2 * q), x0);
+        x1 = __builtin_fma(yth[q].y, lane_bcast(th, 2 * q + 1), x1);
+      }
+    }
+    const double xn = x0 + x1;
+    if (lane < NX)
+      sol[mn.x_off + lane] = xn;
+    double l0 = vxn, l1 = 0.0; // lbd' = vx' + Vxx' x' + Vxt' th  (:369-374)
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      l0 = __builtin_fma(vrow[q].x, lane_bcast(xn, 2 * q), l0);
+      l1 = __builtin_fma(vrow[q].y, lane_bcast(xn, 2 * q + 1), l1);
+      if (!LAST) {
+        l0 = __builtin_fma(vxt[2 * q], lane_bcast(th, 2 * q), l0);
+        l1 = __builtin_fma(vxt[2 * q + 1], lane_bcast(th, 2 * q + 1), l1);
+      }
+    }
+    if (lane < NX)
+      sol[mn.l_off + lane] = l0 + l1;
+    xs = xn;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (has_u) { // u = kff + K x + Kth th: off the chain, its rows into the registers the chain released (requesting
+    load_k();  //  them under the costate's products overflows the register file: 348 B of scratch per lane)
+    double u0 = rec[fo.ff + iK], u1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      u0 = __builtin_fma(kro[q].x, lane_bcast(x_in, 2 * q), u0);
+      u1 = __builtin_fma(kro[q].y, lane_bcast(x_in, 2 * q + 1), u1);
+      if (!LAST) {
+        u0 = __builtin_fma(kth[q].x, lane_bcast(th, 2 * q), u0);
+        u1 = __builtin_fma(kth[q].y, lane_bcast(th, 2 * q + 1), u1);
+      }
+    }
+    if (lane < NU)
+      sol[m.u_off + lane] = u0 + u1;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(64) gar_forward_wide_leg(GenericParams P) {
+  static_assert(NX <= 64 && NX % 2 == 0 && NU <= 64, "state and controls live in the first lanes");
+  const int lane = (int)threadIdx.x;
+  const int leg = (int)blockIdx.x + P.leg_begin, b = (int)blockIdx.y;
+  if (P.only != nullptr && P.only[b] == 0)
+    return;
+  const double *fac = P.fac + (long long)b * P.fac_stride;
+  double *sol = P.sol + (long long)b * P.sol_stride;
+  int t_beg, t_end;
+  gar_get_work(P.horizon, leg, P.num_legs, &t_beg, &t_end);
+  const bool last = (leg == P.num_legs - 1);
+  const int nxb = P.nxb;
+  const double *cs = P.csol + (long long)b * (2 * P.num_legs) * nxb;
+  const gar_stage_meta m0 = P.meta[t_beg];
+  const int iA = lane < NX ? lane : NX - 1;
+  for (int e = lane; e < (leg == 0 ? P.nc0 : NX); e += 64) // scatter of the condensed solution (:215-220)
+    sol[m0.l_off + e] = cs[(2 * leg) * nxb + e];
+  double xs = cs[(2 * leg + 1) * nxb + iA];
+  if (lane < NX)
+    sol[m0.x_off + lane] = xs;
+  if (last) {
+    for (int t = t_beg; t + 1 < t_end; ++t)
+      wide_leg_stage<NX, NU, true, true>(P, fac, sol, t, lane, xs, 0.0);
+    wide_leg_stage<NX, NU, true, false>(P, fac, sol, t_end - 1, lane, xs, 0.0);
+  } else {
+    const double th = cs[(2 * (leg + 1)) * nxb + iA]; // theta = lbdas[end] (:234-236)
+    for (int t = t_beg; t + 1 < t_end; ++t)
+      wide_leg_stage<NX, NU, false, true>(P, fac, sol, t, lane, xs, th);
+    wide_leg_stage<NX, NU, false, false>(P, fac, sol, t_end - 1, lane, xs, th);
+  }
+}
+
 } // namespace gar
