@@ -480,6 +480,8 @@ __global__ void __launch_bounds__(64) gar_initial_wave(GenericParams P) {
   const WG w = wave_self();
   double *sm = gar_smem;
   const int b = (int)blockIdx.x;
+  if (P.only && !P.only[b]) // (pipelined sweeps: only the problems the fused initial stage left behind)
+    return;
   const gar_stage_meta m0 = P.meta[0];
   const gar_factor_offsets fo = gar_factor_layout(m0.nx, m0.nu, m0.nc, m0.nx2, m0.nth);
   const double *rec = P.fac + (long long)b * P.fac_stride + m0.fac_off;

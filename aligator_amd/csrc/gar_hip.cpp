@@ -22,6 +22,7 @@
 #include "gar_generic.hpp"
 #include "gar_layout.h"
 #include "gar_mfma.hpp"
+#include "gar_forward_lean.hpp"
 #include "gar_wave.hpp"
 #include "gar_wave_leg.hpp"
 #include "gar_wave_pair.hpp"
@@ -107,6 +108,7 @@ struct RoctxRange {
 // Every entry point runs on the solver's own device, whatever the caller's current device is, and
 // leaves the caller's current device as it found it (two solvers on two GPUs in one process;
 // torch's notion of the current device).
+void pipe_autojoin(const gar_hip_solver *s);
 struct DeviceGuard {
   int prev = -1, dev;
   explicit DeviceGuard(int device) : dev(device) { // device < 0 (null solver): no-op
@@ -124,7 +126,12 @@ struct DeviceGuard {
   DeviceGuard(const DeviceGuard &) = delete;
   DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
-#define GAR_GUARD(s) DeviceGuard guard_((s) ? (s)->device : -1)
+// (every entry point but the two that feed the pipelined sweep first orders the caller's stream behind the half
+// streams: pipe_join, below)
+#define GAR_GUARD_NOJOIN(s) DeviceGuard guard_((s) ? (s)->device : -1)
+#define GAR_GUARD(s)                                                                                                   \
+  GAR_GUARD_NOJOIN(s);                                                                                                 \
+  pipe_autojoin(s)
 // one process, several devices (gar_multi.hpp): the handle owns one ranked solver per device and serves every
 // entry point by routing to them
 #define GAR_MULTI(s, expr)                                                                                             \
@@ -274,6 +281,20 @@ struct gar_hip_solver {
   hipEvent_t ev_status = nullptr, ev_sol = nullptr;
   bool eager_fwd = false;      // d_sol and h_results hold the roll-out of the last sweep (theta = none)
   bool pref_collapsed = false; // collapseFeedback ran since: stage 0's gains are fetched again
+  // ---- pipelined sweep (gar_hip_set_pipeline; the serial one-wave family, batch >= 2) --------------------------
+  // The batch is cut in two halves with a stream each; backward sweeps alternate between the halves (events), the
+  // forward sweep of a half is gar_forward_lean, which fits in the registers and the LDS the backward wave of the
+  // OTHER half leaves free on every SIMD (gar_forward_lean.hpp): B(h0) | F(h0) + B(h1) | F(h1) + B'(h0) | ...
+  int pipe_halves = 0;                 // 0: off
+  void (*lean_fwd_kernel)(gar::MfmaFwdParams, int) = nullptr;
+  size_t lean_fwd_used = 0;            // LDS the kernel uses
+  size_t lean_fwd_lds_bytes = 0;       // what the launch ASKS for (> half a CU: one workgroup per CU), see pipe_plan
+  int wave_lds_doubles_small = 0;      // the backward launch without the fused initial stage's kkt0 overlay
+  hipStream_t pipe_stream[2] = {nullptr, nullptr};
+  hipEvent_t pipe_evB[2] = {nullptr, nullptr}, pipe_evF[2] = {nullptr, nullptr}, pipe_evFork = nullptr;
+  hipEvent_t pipe_evT[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}; // timing
+  bool pipe_evB_valid[2] = {false, false};
+  bool pipe_forked = false;            // the half streams hold work the caller's stream has not been ordered behind
 };
 
 namespace {
@@ -545,6 +566,12 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
     s->waves_per_block = 1; // one 64-thread workgroup per problem (constant LDS base)
     s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
     s->qr_packed = GAR_QR_PACKED != 0; // the sweep reads only the lower triangles of Q and R (gar_layout.h)
+    // the pipelined sweep's roll-out (gar_hip_set_pipeline): reads the packed Vxx records
+    if (GAR_VXX_PACKED) {
+      s->lean_fwd_kernel = gar::gar_forward_lean<NX, NU>;
+      s->lean_fwd_used = gar::LeanFwdCfg<NX, NU>::USED; // (what it uses; pipe_plan decides what it asks for)
+      s->wave_lds_doubles_small = gar::WaveCfg<NX, NU>::total;
+    }
   }
 }
 
@@ -1174,6 +1201,40 @@ inline bool records_t2(const gar_hip_solver *s, int b) {
   return s->fb_t2 && !(s->fold && s->coupled_known && s->h_coupled[(size_t)b] != 0);
 }
 
+// parameters of the serial specialised sweeps (gar_backward_mfma, gar_backward_wave and its chain)
+gar::MfmaParams make_mfma_params(gar_hip_solver *s, double mueq) {
+  gar::MfmaParams M{};
+  M.prob = s->d_prob;
+  M.fac = s->d_fac;
+  M.status = s->d_status;
+  M.slow = s->d_status + s->batch;
+  M.resume = s->d_status + s->batch + 4;
+  M.prob_stride = s->prob_doubles;
+  M.fac_stride = s->fac_doubles;
+  const int N = s->horizon;
+  M.in_off0 = s->uni_in0;
+  M.in_rec = s->uni_in_rec;
+  M.in_offN = s->meta[N].in_off;
+  M.fac_rec = s->uni_fac_rec;
+  M.fac_offN = s->meta[N].fac_off;
+  M.horizon = N;
+  M.trace = s->d_trace;
+  const bool fused = s->wave_kernel && s->wave_fused_init;
+  M.init = fused ? s->d_init : nullptr;
+  M.init_stride = s->init_doubles;
+  M.G0_off = s->G0_off;
+  M.g0_off = s->g0_off;
+  M.nc0 = s->nc0;
+  M.mueq = mueq;
+  M.init_closed = s->init_closed ? 1 : 0;
+  M.ring0 = s->ring0;
+  {
+    const char *sa = std::getenv("GAR_HIP_SPD_ACCEPT");
+    M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
+  }
+  return M;
+}
+
 // [l0, l1): the legs swept by this call (default: every leg of this solver; gar_hip_backward_blocks sweeps them in
 // chunks, as their knots arrive).  The kernels index legs as blockIdx.x + leg_begin and the tuples as blockIdx.x:
 // a chunk is the same launch with leg_begin = l0 and the tuple buffer advanced to leg l0's slot.
@@ -1281,35 +1342,8 @@ int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
     return GAR_HIP_OK;
   }
   if (s->mfma_kernel || s->wave_kernel) {
-    gar::MfmaParams M{};
-    M.prob = s->d_prob;
-    M.fac = s->d_fac;
-    M.status = s->d_status;
-    M.slow = s->d_status + s->batch;
-    M.resume = s->d_status + s->batch + 4;
-    M.prob_stride = s->prob_doubles;
-    M.fac_stride = s->fac_doubles;
-    const int N = s->horizon;
-    M.in_off0 = s->uni_in0;
-    M.in_rec = s->uni_in_rec;
-    M.in_offN = s->meta[N].in_off;
-    M.fac_rec = s->uni_fac_rec;
-    M.fac_offN = s->meta[N].fac_off;
-    M.horizon = N;
-    M.trace = s->d_trace;
+    const gar::MfmaParams M = make_mfma_params(s, mueq);
     const bool fused = s->wave_kernel && s->wave_fused_init;
-    M.init = fused ? s->d_init : nullptr;
-    M.init_stride = s->init_doubles;
-    M.G0_off = s->G0_off;
-    M.g0_off = s->g0_off;
-    M.nc0 = s->nc0;
-    M.mueq = mueq;
-    M.init_closed = s->init_closed ? 1 : 0;
-    M.ring0 = s->ring0;
-    {
-      const char *sa = std::getenv("GAR_HIP_SPD_ACCEPT");
-      M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
-    }
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->wave_kernel) {
@@ -1355,6 +1389,26 @@ int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
   return GAR_HIP_OK;
 }
 
+gar::MfmaFwdParams make_mfma_fwd_params(gar_hip_solver *s) {
+  gar::MfmaFwdParams F{};
+  const int N = s->horizon;
+  F.fac = s->d_fac;
+  F.init = s->d_init;
+  F.sol = s->d_sol;
+  F.fac_stride = s->fac_doubles;
+  F.init_stride = s->init_doubles;
+  F.sol_stride = s->sol_doubles;
+  F.fac_rec = s->uni_fac_rec;
+  F.fac_offN = s->meta[N].fac_off;
+  F.horizon = N;
+  F.nc0 = s->nc0;
+  F.sol_u = (int)s->sol_u;
+  F.sol_l = (int)s->sol_l;
+  F.sol_v = (int)s->sol_v;
+  F.ring0 = s->ring0;
+  return F;
+}
+
 int launch_forward(gar_hip_solver *s, const double *theta_dev) {
   RoctxRange range_(s->num_legs > 1 ? "gar::parallel_forward" : "gar::forwardImpl");
   if (s->leg_fwd_kernel) {
@@ -1377,22 +1431,7 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
     return GAR_HIP_OK;
   }
   if (s->mfma_fwd_kernel) {
-    gar::MfmaFwdParams F{};
-    const int N = s->horizon;
-    F.fac = s->d_fac;
-    F.init = s->d_init;
-    F.sol = s->d_sol;
-    F.fac_stride = s->fac_doubles;
-    F.init_stride = s->init_doubles;
-    F.sol_stride = s->sol_doubles;
-    F.fac_rec = s->uni_fac_rec;
-    F.fac_offN = s->meta[N].fac_off;
-    F.horizon = N;
-    F.nc0 = s->nc0;
-    F.sol_u = (int)s->sol_u;
-    F.sol_l = (int)s->sol_l;
-    F.sol_v = (int)s->sol_v;
-    F.ring0 = s->ring0;
+    const gar::MfmaFwdParams F = make_mfma_fwd_params(s);
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[3], s->stream));
     hipLaunchKernelGGL(s->mfma_fwd_kernel, dim3((unsigned)s->batch), dim3(64), s->mfma_fwd_lds_bytes, s->stream, F);
@@ -1420,6 +1459,136 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
   HIP_TRY(hipGetLastError());
   if (s->timing)
     HIP_TRY(hipEventRecord(s->ev[4], s->stream));
+  return GAR_HIP_OK;
+}
+
+// ---- the pipelined sweep (gar_hip_set_pipeline) -------------------------------------------------------------------
+// LDS of a CU, planned: 4 backward waves (one per SIMD, wave_lds_doubles_small each: the launch without the fused
+// initial stage's kkt0 overlay) + ONE forward workgroup (gar_forward_lean: four waves, one per SIMD).  The forward
+// launch ASKS for more than half of the CU's LDS, so that a second forward workgroup never fits: two forward waves
+// on a SIMD would take the registers a backward wave needs (432 + 80 of 512).
+constexpr size_t kCuLdsBytes = 160 * 1024, kLdsGranule = 1280; // gfx950: 160 KiB per CU, allocated in 320-dword pieces
+inline size_t lds_round(size_t b) { return (b + kLdsGranule - 1) / kLdsGranule * kLdsGranule; }
+int pipe_plan(gar_hip_solver *s, size_t lean_used) {
+  const size_t bwd = lds_round((size_t)s->wave_lds_doubles_small * sizeof(double));
+  size_t ask = lds_round(lean_used);
+  if (ask <= kCuLdsBytes / 2)
+    ask = lds_round(kCuLdsBytes / 2 + 1);
+  if (4 * bwd + ask > kCuLdsBytes)
+    return fail(GAR_HIP_ERR_UNSUPPORTED, "pipelined sweep: four backward waves (" + std::to_string(bwd) +
+                                             " B of LDS each) and one forward workgroup (" + std::to_string(ask) +
+                                             " B) do not share a CU");
+  s->lean_fwd_lds_bytes = ask;
+  return GAR_HIP_OK;
+}
+inline bool pipe_on(const gar_hip_solver *s) { return s && s->pipe_halves == 2; }
+inline void pipe_range(const gar_hip_solver *s, int h, int *b0, int *nb) {
+  const int first = (s->batch + 1) / 2;
+  *b0 = h == 0 ? 0 : first;
+  *nb = h == 0 ? first : s->batch - first;
+}
+// the caller's stream behind everything the half streams hold
+int pipe_join(gar_hip_solver *s) {
+  if (!s->pipe_forked)
+    return GAR_HIP_OK;
+  for (int h = 0; h < 2; ++h) {
+    HIP_TRY(hipEventRecord(s->pipe_evF[h], s->pipe_stream[h])); // (covers the sweeps too: stream order)
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->pipe_evF[h], 0));
+  }
+  s->pipe_forked = false;
+  return GAR_HIP_OK;
+}
+void pipe_autojoin(const gar_hip_solver *s) {
+  if (s && s->pipe_forked)
+    (void)pipe_join(const_cast<gar_hip_solver *>(s));
+}
+// ... and the half streams behind what the caller's stream holds (uploads, a previous unpipelined sweep)
+int pipe_fork(gar_hip_solver *s) {
+  if (s->pipe_forked)
+    return GAR_HIP_OK;
+  HIP_TRY(hipEventRecord(s->pipe_evFork, s->stream));
+  for (int h = 0; h < 2; ++h)
+    HIP_TRY(hipStreamWaitEvent(s->pipe_stream[h], s->pipe_evFork, 0));
+  s->pipe_forked = true;
+  return GAR_HIP_OK;
+}
+int pipe_backward(gar_hip_solver *s, double mueq) {
+  RoctxRange range_("gar::backwardImpl+factor_initial (pipelined)");
+  s->eager_fwd = false;
+  if (s->ev_pref) {
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_pref, 0));
+    s->pref_b = -1;
+  }
+  if (s->dirty) { // staged host data goes out on the caller's stream: order it, then fork again
+    if (int rc = pipe_join(s))
+      return rc;
+    if (int rc = commit(s))
+      return rc;
+  }
+  if (int rc = pipe_fork(s))
+    return rc;
+  const gar::MfmaParams M0 = make_mfma_params(s, mueq);
+  const gar::GenericParams G0 = make_params(s, mueq);
+  for (int h = 0; h < 2; ++h) {
+    int b0, nb;
+    pipe_range(s, h, &b0, &nb);
+    hipStream_t st = s->pipe_stream[h];
+    // backward sweeps alternate between the halves: this one starts when the other half's last one has ended --
+    // which is also when that half's forward sweep starts (its stream's next kernel)
+    if (s->pipe_evB_valid[1 - h])
+      HIP_TRY(hipStreamWaitEvent(st, s->pipe_evB[1 - h], 0));
+    HIP_TRY(hipMemsetAsync(s->d_status + b0, 0, sizeof(int) * (size_t)nb, st));
+    if (h == 0) // the slow-path counters of "the last backward" cover both halves (the second half runs behind this one)
+      HIP_TRY(hipMemsetAsync(s->d_status + s->batch, 0, sizeof(int) * 4, st));
+    gar::MfmaParams M = M0;
+    M.prob += (long long)b0 * M.prob_stride;
+    M.fac += (long long)b0 * M.fac_stride;
+    M.status += b0;
+    M.resume += b0;
+    M.init = s->d_init + (long long)b0 * M.init_stride;
+    M.init_small = 1;
+    M.trace = nullptr;
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->pipe_evT[h][0], st));
+    hipLaunchKernelGGL(s->wave_kernel, dim3((unsigned)nb), dim3(64), (size_t)s->wave_lds_doubles_small * sizeof(double),
+                       st, M, nb);
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->pipe_evT[h][1], st));
+    // the problems whose initial condition is not "x0 given" (no closed form): every other wave leaves at once
+    gar::GenericParams G = G0;
+    G.prob += (long long)b0 * G.prob_stride;
+    G.fac += (long long)b0 * G.fac_stride;
+    G.init += (long long)b0 * G.init_stride;
+    G.status += b0;
+    G.only = M.resume;
+    hipLaunchKernelGGL(gar::gar_initial_wave, dim3((unsigned)nb), dim3(64),
+                       (size_t)gar::gar_initial_wave_lds_doubles(s->n0, s->nth0) * sizeof(double), st, G);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->pipe_evB[h], st));
+    s->pipe_evB_valid[h] = true;
+  }
+  return GAR_HIP_OK;
+}
+int pipe_forward(gar_hip_solver *s) {
+  RoctxRange range_("gar::forwardImpl (pipelined)");
+  if (int rc = pipe_fork(s))
+    return rc;
+  const gar::MfmaFwdParams F0 = make_mfma_fwd_params(s);
+  for (int h = 0; h < 2; ++h) {
+    int b0, nb;
+    pipe_range(s, h, &b0, &nb);
+    hipStream_t st = s->pipe_stream[h];
+    gar::MfmaFwdParams F = F0;
+    F.fac += (long long)b0 * F.fac_stride;
+    F.init += (long long)b0 * F.init_stride;
+    F.sol += (long long)b0 * F.sol_stride;
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->pipe_evT[h][2], st));
+    hipLaunchKernelGGL(s->lean_fwd_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), s->lean_fwd_lds_bytes, st, F, nb);
+    HIP_TRY(hipGetLastError());
+    if (s->timing)
+      HIP_TRY(hipEventRecord(s->pipe_evT[h][3], st));
+  }
   return GAR_HIP_OK;
 }
 
@@ -2004,6 +2173,17 @@ void gar_hip_solver_destroy(gar_hip_solver *s) {
   }
   GAR_GUARD(s);
   (void)hipStreamSynchronize(s->stream);
+  for (int h = 0; h < 2; ++h)
+    if (s->pipe_stream[h]) {
+      (void)hipStreamSynchronize(s->pipe_stream[h]);
+      (void)hipStreamDestroy(s->pipe_stream[h]);
+      (void)hipEventDestroy(s->pipe_evB[h]);
+      (void)hipEventDestroy(s->pipe_evF[h]);
+      for (auto &e : s->pipe_evT[h])
+        (void)hipEventDestroy(e);
+    }
+  if (s->pipe_evFork)
+    (void)hipEventDestroy(s->pipe_evFork);
   free_device(s);
   if (s->own_stream)
     (void)hipStreamDestroy(s->own_stream);
@@ -2228,7 +2408,10 @@ int gar_hip_commit(gar_hip_solver *s) {
   return commit(s);
 }
 
-double *gar_hip_device_problems(gar_hip_solver *s) { return s ? s->d_prob : nullptr; }
+double *gar_hip_device_problems(gar_hip_solver *s) {
+  pipe_autojoin(s);
+  return s ? s->d_prob : nullptr;
+}
 double *gar_hip_device_factors(gar_hip_solver *s) {
   if (s && s->multi) // (the records live on several devices)
     return nullptr;
@@ -2238,7 +2421,10 @@ double *gar_hip_device_factors(gar_hip_solver *s) {
   }
   return s ? s->d_fac : nullptr;
 }
-double *gar_hip_device_solutions(gar_hip_solver *s) { return s ? s->d_sol : nullptr; }
+double *gar_hip_device_solutions(gar_hip_solver *s) {
+  pipe_autojoin(s); // (a pipelined sweep: the caller's stream is ordered behind it before the pointer leaves)
+  return s ? s->d_sol : nullptr;
+}
 
 int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
   GAR_GUARD(s);
@@ -2272,8 +2458,45 @@ int gar_hip_forward_legs_async(gar_hip_solver *s) {
   return launch_forward(s, nullptr);
 }
 
+int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
+  GAR_GUARD(s); // (orders the caller's stream behind anything the half streams still hold)
+  if (!s)
+    return fail(GAR_HIP_ERR_ARG, "null solver");
+  if (halves <= 1) {
+    s->pipe_halves = 0;
+    return GAR_HIP_OK;
+  }
+  if (halves != 2)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_set_pipeline: 0 (off) or 2 (two half-batches)");
+  if (s->multi || s->world > 1 || s->num_legs != 1 || s->nth0 != 0 || s->batch < 2 || !s->wave_kernel || !s->lean_fwd_kernel ||
+      s->wave_coupled_kernel || s->wave_block_threads != 64 || s->waves_per_block != 1 || !s->vxx_packed || s->dense)
+    return fail(GAR_HIP_ERR_UNSUPPORTED, "pipelined sweep: serial, unconstrained, unparameterised batches (>= 2 problems) "
+                                         "on the one-wave-per-problem kernel family only (this solver runs " +
+                                             s->kernel_name + ")");
+  if (int rc = pipe_plan(s, s->lean_fwd_used))
+    return rc;
+  if (!s->pipe_stream[0]) {
+    HIP_TRY(hipFuncSetAttribute((const void *)s->lean_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)s->lean_fwd_lds_bytes));
+    for (int h = 0; h < 2; ++h) {
+      HIP_TRY(hipStreamCreateWithFlags(&s->pipe_stream[h], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&s->pipe_evB[h], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&s->pipe_evF[h], hipEventDisableTiming));
+      for (auto &e : s->pipe_evT[h])
+        HIP_TRY(hipEventCreate(&e));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&s->pipe_evFork, hipEventDisableTiming));
+  }
+  s->pipe_halves = 2;
+  return GAR_HIP_OK;
+}
+int gar_hip_pipeline(const gar_hip_solver *s) { return s ? s->pipe_halves : 0; }
+
 int gar_hip_backward_async(gar_hip_solver *s, double mueq) {
-  GAR_GUARD(s);
+  GAR_GUARD_NOJOIN(s);
+  if (pipe_on(s))
+    return pipe_backward(s, mueq);
+  pipe_autojoin(s);
   if (int rc = gar_hip_backward_legs_async(s, mueq))
     return rc;
   GAR_MULTI(s, multi_exchange_and_condensed(s));
@@ -2425,9 +2648,12 @@ int gar_hip_backward(gar_hip_solver *s, double mueq) {
 }
 
 int gar_hip_forward_async(gar_hip_solver *s, const double *theta_device) {
-  GAR_GUARD(s);
+  GAR_GUARD_NOJOIN(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  if (pipe_on(s))
+    return pipe_forward(s);
+  pipe_autojoin(s);
   GAR_MULTI(s, multi_forward(s));
   return launch_forward(s, theta_device);
 }
@@ -2964,6 +3190,16 @@ int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]) {
                                          "kernel family after gar_hip_set_timing(s, 1)");
   HIP_TRY(hipStreamSynchronize(s->stream));
   float ms = 0.f;
+  if (pipe_on(s)) { // per HALF-batch launch, the mean of the two halves; the initial stage rides inside the sweep
+    out[0] = out[1] = out[2] = 0.0;
+    for (int h = 0; h < 2; ++h) {
+      HIP_TRY(hipEventElapsedTime(&ms, s->pipe_evT[h][0], s->pipe_evT[h][1]));
+      out[0] += 0.5 * ms;
+      HIP_TRY(hipEventElapsedTime(&ms, s->pipe_evT[h][2], s->pipe_evT[h][3]));
+      out[2] += 0.5 * ms;
+    }
+    return GAR_HIP_OK;
+  }
   HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
   out[0] = ms;
   HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));

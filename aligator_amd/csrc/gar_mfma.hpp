@@ -54,6 +54,10 @@ struct MfmaParams {
   // plain stage (gar_wave2.hpp): a positive definite Rhat keeps the unpivoted register LDL^T even where
   // Bunch-Kaufman would interchange (wave_ldl_fast_neg_pre); 0: the reference's pivot rule literally
   int spd_accept;
+  // pipelined sweep (gar_hip_set_pipeline): the launch carries no LDS for the fused initial stage's kkt0.  Closed
+  // form (G0 = +-I) as ever; any other problem is left to gar_initial_wave, launched behind the sweep on the
+  // problems with resume[b] != 0 (this kernel writes resume[b] for every problem then)
+  int init_small;
   __host__ __device__ long long slot(int t) const {
     const int p = t + ring0;
     return (ring0 != 0 && p >= horizon) ? p - horizon : p;

@@ -1383,6 +1383,16 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
       }
       if (failed && lane == 0)
         atomicOr(&P.status[b], failed);
+      if (P.init_small && lane == 0)
+        P.resume[b] = 0;
+      return;
+    }
+    if (P.init_small) { // no room for kkt0 in this launch's LDS: gar_initial_wave takes the problem (resume[b] != 0)
+      if (lane == 0) {
+        P.resume[b] = 1;
+        if (failed)
+          atomicOr(&P.status[b], failed);
+      }
       return;
     }
     double *k0 = sm + C::oK0, *rhs = k0 + n0 * (n0 + 1) / 2, *sub = rhs + n0;

@@ -188,6 +188,15 @@ class BatchedRiccatiSolver:
     def sync(self):
         self._check(self._L.gar_hip_sync(self._h))
 
+    def set_pipeline(self, halves: int = 2):
+        """gar_hip_set_pipeline: the forward sweep of one half of the batch beside the backward sweep of the other
+        half (same results, bit for bit; serial one-wave-per-problem family only -- raises otherwise)."""
+        self._check(self._L.gar_hip_set_pipeline(self._h, int(halves)))
+
+    @property
+    def pipeline(self) -> int:
+        return int(self._L.gar_hip_pipeline(self._h))
+
     # ---- packing ---------------------------------------------------------------
     def effective_nth(self, t: int) -> int:
         """nth the kernels use for stage t (leg mode re-parameterises, like

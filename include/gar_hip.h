@@ -367,10 +367,24 @@ int gar_hip_collapse_feedback(gar_hip_solver *s);
  * kernel stamps s_memtime at its phase boundaries for one stage of problem 0,
  * 16 marks per wave; `out` (may be NULL) receives the last 4 x 16 stamps. */
 int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
+/* The pipelined sweep (no reference counterpart: the reference's batch axis is a caller's OpenMP loop over
+ * solvers, bench/gar-riccati.cpp:42-51).  halves = 2 cuts the batch in two halves with a stream each, owned by the
+ * library: gar_hip_backward_async / gar_hip_forward_async then enqueue on those streams, the backward sweeps of
+ * the two halves alternating and the forward sweep of a half running BESIDE the backward sweep of the other half
+ * -- of this call pair or of the next one -- on every SIMD (csrc/gar_forward_lean.hpp).  Same results, bit for
+ * bit.  Ordering contract: work the caller enqueued on the solver's stream before the call is waited for; EVERY
+ * other entry point of this library (gar_hip_sync, the getters, uploads, gar_hip_device_problems / _solutions, ...)
+ * first orders the solver's stream behind the half streams, so code that touches the records only through
+ * this header needs no change; a caller that enqueues its own kernels on the records calls gar_hip_sync (or any
+ * getter) first.  halves = 0 / 1: off (the default).  GAR_HIP_ERR_UNSUPPORTED unless the solver runs the serial
+ * one-wave-per-problem family (batch > number of CUs, nc = nth = 0, at least 2 problems). */
+int gar_hip_set_pipeline(gar_hip_solver *s, int halves);
+int gar_hip_pipeline(const gar_hip_solver *s);
 /* Measurement aid (no reference counterpart): with enable != 0 the library brackets the
  * backward sweep kernel, the initial-stage kernel and the forward sweep kernel with HIP events
  * on the launch stream; gar_hip_last_kernel_ms returns the durations (ms) of the last
- * backward/forward pair as out[0..2].  Specialised kernel family only. */
+ * backward/forward pair as out[0..2].  Specialised kernel family only.  Pipelined sweeps: per HALF-batch
+ * launch (mean of the two halves), out[1] = 0 (the initial stage rides inside the sweep). */
 int gar_hip_set_timing(gar_hip_solver *s, int enable);
 int gar_hip_last_kernel_ms(gar_hip_solver *s, double out[3]);
 /* MPC cycling: drop knot 0, shift left, last-but-one knot gets dims5_new.

@@ -210,6 +210,13 @@ inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_s
 
 inline long long clock64() { return 0; }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
+// global_load_lds_dwordx{1,4}: every lane copies `size` bytes from ITS global address to the wave-uniform LDS
+// address + lane * size (the copy completes at once here; the kernels' s_waitcnt arithmetic is not exercised)
+inline void __builtin_amdgcn_global_load_lds(const void *gsrc, void *lds_wave, int size, int offset, int /*aux*/) {
+  const int lane = threadIdx.x & 63;
+  std::memcpy((char *)lds_wave + offset + (size_t)lane * size, (const char *)gsrc + offset, (size_t)size);
+}
 inline double __builtin_amdgcn_rcp(double a) { return 1.0 / a; }
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return o; }
