@@ -1687,11 +1687,15 @@ __global__ void __launch_bounds__(64) gar_stream_sweep2(const gar_double2 *in, g
 
 template <int IN_PL, int OUT_PL>
 __global__ void __launch_bounds__(64) gar_stream_sweep(const gar_double2 *in, gar_double2 *out, double *sink,
-                                                       int nrec, int in_pieces, int out_pieces) {
+                                                       int nrec, int in_pieces, int out_pieces, int stage_major) {
+  // stage_major: record t of problem b at (t * batch + b) * pieces instead of (b * nrec + t) * pieces -- the
+  // waves of a launch then walk ONE window of memory together (layout probe)
   const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
   gar_double2 cur[IN_PL], nxt[IN_PL];
-  const gar_double2 *pin = in + (size_t)b * nrec * in_pieces;
-  gar_double2 *pout = out + (size_t)b * nrec * out_pieces;
+  const size_t nb = gridDim.x;
+  const size_t rin = stage_major ? nb * in_pieces : (size_t)in_pieces, rout = stage_major ? nb * out_pieces : (size_t)out_pieces;
+  const gar_double2 *pin = in + (stage_major ? (size_t)b * in_pieces : (size_t)b * nrec * in_pieces);
+  gar_double2 *pout = out + (stage_major ? (size_t)b * out_pieces : (size_t)b * nrec * out_pieces);
   auto load = [&](const gar_double2 *p, gar_double2 (&r)[IN_PL]) {
 #pragma unroll
     for (int q = 0; q < IN_PL; ++q) {
@@ -1699,11 +1703,11 @@ __global__ void __launch_bounds__(64) gar_stream_sweep(const gar_double2 *in, ga
       r[q] = p[e < in_pieces ? e : in_pieces - 1];
     }
   };
-  load(pin + (size_t)(nrec - 1) * in_pieces, cur);
+  load(pin + (size_t)(nrec - 1) * rin, cur);
   double acc = 0.0;
   for (int t = nrec - 1; t >= 0; --t) {
     if (t > 0)
-      load(pin + (size_t)(t - 1) * in_pieces, nxt);
+      load(pin + (size_t)(t - 1) * rin, nxt);
 #pragma unroll
     for (int q = 0; q < IN_PL; ++q)
       acc += cur[q].x * 1.0000001 + cur[q].y;
@@ -1714,7 +1718,7 @@ __global__ void __launch_bounds__(64) gar_stream_sweep(const gar_double2 *in, ga
     for (int q = 0; q < OUT_PL; ++q) {
       const int e = 64 * q + lane;
       if (e < out_pieces)
-        pout[(size_t)t * out_pieces + e] = gar_double2{acc, cur[q < IN_PL ? q : 0].x};
+        pout[(size_t)t * rout + e] = gar_double2{acc, cur[q < IN_PL ? q : 0].x};
     }
 #pragma unroll
     for (int q = 0; q < IN_PL; ++q)

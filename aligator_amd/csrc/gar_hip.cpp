@@ -1983,6 +1983,8 @@ double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_
   const bool reps_ahead2 = reps < 0;
   if (reps < 0)
     reps = -reps;
+  const char *lay = std::getenv("GAR_STREAM_LAYOUT"); // "stage": the layout probe of gar_stream_sweep
+  const int stage_major = (lay && std::string(lay) == "stage") ? 1 : 0;
   // (north-star records fit the compiled piece counts: <= 32 x 64 x 16 B = 32 KB in, 28 KB out per stage)
   const int in_pieces = (int)((in_bytes_per_stage + 15) / 16), out_pieces = (int)((out_bytes_per_stage + 15) / 16);
   if (batch <= 0 || horizon <= 0 || in_pieces <= 0 || out_pieces <= 0 || in_pieces > 32 * 64 || out_pieces > 28 * 64 ||
@@ -2006,7 +2008,7 @@ double gar_hip_stream_ceiling_ms(int device, int batch, int horizon, int64_t in_
                            horizon, in_pieces, out_pieces);
       else
         hipLaunchKernelGGL((gar::gar_stream_sweep<32, 28>), dim3((unsigned)batch), dim3(64), 0, nullptr, in, out, sink,
-                           horizon, in_pieces, out_pieces);
+                           horizon, in_pieces, out_pieces, stage_major);
       (void)hipEventRecord(e1, nullptr);
       float ms = 0.f;
       if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
@@ -2479,7 +2481,20 @@ int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
     HIP_TRY(hipFuncSetAttribute((const void *)s->lean_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)s->lean_fwd_lds_bytes));
     for (int h = 0; h < 2; ++h) {
-      HIP_TRY(hipStreamCreateWithFlags(&s->pipe_stream[h], hipStreamNonBlocking));
+      {
+        // two streams that share a hardware queue run their kernels one after the other, in submission order: the
+        // runtime hands out at most GPU_MAX_HW_QUEUES (4) queues PER PRIORITY, so the halves ask for different ones
+        // (with GPU_MAX_HW_QUEUES >= 8 in the environment -- bench.py sets it before the runtime starts -- plain
+        // streams get queues of their own; GAR_HIP_PIPE_PRIORITY=0 / 1 forces the choice)
+        const char *pp = std::getenv("GAR_HIP_PIPE_PRIORITY"), *mq = std::getenv("GPU_MAX_HW_QUEUES");
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const bool plain = pp ? pp[0] == '0' : (mq && std::atoi(mq) >= 8);
+        if (plain)
+          HIP_TRY(hipStreamCreateWithFlags(&s->pipe_stream[h], hipStreamNonBlocking));
+        else
+          HIP_TRY(hipStreamCreateWithPriority(&s->pipe_stream[h], hipStreamNonBlocking, h == 0 ? 0 : hi));
+      }
       HIP_TRY(hipEventCreateWithFlags(&s->pipe_evB[h], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&s->pipe_evF[h], hipEventDisableTiming));
       for (auto &e : s->pipe_evT[h])

@@ -874,10 +874,14 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
       const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
       if (i < NX && j < NX) {
         const double v = ti < C::KSF ? S.Fo[tj][ti < C::KSF ? ti : 0][r] : (C::REM4 ? S.FoT[tj][0] : accT[tj][r]);
+#ifndef GAR_PROBE_NO_AFF_STORE // (timing probe: what the 10.4 KB of Aff per stage cost the sweep; results are then wrong)
         if (WIDE)
           stg_b(out, M::fFB + (NK + 16 * ti + 4 * r) * NX + 16 * tj, fbrm, v);
         else
           stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NK + 16 * ti + 4 * r), L.fbl, v);
+#else
+        asm volatile("" ::"v"(v));
+#endif
       }
     } else if (q < nCol) {
       const int sq = q - nRow4; // k-step of F's column tile tj
@@ -898,11 +902,17 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
     for (int s = 0; s < KU; ++s)
 #pragma unroll
       for (int ti = 0; ti < TX; ++ti) {
+#ifdef GAR_PROBE_NO_AFF // (timing probe: ... and its 27 + 3 MFMAs)
+        if (false) {
+        } else if (ti < C::KSF || C::REM4) {
+        } else {
+#else
         if (ti < C::KSF) {
           S.Fo[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], S.Fo[tj][ti], 0, 0, 0);
         } else if (C::REM4) {
           S.FoT[tj][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(Bop4[s], Kb[tj][s], S.FoT[tj][0], 0, 0, 0);
         } else {
+#endif
           accT[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bop[ti][s], Kb[tj][s], accT[tj], 0, 0, 0);
         }
         if (ti < C::KSF || !C::REM4) { // behind a 16x16x4

@@ -9,7 +9,10 @@ sys.path.insert(0, ROOT)
 from aligator_amd import synth
 from aligator_amd.gar import BatchedRiccatiSolver
 libs = {a.split("=")[0]: os.path.join(ROOT, "aligator_amd", a.split("=")[1]) for a in sys.argv[1:]}
-for nx, nu, nc, N, batch, mu in ((36, 12, 0, 256, 4096, 1e-14), (56, 22, 0, 275, 1024, 1e-10), (36, 12, 32, 256, 1024, 1e-11)):
+SHAPES = ((36, 12, 0, 256, 4096, 1e-14), (56, 22, 0, 275, 1024, 1e-10), (36, 12, 32, 256, 1024, 1e-11))
+if os.environ.get("AB_ONLY"):   # e.g. AB_ONLY=0: the north star alone
+    SHAPES = tuple(SHAPES[int(i)] for i in os.environ["AB_ONLY"].split(","))
+for nx, nu, nc, N, batch, mu in SHAPES:
     probs = [synth.generate_lq_problem(100 + i, np.zeros(nx), N, nx, nu, nc=nc, mode="W") for i in range(2)]
     solvers = {}
     for name, path in libs.items():
