@@ -2402,6 +2402,16 @@ int gar_hip_upload_packed_device(gar_hip_solver *s, int b0, int nb, const double
   return GAR_HIP_OK;
 }
 
+int gar_hip_upload_packed_device_fmt(gar_hip_solver *s, int b0, int nb, const double *packed_dev, int record_format) {
+  if (s && ((record_format & GAR_HIP_FMT_QR_PACKED) != 0) != s->qr_packed)
+    return fail(GAR_HIP_ERR_ARG, std::string("gar_hip_upload_packed_device_fmt: the records were written with ") +
+                                     ((record_format & GAR_HIP_FMT_QR_PACKED) ? "packed lower triangles" : "full blocks") +
+                                     " of Q / R, this solver's sweep (" + s->kernel_name + ") reads " +
+                                     (s->qr_packed ? "packed lower triangles" : "full blocks") +
+                                     " (gar_hip_device_record_format)");
+  return gar_hip_upload_packed_device(s, b0, nb, packed_dev);
+}
+
 int gar_hip_commit(gar_hip_solver *s) {
   GAR_GUARD(s);
   if (!s)
@@ -2599,8 +2609,16 @@ int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, cons
   for (int b = 0; b < s->batch; ++b)
     nf += (s->h_status[b] != 0);
   s->last_failed = nf;
-  if (nf > 0)
+  if (nf > 0) {
+    // the roll-out, the solution's copy and the gains' read-back of the FAILED sweep are already enqueued: let them
+    // finish and disarm the "already in flight" shortcuts, so that a later fetch does its own work (and nobody is
+    // handed these gains as if the sweep had succeeded)
+    if (s->ev_pref)
+      HIP_TRY(hipEventSynchronize(s->ev_pref));
+    s->pref_b = -1;
+    s->eager_fwd = false;
     return fail(GAR_HIP_ERR_FACTOR, "Failed stage LDL factorization (" + std::to_string(nf) + " problem(s))");
+  }
   s->eager_fwd = true;
   return GAR_HIP_OK;
 }
@@ -2851,6 +2869,13 @@ static int fetch_results_impl(gar_hip_solver *s, int b, int what, int t_lo, int 
       t_hi = 1;
   }
   if ((what & 2) && t_hi > t_lo) { // device-side gather (fbT2 -> row-major, dummy rows / columns dropped), then ONE device-to-host copy
+    if (s->pref_b >= 0 && s->ev_pref) {
+      // a read-back started by gar_hip_prefetch_gains (of another problem, or of this one over another range) may
+      // still be writing d_gains / h_results on the second stream: this gather and copy reuse both
+      HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_pref, 0));
+      HIP_TRY(hipEventSynchronize(s->ev_pref)); // (h_results is host memory: the caller may read it right after)
+      s->pref_b = -1;
+    }
     if (int rc = ensure_expanded(s))
       return rc;
     const bool t2 = records_t2(s, b);
@@ -3645,8 +3670,15 @@ int gar_hip_device_sizes(const gar_hip_solver *s, int64_t out[8]) {
   if (!s || !out)
     return fail(GAR_HIP_ERR_ARG, "bad argument");
   out[0] = s->prob_doubles; out[1] = s->fac_doubles; out[2] = s->sol_doubles; out[3] = s->nc0;
-  out[4] = s->G0_off; out[5] = s->g0_off; out[6] = (s->padded ? 1 : 0) | (s->qr_packed ? 2 : 0); out[7] = s->init_doubles;
+  out[4] = s->G0_off; out[5] = s->g0_off; out[6] = s->padded ? 1 : 0; out[7] = s->init_doubles;
   return GAR_HIP_OK;
+}
+
+int gar_hip_device_record_format(const gar_hip_solver *s) {
+  if (!s)
+    return 0;
+  return (s->qr_packed ? GAR_HIP_FMT_QR_PACKED : 0) | (s->vxx_packed ? GAR_HIP_FMT_VXX_PACKED : 0) |
+         (s->fb_t2 ? GAR_HIP_FMT_FB_T2 : 0);
 }
 
 } // extern "C"

@@ -77,8 +77,16 @@ void multi_ranges(gar_hip_solver *s) {
   }
 }
 
+int multi_sync(gar_hip_solver *s);
 void multi_destroy(gar_hip_solver *s) {
   gar_multi *M = s->multi;
+  // every device idle FIRST: in pull mode the gather kernels on the other devices' streams read this device's
+  // boundary buffer across xGMI, and hipFree on one device is not ordered against a peer's stream
+  for (gar_hip_solver *q : M->subs)
+    if (q) {
+      DeviceGuard g(q->device);
+      (void)hipStreamSynchronize(q->stream);
+    }
   for (size_t r = 0; r < M->subs.size(); ++r) {
     if (!M->subs[r])
       continue;
@@ -378,7 +386,10 @@ int multi_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
   if (N < 1)
     return GAR_HIP_OK;
   // leg mode: "just reinitialise everything" (parallel-solver.hxx:246-258) -- on every device; the first device's
-  // trial configuration rejects a bad knot before anything changes
+  // trial configuration rejects a bad knot before anything changes.  Every device idle first: re-initialising a
+  // sub-solver frees the boundary buffer its peers' gather kernels may still be reading.
+  if (int rc = multi_sync(s))
+    return rc;
   for (gar_hip_solver *q : M->subs)
     if (int rc = gar_hip_cycle_append(q, d))
       return rc;

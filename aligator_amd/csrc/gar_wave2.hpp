@@ -454,6 +454,13 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
         vbuf[i < NCH ? i : 0] = VO::read(V, i, lane);
       if (i >= 2)
         VO::write(vflush, i - 2, lane, vbuf[i - 2 < NCH ? i - 2 : 0]);
+#ifdef GAR_PROBE_AFF_LINEAR // (timing probe: the bytes of Aff as 16-byte-per-lane linear stores, garbage data)
+      if (i >= 2 && !WIDE) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          *reinterpret_cast<double2_t *>(&(vflush - M::NR * NX)[2 * (64 * (2 * (i - 2) + u) + lane)]) = vbuf[i - 2 < NCH ? i - 2 : 0];
+      }
+#endif
     } else if (i < nA_flush + nA_rows) { // Rhat, lane = row
       const int j = i - nA_flush;
       a_row[j < NU ? j : 0] = Mm[j * NU + frow];

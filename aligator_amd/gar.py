@@ -163,7 +163,8 @@ class BatchedRiccatiSolver:
         self.device_problem_doubles, self.device_factors_doubles, self.device_solution_doubles = (int(v) for v in ds[:3])
         self.device_nc0, self.device_G0_off, self.device_g0_off, self.padded = int(ds[3]), int(ds[4]), int(ds[5]), bool(int(ds[6]) & 1)
         # the device knots t < N keep Q and R as packed lower triangles (csrc/gar_layout.h: the headline sweep's records)
-        self.qr_packed = bool(int(ds[6]) & 2)
+        self.record_format = int(L.gar_hip_device_record_format(h))   # GAR_HIP_FMT_* flags (include/gar_hip.h)
+        self.qr_packed = bool(self.record_format & 1)
         self._factors_cache = {}
         self._mueq = None   # of the last backward (datas[t].kktMat is formed on request)
 
@@ -279,11 +280,17 @@ class BatchedRiccatiSolver:
         nb = packed.size // self.problem_doubles if nb is None else nb
         self._check(self._L.gar_hip_upload_packed(self._h, b0, nb, _ptr(packed)))
 
-    def upload_packed_device(self, dev_ptr: int, b0: int = 0, nb: Optional[int] = None):
+    def upload_packed_device(self, dev_ptr: int, b0: int = 0, nb: Optional[int] = None,
+                             record_format: Optional[int] = None):
         """`dev_ptr`: device address of nb packed DEVICE records (`device_problem_doubles` each, laid out by
-        `device_dims` / `device_stage_offsets`; e.g. a torch tensor's data_ptr())."""
+        `device_dims` / `device_stage_offsets`; e.g. a torch tensor's data_ptr()).  `record_format`: the GAR_HIP_FMT_*
+        flags the producer wrote the records in (Q / R full or packed lower triangles): a mismatch with the solver's
+        `record_format` is refused instead of swept."""
         nb = self.batch - b0 if nb is None else nb
-        self._check(self._L.gar_hip_upload_packed_device(self._h, b0, nb, C.c_void_p(dev_ptr)))
+        if record_format is None:
+            self._check(self._L.gar_hip_upload_packed_device(self._h, b0, nb, C.c_void_p(dev_ptr)))
+        else:
+            self._check(self._L.gar_hip_upload_packed_device_fmt(self._h, b0, nb, C.c_void_p(dev_ptr), int(record_format)))
 
     def device_pointers(self):
         """(problems, factors, solutions) device addresses for device-resident producers."""

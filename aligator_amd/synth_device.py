@@ -109,7 +109,8 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
                           padv(randn(nb, nx), NX)], dim=-1)
         buf[:, offN:offN + term.shape[-1]] = term
         torch.cuda.synchronize()  # generation done before the solver's stream copies it
-        solver.upload_packed_device(buf.data_ptr(), b0, nb)
+        # (the format these records were just written in: refused, not swept, if the solver's differs)
+        solver.upload_packed_device(buf.data_ptr(), b0, nb, record_format=1 if getattr(solver, "qr_packed", False) else 0)
         solver.sync()
         for k in keep_idx:
             if b0 <= k < b0 + nb:

@@ -202,14 +202,27 @@ double *gar_hip_device_solutions(gar_hip_solver *s);
  *                                offset, out[6] = factor record offset, out[7..10] = x,u,v,lbda offsets
  *   gar_hip_device_sizes         out[0..2] = doubles of one device problem / factor set / solution record,
  *                                out[3] = rows of the device G0 (nc0 + dummy states), out[4..5] = offsets of G0, g0,
- *                                out[6] = flags: bit 0 = padded; bit 1 = the knots t < horizon keep Q and R as
- *                                their LOWER TRIANGLES, packed column after column (LAPACK "L" order) in the first
- *                                n (n + 1) / 2 doubles of the Q / R block, the rest of the block unused
- *                                (csrc/gar_layout.h: the headline one-wave sweep reads 19 % fewer bytes per knot;
- *                                every host entry point converts, only in-place device producers need to know),
- *                                out[7] = doubles of one initial-stage record */
+ *                                out[6] = 1 if the solver is padded, 0 otherwise (a boolean),
+ *                                out[7] = doubles of one initial-stage record
+ *   gar_hip_device_record_format the FORMAT of the device records, bit flags (csrc/gar_layout.h):
+ *       GAR_HIP_FMT_QR_PACKED   the knots t < horizon keep Q and R as their LOWER TRIANGLES, packed column after
+ *                               column (LAPACK "L" order) in the first n (n + 1) / 2 doubles of the Q / R block, the
+ *                               rest of the block unused (the headline one-wave sweep reads 19 % fewer bytes per
+ *                               knot).  Every host entry point converts; an in-place DEVICE producer must write
+ *                               this format -- and says which it wrote through gar_hip_upload_packed_device_fmt,
+ *                               which refuses a mismatch instead of sweeping misread blocks.  The format follows
+ *                               the kernel family (batch vs. number of CUs, GAR_HIP_BACKWARD): ask, do not assume.
+ *       GAR_HIP_FMT_VXX_PACKED  factor records: Vxx as its packed lower triangle (gar_sym_index)
+ *       GAR_HIP_FMT_FB_T2       factor records: fb / fth in the fbT2 order */
+#define GAR_HIP_FMT_QR_PACKED 1
+#define GAR_HIP_FMT_VXX_PACKED 2
+#define GAR_HIP_FMT_FB_T2 4
 int gar_hip_device_stage_layout(const gar_hip_solver *s, int t, int64_t out[11]);
 int gar_hip_device_sizes(const gar_hip_solver *s, int64_t out[8]);
+int gar_hip_device_record_format(const gar_hip_solver *s);
+/* gar_hip_upload_packed_device with the producer's statement of the format it wrote (GAR_HIP_FMT_* flags; only
+ * GAR_HIP_FMT_QR_PACKED concerns knot records): GAR_HIP_ERR_ARG when it is not the solver's. */
+int gar_hip_upload_packed_device_fmt(gar_hip_solver *s, int b0, int nb, const double *packed_dev, int record_format);
 
 /* nb packed problems (gar_hip_problem_doubles() each) back to the host (diagnostics, tests) */
 int gar_hip_download_packed(gar_hip_solver *s, int b0, int nb, double *packed);

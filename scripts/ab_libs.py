@@ -38,7 +38,8 @@ for nx, nu, nc, N, batch, mu in SHAPES:
               f"=> {batch / np.median(a.sum(1)) * 1e3:.0f} sweeps/s  failed {solvers[name].num_failed()}", flush=True)
     x = [solvers[k].solution(0) for k in solvers]
     sc = max(1.0, max(float(np.abs(v).max()) for part in x[0] for v in part if v.size))
-    print("   max relative difference between the builds, problem 0:",
-          max(float(np.abs(a - b).max()) for A, B in zip(*x) for a, b in zip(A, B) if a.size) / sc, flush=True)
+    for name, xi in zip(list(solvers)[1:], x[1:]):
+        print(f"   max relative difference {list(solvers)[0]} vs {name}, problem 0:",
+              max(float(np.abs(a - b).max()) for A, B in zip(x[0], xi) for a, b in zip(A, B) if a.size) / sc, flush=True)
     for s in solvers.values():
         s.close()
