@@ -515,7 +515,11 @@ def seam():
     __graft_entry__.build()): the call sequence of include/aligator/gar/hip-riccati.hpp over the C ABI, (36, 12) and
     bench/lqr.cpp's / the Talos walk's (56, 22), N = 256, serial and N/8 legs.  None when the binary is absent."""
     import subprocess
-    exe = os.path.join(ROOT, "tests", "cpp", "_build", "seam_bench")
+    # (bench_lqr_loop: the same program WITH its oracle leg -- the restated reference's iteration on this box's host,
+    # one thread, beside every GPU figure; seam_bench is the build without it)
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_lqr_loop")
+    if not os.path.exists(exe):
+        exe = os.path.join(ROOT, "tests", "cpp", "_build", "seam_bench")
     if not os.path.exists(exe):
         return {"skipped": "tests/cpp/_build/seam_bench not built"}
     try:

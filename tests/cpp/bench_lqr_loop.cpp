@@ -243,7 +243,40 @@ int main(int argc, char **argv) {
       const SeamPhases a = time_phases(p, 1, iters, mu, &k1), b = time_phases(pp, legs, iters, mu, &k2);
       std::printf("\"nx%d_nu%d\": {", sh.dim, sh.nu);
       print_phases_json("serial", a, k1, 1, false);
+#ifndef SEAM_NO_ORACLE
+      print_phases_json("legs", b, k2, legs, false);
+      { // the same iteration on this box's host, one thread: the restated reference (oracle/gar_oracle.c) re-reading
+        // the knots, backward, forward -- the CPU figure to read beside us_per_newton_iteration
+        ora_problem *op = to_oracle(p);
+        ora_prox_solver *os = ora_prox_new(op);
+        auto sol4 = lqrInitializeSolution(p);
+        std::vector<double *> xs, us, vs, ls;
+        for (auto &v : sol4[0]) xs.push_back(v.data());
+        for (auto &v : sol4[1]) us.push_back(v.data());
+        us.resize(xs.size(), nullptr);
+        for (auto &v : sol4[2]) vs.push_back(v.data());
+        for (auto &v : sol4[3]) ls.push_back(v.data());
+        double bw = 1e30, it_us = 1e30;
+        for (int it = 0; it < 5; ++it) {
+          update_lq_subproblem(p, it);
+          const auto t0 = clk::now();
+          sync_oracle(p, op);
+          ora_prox_backward(os, mu);
+          const auto t1 = clk::now();
+          ora_prox_forward(os, xs.data(), us.data(), vs.data(), ls.data(), nullptr);
+          const auto t2 = clk::now();
+          bw = std::min(bw, std::chrono::duration<double, std::micro>(t1 - t0).count());
+          it_us = std::min(it_us, std::chrono::duration<double, std::micro>(t2 - t0).count());
+        }
+        ora_prox_free(os);
+        ora_problem_free(op);
+        std::printf("\"cpu_restated_reference_1_thread\": {\"us_per_newton_iteration\": %.1f, \"backward_us\": %.1f, "
+                    "\"what\": \"oracle/gar_oracle.c (the reference's algorithm restated in C, -O3) on this box's host, one thread: "
+                    "knots re-read, backward, forward; the gains are already on the host\"}", it_us, bw);
+      }
+#else
       print_phases_json("legs", b, k2, legs, true);
+#endif
       std::printf("}%s", i == 0 ? ", " : "");
     }
     std::printf("}\n");

@@ -3,7 +3,11 @@
 // compiled against /root/reference/include (over the Eigen-API stand-in oracle/ref_shim, as oracle/_ref is) and
 // driven through gar::RiccatiSolverBase<double>* exactly as SolverProxDDP drives linear_solver_
 // (solver-proxddp.hxx:208, 608-611, 619, 624-625, 631-632), next to the reference's own ProximalRiccatiSolver /
-// ParallelRiccatiSolver on the same LqrProblemTpl.  Linked with the wave-emulator build of the library on CPU.
+// ParallelRiccatiSolver on the same LqrProblemTpl.  Linked with the wave-emulator build of the library on CPU
+// (tests/test_integration_binding.py) -- or, with -DSEAM_GPU, with the REAL aligator_amd/libgar_hip.so: that
+// executable is built in the container that has /root/reference (tests/integration/build_gpu_driver.sh, from
+// __graft_entry__.build()), travels to the GPU box like oracle/_ref/libgar_ref.so and is run there by the -m gpu test
+// of the same file: the reference's own solvers and the MI355X backend, same LqrProblemTpl, same process.
 #define ALIGATOR_MULTITHREADING
 #include <sched.h>
 #define ALIGATOR_TRACY_SET_THREAD_NAME(x) delete[] (x)
@@ -114,18 +118,33 @@ static double run(Base &solver, Problem &p, Sol &s, double mu, std::vector<doubl
   return scale;
 }
 
+#ifndef SEAM_GPU
 extern "C" void emu_set_device_count(int n); // the emulator build's virtual devices (tests/emu/emu_runtime.cpp)
+#else
+#include <chrono>
+#endif
 
 int main() {
   int bad = 0;
-  emu_set_device_count(3);
   // ndev > 1: the legs split over that many devices behind the ONE RiccatiSolverBase object (gar_hip_multi_create)
   struct Case { uint nx, nu, nc, N; int legs; double mu; const char *want; int ndev; };
+#ifndef SEAM_GPU
+  emu_set_device_count(3);
   const Case cases[] = {{8, 4, 0, 12, 1, 1e-10, "<8,4>", 1},        {7, 3, 0, 9, 1, 1e-10, "<8,4>", 1}, // padded inside the C ABI
                         {8, 4, 3, 10, 1, 1e-6, "generic", 1},       {12, 6, 0, 14, 3, 1e-10, "wave_leg<12,8>", 1},
                         {8, 4, 2, 11, 2, 1e-6, "wave_leg<8,4>+fold", 1},
                         {12, 6, 0, 14, 3, 1e-10, "wave_leg<12,8>", 3}, {8, 4, 0, 17, 5, 1e-10, "wave_leg<8,4>", 2},
                         {5, 2, 1, 11, 4, 1e-6, "generic", 3}};
+#else
+  // on the MI355X: the north star serial and in leg mode, the Talos-walk LQ shape (padded inside the C ABI) serial and
+  // in leg mode, the reference's own benchmark shape nc = 32 (bench/gar-riccati.cpp:19-22) serial and folded into
+  // legs, a generic shape, and the legs behind ONE object split over two sub-solvers (ids {0, 0}: one GPU here)
+  const Case cases[] = {{36, 12, 0, 64, 1, 1e-10, "mfma<36,12>", 1},   {36, 12, 0, 96, 6, 1e-10, "wave_leg<36,12>", 1},
+                        {56, 22, 0, 40, 1, 1e-10, "pair<56,24>", 1},    {56, 22, 0, 48, 6, 1e-10, "pair_leg<56,24>", 1},
+                        {36, 12, 32, 32, 1, 1e-8, "wave<36,12,32>", 1}, {36, 12, 32, 36, 4, 1e-8, "fold", 1},
+                        {7, 3, 0, 9, 1, 1e-10, "<8,4>", 1},             {5, 2, 1, 11, 4, 1e-6, "generic", 1},
+                        {36, 12, 0, 96, 6, 1e-10, "wave_leg<36,12>", 2}, {12, 6, 0, 30, 5, 1e-10, "wave_leg<12,8>", 2}};
+#endif
   for (const Case &c : cases) {
     Problem pr = make_problem(c.nx, c.nu, c.nc, c.N, 7 + c.nx), ph = pr;
     Sol sr(pr), sh(ph);
@@ -146,12 +165,33 @@ int main() {
       } else {
         std::vector<int> devs;
         for (int d = 0; d < c.ndev; ++d)
+#ifndef SEAM_GPU
           devs.push_back(d);
+#else
+          devs.push_back(0);
+#endif
         hip = std::make_unique<gar::HipRiccatiSolver>(ph, c.legs, devs);
       }
     }
     const double scale = run(*ref, pr, sr, c.mu, gr);
     run(*hip, ph, sh, c.mu, gh);
+#ifdef SEAM_GPU
+    { // the iteration again, timed (best of 5): the MI355X backend and, beside it, the reference's own solver as
+      // compiled HERE (over the naive Eigen stand-in: an upper bound on its time, not a fair timing of Eigen)
+      auto best = [&](Base &sv, Problem &p, Sol &sl) {
+        double b = 1e30;
+        std::vector<double> g;
+        for (int r = 0; r < 5; ++r) {
+          const auto t0 = std::chrono::steady_clock::now();
+          run(sv, p, sl, c.mu, g);
+          b = std::min(b, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+        return b;
+      };
+      const double th = best(*hip, ph, sh), tr = best(*ref, pr, sr);
+      std::printf("    one iteration (backward + forward + collapse + every gain): HIP %.0f us, reference over the stand-in %.0f us\n", th, tr);
+    }
+#endif
     double dg = 0, gs = 1;
     for (size_t i = 0; i < std::min(gr.size(), gh.size()); ++i) {
       dg = std::max(dg, std::abs(gr[i] - gh[i]));

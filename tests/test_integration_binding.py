@@ -14,10 +14,31 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = "/root/reference"
 
-pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "include", "aligator", "gar")),
-                                reason="/root/reference absent (GPU box)")
+needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "include", "aligator", "gar")),
+                                     reason="/root/reference absent (GPU box)")
 
 
+@pytest.mark.gpu
+def test_gpu_reference_typed_binding_on_the_device():
+    """The seam on the MI355X with the reference's OWN types: oracle/_ref/seam_driver_gpu is tests/integration/
+    seam_driver.cpp -- `HipRiccatiSolver : RiccatiSolverBase<double>` (the shipped include/aligator/gar/hip-riccati.hpp)
+    against the reference's LqrProblemTpl, next to the reference's own ProximalRiccatiSolver / ParallelRiccatiSolver
+    in the same process -- compiled where /root/reference exists (tests/integration/build_gpu_driver.sh, from
+    __graft_entry__.build()) and linked with the REAL aligator_amd/libgar_hip.so.  Serial, padded (56, 22), nc = 32,
+    leg mode, folded constraints, legs over two sub-solvers (devices {0, 0}); solution and every stage's gains to 1e-8
+    of their scale, the kernel family that ran; the iteration timed on both sides."""
+    if os.path.isdir(os.path.join(REF, "include", "aligator", "gar")):
+        subprocess.run(["bash", os.path.join(HERE, "integration", "build_gpu_driver.sh")], check=True)
+    exe = os.path.join(ROOT, "oracle", "_ref", "seam_driver_gpu")
+    assert os.path.exists(exe), ("oracle/_ref/seam_driver_gpu is built by __graft_entry__.build() in the container that "
+                                 "holds /root/reference and travels with the snapshot: run build() there first")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    print(r.stdout)
+    assert r.returncode == 0 and "seam ok" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
+    assert r.stdout.count(" ok\n") >= 10 and "MISMATCH" not in r.stdout
+
+
+@needs_reference
 def test_the_shipped_binding_compiles_against_the_reference_and_matches_its_solvers(tmp_path):
     import torch
     header = os.path.join(ROOT, "include", "aligator", "gar", "hip-riccati.hpp")

@@ -197,6 +197,73 @@ def test_gpu_multi_device_horizon_2048(monkeypatch, exchange):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("W,legs", [(8, 8), (8, 256), (5, 37), (16, 64)])
+@pytest.mark.parametrize("exchange", ["pull", "copy"])
+def test_gpu_multi_device_eight_way_at_configs3_shape(monkeypatch, W, legs, exchange):
+    """The plumbing of the first 8-GPU run, on the one device this box has: BASELINE configs[3]'s exact shape (N = 2048,
+    nx = 36, nu = 12) with W = 8 sub-solvers -- ONE 256-stage leg per sub-solver (legs = 8) and 32 legs per sub-solver
+    (legs = 256) -- plus an uneven split (5 sub-solvers, 37 legs) and more sub-solvers than a node has GPUs (16); both
+    exchange forms.  Bitwise the one-device solver with the same legs (solution and the bulk read-back of every gain),
+    the serial oracle's solution, and three sweeps in a row (the readers of sweep k gate the writers of sweep k + 1
+    through W x W events).  What this cannot show is xGMI itself: peer access between distinct devices
+    (parallel-solver.hxx:23-28, 132-206 are the reference's partition and exchange)."""
+    from aligator_amd.gar import BatchedRiccatiSolver
+    if exchange == "copy":
+        monkeypatch.setenv("GAR_HIP_MULTI_EXCHANGE", "copy")
+    nx, nu, N = 36, 12, 2048
+    prob = synth.generate_lq_problem(7, np.zeros(nx), N, nx, nu, mode="W")
+    dims = [k.dims for k in prob.stages]
+    many = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=legs, devices=[0] * W)
+    assert many._L.gar_hip_num_devices(many.handle) == W
+    assert many._L.gar_hip_multi_exchange_name(many.handle).decode() == exchange
+    many.upload([prob])
+    for _ in range(3):
+        assert many.backward(1e-10) and many.forward()
+    one = BatchedRiccatiSolver(dims, nx, batch=1, num_legs=legs)
+    one.upload([prob])
+    assert one.backward(1e-10) and one.forward()
+    assert np.array_equal(_flat(one.solution(0)), _flat(many.solution(0)))
+    for x, y in zip(many.fetch_results(0), one.fetch_results(0)):
+        assert np.array_equal(x, y)
+    _, _, ref = pc.oracle_serial(prob, 1e-10)
+    sc = pc.scale_of(ref)
+    for a, b in zip(many.solution(0), ref):
+        assert pc.maxdiff(a, b) <= 1e-8 * sc
+    many.close()
+    one.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bench_lines_for_eight_ranks_on_one_device():
+    """the two command lines of the 8-GPU runs, on one device: `bench.py --gpus 8 --same-device --backend gloo` (eight
+    ranks, the batch axis) and `--mode horizon --single-process --gpus 8 --same-device` (one process, eight sub-solvers):
+    each prints ONE well-formed line"""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--same-device", "--backend", "gloo", "--batch", "64",
+                        "--steps", "2", "--warmup", "1", "--single-generator", "--no-cpu", "--no-extras", "--pmc", "off"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["batch_per_gpu"] == 64
+    assert d["parity"]["max_rel_err_vs_oracle"] < 1e-9 and d["parity"]["failed_factorisations"] == 0
+    hs = d.get("horizon_sharded")
+    assert hs is None or "error" not in hs, hs
+    r = subprocess.run([sys.executable, "bench.py", "--mode", "horizon", "--single-process", "--gpus", "8", "--same-device"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    hs = d["horizon_sharded"]
+    assert d["n_gpus"] == 8 and hs["devices"] == [0] * 8 and hs["max_rel_diff_vs_serial"] < 1e-9
+
+
+@pytest.mark.gpu
 def test_gpu_multi_device_three_way_uneven_and_padded():
     """W = 3 sub-solvers on the one device, 7 legs (2 + 2 + 3), the Talos shape (56, 22) padded inside the C ABI onto
     the segment-leg family, and a generic shape; batch of 2."""
