@@ -39,31 +39,6 @@ template <int NX, int NU> struct LeanFwdCfg {
   static constexpr int USED = WAVES * SLICE;
 };
 
-// one DMA piece: every active lane copies 16 bytes from its own source address to (wave-uniform) dst + 16 lane
-__device__ __forceinline__ void lean_dma16(const char *src_lane, char *dst_wave) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
-                                   (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
-#else
-  __builtin_amdgcn_global_load_lds(src_lane, dst_wave, 16, 0, 0);
-#endif
-}
-// BYTES (a multiple of 16) from src to the LDS image dst, 1 KiB per instruction: exactly ceil(BYTES / 1024)
-// vector-memory instructions (the s_waitcnt arithmetic of the kernel counts on it)
-template <int BYTES>
-__device__ __forceinline__ void lean_dma(const double *src, char *dst, int lane) {
-  constexpr int PIECES = (BYTES + 1023) / 1024;
-  const char *s = reinterpret_cast<const char *>(src) + 16 * lane;
-#pragma unroll
-  for (int p = 0; p < PIECES; ++p) {
-    const int left = BYTES - 1024 * p; // bytes of this piece and the ones behind it
-    if (left >= 1024 || 16 * lane < left)
-      lean_dma16(s + 1024 * p, dst + 1024 * p);
-  }
-}
-// s_waitcnt with one field set (gfx9 encoding: vmcnt [3:0] | [15:14], expcnt [6:4], lgkmcnt [11:8])
-#define GAR_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | ((((n) >> 4) & 3) << 14))
-#define GAR_WAIT_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)
 // a value the compiler must take as new in every iteration: keeps the per-lane LDS addresses derived from it
 // from being hoisted out of the stage loop (36 + 18 loop-invariant addresses would cost the registers the
 // kernel exists to do without)

@@ -562,7 +562,9 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
     // quarter of the CU's LDS (four waves per CU)
     const int with_init = gar::WaveCfg<NX, NU>::total_with_init(s->nc0);
     s->wave_fused_init = (size_t)with_init * sizeof(double) <= 40 * 1024 && s->nth0 == 0;
-    s->wave_lds_doubles = s->wave_fused_init ? with_init : gar::WaveCfg<NX, NU>::total;
+    // (F-DMA: the next knot's [A | B] image lies behind `total`, under the fused initial stage's kkt0)
+    const int sweep = GAR_F_DMA ? gar::WaveCfg<NX, NU>::total_fdma : gar::WaveCfg<NX, NU>::total;
+    s->wave_lds_doubles = s->wave_fused_init ? std::max(with_init, sweep) : sweep;
     s->waves_per_block = 1; // one 64-thread workgroup per problem (constant LDS base)
     s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
     s->qr_packed = GAR_QR_PACKED != 0; // the sweep reads only the lower triangles of Q and R (gar_layout.h)
@@ -570,7 +572,7 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
     if (GAR_VXX_PACKED) {
       s->lean_fwd_kernel = gar::gar_forward_lean<NX, NU>;
       s->lean_fwd_used = gar::LeanFwdCfg<NX, NU>::USED; // (what it uses; pipe_plan decides what it asks for)
-      s->wave_lds_doubles_small = gar::WaveCfg<NX, NU>::total;
+      s->wave_lds_doubles_small = sweep;
     }
   }
 }

@@ -41,6 +41,13 @@
 
 namespace gar {
 
+// F-DMA (see WaveCfg::oF): measured and NOT adopted -- same box, alternating launches, batch 4 096: backward 11.32 ms
+// with it against 10.58 ms without (profiles/r05_ab_f_operands_by_lds_dma_not_kept.log), results bit for bit the same.
+// The 27 operand loads of sixteen 32-byte pieces each are not what the stage waits for.  `make fdma` builds it.
+#ifndef GAR_F_DMA
+#define GAR_F_DMA 0
+#endif
+
 template <int NX, int NU, int NC = 0> struct WaveCfg {
   using M = MfmaCfg<NX, NU, NC>;
   static constexpr int NW = NX + NU, TX = M::TX, TW = M::TW, KS = M::KS, KU = M::KU;
@@ -87,6 +94,13 @@ template <int NX, int NU, int NC = 0> struct WaveCfg {
   static constexpr int oDump = (oBk + 2 * BKS + 1) & ~1; // 2 doubles: target of masked-out LDS writes
   static constexpr int oFlag = oDump + 2;           // MODE 3: verdict of the factorisation (as a double)
   static constexpr int total = oDump + 4;
+  // F-DMA (GAR_F_DMA, the serial one-wave sweep NC = 0): [A | B] of the NEXT knot, requested into LDS at the start
+  // of the stage by global_load_lds (14 linear 1 KiB pieces at (36, 12) instead of 27 loads of sixteen 32-byte
+  // pieces each, no registers), read as MFMA operands where the stage used to load them from HBM.  It lies behind
+  // everything the stage uses -- where the fused initial stage's kkt0 goes once the sweep is over.
+  static constexpr int oF = (total + 1) & ~1;
+  static constexpr int f_doubles = NX * NW;
+  static constexpr int total_fdma = oF + f_doubles;
   // fused initial stage (after the sweep): the packed lower triangle of kkt0 = [Vxx0 G0^T; G0 0]
   // and its right-hand side overlay everything but V
   static constexpr int oK0 = oG;
@@ -96,6 +110,7 @@ template <int NX, int NU, int NC = 0> struct WaveCfg {
   __host__ __device__ static constexpr int total_with_init(int nc0) {
     return (oK0 + k0_doubles(NX + nc0)) > total ? (oK0 + k0_doubles(NX + nc0)) : total;
   }
+  __host__ __device__ static constexpr int imax(int a, int b) { return a > b ? a : b; }
   // ---- parameterised legs (gar_wave_leg.hpp; nth = NX): the extra state of the recursion
   // (riccati-kernel.hxx:278-311) lives in LDS in LANE-PRIVATE layouts, slot (s, tj) at
   // ((s*TX + tj)*64 + lane):
@@ -1312,7 +1327,7 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
                                                                    : fac + P.fac_offN + M::tVxx;
   for (int t = tstart; t >= 0; --t) {
     if constexpr (NC == 0) {
-      wave_stage2<NX, NU>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing);
+      wave_stage2<NX, NU, 0, false, (GAR_F_DMA != 0) && !M::WIDE>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing);
     } else {
       if constexpr (PHASE == 2) {
         if (lane == 0)

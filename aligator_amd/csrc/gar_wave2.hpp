@@ -342,6 +342,9 @@ __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], 
 // factorisation, B for Aff, the gains' stores, the next knot's loads, the V tiles -> LDS -- behind
 // the MFMAs of the tile columns, of Aff and of Vxx.
 #define GAR_SB __builtin_amdgcn_sched_barrier(0)
+#ifndef GAR_F_DMA_YOUNGER
+#define GAR_F_DMA_YOUNGER 24
+#endif
 
 // NC > 0 (equality constraints C x + D u + d = 0 on the knot, riccati-kernel.hxx:232-262): this stage
 // serves the DECOUPLED case D = 0 -- what the reference's own generator and benchmark produce
@@ -358,7 +361,7 @@ __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], 
 // (ldl_solve_mfma4_packed).  Returns 0 only when Bunch-Kaufman interchanges or takes a 2x2 pivot
 // somewhere: the caller then runs the stage with the LDS Bunch-Kaufman (wave_stage).
 // NC = 0: always returns 1.
-template <int NX, int NU, int NC = 0, bool COUPLED = false>
+template <int NX, int NU, int NC = 0, bool COUPLED = false, bool FDMA = false>
 __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, const double *prob,
                                            double *fac, int t, int lane,
                                            const WaveLane<NX, NU, NC> &L, WaveStage<NX, NU> &S,
@@ -394,6 +397,15 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
 #define GAR_WMARK(id)
 #endif
   GAR_WMARK(0)
+  static_assert(!FDMA || (NC == 0 && !WIDE && !COUPLED), "F-DMA: the plain serial stage");
+  // F-DMA: [A | B] of knot t-1 on its way into LDS now (the buffer's previous content -- this knot's -- went into
+  // the F operand registers during the previous stage); read back in the Aff phase below, a stage's worth of
+  // MFMAs later.  Fb: the buffer addressed like the knot record (the lane offsets of F include kA).
+  [[maybe_unused]] const double *Fb = sm + C::oF - M::kA;
+  if constexpr (FDMA) {
+    if (t > 0)
+      lean_dma<8 * C::f_doubles>(recn + M::kA, reinterpret_cast<char *>(sm + C::oF), lane);
+  }
   // ---- operands of the vector recursion: vx'[4s+lk] (LDS), f[4s+lk] (this knot: L2 hit) ------
   double vxs[KS], fs[KS];
 #pragma unroll
@@ -892,14 +904,22 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
       }
     } else if (q < nCol) {
       const int sq = q - nRow4; // k-step of F's column tile tj
-      const double v = WaveLane<NX, NU>::fo_in(tj) ? ldg_b(recn, 16 * tj * NX + 4 * sq, L.fo0)
-                                                   : ldg_b(recn, 4 * sq, L.foX);
+      const double *fsrc = FDMA ? Fb : recn; // (F-DMA: the same addressing, of the LDS image)
+      const double v = WaveLane<NX, NU>::fo_in(tj) ? ldg_b(fsrc, 16 * tj * NX + 4 * sq, L.fo0)
+                                                   : ldg_b(fsrc, 4 * sq, L.foX);
       if (sq < 4 * C::KSF)
         S.Fo[tj][(sq >> 2) < C::KSF ? (sq >> 2) : 0][sq & 3] = v;
       else
         S.FoT[tj][(sq - 4 * C::KSF) < C::KST ? (sq - 4 * C::KSF) : 0] = v;
     }
   };
+  if constexpr (FDMA) {
+    // the DMA pieces were the first vector-memory instructions of this stage; gfx9 retires loads and stores in order
+    // on one counter, so "at most GAR_F_DMA_YOUNGER instructions outstanding" implies "the pieces have landed" as long
+    // as at least that many were issued behind them -- the stage issues > 60 (counted in the ISA, Makefile: fdma_check)
+    GAR_WAIT_VMCNT(GAR_F_DMA_YOUNGER);
+    wave_lds_order();
+  }
   GAR_SB;
   int pend_col = -1, pend_q = 0; // column whose stores/loads are being slotted, next op of it
   int sK = 0;

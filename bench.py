@@ -541,8 +541,17 @@ def secondary_shapes(device, batch=1024):
     out = {}
     for key, (nx, nu, nc, N, mu, what) in {
             "reference_bench_shape_nc32": (36, 12, 32, 256, 1e-11, "bench/gar-riccati.cpp: nx=36 nu=12 nc=32 N=256, D=0 (its generator)"),
+            # the reference's GENERAL constrained stage (riccati-kernel.hxx:224-277): the same shape with a random D
+            # on every knot -- the 44 x 44 reduced KKT matrix [Rhat D^T; D -mu I] is then really coupled
+            "reference_bench_shape_nc32_coupled": (36, 12, 32, 256, 1e-11, "bench/gar-riccati.cpp's shape with D != 0 (U[-1,1]) on every knot: "
+                                                   "the coupled reduced KKT stage, nx=36 nu=12 nc=32 N=256"),
             "talos_walk_lq_shape": (56, 22, 0, 275, 1e-10, "bench/talos-walk.cpp LQ sub-problem shape: nx=56 nu=22 N=275")}.items():
         probs = [synth.generate_lq_problem(100 + i, np.zeros(nx), N, nx, nu, nc=nc, mode="W") for i in range(2)]
+        if key.endswith("_coupled"):
+            rng = np.random.default_rng(77)
+            for p_ in probs:
+                for k_ in p_.stages[:-1]:
+                    k_.D[...] = rng.uniform(-1.0, 1.0, k_.D.shape)
         s = BatchedRiccatiSolver([k.dims for k in probs[0].stages], nx, batch=batch, device=device)
         packed = np.concatenate([s.pack(p) for p in probs])
         for b0 in range(0, batch, 2):
@@ -578,8 +587,10 @@ def secondary_shapes(device, batch=1024):
             scale = max(1.0, max(float(np.abs(v).max()) for part in ref for v in part if v.size))
             err = max(err, max(float(np.abs(a - c).max()) for A, B in zip(sol, ref) for a, c in zip(A, B) if a.size) / scale)
             kkt = max(kkt, max(lqrComputeKktError(prob, *sol, mueq=mu)) / scale)
+        chain = s.constrained_bk_stages() if nc > 0 else None
         out[key] = {"workload": what, "batch": batch, "kernel": s.kernel_name, "sweeps_per_s": batch / dt,
                     "backward_ms": kb / reps, "failed_factorisations": failed,
+                    **({"stages_on_the_coupled_kernel_and_on_lds_bunch_kaufman": [int(v) for v in chain]} if chain is not None else {}),
                     "backward_frac_of_hbm_roofline": 8 * (knot + fac) * N * batch / (kb / reps * 1e-3) / HBM_PEAK,
                     "max_rel_err_vs_oracle": err, "max_kkt_rel": kkt}
         s.close()
