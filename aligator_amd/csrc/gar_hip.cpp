@@ -751,8 +751,12 @@ void select_kernel(gar_hip_solver *s) {
         m.in_off - s->meta[t - 1].in_off != s->meta[1 < N ? 1 : 0].in_off - m0.in_off)
       return;
   }
+  // (the terminal knot's factor record is addressed through compile-time offsets that assume nx2 = nx rows of
+  // [yff | Aff] in it: SolverProxDDP builds its terminal knot with nx2 = 0 (solvers/proxddp/workspace.hxx:54-55) --
+  // such a problem is the any-dimension kernels' unless the caller declares the knot with nx2 = nx, as the shipped
+  // binding include/aligator/gar/hip-riccati.hpp does; found by running the reference's own ProxDDP loop, round 5)
   const gar_stage_meta &mt = s->meta[N];
-  if (mt.nx != m0.nx || mt.nu != 0 || mt.nc != m0.nc || mt.nth != 0)
+  if (mt.nx != m0.nx || mt.nu != 0 || mt.nc != m0.nc || mt.nth != 0 || mt.nx2 != m0.nx)
     return;
   const int nx = m0.nx, nu = m0.nu;
   if (m0.nc != 0) { // every knot constrained (the reference's bench/gar-riccati.cpp shape)

@@ -529,6 +529,24 @@ def seam():
         return {"skipped": f"{type(e).__name__}: {e}"}
 
 
+def proxddp_loop():
+    """BASELINE configs[4] with the loop the reference itself runs: its OWN SolverProxDDP (compiled unchanged from
+    /root/reference over the Eigen stand-in, oracle/ref_ddp_build.sh) on tests/lqr.cpp's case and on bench/lqr.cpp's
+    (dim 56, nu 22: the Talos-walk LQ shape; Talos itself needs Pinocchio + example-robot-data, absent), with
+    `linear_solver_` = the reference's SERIAL / PARALLEL solvers and = the shipped HipRiccatiSolver, same box, same
+    process: convergence, iterations, wall clock per run, ProxDDP iterations per second
+    (tests/integration/proxddp_lqr_driver.cpp; the executable is built where /root/reference exists and travels)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "proxddp_lqr_gpu")
+    if not os.path.exists(exe):
+        return {"skipped": "oracle/_ref/proxddp_lqr_gpu not built (__graft_entry__.build() where /root/reference exists)"}
+    try:
+        r = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=300)
+        return json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    except Exception as e:   # noqa: BLE001
+        return {"skipped": f"{type(e).__name__}: {e}"}
+
+
 def secondary_shapes(device, batch=1024):
     """Two more shapes of the same hot path, outside the timed region (rank 0, one GPU), so that the round's
     bench record carries them: the reference's OWN gar benchmark shape (bench/gar-riccati.cpp:19-22: nx=36,
@@ -776,6 +794,7 @@ def main():
     # copy engines busy and every host<->device copy of the seam runs several times slower (measured: 0.92 -> 2.0 ms
     # and 2.3 -> 4.9 ms right after a 57 GB process, back to 0.92 / 2.3 twenty seconds later).
     seam_line = seam() if (world == 1 and rank == 0 and not args.no_extras) else None
+    ddp_line = proxddp_loop() if (world == 1 and rank == 0 and not args.no_extras) else None
     N, nx, nu, mueq = args.horizon, args.nx, args.nu, 1e-14
     dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
     solver = BatchedRiccatiSolver(dims, nx, batch=args.batch, num_legs=1, device=local_rank)
@@ -984,6 +1003,7 @@ def main():
             out["batch_scan"] = batch_scan(args, local_rank, stream, N, nx, nu, mueq, args.batch, sweeps / elapsed)
             out["config3"] = config3(args, local_rank, stream)
             out["seam"] = seam_line
+            out["proxddp_loop"] = ddp_line
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, nx, nu, N, mueq)
         print(json.dumps(out))

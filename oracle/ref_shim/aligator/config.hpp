@@ -10,3 +10,6 @@
 #define ALIGATOR_DLLEXPORT
 #define ALIGATOR_DLLLOCAL
 #define ALIGATOR_PRAGMA(x) _Pragma(#x)
+// (the generated header also carries these two: empty outside Windows)
+#define ALIGATOR_EXPLICIT_INSTANTIATION_DECLARATION_DLLAPI
+#define ALIGATOR_EXPLICIT_INSTANTIATION_DEFINITION_DLLAPI

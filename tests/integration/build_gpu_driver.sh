@@ -17,7 +17,7 @@ trap 'rm -rf "$FMTDIR"' EXIT
 ln -sfn "$FMT/fmt" "$FMTDIR/fmt"
 OUT="$ROOT/oracle/_ref/seam_driver_gpu"
 SRC="$HERE/seam_driver.cpp"
-if [ -f "$OUT" ] && [ -z "$(find "$SRC" "$ROOT/include" "$ROOT/oracle/ref_shim" "$ROOT/aligator_amd/libgar_hip.so" -newer "$OUT" 2>/dev/null | head -1)" ]; then
+if [ -f "$OUT" ] && [ -f "$ROOT/oracle/_ref/proxddp_lqr_gpu" ] && [ -z "$(find "$SRC" "$HERE/proxddp_lqr_driver.cpp" "$ROOT/include" "$ROOT/oracle/ref_shim" "$ROOT/aligator_amd/libgar_hip.so" -newer "$ROOT/oracle/_ref/proxddp_lqr_gpu" 2>/dev/null | head -1)" ]; then
   exit 0
 fi
 g++ -std=c++17 -O2 -fopenmp -DSEAM_GPU -DFMT_HEADER_ONLY -Wno-deprecated-declarations \
@@ -25,3 +25,12 @@ g++ -std=c++17 -O2 -fopenmp -DSEAM_GPU -DFMT_HEADER_ONLY -Wno-deprecated-declara
   "$SRC" "$REF/src/utils/exceptions.cpp" -L "$ROOT/aligator_amd" -lgar_hip \
   -Wl,-rpath,'$ORIGIN/../../aligator_amd' -Wl,-rpath,/opt/rocm/lib -Wl,--allow-shlib-undefined
 echo "built $OUT"
+# ... and the reference's own SolverProxDDP loop on the backend (tests/integration/proxddp_lqr_driver.cpp over
+# oracle/_ref/libaligator_ddp_ref.so, oracle/ref_ddp_build.sh)
+bash "$ROOT/oracle/ref_ddp_build.sh"
+OUT2="$ROOT/oracle/_ref/proxddp_lqr_gpu"
+g++ -std=c++17 -O2 -fopenmp -DDDP_GPU -DFMT_HEADER_ONLY -include aligator/context.hpp -Wno-deprecated-declarations \
+  -I "$ROOT/oracle/ref_shim" -I "$REF/include" -I "$FMTDIR" -I "$ROOT/include" -o "$OUT2" \
+  "$HERE/proxddp_lqr_driver.cpp" -L "$ROOT/oracle/_ref" -laligator_ddp_ref -L "$ROOT/aligator_amd" -lgar_hip \
+  -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../aligator_amd' -Wl,-rpath,/opt/rocm/lib -Wl,--allow-shlib-undefined
+echo "built $OUT2"

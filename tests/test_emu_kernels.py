@@ -897,3 +897,33 @@ def test_backward_blocks_is_the_upload_and_backward_sequence():
     two = BatchedRiccatiSolver(dims, nx, batch=2, lib_path=EMU)
     with pytest.raises(RuntimeError, match="batch"):
         two.backward_blocks(prob, 1e-10)
+
+
+def test_terminal_knot_without_successor_dimension_goes_to_the_any_dimension_kernels():
+    """SolverProxDDP builds its terminal knot with nx2 = 0 (solvers/proxddp/workspace.hxx:54-55).  The specialised
+    families address the terminal factor record through offsets that assume nx2 = nx rows of [yff | Aff] in it:
+    until round 5 such a problem bound `wave<8,4>` all the same and the sweep wrote 72 doubles past the factor
+    records (found by running the reference's own ProxDDP loop on the backend under AddressSanitizer).  It is the
+    any-dimension kernels' now, with the right answer; the shipped binding declares the knot with nx2 = nx instead
+    (include/aligator/gar/hip-riccati.hpp) and keeps the fast kernels (tests/test_integration_binding.py)."""
+    from aligator_amd.gar import BatchedRiccatiSolver, lqrComputeKktError
+    from aligator_amd.lqr import LqrKnot, LqrProblem
+    nx, nu, N = 8, 4, 6
+    base = synth.generate_lq_problem(5, np.ones(nx), N, nx, nu, mode="W")
+    term = LqrKnot(nx, 0, 0, 0)                       # nx2 = 0
+    term.Q[...] = base.stages[-1].Q
+    term.q[...] = base.stages[-1].q
+    prob = LqrProblem(base.stages[:-1] + [term], nx)
+    prob.G0[...] = base.G0
+    prob.g0[...] = base.g0
+    for batch in (1, 3):
+        s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=batch, lib_path=EMU)
+        assert s.kernel_name == "generic"
+        s.upload([prob] * batch)
+        assert s.backward(1e-10) and s.forward()
+        sol = s.solution(batch - 1)
+        _, _, ref = pc.oracle_serial(base, 1e-10)     # (the oracle never reads the terminal A, f either)
+        for a, b in zip(sol, ref):
+            assert pc.maxdiff(a, b) <= 1e-9 * pc.scale_of(ref)
+        assert max(lqrComputeKktError(prob, *sol, mueq=1e-10)) <= 1e-9
+        s.close()

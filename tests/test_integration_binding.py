@@ -38,6 +38,47 @@ def test_gpu_reference_typed_binding_on_the_device():
     assert r.stdout.count(" ok\n") >= 10 and "MISMATCH" not in r.stdout
 
 
+@pytest.mark.gpu
+def test_gpu_reference_proxddp_loop_on_the_device():
+    """BASELINE configs[0] / [4] as stated: the reference's OWN SolverProxDDP loop (compiled unchanged from
+    /root/reference over the Eigen stand-in: oracle/ref_ddp_build.sh -> oracle/_ref/libaligator_ddp_ref.so) with
+    `linear_solver_` replaced by the shipped HipRiccatiSolver on the real library: tests/lqr.cpp's case converges in
+    ONE iteration exactly as with the reference's own solvers (same trajectories to 1e-8), and bench/lqr.cpp's loop
+    (dim 56, nu 22: the Talos-walk LQ shape) is timed -- ProxDDP iterations per second, reference SERIAL / PARALLEL
+    beside the backend serial / in leg mode, same box (tests/integration/proxddp_lqr_driver.cpp)."""
+    if os.path.isdir(os.path.join(REF, "include", "aligator", "gar")):
+        subprocess.run(["bash", os.path.join(HERE, "integration", "build_gpu_driver.sh")], check=True)
+    exe = os.path.join(ROOT, "oracle", "_ref", "proxddp_lqr_gpu")
+    assert os.path.exists(exe), "oracle/_ref/proxddp_lqr_gpu is built by __graft_entry__.build() where /root/reference exists"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    print("\n".join(ln for ln in r.stdout.splitlines() if "Warning" not in ln))
+    assert r.returncode == 0 and "proxddp ok" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
+    # the specialised families ran (the terminal knot ProxDDP builds has nx2 = 0: the binding declares it with nx2 = nx)
+    assert "kernel wave<8,4>" in r.stdout and "kernel pair<56,24>" in r.stdout and "kernel pair_leg<56,24>" in r.stdout
+
+
+@needs_reference
+def test_the_reference_proxddp_loop_runs_on_the_backend(tmp_path):
+    """the same driver on CPU: linked with the wave-emulator build, tests/lqr.cpp's case in full (num_iters == 1 with
+    the reference's solvers and with HipRiccatiSolver, serial and 4 legs) and a small bench/lqr.cpp-shaped loop"""
+    subprocess.run(["bash", os.path.join(ROOT, "oracle", "ref_ddp_build.sh")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu")], check=True)
+    refdir, emu = os.path.join(ROOT, "oracle", "_ref"), os.path.join(HERE, "emu", "_build")
+    exe = tmp_path / "proxddp_lqr_emu"
+    cmd = ["g++", "-std=c++17", "-O1", "-fopenmp", "-DFMT_HEADER_ONLY", "-include", "aligator/context.hpp",
+           "-Wno-deprecated-declarations", "-I", os.path.join(ROOT, "oracle", "ref_shim"), "-I", os.path.join(REF, "include"),
+           "-I", os.path.join(refdir, "fmt_only"), "-I", os.path.join(ROOT, "include"), "-o", str(exe),
+           os.path.join(HERE, "integration", "proxddp_lqr_driver.cpp"), "-L", refdir, "-laligator_ddp_ref",
+           f"-Wl,-rpath,{refdir}", "-L", emu, "-lgar_hip_emu", f"-Wl,-rpath,{emu}", "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    r = subprocess.run([str(exe), "--quick"], capture_output=True, text=True, timeout=3000)
+    out = "\n".join(ln for ln in r.stdout.splitlines() if "Warning" not in ln)
+    print(out)
+    assert r.returncode == 0 and "proxddp ok" in r.stdout, out[-3000:] + r.stderr[-2000:]
+    assert out.count("num_iters 1 ") == 4 and "kernel wave<8,4>" in out and "kernel wave_leg<8,4>" in out
+
+
 @needs_reference
 def test_the_shipped_binding_compiles_against_the_reference_and_matches_its_solvers(tmp_path):
     import torch
