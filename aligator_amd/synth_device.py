@@ -123,6 +123,8 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
 def download_problem(solver, b: int) -> LqrProblem:
     """Host LqrProblem (the caller's dimensions) of a sampled problem."""
     k = b % solver.batch
-    if solver.padded or getattr(solver, "qr_packed", False):   # the library converts: gar_hip_download_packed
+    # (gar_hip_download_packed converts from whatever the device records are -- padded, packed triangles -- to the
+    # caller's packed layout; the host copies kept by fill_problems serve the problems listed in `keep` only)
+    if solver.padded or getattr(solver, "qr_packed", False) or k not in getattr(solver, "_host_samples", {}):
         return solver.unpack(solver.download_packed(k, 1))
     return solver.unpack(solver._host_samples[k])

@@ -54,7 +54,7 @@ def test_gpu_reference_proxddp_loop_on_the_device():
     print("\n".join(ln for ln in r.stdout.splitlines() if "Warning" not in ln))
     assert r.returncode == 0 and "proxddp ok" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
     # the specialised families ran (the terminal knot ProxDDP builds has nx2 = 0: the binding declares it with nx2 = nx)
-    assert "kernel wave<8,4>" in r.stdout and "kernel pair<56,24>" in r.stdout and "kernel pair_leg<56,24>" in r.stdout
+    assert "<8,4>  ok" in r.stdout and "kernel wave_leg<8,4>" in r.stdout and "kernel pair<56,24>" in r.stdout and "kernel pair_leg<56,24>" in r.stdout
 
 
 @needs_reference
