@@ -33,7 +33,9 @@
 #include "gar_leg_seg.hpp"
 
 namespace gar { // instantiated in gar_wave_sweep.cpp (its own translation unit, its own code-generation flags)
-#define GAR_SWEEP_EXTERN(NX, NU) extern template __global__ void gar_backward_wave<NX, NU, 0>(MfmaParams, int);
+#define GAR_SWEEP_EXTERN(NX, NU)                                                                                        \
+  extern template __global__ void gar_backward_wave<NX, NU, 0>(MfmaParams, int);                                       \
+  extern template __global__ void gar_backward_wave_half<NX, NU>(MfmaParams, int);
 GAR_SWEEP_SHAPES(GAR_SWEEP_EXTERN)
 #undef GAR_SWEEP_EXTERN
 } // namespace gar
@@ -287,6 +289,7 @@ struct gar_hip_solver {
   // OTHER half leaves free on every SIMD (gar_forward_lean.hpp): B(h0) | F(h0) + B(h1) | F(h1) + B'(h0) | ...
   int pipe_halves = 0;                 // 0: off
   void (*lean_fwd_kernel)(gar::MfmaFwdParams, int) = nullptr;
+  void (*wave_half_kernel)(gar::MfmaParams, int) = nullptr; // the backward sweep under its half-batch launch name
   size_t lean_fwd_used = 0;            // LDS the kernel uses
   size_t lean_fwd_lds_bytes = 0;       // what the launch ASKS for (> half a CU: one workgroup per CU), see pipe_plan
   int wave_lds_doubles_small = 0;      // the backward launch without the fused initial stage's kkt0 overlay
@@ -571,6 +574,7 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
     // the pipelined sweep's roll-out (gar_hip_set_pipeline): reads the packed Vxx records
     if (GAR_VXX_PACKED) {
       s->lean_fwd_kernel = gar::gar_forward_lean<NX, NU>;
+      s->wave_half_kernel = gar::gar_backward_wave_half<NX, NU>;
       s->lean_fwd_used = gar::LeanFwdCfg<NX, NU>::USED; // (what it uses; pipe_plan decides what it asks for)
       s->wave_lds_doubles_small = sweep;
     }
@@ -1556,7 +1560,7 @@ int pipe_backward(gar_hip_solver *s, double mueq) {
     M.trace = nullptr;
     if (s->timing)
       HIP_TRY(hipEventRecord(s->pipe_evT[h][0], st));
-    hipLaunchKernelGGL(s->wave_kernel, dim3((unsigned)nb), dim3(64), (size_t)s->wave_lds_doubles_small * sizeof(double),
+    hipLaunchKernelGGL(s->wave_half_kernel, dim3((unsigned)nb), dim3(64), (size_t)s->wave_lds_doubles_small * sizeof(double),
                        st, M, nb);
     if (s->timing)
       HIP_TRY(hipEventRecord(s->pipe_evT[h][1], st));
@@ -2487,7 +2491,7 @@ int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
   if (halves != 2)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_set_pipeline: 0 (off) or 2 (two half-batches)");
   if (s->multi || s->world > 1 || s->num_legs != 1 || s->nth0 != 0 || s->batch < 2 || !s->wave_kernel || !s->lean_fwd_kernel ||
-      s->wave_coupled_kernel || s->wave_block_threads != 64 || s->waves_per_block != 1 || !s->vxx_packed || s->dense)
+      !s->wave_half_kernel || s->wave_coupled_kernel || s->wave_block_threads != 64 || s->waves_per_block != 1 || !s->vxx_packed || s->dense)
     return fail(GAR_HIP_ERR_UNSUPPORTED, "pipelined sweep: serial, unconstrained, unparameterised batches (>= 2 problems) "
                                          "on the one-wave-per-problem kernel family only (this solver runs " +
                                              s->kernel_name + ")");
@@ -2496,6 +2500,8 @@ int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
   if (!s->pipe_stream[0]) {
     HIP_TRY(hipFuncSetAttribute((const void *)s->lean_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)s->lean_fwd_lds_bytes));
+    HIP_TRY(hipFuncSetAttribute((const void *)s->wave_half_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)s->wave_lds_doubles_small * sizeof(double))));
     for (int h = 0; h < 2; ++h) {
       {
         // two streams that share a hardware queue run their kernels one after the other, in submission order: the

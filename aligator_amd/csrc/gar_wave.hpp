@@ -1445,6 +1445,12 @@ template <int NX, int NU, int NC = 0>
 __global__ void __launch_bounds__(64, 1) gar_backward_wave(MfmaParams P, int batch) {
   gar_backward_wave_body<NX, NU, NC, 0>(P, batch);
 }
+// the same sweep under a name of its own for the HALF-batch launches of the pipelined schedule (gar_hip_set_pipeline):
+// a profile of a run that uses both schedules then lists the two launch populations apart
+template <int NX, int NU>
+__global__ void __launch_bounds__(64, 1) gar_backward_wave_half(MfmaParams P, int batch) {
+  gar_backward_wave_body<NX, NU, 0, 0>(P, batch);
+}
 // The plain unconstrained shapes are instantiated ONCE, in gar_wave_sweep.cpp (a translation unit of its own: see
 // there); every other translation unit sees them as extern templates.
 #define GAR_SWEEP_SHAPES(X) X(36, 12) X(32, 12) X(16, 8) X(12, 8) X(12, 4) X(8, 4)

@@ -10,7 +10,9 @@
 #include "gar_wave.hpp"
 
 namespace gar {
-#define GAR_SWEEP_INSTANCE(NX, NU) template __global__ void gar_backward_wave<NX, NU, 0>(MfmaParams, int);
+#define GAR_SWEEP_INSTANCE(NX, NU)                                                                                      \
+  template __global__ void gar_backward_wave<NX, NU, 0>(MfmaParams, int);                                              \
+  template __global__ void gar_backward_wave_half<NX, NU>(MfmaParams, int); // (the pipelined schedule's launches)
 GAR_SWEEP_SHAPES(GAR_SWEEP_INSTANCE)
 #undef GAR_SWEEP_INSTANCE
 } // namespace gar
