@@ -542,7 +542,9 @@ def proxddp_loop():
         return {"skipped": "oracle/_ref/proxddp_lqr_gpu not built (__graft_entry__.build() where /root/reference exists)"}
     try:
         r = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=300)
-        return json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        # (the reference's logger colours its warnings: the JSON object may sit behind an ANSI reset on its line)
+        line = [ln for ln in r.stdout.splitlines() if '{"what"' in ln][-1]
+        return json.loads(line[line.index('{"what"'):])
     except Exception as e:   # noqa: BLE001
         return {"skipped": f"{type(e).__name__}: {e}"}
 

@@ -39,6 +39,7 @@ if has pmc; then
 fi
 if has sq; then
   echo "== sq counters =="
+  mkdir -p $R/gpurun_out/sq
   P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU"
   (cd /tmp && timeout 300 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d $R/gpurun_out/sq/p1 -o sq -- python $R/bench.py --steps 2 --warmup 1 --batch 4096 --no-cpu --no-legs --no-extras --single-generator --pmc off > $R/gpurun_out/sq/p1.log 2>&1)
   python - > $O/sq_counters_batch4096.log <<'PY'
