@@ -92,6 +92,8 @@ SIGNATURES = {
     "gar_hip_deriv_doubles": (C.c_int64, [C.c_void_p]),
     "gar_hip_deriv_offsets": (C.c_int, [C.c_void_p, C.c_int, _PI64]),
     "gar_hip_update_lq_subproblem_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int]),
+    "gar_hip_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "gar_hip_get_option": (C.c_char_p, [C.c_char_p]),
     "gar_hip_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "gar_hip_pipeline": (C.c_int, [C.c_void_p]),
     "gar_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -81,7 +83,7 @@ struct Roctx {
   int (*push)(const char *) = nullptr;
   int (*pop)() = nullptr;
   Roctx() {
-    const char *e = std::getenv("GAR_HIP_ROCTX");
+    const char *e = std::getenv("GAR_HIP_ROCTX"); // (read once, when the first range opens: environment only)
     if (!e || e[0] != '1')
       return;
     if (void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL)) {
@@ -110,6 +112,27 @@ struct RoctxRange {
 // Every entry point runs on the solver's own device, whatever the caller's current device is, and
 // leaves the caller's current device as it found it (two solvers on two GPUs in one process;
 // torch's notion of the current device).
+// Behaviour switches (kernel family, padding, condensed solver, ...): `GAR_HIP_*` names, looked up in the overrides
+// set through gar_hip_set_option first, in the environment second.  Most are read when a solver is created
+// (family selection), some per launch (GAR_HIP_SPD_ACCEPT) -- include/gar_hip.h lists them.
+std::mutex &option_mutex() {
+  static std::mutex m;
+  return m;
+}
+std::map<std::string, std::string> &option_overrides() {
+  static std::map<std::string, std::string> o;
+  return o;
+}
+const char *gar_option(const char *name) {
+  {
+    std::lock_guard<std::mutex> g(option_mutex());
+    auto it = option_overrides().find(name);
+    if (it != option_overrides().end())
+      return it->second.c_str(); // (entries are never erased while in use: an unset stores "" -> treated as unset)
+  }
+  return std::getenv(name);
+}
+
 void pipe_autojoin(const gar_hip_solver *s);
 struct DeviceGuard {
   int prev = -1, dev;
@@ -543,7 +566,7 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
   // one 4-wave workgroup per problem (latency: a problem gets a whole CU; measured 2.2 ms vs
   // 3.0 ms per sweep while there are no more problems than CUs).  GAR_HIP_BACKWARD=wave|wg4
   // overrides the choice.
-  const char *bw = std::getenv("GAR_HIP_BACKWARD");
+  const char *bw = gar_option("GAR_HIP_BACKWARD");
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
   const bool want_wave = bw ? std::string(bw) != "wg4" : s->batch > cus;
@@ -586,7 +609,7 @@ template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
 // and the forward sweep on the generic kernels.
 template <int NX, int NU> void bind_wide(gar_hip_solver *s) {
   // two waves per problem (the tile columns split between them) unless GAR_HIP_WIDE=single
-  const char *w = std::getenv("GAR_HIP_WIDE");
+  const char *w = gar_option("GAR_HIP_WIDE");
   const bool pair = !(w && std::string(w) == "single");
   if (!(w && std::string(w) == "generic-forward"))
     s->mfma_fwd_kernel = gar::gar_forward_wide<NX, NU>; // row-major fb: fb_t2 stays false
@@ -608,14 +631,14 @@ template <int NX, int NU> void bind_wide(gar_hip_solver *s) {
 template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
   s->fb_t2 = true;
   // two waves per leg (plain part / parameter part) unless GAR_HIP_LEG_WAVES=1
-  const char *lw = std::getenv("GAR_HIP_LEG_WAVES");
+  const char *lw = gar_option("GAR_HIP_LEG_WAVES");
   s->leg_waves = (lw && std::string(lw) == "1") ? 1 : 2;
   s->leg_bwd_kernel = s->leg_waves == 2 ? gar::gar_backward_wave_leg2<NX, NU> : gar::gar_backward_wave_leg<NX, NU>;
   s->leg_tuple_kernel = gar::gar_leg_tuples<NX, NU>;
   s->leg_fwd_kernel = gar::gar_forward_wave_leg<NX, NU>;
   s->leg_collapse_kernel = gar::gar_collapse_feedback_t2<NX, NU>;
   s->leg_lds_doubles = s->leg_waves == 2 ? gar::WaveCfg<NX, NU>::leg2_total : gar::WaveCfg<NX, NU>::leg_total;
-  const char *ck = std::getenv("GAR_HIP_CONDENSED");
+  const char *ck = gar_option("GAR_HIP_CONDENSED");
   if (!(ck && std::string(ck) == "generic")) {
     const int lds = 4 * NX * NX + 16 * NX + NX + NX + (NX & 1) + (NX + 16) / 2 + 2 +
                     2 * (2 * s->num_legs) * NX + 2;
@@ -647,7 +670,7 @@ template <int NX, int NU> void bind_seg_leg(gar_hip_solver *s) {
 // leg mode: uniform unconstrained problem whose every leg holds at least two knots
 void select_leg_kernel(gar_hip_solver *s) {
   const int N = s->horizon;
-  const char *lk = std::getenv("GAR_HIP_LEGS");
+  const char *lk = gar_option("GAR_HIP_LEGS");
   if (lk && std::string(lk) == "generic")
     return;
   if (N < 1 || s->nxb != s->dims5[0])
@@ -662,7 +685,7 @@ void select_leg_kernel(gar_hip_solver *s) {
   }
   // constrained knots: folded onto the unconstrained family (gar_fold.hpp); the generic leg kernels are the
   // fallback for problems with D != 0, so they must fit a CU's LDS
-  const char *fe = std::getenv("GAR_HIP_FOLD");
+  const char *fe = gar_option("GAR_HIP_FOLD");
   if (any_nc && (!s->lds_error.empty() || (fe && fe[0] == '0')))
     return;
   for (int i = 0; i < s->num_legs; ++i) {
@@ -678,7 +701,7 @@ void select_leg_kernel(gar_hip_solver *s) {
   else if (nx == 12 && nu == 4) bind_leg<12, 4>(s);
   else if (nx == 8 && nu == 4) bind_leg<8, 4>(s);
   else if (nx == 56 && nu == 24 && !any_nc) {
-    const char *sg = std::getenv("GAR_HIP_SEG_LEGS");
+    const char *sg = gar_option("GAR_HIP_SEG_LEGS");
     if (!(sg && sg[0] == '0') && (size_t)gar::leg_stage_lds_doubles(56, 24) * sizeof(double) <= 160 * 1024)
       bind_seg_leg<56, 24>(s);
   }
@@ -728,7 +751,7 @@ void select_kernel(gar_hip_solver *s) {
   s->vxx_packed = false;
   s->qr_packed = false;
   {
-    const char *ik = std::getenv("GAR_HIP_INIT");
+    const char *ik = gar_option("GAR_HIP_INIT");
     s->init_closed = !(ik && std::string(ik) == "bk");
   }
   s->kernel_name = "generic";
@@ -736,7 +759,7 @@ void select_kernel(gar_hip_solver *s) {
     s->kernel_name = "dense";
     return;
   }
-  const char *force = std::getenv("GAR_HIP_FORCE_GENERIC");
+  const char *force = gar_option("GAR_HIP_FORCE_GENERIC");
   if (force && force[0] == '1')
     return;
   const int N = s->horizon;
@@ -792,7 +815,7 @@ void choose_padding(gar_hip_solver *s) {
   s->nc0 = s->user_nc0;
   s->padded = false;
   s->unx = s->unu = s->pnx = s->pnu = 0;
-  const char *pe = std::getenv("GAR_HIP_PAD");
+  const char *pe = gar_option("GAR_HIP_PAD");
   const int N = s->horizon;
   if (s->dense || (pe && pe[0] == '0') || N < 1)
     return;
@@ -1239,7 +1262,7 @@ gar::MfmaParams make_mfma_params(gar_hip_solver *s, double mueq) {
   M.init_closed = s->init_closed ? 1 : 0;
   M.ring0 = s->ring0;
   {
-    const char *sa = std::getenv("GAR_HIP_SPD_ACCEPT");
+    const char *sa = gar_option("GAR_HIP_SPD_ACCEPT");
     M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
   }
   return M;
@@ -1303,7 +1326,7 @@ int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
     M.horizon = N;
     M.mueq = mueq;
     {
-      const char *sa = std::getenv("GAR_HIP_SPD_ACCEPT");
+      const char *sa = gar_option("GAR_HIP_SPD_ACCEPT");
       M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
     }
     const dim3 grid((unsigned)(l1 - l0), (unsigned)s->batch);
@@ -1472,135 +1495,7 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
   return GAR_HIP_OK;
 }
 
-// ---- the pipelined sweep (gar_hip_set_pipeline) -------------------------------------------------------------------
-// LDS of a CU, planned: 4 backward waves (one per SIMD, wave_lds_doubles_small each: the launch without the fused
-// initial stage's kkt0 overlay) + ONE forward workgroup (gar_forward_lean: four waves, one per SIMD).  The forward
-// launch ASKS for more than half of the CU's LDS, so that a second forward workgroup never fits: two forward waves
-// on a SIMD would take the registers a backward wave needs (432 + 80 of 512).
-constexpr size_t kCuLdsBytes = 160 * 1024, kLdsGranule = 1280; // gfx950: 160 KiB per CU, allocated in 320-dword pieces
-inline size_t lds_round(size_t b) { return (b + kLdsGranule - 1) / kLdsGranule * kLdsGranule; }
-int pipe_plan(gar_hip_solver *s, size_t lean_used) {
-  const size_t bwd = lds_round((size_t)s->wave_lds_doubles_small * sizeof(double));
-  size_t ask = lds_round(lean_used);
-  if (ask <= kCuLdsBytes / 2)
-    ask = lds_round(kCuLdsBytes / 2 + 1);
-  if (4 * bwd + ask > kCuLdsBytes)
-    return fail(GAR_HIP_ERR_UNSUPPORTED, "pipelined sweep: four backward waves (" + std::to_string(bwd) +
-                                             " B of LDS each) and one forward workgroup (" + std::to_string(ask) +
-                                             " B) do not share a CU");
-  s->lean_fwd_lds_bytes = ask;
-  return GAR_HIP_OK;
-}
-inline bool pipe_on(const gar_hip_solver *s) { return s && s->pipe_halves == 2; }
-inline void pipe_range(const gar_hip_solver *s, int h, int *b0, int *nb) {
-  const int first = (s->batch + 1) / 2;
-  *b0 = h == 0 ? 0 : first;
-  *nb = h == 0 ? first : s->batch - first;
-}
-// the caller's stream behind everything the half streams hold
-int pipe_join(gar_hip_solver *s) {
-  if (!s->pipe_forked)
-    return GAR_HIP_OK;
-  for (int h = 0; h < 2; ++h) {
-    HIP_TRY(hipEventRecord(s->pipe_evF[h], s->pipe_stream[h])); // (covers the sweeps too: stream order)
-    HIP_TRY(hipStreamWaitEvent(s->stream, s->pipe_evF[h], 0));
-  }
-  s->pipe_forked = false;
-  return GAR_HIP_OK;
-}
-void pipe_autojoin(const gar_hip_solver *s) {
-  if (s && s->pipe_forked)
-    (void)pipe_join(const_cast<gar_hip_solver *>(s));
-}
-// ... and the half streams behind what the caller's stream holds (uploads, a previous unpipelined sweep)
-int pipe_fork(gar_hip_solver *s) {
-  if (s->pipe_forked)
-    return GAR_HIP_OK;
-  HIP_TRY(hipEventRecord(s->pipe_evFork, s->stream));
-  for (int h = 0; h < 2; ++h)
-    HIP_TRY(hipStreamWaitEvent(s->pipe_stream[h], s->pipe_evFork, 0));
-  s->pipe_forked = true;
-  return GAR_HIP_OK;
-}
-int pipe_backward(gar_hip_solver *s, double mueq) {
-  RoctxRange range_("gar::backwardImpl+factor_initial (pipelined)");
-  s->eager_fwd = false;
-  if (s->ev_pref) {
-    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_pref, 0));
-    s->pref_b = -1;
-  }
-  if (s->dirty) { // staged host data goes out on the caller's stream: order it, then fork again
-    if (int rc = pipe_join(s))
-      return rc;
-    if (int rc = commit(s))
-      return rc;
-  }
-  if (int rc = pipe_fork(s))
-    return rc;
-  const gar::MfmaParams M0 = make_mfma_params(s, mueq);
-  const gar::GenericParams G0 = make_params(s, mueq);
-  for (int h = 0; h < 2; ++h) {
-    int b0, nb;
-    pipe_range(s, h, &b0, &nb);
-    hipStream_t st = s->pipe_stream[h];
-    // backward sweeps alternate between the halves: this one starts when the other half's last one has ended --
-    // which is also when that half's forward sweep starts (its stream's next kernel)
-    if (s->pipe_evB_valid[1 - h])
-      HIP_TRY(hipStreamWaitEvent(st, s->pipe_evB[1 - h], 0));
-    HIP_TRY(hipMemsetAsync(s->d_status + b0, 0, sizeof(int) * (size_t)nb, st));
-    if (h == 0) // the slow-path counters of "the last backward" cover both halves (the second half runs behind this one)
-      HIP_TRY(hipMemsetAsync(s->d_status + s->batch, 0, sizeof(int) * 4, st));
-    gar::MfmaParams M = M0;
-    M.prob += (long long)b0 * M.prob_stride;
-    M.fac += (long long)b0 * M.fac_stride;
-    M.status += b0;
-    M.resume += b0;
-    M.init = s->d_init + (long long)b0 * M.init_stride;
-    M.init_small = 1;
-    M.trace = nullptr;
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->pipe_evT[h][0], st));
-    hipLaunchKernelGGL(s->wave_half_kernel, dim3((unsigned)nb), dim3(64), (size_t)s->wave_lds_doubles_small * sizeof(double),
-                       st, M, nb);
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->pipe_evT[h][1], st));
-    // the problems whose initial condition is not "x0 given" (no closed form): every other wave leaves at once
-    gar::GenericParams G = G0;
-    G.prob += (long long)b0 * G.prob_stride;
-    G.fac += (long long)b0 * G.fac_stride;
-    G.init += (long long)b0 * G.init_stride;
-    G.status += b0;
-    G.only = M.resume;
-    hipLaunchKernelGGL(gar::gar_initial_wave, dim3((unsigned)nb), dim3(64),
-                       (size_t)gar::gar_initial_wave_lds_doubles(s->n0, s->nth0) * sizeof(double), st, G);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->pipe_evB[h], st));
-    s->pipe_evB_valid[h] = true;
-  }
-  return GAR_HIP_OK;
-}
-int pipe_forward(gar_hip_solver *s) {
-  RoctxRange range_("gar::forwardImpl (pipelined)");
-  if (int rc = pipe_fork(s))
-    return rc;
-  const gar::MfmaFwdParams F0 = make_mfma_fwd_params(s);
-  for (int h = 0; h < 2; ++h) {
-    int b0, nb;
-    pipe_range(s, h, &b0, &nb);
-    hipStream_t st = s->pipe_stream[h];
-    gar::MfmaFwdParams F = F0;
-    F.fac += (long long)b0 * F.fac_stride;
-    F.init += (long long)b0 * F.init_stride;
-    F.sol += (long long)b0 * F.sol_stride;
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->pipe_evT[h][2], st));
-    hipLaunchKernelGGL(s->lean_fwd_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), s->lean_fwd_lds_bytes, st, F, nb);
-    HIP_TRY(hipGetLastError());
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->pipe_evT[h][3], st));
-  }
-  return GAR_HIP_OK;
-}
+#include "gar_pipeline.hpp"
 
 int launch_condensed(gar_hip_solver *s) {
   RoctxRange range_("gar::assembleCondensedSystem+symmetricBlockTridiagSolve");
@@ -1807,11 +1702,11 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipMemset(s->d_cscratch, 0, sizeof(double) * (size_t)s->cscratch_doubles * B));
     s->cond_lds_doubles = (int)(3 * bs + 4 * s->nxb + 2 + (s->nxb + 16) / 2 + 2 + (s->nxb < 9 ? 9 * s->nxb : 0));
     {
-      const char *cr = std::getenv("GAR_HIP_CONDENSED_REDUCED");
+      const char *cr = gar_option("GAR_HIP_CONDENSED_REDUCED");
       s->cond_reduced = !(cr && cr[0] == '0') && s->nx0 == s->nxb &&
                         (size_t)gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double) <= 160 * 1024;
       // cyclic reduction of the reduced system: log2 J dependent steps instead of J; below 4 legs the chain is as short
-      const char *cc = std::getenv("GAR_HIP_CONDENSED_CR");
+      const char *cc = gar_option("GAR_HIP_CONDENSED_CR");
       const int cr_min = cc && cc[0] ? std::atoi(cc) : 4;
       s->cond_cr = s->cond_reduced && cr_min >= 1 && s->num_legs >= std::max(cr_min, 2) && s->nc0 <= s->nxb &&
                    (size_t)gar::gar_condensed_cr_back_lds_doubles(s->nxb, s->num_legs) * sizeof(double) <= 160 * 1024;
@@ -1845,7 +1740,7 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(gar_host_malloc((void **)&s->h_prob, staging, hipHostMallocDefault));
     std::memset(s->h_prob, 0, staging);
     s->staged = true;
-    const char *nt = std::getenv("GAR_HIP_STAGE_NT");
+    const char *nt = gar_option("GAR_HIP_STAGE_NT");
     s->stage_nt = nt && nt[0] ? nt[0] == '1' : sizeof(double) * (size_t)s->prob_doubles >= ((size_t)12 << 20);
   }
   s->dirty_iv.assign(B, {});
@@ -2480,6 +2375,36 @@ int gar_hip_forward_legs_async(gar_hip_solver *s) {
   return launch_forward(s, nullptr);
 }
 
+int gar_hip_set_option(const char *name, const char *value) {
+  if (!name || !*name)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_set_option: empty name");
+  std::string key = name;
+  if (key.rfind("GAR_HIP_", 0) != 0)
+    key = "GAR_HIP_" + key;
+  static const char *known[] = {"BACKWARD", "WIDE", "LEG_WAVES", "CONDENSED", "CONDENSED_REDUCED", "CONDENSED_CR", "LEGS",
+                                "FOLD", "SEG_LEGS", "INIT", "FORCE_GENERIC", "PAD", "SPD_ACCEPT", "STAGE_NT", "EAGER",
+                                "MULTI_EXCHANGE", "PIPE_PRIORITY"};
+  bool ok = false;
+  for (const char *k : known)
+    ok |= key == std::string("GAR_HIP_") + k;
+  if (!ok)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_set_option: unknown switch " + key + " (include/gar_hip.h lists them)");
+  std::lock_guard<std::mutex> g(option_mutex());
+  if (value)
+    option_overrides()[key] = value;
+  else
+    option_overrides().erase(key);
+  return GAR_HIP_OK;
+}
+const char *gar_hip_get_option(const char *name) {
+  if (!name)
+    return nullptr;
+  std::string key = name;
+  if (key.rfind("GAR_HIP_", 0) != 0)
+    key = "GAR_HIP_" + key;
+  return gar_option(key.c_str());
+}
+
 int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
   GAR_GUARD(s); // (orders the caller's stream behind anything the half streams still hold)
   if (!s)
@@ -2508,7 +2433,7 @@ int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
         // runtime hands out at most GPU_MAX_HW_QUEUES (4) queues PER PRIORITY, so the halves ask for different ones
         // (with GPU_MAX_HW_QUEUES >= 8 in the environment -- bench.py sets it before the runtime starts -- plain
         // streams get queues of their own; GAR_HIP_PIPE_PRIORITY=0 / 1 forces the choice)
-        const char *pp = std::getenv("GAR_HIP_PIPE_PRIORITY"), *mq = std::getenv("GPU_MAX_HW_QUEUES");
+        const char *pp = gar_option("GAR_HIP_PIPE_PRIORITY"), *mq = std::getenv("GPU_MAX_HW_QUEUES");
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         const bool plain = pp ? pp[0] == '0' : (mq && std::atoi(mq) >= 8);
@@ -2579,7 +2504,7 @@ int gar_hip_backward_blocks(gar_hip_solver *s, const double *const *blocks, cons
   // sweep, with the solution's copy and the gains' read-back (second stream), BEFORE the host waits for the status
   // word -- the device runs sweep, roll-out and copies back to back instead of waiting for the host between them.
   // gar_hip_forward / gar_hip_prefetch_gains / the solution fetch then find their work done.
-  static const bool eager_on = [] { const char *e = std::getenv("GAR_HIP_EAGER"); return !(e && e[0] == '0'); }();
+  const bool eager_on = [] { const char *e = gar_option("GAR_HIP_EAGER"); return !(e && e[0] == '0'); }();
   const bool eager = eager_on && !s->multi && !s->fold && !s->dense && (s->nth0 == 0 || s->num_legs > 1) && s->world == 1;
   if (!eager)
     return gar_hip_backward(s, mueq);

@@ -498,7 +498,7 @@ gar_hip_solver *multi_create(int ndev, const int *dev_ids, int horizon, const in
       if (hipDeviceCanAccessPeer(&can, dev_ids[r], dev_ids[p]) != hipSuccess || !can)
         peers = false;
     }
-  const char *ex = std::getenv("GAR_HIP_MULTI_EXCHANGE");
+  const char *ex = gar_option("GAR_HIP_MULTI_EXCHANGE");
   const bool want_copy = ex && std::string(ex) == "copy";
   if (peers && !want_copy)
     for (int r = 0; r < ndev && peers; ++r) {

@@ -42,6 +42,21 @@ def _f64(a, order="F"):
     return np.require(a, dtype=np.float64, requirements=[order])
 
 
+def set_option(name: str, value: Optional[str], lib_path=None):
+    """gar_hip_set_option: a behaviour switch of the library (`BACKWARD`, `PAD`, `SPD_ACCEPT`, ... -- include/gar_hip.h
+    lists them) set through the API instead of the `GAR_HIP_<NAME>` environment variable; process-wide, takes
+    precedence over the environment, `None` hands the name back to the environment."""
+    L = _lib.load(lib_path)
+    rc = L.gar_hip_set_option(name.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise ValueError(L.gar_hip_last_error().decode())
+
+
+def get_option(name: str, lib_path=None) -> Optional[str]:
+    v = _lib.load(lib_path).gar_hip_get_option(name.encode())
+    return None if v is None else v.decode()
+
+
 def get_work(horz: int, tid: int, num_threads: int):
     """gar/parallel-solver.hxx:23-28."""
     return (tid * (horz + 1) // num_threads, (tid + 1) * (horz + 1) // num_threads)

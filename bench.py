@@ -42,7 +42,7 @@ from aligator_amd import synth_device  # noqa: E402
 from aligator_amd.gar import BatchedRiccatiSolver  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; 6.29e12 measured copy)
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # scripts/collect_pmc.sh (rocprofv3 --pmc)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # scripts/gpu_r5_evidence.sh, step "pmc" (rocprofv3 --pmc, reduced by scripts/pmc_reduce.py)
 
 
 def pmc_traffic(kernel, batch):
@@ -905,7 +905,7 @@ def main():
     traffic, traffic_src = pmc_traffic("backward", args.batch), None
     if rank == 0:
         traffic_src = ("committed rocprofv3 --pmc passes of this kernel at this batch (profiles/pmc_traffic.json, "
-                       "scripts/collect_pmc.sh), NOT collected in this run; null when the batch differs")
+                       "scripts/gpu_r5_evidence.sh), NOT collected in this run; null when the batch differs")
         if world == 1 and args.pmc == "auto":
             solver.sync()
             live, detail = pmc_traffic_in_run(args, N, nx, nu)

@@ -380,6 +380,31 @@ int gar_hip_collapse_feedback(gar_hip_solver *s);
  * kernel stamps s_memtime at its phase boundaries for one stage of problem 0,
  * 16 marks per wave; `out` (may be NULL) receives the last 4 x 16 stamps. */
 int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
+/* Behaviour switches.  The reference exposes its knobs as struct fields (parallel-solver.hpp:92-94: those two have
+ * entry points of their own here, gar_hip_set_refinement / gar_hip_set_condensed_backward_ok); what chooses between
+ * this library's kernel families and measured alternatives is a set of named switches, each of which can be given in
+ * the ENVIRONMENT (GAR_HIP_<NAME>) or through this call, which takes precedence (process-wide; value NULL: back to the
+ * environment; `name` with or without the GAR_HIP_ prefix).  Read when a solver is CREATED unless noted.  Not to be
+ * called concurrently with solver creation.
+ *   BACKWARD = wave | wg4 | pair   serial unconstrained family: one wave per problem (default when batch > #CUs),
+ *                                  one 4-wave workgroup per problem (default otherwise), two waves per problem
+ *   WIDE = single | generic-forward   the (56, 24) family: one wave per problem / the any-dimension roll-out
+ *   FORCE_GENERIC = 1              the any-dimension kernels whatever the shape
+ *   PAD = 0                        never pad a shape onto a specialised family
+ *   INIT = bk                      always factorise kkt0 (no closed form for G0 = +-I)
+ *   SPD_ACCEPT = 0                 (per launch) the reference's pivot rule literally in the headline stage: no
+ *                                  acceptance of an unpivoted positive definite R-hat (deviation 7)
+ *   LEGS = generic | LEG_WAVES = 1 | SEG_LEGS = 0 | FOLD = 0     leg mode: the any-dimension leg kernels / one wave
+ *                                  per leg / no segment legs on the wide shape / constrained knots not folded
+ *   CONDENSED = generic | chain, CONDENSED_REDUCED = 0, CONDENSED_CR = 0 | <k>   the condensed solve: elimination
+ *                                  chain instead of block cyclic reduction (specialised / any-dimension paths)
+ *   STAGE_NT = 0 | 1, EAGER = 0    host staging with / without non-temporal stores; gar_hip_backward_blocks without
+ *                                  the roll-out enqueued behind the sweep (per call)
+ *   MULTI_EXCHANGE = copy          gar_hip_multi_create: hipMemcpyPeerAsync instead of the peer-mapped gather
+ *   PIPE_PRIORITY = 0 | 1          gar_hip_set_pipeline: plain half streams / one at high priority
+ * GAR_HIP_ERR_ARG for a name that is none of these. */
+int gar_hip_set_option(const char *name, const char *value);
+const char *gar_hip_get_option(const char *name);
 /* The pipelined sweep (no reference counterpart: the reference's batch axis is a caller's OpenMP loop over
  * solvers, bench/gar-riccati.cpp:42-51).  halves = 2 cuts the batch in two halves with a stream each, owned by the
  * library: gar_hip_backward_async / gar_hip_forward_async then enqueue on those streams, the backward sweeps of

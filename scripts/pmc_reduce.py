@@ -1,4 +1,4 @@
-"""Reduce the rocprofv3 --pmc passes of scripts/collect_pmc.sh to HBM bytes per launch."""
+"""Reduce the rocprofv3 --pmc passes of scripts/gpu_r5_evidence.sh (step "pmc") to HBM bytes per launch."""
 import csv, glob, json, os, sys
 root, batch = sys.argv[1], int(sys.argv[2])
 GiB = 1 << 30

@@ -927,3 +927,40 @@ def test_terminal_knot_without_successor_dimension_goes_to_the_any_dimension_ker
             assert pc.maxdiff(a, b) <= 1e-9 * pc.scale_of(ref)
         assert max(lqrComputeKktError(prob, *sol, mueq=1e-10)) <= 1e-9
         s.close()
+
+
+def test_behaviour_switches_through_the_api():
+    """gar_hip_set_option: what the GAR_HIP_* environment variables choose can be chosen through the ABI (the
+    reference's knobs are struct fields, parallel-solver.hpp:92-94); the call takes precedence over the environment,
+    None hands the name back to it, an unknown name is refused"""
+    from aligator_amd.gar import BatchedRiccatiSolver, set_option, get_option
+    nx, nu, N = 8, 4, 5
+    prob = synth.generate_lq_problem(3, np.ones(nx), N, nx, nu, mode="W")
+    dims = [k.dims for k in prob.stages]
+
+    def kernel():
+        s = BatchedRiccatiSolver(dims, nx, batch=1, lib_path=EMU)
+        name = s.kernel_name
+        s.upload([prob])
+        assert s.backward(1e-10) and s.forward()
+        sol = s.solution(0)
+        s.close()
+        return name, sol
+    base, sol0 = kernel()
+    assert base == "wave<8,4>" and get_option("BACKWARD", EMU) is None
+    try:
+        set_option("BACKWARD", "wg4", EMU)
+        assert get_option("GAR_HIP_BACKWARD", EMU) == "wg4"
+        n1, sol1 = kernel()
+        assert n1 == "mfma<8,4>"
+        set_option("GAR_HIP_FORCE_GENERIC", "1", EMU)
+        n2, sol2 = kernel()
+        assert n2 == "generic"
+        for a, b, c in zip(sol0, sol1, sol2):
+            assert pc.maxdiff(a, b) <= 1e-12 and pc.maxdiff(a, c) <= 1e-10
+        with pytest.raises(ValueError, match="unknown switch"):
+            set_option("NO_SUCH_SWITCH", "1", EMU)
+    finally:
+        set_option("BACKWARD", None, EMU)
+        set_option("FORCE_GENERIC", None, EMU)
+    assert kernel()[0] == base
