@@ -1,5 +1,5 @@
 """Three sweeps each of the secondary shapes of bench.py (the reference's own benchmark shape nc = 32 with D = 0, the same
-shape with a random D on every knot, and the Talos-walk LQ shape) at batch 1024: the process rocprofv3 is pointed at by scripts/collect_pmc_secondary.sh."""
+shape with a random D on every knot, and the Talos-walk LQ shape) at batch 1024: the process rocprofv3 --kernel-trace --stats is pointed at by scripts/gpu_r5_evidence.sh (step `secondary`)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
