@@ -54,6 +54,7 @@ SIGNATURES = {
     "gar_hip_device_stage_layout": (C.c_int, [C.c_void_p, C.c_int, _PI64]),
     "gar_hip_device_sizes": (C.c_int, [C.c_void_p, _PI64]),
     "gar_hip_device_record_format": (C.c_int, [C.c_void_p]),
+    "gar_hip_packed_stage_dims": (C.c_int, [C.c_void_p, C.c_int, _PI32]),
     "gar_hip_upload_packed_device_fmt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "gar_hip_backward": (C.c_int, [C.c_void_p, C.c_double]),
     "gar_hip_backward_async": (C.c_int, [C.c_void_p, C.c_double]),

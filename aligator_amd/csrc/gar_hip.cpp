@@ -321,6 +321,12 @@ struct gar_hip_solver {
   hipEvent_t pipe_evT[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}; // timing
   bool pipe_evB_valid[2] = {false, false};
   bool pipe_forked = false;            // the half streams hold work the caller's stream has not been ordered behind
+  // SolverProxDDP builds the terminal knot with nx2 = 0 (solvers/proxddp/workspace.hxx:54-55); nothing of the
+  // algorithm reads a terminal knot's A, f (riccati-kernel.hxx:130-193).  Such a knot is taken in as nx2 = nx -- the
+  // uniform record every kernel family addresses -- with zeros for the two blocks; the gains of that knot go back
+  // with the caller's row count (normalise_terminal, gar_hip_upload_stage, gar_hip_get_gains)
+  bool term_grown = false;
+  std::vector<double> term_zeros;
 };
 
 namespace {
@@ -779,9 +785,8 @@ void select_kernel(gar_hip_solver *s) {
       return;
   }
   // (the terminal knot's factor record is addressed through compile-time offsets that assume nx2 = nx rows of
-  // [yff | Aff] in it: SolverProxDDP builds its terminal knot with nx2 = 0 (solvers/proxddp/workspace.hxx:54-55) --
-  // such a problem is the any-dimension kernels' unless the caller declares the knot with nx2 = nx, as the shipped
-  // binding include/aligator/gar/hip-riccati.hpp does; found by running the reference's own ProxDDP loop, round 5)
+  // [yff | Aff] in it; the nx2 = 0 terminal knot SolverProxDDP builds arrives here normalised to nx2 = nx --
+  // normalise_terminal -- anything else is the any-dimension kernels')
   const gar_stage_meta &mt = s->meta[N];
   if (mt.nx != m0.nx || mt.nu != 0 || mt.nc != m0.nc || mt.nth != 0 || mt.nx2 != m0.nx)
     return;
@@ -1875,6 +1880,20 @@ static int upload_stage_impl(gar_hip_solver *s, int b, int t, const double *Q, c
                              const double *q, const double *r, const double *A, const double *B, const double *f,
                              const double *C, const double *D, const double *d, const double *Gth, const double *Gx,
                              const double *Gu, const double *Gv, const double *gamma);
+// (see gar_hip_solver::term_grown) the caller's dimensions as the library keeps them
+void normalise_terminal(gar_hip_solver *s) {
+  const int N = s->horizon;
+  if (s->dense || N < 1)
+    return;
+  int32_t *d = &s->user_dims5[5 * (size_t)N];
+  const int32_t *prev = &s->user_dims5[5 * (size_t)(N - 1)];
+  if (d[1] == 0 && d[3] == 0 && d[4] == 0 && d[0] > 0 && d[0] == prev[3]) {
+    d[3] = d[0];
+    s->term_grown = true;
+    s->term_zeros.assign((size_t)d[0] * (size_t)d[0], 0.0);
+  }
+}
+
 #include "gar_multi.hpp"
 
 extern "C" {
@@ -2007,6 +2026,7 @@ gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int n
   s->world = world;
   s->dense = dense;
   s->user_dims5.assign(dims5, dims5 + 5 * (horizon + 1));
+  normalise_terminal(s);
   DeviceGuard guard_(device); // the caller's current device is restored on return
   {
     int cur = -1;
@@ -3312,6 +3332,8 @@ static int upload_stage_impl(gar_hip_solver *s, int b, int t, const double *Q, c
                              const double *q, const double *r, const double *A, const double *B, const double *f,
                              const double *C, const double *D, const double *d, const double *Gth, const double *Gx,
                              const double *Gu, const double *Gv, const double *gamma) {
+  if (s->term_grown && t == s->horizon) // the caller's terminal A (0 x nx) and f are empty: zeros in the record
+    A = f = s->term_zeros.data();
   if (!s->padded)
     return upload_stage_dev(s, b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma);
   const gar_stage_meta &m = s->meta[t];
@@ -3470,6 +3492,24 @@ int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, d
   if (int rc = check_bt(s, b, t))
     return rc;
   GAR_MULTI(s, gar_hip_get_gains(multi_owner(s, t), b, t, ff, fb, fth));
+  if (s->term_grown && t == s->horizon) {
+    // the caller's terminal knot has nx2 = 0: its ff / fb / fth hold the nc rows [zff | Z | Zth] alone (they lead
+    // the record's rows; a padded solver has nc = 0: nothing to hand back)
+    const gar_stage_meta &m = s->meta[t];
+    const int nc = m.nc, NR = m.nu + m.nc + m.nx2, NX = m.nx, NT = m.nth;
+    if (nc == 0 || s->padded)
+      return GAR_HIP_OK;
+    std::vector<double> F((size_t)NR), Fb((size_t)NR * NX), Ft((size_t)NR * std::max(NT, 1));
+    if (int rc = get_gains_dev(s, b, t, F.data(), Fb.data(), NT > 0 ? Ft.data() : nullptr))
+      return rc;
+    if (ff)
+      std::copy(F.begin(), F.begin() + nc, ff);
+    if (fb)
+      std::copy(Fb.begin(), Fb.begin() + (size_t)nc * NX, fb);
+    if (fth && NT > 0)
+      std::copy(Ft.begin(), Ft.begin() + (size_t)nc * NT, fth);
+    return GAR_HIP_OK;
+  }
   if (!s->padded)
     return get_gains_dev(s, b, t, ff, fb, fth);
   const gar_stage_meta &m = s->meta[t];
@@ -3608,6 +3648,13 @@ int gar_hip_device_sizes(const gar_hip_solver *s, int64_t out[8]) {
     return fail(GAR_HIP_ERR_ARG, "bad argument");
   out[0] = s->prob_doubles; out[1] = s->fac_doubles; out[2] = s->sol_doubles; out[3] = s->nc0;
   out[4] = s->G0_off; out[5] = s->g0_off; out[6] = s->padded ? 1 : 0; out[7] = s->init_doubles;
+  return GAR_HIP_OK;
+}
+
+int gar_hip_packed_stage_dims(const gar_hip_solver *s, int t, int32_t out[5]) {
+  if (!s || !out || t < 0 || t > s->horizon)
+    return fail(GAR_HIP_ERR_ARG, "gar_hip_packed_stage_dims: bad argument");
+  std::copy(&s->user_dims5[5 * (size_t)t], &s->user_dims5[5 * (size_t)t] + 5, out);
   return GAR_HIP_OK;
 }
 

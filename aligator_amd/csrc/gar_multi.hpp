@@ -463,6 +463,7 @@ gar_hip_solver *multi_create(int ndev, const int *dev_ids, int horizon, const in
   s->rank = 0;
   s->world = ndev;
   s->user_dims5.assign(dims5, dims5 + 5 * ((size_t)horizon + 1));
+  normalise_terminal(s);
   gar_multi *M = s->multi;
   M->subs.assign((size_t)ndev, nullptr);
   M->ev_legs.assign((size_t)ndev, nullptr);

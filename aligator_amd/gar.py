@@ -179,6 +179,12 @@ class BatchedRiccatiSolver:
         self.device_nc0, self.device_G0_off, self.device_g0_off, self.padded = int(ds[3]), int(ds[4]), int(ds[5]), bool(int(ds[6]) & 1)
         # the device knots t < N keep Q and R as packed lower triangles (csrc/gar_layout.h: the headline sweep's records)
         self.record_format = int(L.gar_hip_device_record_format(h))   # GAR_HIP_FMT_* flags (include/gar_hip.h)
+        # dimensions of the packed records' stages: the caller's, but for a terminal knot given with nx2 = 0 (kept as
+        # nx2 = nx by the library: gar_hip_packed_stage_dims)
+        pd = np.zeros((self.horizon + 1, 5), dtype=np.int32)
+        for t in range(self.horizon + 1):
+            self._check(L.gar_hip_packed_stage_dims(h, t, pd[t].ctypes.data_as(C.POINTER(C.c_int32))))
+        self.packed_dims = pd
         self.qr_packed = bool(self.record_format & 1)
         self._factors_cache = {}
         self._mueq = None   # of the last backward (datas[t].kktMat is formed on request)
@@ -238,11 +244,17 @@ class BatchedRiccatiSolver:
                 raise ValueError(f"knot {t}: dimensions differ from the solver's")
             stored = nth if self.num_legs == 1 else 0
             p = int(self.stage_offsets[t, 0])
-            for name, shp in block_shapes(nx, nu, nc, nx2, stored).items():
+            nx2p = int(self.packed_dims[t, 3])    # (the record's nx2: the knot's own, or nx for a terminal nx2 = 0)
+            for name, shp in block_shapes(nx, nu, nc, nx2p, stored).items():
                 n = int(np.prod(shp))
                 if name in ("Gth", "Gx", "Gu", "Gv", "gamma") and stored == 0:
                     continue
-                buf[p:p + n] = _f64(getattr(k, name)).ravel(order="F")
+                blk = _f64(getattr(k, name))
+                if blk.shape != tuple(shp):       # the terminal A (0 x nx) / f (0): zeros in the record
+                    full = np.zeros(shp, order="F")
+                    full[tuple(slice(0, d) for d in blk.shape)] = blk
+                    blk = full
+                buf[p:p + n] = blk.ravel(order="F")
                 p += n
         return buf
 
@@ -275,9 +287,10 @@ class BatchedRiccatiSolver:
             stored = nth if self.num_legs == 1 else 0
             k = LqrKnot(nx, nu, nc, nx2, stored)
             p = int(self.stage_offsets[t, 0])
-            for name, shp in block_shapes(nx, nu, nc, nx2, stored).items():
+            for name, shp in block_shapes(nx, nu, nc, int(self.packed_dims[t, 3]), stored).items():
                 n = int(np.prod(shp))
-                getattr(k, name)[...] = buf[p:p + n].reshape(shp, order="F")
+                own = getattr(k, name)
+                own[...] = buf[p:p + n].reshape(shp, order="F")[tuple(slice(0, d) for d in own.shape)]
                 p += n
             knots.append(k)
         prob = LqrProblem(knots, self.nc0)

@@ -54,10 +54,7 @@ public:
                              k.gamma.data()};
       std::copy(b, b + 16, blocks_.begin() + 16 * t);
     }
-    if (term_nx2_grown_) { // the terminal knot was declared with nx2 = nx (create()): A (nx2 x nx) and f of zeros
-      blocks_[16 * (st.size() - 1) + 5] = zeros_.data();
-      blocks_[16 * (st.size() - 1) + 7] = zeros_.data();
-    }
+
     const int rc = gar_hip_backward_blocks(h_, blocks_.data(), problem_->G0.data(), problem_->g0.data(), mueq);
     if (rc == GAR_HIP_ERR_FACTOR)                       // riccati-kernel.hxx:239-241
       ALIGATOR_RUNTIME_ERROR("Failed stage LDL factorization");
@@ -96,15 +93,9 @@ private:
     const auto &st = problem_->stages;
     std::vector<int32_t> dims5;
     for (const Knot &k : st) {
-      int32_t d[5] = {(int)k.nx, (int)k.nu, (int)k.nc, (int)k.nx2, num_legs_ > 1 ? 0 : (int)k.nth};
-      // SolverProxDDP builds its terminal knot with nx2 = 0 (solvers/proxddp/workspace.hxx:54-55): nothing of the
-      // algorithm reads the terminal A, f (riccati-kernel.hxx:130-193), but the specialised kernel families address
-      // a uniform record with nx2 = nx there -- declare it so and hand zeros over for the two blocks
-      if (&k == &st.back() && k.nu == 0 && k.nx2 == 0 && st.size() > 1) {
-        d[3] = (int)k.nx;
-        term_nx2_grown_ = true;
-        zeros_.assign((size_t)k.nx * k.nx, 0.0);
-      }
+      // (the terminal knot SolverProxDDP builds has nx2 = 0, solvers/proxddp/workspace.hxx:54-55: passed as it is --
+      // the library takes such a knot in as nx2 = nx with zeros for its unread A, f: gar_hip.h, gar_hip_solver_create)
+      const int32_t d[5] = {(int)k.nx, (int)k.nu, (int)k.nc, (int)k.nx2, num_legs_ > 1 ? 0 : (int)k.nth};
       dims5.insert(dims5.end(), d, d + 5);
       nxs_ += k.nx; nus_ += k.nu; nvs_ += k.nc;
     }
@@ -148,8 +139,6 @@ private:
   std::vector<VectorMap> ff_; std::vector<RowMatrixMap> fb_;
   std::vector<const double *> blocks_;                  // the 16 block pointers of every knot, rebuilt per backward
   bool gains_stale_ = false;
-  bool term_nx2_grown_ = false;                         // the terminal knot (nx2 = 0 in ProxDDP) is declared with nx2 = nx
-  std::vector<double> zeros_;                           // ... and its A, f are these
 };
 
 } // namespace aligator::gar

@@ -104,6 +104,9 @@ int64_t gar_hip_factor_doubles(const int32_t dims5[5]);
  *   dummy controls / states that solve to exactly zero and are stripped from every result; gar_hip_kernel_name
  *   reports the family that runs.  The device records then have the padded dimensions: device-resident producers
  *   and consumers (gar_hip_device_*) ask gar_hip_device_stage_layout.  GAR_HIP_PAD=0 in the environment disables it.
+ * A terminal knot given with nx2 = 0 (as SolverProxDDP builds it, solvers/proxddp/workspace.hxx:54-55; tests/gar/ gives
+ *   it nx2 = nx) is kept as nx2 = nx -- the uniform record every kernel family addresses -- with zeros for its A, f,
+ *   which nothing of the algorithm reads (riccati-kernel.hxx:130-193): gar_hip_packed_stage_dims.
  * num_legs = 1: serial-in-time ProximalRiccatiSolver semantics.
  * num_legs >= 2: ParallelRiccatiSolver(problem, num_legs) semantics; like the
  *   reference, every knot of a non-final leg is (implicitly) re-parameterised
@@ -214,6 +217,12 @@ double *gar_hip_device_solutions(gar_hip_solver *s);
  *                               the kernel family (batch vs. number of CUs, GAR_HIP_BACKWARD): ask, do not assume.
  *       GAR_HIP_FMT_VXX_PACKED  factor records: Vxx as its packed lower triangle (gar_sym_index)
  *       GAR_HIP_FMT_FB_T2       factor records: fb / fth in the fbT2 order */
+/* The dimensions (nx, nu, nc, nx2, nth) of stage t in the CALLER-FACING packed records (gar_hip_upload_packed /
+ * gar_hip_download_packed; block order of csrc/gar_layout.h): the caller's own, with one exception -- a terminal knot
+ * given with nx2 = 0, as SolverProxDDP builds it (solvers/proxddp/workspace.hxx:54-55), is kept as nx2 = nx (the
+ * uniform record every kernel family addresses; its A and f, which nothing of the algorithm reads, are zeros;
+ * gar_hip_upload_stage ignores the two pointers for that knot and gar_hip_get_gains hands back the caller's rows). */
+int gar_hip_packed_stage_dims(const gar_hip_solver *s, int t, int32_t out[5]);
 #define GAR_HIP_FMT_QR_PACKED 1
 #define GAR_HIP_FMT_VXX_PACKED 2
 #define GAR_HIP_FMT_FB_T2 4

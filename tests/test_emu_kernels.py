@@ -899,33 +899,50 @@ def test_backward_blocks_is_the_upload_and_backward_sequence():
         two.backward_blocks(prob, 1e-10)
 
 
-def test_terminal_knot_without_successor_dimension_goes_to_the_any_dimension_kernels():
-    """SolverProxDDP builds its terminal knot with nx2 = 0 (solvers/proxddp/workspace.hxx:54-55).  The specialised
-    families address the terminal factor record through offsets that assume nx2 = nx rows of [yff | Aff] in it:
-    until round 5 such a problem bound `wave<8,4>` all the same and the sweep wrote 72 doubles past the factor
-    records (found by running the reference's own ProxDDP loop on the backend under AddressSanitizer).  It is the
-    any-dimension kernels' now, with the right answer; the shipped binding declares the knot with nx2 = nx instead
-    (include/aligator/gar/hip-riccati.hpp) and keeps the fast kernels (tests/test_integration_binding.py)."""
+def test_terminal_knot_without_successor_dimension():
+    """SolverProxDDP builds its terminal knot with nx2 = 0 (solvers/proxddp/workspace.hxx:54-55); tests/gar/ builds it
+    with nx2 = nx.  The specialised families address the terminal factor record through offsets that assume nx2 = nx
+    rows of [yff | Aff] in it: until round 5 such a problem bound `wave<8,4>` all the same and the sweep wrote 72
+    doubles past the factor records (found by running the reference's own ProxDDP loop on the backend under
+    AddressSanitizer).  Now the library takes the knot in as nx2 = nx with zeros for its A, f -- which nothing of
+    the algorithm reads (riccati-kernel.hxx:130-193) -- and hands its gains back with the caller's row count: same
+    kernels, same answer as the nx2 = nx problem, serial, padded, in leg mode, constrained at the terminal knot."""
     from aligator_amd.gar import BatchedRiccatiSolver, lqrComputeKktError
     from aligator_amd.lqr import LqrKnot, LqrProblem
-    nx, nu, N = 8, 4, 6
-    base = synth.generate_lq_problem(5, np.ones(nx), N, nx, nu, mode="W")
-    term = LqrKnot(nx, 0, 0, 0)                       # nx2 = 0
-    term.Q[...] = base.stages[-1].Q
-    term.q[...] = base.stages[-1].q
-    prob = LqrProblem(base.stages[:-1] + [term], nx)
-    prob.G0[...] = base.G0
-    prob.g0[...] = base.g0
-    for batch in (1, 3):
-        s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=batch, lib_path=EMU)
-        assert s.kernel_name == "generic"
+
+    def shrink_terminal(base):
+        last = base.stages[-1]
+        term = LqrKnot(last.nx, 0, last.nc, 0)        # nx2 = 0: A is 0 x nx, f empty
+        for name in ("Q", "q", "C", "d"):
+            getattr(term, name)[...] = getattr(last, name)
+        prob = LqrProblem(base.stages[:-1] + [term], base.nc0)
+        prob.G0[...] = base.G0
+        prob.g0[...] = base.g0
+        return prob
+    cases = [(8, 4, 0, 6, 1, 1, "wave<8,4>"), (8, 4, 0, 6, 3, 1, "wave<8,4>"), (6, 3, 0, 7, 1, 1, "wave<8,4>"),
+             (8, 4, 0, 9, 1, 3, "wave_leg<8,4>"), (5, 2, 2, 5, 1, 1, "generic")]
+    for nx, nu, nc, N, batch, legs, want in cases:
+        base = synth.generate_lq_problem(5, np.ones(nx), N, nx, nu, nc=nc, mode="W")
+        prob = shrink_terminal(base)
+        assert prob.stages[-1].dims == (nx, 0, nc, 0, 0)
+        s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=batch, num_legs=legs, lib_path=EMU)
+        assert s.kernel_name.startswith(want), s.kernel_name
         s.upload([prob] * batch)
-        assert s.backward(1e-10) and s.forward()
+        mu = 1e-8 if nc else 1e-10
+        assert s.backward(mu) and s.forward()
         sol = s.solution(batch - 1)
-        _, _, ref = pc.oracle_serial(base, 1e-10)     # (the oracle never reads the terminal A, f either)
+        _, osol, ref = pc.oracle_serial(base, mu)     # (the oracle never reads the terminal A, f either)
         for a, b in zip(sol, ref):
-            assert pc.maxdiff(a, b) <= 1e-9 * pc.scale_of(ref)
-        assert max(lqrComputeKktError(prob, *sol, mueq=1e-10)) <= 1e-9
+            assert pc.maxdiff(a, b) <= 1e-8 * pc.scale_of(ref)
+        assert max(lqrComputeKktError(prob, *sol, mueq=mu)) <= 1e-8 * pc.scale_of(ref)
+        # the terminal knot's gains: the caller's nc rows [zff | Z], through the per-stage getter and the bulk path
+        f = s.factor(N, batch - 1)
+        assert f.ff.shape == (nc,) and f.fb.shape == (nc, nx)
+        ffs, fbs = s.gains_all(batch - 1)
+        assert ffs[N].shape == (nc,) and fbs[N].shape == (nc, nx)
+        if nc:
+            assert pc.maxdiff([f.ff], [osol.datas(N).ff[:nc]]) <= 1e-9 * max(1.0, float(np.abs(f.ff).max()))
+            assert np.array_equal(f.ff, ffs[N]) and np.array_equal(f.fb, fbs[N])
         s.close()
 
 
