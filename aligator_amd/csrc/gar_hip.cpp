@@ -1427,6 +1427,9 @@ int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
   return GAR_HIP_OK;
 }
 
+constexpr size_t kCuLdsBytes = 160 * 1024, kLdsGranule = 1280; // gfx950: 160 KiB per CU, allocated in 320-dword pieces
+inline size_t lds_round(size_t b) { return (b + kLdsGranule - 1) / kLdsGranule * kLdsGranule; }
+
 gar::MfmaFwdParams make_mfma_fwd_params(gar_hip_solver *s) {
   gar::MfmaFwdParams F{};
   const int N = s->horizon;
@@ -1472,6 +1475,18 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
     const gar::MfmaFwdParams F = make_mfma_fwd_params(s);
     if (s->timing)
       HIP_TRY(hipEventRecord(s->ev[3], s->stream));
+    // FORWARD = lean (per launch): the LDS-DMA roll-out of the pipelined schedule (gar_forward_lean.hpp, bit for bit the
+    // same solution) for the whole batch in the plain schedule too -- one workgroup of four problems per CU at a time
+    const char *fw = s->lean_fwd_kernel ? gar_option("GAR_HIP_FORWARD") : nullptr;
+    if (fw && std::string(fw) == "lean") {
+      if (s->lean_fwd_lds_bytes == 0) {
+        s->lean_fwd_lds_bytes = std::max(lds_round(s->lean_fwd_used), lds_round(kCuLdsBytes / 2 + 1));
+        HIP_TRY(hipFuncSetAttribute((const void *)s->lean_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)s->lean_fwd_lds_bytes));
+      }
+      hipLaunchKernelGGL(s->lean_fwd_kernel, dim3((unsigned)((s->batch + 3) / 4)), dim3(256), s->lean_fwd_lds_bytes, s->stream, F,
+                         s->batch);
+    } else
     hipLaunchKernelGGL(s->mfma_fwd_kernel, dim3((unsigned)s->batch), dim3(64), s->mfma_fwd_lds_bytes, s->stream, F);
     HIP_TRY(hipGetLastError());
     if (s->timing)
@@ -2403,7 +2418,7 @@ int gar_hip_set_option(const char *name, const char *value) {
     key = "GAR_HIP_" + key;
   static const char *known[] = {"BACKWARD", "WIDE", "LEG_WAVES", "CONDENSED", "CONDENSED_REDUCED", "CONDENSED_CR", "LEGS",
                                 "FOLD", "SEG_LEGS", "INIT", "FORCE_GENERIC", "PAD", "SPD_ACCEPT", "STAGE_NT", "EAGER",
-                                "MULTI_EXCHANGE", "PIPE_PRIORITY"};
+                                "MULTI_EXCHANGE", "PIPE_PRIORITY", "FORWARD"};
   bool ok = false;
   for (const char *k : known)
     ok |= key == std::string("GAR_HIP_") + k;

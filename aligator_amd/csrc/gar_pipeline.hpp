@@ -10,8 +10,7 @@
 // initial stage's kkt0 overlay) + ONE forward workgroup (gar_forward_lean: four waves, one per SIMD).  The forward
 // launch ASKS for more than half of the CU's LDS, so that a second forward workgroup never fits: two forward waves
 // on a SIMD would take the registers a backward wave needs (432 + 80 of 512).
-constexpr size_t kCuLdsBytes = 160 * 1024, kLdsGranule = 1280; // gfx950: 160 KiB per CU, allocated in 320-dword pieces
-inline size_t lds_round(size_t b) { return (b + kLdsGranule - 1) / kLdsGranule * kLdsGranule; }
+// (kCuLdsBytes, lds_round: gar_hip.cpp, ahead of launch_forward)
 int pipe_plan(gar_hip_solver *s, size_t lean_used) {
   const size_t bwd = lds_round((size_t)s->wave_lds_doubles_small * sizeof(double));
   size_t ask = lds_round(lean_used);

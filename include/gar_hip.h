@@ -411,6 +411,7 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
  *                                  the roll-out enqueued behind the sweep (per call)
  *   MULTI_EXCHANGE = copy          gar_hip_multi_create: hipMemcpyPeerAsync instead of the peer-mapped gather
  *   PIPE_PRIORITY = 0 | 1          gar_hip_set_pipeline: plain half streams / one at high priority
+ *   FORWARD = lean                 (per launch) the LDS-DMA roll-out of the pipelined schedule in the plain one too
  * GAR_HIP_ERR_ARG for a name that is none of these. */
 int gar_hip_set_option(const char *name, const char *value);
 const char *gar_hip_get_option(const char *name);

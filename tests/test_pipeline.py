@@ -168,6 +168,39 @@ def test_gpu_pipelined_sweep_is_bitwise_the_plain_sweep(nx, nu, N, batch, mode, 
 
 
 @pytest.mark.gpu
+def test_gpu_pipelined_sweep_defers_a_general_initial_stage():
+    """on the device: G0 != +-I in most problems of a batch larger than the chip (the pipelined launch carries no LDS
+    for the fused kkt0: flagged per problem, factorised by gar_initial_wave behind the sweep), against the plain
+    schedule's fused initial stage and the KKT residual of every 37th problem"""
+    from aligator_amd.gar import BatchedRiccatiSolver, lqrComputeKktError
+    nx, nu, N, batch = 36, 12, 24, 300
+    rng = np.random.default_rng(3)
+    probs = _problems(nx, nu, N, batch)
+    for i, p in enumerate(probs):
+        if i % 5:
+            p.G0[...] = -np.eye(nx) + 0.2 * rng.standard_normal((nx, nx))
+            p.g0[...] = rng.standard_normal(nx)
+    s = BatchedRiccatiSolver([k.dims for k in probs[0].stages], nx, batch=batch)
+    assert s.kernel_name == "wave<36,12>"
+    s.upload(probs)
+    s.set_pipeline(0)
+    s.backward_async(1e-12); s.forward_async(); s.sync()
+    plain = [s.solution(b) for b in range(0, batch, 37)]
+    s.set_pipeline(2)
+    for _ in range(2):
+        s.backward_async(1e-12); s.forward_async()
+    s.sync()
+    assert s.num_failed() == 0
+    for k, b in enumerate(range(0, batch, 37)):
+        sol = s.solution(b)
+        for A, B in zip(sol, plain[k]):
+            for x, y in zip(A, B):
+                assert pc.maxdiff([x], [y]) <= 1e-11 * max(1.0, float(np.abs(y).max()) if y.size else 1.0)
+        assert max(lqrComputeKktError(probs[b], *sol, mueq=1e-12)) <= 1e-9
+    s.close()
+
+
+@pytest.mark.gpu
 def test_gpu_pipelined_headline_batch_against_the_plain_sweep():
     """the headline launch geometry: 4 096 problems of N = 256 generated on the device, five pipelined steps in a row
     (forward sweeps riding beside the next step's backward sweeps), then bit for bit against one plain step"""
