@@ -196,7 +196,8 @@ def test_gpu_pipelined_sweep_defers_a_general_initial_stage():
         for A, B in zip(sol, plain[k]):
             for x, y in zip(A, B):
                 assert pc.maxdiff([x], [y]) <= 1e-11 * max(1.0, float(np.abs(y).max()) if y.size else 1.0)
-        assert max(lqrComputeKktError(probs[b], *sol, mueq=1e-12)) <= 1e-9
+        scale = max(1.0, max(float(np.abs(v).max()) for part in sol for v in part if v.size))
+        assert max(lqrComputeKktError(probs[b], *sol, mueq=1e-12)) <= 1e-9 * scale   # (a perturbed G0: |lbd| ~ 1e2-1e3)
     s.close()
 
 
