@@ -560,397 +560,7 @@ replan:
   return GAR_HIP_OK;
 }
 
-// ---- specialised kernel dispatch ---------------------------------------------
-template <int NX, int NU> void bind_mfma(gar_hip_solver *s) {
-  s->mfma_kernel = gar::gar_backward_mfma<NX, NU>;
-  s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU>;
-  s->mfma_fwd_lds_bytes = GAR_VXX_PACKED ? sizeof(double) * (size_t)gar_sym_packed_doubles(NX) : 0;
-  s->fb_t2 = true;
-  s->mfma_lds_doubles = gar::MfmaCfg<NX, NU>::total;
-  s->kernel_name = "mfma<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
-  // Two backward kernels: one wave per problem (throughput: every SIMD runs its own problem) and
-  // one 4-wave workgroup per problem (latency: a problem gets a whole CU; measured 2.2 ms vs
-  // 3.0 ms per sweep while there are no more problems than CUs).  GAR_HIP_BACKWARD=wave|wg4
-  // overrides the choice.
-  const char *bw = gar_option("GAR_HIP_BACKWARD");
-  int cus = 256;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
-  const bool want_wave = bw ? std::string(bw) != "wg4" : s->batch > cus;
-  // GAR_HIP_BACKWARD=pair: two waves per problem, the tile columns split between them
-  // (gar_wave_pair.hpp; <= 256 registers per wave, so two waves share a SIMD)
-  constexpr bool can_pair = (NX % 16) != 0 && ((NX >> 4) >= (gar::WaveCfg<NX, NU>::TW / 2)) && (gar::WaveCfg<NX, NU>::TW / 2) >= 1;
-  if (bw && std::string(bw) == "pair" && can_pair) {
-    if constexpr (can_pair) {
-      s->wave_kernel = gar::gar_backward_pair<NX, NU>;
-      s->wave_fused_init = false;
-      s->wave_lds_doubles = gar::PairCfg<NX, NU>::total;
-      s->wave_block_threads = 128;
-      s->waves_per_block = 1;
-      s->kernel_name = "pair<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
-    }
-  } else if (want_wave) {
-    s->wave_kernel = gar::gar_backward_wave<NX, NU>;
-    // the initial stage is fused into the sweep when its packed kkt0 fits beside V in a
-    // quarter of the CU's LDS (four waves per CU)
-    const int with_init = gar::WaveCfg<NX, NU>::total_with_init(s->nc0);
-    s->wave_fused_init = (size_t)with_init * sizeof(double) <= 40 * 1024 && s->nth0 == 0;
-    // (F-DMA: the next knot's [A | B] image lies behind `total`, under the fused initial stage's kkt0)
-    const int sweep = GAR_F_DMA ? gar::WaveCfg<NX, NU>::total_fdma : gar::WaveCfg<NX, NU>::total;
-    s->wave_lds_doubles = s->wave_fused_init ? std::max(with_init, sweep) : sweep;
-    s->waves_per_block = 1; // one 64-thread workgroup per problem (constant LDS base)
-    s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
-    s->qr_packed = GAR_QR_PACKED != 0; // the sweep reads only the lower triangles of Q and R (gar_layout.h)
-    // the pipelined sweep's roll-out (gar_hip_set_pipeline): reads the packed Vxx records
-    if (GAR_VXX_PACKED) {
-      s->lean_fwd_kernel = gar::gar_forward_lean<NX, NU>;
-      s->wave_half_kernel = gar::gar_backward_wave_half<NX, NU>;
-      s->lean_fwd_used = gar::LeanFwdCfg<NX, NU>::USED; // (what it uses; pipe_plan decides what it asks for)
-      s->wave_lds_doubles_small = sweep;
-    }
-  }
-}
-
-// Wide shapes (nx + nu > 64, e.g. the Talos walk's (56, 22) padded to (56, 24)): the one-wave-per-problem
-// backward sweep only (gar_wave2.hpp; fb ROW-major = the generic record layout), the initial stage
-// and the forward sweep on the generic kernels.
-template <int NX, int NU> void bind_wide(gar_hip_solver *s) {
-  // two waves per problem (the tile columns split between them) unless GAR_HIP_WIDE=single
-  const char *w = gar_option("GAR_HIP_WIDE");
-  const bool pair = !(w && std::string(w) == "single");
-  if (!(w && std::string(w) == "generic-forward"))
-    s->mfma_fwd_kernel = gar::gar_forward_wide<NX, NU>; // row-major fb: fb_t2 stays false
-  s->wave_fused_init = false;
-  s->waves_per_block = 1;
-  s->fb_t2 = false;
-  if (pair) {
-    s->wave_kernel = gar::gar_backward_pair<NX, NU>;
-    s->wave_lds_doubles = gar::PairCfg<NX, NU>::total;
-    s->wave_block_threads = 128;
-    s->kernel_name = "pair<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
-  } else {
-    s->wave_kernel = gar::gar_backward_wave<NX, NU>;
-    s->wave_lds_doubles = gar::WaveCfg<NX, NU>::total;
-    s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
-  }
-}
-
-template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
-  s->fb_t2 = true;
-  // two waves per leg (plain part / parameter part) unless GAR_HIP_LEG_WAVES=1
-  const char *lw = gar_option("GAR_HIP_LEG_WAVES");
-  s->leg_waves = (lw && std::string(lw) == "1") ? 1 : 2;
-  s->leg_bwd_kernel = s->leg_waves == 2 ? gar::gar_backward_wave_leg2<NX, NU> : gar::gar_backward_wave_leg<NX, NU>;
-  s->leg_tuple_kernel = gar::gar_leg_tuples<NX, NU>;
-  s->leg_fwd_kernel = gar::gar_forward_wave_leg<NX, NU>;
-  s->leg_collapse_kernel = gar::gar_collapse_feedback_t2<NX, NU>;
-  s->leg_lds_doubles = s->leg_waves == 2 ? gar::WaveCfg<NX, NU>::leg2_total : gar::WaveCfg<NX, NU>::leg_total;
-  const char *ck = gar_option("GAR_HIP_CONDENSED");
-  if (!(ck && std::string(ck) == "generic")) {
-    const int lds = 4 * NX * NX + 16 * NX + NX + NX + (NX & 1) + (NX + 16) / 2 + 2 +
-                    2 * (2 * s->num_legs) * NX + 2;
-    if ((size_t)lds * sizeof(double) <= 160 * 1024) {
-      s->cond_wave_kernel = gar::gar_condensed_wave<NX>;
-      s->cond_wave_lds_doubles = lds;
-    }
-    if (!(ck && std::string(ck) == "chain")) {
-      s->cyc_setup_kernel = gar::gar_cyclic_setup<NX>;
-      s->cyc_reduce_kernel = gar::gar_cyclic_reduce<NX>;
-      s->cyc_top_kernel = gar::gar_cyclic_top<NX>;
-      s->cyc_backlevel_kernel = gar::gar_cyclic_backlevel<NX>;
-      s->cyc_recover_kernel = gar::gar_cyclic_recover<NX>;
-      s->cyc_lds_doubles = gar::CyclicLds<NX>::total;
-    }
-  }
-  s->kernel_name = "wave_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
-}
-
-// the wide shape in leg mode: segment legs (gar_leg_seg.hpp) on the two-wave stage kernel
-template <int NX, int NU> void bind_seg_leg(gar_hip_solver *s) {
-  s->seg_bwd_kernel = gar::gar_backward_pair_leg<NX, NU>;
-  s->seg_fwd_kernel = gar::gar_forward_wide_leg<NX, NU>;
-  s->seg_lds_doubles = gar::PairCfg<NX, NU>::total;
-  s->fb_t2 = false; // row-major fb: the generic roll-out, condensed solve and collapse serve the family
-  s->kernel_name = "pair_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
-}
-
-// leg mode: uniform unconstrained problem whose every leg holds at least two knots
-void select_leg_kernel(gar_hip_solver *s) {
-  const int N = s->horizon;
-  const char *lk = gar_option("GAR_HIP_LEGS");
-  if (lk && std::string(lk) == "generic")
-    return;
-  if (N < 1 || s->nxb != s->dims5[0])
-    return;
-  const int nx = s->dims5[0], nu = s->dims5[1];
-  bool any_nc = false;
-  for (int t = 0; t <= N; ++t) {
-    const int32_t *d = &s->dims5[5 * t];
-    if (d[0] != nx || d[1] != (t < N ? nu : 0) || d[3] != nx || d[4] != 0)
-      return;
-    any_nc |= d[2] != 0;
-  }
-  // constrained knots: folded onto the unconstrained family (gar_fold.hpp); the generic leg kernels are the
-  // fallback for problems with D != 0, so they must fit a CU's LDS
-  const char *fe = gar_option("GAR_HIP_FOLD");
-  if (any_nc && (!s->lds_error.empty() || (fe && fe[0] == '0')))
-    return;
-  for (int i = 0; i < s->num_legs; ++i) {
-    int i0, i1;
-    gar_get_work(N, i, s->num_legs, &i0, &i1);
-    if (i1 - i0 < (i + 1 < s->num_legs ? 2 : 1))
-      return;
-  }
-  if (nx == 36 && nu == 12) bind_leg<36, 12>(s);
-  else if (nx == 32 && nu == 12) bind_leg<32, 12>(s);
-  else if (nx == 16 && nu == 8) bind_leg<16, 8>(s);
-  else if (nx == 12 && nu == 8) bind_leg<12, 8>(s);
-  else if (nx == 12 && nu == 4) bind_leg<12, 4>(s);
-  else if (nx == 8 && nu == 4) bind_leg<8, 4>(s);
-  else if (nx == 56 && nu == 24 && !any_nc) {
-    const char *sg = gar_option("GAR_HIP_SEG_LEGS");
-    if (!(sg && sg[0] == '0') && (size_t)gar::leg_stage_lds_doubles(56, 24) * sizeof(double) <= 160 * 1024)
-      bind_seg_leg<56, 24>(s);
-  }
-  s->fold = any_nc && s->leg_bwd_kernel != nullptr;
-}
-
-// uniform problems with NC constraints on every knot: the one-wave-per-problem kernels with the
-// reduced KKT system factorised by the wave-scope Bunch-Kaufman (gar_wave.hpp, NC > 0)
-template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
-  s->wave_kernel = gar::gar_backward_wave<NX, NU, NC>;
-  s->wave_coupled_kernel = gar::gar_backward_wave_coupled<NX, NU, NC>;
-  s->wave_bk_kernel = gar::gar_backward_wave_bk<NX, NU, NC>;
-  s->mfma_fwd_kernel = gar::gar_forward_mfma<NX, NU, NC>;
-  s->mfma_fwd_lds_bytes = GAR_VXX_PACKED ? sizeof(double) * (size_t)gar_sym_packed_doubles(NX) : 0;
-  s->fb_t2 = true;
-  const int with_init = gar::WaveCfg<NX, NU, NC>::total_with_init(s->nc0);
-  s->wave_fused_init = (size_t)with_init * sizeof(double) <= 64 * 1024 && s->nth0 == 0;
-  s->wave_lds_doubles = s->wave_fused_init ? with_init : gar::WaveCfg<NX, NU, NC>::total;
-  s->waves_per_block = 1;
-  s->kernel_name = "wave<" + std::to_string(NX) + "," + std::to_string(NU) + "," + std::to_string(NC) + ">";
-  s->qr_packed = GAR_QR_PACKED != 0; // the chain's three kernels read only the lower triangles of Q and R (gar_layout.h)
-}
-
-void select_kernel(gar_hip_solver *s) {
-  s->fold = false;
-  s->seg_bwd_kernel = nullptr;
-  s->seg_fwd_kernel = nullptr;
-  s->leg_bwd_kernel = nullptr;
-  s->leg_tuple_kernel = nullptr;
-  s->leg_fwd_kernel = nullptr;
-  s->leg_collapse_kernel = nullptr;
-  s->cond_wave_kernel = nullptr;
-  s->cyc_setup_kernel = nullptr;
-  s->cyc_reduce_kernel = nullptr;
-  s->cyc_top_kernel = nullptr;
-  s->cyc_backlevel_kernel = nullptr;
-  s->cyc_recover_kernel = nullptr;
-  s->mfma_kernel = nullptr;
-  s->mfma_fwd_kernel = nullptr;
-  s->mfma_fwd_lds_bytes = 0;
-  s->wave_kernel = nullptr;
-  s->wave_coupled_kernel = nullptr;
-  s->wave_bk_kernel = nullptr;
-  s->wave_fused_init = false;
-  s->wave_block_threads = 64;
-  s->fb_t2 = false;
-  s->vxx_packed = false;
-  s->qr_packed = false;
-  {
-    const char *ik = gar_option("GAR_HIP_INIT");
-    s->init_closed = !(ik && std::string(ik) == "bk");
-  }
-  s->kernel_name = "generic";
-  if (s->dense) {
-    s->kernel_name = "dense";
-    return;
-  }
-  const char *force = gar_option("GAR_HIP_FORCE_GENERIC");
-  if (force && force[0] == '1')
-    return;
-  const int N = s->horizon;
-  if (s->num_legs > 1) {
-    select_leg_kernel(s);
-    return;
-  }
-  if (N < 1)
-    return;
-  const gar_stage_meta &m0 = s->meta[0];
-  if (m0.nth != 0 || m0.nx2 != m0.nx)
-    return;
-  for (int t = 1; t < N; ++t) {
-    const gar_stage_meta &m = s->meta[t];
-    if (m.nx != m0.nx || m.nu != m0.nu || m.nc != m0.nc || m.nth != 0 || m.nx2 != m0.nx ||
-        m.in_off - s->meta[t - 1].in_off != s->meta[1 < N ? 1 : 0].in_off - m0.in_off)
-      return;
-  }
-  // (the terminal knot's factor record is addressed through compile-time offsets that assume nx2 = nx rows of
-  // [yff | Aff] in it; the nx2 = 0 terminal knot SolverProxDDP builds arrives here normalised to nx2 = nx --
-  // normalise_terminal -- anything else is the any-dimension kernels')
-  const gar_stage_meta &mt = s->meta[N];
-  if (mt.nx != m0.nx || mt.nu != 0 || mt.nc != m0.nc || mt.nth != 0 || mt.nx2 != m0.nx)
-    return;
-  const int nx = m0.nx, nu = m0.nu;
-  if (m0.nc != 0) { // every knot constrained (the reference's bench/gar-riccati.cpp shape)
-    const int nc = m0.nc;
-    if (nx == 36 && nu == 12 && nc == 32) bind_cstr<36, 12, 32>(s);
-    else if (nx == 16 && nu == 8 && nc == 8) bind_cstr<16, 8, 8>(s);
-    else if (nx == 8 && nu == 4 && nc == 4) bind_cstr<8, 4, 4>(s);
-    s->vxx_packed = GAR_VXX_PACKED && s->fb_t2; // (serial one-wave family: gar_layout.h)
-    return;
-  }
-  if (nx == 36 && nu == 12) bind_mfma<36, 12>(s);
-  else if (nx == 32 && nu == 12) bind_mfma<32, 12>(s);
-  else if (nx == 16 && nu == 8) bind_mfma<16, 8>(s);
-  else if (nx == 12 && nu == 8) bind_mfma<12, 8>(s);
-  else if (nx == 12 && nu == 4) bind_mfma<12, 4>(s);
-  else if (nx == 8 && nu == 4) bind_mfma<8, 4>(s);
-  else if (nx == 56 && nu == 24) bind_wide<56, 24>(s);
-  s->vxx_packed = GAR_VXX_PACKED && s->fb_t2; // the serial one-wave family keeps the lower triangle of Vxx, packed (gar_layout.h)
-}
-
-// (nx, nu) shapes with kernels of their own (bind_mfma / bind_leg / bind_wide / bind_seg_leg above)
-struct SpecShape { int nx, nu; bool serial_only; };
-constexpr SpecShape kSpecialised[] = {{36, 12, false}, {32, 12, false}, {16, 8, false}, {12, 8, false},
-                                      {12, 4, false}, {8, 4, false},   {56, 24, false}};
-
-// Decide the device dimensions from the caller's (see gar_hip_solver::padded).  GAR_HIP_PAD=0: never pad.
-void choose_padding(gar_hip_solver *s) {
-  s->dims5 = s->user_dims5;
-  s->nc0 = s->user_nc0;
-  s->padded = false;
-  s->unx = s->unu = s->pnx = s->pnu = 0;
-  const char *pe = gar_option("GAR_HIP_PAD");
-  const int N = s->horizon;
-  if (s->dense || (pe && pe[0] == '0') || N < 1)
-    return;
-  const int32_t *d0 = &s->user_dims5[0];
-  const int nx = d0[0], nu = d0[1];
-  if (nu == 0 || nx <= 0)
-    return;
-  for (int t = 0; t <= N; ++t) {
-    const int32_t *d = &s->user_dims5[5 * t];
-    if (d[0] != nx || d[1] != (t < N ? nu : 0) || d[2] != 0 || d[3] != nx || d[4] != 0)
-      return;
-  }
-  long best = -1;
-  int bx = 0, bu = 0;
-  for (const SpecShape &sh : kSpecialised) {
-    if (s->num_legs > 1 && sh.serial_only)
-      continue;
-    if (sh.nx == nx && sh.nu == nu)
-      return; // the shape has its own kernels
-    if (sh.nx >= nx && sh.nu >= nu) {
-      const long cost = (long)sh.nx * (sh.nx + sh.nu);
-      if (best < 0 || cost < best)
-        best = cost, bx = sh.nx, bu = sh.nu;
-    }
-  }
-  if (best < 0)
-    return;
-  s->padded = true;
-  s->unx = nx;
-  s->unu = nu;
-  s->pnx = bx;
-  s->pnu = bu;
-  for (int t = 0; t <= N; ++t) {
-    int32_t *d = &s->dims5[5 * t];
-    d[0] = d[3] = bx;
-    if (t < N)
-      d[1] = bu;
-  }
-  s->nc0 = s->user_nc0 + (bx - nx); // the dummy states are pinned by extra rows of the initial constraint
-}
-
-int configure_padded_or_not(gar_hip_solver *s);
-
-// Everything that can be decided and validated WITHOUT touching device memory: padding, both layouts, the LDS
-// plan, leg-mode geometry, the kernel family.  create and cycle_append (on a trial object) share it.
-int configure(gar_hip_solver *s) {
-  choose_padding(s);
-  for (;;) {
-    const int rc = configure_padded_or_not(s);
-    // Padded onto a specialised shape, but no kernel of that family binds (leg mode with a leg of fewer than two
-    // knots, GAR_HIP_SEG_LEGS=0, parameter LDS beyond a CU, ...): the any-dimension kernels would then sweep the
-    // PADDED shape -- several times the work and LDS of the caller's own, possibly beyond what fits.  Redo the
-    // configuration on the caller's dimensions.
-    if (s->padded && (rc != GAR_HIP_OK || !(s->wave_kernel || s->mfma_kernel || s->leg_bwd_kernel || s->seg_bwd_kernel))) {
-      s->dims5 = s->user_dims5;
-      s->nc0 = s->user_nc0;
-      s->padded = false;
-      s->unx = s->unu = s->pnx = s->pnu = 0;
-      continue;
-    }
-    return rc;
-  }
-}
-
-int configure_padded_or_not(gar_hip_solver *s) {
-  if (int rc = build_layout(s))
-    return rc;
-  if (int rc = plan_lds(s))
-    return rc;
-  delete s->ulay;
-  s->ulay = nullptr;
-  if (s->padded) {
-    gar_hip_solver *u = new gar_hip_solver();
-    u->horizon = s->horizon;
-    u->batch = s->batch;
-    u->num_legs = s->num_legs;
-    u->dense = s->dense;
-    u->nc0 = s->user_nc0;
-    u->dims5 = s->user_dims5;
-    s->ulay = u;
-    if (int rc = build_layout(u))
-      return rc;
-  }
-  if (s->num_legs > 1) {
-    const int J = s->num_legs, W = s->world;
-    if (W < 1 || W > J || s->rank < 0 || s->rank >= W)
-      return fail(GAR_HIP_ERR_ARG, "horizon sharding needs 1 <= ranks <= num_legs");
-    s->leg_begin = (int)((long long)s->rank * J / W);
-    s->leg_end = (int)((long long)(s->rank + 1) * J / W);
-    s->legs_per_rank = (J + W - 1) / W; // chunk pitch of the gathered tuples (gar_generic.hpp, cond_tuple)
-    int nxb = 0;
-    for (const auto &m : s->meta)
-      nxb = std::max(nxb, std::max(m.nx, m.nx2));
-    if (s->nc0 > nxb)
-      return fail(GAR_HIP_ERR_UNSUPPORTED, "leg mode needs nc0 <= nx");
-    s->nxb = nxb;
-    s->tuple_doubles = 3 * (int64_t)nxb * nxb + 2 * nxb;
-  }
-  select_kernel(s);
-  if (!s->lds_error.empty() && !(s->wave_kernel || s->mfma_kernel || s->leg_bwd_kernel || s->seg_bwd_kernel))
-    return fail(GAR_HIP_ERR_UNSUPPORTED, s->lds_error);
-  delete s->flay;
-  s->flay = nullptr;
-  if (s->seg_bwd_kernel) { // scratch records of the plain kernels: the same knots, serial (nth = 0) layout
-    gar_hip_solver *f = new gar_hip_solver();
-    f->horizon = s->horizon;
-    f->batch = s->batch;
-    f->num_legs = 1;
-    f->nc0 = s->nc0;
-    f->dims5 = s->dims5;
-    s->flay = f;
-    if (int rc = build_layout(f))
-      return rc;
-  }
-  if (s->fold) {
-    gar_hip_solver *f = new gar_hip_solver();
-    f->horizon = s->horizon;
-    f->batch = s->batch;
-    f->num_legs = s->num_legs;
-    f->nc0 = s->nc0;
-    f->dims5 = s->dims5;
-    for (int t = 0; t <= s->horizon; ++t)
-      f->dims5[5 * (size_t)t + 2] = 0;
-    s->flay = f;
-    if (int rc = build_layout(f))
-      return rc;
-    s->kernel_name += "+fold";
-  }
-  return GAR_HIP_OK;
-}
+#include "gar_select.hpp"
 
 gar::GenericParams make_params(gar_hip_solver *s, double mueq) {
   gar::GenericParams P{};
@@ -1239,406 +849,7 @@ inline bool records_t2(const gar_hip_solver *s, int b) {
   return s->fb_t2 && !(s->fold && s->coupled_known && s->h_coupled[(size_t)b] != 0);
 }
 
-// parameters of the serial specialised sweeps (gar_backward_mfma, gar_backward_wave and its chain)
-gar::MfmaParams make_mfma_params(gar_hip_solver *s, double mueq) {
-  gar::MfmaParams M{};
-  M.prob = s->d_prob;
-  M.fac = s->d_fac;
-  M.status = s->d_status;
-  M.slow = s->d_status + s->batch;
-  M.resume = s->d_status + s->batch + 4;
-  M.prob_stride = s->prob_doubles;
-  M.fac_stride = s->fac_doubles;
-  const int N = s->horizon;
-  M.in_off0 = s->uni_in0;
-  M.in_rec = s->uni_in_rec;
-  M.in_offN = s->meta[N].in_off;
-  M.fac_rec = s->uni_fac_rec;
-  M.fac_offN = s->meta[N].fac_off;
-  M.horizon = N;
-  M.trace = s->d_trace;
-  const bool fused = s->wave_kernel && s->wave_fused_init;
-  M.init = fused ? s->d_init : nullptr;
-  M.init_stride = s->init_doubles;
-  M.G0_off = s->G0_off;
-  M.g0_off = s->g0_off;
-  M.nc0 = s->nc0;
-  M.mueq = mueq;
-  M.init_closed = s->init_closed ? 1 : 0;
-  M.ring0 = s->ring0;
-  {
-    const char *sa = gar_option("GAR_HIP_SPD_ACCEPT");
-    M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
-  }
-  return M;
-}
-
-// [l0, l1): the legs swept by this call (default: every leg of this solver; gar_hip_backward_blocks sweeps them in
-// chunks, as their knots arrive).  The kernels index legs as blockIdx.x + leg_begin and the tuples as blockIdx.x:
-// a chunk is the same launch with leg_begin = l0 and the tuple buffer advanced to leg l0's slot.
-int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
-  RoctxRange range_(s->num_legs > 1 ? "gar::parallel_backward" : "gar::backwardImpl+factor_initial");
-  const bool chunk = l0 >= 0;
-  if (!chunk)
-    l0 = s->leg_begin, l1 = s->leg_end;
-  const bool first = l0 == s->leg_begin, last = l1 == s->leg_end;
-  const long long tup_shift = (long long)(l0 - s->leg_begin) * s->tuple_doubles;
-  if (s->leg_bwd_kernel) {
-    gar::LegParams Q = make_leg_params(s);
-    Q.leg_begin = l0;
-    Q.boundary += tup_shift;
-    const dim3 grid((unsigned)(l1 - l0), (unsigned)s->batch);
-    if (s->timing && first)
-      HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    if (s->fold) { // knots with nc > 0: fold C, d into Q, q (gar_fold.hpp); problems with D != 0 get flagged
-      s->fold_mueq = mueq;
-      s->fold_expanded = s->coupled_known = false;
-      hipLaunchKernelGGL(gar::gar_fold_constraints, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch), dim3(256), 0,
-                         s->stream, make_fold_params(s));
-    }
-    hipLaunchKernelGGL(s->leg_bwd_kernel, grid, dim3(64 * s->leg_waves),
-                       (size_t)s->leg_lds_doubles * sizeof(double), s->stream, Q);
-    hipLaunchKernelGGL(s->leg_tuple_kernel, grid, dim3(256), 0, s->stream, Q);
-    if (s->fold) { // ... and are swept by the generic leg kernels (every other problem: an early exit)
-      gar::GenericParams G = make_params(s, mueq);
-      G.only = s->d_status + s->batch + 4;
-      G.leg_begin = l0;
-      G.local_legs = l1 - l0;
-      G.boundary += tup_shift;
-      hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(GAR_BACKWARD_THREADS), (size_t)s->lds.total * sizeof(double), s->stream, G);
-    }
-    HIP_TRY(hipGetLastError());
-    if (s->timing && last)
-      HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-    return GAR_HIP_OK;
-  }
-  if (s->seg_bwd_kernel) { // segment legs (gar_leg_seg.hpp): plain part, then the parameter recursion + tuples
-    const gar_hip_solver *f = s->flay;
-    const int N = s->horizon;
-    gar::MfmaParams M{};
-    M.prob = s->d_prob;
-    M.fac = s->d_fac2;
-    M.status = s->d_status;
-    M.slow = s->d_status + s->batch;
-    M.resume = s->d_status + s->batch + 4;
-    M.prob_stride = s->prob_doubles;
-    M.fac_stride = f->fac_doubles;
-    M.in_off0 = s->uni_in0;
-    M.in_rec = s->uni_in_rec;
-    M.in_offN = s->meta[N].in_off;
-    M.fac_rec = f->uni_fac_rec;
-    M.fac_offN = f->meta[N].fac_off;
-    M.horizon = N;
-    M.mueq = mueq;
-    {
-      const char *sa = gar_option("GAR_HIP_SPD_ACCEPT");
-      M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
-    }
-    const dim3 grid((unsigned)(l1 - l0), (unsigned)s->batch);
-    if (s->timing && first)
-      HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    hipLaunchKernelGGL(s->seg_bwd_kernel, grid, dim3(128), (size_t)s->seg_lds_doubles * sizeof(double), s->stream, M,
-                       s->num_legs, l0);
-    gar::LegParamParams Q{};
-    Q.meta = s->d_meta;
-    Q.meta2 = s->d_meta2;
-    Q.prob = s->d_prob;
-    Q.fac2 = s->d_fac2;
-    Q.fac = s->d_fac;
-    Q.boundary = s->d_bound_local + tup_shift;
-    Q.status = s->d_status;
-    Q.prob_stride = s->prob_doubles;
-    Q.fac_stride = s->fac_doubles;
-    Q.fac2_stride = f->fac_doubles;
-    Q.boundary_stride = (long long)s->legs_per_rank * s->tuple_doubles;
-    Q.horizon = N;
-    Q.num_legs = s->num_legs;
-    Q.leg_begin = l0;
-    Q.tuple_doubles = (int)s->tuple_doubles;
-    Q.nxb = s->nxb;
-    Q.nxM = s->dims5[0];
-    Q.nuM = s->dims5[1];
-    Q.local_legs = l1 - l0;
-    // the chain of Vxt alone per leg; everything else of every stage at once; the running sums and the tuples
-    {
-      hipLaunchKernelGGL(gar::gar_leg_param_chain, grid, dim3(GAR_LEG_PARAM_THREADS),
-                         (size_t)gar::leg_chain_lds_doubles(s->dims5[0]) * sizeof(double), s->stream, Q);
-      hipLaunchKernelGGL(gar::gar_leg_param_stage, dim3((unsigned)N + 1, (unsigned)s->batch), dim3(GAR_LEG_STAGE_THREADS),
-                         (size_t)gar::leg_stage_lds_doubles(s->dims5[0], s->dims5[1]) * sizeof(double), s->stream, Q);
-      hipLaunchKernelGGL(gar::gar_leg_param_finish, grid, dim3(1024), 0, s->stream, Q);
-    }
-    HIP_TRY(hipGetLastError());
-    if (s->timing && last)
-      HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-    return GAR_HIP_OK;
-  }
-  gar::GenericParams P = make_params(s, mueq);
-  if (s->dense) {
-    hipLaunchKernelGGL(gar::gar_backward_dense, dim3((unsigned)s->batch), dim3(GAR_DENSE_THREADS),
-                       (size_t)s->dense_lds.total * sizeof(double), s->stream, P);
-    HIP_TRY(hipGetLastError());
-    return GAR_HIP_OK;
-  }
-  if (s->mfma_kernel || s->wave_kernel) {
-    const gar::MfmaParams M = make_mfma_params(s, mueq);
-    const bool fused = s->wave_kernel && s->wave_fused_init;
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    if (s->wave_kernel) {
-      const int wpb = s->waves_per_block;
-      hipLaunchKernelGGL(s->wave_kernel, dim3((unsigned)((s->batch + wpb - 1) / wpb)),
-                         dim3(s->wave_block_threads * wpb), (size_t)s->wave_lds_doubles * wpb * sizeof(double),
-                         s->stream, M, s->batch);
-      // constrained sweeps: the chain decoupled stage -> coupled stage -> LDS Bunch-Kaufman (gar_wave.hpp)
-      for (auto k : {s->wave_coupled_kernel, s->wave_bk_kernel})
-        if (k)
-          hipLaunchKernelGGL(k, dim3((unsigned)((s->batch + wpb - 1) / wpb)), dim3(s->wave_block_threads * wpb),
-                             (size_t)s->wave_lds_doubles * wpb * sizeof(double), s->stream, M, s->batch);
-    } else {
-      hipLaunchKernelGGL(s->mfma_kernel, dim3((unsigned)s->batch), dim3(256),
-                         (size_t)s->mfma_lds_doubles * sizeof(double), s->stream, M);
-    }
-    HIP_TRY(hipGetLastError());
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-    if (fused) {
-      // nothing to launch: gar_backward_wave already produced kkt0.ff
-    } else if (s->n0 <= 128) { // one wave per problem (wave-scope Bunch-Kaufman handles n <= 128)
-      hipLaunchKernelGGL(gar::gar_initial_wave, dim3((unsigned)s->batch), dim3(64),
-                         (size_t)gar::gar_initial_wave_lds_doubles(s->n0, s->nth0) * sizeof(double),
-                         s->stream, P);
-    } else {
-      hipLaunchKernelGGL(gar::gar_initial_generic, dim3((unsigned)s->batch), dim3(256),
-                         (size_t)s->lds.total * sizeof(double), s->stream, P);
-    }
-    HIP_TRY(hipGetLastError());
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->ev[2], s->stream));
-    return GAR_HIP_OK;
-  }
-  const dim3 grid((unsigned)(l1 - l0), (unsigned)s->batch);
-  P.leg_begin = l0;
-  P.local_legs = l1 - l0;
-  if (P.boundary)
-    P.boundary += tup_shift;
-  hipLaunchKernelGGL(gar::gar_backward_generic, grid, dim3(GAR_BACKWARD_THREADS),
-                     (size_t)s->lds.total * sizeof(double), s->stream, P);
-  HIP_TRY(hipGetLastError());
-  return GAR_HIP_OK;
-}
-
-constexpr size_t kCuLdsBytes = 160 * 1024, kLdsGranule = 1280; // gfx950: 160 KiB per CU, allocated in 320-dword pieces
-inline size_t lds_round(size_t b) { return (b + kLdsGranule - 1) / kLdsGranule * kLdsGranule; }
-
-gar::MfmaFwdParams make_mfma_fwd_params(gar_hip_solver *s) {
-  gar::MfmaFwdParams F{};
-  const int N = s->horizon;
-  F.fac = s->d_fac;
-  F.init = s->d_init;
-  F.sol = s->d_sol;
-  F.fac_stride = s->fac_doubles;
-  F.init_stride = s->init_doubles;
-  F.sol_stride = s->sol_doubles;
-  F.fac_rec = s->uni_fac_rec;
-  F.fac_offN = s->meta[N].fac_off;
-  F.horizon = N;
-  F.nc0 = s->nc0;
-  F.sol_u = (int)s->sol_u;
-  F.sol_l = (int)s->sol_l;
-  F.sol_v = (int)s->sol_v;
-  F.ring0 = s->ring0;
-  return F;
-}
-
-int launch_forward(gar_hip_solver *s, const double *theta_dev) {
-  RoctxRange range_(s->num_legs > 1 ? "gar::parallel_forward" : "gar::forwardImpl");
-  if (s->leg_fwd_kernel) {
-    gar::LegParams Q = make_leg_params(s);
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->ev[3], s->stream));
-    hipLaunchKernelGGL(s->leg_fwd_kernel, dim3((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch),
-                       dim3(64), 0, s->stream, Q);
-    if (s->fold) { // v_t = zff + Z x_t on this rank's stages; flagged problems: the generic roll-out
-      hipLaunchKernelGGL(gar::gar_constraint_multipliers, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch), dim3(64), 0,
-                         s->stream, make_fold_params(s));
-      gar::GenericParams G = make_params(s, 0.0);
-      G.only = s->d_status + s->batch + 4;
-      hipLaunchKernelGGL(gar::gar_forward_generic, dim3((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch), dim3(GAR_FORWARD_THREADS),
-                         (size_t)s->lds.ftotal * sizeof(double), s->stream, G);
-    }
-    HIP_TRY(hipGetLastError());
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->ev[4], s->stream));
-    return GAR_HIP_OK;
-  }
-  if (s->mfma_fwd_kernel) {
-    const gar::MfmaFwdParams F = make_mfma_fwd_params(s);
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->ev[3], s->stream));
-    // FORWARD = lean (per launch): the LDS-DMA roll-out of the pipelined schedule (gar_forward_lean.hpp, bit for bit the
-    // same solution) for the whole batch in the plain schedule too -- one workgroup of four problems per CU at a time
-    const char *fw = s->lean_fwd_kernel ? gar_option("GAR_HIP_FORWARD") : nullptr;
-    if (fw && std::string(fw) == "lean") {
-      if (s->lean_fwd_lds_bytes == 0) {
-        s->lean_fwd_lds_bytes = std::max(lds_round(s->lean_fwd_used), lds_round(kCuLdsBytes / 2 + 1));
-        HIP_TRY(hipFuncSetAttribute((const void *)s->lean_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)s->lean_fwd_lds_bytes));
-      }
-      hipLaunchKernelGGL(s->lean_fwd_kernel, dim3((unsigned)((s->batch + 3) / 4)), dim3(256), s->lean_fwd_lds_bytes, s->stream, F,
-                         s->batch);
-    } else
-    hipLaunchKernelGGL(s->mfma_fwd_kernel, dim3((unsigned)s->batch), dim3(64), s->mfma_fwd_lds_bytes, s->stream, F);
-    HIP_TRY(hipGetLastError());
-    if (s->timing)
-      HIP_TRY(hipEventRecord(s->ev[4], s->stream));
-    return GAR_HIP_OK;
-  }
-  gar::GenericParams P = make_params(s, 0.0);
-  P.theta = theta_dev;
-  if (s->dense) {
-    hipLaunchKernelGGL(gar::gar_forward_dense, dim3((unsigned)s->batch), dim3(256),
-                       (size_t)s->lds.ftotal * sizeof(double), s->stream, P);
-    HIP_TRY(hipGetLastError());
-    return GAR_HIP_OK;
-  }
-  const dim3 grid((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch);
-  if (s->timing)
-    HIP_TRY(hipEventRecord(s->ev[3], s->stream));
-  if (s->seg_bwd_kernel && s->seg_fwd_kernel && s->num_legs > 1) // segment legs: a wave per (leg, problem)
-    hipLaunchKernelGGL(s->seg_fwd_kernel, grid, dim3(64), 0, s->stream, P);
-  else
-    hipLaunchKernelGGL(gar::gar_forward_generic, grid, dim3(GAR_FORWARD_THREADS),
-                       (size_t)s->lds.ftotal * sizeof(double), s->stream, P);
-  HIP_TRY(hipGetLastError());
-  if (s->timing)
-    HIP_TRY(hipEventRecord(s->ev[4], s->stream));
-  return GAR_HIP_OK;
-}
-
-#include "gar_pipeline.hpp"
-
-int launch_condensed(gar_hip_solver *s) {
-  RoctxRange range_("gar::assembleCondensedSystem+symmetricBlockTridiagSolve");
-  gar::CondensedParams C{};
-  C.ball = s->d_bound_all;
-  C.prob = s->d_prob;
-  C.scratch = s->d_cscratch;
-  C.csol = s->d_csol;
-  C.status = s->d_status;
-  C.prob_stride = s->prob_doubles;
-  C.scratch_stride = s->cscratch_doubles;
-  C.G0_off = s->G0_off;
-  C.g0_off = s->g0_off;
-  C.batch = s->batch;
-  C.num_legs = s->num_legs;
-  C.legs_per_rank = s->legs_per_rank;
-  C.world = s->world;
-  C.tuple_doubles = (int)s->tuple_doubles;
-  C.nxb = s->nxb;
-  C.nc0 = s->nc0;
-  C.nx0 = s->nx0;
-  C.max_refinement = s->max_refinement;
-  C.threshold = s->cond_threshold;
-  C.backward_ok = s->cond_backward_ok;
-  C.trace = s->d_trace;
-  C.gated = 0;
-  if (s->cyc_setup_kernel) {
-    gar::CyclicParams Y{};
-    Y.C = C;
-    Y.h = 0;
-    const int J = s->num_legs;
-    const size_t lds = (size_t)s->cyc_lds_doubles * sizeof(double);
-    hipLaunchKernelGGL(s->cyc_setup_kernel, dim3((unsigned)J, (unsigned)s->batch), dim3(64), lds,
-                       s->stream, Y);
-    for (int h = 1; h < J; h *= 2) {
-      Y.h = h;
-      hipLaunchKernelGGL(s->cyc_reduce_kernel,
-                         dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch), dim3(128),
-                         2 * lds + 64 * sizeof(double), s->stream, Y);
-    }
-    // back-substitution: the levels holding at most 4 blocks in one workgroup, the wider ones a
-    // launch each; then the states and the residual, a wave per leg
-    int hmax = 1;
-    while (2 * hmax < J)
-      hmax *= 2;
-    int htop = hmax;
-    while (htop > 1 && (J / (htop / 2) + 1) / 2 <= 4)
-      htop /= 2;
-    Y.h = htop;
-    hipLaunchKernelGGL(s->cyc_top_kernel, dim3((unsigned)s->batch), dim3(256), lds, s->stream, Y);
-    for (int h = htop / 2; h >= 1; h /= 2) {
-      Y.h = h;
-      hipLaunchKernelGGL(s->cyc_backlevel_kernel,
-                         dim3((unsigned)((J / h + 1) / 2), (unsigned)s->batch), dim3(64), 0,
-                         s->stream, Y);
-    }
-    hipLaunchKernelGGL(s->cyc_recover_kernel, dim3((unsigned)J, (unsigned)s->batch), dim3(64), 0,
-                       s->stream, Y);
-    HIP_TRY(hipGetLastError());
-    C.gated = 1; // the chain kernel (with refinement) re-solves only what missed the threshold
-  }
-  if (s->cond_wave_kernel) {
-    hipLaunchKernelGGL(s->cond_wave_kernel, dim3((unsigned)s->batch), dim3(64),
-                       (size_t)s->cond_wave_lds_doubles * sizeof(double), s->stream, C);
-  } else {
-    if (!C.gated && s->cond_reduced) {
-      // the leg states eliminated leg-parallel, the chain on the J remaining blocks, the states back leg-parallel
-      // (gar_generic.hpp: gar_condensed_leg_eliminate); the full chain then runs gated, like behind cyclic reduction
-      const dim3 grid((unsigned)s->num_legs, (unsigned)s->batch);
-      hipLaunchKernelGGL(gar::gar_condensed_leg_eliminate, grid, dim3(GAR_CONDENSED_THREADS),
-                         (size_t)gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double), s->stream, C);
-      if (s->cond_cr) {
-        // the J remaining blocks by block cyclic reduction: a workgroup per block and level (gar_condensed_cr.hpp)
-        const int J = s->num_legs;
-        const size_t blk_bytes = (size_t)s->nxb * s->nxb * sizeof(double);
-        // (the products of a level read their operands from LDS when four blocks fit a CU)
-        const int staged = (size_t)gar::gar_condensed_cr_update_lds_doubles(s->nxb, 1) * sizeof(double) <= 160 * 1024;
-        const size_t upd_bytes = (size_t)gar::gar_condensed_cr_update_lds_doubles(s->nxb, staged) * sizeof(double);
-        hipLaunchKernelGGL(gar::gar_condensed_cr_assemble, grid, dim3(GAR_CONDENSED_THREADS), blk_bytes, s->stream, C);
-        for (int h = 1; h < J; h *= 2) {
-          hipLaunchKernelGGL(gar::gar_condensed_cr_eliminate, dim3((unsigned)((J - 1 + h) / (2 * h)), (unsigned)s->batch),
-                             dim3(GAR_CONDENSED_THREADS),
-                             (size_t)gar::gar_condensed_leg_lds_doubles(s->nxb) * sizeof(double), s->stream, C, h);
-          hipLaunchKernelGGL(gar::gar_condensed_cr_update, dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch),
-                             dim3(GAR_CONDENSED_THREADS), upd_bytes, s->stream, C, h, staged);
-        }
-        hipLaunchKernelGGL(gar::gar_condensed_cr_back, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
-                           (size_t)gar::gar_condensed_cr_back_lds_doubles(s->nxb, J) * sizeof(double), s->stream, C);
-      } else {
-        gar::CondensedParams R = C;
-        R.reduced = 1;
-        hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
-                           (size_t)s->cond_lds_doubles * sizeof(double), s->stream, R);
-      }
-      hipLaunchKernelGGL(gar::gar_condensed_leg_states, grid, dim3(256), (size_t)(5 * s->nxb + 2) * sizeof(double),
-                         s->stream, C);
-      C.gated = 1;
-    }
-    hipLaunchKernelGGL(gar::gar_condensed_generic, dim3((unsigned)s->batch), dim3(GAR_CONDENSED_THREADS),
-                       (size_t)s->cond_lds_doubles * sizeof(double), s->stream, C);
-  }
-  HIP_TRY(hipGetLastError());
-  if (s->timing) // leg mode: the "initial stage" slot of the timing API is the condensed solve
-    HIP_TRY(hipEventRecord(s->ev[2], s->stream));
-  return GAR_HIP_OK;
-}
-
-int check_bt(const gar_hip_solver *s, int b, int t) {
-  if (!s)
-    return fail(GAR_HIP_ERR_ARG, "null solver");
-  if (b < 0 || b >= s->batch)
-    return fail(GAR_HIP_ERR_ARG, "problem index out of range");
-  if (t < 0 || t > s->horizon)
-    return fail(GAR_HIP_ERR_ARG, "stage index out of range");
-  return GAR_HIP_OK;
-}
-
-int d2h(gar_hip_solver *s, double *dst, const double *src, int64_t n) {
-  if (!dst || n <= 0)
-    return GAR_HIP_OK;
-  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
-  return GAR_HIP_OK;
-}
+#include "gar_launch.hpp"
 
 void free_device(gar_hip_solver *s) {
   (void)hipFree(s->d_meta);
@@ -3331,353 +2542,6 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
 }
 
 
-// ---- caller-facing entry points whose records differ under padding (gar_hip_solver::padded) --------------------
-int gar_hip_upload_stage(gar_hip_solver *s, int b, int t, const double *Q, const double *S, const double *R,
-                         const double *q, const double *r, const double *A, const double *B, const double *f,
-                         const double *C, const double *D, const double *d, const double *Gth, const double *Gx,
-                         const double *Gu, const double *Gv, const double *gamma) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, t))
-    return rc;
-  GAR_MULTI(s, gar_hip_upload_stage(multi_owner(s, t), b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma));
-  return upload_stage_impl(s, b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma);
-}
-
-static int upload_stage_impl(gar_hip_solver *s, int b, int t, const double *Q, const double *S, const double *R,
-                             const double *q, const double *r, const double *A, const double *B, const double *f,
-                             const double *C, const double *D, const double *d, const double *Gth, const double *Gx,
-                             const double *Gu, const double *Gv, const double *gamma) {
-  if (s->term_grown && t == s->horizon) // the caller's terminal A (0 x nx) and f are empty: zeros in the record
-    A = f = s->term_zeros.data();
-  if (!s->padded)
-    return upload_stage_dev(s, b, t, Q, S, R, q, r, A, B, f, C, D, d, Gth, Gx, Gu, Gv, gamma);
-  const gar_stage_meta &m = s->meta[t];
-  const int nx = s->unx, nu = m.nu > 0 ? s->unu : 0, NX = m.nx, NU = m.nu;
-  if (!Q || !q || !A || !f || (nu > 0 && (!S || !R || !r || !B)))
-    return fail(GAR_HIP_ERR_ARG, "gar_hip_upload_stage: null block");
-  if (s->staged) {
-    // straight into the pinned staging record, one pass: real rows / columns copied column by column, the dummy
-    // ones written beside them (no intermediate padded copy of the blocks); then the knot is one dirty range
-    const gar_knot_offsets o = gar_knot_layout(NX, NU, 0, NX, 0);
-    double *rec = s->h_prob + (int64_t)b * s->prob_doubles + m.in_off;
-    const bool nt = s->stage_nt;
-    auto put = [rec, nt](int64_t off, const double *src, int r, int c, int R, int C, double diag) {
-      double *dst = rec + off;
-      if (r == R) { // same column pitch (e.g. (56, 22) -> (56, 24): only controls are added): the real columns in one go
-        stage_copy(dst, src, (size_t)r * (size_t)c, nt);
-      } else {
-        for (int j = 0; j < c; ++j) {
-          std::memcpy(dst + (size_t)j * R, src + (size_t)j * r, sizeof(double) * (size_t)r);
-          std::memset(dst + (size_t)j * R + r, 0, sizeof(double) * (size_t)(R - r));
-        }
-      }
-      if (C > c)
-        std::memset(dst + (size_t)c * R, 0, sizeof(double) * (size_t)R * (size_t)(C - c));
-      if (diag != 0.0)
-        for (int i = std::min(r, c); i < std::min(R, C); ++i)
-          dst[(size_t)i * R + i] = diag;
-    };
-    if (s->qr_packed && t < s->horizon) {
-      pack_lower(rec + o.Q, Q, nx, NX, 1.0);
-      pack_lower(rec + o.R, R, nu, NU, 1.0);
-    } else {
-      put(o.Q, Q, nx, nx, NX, NX, 1.0);
-      put(o.R, R, nu, nu, NU, NU, 1.0);
-    }
-    put(o.S, S, nx, nu, NX, NU, 0.0);
-    put(o.q, q, nx, 1, NX, 1, 0.0);
-    put(o.r, r, nu, 1, NU, 1, 0.0);
-    put(o.A, A, nx, nx, NX, NX, 0.0);
-    put(o.B, B, nx, nu, NX, NU, 0.0);
-    put(o.f, f, nx, 1, NX, 1, 0.0);
-    mark_dirty(s, b, m.in_off, m.in_off + gar_knot_doubles(NX, NU, 0, NX, 0));
-    return flush_if_grown(s, b);
-  }
-  thread_local std::vector<double> bQ, bS, bR, bq, br, bA, bB, bf;
-  return upload_stage_dev(s, b, t, padded_block(bQ, Q, nx, nx, NX, NX, 1.0), padded_block(bS, S, nx, nu, NX, NU, 0.0),
-                          padded_block(bR, R, nu, nu, NU, NU, 1.0), padded_block(bq, q, nx, 1, NX, 1, 0.0),
-                          padded_block(br, r, nu, 1, NU, 1, 0.0), padded_block(bA, A, nx, nx, NX, NX, 0.0),
-                          padded_block(bB, B, nx, nu, NX, NU, 0.0), padded_block(bf, f, nx, 1, NX, 1, 0.0), nullptr,
-                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-}
-
-int gar_hip_set_init(gar_hip_solver *s, int b, const double *G0, const double *g0) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
-  GAR_MULTI(s, multi_set_init(s, b, G0, g0));
-  if (!s->padded)
-    return set_init_dev(s, b, G0, g0);
-  if (s->user_nc0 > 0 && (!G0 || !g0))
-    return fail(GAR_HIP_ERR_ARG, "gar_hip_set_init: null block");
-  // [G0 0; 0 -I], [g0; 0]: the dummy states start (and stay) at zero
-  const int nc0u = s->user_nc0, nc0 = s->nc0, nx = s->unx, NX = s->pnx;
-  thread_local std::vector<double> G, g;
-  G.assign((size_t)nc0 * NX, 0.0);
-  g.assign((size_t)nc0, 0.0);
-  for (int j = 0; j < nx; ++j)
-    for (int i = 0; i < nc0u; ++i)
-      G[(size_t)j * nc0 + i] = G0[(size_t)j * nc0u + i];
-  for (int i = 0; i < NX - nx; ++i)
-    G[(size_t)(nx + i) * nc0 + nc0u + i] = -1.0;
-  for (int i = 0; i < nc0u; ++i)
-    g[i] = g0[i];
-  return set_init_dev(s, b, G.data(), g.data());
-}
-
-int gar_hip_set_condensed_backward_ok(gar_hip_solver *s, double omega) {
-  if (!s || !(omega >= 0.0))
-    return fail(GAR_HIP_ERR_ARG, "bad backward-error bound");
-  s->cond_backward_ok = omega;
-  GAR_MULTI(s, multi_all(s, [&](gar_hip_solver *q) { return gar_hip_set_condensed_backward_ok(q, omega); }));
-  return GAR_HIP_OK;
-}
-
-#ifdef GAR_CTRACE
-extern "C" int gar_hip_debug_ctrace(long long *out) {
-  long long z[16] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_ctrace), sizeof(z)) != hipSuccess) return 1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_ctrace), z, sizeof(z)) != hipSuccess) return 2;
-  return 0;
-}
-extern "C" int gar_hip_debug_ptrace(long long *out) {
-  long long z[16] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_ptrace), sizeof(z)) != hipSuccess) return 1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_ptrace), z, sizeof(z)) != hipSuccess) return 2;
-  return 0;
-}
-extern "C" int gar_hip_debug_crtrace(long long *out) {
-  long long z[16] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gar::g_crtrace), sizeof(z)) != hipSuccess) return 1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(gar::g_crtrace), z, sizeof(z)) != hipSuccess) return 2;
-  return 0;
-}
-#endif
-int gar_hip_condensed_resolved(gar_hip_solver *s, int b, int *out) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
-  GAR_MULTI(s, gar_hip_condensed_resolved(s->multi->subs[0], b, out));
-  if (s->num_legs < 2 || !out)
-    return fail(GAR_HIP_ERR_ARG, "condensed info needs leg mode");
-  const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
-  const double *info = s->d_cscratch + (int64_t)b * s->cscratch_doubles + 4 * nblk * bs + 4 * nblk * s->nxb;
-  double v = 0.0;
-  if (int rc = d2h(s, &v, info + 3, 1))
-    return rc;
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  *out = v != 0.0 ? 1 : 0;
-  return GAR_HIP_OK;
-}
-
-int gar_hip_condensed_backward_error(gar_hip_solver *s, int b, double *out) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
-  GAR_MULTI(s, gar_hip_condensed_backward_error(s->multi->subs[0], b, out));
-  if (s->num_legs < 2 || !out)
-    return fail(GAR_HIP_ERR_ARG, "condensed info needs leg mode");
-  const int64_t nblk = 2 * s->num_legs, bs = (int64_t)s->nxb * s->nxb;
-  const double *info = s->d_cscratch + (int64_t)b * s->cscratch_doubles + 4 * nblk * bs + 4 * nblk * s->nxb;
-  double v[3] = {0.0, 0.0, 0.0};
-  if (int rc = d2h(s, v, info, 3))
-    return rc;
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  *out = v[2] > 0.0 ? v[0] / v[2] : 0.0;
-  return GAR_HIP_OK;
-}
-
-int gar_hip_get_solution(gar_hip_solver *s, int b, double *xs, double *us, double *vs, double *lbdas) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
-  GAR_MULTI(s, multi_get_solution(s, b, xs, us, vs, lbdas));
-  if (!s->padded)
-    return get_solution_dev(s, b, xs, us, vs, lbdas);
-  std::vector<double> rec((size_t)s->sol_doubles);
-  HIP_TRY(hipMemcpyAsync(rec.data(), s->d_sol + (int64_t)b * s->sol_doubles, sizeof(double) * rec.size(),
-                         hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  strip_solution(s, rec.data(), xs, us, vs, lbdas);
-  return GAR_HIP_OK;
-}
-
-int gar_hip_get_gains(gar_hip_solver *s, int b, int t, double *ff, double *fb, double *fth) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, t))
-    return rc;
-  GAR_MULTI(s, gar_hip_get_gains(multi_owner(s, t), b, t, ff, fb, fth));
-  if (s->term_grown && t == s->horizon) {
-    // the caller's terminal knot has nx2 = 0: its ff / fb / fth hold the nc rows [zff | Z | Zth] alone (they lead
-    // the record's rows; a padded solver has nc = 0: nothing to hand back)
-    const gar_stage_meta &m = s->meta[t];
-    const int nc = m.nc, NR = m.nu + m.nc + m.nx2, NX = m.nx, NT = m.nth;
-    if (nc == 0 || s->padded)
-      return GAR_HIP_OK;
-    std::vector<double> F((size_t)NR), Fb((size_t)NR * NX), Ft((size_t)NR * std::max(NT, 1));
-    if (int rc = get_gains_dev(s, b, t, F.data(), Fb.data(), NT > 0 ? Ft.data() : nullptr))
-      return rc;
-    if (ff)
-      std::copy(F.begin(), F.begin() + nc, ff);
-    if (fb)
-      std::copy(Fb.begin(), Fb.begin() + (size_t)nc * NX, fb);
-    if (fth && NT > 0)
-      std::copy(Ft.begin(), Ft.begin() + (size_t)nc * NT, fth);
-    return GAR_HIP_OK;
-  }
-  if (!s->padded)
-    return get_gains_dev(s, b, t, ff, fb, fth);
-  const gar_stage_meta &m = s->meta[t];
-  const int NR = m.nu + m.nx2, NX = m.nx, NT = m.nth;
-  const int nx = s->unx, nu = m.nu > 0 ? s->unu : 0, nr = nu + nx, nt = NT > 0 ? nx : 0;
-  std::vector<double> F((size_t)NR), Fb((size_t)NR * NX), Ft((size_t)NR * std::max(NT, 1));
-  if (int rc = get_gains_dev(s, b, t, F.data(), Fb.data(), NT > 0 ? Ft.data() : nullptr))
-    return rc;
-  for (int r = 0; r < nr; ++r) {
-    const int rd = gain_row(s, r, m.nu);
-    if (ff)
-      ff[r] = F[(size_t)rd];
-    if (fb)
-      for (int j = 0; j < nx; ++j)
-        fb[(size_t)r * nx + j] = Fb[(size_t)rd * NX + j];
-    if (fth)
-      for (int j = 0; j < nt; ++j)
-        fth[(size_t)r * nt + j] = Ft[(size_t)rd * NT + j];
-  }
-  return GAR_HIP_OK;
-}
-
-int gar_hip_get_value(gar_hip_solver *s, int b, int t, double *Vxx, double *vx, double *Vxt, double *Vtt,
-                      double *vt) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, t))
-    return rc;
-  GAR_MULTI(s, gar_hip_get_value(multi_owner(s, t), b, t, Vxx, vx, Vxt, Vtt, vt));
-  if (!s->padded)
-    return get_value_dev(s, b, t, Vxx, vx, Vxt, Vtt, vt);
-  const gar_stage_meta &m = s->meta[t];
-  const int NX = m.nx, NT = m.nth, nx = s->unx, nt = NT > 0 ? nx : 0;
-  std::vector<double> V((size_t)NX * NX), v((size_t)NX), Xt((size_t)NX * std::max(NT, 1)),
-      Tt((size_t)std::max(NT, 1) * std::max(NT, 1)), tv((size_t)std::max(NT, 1));
-  if (int rc = get_value_dev(s, b, t, V.data(), v.data(), Xt.data(), Tt.data(), tv.data()))
-    return rc;
-  for (int j = 0; j < nx; ++j) {
-    if (Vxx)
-      std::memcpy(Vxx + (size_t)j * nx, &V[(size_t)j * NX], sizeof(double) * (size_t)nx);
-    if (vx)
-      vx[j] = v[(size_t)j];
-  }
-  for (int j = 0; j < nt; ++j) {
-    if (Vxt)
-      std::memcpy(Vxt + (size_t)j * nx, &Xt[(size_t)j * NX], sizeof(double) * (size_t)nx);
-    if (Vtt)
-      std::memcpy(Vtt + (size_t)j * nt, &Tt[(size_t)j * NT], sizeof(double) * (size_t)nt);
-    if (vt)
-      vt[j] = tv[(size_t)j];
-  }
-  return GAR_HIP_OK;
-}
-
-int gar_hip_get_kkt(gar_hip_solver *s, int b, int t, double mueq, double *out) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, t))
-    return rc;
-  GAR_MULTI(s, gar_hip_get_kkt(multi_owner(s, t), b, t, mueq, out));
-  if (!s->padded)
-    return get_kkt_dev(s, b, t, mueq, out);
-  if (!out)
-    return fail(GAR_HIP_ERR_ARG, "null output");
-  const gar_stage_meta &m = s->meta[t];
-  const int NU = m.nu, nu = NU > 0 ? s->unu : 0;
-  if (nu == 0)
-    return GAR_HIP_OK;
-  std::vector<double> K((size_t)NU * NU);
-  if (int rc = get_kkt_dev(s, b, t, mueq, K.data()))
-    return rc;
-  for (int j = 0; j < nu; ++j)
-    std::memcpy(out + (size_t)j * nu, &K[(size_t)j * NU], sizeof(double) * (size_t)nu);
-  return GAR_HIP_OK;
-}
-
-int gar_hip_get_initial(gar_hip_solver *s, int b, double *kkt0_ff, double *kkt0_fth, double *thGrad,
-                        double *thHess) {
-  GAR_GUARD(s);
-  if (int rc = check_bt(s, b, 0))
-    return rc;
-  GAR_MULTI(s, gar_hip_get_initial(s->multi->subs[0], b, kkt0_ff, kkt0_fth, thGrad, thHess));
-  if (!s->padded)
-    return get_initial_dev(s, b, kkt0_ff, kkt0_fth, thGrad, thHess);
-  const int n0 = s->n0, NT = s->nth0, NX = s->pnx, nx = s->unx, nt = NT > 0 ? nx : 0, n0u = nx + s->user_nc0;
-  std::vector<double> F((size_t)n0), Ft((size_t)n0 * std::max(NT, 1)), g((size_t)std::max(NT, 1)),
-      H((size_t)std::max(NT, 1) * std::max(NT, 1));
-  if (int rc = get_initial_dev(s, b, F.data(), Ft.data(), g.data(), H.data()))
-    return rc;
-  for (int r = 0; r < n0u; ++r) { // kkt0.ff = [x0; lbd0]: the real entries of each part
-    const int rd = r < nx ? r : r - nx + NX;
-    if (kkt0_ff)
-      kkt0_ff[r] = F[(size_t)rd];
-    if (kkt0_fth)
-      for (int j = 0; j < nt; ++j)
-        kkt0_fth[(size_t)r * nt + j] = Ft[(size_t)rd * NT + j];
-  }
-  for (int j = 0; j < nt; ++j) {
-    if (thGrad)
-      thGrad[j] = g[(size_t)j];
-    if (thHess)
-      std::memcpy(thHess + (size_t)j * nt, &H[(size_t)j * NT], sizeof(double) * (size_t)nt);
-  }
-  return GAR_HIP_OK;
-}
-
-/* ---- the device side of a (possibly padded) solver, for device-resident producers and consumers ---------------- */
-int gar_hip_device_stage_layout(const gar_hip_solver *s, int t, int64_t out[11]) {
-  if (int rc = check_bt(s, 0, t))
-    return rc;
-  const gar_stage_meta &m = s->meta[t];
-  out[0] = m.nx; out[1] = m.nu; out[2] = m.nc; out[3] = m.nx2; out[4] = s->dims5[5 * (size_t)t + 4];
-  out[5] = m.in_off; out[6] = m.fac_off; out[7] = m.x_off; out[8] = m.u_off; out[9] = m.v_off; out[10] = m.l_off;
-  return GAR_HIP_OK;
-}
-
-gar_hip_solver *gar_hip_multi_create(int ndev, const int *dev_ids, int horizon, const int32_t *dims5, int nc0, int batch,
-                                     int num_legs) {
-  return multi_create(ndev, dev_ids, horizon, dims5, nc0, batch, num_legs);
-}
-
-int gar_hip_num_devices(const gar_hip_solver *s) { return !s ? 0 : (s->multi ? (int)s->multi->subs.size() : 1); }
-
-int gar_hip_stage_device(const gar_hip_solver *s, int t) {
-  if (int rc = check_bt(s, 0, t))
-    return rc;
-  return s->multi ? s->multi->subs[(size_t)s->multi->owner[(size_t)t]]->device : s->device;
-}
-
-const char *gar_hip_multi_exchange_name(const gar_hip_solver *s) {
-  return (s && s->multi) ? (s->multi->pull ? "pull" : "copy") : "";
-}
-
-long long gar_hip_debug_alloc_count(void) { return g_alloc_count.load(std::memory_order_relaxed); }
-
-int gar_hip_device_sizes(const gar_hip_solver *s, int64_t out[8]) {
-  if (!s || !out)
-    return fail(GAR_HIP_ERR_ARG, "bad argument");
-  out[0] = s->prob_doubles; out[1] = s->fac_doubles; out[2] = s->sol_doubles; out[3] = s->nc0;
-  out[4] = s->G0_off; out[5] = s->g0_off; out[6] = s->padded ? 1 : 0; out[7] = s->init_doubles;
-  return GAR_HIP_OK;
-}
-
-int gar_hip_packed_stage_dims(const gar_hip_solver *s, int t, int32_t out[5]) {
-  if (!s || !out || t < 0 || t > s->horizon)
-    return fail(GAR_HIP_ERR_ARG, "gar_hip_packed_stage_dims: bad argument");
-  std::copy(&s->user_dims5[5 * (size_t)t], &s->user_dims5[5 * (size_t)t] + 5, out);
-  return GAR_HIP_OK;
-}
-
-int gar_hip_device_record_format(const gar_hip_solver *s) {
-  if (!s)
-    return 0;
-  return (s->qr_packed ? GAR_HIP_FMT_QR_PACKED : 0) | (s->vxx_packed ? GAR_HIP_FMT_VXX_PACKED : 0) |
-         (s->fb_t2 ? GAR_HIP_FMT_FB_T2 : 0);
-}
+#include "gar_entry_io.hpp"
 
 } // extern "C"
