@@ -946,6 +946,46 @@ def test_terminal_knot_without_successor_dimension():
         s.close()
 
 
+def test_terminal_knot_without_successor_dimension_through_the_solver_classes(monkeypatch):
+    """the same problem shape through the host mirror's solver classes (gar_hip_upload_stage knot by knot, the
+    per-stage getters) and with the legs over two (virtual) devices behind one handle"""
+    from aligator_amd.gar import (ParallelRiccatiSolver, ProximalRiccatiSolver, lqrComputeKktError,
+                                  lqrInitializeSolution)
+    from aligator_amd.lqr import LqrKnot, LqrProblem
+    monkeypatch.setenv("GAR_EMU_DEVICES", "2")
+    nx, nu, N = 8, 4, 9
+    base = synth.generate_lq_problem(11, np.ones(nx), N, nx, nu, mode="W")
+    term = LqrKnot(nx, 0, 0, 0)
+    term.Q[...] = base.stages[-1].Q
+    term.q[...] = base.stages[-1].q
+    prob = LqrProblem(base.stages[:-1] + [term], nx)
+    prob.G0[...] = base.G0
+    prob.g0[...] = base.g0
+    _, _, ref = pc.oracle_serial(base, 1e-10)
+    ser = ProximalRiccatiSolver(prob, lib_path=EMU)
+    assert ser.kernel_name == "wave<8,4>"
+    ser.backward(1e-10)
+    sol = lqrInitializeSolution(prob)
+    ser.forward(*sol)
+    for a, b in zip(sol, ref):
+        assert pc.maxdiff(a, b) <= 1e-10 * pc.scale_of(ref)
+    assert ser.datas[N].ff.shape == (0,) and ser.datas[N].fb.shape == (0, nx)
+    assert ser.getFeedback(0).shape[1] == nx and max(lqrComputeKktError(prob, *sol, mueq=1e-10)) <= 1e-9
+    import ctypes as C
+    L = C.CDLL(EMU)
+    L.emu_set_device_count(2)
+    try:
+        par = ParallelRiccatiSolver(prob.copy(), 3, lib_path=EMU, devices=[0, 1])
+        assert par.kernel_name.startswith("wave_leg<8,4>")
+        par.backward(1e-10)
+        psol = lqrInitializeSolution(prob)
+        par.forward(*psol)
+        for a, b in zip(psol, ref):
+            assert pc.maxdiff(a, b) <= 1e-9 * pc.scale_of(ref)
+    finally:
+        L.emu_set_device_count(1)
+
+
 def test_behaviour_switches_through_the_api():
     """gar_hip_set_option: what the GAR_HIP_* environment variables choose can be chosen through the ABI (the
     reference's knobs are struct fields, parallel-solver.hpp:92-94); the call takes precedence over the environment,
