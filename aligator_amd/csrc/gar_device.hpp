@@ -46,7 +46,7 @@ __device__ __forceinline__ void wave_sync() {
 }
 // ---- LDS-DMA (gfx950 global_load_lds_dwordx4): HBM -> LDS without passing through registers ---------------------
 // one DMA piece: every active lane copies 16 bytes from its own source address to (wave-uniform) dst + 16 lane
-__device__ __forceinline__ void lean_dma16(const char *src_lane, char *dst_wave) {
+__device__ __forceinline__ void wave_dma16(const char *src_lane, char *dst_wave) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
                                    (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
@@ -64,7 +64,7 @@ __device__ __forceinline__ void lean_dma(const double *src, char *dst, int lane)
   for (int p = 0; p < PIECES; ++p) {
     const int left = BYTES - 1024 * p; // bytes of this piece and the ones behind it
     if (left >= 1024 || 16 * lane < left)
-      lean_dma16(s + 1024 * p, dst + 1024 * p);
+      wave_dma16(s + 1024 * p, dst + 1024 * p);
   }
 }
 // s_waitcnt with one field set (gfx9 encoding: vmcnt [3:0] | [15:14], expcnt [6:4], lgkmcnt [11:8])

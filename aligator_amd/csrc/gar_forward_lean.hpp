@@ -96,13 +96,13 @@ __global__ void __launch_bounds__(256) GAR_LEAN_BUDGET gar_forward_lean(MfmaFwdP
   // (past the end: a harmless re-read of the last stage -- every stage issues the same number of pieces)
   auto fill_fb = [&](int t) {
     const int tc = t < N ? t : N - 1;
-    lean_dma<L::FB_BYTES>(fac + P.slot(tc) * P.fac_rec + C::fFF, sl + L::oFB, lane);
+    wave_dma<L::FB_BYTES>(fac + P.slot(tc) * P.fac_rec + C::fFF, sl + L::oFB, lane);
   };
   auto fill_vx = [&](int t) { // value function of stage t + 1 (the terminal knot's when t + 1 >= N)
     const double *recn = (t + 1 < N) ? fac + P.slot(t + 1) * P.fac_rec : fac + P.fac_offN;
     const int oV = (t + 1 < N) ? C::fVxx : C::tVxx, ov = (t + 1 < N) ? C::fvx : C::tvx;
-    lean_dma<L::VX_BYTES>(recn + oV, sl + L::oVX, lane);
-    lean_dma<8 * NX>(recn + ov, sl + L::ovx, lane);
+    wave_dma<L::VX_BYTES>(recn + oV, sl + L::oVX, lane);
+    wave_dma<8 * NX>(recn + ov, sl + L::ovx, lane);
   };
   constexpr int FBP = L::FB_PIECES, VXP = L::VX_PIECES + 1; // vector-memory instructions per refill
   if (N > 0) {

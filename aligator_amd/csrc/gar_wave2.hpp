@@ -404,7 +404,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   [[maybe_unused]] const double *Fb = sm + C::oF - M::kA;
   if constexpr (FDMA) {
     if (t > 0)
-      lean_dma<8 * C::f_doubles>(recn + M::kA, reinterpret_cast<char *>(sm + C::oF), lane);
+      wave_dma<8 * C::f_doubles>(recn + M::kA, reinterpret_cast<char *>(sm + C::oF), lane);
   }
   // ---- operands of the vector recursion: vx'[4s+lk] (LDS), f[4s+lk] (this knot: L2 hit) ------
   double vxs[KS], fs[KS];
