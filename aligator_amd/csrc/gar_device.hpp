@@ -57,7 +57,7 @@ __device__ __forceinline__ void wave_dma16(const char *src_lane, char *dst_wave)
 // BYTES (a multiple of 16) from src to the LDS image dst, 1 KiB per instruction: exactly ceil(BYTES / 1024)
 // vector-memory instructions (the s_waitcnt arithmetic of the kernel counts on it)
 template <int BYTES>
-__device__ __forceinline__ void lean_dma(const double *src, char *dst, int lane) {
+__device__ __forceinline__ void wave_dma(const double *src, char *dst, int lane) {
   constexpr int PIECES = (BYTES + 1023) / 1024;
   const char *s = reinterpret_cast<const char *>(src) + 16 * lane;
 #pragma unroll
