@@ -1,21 +1,24 @@
 // gar_forward_lean.hpp -- the roll-out (computeInitial + forwardImpl, riccati-kernel.hxx:195-207, 314-377,
-// nc = nth = 0) cut to fit BESIDE a backward sweep: the pipelined sweep of gar_hip_set_pipeline runs the forward
-// sweep of one half of the batch while the backward sweep of the other half holds the chip.
+// nc = nth = 0) cut to fit BESIDE a backward sweep: the pipelined schedule of gar_hip_set_pipeline runs the forward
+// sweep of one half of the batch while the backward sweep of the other half holds the chip (gar_pipeline.hpp).
 //
-// gar_backward_wave<36,12> allocates 432 of a SIMD's 512 registers and ~17 KB of LDS per wave, and leaves 46 % of
-// its wave cycles waiting on the instruction it just issued; HBM is drawn at 0.54 of its peak.  A forward wave that
+// gar_backward_wave<36,12> allocates 432 of a SIMD's 512 registers and 18.5 KB of LDS per wave.  A forward wave that
 // fits in the remaining 80 registers shares the SIMD with it:
 //
 //  * one 256-thread workgroup = four independent waves, one problem each (no workgroup barrier anywhere);
 //  * the stage's factor record never passes through registers on its way in: `global_load_lds_dwordx4` (gfx950)
-//    copies [ff | fb] (13.9 KB, the fbT2 image as it lies in HBM) and the next stage's packed Vxx' | vx' (5.5 KB)
+//    copies [ff | fb] (13.9 KB, the fbT2 image as it lies in HBM) and the next stage's packed Vxx' | vx' (5.6 KB)
 //    straight into this wave's LDS slice, 1 KiB per instruction; each buffer is refilled for the NEXT stage the
 //    moment its rows have been consumed, so a whole stage (20 KB) is in flight per wave with no register cost;
 //  * rows come back with ds_read_b128 (lane = row, conflict-free) in the SAME order and with the SAME two
-//    accumulators as gar_forward_mfma: the solutions of the two kernels are bitwise identical;
-//  * the workgroup asks for more than half of a CU's LDS, so at most ONE such workgroup lives on a CU -- one forward
-//    wave per SIMD, never two (two would take the backward wave's registers) -- and 4 backward waves + 1 forward
-//    workgroup fill the CU's 160 KB exactly as planned by gar_hip.cpp (pipe_lds_plan).
+//    accumulators as gar_forward_mfma: the solutions of the two kernels are bitwise identical (66 registers);
+//  * the workgroup ASKS for more than half of a CU's LDS (85 KB; it uses 84), so at most ONE such workgroup lives on a
+//    CU -- one forward wave per SIMD, never two (two would take the backward wave's registers) -- and 4 backward waves
+//    + 1 forward workgroup fill the CU's 160 KB exactly (gar_pipeline.hpp: pipe_plan).
+//
+// Measured (profiles/r05_*): alone it is as fast as gar_forward_mfma to 0.5 % on the same records (the
+// roll-out's time is the memory system's); resident beside a backward sweep both slow down by what the other adds --
+// the two sweeps contend for the CU's vector-memory path, the pipelined schedule gains the tails only (+1 ... 3 %).
 #pragma once
 #include "gar_mfma.hpp"
 
