@@ -280,6 +280,82 @@ static void raw_c_abi_wide_shape() {
   }
 }
 
+// The pipelined sweep (gar_hip_set_pipeline, round 5) through the raw C ABI: a batch of three problems, plain then
+// pipelined (two call pairs in a row), solutions bit for bit; and the terminal knot as SolverProxDDP builds it
+// (nx2 = 0, solvers/proxddp/workspace.hxx:54-55): null A / f for that knot, the specialised kernels all the same, the
+// nx2 = nx problem's solution
+static void raw_c_abi_pipeline_and_terminal_knot() {
+  const uint nx = 8, nu = 4, horz = 6;
+  const int batch = 3;
+  std::printf("raw_c_abi_pipeline_and_terminal_knot (nx=%u, nu=%u, N=%u, batch %d)\n", nx, nu, horz, batch);
+  std::vector<LqrProblem> probs;
+  for (int b = 0; b < batch; ++b) {
+    std::mt19937 rng(100 + (unsigned)b);
+    probs.push_back(generate_problem(rng, VectorXs(nx, 0.3 * (b + 1)), horz, nx, nu));
+  }
+  std::vector<int32_t> dims5;
+  for (const LqrKnot &k : probs[0].stages) {
+    const int32_t d[5] = {(int)k.nx, (int)k.nu, (int)k.nc, (int)k.nx2, (int)k.nth};
+    dims5.insert(dims5.end(), d, d + 5);
+  }
+  std::vector<int32_t> dims_t0 = dims5;
+  dims_t0[5 * horz + 3] = 0; // the terminal knot with nx2 = 0
+  const size_t nX = (size_t)(horz + 1) * nx, nU = (size_t)horz * nu, nL = (size_t)nx + (size_t)horz * nx;
+  auto solve = [&](const std::vector<int32_t> &d5, bool null_terminal, int pipeline, std::vector<double> &out) {
+    gar_hip_solver *h = gar_hip_solver_create(0, (int)horz, d5.data(), (int)nx, batch, 1);
+    REQUIRE(h != nullptr);
+    if (!h)
+      return;
+    REQUIRE(std::string(gar_hip_kernel_name(h)).find("<8,4>") != std::string::npos);
+    for (int b = 0; b < batch; ++b) {
+      for (int t = 0; t <= (int)horz; ++t) {
+        const LqrKnot &k = probs[(size_t)b].stages[(size_t)t];
+        const bool nt = null_terminal && t == (int)horz;
+        REQUIRE(gar_hip_upload_stage(h, b, t, k.Q.data(), k.S.data(), k.R.data(), k.q.data(), k.r.data(),
+                                     nt ? nullptr : k.A.data(), k.B.data(), nt ? nullptr : k.f.data(), k.C.data(), k.D.data(),
+                                     k.d.data(), k.Gth.data(), k.Gx.data(), k.Gu.data(), k.Gv.data(), k.gamma.data()) == GAR_HIP_OK);
+      }
+      REQUIRE(gar_hip_set_init(h, b, probs[(size_t)b].G0.data(), probs[(size_t)b].g0.data()) == GAR_HIP_OK);
+    }
+    const int rc = gar_hip_set_pipeline(h, pipeline);
+    if (pipeline == 2 && batch >= 2 && std::string(gar_hip_kernel_name(h)) == "wave<8,4>")
+      REQUIRE(rc == GAR_HIP_OK && gar_hip_pipeline(h) == 2);
+    for (int rep = 0; rep < 2; ++rep) {
+      REQUIRE(gar_hip_backward_async(h, 1e-12) == GAR_HIP_OK);
+      REQUIRE(gar_hip_forward_async(h, nullptr) == GAR_HIP_OK);
+    }
+    REQUIRE(gar_hip_sync(h) == GAR_HIP_OK);
+    REQUIRE(gar_hip_num_failed(h) == 0);
+    out.assign((size_t)batch * (nX + nU + nL), 0.0);
+    for (int b = 0; b < batch; ++b) {
+      double *o = out.data() + (size_t)b * (nX + nU + nL);
+      REQUIRE(gar_hip_get_solution(h, b, o, o + nX, nullptr, o + nX + nU) == GAR_HIP_OK);
+    }
+    if (null_terminal) { // the terminal knot's gains: the caller's 0 rows -- nothing is written
+      double guard[2] = {-7.0, -7.0};
+      REQUIRE(gar_hip_get_gains(h, 0, (int)horz, guard, guard + 1, nullptr) == GAR_HIP_OK);
+      REQUIRE(guard[0] == -7.0 && guard[1] == -7.0);
+      int32_t pd[5];
+      REQUIRE(gar_hip_packed_stage_dims(h, (int)horz, pd) == GAR_HIP_OK && pd[3] == (int32_t)nx);
+    }
+    gar_hip_solver_destroy(h);
+  };
+  std::vector<double> plain, piped, term0;
+  solve(dims5, false, 0, plain);
+  solve(dims5, false, 2, piped);
+  solve(dims_t0, true, 0, term0);
+  REQUIRE(plain.size() == piped.size() && plain.size() == term0.size());
+  double d1 = 0.0, d2 = 0.0, sc = 1.0;
+  for (size_t i = 0; i < plain.size(); ++i) {
+    d1 = std::max(d1, std::abs(plain[i] - piped[i]));
+    d2 = std::max(d2, std::abs(plain[i] - term0[i]));
+    sc = std::max(sc, std::abs(plain[i]));
+  }
+  std::printf("  |plain - pipelined| %.1e   |nx2 = nx - nx2 = 0| %.1e (scale %.1e)\n", d1, d2, sc);
+  REQUIRE(d1 == 0.0);
+  REQUIRE(d2 <= 1e-12 * sc);
+}
+
 // tests/gar/riccati.cpp:141-155 ("test dense solver"): KKT error <= 1e-8, and the same trajectory as
 // the Riccati recursion
 static void dense_solver() {
@@ -426,6 +502,7 @@ int main() {
   padded_shape(12, 6, "12,8");
   padded_shape(10, 3, "12,4");
   raw_c_abi_wide_shape();
+  raw_c_abi_pipeline_and_terminal_knot();
   error_behaviour();
   std::printf(g_failed ? "%d REQUIRE(s) FAILED\n" : "all passed\n", g_failed);
   return g_failed ? 1 : 0;
