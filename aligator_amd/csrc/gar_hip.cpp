@@ -124,11 +124,18 @@ std::map<std::string, std::string> &option_overrides() {
   return o;
 }
 const char *gar_option(const char *name) {
+  // (the value is copied out under the lock into a per-thread slot: a concurrent gar_hip_set_option cannot pull the
+  // string from under the caller; eight slots cover every use that holds more than one option at a time)
+  thread_local std::string slot[8];
+  thread_local unsigned next = 0;
   {
     std::lock_guard<std::mutex> g(option_mutex());
     auto it = option_overrides().find(name);
-    if (it != option_overrides().end())
-      return it->second.c_str(); // (entries are never erased while in use: an unset stores "" -> treated as unset)
+    if (it != option_overrides().end()) {
+      std::string &v = slot[next++ & 7u];
+      v = it->second;
+      return v.c_str();
+    }
   }
   return std::getenv(name);
 }

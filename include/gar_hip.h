@@ -393,8 +393,8 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
  * entry points of their own here, gar_hip_set_refinement / gar_hip_set_condensed_backward_ok); what chooses between
  * this library's kernel families and measured alternatives is a set of named switches, each of which can be given in
  * the ENVIRONMENT (GAR_HIP_<NAME>) or through this call, which takes precedence (process-wide; value NULL: back to the
- * environment; `name` with or without the GAR_HIP_ prefix).  Read when a solver is CREATED unless noted.  Not to be
- * called concurrently with solver creation.
+ * environment; `name` with or without the GAR_HIP_ prefix).  Read when a solver is CREATED unless noted (a change
+ * does not reach solvers that exist already); thread-safe.
  *   BACKWARD = wave | wg4 | pair   serial unconstrained family: one wave per problem (default when batch > #CUs),
  *                                  one 4-wave workgroup per problem (default otherwise), two waves per problem
  *   WIDE = single | generic-forward   the (56, 24) family: one wave per problem / the any-dimension roll-out
