@@ -445,7 +445,7 @@ def check_bulk_gains(prob, mueq, lib_path=None, num_legs=1, devices=None):
     return s
 
 
-def check_cycle_append_ring(lib_path=None, nx=8, nu=4, horz=5, cycles=8, family=None, dense=False):
+def check_cycle_append_ring(lib_path=None, nx=8, nu=4, horz=5, cycles=8, family=None, dense=False, pipeline=False):
     """MPC cycling as a ring (proximal-riccati.hxx:79-86, tests/mpc-cycle.cpp): after cycleAppend only the
     NEW last-but-one knot is uploaded -- every other knot must still be where the kernels look for it,
     through more cycles than there are stages (the ring wraps) -- and the sweep must match the oracle on
@@ -461,6 +461,19 @@ def check_cycle_append_ring(lib_path=None, nx=8, nu=4, horz=5, cycles=8, family=
         s = BatchedRiccatiSolver(dims, probs[0].nc0, batch=2, lib_path=lib_path, dense=dense)
         s.upload(probs)
         mu = 1e-10
+        if pipeline:   # the pipelined schedule (gar_hip_set_pipeline): the ring offset reaches gar_forward_lean too
+            s.set_pipeline(2)
+            plain_backward, plain_forward = s.backward, s.forward
+
+            def _bw(m):
+                s.backward_async(m)
+                return True
+
+            def _fw():
+                s.forward_async()
+                s.sync()
+                return s.num_failed() == 0
+            s.backward, s.forward = _bw, _fw
         assert s.backward(mu) and s.forward()
         for c in range(cycles):
             s.cycle_append(dims[0])

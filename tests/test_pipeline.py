@@ -136,6 +136,14 @@ def test_pipelined_sweep_reports_failed_factorisations(emu):
     s.close()
 
 
+def test_pipelined_sweep_on_the_mpc_ring(emu):
+    """cycleAppend under the pipelined schedule: the records never move, logical stage t lives in slot (t + ring0)
+    mod N -- in gar_forward_lean's DMA addresses as in the backward sweep's -- through more cycles than stages, against
+    the oracle on the caller's rotated problems (tests/mpc-cycle.cpp; proximal-riccati.hxx:79-86)"""
+    s = pc.check_cycle_append_ring(emu, nx=8, nu=4, horz=4, cycles=6, family="wave", pipeline=True)
+    assert s.kernel_name == "wave<8,4>" and s.pipeline == 2
+
+
 def test_pipeline_is_refused_where_it_does_not_apply(emu):
     from aligator_amd.gar import BatchedRiccatiSolver
     nx, nu, N = 8, 4, 8
