@@ -318,6 +318,7 @@ struct gar_hip_solver {
   // forward sweep of a half is gar_forward_lean, which fits in the registers and the LDS the backward wave of the
   // OTHER half leaves free on every SIMD (gar_forward_lean.hpp): B(h0) | F(h0) + B(h1) | F(h1) + B'(h0) | ...
   int pipe_halves = 0;                 // 0: off
+  int pipe_requested = 0;              // what the caller last asked gar_hip_set_pipeline for (a rebuild re-validates it)
   void (*lean_fwd_kernel)(gar::MfmaFwdParams, int) = nullptr;
   void (*wave_half_kernel)(gar::MfmaParams, int) = nullptr; // the backward sweep under its half-batch launch name
   size_t lean_fwd_used = 0;            // LDS the kernel uses
@@ -1588,6 +1589,8 @@ double *gar_hip_device_factors(gar_hip_solver *s) {
   if (s && s->fold) { // the caller-visible records of a folded solver are formed on request
     GAR_GUARD(s);
     (void)ensure_expanded(s);
+  } else if (s && s->pipe_forked) { // (a pipelined sweep: the caller's stream is ordered behind it before the pointer leaves)
+    GAR_GUARD(s);
   }
   return s ? s->d_fac : nullptr;
 }
@@ -1663,7 +1666,7 @@ int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
   if (halves <= 1) {
-    s->pipe_halves = 0;
+    s->pipe_halves = s->pipe_requested = 0;
     return GAR_HIP_OK;
   }
   if (halves != 2)
@@ -1702,7 +1705,7 @@ int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
     }
     HIP_TRY(hipEventCreateWithFlags(&s->pipe_evFork, hipEventDisableTiming));
   }
-  s->pipe_halves = 2;
+  s->pipe_halves = s->pipe_requested = 2;
   return GAR_HIP_OK;
 }
 int gar_hip_pipeline(const gar_hip_solver *s) { return s ? s->pipe_halves : 0; }
@@ -2543,9 +2546,22 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
   free_device(s);
   s->staged = s->dirty = false;
   s->user_dims5 = nd;
+  // the pipelined schedule belongs to the kernel family that was bound: it is re-validated against the new one (its
+  // half streams and events are kept), and silently off when the new shape has no such family
+  const bool was_piped = s->pipe_requested == 2;
+  s->pipe_halves = 0;
+  s->pipe_forked = false;
+  s->pipe_evB_valid[0] = s->pipe_evB_valid[1] = false;
   if (int rc = configure(s))
     return rc;
-  return allocate(s);
+  if (int rc = allocate(s))
+    return rc;
+  if (was_piped) { // (kept as the caller's wish even where this shape refuses it: a later rebuild may serve it again)
+    if (gar_hip_set_pipeline(s, 2) != GAR_HIP_OK)
+      s->pipe_halves = 0;
+    s->pipe_requested = 2;
+  }
+  return GAR_HIP_OK;
 }
 
 

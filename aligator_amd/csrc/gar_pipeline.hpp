@@ -45,8 +45,11 @@ void pipe_autojoin(const gar_hip_solver *s) {
     (void)pipe_join(const_cast<gar_hip_solver *>(s));
 }
 // ... and the half streams behind what the caller's stream holds (uploads, a previous unpipelined sweep)
-int pipe_fork(gar_hip_solver *s) {
-  if (s->pipe_forked)
+// (`again`: a sweep re-records the fork even while the halves are forked -- what the caller enqueued on the solver's
+// stream since the first fork, a producer kernel or a copy into the records, is then waited for as gar_hip.h
+// promises; an event on a stream that holds nothing new is complete at once, so the halves keep overlapping)
+int pipe_fork(gar_hip_solver *s, bool again = false) {
+  if (s->pipe_forked && !again)
     return GAR_HIP_OK;
   HIP_TRY(hipEventRecord(s->pipe_evFork, s->stream));
   for (int h = 0; h < 2; ++h)
@@ -67,7 +70,7 @@ int pipe_backward(gar_hip_solver *s, double mueq) {
     if (int rc = commit(s))
       return rc;
   }
-  if (int rc = pipe_fork(s))
+  if (int rc = pipe_fork(s, /*again=*/true))
     return rc;
   const gar::MfmaParams M0 = make_mfma_params(s, mueq);
   const gar::GenericParams G0 = make_params(s, mueq);

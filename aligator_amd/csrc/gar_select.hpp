@@ -194,6 +194,13 @@ void select_kernel(gar_hip_solver *s) {
   s->wave_kernel = nullptr;
   s->wave_coupled_kernel = nullptr;
   s->wave_bk_kernel = nullptr;
+  // (the pipelined sweep's kernels belong to the family bound below: a rebuild for other dimensions must not keep
+  // launching the old shape's half-batch kernels over the new records)
+  s->lean_fwd_kernel = nullptr;
+  s->wave_half_kernel = nullptr;
+  s->lean_fwd_used = 0;
+  s->lean_fwd_lds_bytes = 0;
+  s->wave_lds_doubles_small = 0;
   s->wave_fused_init = false;
   s->wave_block_threads = 64;
   s->fb_t2 = false;

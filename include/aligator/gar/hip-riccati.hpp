@@ -105,6 +105,7 @@ private:
     h_ = gar_hip_multi_create((int)devices_.size(), devices_.data(), (int)st.size() - 1, dims5.data(),
                               (int)problem_->nc0(), 1, num_legs_);
     if (!h_) ALIGATOR_RUNTIME_ERROR(gar_hip_last_error());   // no HIP device: there is no CPU fallback
+    blocks_.reserve(16 * st.size());                    // (backward() must not allocate: ALIGATOR_NOMALLOC_SCOPED covers every call)
     map_gains();
   }
   // ff_[t] / fb_[t]: Eigen::Map views onto the library's pinned host buffer (solver-owned host memory,

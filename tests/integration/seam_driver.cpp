@@ -200,17 +200,19 @@ int main() {
     const double dx = diff(sr.xs, sh.xs), du = diff(sr.us, sh.us), dv = diff(sr.vs, sh.vs), dl = diff(sr.lbdas, sh.lbdas);
     const auto &hs = static_cast<gar::HipRiccatiSolver &>(*hip);
     const char *name = hs.kernelName();
-    // unconstrained: 1e-8 of the solution's scale.  Constrained knots with a small mu carry multipliers of order
-    // 1 / mu whose trailing digits no two factorisations share (here: the reference's leg-parallel solve against
-    // the folded leg kernels); the reference's own bar at this size is 1e-6 (tests/gar/riccati.cpp:138): x, u to
-    // 1e-5 of their scale, v and lbd to 1e-5 of theirs
+    // 1e-8 of their scale for the solution and for EVERY stage's gains, in every case but one: constrained knots folded
+    // into legs with a small mu carry multipliers of order 1 / mu whose trailing digits no two factorisations share (the
+    // reference's leg-parallel solve against the folded leg kernels); there the reference's own bar at this size is
+    // 1e-6 (tests/gar/riccati.cpp:138) and x, u are held to 1e-5 of their scale, v and lbd to 1e-5 of theirs -- the
+    // gains stay at 1e-8
     double xs_scale = 1.0;
     for (const auto &x : sr.xs)
       for (Eigen::Index j = 0; j < x.size(); ++j)
         xs_scale = std::max(xs_scale, std::abs(x(j)));
-    const double tol = c.nc > 0 ? 1e-5 : 1e-8;
+    const bool folded = std::string(name).find("fold") != std::string::npos;
+    const double tol = folded ? 1e-5 : 1e-8, tol_gains = 1e-8;
     const bool ok = hs.numDevices() == c.ndev && gr.size() == gh.size() && std::max(dx, du) <= tol * (c.nc > 0 ? xs_scale : scale) &&
-                    std::max(dv, dl) <= tol * scale && dg <= tol * gs && std::string(name).find(c.want) != std::string::npos;
+                    std::max(dv, dl) <= tol * scale && dg <= tol_gains * gs && std::string(name).find(c.want) != std::string::npos;
     std::printf("nx=%u nu=%u nc=%u N=%u legs=%d devices=%d kernel %-22s |x| %.1e |u| %.1e |v| %.1e |lbd| %.1e |gains| %.1e (rel %.1e)  %s\n", c.nx, c.nu,
                 c.nc, c.N, c.legs, c.ndev, name, dx, du, dv, dl, dg, dg / gs, ok ? "ok" : "MISMATCH");
     bad += !ok;

@@ -144,6 +144,56 @@ def test_pipelined_sweep_on_the_mpc_ring(emu):
     assert s.kernel_name == "wave<8,4>" and s.pipeline == 2
 
 
+def test_dims_changing_cycle_append_under_the_pipeline(emu):
+    """A cycleAppend whose knot has OTHER dimensions rebuilds layout and kernel family (gar_hip_cycle_append's rebuild
+    path): the pipelined schedule must not keep launching the old shape's half-batch kernels over the new records --
+    it is re-validated against the new family (off here: the mixed-dimension problem runs on the any-dimension
+    kernels) and the async call pair gives the oracle's solution.  Then a second rebuild back to a uniform shape, where
+    the pipeline the caller asked for comes back on."""
+    from aligator_amd.gar import BatchedRiccatiSolver, lqrInitializeSolution
+    from oracle import oracle as ora
+    nx, nu, N, batch, mu = 8, 4, 5, 3, 1e-10
+    rng = np.random.default_rng(5)
+    probs = [synth.generate_lq_problem(rng, rng.standard_normal(nx), N, nx, nu, mode="W") for _ in range(batch)]
+    s = BatchedRiccatiSolver([k.dims for k in probs[0].stages], nx, batch=batch, lib_path=emu)
+    s.upload(probs)
+    s.set_pipeline(2)
+    s.backward_async(mu)
+    s.forward_async()
+    s.sync()
+    assert s.pipeline == 2 and s.kernel_name == "wave<8,4>"
+
+    def check(expect_pipeline, expect_kernel):
+        s.upload(probs)                     # a rebuild does not carry resident problem data over
+        s.backward_async(mu)
+        s.forward_async()
+        s.sync()
+        assert s.num_failed() == 0
+        assert s.pipeline == expect_pipeline and s.kernel_name == expect_kernel, (s.pipeline, s.kernel_name)
+        for b, p in enumerate(probs):
+            op = ora.Problem.from_knots(p.stages, p.G0, p.g0)
+            osol = ora.ProximalRiccatiSolver(op)
+            osol.backward(mu)
+            ref = lqrInitializeSolution(p)
+            osol.forward(*ref)
+            scale = max(1.0, max(float(np.max(np.abs(a))) for A in ref for a in A if a.size))
+            for A, B in zip(s.solution(b), ref):
+                assert pc.maxdiff(A, B) <= 1e-9 * scale, b
+
+    odd = synth.generate_knot(rng, nx, 3, mode="W")            # nu = 3 on the new last-but-one knot
+    s.cycle_append(odd.dims)
+    for p in probs:
+        k = synth.generate_knot(rng, nx, 3, mode="W")
+        p.stages[:N] = p.stages[1:N] + [k]
+    check(0, "generic")
+    for _ in range(N):                                          # ... until every knot is (8, 4) again
+        s.cycle_append(probs[0].stages[0].dims if probs[0].stages[0].dims[1] == nu else (nx, nu, 0, nx, 0))
+        for p in probs:
+            p.stages[:N] = p.stages[1:N] + [synth.generate_knot(rng, nx, nu, mode="W")]
+    check(2, "wave<8,4>")
+    s.close()
+
+
 def test_pipeline_is_refused_where_it_does_not_apply(emu):
     from aligator_amd.gar import BatchedRiccatiSolver
     nx, nu, N = 8, 4, 8
