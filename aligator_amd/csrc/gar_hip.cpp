@@ -1292,6 +1292,12 @@ gar_hip_solver *create_impl(int device, int horizon, const int32_t *dims5, int n
     delete s;
     return nullptr;
   }
+  { // the default schedule is the library's own choice (GAR_HIP_PIPELINE = auto | 0 | 2; gar_hip_set_pipeline overrides)
+    const char *pl = gar_option("GAR_HIP_PIPELINE");
+    const int want = pl ? (pl[0] == '0' ? 0 : pl[0] == '2' ? 2 : -1) : -1;
+    if (want != 0 && gar_hip_set_pipeline(s, want) != GAR_HIP_OK)
+      s->pipe_halves = s->pipe_requested = 0; // (an explicit 2 on a shape without the family: plain, not an error at create)
+  }
   return s;
 }
 } // namespace
@@ -1639,7 +1645,7 @@ int gar_hip_set_option(const char *name, const char *value) {
     key = "GAR_HIP_" + key;
   static const char *known[] = {"BACKWARD", "WIDE", "LEG_WAVES", "CONDENSED", "CONDENSED_REDUCED", "CONDENSED_CR", "LEGS",
                                 "FOLD", "SEG_LEGS", "INIT", "FORCE_GENERIC", "PAD", "SPD_ACCEPT", "STAGE_NT", "EAGER",
-                                "MULTI_EXCHANGE", "PIPE_PRIORITY", "FORWARD"};
+                                "MULTI_EXCHANGE", "PIPE_PRIORITY", "FORWARD", "PIPELINE"};
   bool ok = false;
   for (const char *k : known)
     ok |= key == std::string("GAR_HIP_") + k;
@@ -1661,18 +1667,49 @@ const char *gar_hip_get_option(const char *name) {
   return gar_option(key.c_str());
 }
 
+namespace {
+bool pipe_eligible(const gar_hip_solver *s) {
+  return !(s->multi || s->world > 1 || s->num_legs != 1 || s->nth0 != 0 || s->batch < 2 || !s->wave_kernel || !s->lean_fwd_kernel ||
+           !s->wave_half_kernel || s->wave_coupled_kernel || s->wave_block_threads != 64 || s->waves_per_block != 1 || !s->vxx_packed ||
+           s->dense);
+}
+// The library's own choice of schedule (GAR_HIP_PIPELINE = auto, the default): the pipelined sweep pays by the tails
+// it hides -- the forward sweep of one half starts while the other half's backward sweep still runs -- and only once
+// EACH half fills every SIMD of the chip with a backward wave (measured, round 5: +0.4 ... +3.7 % at 4 096 problems on
+// 256 CUs over four boxes, -0.2 % on one; below two full waves of problems per half the plain schedule's whole-chip
+// launches win).  So: 2 halves iff the solver is eligible and batch >= 2 x (4 SIMDs x #CUs); plain otherwise.
+int pipe_auto_halves(const gar_hip_solver *s) {
+  if (!pipe_eligible(s))
+    return 0;
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
+  if (cus <= 0) // (a runtime that does not know: the MI355X's count)
+    cus = 256;
+  return s->batch >= 8 * cus ? 2 : 0;
+}
+} // namespace
+
 int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
   GAR_GUARD(s); // (orders the caller's stream behind anything the half streams still hold)
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  bool automatic = false;
+  if (halves < 0) { // the library's choice: never an error
+    automatic = true;
+    halves = pipe_auto_halves(s);
+    if (halves <= 1) {
+      s->pipe_halves = 0;
+      s->pipe_requested = -1;
+      return GAR_HIP_OK;
+    }
+  }
   if (halves <= 1) {
     s->pipe_halves = s->pipe_requested = 0;
     return GAR_HIP_OK;
   }
   if (halves != 2)
     return fail(GAR_HIP_ERR_ARG, "gar_hip_set_pipeline: 0 (off) or 2 (two half-batches)");
-  if (s->multi || s->world > 1 || s->num_legs != 1 || s->nth0 != 0 || s->batch < 2 || !s->wave_kernel || !s->lean_fwd_kernel ||
-      !s->wave_half_kernel || s->wave_coupled_kernel || s->wave_block_threads != 64 || s->waves_per_block != 1 || !s->vxx_packed || s->dense)
+  if (!pipe_eligible(s))
     return fail(GAR_HIP_ERR_UNSUPPORTED, "pipelined sweep: serial, unconstrained, unparameterised batches (>= 2 problems) "
                                          "on the one-wave-per-problem kernel family only (this solver runs " +
                                              s->kernel_name + ")");
@@ -1705,7 +1742,8 @@ int gar_hip_set_pipeline(gar_hip_solver *s, int halves) {
     }
     HIP_TRY(hipEventCreateWithFlags(&s->pipe_evFork, hipEventDisableTiming));
   }
-  s->pipe_halves = s->pipe_requested = 2;
+  s->pipe_halves = 2;
+  s->pipe_requested = automatic ? -1 : 2;
   return GAR_HIP_OK;
 }
 int gar_hip_pipeline(const gar_hip_solver *s) { return s ? s->pipe_halves : 0; }
@@ -2548,7 +2586,7 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
   s->user_dims5 = nd;
   // the pipelined schedule belongs to the kernel family that was bound: it is re-validated against the new one (its
   // half streams and events are kept), and silently off when the new shape has no such family
-  const bool was_piped = s->pipe_requested == 2;
+  const int wanted = s->pipe_requested; // 2: the caller's explicit wish; -1: the library's own choice; 0: off
   s->pipe_halves = 0;
   s->pipe_forked = false;
   s->pipe_evB_valid[0] = s->pipe_evB_valid[1] = false;
@@ -2556,10 +2594,10 @@ int gar_hip_cycle_append(gar_hip_solver *s, const int32_t d[5]) {
     return rc;
   if (int rc = allocate(s))
     return rc;
-  if (was_piped) { // (kept as the caller's wish even where this shape refuses it: a later rebuild may serve it again)
-    if (gar_hip_set_pipeline(s, 2) != GAR_HIP_OK)
+  if (wanted != 0) { // (kept as the caller's wish even where this shape refuses it: a later rebuild may serve it again)
+    if (gar_hip_set_pipeline(s, wanted) != GAR_HIP_OK)
       s->pipe_halves = 0;
-    s->pipe_requested = 2;
+    s->pipe_requested = wanted;
   }
   return GAR_HIP_OK;
 }

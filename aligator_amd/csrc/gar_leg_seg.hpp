@@ -77,12 +77,12 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
   const double *rec1 = prob + P.in_off0 + P.slot(t_first) * P.in_rec;
   if (wave == 0) {
     WaveStage<NX, NU> S;
-    pair_load<NX, NU, 0>(rec1, L, S);
+    pair_load<NX, NU, 0>(rec1, L, S, lane);
     for (int t = t_first; t >= t_beg; --t)
       pair_stage<NX, NU, 0>(P, sm, prob, fac, t, lane, L, S, failed);
   } else {
     WaveStage<NX, NU> S;
-    pair_load<NX, NU, 1>(rec1, L, S);
+    pair_load<NX, NU, 1>(rec1, L, S, lane);
     for (int t = t_first; t >= t_beg; --t)
       pair_stage<NX, NU, 1>(P, sm, prob, fac, t, lane, L, S, failed);
   }

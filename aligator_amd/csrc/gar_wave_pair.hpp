@@ -24,9 +24,33 @@
 
 namespace gar {
 
+// Wide F loads (round 6).  The contraction index of P = V'F and H = W + F^T P -- the NEXT state's index, the rows of
+// F = [A | B] -- is free to be relabelled: MFMA k-step s, lane group lk may stand for ANY row as long as both operands
+// of a product agree.  With row(s, lk) = KS lk + s instead of 4 s + lk a lane's KS operand values of one tile column
+// are KS CONTIGUOUS doubles of a column of the column-major knot block: KS / 2 16-byte loads (global_load_dwordx4)
+// instead of KS 8-byte ones -- 35 instead of 70 load instructions for wave 0 at (56, 24), 21 instead of 42 for wave 1,
+// on a wave whose end-of-stage burst of ~100 loads behind ~40 record stores is what it waits for (gfx9: ONE in-order
+// counter of 63 outstanding memory instructions).  Everything indexed by the next state follows the same relabelling
+// pos -> row: pos = 4 s + lk (the position the hardware's C/D layout gives the accumulators) holds row
+// pi(pos) = KS (pos & 3) + (pos >> 2): the rows of V' read as the A operand of P (so P comes out with its rows in
+// position order and feeds H unchanged), vx' and f in the vector part, the rows of B as the A operand of Aff, the
+// rows of Aff / yff on their way out.  Results: the same sums in the same order per entry (the k-steps visit the
+// rows in another order: last-digit differences against the 8-byte build, none against the record layout).
+#ifndef GAR_PAIR_WIDE_F
+#define GAR_PAIR_WIDE_F 1
+#endif
+#ifndef GAR_PAIR_ORDER
+#define GAR_PAIR_ORDER 1
+#endif
+
 template <int NX, int NU> struct PairCfg {
   using C = WaveCfg<NX, NU, 0>;
   static constexpr int SPLIT = C::TW / 2;
+  // (the wide shapes only: their records carry fb row-major; an even number of k-steps keeps every piece 16-byte aligned)
+  static constexpr bool PX = GAR_PAIR_WIDE_F && MfmaCfg<NX, NU, 0>::WIDE && (C::KS % 2 == 0) && (NX % 4 == 0);
+  // next-state row that k-step s, lane group lk stands for / that accumulator position pos holds
+  __host__ __device__ static constexpr int krow(int s, int lk) { return PX ? C::KS * lk + s : 4 * s + lk; }
+  __host__ __device__ static constexpr int prow(int pos) { return PX ? C::KS * (pos & 3) + (pos >> 2) : pos; }
   static constexpr int oHq = (C::total + 1) & ~1;          // [qhat; rhat], one entry per index
   static constexpr int oFlag2 = oHq + ((C::NW + 1) & ~1);  // verdict of the factorisation (int)
   static constexpr int total = oFlag2 + 2;
@@ -36,8 +60,29 @@ template <int NX, int NU> struct PairCfg {
 // knot t's operands for wave W: F tile columns it multiplies with (all of them for wave 0: H(ti, tj)
 // needs F(:, ti) for every ti >= tj), the Hessian tiles of its own tile columns
 template <int NX, int NU, class LANE>
-__device__ __forceinline__ void pair_load_F(const double *rec, const LANE &L, WaveStage<NX, NU> &S, int t) {
+__device__ __forceinline__ void pair_load_F(const double *rec, const LANE &L, WaveStage<NX, NU> &S, int t, int lane) {
   using C = WaveCfg<NX, NU>;
+  using PC = PairCfg<NX, NU>;
+  if constexpr (PC::PX) {
+    // rows KS lk .. KS lk + KS - 1 of column 16 t + li: KS / 2 pieces of 16 bytes
+    using M = MfmaCfg<NX, NU, 0>;
+    const int li = lane & 15, lk = lane >> 4;
+    const int col = (16 * t + li) < C::NW ? (16 * t + li) : C::NW - 1;
+    const unsigned lb = 8u * (unsigned)(M::kA + (WaveLane<NX, NU>::fo_in(t) ? li : col) * NX + C::KS * lk);
+    const double *base = rec + (WaveLane<NX, NU>::fo_in(t) ? 16 * t * NX : 0);
+#pragma unroll
+    for (int s = 0; s < C::KS; s += 2) {
+      const double2_t v = *reinterpret_cast<const double2_t *>(reinterpret_cast<const char *>(base + s) + lb);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (s + e < 4 * C::KSF)
+          S.Fo[t][(s + e) >> 2][(s + e) & 3] = v[e];
+        else
+          S.FoT[t][s + e - 4 * C::KSF] = v[e];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < C::KS; ++s) {
     const double v = WaveLane<NX, NU>::fo_in(t) ? ldg_b(rec, 16 * t * NX + 4 * s, L.fo0) : ldg_b(rec, 4 * s, L.foX);
@@ -63,19 +108,39 @@ __device__ __forceinline__ void pair_load_H(const double *rec, const LANE &L, Wa
   }
 }
 template <int NX, int NU, int W, class LANE>
-__device__ __forceinline__ void pair_load(const double *rec, const LANE &L, WaveStage<NX, NU> &S) {
+__device__ __forceinline__ void pair_load(const double *rec, const LANE &L, WaveStage<NX, NU> &S, int lane) {
   using C = WaveCfg<NX, NU>;
   using PC = PairCfg<NX, NU>;
+#if GAR_PAIR_ORDER
+  // in the order the next stage consumes them (loads return in order: its first products wait for the first pieces
+  // only): tile columns from the last one down -- F(:, tj) feeds P(:, tj), then H(ti, tj), ti = tj .., wants F(:, ti)
+  // and its Hessian tile
+  bool have[C::TW] = {};
+#pragma unroll
+  for (int tj = C::TW - 1; tj >= 0; --tj) {
+    if (PC::owner(tj) != W)
+      continue;
+#pragma unroll
+    for (int ti = tj; ti < C::TW; ++ti) {
+      if (!have[ti]) {
+        pair_load_F<NX, NU>(rec, L, S, ti, lane);
+        have[ti] = true;
+      }
+      pair_load_H<NX, NU>(rec, L, S, ti, tj);
+    }
+  }
+#else
 #pragma unroll
   for (int t = 0; t < C::TW; ++t)
     if (!(W == 1 && t < PC::SPLIT))
-      pair_load_F<NX, NU>(rec, L, S, t);
+      pair_load_F<NX, NU>(rec, L, S, t, lane);
 #pragma unroll
   for (int ti = 0; ti < C::TW; ++ti)
 #pragma unroll
     for (int tj = 0; tj <= ti; ++tj)
       if (PC::owner(tj) == W)
         pair_load_H<NX, NU>(rec, L, S, ti, tj);
+#endif
 }
 
 template <int NX, int NU, int W>
@@ -116,12 +181,12 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   double vxs[KS], fs[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s)
-    vxs[s] = vn[4 * s + lk];
+    vxs[s] = PC::PX ? vn[KS * lk + s] : vn[4 * s + lk];
   {
-    const unsigned lkb = 8u * (unsigned)lk;
+    const unsigned lkb = 8u * (unsigned)(PC::PX ? KS * lk : lk);
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      fs[s] = ldg_b(rec, M::kf + 4 * s, lkb);
+      fs[s] = ldg_b(rec, M::kf + (PC::PX ? s : 4 * s), lkb);
   }
   double qrv[TW]; // [q; r] entries of this wave's columns: issued here, used after the products
 #pragma unroll
@@ -144,8 +209,9 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
       const double bq = S.fo(tj, s);
 #pragma unroll
       for (int tm = 0; tm < TX; ++tm) {
-        const int ic = (16 * tm + li) < NX ? (16 * tm + li) : NX - 1;
-        Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[ic * PK + 4 * s + lk], bq, Pt[tm], 0, 0, 0);
+        // (PX: the row of V' whose product lands on accumulator position 16 tm + li, the column of k-step s)
+        const int ic = (16 * tm + li) < NX ? PC::prow(16 * tm + li) : NX - 1;
+        Pt[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[ic * PK + PC::krow(s, lk)], bq, Pt[tm], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -170,12 +236,17 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   for (int ti = 0; ti < TX; ++ti)
 #pragma unroll
     for (int s = 0; s < KU; ++s)
-      Bop[ti][s] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * s * NX + 16 * ti, L.bop0) : ldg_b(rec, 4 * s * NX, L.bopX);
+      if constexpr (PC::PX) { // B(pi(16 ti + li), 4 s + lk): the row whose Aff lands on accumulator position 16 ti + li
+        const int p = 16 * ti + li, row = p < NX ? PC::prow(p) : NX - 1;
+        Bop[ti][s] = ldg_b(rec, M::kB + 4 * s * NX, 8u * (unsigned)(lk * NX + row));
+      } else {
+        Bop[ti][s] = WaveLane<NX, NU>::x_in(ti) ? ldg_b(rec, 4 * s * NX + 16 * ti, L.bop0) : ldg_b(rec, 4 * s * NX, L.bopX);
+      }
   double fyf[TX];
 #pragma unroll
   for (int ti = 0; ti < TX; ++ti)
     if (PC::owner(ti) == W) {
-      const int i = 16 * ti + li, ic = i < NX ? i : NX - 1;
+      const int i = 16 * ti + li, ic = i < NX ? PC::prow(i) : NX - 1;
       fyf[ti] = ldg_b(rec, M::kf, 8u * (unsigned)ic);
     }
   GAR_PMARK(1)
@@ -345,7 +416,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
       const double yf = fyf[ti] + rows_sum(a, lane);
       const double vxv = hqv[ic] + rows_sum(c, lane);
       if (lk == 0 && i < NX) {
-        out[M::fFF + NK + i] = yf;
+        out[M::fFF + NK + PC::prow(i)] = yf; // (PX: position i holds next-state row pi(i); vx is indexed by THIS state)
         out[ovx + i] = vxv;
         vn[i] = vxv;
       }
@@ -378,7 +449,9 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
         if (16 * ti + 4 * r < NX) {
           if (i < NX && j < NX) {
             const double v = ti < C::KSF ? S.Fo[tj][ti < C::KSF ? ti : 0][r] : accT[r];
-            if (WIDE)
+            if (PC::PX) // position 16 ti + 4 r + lk holds row KS lk + 4 ti + r
+              stg_b(out, M::fFB + (NK + 4 * ti + r) * NX + 16 * tj, 8u * (unsigned)(KS * lk * NX + li), v);
+            else if (WIDE)
               stg_b(out, M::fFB + (NK + 16 * ti + 4 * r) * NX + 16 * tj, fbrm, v);
             else
               stg_b(out, M::fFB + 8 * tj * 2 * NR + 2 * (NK + 16 * ti + 4 * r), L.fbl, v);
@@ -417,7 +490,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
     }
   }
   GAR_PMARK(10)
-  pair_load<NX, NU, W>(recn, L, S); // knot t-1 into the registers this stage released
+  pair_load<NX, NU, W>(recn, L, S, lane); // knot t-1 into the registers this stage released
   GAR_PMARK(11)
   __syncthreads(); // (4) V, vx complete
   GAR_PMARK(12)
@@ -474,12 +547,12 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
   // carry the union of both waves' state through either path)
   if (wave == 0) {
     WaveStage<NX, NU> S;
-    pair_load<NX, NU, 0>(recN1, L, S);
+    pair_load<NX, NU, 0>(recN1, L, S, lane);
     for (int t = N - 1; t >= 0; --t)
       pair_stage<NX, NU, 0>(P, sm, prob, fac, t, lane, L, S, failed);
   } else {
     WaveStage<NX, NU> S;
-    pair_load<NX, NU, 1>(recN1, L, S);
+    pair_load<NX, NU, 1>(recN1, L, S, lane);
     for (int t = N - 1; t >= 0; --t)
       pair_stage<NX, NU, 1>(P, sm, prob, fac, t, lane, L, S, failed);
   }

@@ -212,7 +212,8 @@ class BatchedRiccatiSolver:
 
     def set_pipeline(self, halves: int = 2):
         """gar_hip_set_pipeline: the forward sweep of one half of the batch beside the backward sweep of the other
-        half (same results, bit for bit; serial one-wave-per-problem family only -- raises otherwise)."""
+        half (same results, bit for bit; serial one-wave-per-problem family only -- raises otherwise).  halves = -1:
+        the library's own choice from batch size and CU count (what a new solver starts with; never raises)."""
         self._check(self._L.gar_hip_set_pipeline(self._h, int(halves)))
 
     @property

@@ -5,7 +5,9 @@ Same distributions as aligator_amd.synth (which restates
 tests/gar/test_util.cpp:14-76): generator "F" (faithful) or "W"
 (well-conditioned), every knot of every problem drawn independently, so the
 timed sweep streams distinct data from HBM (no cache-resident replicas).
-Only uniform-dimension problems (nc = nth = 0) are generated here.
+Uniform-dimension problems (nth = 0): unconstrained, or -- the reference's own benchmark shape,
+bench/gar-riccati.cpp:19-22 -- with nc equality constraints on every knot, `C = [I 0]`, `d ~ U[-1,1]`
+(test_util.cpp:41-44) and `D = 0` or (`coupled=True`) `D ~ U[-1,1]`: the coupled reduced-KKT stage.
 """
 from __future__ import annotations
 
@@ -21,20 +23,22 @@ def _colmajor(m: torch.Tensor) -> torch.Tensor:
 
 
 def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = True,
-                  chunk: int = 64, keep=(0, -1)):
+                  chunk: int = 64, keep=(0, -1), coupled: bool = False):
     """Generate `solver.batch` problems on the GPU and load them into the solver.
     Keeps host copies of the problems listed in `keep` (for oracle spot checks)."""
     d = solver.dims
     N = solver.horizon
-    nx, nu = int(d[0, 0]), int(d[0, 1])
-    assert N >= 1 and (d[:N] == d[0]).all() and d[0, 2] == 0 and d[0, 4] == 0 and d[N, 1] == 0
+    nx, nu, nc = int(d[0, 0]), int(d[0, 1]), int(d[0, 2])
+    assert N >= 1 and (d[:N] == d[0]).all() and d[0, 4] == 0 and d[N, 1] == 0 and d[N, 2] == nc
     assert solver.nc0 == nx
+    assert nc == 0 or not solver.padded, "constrained shapes are generated in their own dimensions"
     # the DEVICE records (= the caller's unless the library padded the shape onto a specialised family: then the
     # dummy states / controls are filled in as the library itself does -- Q = I, R = I on them, everything else 0,
     # pinned by the extra rows [0 -I] of G0)
     dd = solver.device_dims
     NX, NU = int(dd[0, 0]), int(dd[0, 1])
-    dev = torch.device("cuda", torch.cuda.current_device())
+    # (without a GPU -- the test-only emulator build of the library -- the same records are built in host memory)
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     f64 = torch.float64
@@ -98,6 +102,10 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
         stage = torch.cat([sym_block(pad(Q, NX, NX, 1.0), NX), _colmajor(pad(S, NX, NU)), sym_block(pad(R, NU, NU, 1.0), NU),
                            padv(randu(nb, N, nx), NX), padv(randu(nb, N, nu), NU), _colmajor(pad(A, NX, NX)),
                            _colmajor(pad(B, NX, NU)), padv(randn(nb, N, nx), NX)], dim=-1)
+        if nc > 0:   # C = [I 0], D = 0 or U[-1, 1], d ~ U[-1, 1]   (test_util.cpp:41-44)
+            Cm = torch.eye(nc, nx, device=dev, dtype=f64).expand(nb, N, nc, nx)
+            Dm = randu(nb, N, nc, nu) if coupled else torch.zeros(nb, N, nc, nu, device=dev, dtype=f64)
+            stage = torch.cat([stage, _colmajor(Cm), _colmajor(Dm), randu(nb, N, nc)], dim=-1)
         assert stage.shape[-1] <= rec
         view = buf[:, off0:off0 + N * rec].view(nb, N, rec)
         view[..., :stage.shape[-1]] = stage
@@ -107,15 +115,19 @@ def fill_problems(solver, seed: int = 1234, mode: str = "W", singular: bool = Tr
         At = randu(nb, nx, nx) if mode == "F" else (torch.eye(nx, device=dev, dtype=f64) + 0.1 * randu(nb, nx, nx))
         term = torch.cat([_colmajor(pad(Qt, NX, NX, 1.0)), padv(randu(nb, nx), NX), _colmajor(pad(At, NX, NX)),
                           padv(randn(nb, nx), NX)], dim=-1)
+        if nc > 0:   # the terminal knot carries its constraint too (nu = 0: no D block)
+            term = torch.cat([term, _colmajor(torch.eye(nc, nx, device=dev, dtype=f64).expand(nb, nc, nx)), randu(nb, nc)], dim=-1)
         buf[:, offN:offN + term.shape[-1]] = term
-        torch.cuda.synchronize()  # generation done before the solver's stream copies it
+        if dev.type == "cuda":
+            torch.cuda.synchronize()  # generation done before the solver's stream copies it
         # (the format these records were just written in: refused, not swept, if the solver's differs)
         solver.upload_packed_device(buf.data_ptr(), b0, nb, record_format=1 if getattr(solver, "qr_packed", False) else 0)
         solver.sync()
         for k in keep_idx:
             if b0 <= k < b0 + nb:
                 solver._host_samples[k] = buf[k - b0].cpu().numpy()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         del buf, root, qsr, stage
     solver.sync()
 

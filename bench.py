@@ -119,6 +119,7 @@ def pmc_child(args):
     torch.cuda.set_device(0)
     solver = BatchedRiccatiSolver(dims, nx, batch=args.batch, num_legs=1, device=0)
     synth_device.fill_problems(solver, seed=1234, mode=args.generator, keep=())
+    solver.set_pipeline(0)   # whole-batch launches: the counters are reduced per launch of `batch` problems
     for _ in range(3):
         solver.backward_async(1e-14)
         solver.forward_async()
@@ -566,16 +567,13 @@ def secondary_shapes(device, batch=1024):
             "reference_bench_shape_nc32_coupled": (36, 12, 32, 256, 1e-11, "bench/gar-riccati.cpp's shape with D != 0 (U[-1,1]) on every knot: "
                                                    "the coupled reduced KKT stage, nx=36 nu=12 nc=32 N=256"),
             "talos_walk_lq_shape": (56, 22, 0, 275, 1e-10, "bench/talos-walk.cpp LQ sub-problem shape: nx=56 nu=22 N=275")}.items():
-        probs = [synth.generate_lq_problem(100 + i, np.zeros(nx), N, nx, nu, nc=nc, mode="W") for i in range(2)]
-        if key.endswith("_coupled"):
-            rng = np.random.default_rng(77)
-            for p_ in probs:
-                for k_ in p_.stages[:-1]:
-                    k_.D[...] = rng.uniform(-1.0, 1.0, k_.D.shape)
-        s = BatchedRiccatiSolver([k.dims for k in probs[0].stages], nx, batch=batch, device=device)
-        packed = np.concatenate([s.pack(p) for p in probs])
-        for b0 in range(0, batch, 2):
-            s.upload_packed(packed, b0, 2)
+        # every problem of the batch is its own draw, generated on the device like the headline's (round 6: the two
+        # host problems replicated 512 times that stood here were served from the last-level cache, and their
+        # per-problem uploads made rocprofv3 counter passes over this code impractical)
+        dims = [(nx, nu, nc, nx, 0)] * N + [(nx, 0, nc, nx, 0)]
+        s = BatchedRiccatiSolver(dims, nx, batch=batch, device=device)
+        synth_device.fill_problems(s, seed=100 + 7 * nc + nx, mode="W", coupled=key.endswith("_coupled"))
+        torch.cuda.synchronize()
         s.backward(mu); s.forward(); s.sync()
         failed = s.num_failed()
         s._check(s._L.gar_hip_set_timing(s.handle, 1))
@@ -597,7 +595,7 @@ def secondary_shapes(device, batch=1024):
         from oracle import oracle as ora
         err = kkt = 0.0
         for b in (0, batch - 1):
-            prob = probs[b % 2]
+            prob = synth_device.download_problem(s, b)
             sol = s.solution(b)
             op = ora.Problem.from_knots(prob.stages, prob.G0, prob.g0)
             osol = ora.ProximalRiccatiSolver(op)
@@ -619,7 +617,7 @@ def secondary_shapes(device, batch=1024):
             # (bench/talos-walk.cpp:102-127, bench/lqr.cpp:112-134) -- latency of one backward + forward sweep in leg
             # mode against the serial kernel on the same problem, the leg-mode solution against the serial oracle's
             # (tests/gar/parallel.cpp:211-235) in the same run
-            prob = probs[(batch - 1) % 2]   # (the problem `ref` and `scale` above belong to)
+            # (`prob`, `ref` and `scale` are those of the batch's last problem)
             lat = {}
             for legs in (1, 34):
                 s1 = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs, device=device)
@@ -729,8 +727,10 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "0", "2"],
                     help="the schedule of the timed steps: 0 = backward then forward sweep of the whole batch on one "
                          "stream; 2 = gar_hip_set_pipeline(2), the forward sweep of one half of the batch beside the "
-                         "backward sweep of the other half (same results, bit for bit); auto: both are timed (K steps "
-                         "each, same data) and `value` is the faster one -- both figures are in the line")
+                         "backward sweep of the other half (same results, bit for bit); auto: `value` is timed in the "
+                         "schedule the LIBRARY chooses by itself (gar_hip_set_pipeline(-1), what a new solver starts "
+                         "with: a caller's default) -- the other schedule is timed beside it (K steps, same data) and "
+                         "both figures are in the line")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -879,8 +879,14 @@ def main():
     second = None if args.single_generator else measure(other, 4321 + 7919 * rank)
     main_res = measure(args.generator, 1234 + 7919 * rank)
 
+    # `value` is the schedule a caller gets WITHOUT asking: the library's own choice for this batch on this device
+    solver.set_pipeline(-1)
+    library_default = solver.pipeline
+    solver.set_pipeline(0)
+
     def best_of(res):
-        sched = min((p for p in (0, 2) if p in res), key=lambda p: res[p]["elapsed"])
+        """(historical name) the schedule `value` is quoted in: the library's default when it was timed"""
+        sched = library_default if library_default in res else min((p for p in (0, 2) if p in res), key=lambda p: res[p]["elapsed"])
         return sched, res[sched]["elapsed"]
     sched, elapsed = best_of(main_res)
     # the roofline's kernel figures are those of the PLAIN schedule whenever it ran (full-batch launches, each kernel
@@ -954,7 +960,9 @@ def main():
             "config": {"workload": f"batched serial-in-time Riccati N={N} nx={nx} nu={nu} nc=0 fp64 "
                                    f"(BASELINE.json configs[1])",
                        "batch_per_gpu": args.batch, "kernel": solver.kernel_name,
-                       "schedule": "pipelined (two half-batches, forward beside backward)" if sched == 2 else "plain",
+                       "schedule": ("pipelined (two half-batches, forward beside backward)" if sched == 2 else "plain") +
+                                   (" = the library's default for this batch (gar_hip_set_pipeline(-1))" if sched == library_default
+                                    else " (forced by --pipeline; the library's default is the other one)"),
                        "parallelism": f"batch-sharded x{world} (no data-path collective)"},
             "schedules": sched_obj(main_res),
             "kernel_ms": {"backward_sweep": bwd_ms, "initial_stage": init_ms, "forward_sweep": fwd_ms,

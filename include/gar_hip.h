@@ -410,6 +410,7 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
  *   STAGE_NT = 0 | 1, EAGER = 0    host staging with / without non-temporal stores; gar_hip_backward_blocks without
  *                                  the roll-out enqueued behind the sweep (per call)
  *   MULTI_EXCHANGE = copy          gar_hip_multi_create: hipMemcpyPeerAsync instead of the peer-mapped gather
+ *   PIPELINE = auto | 0 | 2        the schedule a NEW solver starts with (default auto: gar_hip_set_pipeline(s, -1))
  *   PIPE_PRIORITY = 0 | 1          gar_hip_set_pipeline: plain half streams / one at high priority
  *   FORWARD = lean                 (per launch) the LDS-DMA roll-out of the pipelined schedule in the plain one too
  * GAR_HIP_ERR_ARG for a name that is none of these. */
@@ -424,8 +425,12 @@ const char *gar_hip_get_option(const char *name);
  * other entry point of this library (gar_hip_sync, the getters, uploads, gar_hip_device_problems / _solutions, ...)
  * first orders the solver's stream behind the half streams, so code that touches the records only through
  * this header needs no change; a caller that enqueues its own kernels on the records calls gar_hip_sync (or any
- * getter) first.  halves = 0 / 1: off (the default).  GAR_HIP_ERR_UNSUPPORTED unless the solver runs the serial
- * one-wave-per-problem family (batch > number of CUs, nc = nth = 0, at least 2 problems). */
+ * getter) first.  halves = 0 / 1: off.  GAR_HIP_ERR_UNSUPPORTED unless the solver runs the serial
+ * one-wave-per-problem family (batch > number of CUs, nc = nth = 0, at least 2 problems).
+ * halves = -1: the LIBRARY chooses (never an error) -- two halves iff the solver is eligible and each half fills every
+ * SIMD of the device with a backward wave (batch >= 8 x #CUs: 2 048 on an MI355X), plain otherwise.  This is what a
+ * new solver starts with (round 6; switch PIPELINE above), and what a cycleAppend that rebuilds the solver for other
+ * dimensions re-evaluates; gar_hip_pipeline tells which schedule is in force. */
 int gar_hip_set_pipeline(gar_hip_solver *s, int halves);
 int gar_hip_pipeline(const gar_hip_solver *s);
 /* Measurement aid (no reference counterpart): with enable != 0 the library brackets the

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-6 box visits (every step under its own timeout; STEPS selects): tests | abpair | tracepair | bench | absh (generic
+# A/B: SHAPE, LIBS) ...  Writes under gpurun_out/r6/.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r6; mkdir -p $O; export TMPDIR=/tmp
+STEPS=${STEPS:-"tests abpair tracepair bench"}
+cd $R
+has() { [[ " $STEPS " == *" $1 "* ]]; }
+if has tests; then
+  echo "== pytest gpu =="; timeout 1500 python -m pytest tests -m gpu -q -rA -p no:xdist > $O/pytest_gpu.log 2>&1; echo "rc=$?"; grep -E "^(PASSED|FAILED|ERROR|SKIPPED)|passed|failed" $O/pytest_gpu.log | grep -vE "^PASSED" | tail -15
+  echo "== smoke =="; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -E "smoke|Error" | tee $O/smoke.log
+fi
+if has abpair; then
+  echo "== A/B pair<56,24>: 8-byte F loads | wide F loads | wide + consumption order =="
+  SHAPE=talos timeout 900 python scripts/ab_shape.py ${LIBS:-base=libgar_hip_pairbase.so wide=libgar_hip_pairwide.so wide+order=libgar_hip.so} 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab_pair.log
+fi
+if has absh; then
+  echo "== A/B $SHAPE: $LIBS =="
+  timeout 900 python scripts/ab_shape.py $LIBS 2>&1 | grep -vE "amdgpu.ids" | tee -a $O/ab_${SHAPE}.log
+fi
+if has tracepair; then
+  echo "== trace pair (tracing build of the current sources) =="
+  timeout 300 python scripts/trace_pair.py 1024 2>&1 | grep -vE "amdgpu.ids" | tee $O/trace_pair.log
+fi
+if has bench; then
+  echo "== bench default =="; timeout 900 python bench.py --steps 20 --warmup 2 2> $O/bench.err | tail -1 > $O/bench_default_batch4096.json
+  python - <<PY
+import json; d=json.loads(open("$O/bench_default_batch4096.json").read())
+print(d["value"], d["config"]["schedule"], d["roofline"]["frac"], d["kernel_ms"], {k: (v["value"] if isinstance(v, dict) else v) for k, v in d["schedules"].items()})
+print("traffic", d["roofline"]["traffic"], "parity", d["parity"])
+for k, v in d["secondary_shapes"].items(): print(k, v["kernel"], v["sweeps_per_s"], v["backward_ms"], v["backward_frac_of_hbm_roofline"], v["max_rel_err_vs_oracle"])
+print("seam", {k: v["legs"]["us_per_newton_iteration"] for k, v in d["seam"].items() if isinstance(v, dict) and "legs" in v})
+PY
+fi

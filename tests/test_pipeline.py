@@ -194,6 +194,36 @@ def test_dims_changing_cycle_append_under_the_pipeline(emu):
     s.close()
 
 
+def test_the_library_chooses_its_schedule(emu):
+    """gar_hip_set_pipeline(s, -1) (round 6: what a NEW solver starts with, switch PIPELINE): never an error; plain
+    below 8 x #CUs problems or where the family does not apply; the switch forces either schedule at create."""
+    from aligator_amd import _lib
+    from aligator_amd.gar import BatchedRiccatiSolver
+    L = _lib.load(emu)
+    dims = [(8, 4, 0, 8, 0)] * 3 + [(8, 0, 0, 8, 0)]
+    s = BatchedRiccatiSolver(dims, 8, batch=4, lib_path=emu)
+    assert s.pipeline == 0                      # 4 problems do not fill a chip twice
+    s.set_pipeline(-1)
+    assert s.pipeline == 0
+    s.set_pipeline(2)
+    assert s.pipeline == 2
+    s.set_pipeline(-1)                          # back to the library's choice
+    assert s.pipeline == 0
+    s.close()
+    try:
+        assert L.gar_hip_set_option(b"PIPELINE", b"2") == 0
+        s = BatchedRiccatiSolver(dims, 8, batch=4, lib_path=emu)
+        assert s.pipeline == 2
+        s.close()
+        legs = BatchedRiccatiSolver(dims, 8, batch=4, num_legs=2, lib_path=emu)   # not the family: plain, no error
+        assert legs.pipeline == 0
+        legs.set_pipeline(-1)
+        assert legs.pipeline == 0
+        legs.close()
+    finally:
+        L.gar_hip_set_option(b"PIPELINE", None)
+
+
 def test_pipeline_is_refused_where_it_does_not_apply(emu):
     from aligator_amd.gar import BatchedRiccatiSolver
     nx, nu, N = 8, 4, 8
