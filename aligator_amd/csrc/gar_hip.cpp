@@ -267,6 +267,7 @@ struct gar_hip_solver {
   int wave_block_threads = 64; // 128: two waves per problem (gar_wave_pair.hpp)
   bool fb_t2 = false;      // factor records keep fb / fth in the fbT2 device order (gar_mfma.hpp)
   bool vxx_packed = false; // ... and the lower triangle of Vxx, packed (gar_layout.h: the serial one-wave family)
+  bool wide_vxx_packed = false; // (set by bind_wide: the serial two-wave family with packed records)
   bool qr_packed = false;  // knots t < N keep Q and R as packed lower triangles (gar_layout.h: the headline sweep)
   std::string lds_error;   // the generic kernels do not fit a CU's LDS (fatal unless a specialised family serves the shape)
   bool wave_fused_init = false;

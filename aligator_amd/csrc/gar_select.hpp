@@ -60,13 +60,26 @@ template <int NX, int NU> void bind_wide(gar_hip_solver *s) {
   // two waves per problem (the tile columns split between them) unless GAR_HIP_WIDE=single
   const char *w = gar_option("GAR_HIP_WIDE");
   const bool pair = !(w && std::string(w) == "single");
-  if (!(w && std::string(w) == "generic-forward"))
+  const bool generic_fwd = w && std::string(w) == "generic-forward";
+  if (!generic_fwd)
     s->mfma_fwd_kernel = gar::gar_forward_wide<NX, NU>; // row-major fb: fb_t2 stays false
   s->wave_fused_init = false;
   s->waves_per_block = 1;
   s->fb_t2 = false;
   if (pair) {
-    s->wave_kernel = gar::gar_backward_pair<NX, NU>;
+    // packed records (gar_wave_pair.hpp, GAR_PAIR_PACKED): lower triangles of Q, R in the knots, of Vxx in the factors
+    // -- with the roll-out that reads them (the any-dimension roll-out reads the flag from its parameters)
+    // (the any-dimension roll-out reads full Vxx blocks: GAR_HIP_WIDE=generic-forward keeps the full records)
+    constexpr bool PKD = GAR_PAIR_PACKED && GAR_QR_PACKED && GAR_VXX_PACKED && (NX % 4 == 0);
+    if (PKD && !generic_fwd) {
+      s->wave_kernel = gar::gar_backward_pair<NX, NU, PKD>;
+      s->qr_packed = true;
+      s->wide_vxx_packed = true;
+      s->mfma_fwd_kernel = gar::gar_forward_wide<NX, NU, true>;
+      s->mfma_fwd_lds_bytes = sizeof(double) * (size_t)gar_sym_packed_doubles(NX);
+    } else {
+      s->wave_kernel = gar::gar_backward_pair<NX, NU, false>;
+    }
     s->wave_lds_doubles = gar::PairCfg<NX, NU>::total;
     s->wave_block_threads = 128;
     s->kernel_name = "pair<" + std::to_string(NX) + "," + std::to_string(NU) + ">";
@@ -205,6 +218,7 @@ void select_kernel(gar_hip_solver *s) {
   s->wave_block_threads = 64;
   s->fb_t2 = false;
   s->vxx_packed = false;
+  s->wide_vxx_packed = false;
   s->qr_packed = false;
   {
     const char *ik = gar_option("GAR_HIP_INIT");
@@ -256,7 +270,8 @@ void select_kernel(gar_hip_solver *s) {
   else if (nx == 12 && nu == 4) bind_mfma<12, 4>(s);
   else if (nx == 8 && nu == 4) bind_mfma<8, 4>(s);
   else if (nx == 56 && nu == 24) bind_wide<56, 24>(s);
-  s->vxx_packed = GAR_VXX_PACKED && s->fb_t2; // the serial one-wave family keeps the lower triangle of Vxx, packed (gar_layout.h)
+  // the serial one-wave family keeps the lower triangle of Vxx, packed (gar_layout.h); round 6: the two-wave wide family too
+  s->vxx_packed = GAR_VXX_PACKED && (s->fb_t2 || s->wide_vxx_packed);
 }
 
 // (nx, nu) shapes with kernels of their own (bind_mfma / bind_leg / bind_wide / bind_seg_leg above)

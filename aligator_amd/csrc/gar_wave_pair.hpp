@@ -36,11 +36,25 @@ namespace gar {
 // position order and feeds H unchanged), vx' and f in the vector part, the rows of B as the A operand of Aff, the
 // rows of Aff / yff on their way out.  Results: the same sums in the same order per entry (the k-steps visit the
 // rows in another order: last-digit differences against the 8-byte build, none against the record layout).
+// MEASURED AND NOT ADOPTED (round 6; same box, alternating launches, 1 024 distinct device-generated problems, N = 275;
+// profiles/r06_ab_pair_wide_f_loads_and_load_order_not_kept.log): backward 14.45 ms with the 8-byte loads, 14.72 ms
+// with the 16-byte ones, 14.70 ms with those issued in consumption order (GAR_PAIR_ORDER) -- solutions equal to
+// 5e-15.  The number of load instructions is not what the production schedule waits for (the tracing build, whose
+// marks pin the schedule, shows the burst shrink from 23.7 k to 7.9 k cycles on wave 1: the compiler's own placement
+// of the loads had hidden it already).  Both stay available: make variant NAME=pairwide DEFS="-DGAR_PAIR_WIDE_F=1".
 #ifndef GAR_PAIR_WIDE_F
-#define GAR_PAIR_WIDE_F 1
+#define GAR_PAIR_WIDE_F 0
 #endif
 #ifndef GAR_PAIR_ORDER
-#define GAR_PAIR_ORDER 1
+#define GAR_PAIR_ORDER 0
+#endif
+// Packed records for the SERIAL wide family (round 6; what the headline family has had since rounds 3 / 4): the knot
+// records keep Q and R as packed lower triangles (gar_layout.h: gar_lower_index; 1 540 + 276 of 9 672 doubles less read
+// per knot at (56, 24) -- the upper triangles never reach a result), the factor records the lower triangle of Vxx,
+// rectangular packed (gar_sym_index: 1 596 instead of 3 136 doubles written per stage and read by the roll-out,
+// gar_forward_wide<.., true>).  The segment-leg kernels (gar_leg_seg.hpp) keep full blocks: PKD = false there.
+#ifndef GAR_PAIR_PACKED
+#define GAR_PAIR_PACKED 1
 #endif
 
 template <int NX, int NU> struct PairCfg {
@@ -92,14 +106,15 @@ __device__ __forceinline__ void pair_load_F(const double *rec, const LANE &L, Wa
       S.FoT[t][s - 4 * C::KSF] = v;
   }
 }
-template <int NX, int NU, class LANE>
+template <int NX, int NU, bool QP, class LANE>
 __device__ __forceinline__ void pair_load_H(const double *rec, const LANE &L, WaveStage<NX, NU> &S, int ti, int tj) {
   using C = WaveCfg<NX, NU>;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row0 = 16 * ti + 4 * r; // + lk
     if (row0 + 3 < NX)
-      S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, 16 * tj * NX + row0, L.hcx0) : ldg_b(rec, row0, L.hcxX[tj]);
+      S.Hc[ti][tj][r] = QP ? ldg_b(rec, row0, L.hcq[tj])
+                           : (WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, 16 * tj * NX + row0, L.hcx0) : ldg_b(rec, row0, L.hcxX[tj]));
     else if (row0 >= NX && row0 + 3 < C::NW)
       S.Hc[ti][tj][r] = WaveLane<NX, NU>::x_in(tj) ? ldg_b(rec, (row0 - NX) * NX + 16 * tj, L.hcu0)
                                                    : ldg_b(rec, 0, L.hcuX[tj][(row0 - NX) >> 2]);
@@ -107,7 +122,7 @@ __device__ __forceinline__ void pair_load_H(const double *rec, const LANE &L, Wa
       S.Hc[ti][tj][r] = 0.0;
   }
 }
-template <int NX, int NU, int W, class LANE>
+template <int NX, int NU, int W, bool QP = false, class LANE>
 __device__ __forceinline__ void pair_load(const double *rec, const LANE &L, WaveStage<NX, NU> &S, int lane) {
   using C = WaveCfg<NX, NU>;
   using PC = PairCfg<NX, NU>;
@@ -126,7 +141,7 @@ __device__ __forceinline__ void pair_load(const double *rec, const LANE &L, Wave
         pair_load_F<NX, NU>(rec, L, S, ti, lane);
         have[ti] = true;
       }
-      pair_load_H<NX, NU>(rec, L, S, ti, tj);
+      pair_load_H<NX, NU, QP>(rec, L, S, ti, tj);
     }
   }
 #else
@@ -139,11 +154,11 @@ __device__ __forceinline__ void pair_load(const double *rec, const LANE &L, Wave
 #pragma unroll
     for (int tj = 0; tj <= ti; ++tj)
       if (PC::owner(tj) == W)
-        pair_load_H<NX, NU>(rec, L, S, ti, tj);
+        pair_load_H<NX, NU, QP>(rec, L, S, ti, tj);
 #endif
 }
 
-template <int NX, int NU, int W>
+template <int NX, int NU, int W, bool PKD = false>
 __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, const double *prob, double *fac,
                                            int t, int lane, const WaveLane<NX, NU, 0> &L,
                                            WaveStage<NX, NU> &S, int &failed) {
@@ -490,14 +505,14 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
     }
   }
   GAR_PMARK(10)
-  pair_load<NX, NU, W>(recn, L, S, lane); // knot t-1 into the registers this stage released
+  pair_load<NX, NU, W, PKD>(recn, L, S, lane); // knot t-1 into the registers this stage released
   GAR_PMARK(11)
   __syncthreads(); // (4) V, vx complete
   GAR_PMARK(12)
   // ---- Vxx -> HBM, 16 B per lane, the chunks alternate between the waves: column-major and symmetric for the wide
   // shapes, the packed lower triangle (gar_layout.h) where the roll-out is gar_forward_mfma ----
   {
-    using VO = VxxOut<NX, GAR_VXX_PACKED && !WIDE, PK>;
+    using VO = VxxOut<NX, PKD || (GAR_VXX_PACKED && !WIDE), PK>;
 #pragma unroll
     for (int q = W; q < VO::NCH; q += 2)
       VO::write(out + oVxx, q, lane, VO::read(V, q, lane));
@@ -506,7 +521,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
 
 // (the narrow shapes fit 256 registers per wave: two waves share a SIMD, i.e. four problems per CU, and
 // one problem's waits hide behind the other's arithmetic; the wide ones need the whole register file)
-template <int NX, int NU>
+template <int NX, int NU, bool PKD = false>
 __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair(MfmaParams P, int batch) {
   using C = WaveCfg<NX, NU, 0>;
   using M = MfmaCfg<NX, NU, 0>;
@@ -521,16 +536,16 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
   const int N = P.horizon;
   double *V = sm + C::oV, *vn = sm + C::oVn;
   WaveLane<NX, NU, 0> L;
-  wave_lane_init<NX, NU>(L, lane);
+  wave_lane_init<NX, NU, 0, PKD>(L, lane);
   const double *recN1 = prob + P.in_off0 + P.slot(N - 1) * P.in_rec;
-  { // terminal knot (terminalSolve, nu = 0, :146-149, :175-178): Vxx = Q, vx = q
+  { // terminal knot (terminalSolve, nu = 0, :146-149, :175-178): Vxx = Q, vx = q (its record keeps the full Q)
     const double *rec = prob + P.in_offN;
     double *out = fac + P.fac_offN;
     for (int e = tid; e < NX * NX; e += 128) {
       const int j = e / NX, i = e - j * NX;
       const double v = (i >= j) ? rec[M::tQ + e] : rec[M::tQ + i * NX + j];
       V[i * PK + j] = v;
-      if (M::WIDE || !GAR_VXX_PACKED)
+      if (!PKD && (M::WIDE || !GAR_VXX_PACKED))
         out[M::tVxx + e] = v;
       else if (i >= j)
         out[M::tVxx + gar_sym_index(1, NX, i, j)] = v; // (packed lower triangle: gar_layout.h)
@@ -547,14 +562,14 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
   // carry the union of both waves' state through either path)
   if (wave == 0) {
     WaveStage<NX, NU> S;
-    pair_load<NX, NU, 0>(recN1, L, S, lane);
+    pair_load<NX, NU, 0, PKD>(recN1, L, S, lane);
     for (int t = N - 1; t >= 0; --t)
-      pair_stage<NX, NU, 0>(P, sm, prob, fac, t, lane, L, S, failed);
+      pair_stage<NX, NU, 0, PKD>(P, sm, prob, fac, t, lane, L, S, failed);
   } else {
     WaveStage<NX, NU> S;
-    pair_load<NX, NU, 1>(recN1, L, S, lane);
+    pair_load<NX, NU, 1, PKD>(recN1, L, S, lane);
     for (int t = N - 1; t >= 0; --t)
-      pair_stage<NX, NU, 1>(P, sm, prob, fac, t, lane, L, S, failed);
+      pair_stage<NX, NU, 1, PKD>(P, sm, prob, fac, t, lane, L, S, failed);
   }
   if (failed && lane == 0)
     atomicOr(&P.status[b], failed);
@@ -567,9 +582,14 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
 // nx = 56, read as 16-byte pieces).  u = kff + K x, x' = yff + Aff x, lbd' = vx' + Vxx' x' with the state
 // broadcast from the lanes that hold it (v_readlane).  Replaces the generic 256-thread kernel on these
 // shapes (18.4 of 48.6 ms per 2 048 sweeps at (56, 22), N = 275).
-template <int NX, int NU>
+// VPACK (round 6): the records keep the lower triangle of Vxx, rectangular packed (gar_layout.h) -- the next stage's
+// 12.8 KB at nx = 56 are fetched LINEARLY (13 whole-line requests per lane instead of 28 pieces of a 448-byte row
+// each) and become rows through LDS, as in gar_forward_mfma.
+template <int NX, int NU, bool VPACK = false>
 __global__ void __launch_bounds__(64) gar_forward_wide(MfmaFwdParams P) {
   using M = MfmaCfg<NX, NU, 0>;
+  using VO = VxxOut<NX, true>;
+  double *vb = gar_smem; // VPACK: nx (nx + 1) / 2 doubles of dynamic LDS
   static_assert(NX <= 64 && NX % 2 == 0, "the state lives in the first NX lanes");
   constexpr int NR = M::NR;
   const int lane = (int)threadIdx.x;
@@ -588,15 +608,23 @@ __global__ void __launch_bounds__(64) gar_forward_wide(MfmaFwdParams P) {
     const double *rec = fac + P.slot(t) * P.fac_rec;
     const double *recn = (t + 1 < N) ? fac + P.slot(t + 1) * P.fac_rec : fac + P.fac_offN;
     const int oVn = (t + 1 < N) ? M::fVxx : M::tVxx, ovn = (t + 1 < N) ? M::fvx : M::tvx;
-    double2_t aff[NX / 2], kro[NX / 2], vrow[NX / 2];
+    double2_t aff[NX / 2], kro[NX / 2], vrow[VPACK ? 1 : NX / 2], vp[VPACK ? VO::NCH : 1];
 #pragma unroll
     for (int m = 0; m < NX / 2; ++m) {
       kro[m] = *reinterpret_cast<const double2_t *>(rec + M::fFB + iK * NX + 2 * m);
       aff[m] = *reinterpret_cast<const double2_t *>(rec + M::fFB + (NU + iA) * NX + 2 * m);
     }
+    if constexpr (VPACK) {
 #pragma unroll
-    for (int m = 0; m < NX / 2; ++m)
-      vrow[m] = *reinterpret_cast<const double2_t *>(recn + oVn + iA * NX + 2 * m);
+      for (int q = 0; q < VO::NCH; ++q) {
+        const int e = 64 * q + lane, ec = (64 * q + 63 < VO::NP2 || e < VO::NP2) ? e : VO::NP2 - 1;
+        vp[q] = *reinterpret_cast<const double2_t *>(recn + oVn + 2 * ec);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < NX / 2; ++m)
+        vrow[m] = *reinterpret_cast<const double2_t *>(recn + oVn + iA * NX + 2 * m);
+    }
     const double kff = rec[M::fFF + iK], yff = rec[M::fFF + NU + iA], vxn = recn[ovn + iA];
     double u0 = kff, u1 = 0.0, x0 = yff, x1 = 0.0;
 #pragma unroll
@@ -613,10 +641,31 @@ __global__ void __launch_bounds__(64) gar_forward_wide(MfmaFwdParams P) {
     if (lane < NX)
       sol[(t + 1) * NX + lane] = xn;
     double l0 = vxn, l1 = 0.0; // lbd' = vx' + Vxx' x'  (:369-371)
+    if constexpr (VPACK) {
+      wave_sync(); // (the previous stage's row reads are done)
 #pragma unroll
-    for (int m = 0; m < NX / 2; ++m) {
-      l0 = __builtin_fma(vrow[m].x, lane_bcast(xn, 2 * m), l0);
-      l1 = __builtin_fma(vrow[m].y, lane_bcast(xn, 2 * m + 1), l1);
+      for (int q = 0; q < VO::NCH; ++q) {
+        const int e = 64 * q + lane;
+        if (64 * q + 63 < VO::NP2 || e < VO::NP2)
+          *reinterpret_cast<double2_t *>(&vb[2 * e]) = vp[q];
+      }
+      wave_sync();
+      // row iA of the symmetric matrix from its packed lower triangle (gar_sym_index): elements (iA, j), j <= iA, at
+      // cj + iA; (j, iA), j > iA, at lowbase + j
+      const int lowbase = 2 * iA < NX ? iA * NX : (NX - 1 - iA) * (NX + 1) + 1;
+#pragma unroll
+      for (int j = 0; j < NX; j += 2) {
+        const int c0 = 2 * j < NX ? j * NX : (NX - 1 - j) * (NX + 1) + 1;
+        const int c1 = 2 * (j + 1) < NX ? (j + 1) * NX : (NX - 2 - j) * (NX + 1) + 1;
+        l0 = __builtin_fma(vb[iA >= j ? c0 + iA : lowbase + j], lane_bcast(xn, j), l0);
+        l1 = __builtin_fma(vb[iA >= j + 1 ? c1 + iA : lowbase + j + 1], lane_bcast(xn, j + 1), l1);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < NX / 2; ++m) {
+        l0 = __builtin_fma(vrow[m].x, lane_bcast(xn, 2 * m), l0);
+        l1 = __builtin_fma(vrow[m].y, lane_bcast(xn, 2 * m + 1), l1);
+      }
     }
     if (lane < NX)
       sol[P.sol_l + P.nc0 + t * NX + lane] = l0 + l1;

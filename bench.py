@@ -280,6 +280,49 @@ def cpu_baseline(args, nx, nu, N, mueq):
     except Exception as e:  # the baseline never fails the bench line
         out["nc32_sweeps_per_s"] = None
         out["nc32_error"] = str(e)[:100]
+    # C5 (round 6): the reference's OWN compiled code beside the port -- oracle/_ref/libgar_ref.so, its gar sources
+    # compiled unchanged over the naive Eigen stand-in (oracle/ref_build.sh; prebuilt where /root/reference exists, it
+    # travels to the GPU box) -- on the first problem above, one thread: ProximalRiccatiSolver backward + forward, and
+    # ParallelRiccatiSolver with 4 threads.  An UPPER bound on the Eigen build's time (the stand-in's products are
+    # plain loops), flagged as such; `kind` stays "port".
+    try:
+        from oracle import ref as oref
+        if not os.path.exists(oref.PATH):
+            raise RuntimeError("oracle/_ref/libgar_ref.so is not in the snapshot")
+        rp = oref.Problem(first)
+        rs = oref.ProximalRiccatiSolver(rp)
+        best = 1e30
+        for _ in range(3):
+            t1 = time.perf_counter()
+            rs.backward(mueq)
+            rsol = rs.forward()
+            best = min(best, time.perf_counter() - t1)
+        # ... the same problem through the port, one thread, and the two solutions against each other
+        op1 = ora.Problem.from_knots(first.stages, first.G0, first.g0, native=True)
+        os1 = ora.ProximalRiccatiSolver(op1)
+        os1.backward(mueq)
+        psol = op1.initialize_solution()
+        os1.forward(*psol)
+        scale = max(1.0, max(float(np.abs(v).max()) for part in psol for v in part if v.size))
+        dref = max(float(np.abs(a - b).max()) for A, B in zip(rsol, psol) for a, b in zip(A, B) if a.size) / scale
+        rpar = oref.Problem(first)
+        rpp = oref.ParallelRiccatiSolver(rpar, 4)
+        bestp = 1e30
+        for _ in range(3):
+            t1 = time.perf_counter()
+            rpp.backward(mueq)
+            rpp.forward()
+            bestp = min(bestp, time.perf_counter() - t1)
+        out["reference_standin"] = {
+            "what": "the reference's own ProximalRiccatiSolver / ParallelRiccatiSolver, sources compiled unchanged "
+                    "(oracle/ref_build.sh) over the naive Eigen stand-in: an UPPER BOUND on the Eigen build's time "
+                    "(naive products), same problem, this box's host",
+            "serial_one_thread_ms_per_sweep": best * 1e3, "serial_sweeps_per_s_one_thread": 1.0 / best,
+            "parallel_4_threads_ms_per_sweep": bestp * 1e3,
+            "port_one_thread_ms_per_sweep": lat * 1e3,
+            "max_rel_diff_reference_vs_port": dref}
+    except Exception as e:  # the baseline never fails the bench line
+        out["reference_standin"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
     del L
     return out
 

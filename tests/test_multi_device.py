@@ -299,3 +299,18 @@ def test_gpu_bench_horizon_single_process():
     r = subprocess.run([sys.executable, "bench.py", "--mode", "horizon", "--single-process", "--gpus", str(n + 1)],
                        cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "visible" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_gpu_first_multi_gpu_script():
+    """scripts/first_multi_gpu.sh -- the script of the first run on several physical GPUs (peer-access matrix; one
+    process with the legs over the devices, pull vs copy, bitwise the one-device solver at configs[3]'s shape; RCCL
+    --mode horizon; the batch axis) -- exercised here with every rank / sub-solver on this box's device (on a box with
+    several devices it runs for real): every step must report ok."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "first_multi_gpu.sh"), "--quick"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=2400)
+    print(r.stdout[-6000:])
+    assert r.returncode == 0 and "first_multi_gpu: every step ok" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "multi-device ok" in r.stdout
