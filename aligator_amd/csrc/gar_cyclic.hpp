@@ -32,6 +32,7 @@
 // tolerance, checked by the same residual the reference checks.
 #pragma once
 #include "gar_wave_leg.hpp"
+#include "gar_ldl_blocked.hpp"
 
 namespace gar {
 
@@ -107,15 +108,39 @@ template <int NX> struct CyclicLds {
 // complements -- so no pivoting is needed for stability) + blocked inverse.  Returns 1 on a zero or
 // non-finite pivot: the caller then poisons the residual, which hands the problem to the
 // elimination-chain kernel (Bunch-Kaufman pivoting, refinement).
+// Round 6: blocks wider than one DPP row (36, 32) are factorised in panels of 12 / 16 columns with the trailing
+// matrix updated on MFMA tiles (gar_ldl_blocked.hpp; 630 v_readlane broadcast-FMA pairs at NX = 36 otherwise): L goes
+// straight to LDS where the blocked inverse wants it.  Dm is consumed.
+#ifndef GAR_CYC_BLOCKED_LDL
+#define GAR_CYC_BLOCKED_LDL 1
+#endif
 template <int NX>
 __device__ __forceinline__ int cyc_inverse(double *sm, int lane) {
   using L = CyclicLds<NX>;
   double *Dm = sm + L::oD, *Wm = sm + L::oW, *Mm = sm + L::oM, *Tm = sm + L::oT, *Dl = sm + L::oDl;
-  double a_row[NX], nd[NX];
-  const int failed = wave_ldl_fast<NX, true>(Dm, lane, a_row, nd);
-  cond_inverse<NX>(a_row, nd, Wm, Mm, Wm, Tm, Dl, lane);
-  wave_sync();
-  return failed;
+  if constexpr (GAR_CYC_BLOCKED_LDL && NX > 16 && (CondCfg<NX>::BS == 12 || CondCfg<NX>::BS == 16)) {
+    for (int e = lane; e < NX * NX; e += 64) { // unit diagonal, zeros above it: the strictly lower part is the routine's
+      const int j = e / NX, i = e - j * NX;
+      if (i <= j)
+        Wm[e] = (i == j) ? 1.0 : 0.0;
+    }
+    bool ff;
+    const int failed = wave_ldl_blocked<NX, CondCfg<NX>::BS, true, LdlColMajor<NX>, LdlColMajor<NX>, true>(Dm, Tm, Wm, Dl, lane, ff, false);
+    wave_lds_order();
+    const double dl = -Dl[lane < NX ? lane : NX - 1]; // -1 / d_k -> 1 / d_k
+    wave_lds_order();
+    if (lane < NX)
+      Dl[lane] = dl;
+    cond_inverse_from_lds<NX>(Wm, Mm, Wm, Tm, Dl, lane);
+    wave_sync();
+    return failed;
+  } else {
+    double a_row[NX], nd[NX];
+    const int failed = wave_ldl_fast<NX, true>(Dm, lane, a_row, nd);
+    cond_inverse<NX>(a_row, nd, Wm, Mm, Wm, Tm, Dl, lane);
+    wave_sync();
+    return failed;
+  }
 }
 // a failed block inverse: the residual slot is set to +inf (atomicMax on the bit pattern)
 __device__ __forceinline__ void cyc_poison(double *info) {

@@ -274,6 +274,13 @@ __device__ __attribute__((noinline)) int wave_bk_second_test(LdlRow<NU> R, doubl
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) {
   return __builtin_amdgcn_ballot_w64(p); // the v_cmp result itself (HIP's __ballot goes through an int)
 }
+} // namespace gar
+// (the blocked wave-scope L D L^T: built on row_bcast / wave_ballot / wave_lds_order above, used by the coupled stage below)
+#include "gar_ldl_blocked.hpp"
+#ifndef GAR_COUPLED_BLOCKED_LDL
+#define GAR_COUPLED_BLOCKED_LDL 1
+#endif
+namespace gar {
 // The register LDL^T of wave_ldl_fast_neg on rows already in registers (a[j] = Rhat(row, j)), under
 // the COMPLETE pivot rule: a column that fails the first test is checked out of line against the
 // second one and the elimination goes on when Bunch-Kaufman keeps kp = k.  Returns 0 when it kept
@@ -595,7 +602,25 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
       else
         a44[j] = (lane == j || (lane >= NK && j == NK - 1)) ? -P.mueq : 0.0;
     }
+#if GAR_COUPLED_BLOCKED_LDL
+    // round 6: the 44-row factorisation (946 v_readlane broadcast-FMA pairs in registers) in panels of 12 columns on
+    // DPP broadcasts, the trailing matrix updated on MFMA tiles (gar_ldl_blocked.hpp) -- IN PLACE on the matrix packed
+    // by rows in Mm, which is exactly where and how the solve below reads -L.  A column that fails Bunch-Kaufman's
+    // first test leaves with verdict 2: the caller's chain hands the knot to the LDS Bunch-Kaufman kernel (the
+    // reference's complete rule), as for a knot where it really pivots.
+    if (lane < NK) {
+      const int base0 = (lane * (lane + 1)) >> 1;
+#pragma unroll
+      for (int j = 0; j < NK; ++j)
+        if (j <= lane)
+          Lpk[base0 + j] = a44[j];
+    }
+    wave_lds_order();
+    verdict = wave_ldl_blocked<NK, 12, false, LdlRowPacked, LdlRowPacked>(Lpk, nd44p + ((NK + 3) & ~3), Lpk, nd44p, lane, first_failed, false);
+    wave_lds_order();
+#else
     verdict = wave_ldl_fast_neg_pre<NK, 1>(lane, a44, nd44, first_failed, nd44p);
+#endif
   } else {
     verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed, nullptr, P.spd_accept != 0);
   }
@@ -607,11 +632,13 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   if constexpr (COUPLED) {
     if (verdict != 0)
       return 0;
+#if !GAR_COUPLED_BLOCKED_LDL
     const int base = (lane * (lane + 1)) >> 1;
 #pragma unroll
     for (int j = 0; j < NK - 1; ++j)
       if (j < lane && lane < NK)
         Lpk[base + j] = a44[j];
+#endif
   } else {
     if (lane < NU) {
 #pragma unroll

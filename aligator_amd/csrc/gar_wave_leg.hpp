@@ -537,13 +537,14 @@ __device__ __forceinline__ void cond_blk_store(double *Mx, int r0, int c0, doubl
 // parallel substitution -- lane = (block, column) --, off-diagonal blocks as small MFMA products),
 // then W = M^T Dd^{-1} M on MFMA tiles, skipping the k-steps where the triangular M is zero.
 // Lm may alias Wm.
+// (cond_inverse_from_lds: the second half alone -- unit-lower L column-major in Lm, 1/d_k in Dl already in LDS, as the
+// blocked factorisation of gar_ldl_blocked.hpp leaves them)
+template <int NX>
+__device__ __forceinline__ void cond_inverse_from_lds(double *Lm, double *Mm, double *Wm, double *Tm, double *Dl, int lane);
 template <int NX>
 __device__ __forceinline__ void cond_inverse(const double (&a_row)[NX], const double (&nd)[NX],
                                              double *Lm, double *Mm, double *Wm, double *Tm,
                                              double *Dl, int lane) {
-  using K = CondCfg<NX>;
-  constexpr int BS = K::BS, NB = K::NB, TX = K::TX, KS = K::KS;
-  const int li = lane & 15, lk = lane >> 4;
   // clean unit-lower L, column-major; 1/d_k to lane k
   if (lane < NX) {
 #pragma unroll
@@ -558,6 +559,13 @@ __device__ __forceinline__ void cond_inverse(const double (&a_row)[NX], const do
     if (lane < NX)
       Dl[lane] = dl;
   }
+  cond_inverse_from_lds<NX>(Lm, Mm, Wm, Tm, Dl, lane);
+}
+template <int NX>
+__device__ __forceinline__ void cond_inverse_from_lds(double *Lm, double *Mm, double *Wm, double *Tm, double *Dl, int lane) {
+  using K = CondCfg<NX>;
+  constexpr int BS = K::BS, NB = K::NB, TX = K::TX, KS = K::KS;
+  const int li = lane & 15, lk = lane >> 4;
   for (int e = lane; e < NX * NX; e += 64)
     Mm[e] = 0.0;
   wave_sync();

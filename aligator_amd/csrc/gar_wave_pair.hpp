@@ -21,6 +21,7 @@
 // these shapes are the generic kernels.
 #pragma once
 #include "gar_wave2.hpp"
+#include "gar_ldl_blocked.hpp"
 
 namespace gar {
 
@@ -56,6 +57,12 @@ namespace gar {
 #ifndef GAR_PAIR_PACKED
 #define GAR_PAIR_PACKED 1
 #endif
+// The 24 x 24 register L D L^T of Rhat (276 broadcast-FMA pairs through v_readlane: 10.6 - 11.8 k cycles of the stage
+// with the other wave idle) as TWO 12-column panels on DPP broadcasts + one MFMA trailing update
+// (gar_ldl_blocked.hpp).  Shapes whose Rhat fits one DPP row (NU <= 16) keep the register version.
+#ifndef GAR_PAIR_BLOCKED_LDL
+#define GAR_PAIR_BLOCKED_LDL 1
+#endif
 
 template <int NX, int NU> struct PairCfg {
   using C = WaveCfg<NX, NU, 0>;
@@ -67,7 +74,9 @@ template <int NX, int NU> struct PairCfg {
   __host__ __device__ static constexpr int prow(int pos) { return PX ? C::KS * (pos & 3) + (pos >> 2) : pos; }
   static constexpr int oHq = (C::total + 1) & ~1;          // [qhat; rhat], one entry per index
   static constexpr int oFlag2 = oHq + ((C::NW + 1) & ~1);  // verdict of the factorisation (int)
-  static constexpr int total = oFlag2 + 2;
+  static constexpr bool BLK = GAR_PAIR_BLOCKED_LDL && NU > 16 && NU % 4 == 0;
+  static constexpr int oLdl = oFlag2 + 2;                  // blocked factorisation: working copy of Rhat | -d_k
+  static constexpr int total = oLdl + (BLK ? LdlBlockedLds<NU>::total : 0);
   __host__ __device__ static constexpr int owner(int tj) { return tj >= SPLIT ? 1 : 0; }
 };
 
@@ -300,22 +309,36 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   GAR_PMARK(3)
   // ---- wave 1: register LDL^T of Rhat under the complete Bunch-Kaufman rule; -L, -1/d -> LDS -------
   if (W == 1) {
-    double a_row[NU], nd[NU];
-    const int frow = lane < NU ? lane : NU - 1;
-#pragma unroll
-    for (int j = 0; j < NU; ++j)
-      a_row[j] = Mm[j * NU + frow];
-    bool first_failed;
-    const int verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed, nullptr, P.spd_accept != 0);
-    if (lane < NU) {
+    bool first_failed = false;
+    int verdict = 2;
+    if constexpr (PC::BLK) { // two DPP panels + an MFMA trailing update on a working copy (Mm stays pristine for the
+      // complete rule / the device Bunch-Kaufman below)
+      double *Wc = sm + PC::oLdl + LdlBlockedLds<NU>::oW, *npv = sm + PC::oLdl + LdlBlockedLds<NU>::oNp;
+      for (int e = lane; e < NU * NU; e += 64)
+        Wc[e] = Mm[e];
+      wave_lds_order();
+      verdict = wave_ldl_blocked<NU, 12, false>(Wc, npv, Lr, ndi, lane, first_failed, P.spd_accept != 0);
+      wave_lds_order();
+    }
+    if (verdict == 2) { // (the register version: every shape with NU <= 16; a column that needs the complete rule)
+      double a_row[NU], nd[NU];
+      const int frow = lane < NU ? lane : NU - 1;
 #pragma unroll
       for (int j = 0; j < NU; ++j)
-        Lr[lane * NU + j] = a_row[j];
+        a_row[j] = Mm[j * NU + frow];
+      verdict = wave_ldl_fast_neg_pre<NU>(lane, a_row, nd, first_failed, nullptr, P.spd_accept != 0);
+      if (lane < NU) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+          Lr[lane * NU + j] = a_row[j];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+          ndi[j] = nd[j];
+      }
     }
     if (lane == 0) {
-#pragma unroll
-      for (int j = 0; j < NU; ++j)
-        ndi[j] = nd[j];
       flag[0] = verdict;
       if (first_failed) {
         atomicAdd(&P.slow[0], 1);

@@ -32,3 +32,18 @@ for k, v in d["secondary_shapes"].items(): print(k, v["kernel"], v["sweeps_per_s
 print("seam", {k: v["legs"]["us_per_newton_iteration"] for k, v in d["seam"].items() if isinstance(v, dict) and "legs" in v})
 PY
 fi
+if has ab2; then
+  echo "== A/B talos: full records + register LDL | packed records | packed + blocked LDL =="
+  SHAPE=talos timeout 900 python scripts/ab_shape.py full=libgar_hip_pairfull.so packed=libgar_hip_noblk.so packed+blocked=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab2_talos.log
+  echo "== A/B coupled nc32 (D != 0): register 44 x 44 LDL | blocked =="
+  SHAPE=nc32c timeout 900 python scripts/ab_shape.py register=libgar_hip_noblk.so blocked=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab2_nc32c.log
+  echo "== A/B legs (the seam's device side): register 36 x 36 LDL in the cyclic reduction | blocked =="
+  timeout 300 python scripts/ab_legs.py register=libgar_hip_noblk.so blocked=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab2_legs.log
+  LEGS=64 timeout 300 python scripts/ab_legs.py register=libgar_hip_noblk.so blocked=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee -a $O/ab2_legs.log
+  SHAPE=talos timeout 300 python scripts/ab_legs.py register=libgar_hip_noblk.so blocked=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee -a $O/ab2_legs.log
+fi
+if has tracecstr; then
+  echo "== trace coupled stage (tracing build) =="
+  DNONZERO=1 timeout 300 python scripts/trace_cstr.py 1024 2>&1 | grep -vE "amdgpu.ids" | tee $O/trace_cstr_coupled.log
+  timeout 300 python scripts/trace_cstr.py 1024 2>&1 | grep -vE "amdgpu.ids" | tee $O/trace_cstr_decoupled.log
+fi
