@@ -277,8 +277,12 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) {
 } // namespace gar
 // (the blocked wave-scope L D L^T: built on row_bcast / wave_ballot / wave_lds_order above, used by the coupled stage below)
 #include "gar_ldl_blocked.hpp"
+// MEASURED AND NOT ADOPTED for the coupled stage (profiles/r06_ab_coupled_blocked_ldl_not_kept.log,
+// r06_trace_cstr_coupled.log): backward 15.59 ms against 12.71 with the register version -- inside this kernel, which
+// already holds 512 registers, the compiler pays for the blocked routine with ~95 spill reloads from scratch on the
+// factorisation's critical path (84.6 k cycles for the phase).  Results equal to 2e-15.
 #ifndef GAR_COUPLED_BLOCKED_LDL
-#define GAR_COUPLED_BLOCKED_LDL 1
+#define GAR_COUPLED_BLOCKED_LDL 0
 #endif
 namespace gar {
 // The register LDL^T of wave_ldl_fast_neg on rows already in registers (a[j] = Rhat(row, j)), under

@@ -60,8 +60,12 @@ namespace gar {
 // The 24 x 24 register L D L^T of Rhat (276 broadcast-FMA pairs through v_readlane: 10.6 - 11.8 k cycles of the stage
 // with the other wave idle) as TWO 12-column panels on DPP broadcasts + one MFMA trailing update
 // (gar_ldl_blocked.hpp).  Shapes whose Rhat fits one DPP row (NU <= 16) keep the register version.
+// MEASURED AND NOT ADOPTED (profiles/r06_ab_pair_packed_records_and_blocked_ldl.log, r06_trace_pair_packed_blocked_build.log):
+// backward 14.03 ms with it, 14.03 without; the traced factorisation phase 12.3 k cycles against 11.8 k -- a 12-column
+// DPP panel costs ~6 k cycles by itself (the pivot-to-pivot chain: broadcast, test, reciprocal, scale), two of them
+// plus the LDS round trips of the trailing update are what the 276 v_readlane pairs were.
 #ifndef GAR_PAIR_BLOCKED_LDL
-#define GAR_PAIR_BLOCKED_LDL 1
+#define GAR_PAIR_BLOCKED_LDL 0
 #endif
 
 template <int NX, int NU> struct PairCfg {

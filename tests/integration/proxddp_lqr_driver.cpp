@@ -98,6 +98,32 @@ static TrajOptProblem bench_problem(size_t nsteps, int dim = 56, int nu = 22) {
   return problem;
 }
 
+// the share of a run spent INSIDE the linear solver (every virtual of RiccatiSolverBase, gains included): a
+// pass-through around whichever solver `linear_solver_` holds -- what is left of the run is the reference's own loop
+// (updateLQSubproblem, roll-out, merit function ...) over the Eigen stand-in, on BOTH sides of the comparison
+struct TimedSolver : gar::RiccatiSolverBase<double> {
+  using Base = gar::RiccatiSolverBase<double>;
+  std::unique_ptr<Base> in;
+  mutable double us = 0.0;
+  explicit TimedSolver(std::unique_ptr<Base> s) : in(std::move(s)) {}
+  struct Tick {
+    double &acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Tick(double &a) : acc(a) {}
+    ~Tick() { acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+  };
+  bool backward(const double mu) override { Tick t(us); return in->backward(mu); }
+  bool forward(std::vector<VectorXs> &xs, std::vector<VectorXs> &us_, std::vector<VectorXs> &vs, std::vector<VectorXs> &lbdas,
+               const std::optional<ConstVectorRef> &theta = std::nullopt) const override {
+    Tick t(us);
+    return in->forward(xs, us_, vs, lbdas, theta);
+  }
+  void cycleAppend(const LqrKnot &k) override { Tick t(us); in->cycleAppend(k); }
+  void collapseFeedback() override { Tick t(us); in->collapseFeedback(); }
+  VectorRef getFeedforward(size_t i) override { Tick t(us); return in->getFeedforward(i); }
+  RowMatrixRef getFeedback(size_t i) override { Tick t(us); return in->getFeedback(i); }
+};
+
 enum class Backend { REF, HIP };
 // setup as the reference does; HIP: the public member `linear_solver_` (solver-proxddp.hpp:181) is replaced by the
 // MI355X backend on the SAME workspace_.lqr_problem (for legs: the problem ParallelRiccatiSolver's constructor has
@@ -110,6 +136,12 @@ static void plug(Solver &s, const TrajOptProblem &problem, Backend be, int legs)
   s.setup(problem);
   if (be == Backend::HIP)
     s.linear_solver_ = std::make_unique<gar::HipRiccatiSolver>(s.workspace_.lqr_problem, legs);
+}
+static TimedSolver &timed(Solver &s) { // wraps whatever plug() left in place
+  auto t = std::make_unique<TimedSolver>(std::move(s.linear_solver_));
+  TimedSolver &r = *t;
+  s.linear_solver_ = std::move(t);
+  return r;
 }
 
 static double maxdiff(const std::vector<VectorXd> &a, const std::vector<VectorXd> &b) {
@@ -165,14 +197,25 @@ int main(int argc, char **argv) {
   // ---- 2. bench/lqr.cpp: wall clock of solver.run ---------------------------------------------------------------
   struct Cfg { const char *what; Backend be; int legs; };
   std::string part2 = "";
-  const size_t sizes_full[] = {64, 256}, sizes_quick[] = {16};
+  // horizons: 64 and 256 (rounds 5's rows) and the reference's own, bench/talos-walk.cpp:26-28: 165, 220, 275; the
+  // reference's PARALLEL solver at the thread counts of its benchmark, :94-111: 2, 4, 6, 8
+  const size_t sizes_full[] = {64, 165, 220, 256, 275}, sizes_quick[] = {16};
   const size_t *sizes = quick ? sizes_quick : sizes_full;
-  const size_t nsizes = quick ? 1 : 2;
+  const size_t nsizes = quick ? 1 : 5;
   for (size_t si = 0; si < nsizes; ++si) {
     const size_t nsteps = sizes[si];
     const int big = quick ? 2 : int(nsteps / 8);
-    const Cfg cfgs[] = {{"reference SERIAL", Backend::REF, 1}, {"reference PARALLEL(4 threads)", Backend::REF, quick ? 2 : 4},
-                        {"HIP serial", Backend::HIP, 1}, {"HIP legs", Backend::HIP, big}};
+    std::vector<Cfg> cfgs = {{"reference SERIAL", Backend::REF, 1}};
+    if (quick) {
+      cfgs.push_back({"reference PARALLEL(2 threads)", Backend::REF, 2});
+    } else {
+      cfgs.push_back({"reference PARALLEL(2 threads)", Backend::REF, 2});
+      cfgs.push_back({"reference PARALLEL(4 threads)", Backend::REF, 4});
+      cfgs.push_back({"reference PARALLEL(6 threads)", Backend::REF, 6});
+      cfgs.push_back({"reference PARALLEL(8 threads)", Backend::REF, 8});
+    }
+    cfgs.push_back({"HIP serial", Backend::HIP, 1});
+    cfgs.push_back({"HIP legs", Backend::HIP, big});
     std::vector<VectorXd> xref;
     for (const Cfg &c : cfgs) {
       TrajOptProblem problem = bench_problem(nsteps, quick ? 8 : 56, quick ? 4 : 22);
@@ -184,16 +227,20 @@ int main(int argc, char **argv) {
       Solver solver(1e-7, 1e-10, 2, QUIET);
       solver.force_initial_condition_ = false;
       plug(solver, problem, c.be, c.legs);
-      double best = 1e30;
+      TimedSolver &tm = timed(solver);
+      double best = 1e30, best_in = 0;
       size_t iters = 0;
       bool conv = true;
       const int reps = quick ? 2 : 5;
       for (int rep = 0; rep < reps + 1; ++rep) { // first run: warm-up
+        tm.us = 0.0;
         const auto t0 = std::chrono::steady_clock::now();
         conv = solver.run(problem, xs_init, us_init) && conv;
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        if (rep > 0)
-          best = std::min(best, us);
+        if (rep > 0 && us < best) {
+          best = us;
+          best_in = tm.us;
+        }
         iters = solver.results_.num_iters;
       }
       double dx = 0;
@@ -201,16 +248,16 @@ int main(int argc, char **argv) {
         xref = solver.results_.xs;
       else
         dx = maxdiff(solver.results_.xs, xref);
-      const char *kern = c.be == Backend::HIP ? static_cast<gar::HipRiccatiSolver &>(*solver.linear_solver_).kernelName() : "-";
+      const char *kern = c.be == Backend::HIP ? static_cast<gar::HipRiccatiSolver &>(*tm.in).kernelName() : "-";
       const bool ok = conv && dx <= 1e-7;
       if (!json)
-        std::printf("bench/lqr.cpp  N=%-4zu %-30s legs/threads %-3d run %9.1f us  %zu iteration(s)  => %8.1f ProxDDP iterations/s  |x - ref| %.1e kernel %s %s\n",
-                    nsteps, c.what, c.legs, best, iters, 1e6 * double(iters) / best, dx, kern, ok ? "ok" : "MISMATCH");
+        std::printf("bench/lqr.cpp  N=%-4zu %-30s legs/threads %-3d run %9.1f us (inside the linear solver %8.1f us = %4.1f %%)  %zu iteration(s)  => %8.1f ProxDDP iterations/s  |x - ref| %.1e kernel %s %s\n",
+                    nsteps, c.what, c.legs, best, best_in, 100.0 * best_in / best, iters, 1e6 * double(iters) / best, dx, kern, ok ? "ok" : "MISMATCH");
       bad += !ok;
-      char buf[320];
-      std::snprintf(buf, sizeof buf, "%s\"N%zu %s\": {\"legs_or_threads\": %d, \"us_per_run\": %.1f, \"iterations\": %zu, \"iterations_per_s\": %.1f, "
+      char buf[400];
+      std::snprintf(buf, sizeof buf, "%s\"N%zu %s\": {\"legs_or_threads\": %d, \"us_per_run\": %.1f, \"us_inside_the_linear_solver\": %.1f, \"iterations\": %zu, \"iterations_per_s\": %.1f, "
                     "\"converged\": %s, \"max_dx_vs_reference_serial\": %.2e, \"kernel\": \"%s\"}",
-                    part2.empty() ? "" : ", ", nsteps, c.what, c.legs, best, iters, 1e6 * double(iters) / best, conv ? "true" : "false", dx, kern);
+                    part2.empty() ? "" : ", ", nsteps, c.what, c.legs, best, best_in, iters, 1e6 * double(iters) / best, conv ? "true" : "false", dx, kern);
       part2 += buf;
     }
   }
