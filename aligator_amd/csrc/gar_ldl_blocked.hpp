@@ -53,8 +53,14 @@ struct LdlRowPacked {                  // lower triangle packed by rows: (i, j),
 // pristine matrix).  first_failed: some column failed the first test (diagnostics).
 template <int N, int NB, bool DEFINITE, class WI = LdlColMajor<N>, class LI = LdlRowMajor<N>, bool POSL = false>
 __device__ __forceinline__ int wave_ldl_blocked(double *W, double *npv, double *Lr, double *ndi, int lane,
-                                                bool &first_failed, const bool spd_accept) {
+                                                bool &first_failed, const bool spd_accept, const double dep = 0.0) {
   static_assert(NB % 4 == 0 && NB <= 16 && N <= 64, "panels of k-steps of four inside one DPP row; lane = row");
+  // `dep`: any value the calling stage has just produced.  Every LDS address below is a function of the lane alone:
+  // inside a stage loop the compiler hoists ALL of them out of the loop (~100 loop-invariant registers), finds no room
+  // in a kernel that is full already and SPILLS them -- measured in the coupled stage: 95 scratch reloads, each waited
+  // for with vmcnt(0), on the factorisation's critical path (profiles/r06_ab_coupled_blocked_ldl_not_kept.log).  A lane
+  // index the compiler believes to depend on `dep` keeps the address arithmetic where it is used.
+  lane += fence0(dep);
   const double alpha = (1.0 + 4.123105625617661) / 8.0;
   const int li = lane & 15, lk = lane >> 4;
   const int row = lane < N ? lane : N - 1;

@@ -47,6 +47,9 @@ namespace gar {
 #ifndef GAR_F_DMA
 #define GAR_F_DMA 0
 #endif
+#ifndef GAR_COUPLED_REFRESH_LANE
+#define GAR_COUPLED_REFRESH_LANE 1
+#endif
 
 template <int NX, int NU, int NC = 0> struct WaveCfg {
   using M = MfmaCfg<NX, NU, NC>;
@@ -1336,7 +1339,20 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
       } else {
         if (PHASE == 1 && lane == 0)
           atomicAdd(&P.slow[2], 1);
+#if GAR_COUPLED_REFRESH_LANE
+        // The coupled stage holds every one of the 512 registers; the ~100 loop-invariant lane offsets of WaveLane (and
+        // everything else the compiler derives from the lane index once, outside the stage loop) then live in SCRATCH
+        // and come back through vmcnt(0) waits inside the stage -- 1.42 x the algorithmic bytes in FETCH_SIZE (round 6,
+        // profiles/r06_pmc_and_sq_secondary_shapes.json).  Re-deriving them per stage from a lane index the compiler
+        // cannot prove loop-invariant costs ~100 integer instructions per 100 k-cycle stage.
+        const int lane_t = PHASE == 1 ? lane + fence0(S.fi) : lane;
+        WaveLane<NX, NU, NC> Lt;
+        if constexpr (PHASE == 1)
+          wave_lane_init<NX, NU, NC, QP>(Lt, lane_t);
+        if (!wave_stage2<NX, NU, NC, PHASE == 1>(P, sm, prob, fac, t, lane_t, PHASE == 1 ? Lt : L, S, failed, vflush, tracing)) {
+#else
         if (!wave_stage2<NX, NU, NC, PHASE == 1>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing)) {
+#endif
           if (lane == 0) { // over to the next kernel of the chain from this knot on
             P.resume[b] = t;
             if (PHASE == 1)

@@ -282,7 +282,7 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) {
 // already holds 512 registers, the compiler pays for the blocked routine with ~95 spill reloads from scratch on the
 // factorisation's critical path (84.6 k cycles for the phase).  Results equal to 2e-15.
 #ifndef GAR_COUPLED_BLOCKED_LDL
-#define GAR_COUPLED_BLOCKED_LDL 0
+#define GAR_COUPLED_BLOCKED_LDL 1
 #endif
 namespace gar {
 // The register LDL^T of wave_ldl_fast_neg on rows already in registers (a[j] = Rhat(row, j)), under
@@ -620,7 +620,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
           Lpk[base0 + j] = a44[j];
     }
     wave_lds_order();
-    verdict = wave_ldl_blocked<NK, 12, false, LdlRowPacked, LdlRowPacked>(Lpk, nd44p + ((NK + 3) & ~3), Lpk, nd44p, lane, first_failed, false);
+    verdict = wave_ldl_blocked<NK, 12, false, LdlRowPacked, LdlRowPacked>(Lpk, nd44p + ((NK + 3) & ~3), Lpk, nd44p, lane, first_failed, false, a44[0]);
     wave_lds_order();
 #else
     verdict = wave_ldl_fast_neg_pre<NK, 1>(lane, a44, nd44, first_failed, nd44p);

@@ -321,7 +321,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
       for (int e = lane; e < NU * NU; e += 64)
         Wc[e] = Mm[e];
       wave_lds_order();
-      verdict = wave_ldl_blocked<NU, 12, false>(Wc, npv, Lr, ndi, lane, first_failed, P.spd_accept != 0);
+      verdict = wave_ldl_blocked<NU, 12, false>(Wc, npv, Lr, ndi, lane, first_failed, P.spd_accept != 0, Wc[lane]);
       wave_lds_order();
     }
     if (verdict == 2) { // (the register version: every shape with NU <= 16; a column that needs the complete rule)

@@ -78,7 +78,7 @@ import json; d = json.load(open("$O/pmc_and_sq_secondary_shapes.json"))
 for k, v in d["kernels"].items(): print(k, "fetch GB", round(v["fetch_bytes"] / 1e9, 2), "write GB", round(v["write_bytes"] / 1e9, 2), "traffic / algorithmic", round(v["traffic_over_algorithmic"], 3))
 for k, v in d["sq"].items(): print(k[:60], "mfma busy", round(v.get("mfma_busy_over_4x_wave_cycles", 0), 3), "wait_inst_any", round(v.get("wait_inst_any_over_wave_cycles", 0), 3))
 PY
-  find $R/gpurun_out/secpmc -name "*.csv" -size +200k -delete 2>/dev/null
+  [ -s $O/pmc_and_sq_secondary_shapes.json ] && find $R/gpurun_out/secpmc -name "*.csv" -size +200k -delete 2>/dev/null
 fi
 if has multi; then
   echo "== scripts/first_multi_gpu.sh (one device: every rank / sub-solver on device 0) =="

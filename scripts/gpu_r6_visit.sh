@@ -47,3 +47,13 @@ if has tracecstr; then
   DNONZERO=1 timeout 300 python scripts/trace_cstr.py 1024 2>&1 | grep -vE "amdgpu.ids" | tee $O/trace_cstr_coupled.log
   timeout 300 python scripts/trace_cstr.py 1024 2>&1 | grep -vE "amdgpu.ids" | tee $O/trace_cstr_decoupled.log
 fi
+if has ab3; then
+  echo "== A/B coupled nc32 (D != 0): register 44 x 44 LDL | blocked, LDS addresses kept out of the loop-invariant spills =="
+  SHAPE=nc32c timeout 900 python scripts/ab_shape.py register=libgar_hip.so blocked=libgar_hip_blk2.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab3_nc32c.log
+  echo "== A/B talos: register 24 x 24 | blocked =="
+  SHAPE=talos timeout 900 python scripts/ab_shape.py register=libgar_hip.so blocked=libgar_hip_blk2.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab3_talos.log
+fi
+if has ab4; then
+  echo "== A/B coupled nc32 (D != 0): as it was | register LDL + lane offsets re-derived per stage | blocked LDL + re-derived =="
+  SHAPE=nc32c timeout 900 python scripts/ab_shape.py old=libgar_hip_cpl_old.so register+refresh=libgar_hip_cpl_reg_refresh.so blocked+refresh=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab4_nc32c.log
+fi

@@ -21,7 +21,7 @@ cal = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in counters(os.path.join(root, "cal_" + C), C).items():
         short = "b64" if "b64" in k else "b128" if "b128" in k else "seg32" if "seg32" in k else None
-        if short:
+        if short and sum(v) > 1000:   # (the read-only calibration kernel writes nothing: no WRITE_SIZE:seg32)
             cal[(C, short)] = GiB / (sum(v) / len(v))
             res["calibration"][f"{C}:{short}"] = {"bytes_per_count": cal[(C, short)]}
 fetch = counters(os.path.join(root, "sec_FETCH_SIZE"), "FETCH_SIZE")

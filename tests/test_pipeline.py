@@ -325,3 +325,28 @@ def test_gpu_pipelined_headline_batch_against_the_plain_sweep():
     assert torch.equal(sol, piped)
     assert float(sol.abs().max()) > 0
     s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_the_default_schedule_is_the_librarys_choice():
+    """What a caller gets WITHOUT asking (round 6): a new solver of the headline family starts pipelined once each half of
+    its batch fills every SIMD (batch >= 8 x #CUs), plain below; the default's results are bit for bit those of the plain
+    schedule on the same data (short horizon: the test is about the choice, not the sweep)."""
+    import torch
+    from aligator_amd import synth_device
+    from aligator_amd.gar import BatchedRiccatiSolver
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    nx, nu, N = 36, 12, 8
+    dims = [(nx, nu, 0, nx, 0)] * N + [(nx, 0, 0, nx, 0)]
+    small = BatchedRiccatiSolver(dims, nx, batch=8 * cus - 1)
+    assert small.pipeline == 0 and small.kernel_name == "wave<36,12>"
+    small.close()
+    s = BatchedRiccatiSolver(dims, nx, batch=8 * cus)
+    assert s.pipeline == 2
+    synth_device.fill_problems(s, seed=3, mode="W")
+    piped = _sweep(s, 1e-12, True, steps=2)
+    s.set_pipeline(-1)
+    assert s.pipeline == 2
+    plain = _sweep(s, 1e-12, False)
+    _same(plain, piped)
+    s.close()

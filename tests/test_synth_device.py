@@ -40,3 +40,31 @@ def test_generated_records_are_the_problems_read_back(nx, nu, nc, N, coupled, mu
         err = max(float(np.abs(a - c).max()) for A, B in zip(s.solution(b), ref) for a, c in zip(A, B) if a.size) / scale
         assert err <= 1e-9, (b, err)
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,nu,nc,N,coupled,mu", [(36, 12, 32, 16, False, 1e-11), (36, 12, 32, 16, True, 1e-11), (56, 22, 0, 12, False, 1e-10)])
+def test_gpu_generated_secondary_shapes_against_the_oracle(nx, nu, nc, N, coupled, mu):
+    """bench.py's secondary shapes as it generates them since round 6 (on the device, every problem its own draw): the
+    first and the last problem of a batch larger than the CU count, read back and solved by the oracle."""
+    from aligator_amd.gar import lqrComputeKktError
+    from oracle import oracle as ora
+    dims = [(nx, nu, nc, nx, 0)] * N + [(nx, 0, nc, nx, 0)]
+    s = BatchedRiccatiSolver(dims, nx, batch=300)
+    synth_device.fill_problems(s, seed=9, mode="W", coupled=coupled)
+    assert s.backward(mu) and s.forward()
+    if nc:
+        chain = s.constrained_bk_stages()
+        assert (chain[0] > 0) == coupled
+    for b in (0, 299):
+        prob = synth_device.download_problem(s, b)
+        op = ora.Problem.from_knots(prob.stages, prob.G0, prob.g0)
+        o = ora.ProximalRiccatiSolver(op)
+        o.backward(mu)
+        ref = op.initialize_solution()
+        o.forward(*ref)
+        scale = max(1.0, max(float(np.abs(v).max()) for part in ref for v in part if v.size))
+        err = max(float(np.abs(a - c).max()) for A, B in zip(s.solution(b), ref) for a, c in zip(A, B) if a.size) / scale
+        assert err <= 1e-9, (b, err)
+        assert max(lqrComputeKktError(prob, *s.solution(b), mueq=mu)) / scale <= 1e-9
+    s.close()
