@@ -50,6 +50,12 @@ namespace gar {
 #ifndef GAR_COUPLED_REFRESH_LANE
 #define GAR_COUPLED_REFRESH_LANE 1
 #endif
+#ifndef GAR_SWEEP_REFRESH_LANE  // ... and for the unconstrained headline sweep
+#define GAR_SWEEP_REFRESH_LANE 0
+#endif
+#ifndef GAR_CSTR_REFRESH_LANE   // the same for the decoupled constrained stage (first kernel of the chain)
+#define GAR_CSTR_REFRESH_LANE 0
+#endif
 
 template <int NX, int NU, int NC = 0> struct WaveCfg {
   using M = MfmaCfg<NX, NU, NC>;
@@ -1330,7 +1336,14 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
                                                                    : fac + P.fac_offN + M::tVxx;
   for (int t = tstart; t >= 0; --t) {
     if constexpr (NC == 0) {
+#if GAR_SWEEP_REFRESH_LANE
+      const int lane_t = lane + fence0(S.fi);
+      WaveLane<NX, NU, NC> Lt;
+      wave_lane_init<NX, NU, NC, QP>(Lt, lane_t);
+      wave_stage2<NX, NU, 0, false, (GAR_F_DMA != 0) && !M::WIDE>(P, sm, prob, fac, t, lane_t, Lt, S, failed, vflush, tracing);
+#else
       wave_stage2<NX, NU, 0, false, (GAR_F_DMA != 0) && !M::WIDE>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing);
+#endif
     } else {
       if constexpr (PHASE == 2) {
         if (lane == 0)
@@ -1340,16 +1353,19 @@ __device__ __forceinline__ void gar_backward_wave_body(const MfmaParams &P, int 
         if (PHASE == 1 && lane == 0)
           atomicAdd(&P.slow[2], 1);
 #if GAR_COUPLED_REFRESH_LANE
-        // The coupled stage holds every one of the 512 registers; the ~100 loop-invariant lane offsets of WaveLane (and
-        // everything else the compiler derives from the lane index once, outside the stage loop) then live in SCRATCH
-        // and come back through vmcnt(0) waits inside the stage -- 1.42 x the algorithmic bytes in FETCH_SIZE (round 6,
-        // profiles/r06_pmc_and_sq_secondary_shapes.json).  Re-deriving them per stage from a lane index the compiler
-        // cannot prove loop-invariant costs ~100 integer instructions per 100 k-cycle stage.
-        const int lane_t = PHASE == 1 ? lane + fence0(S.fi) : lane;
+        // The coupled stage held every one of the 512 registers AND 768 bytes of scratch per lane: the ~100 loop-invariant
+        // lane offsets of WaveLane (and everything else the compiler derives from the lane index once, outside the stage
+        // loop) lived in scratch and came back through vmcnt(0) waits inside the stage -- 1.42 x the algorithmic bytes
+        // in FETCH_SIZE (round 6, profiles/r06_pmc_and_sq_secondary_shapes.json).  Re-deriving them per stage from a
+        // lane index the compiler cannot prove loop-invariant costs ~100 integer instructions per stage and leaves the
+        // kernel at 432 registers, no scratch: backward 12.63 -> 7.98 ms at batch 1 024, N = 256 (0.198 -> 0.314 of the
+        // HBM roofline), results BITWISE the same (profiles/r06_ab_coupled_lane_offsets_rederived_per_stage.log).
+        constexpr bool REFRESH = PHASE == 1 || (GAR_CSTR_REFRESH_LANE != 0);
+        const int lane_t = REFRESH ? lane + fence0(S.fi) : lane;
         WaveLane<NX, NU, NC> Lt;
-        if constexpr (PHASE == 1)
+        if constexpr (REFRESH)
           wave_lane_init<NX, NU, NC, QP>(Lt, lane_t);
-        if (!wave_stage2<NX, NU, NC, PHASE == 1>(P, sm, prob, fac, t, lane_t, PHASE == 1 ? Lt : L, S, failed, vflush, tracing)) {
+        if (!wave_stage2<NX, NU, NC, PHASE == 1>(P, sm, prob, fac, t, lane_t, REFRESH ? Lt : L, S, failed, vflush, tracing)) {
 #else
         if (!wave_stage2<NX, NU, NC, PHASE == 1>(P, sm, prob, fac, t, lane, L, S, failed, vflush, tracing)) {
 #endif

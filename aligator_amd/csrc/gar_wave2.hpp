@@ -277,12 +277,18 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) {
 } // namespace gar
 // (the blocked wave-scope L D L^T: built on row_bcast / wave_ballot / wave_lds_order above, used by the coupled stage below)
 #include "gar_ldl_blocked.hpp"
-// MEASURED AND NOT ADOPTED for the coupled stage (profiles/r06_ab_coupled_blocked_ldl_not_kept.log,
-// r06_trace_cstr_coupled.log): backward 15.59 ms against 12.71 with the register version -- inside this kernel, which
-// already holds 512 registers, the compiler pays for the blocked routine with ~95 spill reloads from scratch on the
-// factorisation's critical path (84.6 k cycles for the phase).  Results equal to 2e-15.
+// MEASURED AND NOT ADOPTED for the coupled stage (same box, alternating launches, 1 024 distinct problems):
+//   * first form (profiles/r06_ab_coupled_blocked_ldl_not_kept.log, r06_trace_cstr_coupled.log): backward 15.59 ms
+//     against 12.71 with the register version -- every LDS address of the routine is a function of the lane alone, the
+//     compiler hoisted them out of the stage loop into a kernel that was full and reloaded them from SCRATCH inside
+//     the factorisation (95 reloads, each behind a vmcnt(0)); 84.6 k cycles for the phase;
+//   * with the lane index made opaque per stage (fence0: the addresses are computed where they are used):
+//     11.98 ms against 12.70 (r06_ab_coupled_blocked_ldl_without_address_spills.log);
+//   * and once the SAME cure was applied to the whole coupled stage (GAR_COUPLED_REFRESH_LANE, gar_wave.hpp: no scratch
+//     at all, 432 registers) the register version is the faster one: 7.98 ms against 8.54 blocked
+//     (r06_ab_coupled_lane_offsets_rederived_per_stage.log).  Results equal to 2e-15 throughout.
 #ifndef GAR_COUPLED_BLOCKED_LDL
-#define GAR_COUPLED_BLOCKED_LDL 1
+#define GAR_COUPLED_BLOCKED_LDL 0
 #endif
 namespace gar {
 // The register LDL^T of wave_ldl_fast_neg on rows already in registers (a[j] = Rhat(row, j)), under

@@ -67,6 +67,13 @@ namespace gar {
 #ifndef GAR_PAIR_BLOCKED_LDL
 #define GAR_PAIR_BLOCKED_LDL 0
 #endif
+// (measured and NOT adopted here: 402 instead of 501 registers, a third fewer accumulator-register copies -- and the
+// backward sweep 4 % SLOWER, 14.60 against 14.04 ms; the same on wave<36,12,32> with D = 0 (+5.5 %) and on the headline
+// sweep (+5 %): profiles/r06_ab5_*_lane_offsets_rederived_not_kept.log.  It pays where the parked values had gone to
+// scratch -- the coupled stage -- and nowhere else.)
+#ifndef GAR_PAIR_REFRESH_LANE
+#define GAR_PAIR_REFRESH_LANE 0
+#endif
 
 template <int NX, int NU> struct PairCfg {
   using C = WaveCfg<NX, NU, 0>;
@@ -587,6 +594,30 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
   int failed = 0;
   // one loop per wave: each keeps only ITS tiles in registers across the stages (a common loop would
   // carry the union of both waves' state through either path)
+#if GAR_PAIR_REFRESH_LANE
+  // (as in the coupled constrained stage, gar_wave.hpp GAR_COUPLED_REFRESH_LANE: the lane offsets re-derived per stage
+  // from a lane index the compiler cannot prove loop-invariant, instead of ~100 values parked in accumulator registers
+  // and copied back at every use)
+  if (wave == 0) {
+    WaveStage<NX, NU> S;
+    pair_load<NX, NU, 0, PKD>(recN1, L, S, lane);
+    for (int t = N - 1; t >= 0; --t) {
+      const int lane_t = lane + fence0(S.Fo[0][0][0]);
+      WaveLane<NX, NU, 0> Lt;
+      wave_lane_init<NX, NU, 0, PKD>(Lt, lane_t);
+      pair_stage<NX, NU, 0, PKD>(P, sm, prob, fac, t, lane_t, Lt, S, failed);
+    }
+  } else {
+    WaveStage<NX, NU> S;
+    pair_load<NX, NU, 1, PKD>(recN1, L, S, lane);
+    for (int t = N - 1; t >= 0; --t) {
+      const int lane_t = lane + fence0(S.Fo[PairCfg<NX, NU>::SPLIT][0][0]);
+      WaveLane<NX, NU, 0> Lt;
+      wave_lane_init<NX, NU, 0, PKD>(Lt, lane_t);
+      pair_stage<NX, NU, 1, PKD>(P, sm, prob, fac, t, lane_t, Lt, S, failed);
+    }
+  }
+#else
   if (wave == 0) {
     WaveStage<NX, NU> S;
     pair_load<NX, NU, 0, PKD>(recN1, L, S, lane);
@@ -598,6 +629,7 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
     for (int t = N - 1; t >= 0; --t)
       pair_stage<NX, NU, 1, PKD>(P, sm, prob, fac, t, lane, L, S, failed);
   }
+#endif
   if (failed && lane == 0)
     atomicOr(&P.status[b], failed);
 }

@@ -57,3 +57,11 @@ if has ab4; then
   echo "== A/B coupled nc32 (D != 0): as it was | register LDL + lane offsets re-derived per stage | blocked LDL + re-derived =="
   SHAPE=nc32c timeout 900 python scripts/ab_shape.py old=libgar_hip_cpl_old.so register+refresh=libgar_hip_cpl_reg_refresh.so blocked+refresh=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab4_nc32c.log
 fi
+if has ab5; then
+  echo "== A/B lane offsets re-derived per stage: pair<56,24> =="
+  SHAPE=talos timeout 900 python scripts/ab_shape.py parked=libgar_hip_pairnorefresh.so rederived=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab5_talos.log
+  echo "== ... the decoupled constrained stage wave<36,12,32> =="
+  SHAPE=nc32 timeout 900 python scripts/ab_shape.py parked=libgar_hip.so rederived=libgar_hip_cstrrefresh.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab5_nc32.log
+  echo "== ... the headline sweep wave<36,12>, batch 4096 =="
+  SHAPE=north BATCH=4096 timeout 900 python scripts/ab_shape.py parked=libgar_hip.so rederived=libgar_hip_sweeprefresh.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab5_north.log
+fi
