@@ -74,6 +74,9 @@ namespace gar {
 #ifndef GAR_PAIR_REFRESH_LANE
 #define GAR_PAIR_REFRESH_LANE 0
 #endif
+#ifndef GAR_WIDE_FWD_PIPELINED
+#define GAR_WIDE_FWD_PIPELINED 1
+#endif
 
 template <int NX, int NU> struct PairCfg {
   using C = WaveCfg<NX, NU, 0>;
@@ -663,6 +666,85 @@ __global__ void __launch_bounds__(64) gar_forward_wide(MfmaFwdParams P) {
     sol[lane] = xs;
   for (int e = lane; e < P.nc0; e += 64)
     sol[P.sol_l + e] = io[NX + e]; // lbd0
+#if GAR_WIDE_FWD_PIPELINED
+  if constexpr (VPACK) {
+    // The packed roll-out, software-pipelined (round 6): a stage's operands are two groups -- G1 = its [kff | K],
+    // [yff | Aff] rows (u, x' need them), G2 = the NEXT stage's packed Vxx', vx' (lbd' needs them) -- and each group is
+    // requested again, for the next stage, the moment its registers are free: G1(t + 1) travels under the lbd' phase of
+    // stage t, G2(t + 1) under the u / x' phase of stage t + 1.  Same sums in the same order as the plain loop below.
+    double2_t aff[NX / 2], kro[NX / 2], vp[VO::NCH];
+    double kff, yff, vxn;
+    auto load_g1 = [&](int t) {
+      const double *rec = fac + P.slot(t) * P.fac_rec;
+#pragma unroll
+      for (int m = 0; m < NX / 2; ++m) {
+        kro[m] = *reinterpret_cast<const double2_t *>(rec + M::fFB + iK * NX + 2 * m);
+        aff[m] = *reinterpret_cast<const double2_t *>(rec + M::fFB + (NU + iA) * NX + 2 * m);
+      }
+      kff = rec[M::fFF + iK];
+      yff = rec[M::fFF + NU + iA];
+    };
+    auto load_g2 = [&](int t) {
+      const double *recn = (t + 1 < N) ? fac + P.slot(t + 1) * P.fac_rec : fac + P.fac_offN;
+      const int oVn = (t + 1 < N) ? M::fVxx : M::tVxx, ovn = (t + 1 < N) ? M::fvx : M::tvx;
+#pragma unroll
+      for (int q = 0; q < VO::NCH; ++q) {
+        const int e = 64 * q + lane, ec = (64 * q + 63 < VO::NP2 || e < VO::NP2) ? e : VO::NP2 - 1;
+        vp[q] = *reinterpret_cast<const double2_t *>(recn + oVn + 2 * ec);
+      }
+      vxn = recn[ovn + iA];
+    };
+    if (N > 0) {
+      load_g1(0);
+      load_g2(0);
+    }
+    for (int t = 0; t < N; ++t) {
+      double u0 = kff, u1 = 0.0, x0 = yff, x1 = 0.0;
+#pragma unroll
+      for (int m = 0; m < NX / 2; ++m) {
+        const double xa = lane_bcast(xs, 2 * m), xb = lane_bcast(xs, 2 * m + 1);
+        u0 = __builtin_fma(kro[m].x, xa, u0);
+        u1 = __builtin_fma(kro[m].y, xb, u1);
+        x0 = __builtin_fma(aff[m].x, xa, x0);
+        x1 = __builtin_fma(aff[m].y, xb, x1);
+      }
+      const double u = u0 + u1, xn = x0 + x1;
+      if (lane < NU)
+        sol[P.sol_u + t * NU + lane] = u;
+      if (lane < NX)
+        sol[(t + 1) * NX + lane] = xn;
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < N)
+        load_g1(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      double l0 = vxn, l1 = 0.0; // lbd' = vx' + Vxx' x'  (:369-371)
+      wave_sync(); // (the previous stage's row reads are done)
+#pragma unroll
+      for (int q = 0; q < VO::NCH; ++q) {
+        const int e = 64 * q + lane;
+        if (64 * q + 63 < VO::NP2 || e < VO::NP2)
+          *reinterpret_cast<double2_t *>(&vb[2 * e]) = vp[q];
+      }
+      wave_sync();
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < N)
+        load_g2(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int lowbase = 2 * iA < NX ? iA * NX : (NX - 1 - iA) * (NX + 1) + 1;
+#pragma unroll
+      for (int j = 0; j < NX; j += 2) {
+        const int c0 = 2 * j < NX ? j * NX : (NX - 1 - j) * (NX + 1) + 1;
+        const int c1 = 2 * (j + 1) < NX ? (j + 1) * NX : (NX - 2 - j) * (NX + 1) + 1;
+        l0 = __builtin_fma(vb[iA >= j ? c0 + iA : lowbase + j], lane_bcast(xn, j), l0);
+        l1 = __builtin_fma(vb[iA >= j + 1 ? c1 + iA : lowbase + j + 1], lane_bcast(xn, j + 1), l1);
+      }
+      if (lane < NX)
+        sol[P.sol_l + P.nc0 + t * NX + lane] = l0 + l1;
+      xs = xn;
+    }
+    return;
+  }
+#endif
   for (int t = 0; t < N; ++t) {
     const double *rec = fac + P.slot(t) * P.fac_rec;
     const double *recn = (t + 1 < N) ? fac + P.slot(t + 1) * P.fac_rec : fac + P.fac_offN;

@@ -65,3 +65,7 @@ if has ab5; then
   echo "== ... the headline sweep wave<36,12>, batch 4096 =="
   SHAPE=north BATCH=4096 timeout 900 python scripts/ab_shape.py parked=libgar_hip.so rederived=libgar_hip_sweeprefresh.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab5_north.log
 fi
+if has ab6; then
+  echo "== A/B roll-out of the wide shape: plain loop | software-pipelined =="
+  SHAPE=talos timeout 900 python scripts/ab_shape.py plain=libgar_hip_fwdplain.so pipelined=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab6_talos_forward.log
+fi
