@@ -51,7 +51,10 @@ struct LdlRowPacked {                  // lower triangle packed by rows: (i, j),
 // a column that fails it: with spd_accept the elimination goes on and stands iff every pivot is positive (else 1);
 // without, 2 is returned at once -- the caller runs the complete rule (the unblocked register version, from the
 // pristine matrix).  first_failed: some column failed the first test (diagnostics).
-template <int N, int NB, bool DEFINITE, class WI = LdlColMajor<N>, class LI = LdlRowMajor<N>, bool POSL = false>
+// NPANELS > 0: only the first NPANELS panels are eliminated (with their trailing updates): the caller goes on from the
+// updated matrix in W (the hybrid of the coupled constrained stage: one DPP panel for the Rhat columns, whose trailing
+// update forms the 32 x 32 Schur complement on MFMA tiles, the rest in registers).
+template <int N, int NB, bool DEFINITE, class WI = LdlColMajor<N>, class LI = LdlRowMajor<N>, bool POSL = false, int NPANELS = 0>
 __device__ __forceinline__ int wave_ldl_blocked(double *W, double *npv, double *Lr, double *ndi, int lane,
                                                 bool &first_failed, const bool spd_accept, const double dep = 0.0) {
   static_assert(NB % 4 == 0 && NB <= 16 && N <= 64, "panels of k-steps of four inside one DPP row; lane = row");
@@ -167,6 +170,8 @@ __device__ __forceinline__ int wave_ldl_blocked(double *W, double *npv, double *
       }
     }
     wave_lds_order();
+    if (NPANELS > 0 && p + 1 >= NPANELS)
+      break;
   }
   if (!DEFINITE && spd_accept && first_failed) // the unpivoted factorisation stands only if the matrix proved positive definite
     bad |= __builtin_amdgcn_readfirstlane(minpiv > 0.0 ? 0 : 1);

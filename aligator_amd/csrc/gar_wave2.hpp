@@ -290,6 +290,14 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) {
 #ifndef GAR_COUPLED_BLOCKED_LDL
 #define GAR_COUPLED_BLOCKED_LDL 0
 #endif
+#ifndef GAR_COUPLED_RELOAD_C   // 1: the C operands are loaded again behind the KKT solve (as until round 6); 0: they
+#define GAR_COUPLED_RELOAD_C 0 //    stay in registers (the kernel has room since GAR_COUPLED_REFRESH_LANE): 7.82 -> 7.54 ms
+#endif
+// (the hybrid -- Rhat's columns as one DPP panel with the Schur complement on MFMA tiles, the rest in registers --
+// measured and NOT adopted: 7.95 ms against 7.52, profiles/r06_ab_coupled_hybrid_ldl_not_kept.log)
+#ifndef GAR_COUPLED_HYBRID_LDL
+#define GAR_COUPLED_HYBRID_LDL 0
+#endif
 namespace gar {
 // The register LDL^T of wave_ldl_fast_neg on rows already in registers (a[j] = Rhat(row, j)), under
 // the COMPLETE pivot rule: a column that fails the first test is checked out of line against the
@@ -312,7 +320,8 @@ template <int NU> __device__ __forceinline__ double ldl_bcast(double v, int n, i
 // runs the device Bunch-Kaufman, the reference's own rule (interchanges, 2x2 pivots).  On the reference's generator
 // at the north star 3.7 % of the stages used to take that 85 k-cycle path for interchanges that stability does not
 // need.  GAR_HIP_SPD_ACCEPT=0 follows the reference's pivot rule literally.
-template <int NU, int NDN = NU>
+// (K0 > 0: the columns before K0 have been eliminated already -- the trailing matrix is in a[K0 ..])
+template <int NU, int NDN = NU, int K0 = 0>
 __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], double (&nd)[NDN], bool &first_failed,
                                                      double *nd_lds = nullptr, const bool spd_accept = false) {
   const double alpha = (1.0 + 4.123105625617661) / 8.0;
@@ -320,7 +329,7 @@ __device__ __forceinline__ int wave_ldl_fast_neg_pre(int lane, double (&a)[NU], 
   first_failed = false;
   double minpiv = 1.0; // smallest pivot so far (wave-uniform); NaN-safe: the comparison below is !(x > 0)
 #pragma unroll
-  for (int k = 0; k < NU; ++k) {
+  for (int k = K0; k < NU; ++k) {
     const double akk = ldl_bcast<NU>(a[k], k, lane);
     minpiv = !(akk > 0.0) ? -1.0 : minpiv;
     const unsigned long long nok = wave_ballot(!(fabs(akk) >= alpha * fabs(a[k])) || akk == 0.0);
@@ -612,7 +621,40 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
       else
         a44[j] = (lane == j || (lane >= NK && j == NK - 1)) ? -P.mueq : 0.0;
     }
-#if GAR_COUPLED_BLOCKED_LDL
+#if GAR_COUPLED_HYBRID_LDL
+    // round 6, hybrid: the NU columns of Rhat as ONE DPP panel of the blocked routine (gar_ldl_blocked.hpp) -- its
+    // trailing update forms the NC x NC Schur complement -mu I - D Rhat^{-1} D^T on MFMA tiles instead of NU x NC
+    // broadcast-FMA pairs per lane -- and the Schur complement's own factorisation in registers as before.  In place on
+    // the row-packed matrix in Mm, where the solve reads -L.  A column of the panel that fails the first test: verdict 2.
+    static_assert(NU % 4 == 0 && NU <= 16, "the Rhat columns are one DPP panel");
+    if (lane < NK) {
+      const int base0 = (lane * (lane + 1)) >> 1;
+#pragma unroll
+      for (int j = 0; j < NK; ++j)
+        if (j <= lane)
+          Lpk[base0 + j] = a44[j];
+    }
+    wave_lds_order();
+    verdict = wave_ldl_blocked<NK, NU, false, LdlRowPacked, LdlRowPacked, false, 1>(Lpk, nd44p + ((NK + 3) & ~3), Lpk, nd44p, lane,
+                                                                                    first_failed, false, a44[0]);
+    wave_lds_order();
+    if (verdict == 0) {
+      const int rowh = lane < NK ? lane : NK - 1, baseh = (rowh * (rowh + 1)) >> 1;
+#pragma unroll
+      for (int j = NU; j < NK; ++j)
+        a44[j] = Lpk[j <= rowh ? baseh + j : ((j * (j + 1)) >> 1) + rowh]; // (above the diagonal: the mirror entry, unused)
+      bool ff2;
+      verdict = wave_ldl_fast_neg_pre<NK, 1, NU>(lane, a44, nd44, ff2, nd44p);
+      first_failed |= ff2;
+      if (lane < NK) {
+        const int base1 = (lane * (lane + 1)) >> 1;
+#pragma unroll
+        for (int j = NU; j < NK - 1; ++j)
+          if (j < lane)
+            Lpk[base1 + j] = a44[j];
+      }
+    }
+#elif GAR_COUPLED_BLOCKED_LDL
     // round 6: the 44-row factorisation (946 v_readlane broadcast-FMA pairs in registers) in panels of 12 columns on
     // DPP broadcasts, the trailing matrix updated on MFMA tiles (gar_ldl_blocked.hpp) -- IN PLACE on the matrix packed
     // by rows in Mm, which is exactly where and how the solve below reads -L.  A column that fails Bunch-Kaufman's
@@ -642,7 +684,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   if constexpr (COUPLED) {
     if (verdict != 0)
       return 0;
-#if !GAR_COUPLED_BLOCKED_LDL
+#if !GAR_COUPLED_BLOCKED_LDL && !GAR_COUPLED_HYBRID_LDL
     const int base = (lane * (lane + 1)) >> 1;
 #pragma unroll
     for (int j = 0; j < NK - 1; ++j)
@@ -750,7 +792,9 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
       for (int sc = 0; sc < KC; ++sc)
         Zb[tj][sc] = X[tj][KU + sc];
     }
+#if GAR_COUPLED_RELOAD_C
     load_cop(); // (again, L2 hits: the operands do not stay in registers across the solve)
+#endif
     GAR_WMARK(22)
     // [kff; zff] -> column 0 of G (rows 0..NK-1): read back one entry per lane row below
     if (li == (SPARE_C ? lcc : 0)) {

@@ -69,3 +69,11 @@ if has ab6; then
   echo "== A/B roll-out of the wide shape: plain loop | software-pipelined =="
   SHAPE=talos timeout 900 python scripts/ab_shape.py plain=libgar_hip_fwdplain.so pipelined=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab6_talos_forward.log
 fi
+if has ab7; then
+  echo "== A/B coupled stage: C operands reloaded behind the KKT solve | kept in registers =="
+  SHAPE=nc32c timeout 900 python scripts/ab_shape.py reload=libgar_hip.so keep=libgar_hip_norelc.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab7_nc32c.log
+fi
+if has ab8; then
+  echo "== A/B coupled stage (C operands kept in registers): 44-row register LDL | hybrid: Rhat columns as a DPP panel + MFMA Schur complement, rest in registers =="
+  SHAPE=nc32c timeout 900 python scripts/ab_shape.py register=libgar_hip_nohybrid.so hybrid=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab8_nc32c.log
+fi
