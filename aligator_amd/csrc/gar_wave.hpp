@@ -53,8 +53,8 @@ namespace gar {
 #ifndef GAR_SWEEP_REFRESH_LANE  // ... and for the unconstrained headline sweep
 #define GAR_SWEEP_REFRESH_LANE 0
 #endif
-#ifndef GAR_CSTR_REFRESH_LANE   // the same for the decoupled constrained stage (first kernel of the chain)
-#define GAR_CSTR_REFRESH_LANE 0
+#ifndef GAR_CSTR_REFRESH_LANE   // the same for the decoupled constrained stage (first kernel of the chain): by itself
+#define GAR_CSTR_REFRESH_LANE 1 // +5.5 % slower; together with GAR_CSTR_EARLY_C (gar_wave2.hpp), which needs the room, -9 %
 #endif
 
 template <int NX, int NU, int NC = 0> struct WaveCfg {

@@ -295,6 +295,14 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) {
 #endif
 // (the hybrid -- Rhat's columns as one DPP panel with the Schur complement on MFMA tiles, the rest in registers --
 // measured and NOT adopted: 7.95 ms against 7.52, profiles/r06_ab_coupled_hybrid_ldl_not_kept.log)
+// GAR_CSTR_EARLY_C (round 6; with GAR_CSTR_REFRESH_LANE, gar_wave.hpp): the decoupled constrained stage requests its
+// constraint operands C, d at the START of the stage instead of behind the factorisation (where the leave-early branch
+// keeps the compiler from moving them up): backward 4.54 -> 4.13 ms at batch 1 024 (0.551 -> 0.606 of the roofline),
+// bitwise.  It needs the 80 registers the re-derived lane offsets free: without them the operands spill (5.99 ms).
+// profiles/r06_ab_constrained_stage_c_operands_requested_early.log
+#ifndef GAR_CSTR_EARLY_C
+#define GAR_CSTR_EARLY_C 1
+#endif
 #ifndef GAR_COUPLED_HYBRID_LDL
 #define GAR_COUPLED_HYBRID_LDL 0
 #endif
@@ -450,6 +458,32 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
     for (int j = 0; j < NU; ++j)
       td[j] = ldg_b(rec, M::kD + j * NC, 8u * (unsigned)crow);
   }
+  constexpr int KC1 = KC > 0 ? KC : 1;
+  double Cop[TX][KC1]; // C[4s+lk][16t+li]: A operand (C^T) and, times 1/mu, B operand (Z) of Vxx += C^T Z
+  double Cop4[KC1];    // REM4: C[4s+k4][NX-4+i4]
+  double dz[KC1];      // zff[4s+lk] = d[4s+lk] / mu
+  auto load_cop = [&]() {
+    const int i4c = lane & 3, k4c = lane >> 4;
+#pragma unroll
+    for (int tc = 0; tc < TX; ++tc) {
+      const int x = (16 * tc + li) < NX ? (16 * tc + li) : NX - 1;
+#pragma unroll
+      for (int sc = 0; sc < KC; ++sc)
+        Cop[tc][sc] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)(x * NC + lk));
+    }
+#pragma unroll
+    for (int sc = 0; sc < KC; ++sc)
+      if (C::REM4)
+        Cop4[sc] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)((NX - 4 + i4c) * NC + k4c));
+#pragma unroll
+    for (int sc = 0; sc < KC; ++sc)
+      dz[sc] = ldg_b(rec, M::kd + 4 * sc, 8u * (unsigned)lk);
+  };
+  // (GAR_CSTR_EARLY_C: the constraint operands are requested at the START of the stage, like D -- they used to be
+  // requested behind the factorisation, where the stage's leave-early branch sits in front of them)
+  constexpr bool EARLY_C = NC > 0 && !COUPLED && (GAR_CSTR_EARLY_C != 0); // (the coupled stage has no room for them across its 44-row factorisation)
+  if constexpr (EARLY_C)
+    load_cop();
   double qri1 = 0.0; // WIDE: [q; r][64 + lane]
   if (WIDE)
     qri1 = ldg_b(rec, M::kq + 64, 8u * (unsigned)(lane < NW - 64 ? lane : NW - 65));
@@ -703,31 +737,12 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
         ndi[j] = nd[j];
     }
   }
-  constexpr int KC1 = KC > 0 ? KC : 1;
-  double Cop[TX][KC1]; // C[4s+lk][16t+li]: A operand (C^T) and, times 1/mu, B operand (Z) of Vxx += C^T Z
-  double Cop4[KC1];    // REM4: C[4s+k4][NX-4+i4]
-  double dz[KC1];      // zff[4s+lk] = d[4s+lk] / mu
   const double imu = 1.0 / P.mueq;
-  auto load_cop = [&]() {
-#pragma unroll
-    for (int tc = 0; tc < TX; ++tc) {
-      const int x = (16 * tc + li) < NX ? (16 * tc + li) : NX - 1;
-#pragma unroll
-      for (int sc = 0; sc < KC; ++sc)
-        Cop[tc][sc] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)(x * NC + lk));
-    }
-#pragma unroll
-    for (int sc = 0; sc < KC; ++sc)
-      if (C::REM4)
-        Cop4[sc] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)((NX - 4 + i4) * NC + k4));
-  };
   if (NC > 0) {
     if (verdict != 0 || (!COUPLED && d_nonzero))
       return 0;
-    load_cop();
-#pragma unroll
-    for (int sc = 0; sc < KC; ++sc)
-      dz[sc] = ldg_b(rec, M::kd + 4 * sc, 8u * (unsigned)lk);
+    if constexpr (!EARLY_C)
+      load_cop();
   }
   GAR_WMARK(3)
   // ---- [qhat; rhat] = [q; r] + F^T vx' + P^T f (:217-218, :227-228) ---------------------------

@@ -77,3 +77,7 @@ if has ab8; then
   echo "== A/B coupled stage (C operands kept in registers): 44-row register LDL | hybrid: Rhat columns as a DPP panel + MFMA Schur complement, rest in registers =="
   SHAPE=nc32c timeout 900 python scripts/ab_shape.py register=libgar_hip_nohybrid.so hybrid=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab8_nc32c.log
 fi
+if has ab9; then
+  echo "== A/B decoupled constrained stage wave<36,12,32>: C requested behind the factorisation | at the start of the stage (+ lane offsets re-derived) | at the start only =="
+  SHAPE=nc32 timeout 900 python scripts/ab_shape.py late=libgar_hip.so early+refresh=libgar_hip_earlyc.so early=libgar_hip_earlyc_norefresh.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab9_nc32.log
+fi
