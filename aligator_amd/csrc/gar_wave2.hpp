@@ -303,6 +303,9 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) {
 #ifndef GAR_CSTR_EARLY_C
 #define GAR_CSTR_EARLY_C 1
 #endif
+#ifndef GAR_CSTR_SLOT_C
+#define GAR_CSTR_SLOT_C 1
+#endif
 #ifndef GAR_COUPLED_HYBRID_LDL
 #define GAR_COUPLED_HYBRID_LDL 0
 #endif
@@ -482,7 +485,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   // (GAR_CSTR_EARLY_C: the constraint operands are requested at the START of the stage, like D -- they used to be
   // requested behind the factorisation, where the stage's leave-early branch sits in front of them)
   constexpr bool EARLY_C = NC > 0 && !COUPLED && (GAR_CSTR_EARLY_C != 0); // (the coupled stage has no room for them across its 44-row factorisation)
-  if constexpr (EARLY_C)
+  if constexpr (EARLY_C && !((GAR_CSTR_SLOT_C != 0) && !M::WIDE))
     load_cop();
   double qri1 = 0.0; // WIDE: [q; r][64 + lane]
   if (WIDE)
@@ -517,7 +520,12 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   using VO = VxxOut<NX, GAR_VXX_PACKED && !WIDE, PK>;
   constexpr int NCH = VO::NCH;
   constexpr int nA_flush = NCH + 2, nA_rows = NU, nA_bop = TX * KU + (C::REM4 ? KU : 0);
-  constexpr int nA = nA_flush + nA_rows + nA_bop;
+  // (EARLY_C && GAR_CSTR_SLOT_C: the constraint operands C, d join the list instead of being issued in one burst at the
+  // start of the stage -- 40 more loads behind the MFMAs of the state tile columns)
+  constexpr bool SLOT_C = EARLY_C && (GAR_CSTR_SLOT_C != 0) && !WIDE;
+  constexpr int nA_cop = SLOT_C ? TX * KC + (C::REM4 ? KC : 0) + KC : 0;
+  constexpr int nA_base = nA_flush + nA_rows + nA_bop;
+  constexpr int nA = nA_base + nA_cop;
   double2_t vbuf[NCH];
   const int frow = lane < NU ? lane : NU - 1;
   auto slotA = [&](int i) { // i: compile-time after unrolling
@@ -536,7 +544,20 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
     } else if (i < nA_flush + nA_rows) { // Rhat, lane = row
       const int j = i - nA_flush;
       a_row[j < NU ? j : 0] = Mm[j * NU + frow];
-    } else if (i < nA) {
+    } else if (i >= nA_base) { // (SLOT_C) C[4s+lk][16t+li], the REM4 operands, d
+      const int q = i - nA_base;
+      if (q < TX * KC) {
+        const int tc = q / KC1, sc = q % KC1;
+        const int x = (16 * tc + li) < NX ? (16 * tc + li) : NX - 1;
+        Cop[tc < TX ? tc : 0][sc] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)(x * NC + lk));
+      } else if (C::REM4 && q < TX * KC + KC) {
+        const int sc = q - TX * KC;
+        Cop4[sc < KC1 ? sc : 0] = ldg_b(rec, M::kC + 4 * sc, 8u * (unsigned)((NX - 4 + (lane & 3)) * NC + (lane >> 4)));
+      } else {
+        const int sc = q - TX * KC - (C::REM4 ? KC : 0);
+        dz[sc < KC1 ? sc : 0] = ldg_b(rec, M::kd + 4 * sc, 8u * (unsigned)lk);
+      }
+    } else if (i < nA_base) {
       const int q = i - nA_flush - nA_rows;
       if (q < TX * KU) {
         const int ti = q / KU, sq = q % KU;
@@ -894,7 +915,7 @@ __device__ __forceinline__ int wave_stage2(const MfmaParams &P, double *sm, cons
   GAR_WMARK(6)
   if (WIDE) {
 #pragma unroll
-    for (int i = nA_flush + nA_rows; i < nA; ++i)
+    for (int i = nA_flush + nA_rows; i < nA_base; ++i)
       slotA(i); // B as the A operand of Aff, and of yff = f + B kff
   }
   // ---- kff; yff = f + B kff (:266); vx = qhat + Shat kff (:275-276) ----------------

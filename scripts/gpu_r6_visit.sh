@@ -81,3 +81,7 @@ if has ab9; then
   echo "== A/B decoupled constrained stage wave<36,12,32>: C requested behind the factorisation | at the start of the stage (+ lane offsets re-derived) | at the start only =="
   SHAPE=nc32 timeout 900 python scripts/ab_shape.py late=libgar_hip.so early+refresh=libgar_hip_earlyc.so early=libgar_hip_earlyc_norefresh.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab9_nc32.log
 fi
+if has ab10; then
+  echo "== A/B decoupled constrained stage: C requested in one burst at the start | slotted behind the first half's MFMAs =="
+  SHAPE=nc32 timeout 900 python scripts/ab_shape.py burst=libgar_hip_noslotc.so slotted=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab10_nc32.log
+fi
