@@ -72,7 +72,16 @@ namespace gar {
 // sweep (+5 %): profiles/r06_ab5_*_lane_offsets_rederived_not_kept.log.  It pays where the parked values had gone to
 // scratch -- the coupled stage -- and nowhere else.)
 #ifndef GAR_PAIR_REFRESH_LANE
-#define GAR_PAIR_REFRESH_LANE 0
+#define GAR_PAIR_REFRESH_LANE 1   // (by itself a loss, see above; the uneven first half below needs the room it makes)
+#endif
+// Uneven FIRST half (round 6): wave 1 keeps only the tile columns that hold Rhat ({3, 4} at (56, 24): 154 MFMAs) and
+// factorises Rhat right behind them, while wave 0 computes the three state tile columns {0, 1, 2} (336 MFMAs): the two
+// sides are balanced at ~22-23 k cycles and ONE workgroup barrier replaces two (the 24 x 24 factorisation, ~12 k cycles,
+// used to run with wave 0 idle behind an even 238 / 252 split).  The second half keeps its even split by STATE columns
+// ({0, 1} / {2, 3}): what wave 1 then needs of tile column 2 comes through LDS -- Shat^T from G, where it is exported
+// anyway, the two Qhat tiles through a 4 KB hand-off buffer.
+#ifndef GAR_PAIR_UNEVEN
+#define GAR_PAIR_UNEVEN 1
 #endif
 #ifndef GAR_WIDE_FWD_PIPELINED
 #define GAR_WIDE_FWD_PIPELINED 1
@@ -90,8 +99,15 @@ template <int NX, int NU> struct PairCfg {
   static constexpr int oFlag2 = oHq + ((C::NW + 1) & ~1);  // verdict of the factorisation (int)
   static constexpr bool BLK = GAR_PAIR_BLOCKED_LDL && NU > 16 && NU % 4 == 0;
   static constexpr int oLdl = oFlag2 + 2;                  // blocked factorisation: working copy of Rhat | -d_k
-  static constexpr int total = oLdl + (BLK ? LdlBlockedLds<NU>::total : 0);
-  __host__ __device__ static constexpr int owner(int tj) { return tj >= SPLIT ? 1 : 0; }
+  // first-half split (tile columns >= SPLIT1 belong to wave 1): uneven for the wide shape, where Rhat's tiles all lie in
+  // the columns >= NX / 16
+  static constexpr bool UNEVEN = GAR_PAIR_UNEVEN && MfmaCfg<NX, NU, 0>::WIDE && (NX >> 4) > SPLIT;
+  static constexpr int SPLIT1 = UNEVEN ? (NX >> 4) : SPLIT;
+  static constexpr int nXq = UNEVEN ? (SPLIT1 - SPLIT) * C::TX * 4 * 64 : 0; // hand-off of the Qhat tiles of the columns that change hands
+  static constexpr int oXq = oLdl + (BLK ? LdlBlockedLds<NU>::total : 0);
+  static constexpr int total = oXq + nXq;
+  __host__ __device__ static constexpr int owner(int tj) { return tj >= SPLIT ? 1 : 0; }   // second half: state columns
+  __host__ __device__ static constexpr int owner1(int tj) { return tj >= SPLIT1 ? 1 : 0; } // first half: tile columns
 };
 
 // knot t's operands for wave W: F tile columns it multiplies with (all of them for wave 0: H(ti, tj)
@@ -156,7 +172,7 @@ __device__ __forceinline__ void pair_load(const double *rec, const LANE &L, Wave
   bool have[C::TW] = {};
 #pragma unroll
   for (int tj = C::TW - 1; tj >= 0; --tj) {
-    if (PC::owner(tj) != W)
+    if (PC::owner1(tj) != W)
       continue;
 #pragma unroll
     for (int ti = tj; ti < C::TW; ++ti) {
@@ -167,6 +183,10 @@ __device__ __forceinline__ void pair_load(const double *rec, const LANE &L, Wave
       pair_load_H<NX, NU, QP>(rec, L, S, ti, tj);
     }
   }
+#pragma unroll
+  for (int t = 0; t < C::TW; ++t) // (F columns a wave needs for Aff only)
+    if (!have[t] && !(W == 1 && t < PC::SPLIT))
+      pair_load_F<NX, NU>(rec, L, S, t, lane);
 #else
 #pragma unroll
   for (int t = 0; t < C::TW; ++t)
@@ -176,7 +196,7 @@ __device__ __forceinline__ void pair_load(const double *rec, const LANE &L, Wave
   for (int ti = 0; ti < C::TW; ++ti)
 #pragma unroll
     for (int tj = 0; tj <= ti; ++tj)
-      if (PC::owner(tj) == W)
+      if (PC::owner1(tj) == W)
         pair_load_H<NX, NU, QP>(rec, L, S, ti, tj);
 #endif
 }
@@ -229,14 +249,14 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   double qrv[TW]; // [q; r] entries of this wave's columns: issued here, used after the products
 #pragma unroll
   for (int tj = 0; tj < TW; ++tj)
-    if (PC::owner(tj) == W) {
+    if (PC::owner1(tj) == W) {
       const int j = 16 * tj + li;
       qrv[tj] = ldg_b(rec, M::kq + (16 * tj + 15 < NW ? 16 * tj : 0), 16 * tj + 15 < NW ? lib : 8u * (unsigned)(j < NW ? j : NW - 1));
     }
   double part[TW];
 #pragma unroll
   for (int tj = TW - 1; tj >= 0; --tj) {
-    if (PC::owner(tj) != W)
+    if (PC::owner1(tj) != W)
       continue;
     double4_t Pt[TX];
 #pragma unroll
@@ -291,7 +311,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   // ---- [qhat; rhat] entries of this wave's columns (:217-218, :227-228), Shat^T, Rhat -> LDS -------
 #pragma unroll
   for (int tj = 0; tj < TW; ++tj) {
-    if (PC::owner(tj) != W)
+    if (PC::owner1(tj) != W)
       continue;
     const int j = 16 * tj + li;
     const double e = qrv[tj] + rows_sum(part[tj], lane);
@@ -305,7 +325,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
   for (int ti = 0; ti < TW; ++ti)
 #pragma unroll
     for (int tj = 0; tj <= ti; ++tj) {
-      if (PC::owner(tj) != W)
+      if (PC::owner1(tj) != W)
         continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -318,8 +338,24 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
         }
       }
     }
+  double *Xq = sm + PC::oXq;
+  if constexpr (PC::UNEVEN) { // the Qhat tiles of the state columns that change hands (computed here, consumed by the other wave)
+#pragma unroll
+    for (int tj = 0; tj < TX; ++tj) {
+      if (!(PC::owner1(tj) == W && PC::owner(tj) != W))
+        continue;
+#pragma unroll
+      for (int ti = tj; ti < TX; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Xq[(((tj - PC::SPLIT) * TX + ti) * 4 + r) * 64 + lane] = S.Hc[ti][tj][r];
+    }
+  }
   GAR_PMARK(2)
-  __syncthreads(); // (1) [qhat; rhat], Shat^T, Rhat in LDS
+  if constexpr (!PC::UNEVEN)
+    __syncthreads(); // (1) [qhat; rhat], Shat^T, Rhat in LDS
+  else
+    wave_lds_order(); // (uneven split: Rhat is this wave's own export; everything else is read behind barrier (2))
   GAR_PMARK(3)
   // ---- wave 1: register LDL^T of Rhat under the complete Bunch-Kaufman rule; -L, -1/d -> LDS -------
   if (W == 1) {
@@ -360,7 +396,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
           atomicAdd(&P.slow[1], 1);
       }
     }
-    if (verdict != 0) {
+    if (!PC::UNEVEN && verdict != 0) {
       // Bunch-Kaufman interchanges or takes a 2x2 pivot here: the generic device Bunch-Kaufman, exactly
       // what the reference does, by this wave alone; [kff | K] goes to the V buffer (V' is dead until
       // this stage's Vxx is written), Shat^T stays in G for the Vxx products
@@ -378,9 +414,26 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
     }
   }
   GAR_PMARK(4)
-  __syncthreads(); // (2) the factorisation (or [kff | K] itself) is in LDS
+  __syncthreads(); // (2) the factorisation (or [kff | K] itself) is in LDS  [uneven split: AND everybody's exports]
   GAR_PMARK(5)
   const int verdict = flag[0];
+  if constexpr (PC::UNEVEN) {
+    if (verdict != 0) { // (wave-uniform over the workgroup) the device Bunch-Kaufman needs wave 0's Shat^T in G: behind the barrier
+      if (W == 1) {
+        double *Kv = V;
+        for (int e = lane; e < NU * PG; e += 64)
+          Kv[e] = -G[e];
+        double *sub = sm + C::oBk;
+        int *piv = (int *)(sub + C::BKS);
+        const WG w1 = wave_self();
+        wave_sync();
+        failed |= wg_bk_factor(w1, NU, Mm, NU, sub, piv, piv + C::BKS);
+        wg_bk_solve(w1, NU, Mm, NU, sub, piv, Kv, PG, 1, NX + 1);
+        wave_sync();
+      }
+      __syncthreads();
+    }
+  }
   // ---- [kff | K] = -Rhat^{-1} [rhat | Shat^T] (:248-262) for this wave's state columns ------------
   double Kb[TX][KU];
   constexpr int lc = NX % 16;
@@ -404,7 +457,9 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
         continue;
 #pragma unroll
       for (int sp = 0; sp < KU; ++sp) {
-        const double sv = S.Hc[C::shTile(sp)][tj][C::shReg(sp)]; // Shat^T(4sp+lk, 16tj+li)
+        // Shat^T(4sp+lk, 16tj+li): this wave's own tile registers, or (a column the other wave computed) its export in G
+        const int cs = (16 * tj + li) < NX ? (16 * tj + li) : NX - 1;
+        const double sv = PC::owner1(tj) == W ? S.Hc[C::shTile(sp)][tj][C::shReg(sp)] : G[(4 * sp + lk) * PG + 1 + cs];
         const double g0 = tj == TX - 1 ? G[(4 * sp + lk) * PG] : 0.0; // (read by every lane, then selected: a
         Kb[tj][sp] = (tj == TX - 1 && li == lc) ? g0 : sv;            //  conditional load becomes a branch)
       }
@@ -520,7 +575,18 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
       continue;
 #pragma unroll
     for (int ti = tj; ti < TX; ++ti) {
-      double4_t acc = S.Hc[ti][tj];
+      double4_t acc;
+      if constexpr (PC::UNEVEN) {
+        if (PC::owner1(tj) == W) {
+          acc = S.Hc[ti][tj];
+        } else { // Qhat of a column the other wave computed: through the hand-off buffer
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[r] = Xq[(((tj - PC::SPLIT) * TX + ti) * 4 + r) * 64 + lane];
+        }
+      } else {
+        acc = S.Hc[ti][tj];
+      }
       const int ic = (16 * ti + li) < NX ? (16 * ti + li) : NX - 1;
 #pragma unroll
       for (int s = 0; s < KU; ++s)

@@ -85,3 +85,7 @@ if has ab10; then
   echo "== A/B decoupled constrained stage: C requested in one burst at the start | slotted behind the first half's MFMAs =="
   SHAPE=nc32 timeout 900 python scripts/ab_shape.py burst=libgar_hip_noslotc.so slotted=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab10_nc32.log
 fi
+if has ab11; then
+  echo "== A/B pair<56,24>: even first half | uneven (Rhat columns + factorisation on wave 1) with lane offsets re-derived | uneven with the spills =="
+  SHAPE=talos timeout 900 python scripts/ab_shape.py even=libgar_hip_pair_even.so uneven=libgar_hip.so uneven_spilling=libgar_hip_pair_uneven_spill.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab11_talos.log
+fi
