@@ -39,6 +39,7 @@ namespace gar { // instantiated in gar_wave_sweep.cpp (its own translation unit,
   extern template __global__ void gar_backward_wave<NX, NU, 0>(MfmaParams, int);                                       \
   extern template __global__ void gar_backward_wave_half<NX, NU>(MfmaParams, int);
 GAR_SWEEP_SHAPES(GAR_SWEEP_EXTERN)
+  extern template __global__ void gar_backward_wave<56, 24, 0>(MfmaParams, int); // gar_wave_wide.cpp
 #undef GAR_SWEEP_EXTERN
 } // namespace gar
 
