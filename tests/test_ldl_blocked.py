@@ -15,12 +15,19 @@ from aligator_amd import synth
 import parity_cases as pc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "emu", "_build", "blocked", "libgar_hip_emu.so")
 
 
-def test_blocked_ldl_in_the_pair_and_coupled_stages():
-    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu"), "BUILD=_build/blocked",
-                    "SAN=-DGAR_PAIR_BLOCKED_LDL=1 -DGAR_COUPLED_BLOCKED_LDL=1", "_build/blocked/libgar_hip_emu.so"], check=True)
+import pytest
+
+
+@pytest.mark.parametrize("build,switches", [("blocked", "-DGAR_PAIR_BLOCKED_LDL=1 -DGAR_COUPLED_BLOCKED_LDL=1"),
+                                            # the hybrid of the coupled stage: Rhat's columns as ONE panel (NPANELS = 1), the
+                                            # Schur complement's factorisation in registers from column NU on (K0 = NU)
+                                            ("hybrid", "-DGAR_COUPLED_HYBRID_LDL=1 -DGAR_PAIR_REFRESH_LANE=0 -DGAR_PAIR_UNEVEN=0")])
+def test_blocked_ldl_in_the_pair_and_coupled_stages(build, switches):
+    LIB = os.path.join(HERE, "emu", "_build", build, "libgar_hip_emu.so")
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu"), f"BUILD=_build/{build}",
+                    f"SAN={switches}", f"_build/{build}/libgar_hip_emu.so"], check=True)
     from aligator_amd.gar import BatchedRiccatiSolver
     from oracle import oracle as ora
     rng = np.random.default_rng(3)
