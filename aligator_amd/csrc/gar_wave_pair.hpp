@@ -83,6 +83,9 @@ namespace gar {
 #ifndef GAR_PAIR_UNEVEN
 #define GAR_PAIR_UNEVEN 1
 #endif
+#ifndef GAR_PAIR_EARLY_LOADS
+#define GAR_PAIR_EARLY_LOADS 1
+#endif
 #ifndef GAR_WIDE_FWD_PIPELINED
 #define GAR_WIDE_FWD_PIPELINED 1
 #endif
@@ -103,6 +106,7 @@ template <int NX, int NU> struct PairCfg {
   // the columns >= NX / 16
   static constexpr bool UNEVEN = GAR_PAIR_UNEVEN && MfmaCfg<NX, NU, 0>::WIDE && (NX >> 4) > SPLIT;
   static constexpr int SPLIT1 = UNEVEN ? (NX >> 4) : SPLIT;
+  static constexpr bool EARLY = UNEVEN && (GAR_PAIR_EARLY_LOADS != 0) && !GAR_PAIR_ORDER;
   static constexpr int nXq = UNEVEN ? (SPLIT1 - SPLIT) * C::TX * 4 * 64 : 0; // hand-off of the Qhat tiles of the columns that change hands
   static constexpr int oXq = oLdl + (BLK ? LdlBlockedLds<NU>::total : 0);
   static constexpr int total = oXq + nXq;
@@ -161,10 +165,19 @@ __device__ __forceinline__ void pair_load_H(const double *rec, const LANE &L, Wa
       S.Hc[ti][tj][r] = 0.0;
   }
 }
-template <int NX, int NU, int W, bool QP = false, class LANE>
+// PART (uneven first half, GAR_PAIR_EARLY_LOADS): 0 = everything; 1 = only what this wave's registers can take right
+// behind its FIRST half -- wave 0: F's tile columns >= SPLIT (its Aff needs the first SPLIT only) and the Hessian tiles of
+// the state columns it computed for wave 1; wave 1: F's pure control column(s) and the Rhat-only tile(s) --; 2 = the rest.
+// The workgroup barriers of the stage are fences the compiler does not move loads across: without the split every one of
+// these requests waits for the end of the stage although its destination has been dead since the first half.
+template <int NX, int NU, int W, bool QP = false, int PART = 0, class LANE>
 __device__ __forceinline__ void pair_load(const double *rec, const LANE &L, WaveStage<NX, NU> &S, int lane) {
   using C = WaveCfg<NX, NU>;
   using PC = PairCfg<NX, NU>;
+  [[maybe_unused]] auto early_F = [](int t) { return PC::UNEVEN && (W == 0 ? t >= PC::SPLIT : 16 * t >= NX); };
+  [[maybe_unused]] auto early_H = [](int ti, int tj) {
+    return PC::UNEVEN && (W == 0 ? PC::owner(tj) == 1 : (16 * tj >= NX && 16 * ti >= NX));
+  };
 #if GAR_PAIR_ORDER
   // in the order the next stage consumes them (loads return in order: its first products wait for the first pieces
   // only): tile columns from the last one down -- F(:, tj) feeds P(:, tj), then H(ti, tj), ti = tj .., wants F(:, ti)
@@ -190,13 +203,13 @@ __device__ __forceinline__ void pair_load(const double *rec, const LANE &L, Wave
 #else
 #pragma unroll
   for (int t = 0; t < C::TW; ++t)
-    if (!(W == 1 && t < PC::SPLIT))
+    if (!(W == 1 && t < PC::SPLIT) && (PART == 0 || (PART == 1) == early_F(t)))
       pair_load_F<NX, NU>(rec, L, S, t, lane);
 #pragma unroll
   for (int ti = 0; ti < C::TW; ++ti)
 #pragma unroll
     for (int tj = 0; tj <= ti; ++tj)
-      if (PC::owner1(tj) == W)
+      if (PC::owner1(tj) == W && (PART == 0 || (PART == 1) == early_H(ti, tj)))
         pair_load_H<NX, NU, QP>(rec, L, S, ti, tj);
 #endif
 }
@@ -356,6 +369,8 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
     __syncthreads(); // (1) [qhat; rhat], Shat^T, Rhat in LDS
   else
     wave_lds_order(); // (uneven split: Rhat is this wave's own export; everything else is read behind barrier (2))
+  if constexpr (PC::EARLY)
+    pair_load<NX, NU, W, PKD, 1>(recn, L, S, lane); // knot t-1 into the registers the first half released
   GAR_PMARK(3)
   // ---- wave 1: register LDL^T of Rhat under the complete Bunch-Kaufman rule; -L, -1/d -> LDS -------
   if (W == 1) {
@@ -608,7 +623,7 @@ __device__ __forceinline__ void pair_stage(const MfmaParams &P, double *sm, cons
     }
   }
   GAR_PMARK(10)
-  pair_load<NX, NU, W, PKD>(recn, L, S, lane); // knot t-1 into the registers this stage released
+  pair_load<NX, NU, W, PKD, PC::EARLY ? 2 : 0>(recn, L, S, lane); // knot t-1 into the registers this stage released
   GAR_PMARK(11)
   __syncthreads(); // (4) V, vx complete
   GAR_PMARK(12)

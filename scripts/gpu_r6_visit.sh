@@ -89,3 +89,7 @@ if has ab11; then
   echo "== A/B pair<56,24>: even first half | uneven (Rhat columns + factorisation on wave 1) with lane offsets re-derived | uneven with the spills =="
   SHAPE=talos timeout 900 python scripts/ab_shape.py even=libgar_hip_pair_even.so uneven=libgar_hip.so uneven_spilling=libgar_hip_pair_uneven_spill.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab11_talos.log
 fi
+if has ab12; then
+  echo "== A/B pair<56,24> (uneven first half): next-knot operands all at the end of the stage | what the first half released, right behind it =="
+  SHAPE=talos timeout 900 python scripts/ab_shape.py late=libgar_hip_pair_late.so early=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab12_talos.log
+fi
