@@ -75,6 +75,28 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
     return; // a leg made of the terminal knot alone
   int failed = 0;
   const double *rec1 = prob + P.in_off0 + P.slot(t_first) * P.in_rec;
+#if GAR_PAIR_REFRESH_LANE
+  // (the lane offsets re-derived per stage, as in gar_backward_pair: the uneven first half of pair_stage needs the room)
+  if (wave == 0) {
+    WaveStage<NX, NU> S;
+    pair_load<NX, NU, 0>(rec1, L, S, lane);
+    for (int t = t_first; t >= t_beg; --t) {
+      const int lane_t = lane + fence0(S.Fo[0][0][0]);
+      WaveLane<NX, NU, 0> Lt;
+      wave_lane_init<NX, NU>(Lt, lane_t);
+      pair_stage<NX, NU, 0>(P, sm, prob, fac, t, lane_t, Lt, S, failed);
+    }
+  } else {
+    WaveStage<NX, NU> S;
+    pair_load<NX, NU, 1>(rec1, L, S, lane);
+    for (int t = t_first; t >= t_beg; --t) {
+      const int lane_t = lane + fence0(S.Fo[PairCfg<NX, NU>::SPLIT][0][0]);
+      WaveLane<NX, NU, 0> Lt;
+      wave_lane_init<NX, NU>(Lt, lane_t);
+      pair_stage<NX, NU, 1>(P, sm, prob, fac, t, lane_t, Lt, S, failed);
+    }
+  }
+#else
   if (wave == 0) {
     WaveStage<NX, NU> S;
     pair_load<NX, NU, 0>(rec1, L, S, lane);
@@ -86,6 +108,7 @@ __global__ void __launch_bounds__(128, (NX + NU > 64) ? 1 : 2) gar_backward_pair
     for (int t = t_first; t >= t_beg; --t)
       pair_stage<NX, NU, 1>(P, sm, prob, fac, t, lane, L, S, failed);
   }
+#endif
   if (failed && lane == 0)
     atomicOr(&P.status[b], failed);
 }
