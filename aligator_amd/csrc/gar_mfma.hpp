@@ -100,7 +100,10 @@ template <int NX, int NU, int NC = 0> struct MfmaCfg {
   // fallback solves in place there; sub (16) and piv+ctrl (16 doubles) follow
   static constexpr int oG2 = (oVp + NX + 1) & ~1;
   static constexpr int oBk = oG2 + NU * PG + 16;
-  static constexpr int total = oBk + 16 + 16;
+  // (gar_backward_mfma, GAR_MFMA_EARLY_FACTOR: L of Rhat, 1 / d_k and the verdict, handed from the worker wave that
+  // factorises to wave 3, which solves)
+  static constexpr int oLf = oBk + 16 + 16;
+  static constexpr int total = oLf + NU * NU + NU + 2;
   // record offsets (uniform stage / terminal knot)
   static constexpr int kQ = 0, kS = NX * NX, kR = kS + NX * NU, kq = kR + NU * NU, kr = kq + NX,
                        kA = kr + NU, kB = kA + NX * NX, kf = kB + NX * NU;
@@ -275,10 +278,20 @@ __device__ __forceinline__ void ldl_solve_bcast(const double (&a)[NU], const dou
   }
 }
 
+#ifndef GAR_MFMA_EARLY_FACTOR
+#define GAR_MFMA_EARLY_FACTOR 1
+#endif
+// (GAR_MFMA_EARLY_H measured and NOT adopted: backward 1.786 against 1.741 ms at batch 256 -- the tiles' latency was
+// hidden behind the first product already; profiles/r06_ab_mfma_4wave_early_hessian_tiles_not_kept.log)
+#ifndef GAR_MFMA_EARLY_H
+#define GAR_MFMA_EARLY_H 0
+#endif
 template <int NX, int NU>
 __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
   using C = MfmaCfg<NX, NU>;
   static_assert(C::TW <= 3 && NU <= 16, "one column tile per worker wave (3 workers), NW <= 64");
+  // Rhat (rows / columns NX .. NW-1) inside the LAST tile column alone: the worker that holds it factorises it
+  constexpr bool EARLY_FACTOR = (GAR_MFMA_EARLY_FACTOR != 0) && (NX >= 16 * (C::TW - 1));
   constexpr int NW = C::NW, PK = C::PK, PG = C::PG;
   double *sm = gar_smem;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -334,14 +347,13 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
     const int tj = wave;
     const int c = 16 * tj + li;               // this lane's column in tile tj
     const int cc = c < NX ? c : NX - 1;
-    for (int t = N - 1; t >= 0; --t) {
-      GAR_MARK(0)
+    double4_t Hc[C::TW]; // H tiles (ti, tj), ti >= tj
+    // C-init of H from the knot record (lower elements).  GAR_MFMA_EARLY_H: the tiles of knot t - 1 are requested at the
+    // END of stage t, before its last workgroup barrier -- a fence the compiler does not move loads across -- instead
+    // of at the start of stage t - 1, where their HBM latency had only the first product to hide behind
+    auto load_h = [&](int t) {
       const double *rec = prob + P.in_off0 + P.slot(t) * P.in_rec;
-      double *out = fac + P.slot(t) * P.fac_rec;
-      const double *Ft = sm + ((t & 1) ? C::oFt1 : C::oFt0);
-      double4_t Hc[C::TW]; // H tiles (ti, tj), ti >= tj
       if (tj < C::TW) {
-        // C-init of H from the knot record (lower elements); the HBM latency hides under S1
 #pragma unroll
         for (int ti = 0; ti < C::TW; ++ti)
           if (ti >= tj) {
@@ -349,6 +361,17 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
             for (int r = 0; r < 4; ++r)
               Hc[ti][r] = w_lower<NX, NU>(rec, 16 * ti + lk + 4 * r, c);
           }
+      }
+    };
+    if (GAR_MFMA_EARLY_H && N > 0)
+      load_h(N - 1);
+    for (int t = N - 1; t >= 0; --t) {
+      GAR_MARK(0)
+      double *out = fac + P.slot(t) * P.fac_rec;
+      const double *Ft = sm + ((t & 1) ? C::oFt1 : C::oFt0);
+      if (!GAR_MFMA_EARLY_H)
+        load_h(t);
+      if (tj < C::TW) {
         // S1: P(:, tj) = V' F(:, tj)            (:216-221, AtV / BtV fused)
         double4_t Pt[C::TX];
 #pragma unroll
@@ -391,6 +414,36 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
               }
             }
           }
+      }
+      if constexpr (EARLY_FACTOR) {
+        // Rhat lies in this worker's tile alone (the last tile column): it is factorised HERE, right behind the export,
+        // while the workers of the wider tile columns are still multiplying -- wave 3 then only solves behind barrier A
+        // (the 12 x 12 factorisation used to sit between the two barriers with all three workers idle)
+        if (tj == C::TW - 1) {
+          wave_sync(); // (this wave's own export of Rhat is what it reads: LDS order within the wave)
+          double a_row[NU], dinv[NU];
+          int verdict = wave_ldl_lean<NU>(Mm, lane, a_row, dinv);
+          if (verdict != 0) { // rare: evaluate the complete Bunch-Kaufman rule
+            verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
+            if (lane == 0) {
+              atomicAdd(&P.slow[0], 1);
+              if (verdict != 0)
+                atomicAdd(&P.slow[1], 1);
+            }
+          }
+          double *Lf = sm + C::oLf;
+          if (lane < NU) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j)
+              Lf[lane * NU + j] = a_row[j];
+          }
+          if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+              Lf[NU * NU + k] = dinv[k];
+            reinterpret_cast<int *>(Lf + NU * NU + NU)[0] = verdict;
+          }
+        }
       }
       GAR_MARK(3)
       __syncthreads(); // A: G, M complete -> wave 3 factors and solves
@@ -447,6 +500,8 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
           }
       }
       GAR_MARK(7)
+      if (GAR_MFMA_EARLY_H && t > 0)
+        load_h(t - 1);
       __syncthreads(); // C: V, vn, Ft[next] complete
       GAR_MARK(8)
       for (int e = tid; e < NX * NX; e += 192) { // Vxx -> HBM (packed lower triangle: gar_layout.h)
@@ -531,13 +586,26 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
       GAR_MARK(4)
       // ---- factor Rhat in registers (lane = row) under the Bunch-Kaufman rule ----
       double a_row[NU], dinv[NU], x[NU];
-      int verdict = wave_ldl_lean<NU>(Mm, lane, a_row, dinv);
-      if (verdict != 0) { // rare: evaluate the complete Bunch-Kaufman rule
-        verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
-        if (lane == 0) { // (this code runs in wave 3 only: threadIdx.x == 0 never gets here)
-          atomicAdd(&P.slow[0], 1);
-          if (verdict != 0)
-            atomicAdd(&P.slow[1], 1);
+      int verdict;
+      if constexpr (EARLY_FACTOR) { // (done by the last worker wave before barrier A: its L, 1 / d, verdict from LDS)
+        const double *Lf = sm + C::oLf;
+        const int frow = lane < NU ? lane : NU - 1;
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+          a_row[j] = Lf[frow * NU + j];
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+          dinv[k] = Lf[NU * NU + k];
+        verdict = reinterpret_cast<const int *>(Lf + NU * NU + NU)[0];
+      } else {
+        verdict = wave_ldl_lean<NU>(Mm, lane, a_row, dinv);
+        if (verdict != 0) { // rare: evaluate the complete Bunch-Kaufman rule
+          verdict = wave_ldl_bk_rule<NU>(Mm, lane, a_row, dinv);
+          if (lane == 0) { // (this code runs in wave 3 only: threadIdx.x == 0 never gets here)
+            atomicAdd(&P.slow[0], 1);
+            if (verdict != 0)
+              atomicAdd(&P.slow[1], 1);
+          }
         }
       }
       GAR_MARK(5)

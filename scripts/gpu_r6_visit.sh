@@ -93,3 +93,11 @@ if has ab12; then
   echo "== A/B pair<56,24> (uneven first half): next-knot operands all at the end of the stage | what the first half released, right behind it =="
   SHAPE=talos timeout 900 python scripts/ab_shape.py late=libgar_hip_pair_late.so early=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee $O/ab12_talos.log
 fi
+if has ab13; then
+  echo "== A/B the 4-wave latency kernel mfma<36,12>: factorisation on wave 3 between the barriers | on the last worker wave behind its export =="
+  for B in 256 64 1; do SHAPE=north BATCH=$B REPS=10 timeout 600 python scripts/ab_shape.py late=libgar_hip_mfma_late.so early=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab13_mfma.log
+fi
+if has ab14; then
+  echo "== A/B mfma<36,12>: Hessian tiles of the next knot requested at the start of its stage | before the last barrier of the stage before =="
+  for B in 256 1; do SHAPE=north BATCH=$B REPS=10 timeout 600 python scripts/ab_shape.py late=libgar_hip_mfma_lateh.so early=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab14_mfma.log
+fi
