@@ -278,16 +278,75 @@ __device__ __forceinline__ void ldl_solve_bcast(const double (&a)[NU], const dou
   }
 }
 
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// Vxx -> HBM, 16 B per lane.  PACK (the serial family with the gar_forward_mfma roll-out): the LOWER TRIANGLE of V
+// (LDS, pitch NX), rectangular packed (gar_layout.h: gar_sym_index) -- half the bytes of the full block,
+// contiguous.  Otherwise (the wide shapes, whose roll-out reads the full block): V as it is, linear.
+template <int NX, bool PACK, int PK = NX> struct VxxOut { // PK: pitch of V in LDS
+  static_assert(!PACK || NX % 4 == 0, "packed Vxx: nx (nx + 1) / 2 must be even (16-byte stores)");
+  static_assert(NX % 2 == 0 && PK % 2 == 0, "16-byte pieces stay inside a column");
+  static constexpr int NP2 = PACK ? NX * (NX + 1) / 4 : NX * NX / 2; // 16-byte pairs
+  static constexpr int NCH = (NP2 + 63) / 64;                        // pairs per lane
+  __device__ static __forceinline__ int lds_of(int p) { // LDS offset of packed element p
+    const int c = p / (NX + 1), k = p - c * (NX + 1);
+    const bool first = k < NX - c;
+    const int j = first ? c : NX - 1 - c;
+    const int i = first ? c + k : j + k - (NX - c);
+    return i * PK + j;
+  }
+  __device__ static __forceinline__ double2_t read(const double *V, int q, int lane) { // chunk q of this lane
+    const int e = 64 * q + lane, ec = (64 * q + 63 < NP2 || e < NP2) ? e : NP2 - 1;
+    double2_t v;
+    if constexpr (PACK) {
+      v.x = V[lds_of(2 * ec)];
+      v.y = V[lds_of(2 * ec + 1)];
+    } else if constexpr (PK == NX) {
+      v = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
+    } else { // column (2 ec) / NX of the record = column of V, rows 2 ec % NX, + 1
+      const int col = (2 * ec) / NX, row = 2 * ec - col * NX;
+      v = *reinterpret_cast<const double2_t *>(&V[col * PK + row]);
+    }
+    return v;
+  }
+  __device__ static __forceinline__ void write(double *dst, int q, int lane, double2_t v) {
+    const int e = 64 * q + lane;
+    if (64 * q + 63 < NP2 || e < NP2)
+      *reinterpret_cast<double2_t *>(&dst[2 * e]) = v;
+  }
+};
+template <int NX, bool PACK = true, int PK = NX>
+__device__ __forceinline__ void wave_flush_vxx(const double *V, double *dst, int lane) {
+  using VO = VxxOut<NX, PACK, PK>;
+  double2_t vbuf[VO::NCH];
+#pragma unroll
+  for (int q = 0; q < VO::NCH; ++q) // all the LDS reads first (one latency), then the stores
+    vbuf[q] = VO::read(V, q, lane);
+#pragma unroll
+  for (int q = 0; q < VO::NCH; ++q)
+    VO::write(dst, q, lane, vbuf[q]);
+}
+
 #ifndef GAR_MFMA_EARLY_FACTOR
 #define GAR_MFMA_EARLY_FACTOR 1
+#endif
+#ifndef GAR_MFMA_FLUSH16
+#define GAR_MFMA_FLUSH16 1
 #endif
 // (GAR_MFMA_EARLY_H measured and NOT adopted: backward 1.786 against 1.741 ms at batch 256 -- the tiles' latency was
 // hidden behind the first product already; profiles/r06_ab_mfma_4wave_early_hessian_tiles_not_kept.log)
 #ifndef GAR_MFMA_EARLY_H
 #define GAR_MFMA_EARLY_H 0
 #endif
+// (launch bounds: the kernel only ever runs with at most one workgroup per CU -- the library binds it while
+// batch <= #CUs --, so it could take the registers two resident workgroups share; measured: (256, 1) = 304 registers, no
+// scratch: 1.621 against 1.556 ms at batch 256, 1.494 against 1.528 at batch 1 -- kept at (256, 2) for the reporting point;
+// profiles/r06_ab_mfma_4wave_launch_bounds_not_kept.log)
+#ifndef GAR_MFMA_MIN_BLOCKS
+#define GAR_MFMA_MIN_BLOCKS 2
+#endif
 template <int NX, int NU>
-__global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
+__global__ void __launch_bounds__(256, GAR_MFMA_MIN_BLOCKS) gar_backward_mfma(MfmaParams P) {
   using C = MfmaCfg<NX, NU>;
   static_assert(C::TW <= 3 && NU <= 16, "one column tile per worker wave (3 workers), NW <= 64");
   // Rhat (rows / columns NX .. NW-1) inside the LAST tile column alone: the worker that holds it factorises it
@@ -504,6 +563,16 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
         load_h(t - 1);
       __syncthreads(); // C: V, vn, Ft[next] complete
       GAR_MARK(8)
+#if GAR_MFMA_FLUSH16
+      { // Vxx -> HBM (packed lower triangle: gar_layout.h) in 16-byte pieces, the chunks dealt over the three workers:
+        // two stores per lane instead of seven 8-byte ones behind an index division (round 6)
+        using VO = VxxOut<NX, GAR_VXX_PACKED != 0, PK>;
+#pragma unroll
+        for (int q0 = 0; q0 < VO::NCH; q0 += 3)
+          if (q0 + wave < VO::NCH)
+            VO::write(out + C::fVxx, q0 + wave, lane, VO::read(V, q0 + wave, lane));
+      }
+#else
       for (int e = tid; e < NX * NX; e += 192) { // Vxx -> HBM (packed lower triangle: gar_layout.h)
         const int j = e / NX, i = e - j * NX;
         if (!GAR_VXX_PACKED)
@@ -511,6 +580,7 @@ __global__ void __launch_bounds__(256, 2) gar_backward_mfma(MfmaParams P) {
         else if (i >= j)
           out[C::fVxx + gar_sym_index(1, NX, i, j)] = V[i * PK + j];
       }
+#endif
       GAR_MARK(9)
     }
   } else {
@@ -705,55 +775,6 @@ struct MfmaFwdParams {
     return (ring0 != 0 && p >= horizon) ? p - horizon : p;
   }
 };
-
-typedef double double2_t __attribute__((ext_vector_type(2)));
-
-// Vxx -> HBM, 16 B per lane.  PACK (the serial family with the gar_forward_mfma roll-out): the LOWER TRIANGLE of V
-// (LDS, pitch NX), rectangular packed (gar_layout.h: gar_sym_index) -- half the bytes of the full block,
-// contiguous.  Otherwise (the wide shapes, whose roll-out reads the full block): V as it is, linear.
-template <int NX, bool PACK, int PK = NX> struct VxxOut { // PK: pitch of V in LDS
-  static_assert(!PACK || NX % 4 == 0, "packed Vxx: nx (nx + 1) / 2 must be even (16-byte stores)");
-  static_assert(NX % 2 == 0 && PK % 2 == 0, "16-byte pieces stay inside a column");
-  static constexpr int NP2 = PACK ? NX * (NX + 1) / 4 : NX * NX / 2; // 16-byte pairs
-  static constexpr int NCH = (NP2 + 63) / 64;                        // pairs per lane
-  __device__ static __forceinline__ int lds_of(int p) { // LDS offset of packed element p
-    const int c = p / (NX + 1), k = p - c * (NX + 1);
-    const bool first = k < NX - c;
-    const int j = first ? c : NX - 1 - c;
-    const int i = first ? c + k : j + k - (NX - c);
-    return i * PK + j;
-  }
-  __device__ static __forceinline__ double2_t read(const double *V, int q, int lane) { // chunk q of this lane
-    const int e = 64 * q + lane, ec = (64 * q + 63 < NP2 || e < NP2) ? e : NP2 - 1;
-    double2_t v;
-    if constexpr (PACK) {
-      v.x = V[lds_of(2 * ec)];
-      v.y = V[lds_of(2 * ec + 1)];
-    } else if constexpr (PK == NX) {
-      v = *reinterpret_cast<const double2_t *>(&V[2 * ec]);
-    } else { // column (2 ec) / NX of the record = column of V, rows 2 ec % NX, + 1
-      const int col = (2 * ec) / NX, row = 2 * ec - col * NX;
-      v = *reinterpret_cast<const double2_t *>(&V[col * PK + row]);
-    }
-    return v;
-  }
-  __device__ static __forceinline__ void write(double *dst, int q, int lane, double2_t v) {
-    const int e = 64 * q + lane;
-    if (64 * q + 63 < NP2 || e < NP2)
-      *reinterpret_cast<double2_t *>(&dst[2 * e]) = v;
-  }
-};
-template <int NX, bool PACK = true, int PK = NX>
-__device__ __forceinline__ void wave_flush_vxx(const double *V, double *dst, int lane) {
-  using VO = VxxOut<NX, PACK, PK>;
-  double2_t vbuf[VO::NCH];
-#pragma unroll
-  for (int q = 0; q < VO::NCH; ++q) // all the LDS reads first (one latency), then the stores
-    vbuf[q] = VO::read(V, q, lane);
-#pragma unroll
-  for (int q = 0; q < VO::NCH; ++q)
-    VO::write(dst, q, lane, vbuf[q]);
-}
 
 template <int NX, int NC = 0> struct FwdStage {
   double2_t g[NX / 2];

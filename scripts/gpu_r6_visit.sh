@@ -101,3 +101,11 @@ if has ab14; then
   echo "== A/B mfma<36,12>: Hessian tiles of the next knot requested at the start of its stage | before the last barrier of the stage before =="
   for B in 256 1; do SHAPE=north BATCH=$B REPS=10 timeout 600 python scripts/ab_shape.py late=libgar_hip_mfma_lateh.so early=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab14_mfma.log
 fi
+if has ab15; then
+  echo "== A/B mfma<36,12>: Vxx flush in 8-byte pieces behind an index division | 16-byte pieces (VxxOut), chunks dealt over the workers =="
+  for B in 256 1; do SHAPE=north BATCH=$B REPS=10 timeout 600 python scripts/ab_shape.py flush8=libgar_hip_mfma_flush8.so flush16=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab15_mfma.log
+fi
+if has ab16; then
+  echo "== A/B mfma<36,12>: __launch_bounds__(256, 2) | (256, 1) =="
+  for B in 256 1; do SHAPE=north BATCH=$B REPS=10 timeout 600 python scripts/ab_shape.py lb2=libgar_hip_mfma_lb2.so lb1=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab16_mfma.log
+fi
