@@ -34,6 +34,7 @@ struct FoldParams {
   int *coupled; // per problem: != 0 if some knot has D != 0 (generic kernels take the problem)
   int horizon, t2, t_lo, t_hi;
   double mueq;
+  int qr_packed; // the caller's knots t < horizon keep Q, R as packed lower triangles (gar_layout.h); the folded knots: full
 };
 
 // grid (horizon + 1, batch) x 256
@@ -47,10 +48,17 @@ __global__ void __launch_bounds__(256) gar_fold_constraints(FoldParams P) {
   // Q S R q r A B f sit at the same offsets in both layouts (C D d come last)
   const double *Cm = src + ko.C, *dv = src + ko.d;
   const double mu = P.mueq;
+  const bool pk = P.qr_packed && t < P.horizon;
   for (int e = tid; e < ko.C; e += 256) {
     double v = src[e];
+    if (pk && e >= ko.R && e < ko.R + nu * nu) { // (the folded knot keeps full blocks: the wave-leg family's format)
+      const int j = (e - ko.R) / nu, i = (e - ko.R) - j * nu;
+      v = src[ko.R + (i >= j ? gar_lower_index(nu, i, j) : gar_lower_index(nu, j, i))];
+    }
     if (e < nx * nx) { // Q(i, j) += sum_k C(k, i) * (C(k, j) / mu)
       const int j = e / nx, i = e - j * nx;
+      if (pk)
+        v = src[ko.Q + (i >= j ? gar_lower_index(nx, i, j) : gar_lower_index(nx, j, i))];
       double acc = 0.0;
       for (int k = 0; k < nc; ++k)
         acc = __builtin_fma(Cm[i * nc + k], Cm[j * nc + k] / mu, acc);

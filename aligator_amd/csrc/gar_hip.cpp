@@ -32,6 +32,7 @@
 #include "gar_condensed_cr.hpp"
 #include "gar_dense.hpp"
 #include "gar_fold.hpp"
+#include "gar_cstr_seg_api.hpp"
 #include "gar_leg_seg.hpp"
 
 namespace gar { // instantiated in gar_wave_sweep.cpp (its own translation unit, its own code-generation flags)
@@ -207,6 +208,14 @@ struct gar_hip_solver {
   void (*seg_fwd_kernel)(gar::GenericParams) = nullptr; // its roll-out (gar_forward_wide_leg), leg mode
   int seg_lds_doubles = 0;
   bool fold = false, fold_expanded = false, coupled_known = false;
+  // ... unless the shape has the constrained segment legs (gar_cstr_seg.hpp, round 6): then the flagged problems run
+  // on the serial constrained chain's stage kernels, leg by leg, + a parameter recursion; the knots keep Q, R packed
+  // (qr_packed), the plain part's records go to the flagged problem's slice of d_fac2, d_cseg_resume holds the chain's
+  // hand-over knot per (problem, local leg)
+  bool cseg_on = false;
+  bool mu_divides = false; // some knot's solve divides by mueq outright (see gar_hip_backward_legs_async)
+  gar::CsegKernels cseg;
+  int *d_cseg_resume = nullptr;
   gar_hip_solver *flay = nullptr;
   double *d_prob2 = nullptr, *d_fac2 = nullptr;
   gar_stage_meta *d_meta2 = nullptr;
@@ -830,6 +839,7 @@ gar::FoldParams make_fold_params(gar_hip_solver *s) {
   F.t_lo = lo;
   F.t_hi = hi;
   F.mueq = s->fold_mueq;
+  F.qr_packed = s->qr_packed ? 1 : 0;
   return F;
 }
 
@@ -881,6 +891,8 @@ void free_device(gar_hip_solver *s) {
 
   (void)hipFree(s->d_prob2);
   (void)hipFree(s->d_fac2);
+  (void)hipFree(s->d_cseg_resume);
+  s->d_cseg_resume = nullptr;
   (void)hipFree(s->d_meta2);
   s->d_prob2 = s->d_fac2 = nullptr;
   s->d_meta2 = nullptr;
@@ -974,6 +986,18 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipMemset(s->d_fac2, 0, sizeof(double) * (size_t)f->fac_doubles * B));
     HIP_TRY(gar_dev_malloc((void **)&s->d_meta2, sizeof(gar_stage_meta) * f->meta.size()));
     HIP_TRY(hipMemcpy(s->d_meta2, f->meta.data(), sizeof(gar_stage_meta) * f->meta.size(), hipMemcpyHostToDevice));
+    if (s->cseg_on) {
+      const size_t units = B * (size_t)s->legs_per_rank;
+      HIP_TRY(gar_dev_malloc((void **)&s->d_cseg_resume, sizeof(int) * units));
+      HIP_TRY(hipMemset(s->d_cseg_resume, 0xff, sizeof(int) * units));
+      for (auto k : s->cseg.backward)
+        HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(s->cseg.backward_lds_doubles * sizeof(double))));
+      HIP_TRY(hipFuncSetAttribute((const void *)s->cseg.chain, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(s->cseg.chain_lds_doubles * sizeof(double))));
+      HIP_TRY(hipFuncSetAttribute((const void *)s->cseg.stage, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(s->cseg.stage_lds_doubles * sizeof(double))));
+    }
   }
   s->fold_expanded = s->coupled_known = false;
   const size_t staging = sizeof(double) * (size_t)s->prob_doubles * B;
@@ -1611,6 +1635,13 @@ int gar_hip_backward_legs_async(gar_hip_solver *s, double mueq) {
   GAR_GUARD(s);
   if (!s)
     return fail(GAR_HIP_ERR_ARG, "null solver");
+  // A knot whose solve divides by mueq outright -- terminalSolve without controls, Z = C / mu (riccati-kernel.hxx:146-149);
+  // the decoupled constrained stage and the fold (gar_wave2.hpp, gar_fold.hpp: D = 0 makes kktMat singular at mu = 0, the
+  // reference throws there, :239-241) -- turns mueq = 0 (or a NaN) into infinities that the factorisations downstream
+  // index with: reported as the failed stage it is, before anything is launched
+  if (s->mu_divides && !(std::fabs(mueq) >= 1e-290))
+    return fail(GAR_HIP_ERR_FACTOR, "Failed stage LDL factorization (mueq = " + std::to_string(mueq) +
+                                        " on constrained knots whose solve divides by it)");
   GAR_MULTI(s, multi_backward_legs(s, mueq));
   s->eager_fwd = false;
   if (s->ev_pref) { // a read-back of the previous sweep's gains may still be in flight on the second stream

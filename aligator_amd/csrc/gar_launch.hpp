@@ -63,7 +63,79 @@ int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
     hipLaunchKernelGGL(s->leg_bwd_kernel, grid, dim3(64 * s->leg_waves),
                        (size_t)s->leg_lds_doubles * sizeof(double), s->stream, Q);
     hipLaunchKernelGGL(s->leg_tuple_kernel, grid, dim3(256), 0, s->stream, Q);
-    if (s->fold) { // ... and are swept by the generic leg kernels (every other problem: an early exit)
+    if (s->fold && s->cseg_on) { // ... and are swept by the constrained segment legs (gar_cstr_seg.hpp; every other problem: an early exit)
+      const int *flagged = s->d_status + s->batch + 4;
+      const int N = s->horizon;
+      gar::MfmaParams M{};
+      M.prob = s->d_prob;
+      M.fac = s->d_fac2;
+      M.status = s->d_status;
+      M.slow = s->d_status + s->batch;
+      M.resume = s->d_cseg_resume;
+      M.prob_stride = s->prob_doubles;
+      M.fac_stride = s->flay->fac_doubles;
+      M.in_off0 = s->uni_in0;
+      M.in_rec = s->uni_in_rec;
+      M.in_offN = s->meta[N].in_off;
+      M.fac_rec = s->cseg.rec;
+      M.fac_offN = (long long)N * s->cseg.rec;
+      M.horizon = N;
+      M.mueq = mueq;
+      {
+        const char *sa = gar_option("GAR_HIP_SPD_ACCEPT");
+        M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
+      }
+      // the chain, leg by leg, in two rounds (gar_cstr_seg.hpp): decoupled stage -> coupled stage and LDS Bunch-Kaufman for
+      // ONE stage each (a leg end is where Bunch-Kaufman pivots), then the same again from the hand-over knot, to the end
+      for (int round = 0; round < 2; ++round)
+        for (int ph = 0; ph < 3; ++ph)
+          hipLaunchKernelGGL(s->cseg.backward[ph], grid, dim3(64), (size_t)s->cseg.backward_lds_doubles * sizeof(double),
+                             s->stream, M, s->num_legs, l0, flagged,
+                             (round == 1 && ph == 0 ? gar::kCsegReenter : 0) | (round == 0 && ph >= 1 ? gar::kCsegSingle : 0));
+      gar::CsegParams Cp{};
+      Cp.meta = s->d_meta;
+      Cp.prob = s->d_prob;
+      Cp.fac2 = s->d_fac2;
+      Cp.fac = s->d_fac;
+      Cp.status = s->d_status;
+      Cp.only = flagged;
+      Cp.prob_stride = s->prob_doubles;
+      Cp.fac_stride = s->fac_doubles;
+      Cp.fac2_stride = s->flay->fac_doubles;
+      Cp.in_off0 = s->uni_in0;
+      Cp.in_rec = s->uni_in_rec;
+      Cp.horizon = N;
+      Cp.num_legs = s->num_legs;
+      Cp.leg_begin = l0;
+      Cp.local_legs = l1 - l0;
+      Cp.mueq = mueq;
+      hipLaunchKernelGGL(s->cseg.chain, grid, dim3((unsigned)s->cseg.chain_threads),
+                         (size_t)s->cseg.chain_lds_doubles * sizeof(double), s->stream, Cp);
+      hipLaunchKernelGGL(s->cseg.stage, dim3((unsigned)N + 1, (unsigned)s->batch), dim3((unsigned)s->cseg.stage_threads),
+                         (size_t)s->cseg.stage_lds_doubles * sizeof(double), s->stream, Cp);
+      gar::LegParamParams Lp{};
+      Lp.meta = s->d_meta;
+      Lp.meta2 = s->d_meta2;
+      Lp.prob = s->d_prob;
+      Lp.fac2 = s->d_fac2;
+      Lp.fac = s->d_fac;
+      Lp.boundary = s->d_bound_local + tup_shift;
+      Lp.status = s->d_status;
+      Lp.prob_stride = s->prob_doubles;
+      Lp.fac_stride = s->fac_doubles;
+      Lp.fac2_stride = s->flay->fac_doubles;
+      Lp.boundary_stride = (long long)s->legs_per_rank * s->tuple_doubles;
+      Lp.horizon = N;
+      Lp.num_legs = s->num_legs;
+      Lp.leg_begin = l0;
+      Lp.tuple_doubles = (int)s->tuple_doubles;
+      Lp.nxb = s->nxb;
+      Lp.nxM = s->dims5[0];
+      Lp.nuM = s->dims5[1];
+      Lp.local_legs = l1 - l0;
+      Lp.only = flagged;
+      hipLaunchKernelGGL(gar::gar_leg_param_finish, grid, dim3(1024), 0, s->stream, Lp);
+    } else if (s->fold) { // ... and are swept by the generic leg kernels (every other problem: an early exit)
       gar::GenericParams G = make_params(s, mueq);
       G.only = s->d_status + s->batch + 4;
       G.leg_begin = l0;

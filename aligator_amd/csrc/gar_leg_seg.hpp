@@ -126,6 +126,7 @@ struct LegParamParams {
   int horizon, num_legs, leg_begin, tuple_doubles, nxb;
   int nxM, nuM; // largest nx, nu (LDS carve)
   int local_legs;
+  const int *only; // gar_leg_param_finish behind the constrained segment legs (gar_cstr_seg.hpp): problems with only[b] == 1 (null: all)
 };
 
 __host__ __device__ inline int leg_prepare_lds_doubles(int nx, int nu) { // V' | Bm VB Tm | Rh Rc | wk | sub piv ctrl (the front of gar_leg_param_stage's carve)
@@ -389,6 +390,8 @@ __global__ void __launch_bounds__(GAR_LEG_STAGE_THREADS) gar_leg_param_stage(Leg
 __global__ void __launch_bounds__(1024) gar_leg_param_finish(LegParamParams P) {
   const WG w = wg_self();
   const int leg = (int)blockIdx.x + P.leg_begin, b = (int)blockIdx.y;
+  if (P.only != nullptr && P.only[b] != 1)
+    return;
   int t_beg, t_end;
   gar_get_work(P.horizon, leg, P.num_legs, &t_beg, &t_end);
   const bool last_leg = (leg == P.num_legs - 1);
@@ -425,7 +428,7 @@ __global__ void __launch_bounds__(1024) gar_leg_param_finish(LegParamParams P) {
         for (int c = 0; c < CH; ++c) {
           const int t = (t1 - c >= t_beg) ? t1 - c : t_beg;
           const gar_stage_meta m = P.meta[t];
-          const gar_factor_offsets fo = gar_factor_layout(m.nx, m.nu, 0, m.nx2, nth);
+          const gar_factor_offsets fo = gar_factor_layout(m.nx, m.nu, m.nc, m.nx2, nth);
           q[c] = fac + m.fac_off + (mat ? fo.Vtt + j * nth + i : fo.vt + i);
           v[c] = *q[c];
         }

@@ -189,6 +189,7 @@ template <int NX, int NU, int NC> void bind_cstr(gar_hip_solver *s) {
 
 void select_kernel(gar_hip_solver *s) {
   s->fold = false;
+  s->cseg_on = false;
   s->seg_bwd_kernel = nullptr;
   s->seg_fwd_kernel = nullptr;
   s->leg_bwd_kernel = nullptr;
@@ -413,6 +414,27 @@ int configure_padded_or_not(gar_hip_solver *s) {
     if (int rc = build_layout(f))
       return rc;
     s->kernel_name += "+fold";
+    // problems with D != 0: the constrained segment legs (gar_cstr_seg.hpp) where every knot carries the same number of
+    // constraints and the shape has the serial constrained chain; their scratch records live in the flagged problem's
+    // slice of the wave-leg family's factor buffer
+    s->cseg_on = false;
+    const char *cs = gar_option("GAR_HIP_CSTR_SEG_LEGS");
+    const int nx = s->dims5[0], nu = s->dims5[1], nc = s->dims5[2];
+    bool uniform_nc = nc > 0 && GAR_QR_PACKED != 0 && GAR_VXX_PACKED != 0;
+    for (int t = 0; t <= s->horizon; ++t)
+      uniform_nc &= s->dims5[5 * (size_t)t + 2] == nc;
+    if (uniform_nc && !(cs && cs[0] == '0') && gar::cseg_bind(nx, nu, nc, &s->cseg) &&
+        s->cseg.scratch_doubles(s->horizon, s->num_legs) <= f->fac_doubles) {
+      s->cseg_on = true;
+      s->qr_packed = true; // the chain's kernels read only the lower triangles of Q and R (gar_layout.h); the fold unpacks
+      s->kernel_name += "|wave_seg<" + std::to_string(nx) + "," + std::to_string(nu) + "," + std::to_string(nc) + ">";
+    }
+  }
+  // (see gar_hip_backward_legs_async)
+  s->mu_divides = s->fold;
+  for (int t = 0; t <= s->horizon; ++t) {
+    const int32_t *d = &s->dims5[5 * (size_t)t];
+    s->mu_divides |= d[2] > 0 && (d[1] == 0 || s->wave_kernel != nullptr);
   }
   return GAR_HIP_OK;
 }

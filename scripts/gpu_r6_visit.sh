@@ -109,3 +109,17 @@ if has ab16; then
   echo "== A/B mfma<36,12>: __launch_bounds__(256, 2) | (256, 1) =="
   for B in 256 1; do SHAPE=north BATCH=$B REPS=10 timeout 600 python scripts/ab_shape.py lb2=libgar_hip_mfma_lb2.so lb1=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab16_mfma.log
 fi
+if has cseg; then
+  echo "== leg mode with coupled constraints: the constrained segment legs (gar_cstr_seg.hpp) against the any-dimension leg kernels =="
+  timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "segment_legs or fold" 2>&1 | tail -5 | tee $O/cseg_tests.log
+  timeout 900 python scripts/time_coupled_legs.py 2>&1 | grep -vE "amdgpu.ids" | tee $O/cseg_time.log
+fi
+if has csegprof; then
+  echo "== kernel split of leg mode with coupled constraints (LEGS=${LEGS:-32}) =="
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/csegprof -o cseg -- python $R/scripts/prof_coupled_legs.py 2>&1 | grep -E "done|rror")
+  find $O/csegprof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/cseg_kernel_stats_${LEGS:-32}legs.csv; head -24 $O/cseg_kernel_stats_${LEGS:-32}legs.csv < /dev/null | cut -c1-150; rm -rf $O/csegprof
+fi
+if has csegbatch; then
+  echo "== leg mode with coupled constraints, a batch of problems =="
+  BATCH=${BATCH:-64} timeout 900 python scripts/time_coupled_legs.py 2>&1 | grep -vE "amdgpu.ids" | tee $O/cseg_time_batch${BATCH:-64}.log
+fi

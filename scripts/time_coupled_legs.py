@@ -1,6 +1,7 @@
 """Leg mode on the reference's benchmark shape (36, 12, nc = 32), N = 256, ONE problem, with D = 0 (the fold onto the
-wave-leg kernels, csrc/gar_fold.hpp) and with a random D on every knot (coupled constraints: the any-dimension leg
-kernels -- VERDICT r5 item 7, not specialised): ms per backward + forward sweep beside the serial chain."""
+wave-leg kernels, csrc/gar_fold.hpp) and with a random D on every knot (coupled constraints: round 6 the constrained
+segment legs of csrc/gar_cstr_seg.hpp; GAR_HIP_CSTR_SEG_LEGS=0: the any-dimension leg kernels, as before): ms per backward
++ forward sweep beside the serial chain, and the kernels' own times from the library's events."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +10,7 @@ from aligator_amd import synth
 from aligator_amd.gar import BatchedRiccatiSolver
 import parity_cases as pc
 nx, nu, nc, N, mu = 36, 12, 32, 256, 1e-8
+batch = int(os.environ.get("BATCH", "1"))   # (BATCH > 1: the same problem in every slot)
 for coupled in (False, True):
     prob = synth.generate_lq_problem(7, np.zeros(nx), N, nx, nu, nc=nc, mode="W")
     if coupled:
@@ -17,9 +19,12 @@ for coupled in (False, True):
             k.D[...] = rng.uniform(-1, 1, k.D.shape)
     _, _, ref = pc.oracle_serial(prob, mu)
     sc = pc.scale_of(ref)
-    for legs in (1, 6, 32):
-        s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs)
-        s.upload([prob])
+    for legs, seg in ((1, "1"), (6, "1"), (6, "0"), (32, "1"), (32, "0"), (64, "1")):
+        if not coupled and seg == "0":
+            continue
+        os.environ["GAR_HIP_CSTR_SEG_LEGS"] = seg
+        s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=batch, num_legs=legs)
+        s.upload([prob] * batch)
         for _ in range(3):
             s.backward_async(mu); s.forward_async()
         s.sync()
@@ -29,5 +34,5 @@ for coupled in (False, True):
         s.sync()
         ms = (time.perf_counter() - t0) / 10 * 1e3
         err = max(pc.maxdiff(a, b) for a, b in zip(s.solution(0)[:2], ref[:2])) / max(1.0, max(float(np.abs(v).max()) for v in ref[0]))
-        print(f"D {'random' if coupled else '= 0   '} legs {legs:3d} {s.kernel_name:24s} {ms:8.3f} ms per sweep   |x, u - serial oracle| {err:.1e}", flush=True)
+        print(f"batch {batch} D {'random' if coupled else '= 0   '} legs {legs:3d} {s.kernel_name:42s} {ms:8.3f} ms per sweep   |x, u - serial oracle| {err:.1e}", flush=True)
         s.close()

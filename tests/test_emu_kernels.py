@@ -436,7 +436,7 @@ def test_parallel_solver_on_the_reference_bench_shape_nc32():
     rng = np.random.default_rng(3)
     prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), 5, nx, nu, nc=nc, mode="W")
     par = pc.check_parallel(prob, 1e-8, 2, 1e-7, EMU)
-    assert par._impl.kernel_name == "wave_leg<36,12>+fold"      # round 3: folded onto the wave-leg family (gar_fold.hpp)
+    assert par._impl.kernel_name.startswith("wave_leg<36,12>+fold")      # round 3: folded onto the wave-leg family (gar_fold.hpp)
 
 
 def test_parallel_solver_nc32_on_the_generic_leg_kernels(monkeypatch):
@@ -451,6 +451,23 @@ def test_parallel_solver_nc32_on_the_generic_leg_kernels(monkeypatch):
 
 def test_constrained_legs_fold_onto_the_wave_leg_kernels():
     pc.check_constrained_legs_fold(EMU)
+
+
+def test_coupled_constraints_in_leg_mode_on_the_constrained_segment_legs():
+    """Round 6 (gar_cstr_seg.hpp): D != 0 in leg mode on the serial constrained chain's stage kernels, leg by leg, + the
+    parameter recursion; the chain's three kernels all reached inside legs."""
+    pc.check_constrained_legs_segments(EMU)
+
+
+def test_mueq_zero_on_a_serial_constrained_solver_is_a_reported_failure():
+    rng = np.random.default_rng(3)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(8), 6, 8, 4, nc=4, mode="W")
+    from aligator_amd.gar import ProximalRiccatiSolver
+    s = ProximalRiccatiSolver(prob, lib_path=EMU)
+    assert s.kernel_name == "wave<8,4,4>"
+    with pytest.raises(RuntimeError, match="Failed stage LDL factorization"):
+        s.backward(0.0)
+    assert s.backward(1e-6)
 
 
 def test_constrained_wave_kernels_decoupled_dense_c_and_alternating_d():
