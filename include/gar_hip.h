@@ -256,7 +256,10 @@ int gar_hip_update_lq_subproblem_device(gar_hip_solver *s, const double *deriv_d
 
 /* ---- the sweep ------------------------------------------------------------ */
 /* backward(mueq): returns 0, or GAR_HIP_ERR_FACTOR if any stage factorisation
- * of any problem failed (the reference throws). */
+ * of any problem failed (the reference throws).  mueq = 0 (|mueq| < 1e-290, NaN) on a problem with a knot whose
+ * solve divides by it -- a constrained knot without controls, Z = C / mu (riccati-kernel.hxx:146-149); the
+ * specialised constrained families -- is GAR_HIP_ERR_FACTOR before anything is launched (the reference: infinities,
+ * or its "failed stage" exception on the singular [Rhat 0; 0 0]). */
 int gar_hip_backward(gar_hip_solver *s, double mueq);
 int gar_hip_backward_async(gar_hip_solver *s, double mueq);
 /* forward: theta (host, ntheta doubles per problem, batch-major) or NULL.
@@ -405,6 +408,8 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
  *                                  acceptance of an unpivoted positive definite R-hat (deviation 7)
  *   LEGS = generic | LEG_WAVES = 1 | SEG_LEGS = 0 | FOLD = 0     leg mode: the any-dimension leg kernels / one wave
  *                                  per leg / no segment legs on the wide shape / constrained knots not folded
+ *   CSTR_SEG_LEGS = 0              leg mode, problems with D != 0 on the any-dimension leg kernels instead of the
+ *                                  constrained segment legs (csrc/gar_cstr_seg.hpp; (36,12,32), (16,8,8), (8,4,4))
  *   CONDENSED = generic | chain, CONDENSED_REDUCED = 0, CONDENSED_CR = 0 | <k>   the condensed solve: elimination
  *                                  chain instead of block cyclic reduction (specialised / any-dimension paths)
  *   STAGE_NT = 0 | 1, EAGER = 0    host staging with / without non-temporal stores; gar_hip_backward_blocks without
