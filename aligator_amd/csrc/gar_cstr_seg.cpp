@@ -11,6 +11,7 @@ template <int NX, int NU, int NC> static void cseg_fill(CsegKernels *k) {
   k->backward[2] = gar_cseg_backward<NX, NU, NC, 2>;
   k->chain = gar_cseg_param_chain<NX, NU, NC>;
   k->stage = gar_cseg_param_stage<NX, NU, NC>;
+  k->forward = gar_cseg_forward<NX, NU, NC>;
   k->backward_lds_doubles = WaveCfg<NX, NU, NC>::total;
   k->chain_lds_doubles = cseg_chain_lds_doubles<NX>();
   k->stage_lds_doubles = cseg_stage_lds_doubles<NX, NU, NC>();

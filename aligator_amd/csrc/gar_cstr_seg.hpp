@@ -413,4 +413,132 @@ __global__ void __launch_bounds__(GAR_CSEG_STAGE_THREADS) gar_cseg_param_stage(C
     atomicOr(&P.status[b], 1);
 }
 
+// ---- (3) the roll-out: one wave per (leg, problem), lane = row --------------------------------------------------------
+// forwardImpl over one leg (riccati-kernel.hxx:314-377 under parallel-solver.hxx:209-243) in gar_forward_wide_leg's scheme
+// (gar_leg_seg.hpp), with the constraint rows: lane r < nu + nc owns row r of [K; Z] and [Kth; Zth], lane r < NX row r
+// of Aff, Yth, Vxx' and Vxt' (fb, fth row-major, Vxt' column-major); the state and the parameter are broadcast from the
+// lanes that hold them:
+//   [u; v] = [kff; zff] + [K; Z] x + [Kth; Zth] th,   x' = yff + Aff x + Yth th,   lbd' = vx' + Vxx' x' + Vxt' th
+// Replaces the any-dimension roll-out on these problems (60 us per sweep at N = 256, 32 legs).
+template <int NX, bool LAST, bool MORE>
+__device__ __forceinline__ void cseg_fwd_stage(const CsegFwdParams &P, const double *fac, double *sol, int t, int lane,
+                                               double &xs, double th) {
+  constexpr int NTH = LAST ? 0 : NX;
+  const gar_stage_meta m = P.meta[t];
+  const int nu = m.nu, nk = m.nu + m.nc; // (nu = 0 at the terminal knot)
+  const int iA = lane < NX ? lane : NX - 1, iK = lane < nk ? lane : (nk > 0 ? nk - 1 : 0);
+  const gar_factor_offsets fo = gar_factor_layout(NX, nu, m.nc, m.nx2, NTH);
+  const double *rec = fac + m.fac_off;
+  const double x_in = xs;
+  if (MORE) {
+    const gar_stage_meta mn = P.meta[t + 1];
+    const gar_factor_offsets fn = gar_factor_layout(NX, mn.nu, mn.nc, mn.nx2, NTH);
+    const double *recn = fac + mn.fac_off;
+    double2_t aff[NX / 2], yth[LAST ? 1 : NX / 2], vrow[NX / 2];
+    double vxt[LAST ? 1 : NX];
+    const double *ap = rec + fo.fb + (long long)(nk + iA) * NX, *ytp = rec + fo.fth + (long long)(nk + iA) * NX;
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      aff[q] = *reinterpret_cast<const double2_t *>(ap + 2 * q);
+      if (!LAST)
+        yth[q] = *reinterpret_cast<const double2_t *>(ytp + 2 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q)
+      vrow[q] = *reinterpret_cast<const double2_t *>(recn + fn.Vxx + (long long)iA * NX + 2 * q);
+    if (!LAST) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j)
+        vxt[j] = recn[fn.Vxt + (long long)j * NX + iA];
+    }
+    const double yff = rec[fo.ff + nk + iA], vxn = recn[fn.vx + iA];
+    __builtin_amdgcn_sched_barrier(0);
+    double x0 = yff, x1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      x0 = __builtin_fma(aff[q].x, lane_bcast(x_in, 2 * q), x0);
+      x1 = __builtin_fma(aff[q].y, lane_bcast(x_in, 2 * q + 1), x1);
+      if (!LAST) {
+        x0 = __builtin_fma(yth[q].x, lane_bcast(th, 2 * q), x0);
+        x1 = __builtin_fma(yth[q].y, lane_bcast(th, 2 * q + 1), x1);
+      }
+    }
+    const double xn = x0 + x1;
+    if (lane < NX)
+      sol[mn.x_off + lane] = xn;
+    double l0 = vxn, l1 = 0.0; // lbd' = vx' + Vxx' x' + Vxt' th  (:369-374)
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      l0 = __builtin_fma(vrow[q].x, lane_bcast(xn, 2 * q), l0);
+      l1 = __builtin_fma(vrow[q].y, lane_bcast(xn, 2 * q + 1), l1);
+      if (!LAST) {
+        l0 = __builtin_fma(vxt[2 * q], lane_bcast(th, 2 * q), l0);
+        l1 = __builtin_fma(vxt[2 * q + 1], lane_bcast(th, 2 * q + 1), l1);
+      }
+    }
+    if (lane < NX)
+      sol[mn.l_off + lane] = l0 + l1;
+    xs = xn;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (nk > 0) { // [u; v] = [kff; zff] + [K; Z] x + [Kth; Zth] th: off the chain
+    double2_t kro[NX / 2], kth[LAST ? 1 : NX / 2];
+    const double *kp = rec + fo.fb + (long long)iK * NX, *ktp = rec + fo.fth + (long long)iK * NX;
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      kro[q] = *reinterpret_cast<const double2_t *>(kp + 2 * q);
+      if (!LAST)
+        kth[q] = *reinterpret_cast<const double2_t *>(ktp + 2 * q);
+    }
+    double u0 = rec[fo.ff + iK], u1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < NX / 2; ++q) {
+      u0 = __builtin_fma(kro[q].x, lane_bcast(x_in, 2 * q), u0);
+      u1 = __builtin_fma(kro[q].y, lane_bcast(x_in, 2 * q + 1), u1);
+      if (!LAST) {
+        u0 = __builtin_fma(kth[q].x, lane_bcast(th, 2 * q), u0);
+        u1 = __builtin_fma(kth[q].y, lane_bcast(th, 2 * q + 1), u1);
+      }
+    }
+    if (lane < nu)
+      sol[m.u_off + lane] = u0 + u1;
+    else if (lane < nk)
+      sol[m.v_off + (lane - nu)] = u0 + u1;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NX, int NU, int NC>
+__global__ void __launch_bounds__(64) gar_cseg_forward(CsegFwdParams P) {
+  static_assert(NX <= 64 && NX % 2 == 0 && NU + NC <= 64, "state and [u; v] live in the first lanes");
+  const int lane = (int)threadIdx.x;
+  const int leg = (int)blockIdx.x + P.leg_begin, b = (int)blockIdx.y;
+  if (P.only[b] != 1)
+    return;
+  const double *fac = P.fac + (long long)b * P.fac_stride;
+  double *sol = P.sol + (long long)b * P.sol_stride;
+  int t_beg, t_end;
+  gar_get_work(P.horizon, leg, P.num_legs, &t_beg, &t_end);
+  const bool last = (leg == P.num_legs - 1);
+  const int nxb = P.nxb;
+  const double *cs = P.csol + (long long)b * (2 * P.num_legs) * nxb;
+  const gar_stage_meta m0 = P.meta[t_beg];
+  const int iA = lane < NX ? lane : NX - 1;
+  for (int e = lane; e < (leg == 0 ? P.nc0 : NX); e += 64) // scatter of the condensed solution (:215-220)
+    sol[m0.l_off + e] = cs[(2 * leg) * nxb + e];
+  double xs = cs[(2 * leg + 1) * nxb + iA];
+  if (lane < NX)
+    sol[m0.x_off + lane] = xs;
+  if (last) {
+    for (int t = t_beg; t + 1 < t_end; ++t)
+      cseg_fwd_stage<NX, true, true>(P, fac, sol, t, lane, xs, 0.0);
+    cseg_fwd_stage<NX, true, false>(P, fac, sol, t_end - 1, lane, xs, 0.0);
+  } else {
+    const double th = cs[(2 * (leg + 1)) * nxb + iA]; // theta = lbdas[end] (:234-236)
+    for (int t = t_beg; t + 1 < t_end; ++t)
+      cseg_fwd_stage<NX, false, true>(P, fac, sol, t, lane, xs, th);
+    cseg_fwd_stage<NX, false, false>(P, fac, sol, t_end - 1, lane, xs, th);
+  }
+}
+
 } // namespace gar

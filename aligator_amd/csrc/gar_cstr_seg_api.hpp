@@ -20,10 +20,21 @@ struct CsegParams {
 };
 
 constexpr int kCsegReenter = 1, kCsegSingle = 2; // flags of the plain kernels (gar_cstr_seg.hpp)
+struct CsegFwdParams {
+  const gar_stage_meta *meta; // caller-visible layout
+  const double *fac;          // caller-visible records (row-major fb / fth, full Vxx)
+  double *sol;
+  const double *csol;         // condensed solution [problem][2 * legs][nxb]
+  const int *only;
+  long long fac_stride, sol_stride;
+  int horizon, num_legs, leg_begin, nxb, nc0;
+};
+
 struct CsegKernels {
   void (*backward[3])(MfmaParams, int, int, const int *, int) = {nullptr, nullptr, nullptr}; // the chain: decoupled, coupled, LDS Bunch-Kaufman
   void (*chain)(CsegParams) = nullptr;
   void (*stage)(CsegParams) = nullptr;
+  void (*forward)(CsegFwdParams) = nullptr; // the roll-out, one wave per (leg, problem)
   int backward_lds_doubles = 0, chain_lds_doubles = 0, stage_lds_doubles = 0, chain_threads = 0, stage_threads = 0;
   long long rec = 0;               // pitch of the scratch records (the terminal knot's at horizon * rec)
   long long (*scratch_doubles)(int horizon, int num_legs) = nullptr; // per problem

@@ -35,7 +35,9 @@ struct FoldParams {
   int horizon, t2, t_lo, t_hi;
   double mueq;
   int qr_packed; // the caller's knots t < horizon keep Q, R as packed lower triangles (gar_layout.h); the folded knots: full
+  int lds;       // gar_fold_constraints: the launch carries fold_lds_doubles(max nx, max nc) doubles of LDS
 };
+__host__ __device__ inline int fold_lds_doubles(int nx, int nc) { return nx * (nc + 1) + nx * nc + nc + 2; }
 
 // grid (horizon + 1, batch) x 256
 __global__ void __launch_bounds__(256) gar_fold_constraints(FoldParams P) {
@@ -49,6 +51,44 @@ __global__ void __launch_bounds__(256) gar_fold_constraints(FoldParams P) {
   const double *Cm = src + ko.C, *dv = src + ko.d;
   const double mu = P.mueq;
   const bool pk = P.qr_packed && t < P.horizon;
+  // C and Z = C / mu, zff = d / mu staged in LDS once per knot (round 6: every one of the nx^2 nc products used to divide
+  // -- 41 k f64 divisions per (36, 12, 32) knot, 60 us per sweep on one problem; same operations on the same operands in
+  // the same order: bitwise the same folded knot).  C's copy has the odd pitch nc + 1 (lanes = consecutive i).
+  if (P.lds && nc > 0) {
+    double *Cs = gar_smem, *Zs = Cs + nx * (nc + 1), *zd = Zs + nx * nc;
+    for (int e = tid; e < nx * nc; e += 256) {
+      const int i = e / nc, k = e - i * nc;
+      const double c = Cm[e];
+      Cs[i * (nc + 1) + k] = c;
+      Zs[e] = c / mu;
+    }
+    for (int k = tid; k < nc; k += 256)
+      zd[k] = dv[k] / mu;
+    __syncthreads();
+    for (int e = tid; e < ko.C; e += 256) {
+      double v = src[e];
+      if (pk && e >= ko.R && e < ko.R + nu * nu) {
+        const int j = (e - ko.R) / nu, i = (e - ko.R) - j * nu;
+        v = src[ko.R + (i >= j ? gar_lower_index(nu, i, j) : gar_lower_index(nu, j, i))];
+      }
+      if (e < nx * nx) { // Q(i, j) += sum_k C(k, i) * (C(k, j) / mu)
+        const int j = e / nx, i = e - j * nx;
+        if (pk)
+          v = src[ko.Q + (i >= j ? gar_lower_index(nx, i, j) : gar_lower_index(nx, j, i))];
+        double acc = 0.0;
+        for (int k = 0; k < nc; ++k)
+          acc = __builtin_fma(Cs[i * (nc + 1) + k], Zs[j * nc + k], acc);
+        v += acc;
+      } else if (e >= ko.q && e < ko.q + nx) { // q(i) += sum_k C(k, i) * (d(k) / mu)
+        const int i = e - ko.q;
+        double acc = 0.0;
+        for (int k = 0; k < nc; ++k)
+          acc = __builtin_fma(Cs[i * (nc + 1) + k], zd[k], acc);
+        v += acc;
+      }
+      dst[e] = v;
+    }
+  } else
   for (int e = tid; e < ko.C; e += 256) {
     double v = src[e];
     if (pk && e >= ko.R && e < ko.R + nu * nu) { // (the folded knot keeps full blocks: the wave-leg family's format)

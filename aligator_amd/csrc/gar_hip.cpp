@@ -815,6 +815,14 @@ gar::LegParams make_leg_params(gar_hip_solver *s) {
   return Q;
 }
 
+// gar_fold_constraints stages C and C / mu in LDS where they fit the default dynamic allocation (0: they do not)
+size_t fold_lds_bytes(const gar_hip_solver *s) {
+  int nxm = 0, ncm = 0;
+  for (const auto &m : s->meta)
+    nxm = std::max(nxm, (int)m.nx), ncm = std::max(ncm, (int)m.nc);
+  const size_t b = sizeof(double) * (size_t)gar::fold_lds_doubles(nxm, ncm);
+  return b <= 48 * 1024 ? b : 0;
+}
 gar::FoldParams make_fold_params(gar_hip_solver *s) {
   gar::FoldParams F{};
   const gar_hip_solver *f = s->flay;
@@ -840,6 +848,7 @@ gar::FoldParams make_fold_params(gar_hip_solver *s) {
   F.t_hi = hi;
   F.mueq = s->fold_mueq;
   F.qr_packed = s->qr_packed ? 1 : 0;
+  F.lds = fold_lds_bytes(s) > 0 ? 1 : 0;
   return F;
 }
 

@@ -57,8 +57,8 @@ int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
     if (s->fold) { // knots with nc > 0: fold C, d into Q, q (gar_fold.hpp); problems with D != 0 get flagged
       s->fold_mueq = mueq;
       s->fold_expanded = s->coupled_known = false;
-      hipLaunchKernelGGL(gar::gar_fold_constraints, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch), dim3(256), 0,
-                         s->stream, make_fold_params(s));
+      hipLaunchKernelGGL(gar::gar_fold_constraints, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch), dim3(256),
+                         fold_lds_bytes(s), s->stream, make_fold_params(s));
     }
     hipLaunchKernelGGL(s->leg_bwd_kernel, grid, dim3(64 * s->leg_waves),
                        (size_t)s->leg_lds_doubles * sizeof(double), s->stream, Q);
@@ -297,10 +297,28 @@ int launch_forward(gar_hip_solver *s, const double *theta_dev) {
     if (s->fold) { // v_t = zff + Z x_t on this rank's stages; flagged problems: the generic roll-out
       hipLaunchKernelGGL(gar::gar_constraint_multipliers, dim3((unsigned)(s->horizon + 1), (unsigned)s->batch), dim3(64), 0,
                          s->stream, make_fold_params(s));
+      const char *cf = gar_option("GAR_HIP_CSTR_SEG_FORWARD");
+      if (s->cseg_on && !(cf && std::string(cf) == "generic")) { // the constrained segment legs' own roll-out (gar_cstr_seg.hpp)
+        gar::CsegFwdParams F{};
+        F.meta = s->d_meta;
+        F.fac = s->d_fac;
+        F.sol = s->d_sol;
+        F.csol = s->d_csol;
+        F.only = s->d_status + s->batch + 4;
+        F.fac_stride = s->fac_doubles;
+        F.sol_stride = s->sol_doubles;
+        F.horizon = s->horizon;
+        F.num_legs = s->num_legs;
+        F.leg_begin = s->leg_begin;
+        F.nxb = s->nxb;
+        F.nc0 = s->nc0;
+        hipLaunchKernelGGL(s->cseg.forward, dim3((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch), dim3(64), 0, s->stream, F);
+      } else {
       gar::GenericParams G = make_params(s, 0.0);
       G.only = s->d_status + s->batch + 4;
       hipLaunchKernelGGL(gar::gar_forward_generic, dim3((unsigned)(s->leg_end - s->leg_begin), (unsigned)s->batch), dim3(GAR_FORWARD_THREADS),
                          (size_t)s->lds.ftotal * sizeof(double), s->stream, G);
+      }
     }
     HIP_TRY(hipGetLastError());
     if (s->timing)
