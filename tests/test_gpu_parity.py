@@ -152,7 +152,7 @@ def test_round4_soak_failure_replayed():
     try:
         rep = {}
         par = pc.check_parallel(d["prob"], d["mu"], d["legs"], 1e-8, conditioned=True, report=rep)
-        assert par._impl.kernel_name == "wave_leg<8,4>+fold" and par._impl.condensed_resolved(0)
+        assert par._impl.kernel_name.startswith("wave_leg<8,4>+fold") and par._impl.condensed_resolved(0)
         assert max(rep["hip_leg-lapack"][:2]) <= 1e-12 and max(rep["hip_leg-lapack"][2:]) <= 1e-5
     finally:
         os.environ.pop("GAR_HIP_BACKWARD", None)
