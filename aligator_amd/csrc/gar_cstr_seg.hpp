@@ -85,7 +85,12 @@ __global__ void __launch_bounds__(64, 1) gar_cseg_backward(MfmaParams P, int num
   int tstart = t_first;
   const bool resumed = PHASE > 0 || (flags & CSEG_REENTER) != 0;
   if (resumed) {
+    // resume[unit]: t >= 0: the knot the NEXT kernel of the chain takes over at; -1: the leg is done; -2 - t: the coupled
+    // kernel of round 1 handed the leg back at knot t without having met a pivot -- round 2's first kernel picks it up,
+    // the LDS Bunch-Kaufman kernel in between leaves it alone
     tstart = P.resume[unit];
+    if (PHASE == 0 && tstart <= -2)
+      tstart = -2 - tstart;
     if (tstart < 0)
       return;
   }
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(64, 1) gar_cseg_backward(MfmaParams P, int num
   }
   if constexpr (PHASE < 2) {
     if (lane == 0)
-      P.resume[unit] = (PHASE == 1 && (flags & CSEG_SINGLE) && tstart >= t_beg) ? tstart : -1;
+      P.resume[unit] = (PHASE == 1 && (flags & CSEG_SINGLE) && tstart >= t_beg) ? -2 - tstart : -1;
     wave_flush_vxx<NX, GAR_VXX_PACKED != 0, PK>(V, vflush, lane);
   }
   if (failed && lane == 0)

@@ -123,3 +123,7 @@ if has csegbatch; then
   echo "== leg mode with coupled constraints, a batch of problems =="
   BATCH=${BATCH:-64} timeout 900 python scripts/time_coupled_legs.py 2>&1 | grep -vE "amdgpu.ids" | tee $O/cseg_time_batch${BATCH:-64}.log
 fi
+if has csegab; then
+  echo "== constrained segment legs: threads of the per-stage parameter kernel (256 | 512 | 1024), 32 and 6 legs =="
+  for L in 32 6; do for lib in libgar_hip_cseg_st256.so libgar_hip.so libgar_hip_cseg_st1024.so; do LEGS=$L LIB=$lib timeout 200 python scripts/prof_coupled_legs.py 2>&1 | grep done; done; done | tee $O/cseg_ab_stage_threads.log
+fi

@@ -13,9 +13,15 @@ prob = synth.generate_lq_problem(7, np.zeros(nx), N, nx, nu, nc=nc, mode="W")
 rng = np.random.default_rng(9)
 for k in prob.stages[:-1]:
     k.D[...] = rng.uniform(-1, 1, k.D.shape)
-s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs)
+LIB = os.environ.get("LIB")
+s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs, lib_path=(os.path.join(ROOT, "aligator_amd", LIB) if LIB else None))
 s.upload([prob])
+import time
+for _ in range(5):
+    s.backward_async(mu); s.forward_async()
+s.sync()
+t0 = time.perf_counter()
 for _ in range(20):
     s.backward_async(mu); s.forward_async()
 s.sync()
-print(s.kernel_name, "done")
+print(s.kernel_name, LIB or "libgar_hip.so", f"{(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per sweep, {legs} legs", "done")

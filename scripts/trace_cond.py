@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aligator_amd import synth
 from aligator_amd.gar import BatchedRiccatiSolver
-nx, nu, N, legs = 36, 12, 256, 8
+nx, nu, N, legs = 36, 12, 256, int(os.environ.get("LEGS", "8"))
 prob = synth.generate_lq_problem(5, np.zeros(nx), N, nx, nu, mode="W")
 TRACE_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aligator_amd", "libgar_hip_trace.so")  # make -C aligator_amd/csrc trace
 s = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs, lib_path=TRACE_LIB)
