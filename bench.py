@@ -655,6 +655,39 @@ def secondary_shapes(device, batch=1024):
                     "backward_frac_of_hbm_roofline": 8 * (knot + fac) * N * batch / (kb / reps * 1e-3) / HBM_PEAK,
                     "max_rel_err_vs_oracle": err, "max_kkt_rel": kkt}
         s.close()
+        if nc > 0:
+            # ... and the way the reference itself benchmarks this shape: ONE problem, ParallelRiccatiSolver (BM_parallel,
+            # bench/gar-riccati.cpp:64-90): D = 0 through the fold onto the wave-leg kernels (csrc/gar_fold.hpp); D != 0 on the
+            # constrained segment legs (csrc/gar_cstr_seg.hpp, round 6), beside the any-dimension leg kernels that served such
+            # problems before (GAR_HIP_CSTR_SEG_LEGS=0) and the serial chain; x, u against the serial oracle in the same run
+            lat, names = {}, {}
+            for legs, seg in ((1, "1"), (32, "1")) + (((32, "0"),) if key.endswith("_coupled") else ()):
+                os.environ["GAR_HIP_CSTR_SEG_LEGS"] = seg
+                s1 = BatchedRiccatiSolver([k.dims for k in prob.stages], nx, batch=1, num_legs=legs, device=device)
+                os.environ.pop("GAR_HIP_CSTR_SEG_LEGS")
+                s1.upload([prob])
+                for _ in range(2):
+                    s1.backward_async(mu); s1.forward_async()
+                s1.sync()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    s1.backward_async(mu); s1.forward_async()
+                s1.sync()
+                lat[(legs, seg)] = (time.perf_counter() - t0) / 10 * 1e3
+                names[(legs, seg)] = s1.kernel_name
+                if legs > 1 and seg == "1":
+                    sol = s1.solution(0)
+                    xu = max(float(np.abs(a - c).max()) for A, B in zip(sol[:2], ref[:2]) for a, c in zip(A, B) if a.size)
+                    xu /= max(1.0, max(float(np.abs(v).max()) for v in ref[0]))
+                    out[key]["parallel_mode_one_problem"] = {
+                        "legs": legs, "kernel": s1.kernel_name, "condensed_solver": s1.condensed_solver_name,
+                        "ms_per_sweep": lat[(legs, seg)], "serial_ms_per_sweep": lat[(1, "1")],
+                        "max_rel_err_x_u_vs_serial_oracle": xu,
+                        "note": "multipliers are of order 1/mu at mu = 1e-11: x, u are what a leg-parallel solve of this problem "
+                                "pins (DESIGN.md 2, conditioning bound; tests/test_gpu_parity.py checks v, lambda against it)"}
+                s1.close()
+            if (32, "0") in lat:
+                out[key]["parallel_mode_one_problem"]["ms_per_sweep_on_the_any_dimension_leg_kernels"] = lat[(32, "0")]
         if nc == 0:
             # ... and the way the reference itself benchmarks this shape: ONE problem, LQSolverChoice::PARALLEL
             # (bench/talos-walk.cpp:102-127, bench/lqr.cpp:112-134) -- latency of one backward + forward sweep in leg

@@ -8,6 +8,8 @@ well-conditioned generator "W", 1e-6 on the reference-faithful generator "F"
 (the reference's own bar at nx=36, tests/gar/riccati.cpp:138), relative to the
 largest multiplier / value-function entry of the oracle solution.
 """
+import os
+
 import numpy as np
 
 from aligator_amd import synth
@@ -598,7 +600,13 @@ def check_constrained_legs_fold(lib_path=None, shapes=((8, 4, 4, 11, 3, 1e-6), (
         coupled = prob.copy()
         for k in coupled.stages[1:horz:3]:
             k.D[...] = rng.uniform(-1, 1, k.D.shape)
-        par = check_parallel(coupled, mu, legs, tol, lib_path, conditioned=True)   # same family name, generic kernels underneath
+        par = check_parallel(coupled, mu, legs, tol, lib_path, conditioned=True)   # (round 6: the constrained segment legs underneath)
+        os.environ["GAR_HIP_CSTR_SEG_LEGS"] = "0"                                  # ... and the any-dimension leg kernels, as before
+        try:
+            par = check_parallel(coupled, mu, legs, tol, lib_path, conditioned=True)
+            assert par._impl.kernel_name == f"wave_leg<{nx},{nu}>+fold"
+        finally:
+            del os.environ["GAR_HIP_CSTR_SEG_LEGS"]
         # one batch, both kinds: problem 1 has D != 0
         probs = [prob, coupled, prob.copy()]
         probs[2].stages[0].q[...] += 1.0
