@@ -276,13 +276,16 @@ __global__ void __launch_bounds__(GAR_CSEG_CHAIN_THREADS) gar_cseg_param_chain(C
   }
 }
 
+#ifndef GAR_CSEG_BK_BLOCKED
+#define GAR_CSEG_BK_BLOCKED 1
+#endif
 #ifndef GAR_CSEG_STAGE_THREADS
 #define GAR_CSEG_STAGE_THREADS 512
 #endif
 template <int NX, int NU, int NC> __host__ __device__ constexpr int cseg_stage_lds_doubles() {
   constexpr int NK = NU + NC;
-  // Vn | Bm VB | Mk | Tm | Gh | Kt | yf | sub | piv | ctrl
-  return NX * NX + 2 * NX * NU + NK * NK + NK * NX + NU * NX + NK * NX + NX + NK + NK + 16 + 16;
+  // Vn | Bm VB | Mk | Tm | Gh | Kt | yf | sub | piv | ctrl | wk (the blocked Bunch-Kaufman's panel)
+  return NX * NX + 2 * NX * NU + NK * NK + NK * NX + NU * NX + NK * NX + NX + NK + NK + 16 + NK * GAR_BK_PANEL + 16;
 }
 
 // (2b) everything else of stage t, all stages at once; also the caller-visible record (row-major fb, full Vxx: what the
@@ -349,6 +352,7 @@ __global__ void __launch_bounds__(GAR_CSEG_STAGE_THREADS) gar_cseg_param_stage(C
   double *Vn = take(bs), *Bm = take(NX * NU), *VB = take(NX * NU), *Mk = take(NK * NK), *Tm = take(NK * NX);
   double *Gh = take(NU * NX), *Kt = take(NK * NX), *yf = take(NX), *sub = take(NK);
   int *piv = (int *)take(NK), *ctrl = (int *)take(16);
+  [[maybe_unused]] double *wk = take(NK * GAR_BK_PANEL);
   const double *knot = prob + P.in_off0 + (long long)t * P.in_rec;
   for (int e = w.tid; e < NK * NX; e += w.nthr) { // [B^T; 0]: B^T (nu x nx2, row-major) = B column-major, as it is
     const double v = e < NU * NX ? knot[M::kB + e] : 0.0;
@@ -393,7 +397,13 @@ __global__ void __launch_bounds__(GAR_CSEG_STAGE_THREADS) gar_cseg_param_stage(C
       Vn[e] = Xg[e];
   }
   // the reference's own factorisation of kktMat: Bunch-Kaufman (:237-241)
-  int failed = wg_bk_factor(w, NK, Mk, NK, sub, piv, ctrl);
+  // (from 24 columns on in its panel-blocked form, as the any-dimension stage kernel does: one wave runs the pivot search,
+  // the trailing matrix is updated once per panel on MFMA tiles -- bunchkaufman.hpp:172-344 is the reference's own)
+  int failed;
+  if constexpr (GAR_CSEG_BK_BLOCKED != 0 && NK >= 24)
+    failed = wg_bk_factor_blocked(w, NK, Mk, NK, sub, piv, ctrl, wk);
+  else
+    failed = wg_bk_factor(w, NK, Mk, NK, sub, piv, ctrl);
   __syncthreads();
   wg_bk_solve(w, NK, Mk, NK, sub, piv, Tm, NX, 1, NX); // T = M^{-1} [B^T; 0], rows of nx2
   __syncthreads();

@@ -127,3 +127,8 @@ if has csegab; then
   echo "== constrained segment legs: threads of the per-stage parameter kernel (256 | 512 | 1024), 32 and 6 legs =="
   for L in 32 6; do for lib in libgar_hip_cseg_st256.so libgar_hip.so libgar_hip_cseg_st1024.so; do LEGS=$L LIB=$lib timeout 200 python scripts/prof_coupled_legs.py 2>&1 | grep done; done; done | tee $O/cseg_ab_stage_threads.log
 fi
+if has csegab2; then
+  echo "== constrained segment legs, per-stage parameter kernel: Bunch-Kaufman of the 44 x 44 kktMat column by column | panel-blocked =="
+  for L in 32 6; do for lib in libgar_hip_cseg_bkplain.so libgar_hip.so; do LEGS=$L LIB=$lib timeout 200 python scripts/prof_coupled_legs.py 2>&1 | grep done; done; done | tee $O/cseg_ab_bk_blocked.log
+  timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "segment_legs or fold" 2>&1 | tail -2 | tee -a $O/cseg_ab_bk_blocked.log
+fi
