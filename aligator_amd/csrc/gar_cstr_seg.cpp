@@ -9,6 +9,8 @@ template <int NX, int NU, int NC> static void cseg_fill(CsegKernels *k) {
   k->backward[0] = gar_cseg_backward<NX, NU, NC, 0>;
   k->backward[1] = gar_cseg_backward<NX, NU, NC, 1>;
   k->backward[2] = gar_cseg_backward<NX, NU, NC, 2>;
+  k->leg_end = gar_cseg_leg_end<NX, NU, NC>;
+  k->leg_end_lds_doubles = cseg_leg_end_lds_doubles<NX, NU, NC>();
   k->chain = gar_cseg_param_chain<NX, NU, NC>;
   k->stage = gar_cseg_param_stage<NX, NU, NC>;
   k->forward = gar_cseg_forward<NX, NU, NC>;

@@ -213,6 +213,144 @@ __global__ void __launch_bounds__(64, 1) gar_cseg_backward(MfmaParams P, int num
     atomicOr(&P.status[b], failed);
 }
 
+#ifndef GAR_CSEG_BK_BLOCKED
+#define GAR_CSEG_BK_BLOCKED 1
+#endif
+#ifndef GAR_CSEG_STAGE_THREADS
+#define GAR_CSEG_STAGE_THREADS 512
+#endif
+// ---- (1b) the leg-END stage of every non-final leg, one workgroup per (leg, problem) ---------------------------------
+// Behind a leg end V' = 0: the stage is [kff K; zff Z] = -M^-1 [r S^T; d C] with M = [R D^T; D -mu I] of the knot's own
+// blocks (:151-172), yff = f + B kff, Aff = A + B K, Vxx = Q + S K + C^T Z, vx = q + S kff + C^T zff (:175-183) -- no
+// product with a value function, so nothing of it needs the stage kernels' MFMA pipeline, and M is exactly the matrix on
+// which Bunch-Kaufman pivots (R bare against D).  Through the chain it cost a failed attempt of the coupled kernel + one
+// stage of the one-wave LDS Bunch-Kaufman kernel + a second round of launches (51 + 122 us); here it is one workgroup
+// with the panel-blocked Bunch-Kaufman (the reference's own factorisation, as in gar_cseg_param_stage), and the chain
+// behind it runs ONCE, from the knot below (flags & CSEG_REENTER on its first kernel).  Writes the stage's scratch
+// record in the stage kernels' format (fbT2, packed lower Vxx) and hands the leg on through P.resume.
+// grid (local legs, batch) x GAR_CSEG_STAGE_THREADS
+template <int NX, int NU, int NC> __host__ __device__ constexpr int cseg_leg_end_lds_doubles() {
+  constexpr int NK = NU + NC;
+  // Mk | G | Sm Bm | Cm | Am | Qm | q f yff vx | sub | piv | ctrl | wk
+  return NK * NK + NK * (NX + 2) + 2 * NX * NU + NC * NX + 2 * NX * NX + 4 * NX + NK + NK + 16 + NK * GAR_BK_PANEL + 16;
+}
+template <int NX, int NU, int NC>
+__global__ void __launch_bounds__(GAR_CSEG_STAGE_THREADS) gar_cseg_leg_end(MfmaParams P, int num_legs, int leg_begin,
+                                                                          const int *only) {
+  using M = MfmaCfg<NX, NU, NC>;
+  constexpr int NK = M::NK, bs = NX * NX, GLD = NX + 2; // G = [rhs | matrix | pad]: rows of NX + 2 doubles
+  const WG w = wg_self();
+  double *sm = gar_smem;
+  const int leg = (int)blockIdx.x + leg_begin, b = (int)blockIdx.y;
+  if (only[b] != 1)
+    return;
+  const int unit = b * (int)gridDim.x + (int)blockIdx.x;
+  const int N = P.horizon;
+  int t_beg, t_end;
+  gar_get_work(N, leg, num_legs, &t_beg, &t_end);
+  if (leg == num_legs - 1) { // the last leg starts from the true terminal knot: the chain's first kernel does that
+    if (w.tid == 0)
+      P.resume[unit] = (N - 1 >= t_beg) ? -2 - (N - 1) : -1;
+    return;
+  }
+  const int t = t_end - 1;
+  if (t < t_beg) {
+    if (w.tid == 0)
+      P.resume[unit] = -1;
+    return;
+  }
+  const double *knot = P.prob + (long long)b * P.prob_stride + P.in_off0 + (long long)t * P.in_rec;
+  double *out = P.fac + (long long)b * P.fac_stride + (long long)t * P.fac_rec;
+  double *p = sm;
+  auto take = [&](int n) { double *o = p; p += n; return o; };
+  double *Mk = take(NK * NK), *G = take(NK * GLD), *Sm = take(NX * NU), *Bm = take(NX * NU), *Cm = take(NC * NX);
+  double *Am = take(bs), *Qm = take(bs), *qv = take(NX), *fv = take(NX), *yf = take(NX), *vx = take(NX), *sub = take(NK);
+  int *piv = (int *)take(NK), *ctrl = (int *)take(16);
+  double *wk = take(NK * GAR_BK_PANEL);
+  for (int e = w.tid; e < NK * NK; e += w.nthr) { // [R D^T; D -mu I] (:151-154), column-major, both triangles
+    const int j = e / NK, i = e - j * NK;
+    const int a = i >= j ? i : j, c = i >= j ? j : i;
+    double v;
+    if (a < NU)
+      v = GAR_QR_PACKED ? knot[M::kR + gar_lower_index(NU, a, c)] : knot[M::kR + c * NU + a];
+    else if (c < NU)
+      v = knot[M::kD + c * NC + (a - NU)];
+    else
+      v = (a == c) ? -P.mueq : 0.0;
+    Mk[e] = v;
+  }
+  for (int e = w.tid; e < NK * GLD; e += w.nthr) { // -[r S^T; d C] (:156-159), row i: rhs | matrix row
+    const int i = e / GLD, j = e - i * GLD;
+    double v = 0.0;
+    if (j == 0)
+      v = i < NU ? -knot[M::kr + i] : -knot[M::kd + (i - NU)];
+    else if (j <= NX)
+      v = i < NU ? -knot[M::kS + i * NX + (j - 1)] : -knot[M::kC + (j - 1) * NC + (i - NU)];
+    G[e] = v;
+  }
+  for (int e = w.tid; e < NX * NU; e += w.nthr) {
+    Sm[e] = knot[M::kS + e];
+    Bm[e] = knot[M::kB + e];
+  }
+  for (int e = w.tid; e < NC * NX; e += w.nthr)
+    Cm[e] = knot[M::kC + e];
+  for (int e = w.tid; e < bs; e += w.nthr) {
+    const int j = e / NX, i = e - j * NX;
+    Am[e] = knot[M::kA + e];
+    Qm[e] = GAR_QR_PACKED ? knot[M::kQ + (i >= j ? gar_lower_index(NX, i, j) : gar_lower_index(NX, j, i))] : knot[M::kQ + e];
+  }
+  for (int e = w.tid; e < NX; e += w.nthr) {
+    qv[e] = knot[M::kq + e];
+    fv[e] = knot[M::kf + e];
+  }
+  __syncthreads();
+  int failed;
+  if constexpr (GAR_CSEG_BK_BLOCKED != 0 && NK >= 24)
+    failed = wg_bk_factor_blocked(w, NK, Mk, NK, sub, piv, ctrl, wk);
+  else
+    failed = wg_bk_factor(w, NK, Mk, NK, sub, piv, ctrl);
+  __syncthreads();
+  wg_bk_solve(w, NK, Mk, NK, sub, piv, G, GLD, 1, NX + 1); // [kff K; zff Z]
+  __syncthreads();
+  const MatV Km = rowmajor(G + 1, GLD), Zm = rowmajor(G + NU * GLD + 1, GLD), Bv = colmajor(Bm, NX), Sv = colmajor(Sm, NX);
+  // yff = f + B kff ; Aff = A + B K (:266-267) ; Vxx = Q + S K (+ C^T Z below) ; vx = q + S kff + C^T zff (:175-183)
+  wg_gemm(w, NX, NX, NU, Bv, Km, colmajor(Am, NX), colmajor(Am, NX), 1.0);
+  wg_gemm(w, NX, NX, NU, Sv, Km, colmajor(Qm, NX), colmajor(Qm, NX), 1.0);
+  for (int i = w.tid; i < NX; i += w.nthr) {
+    double y = fv[i], v = qv[i];
+    for (int k = 0; k < NU; ++k) {
+      y = __builtin_fma(Bm[k * NX + i], G[k * GLD], y);
+      v = __builtin_fma(Sm[k * NX + i], G[k * GLD], v);
+    }
+    for (int k = 0; k < NC; ++k)
+      v = __builtin_fma(Cm[i * NC + k], G[(NU + k) * GLD], v);
+    yf[i] = y;
+    vx[i] = v;
+  }
+  __syncthreads();
+  wg_gemm(w, NX, NX, NC, colmajor(Cm, NC).T(), Zm, colmajor(Qm, NX), colmajor(Qm, NX), 1.0);
+  __syncthreads();
+  // the scratch record, in the stage kernels' format: ff = [kff; zff; yff], fb = [K; Z; Aff] as fbT2, packed lower Vxx, vx
+  for (int e = w.tid; e < M::NR; e += w.nthr)
+    out[M::fFF + e] = e < NK ? G[e * GLD] : yf[e - NK];
+  for (int e = w.tid; e < M::NR * NX; e += w.nthr) {
+    const int r = e / NX, j = e - r * NX;
+    out[M::fFB + M::fbT2(r, j)] = r < NK ? G[r * GLD + 1 + j] : Am[j * NX + (r - NK)];
+  }
+  for (int e = w.tid; e < bs; e += w.nthr) {
+    const int j = e / NX, i = e - j * NX;
+    if (i >= j)
+      out[M::fVxx + gar_sym_index(GAR_VXX_PACKED, NX, i, j)] = Qm[e];
+  }
+  for (int e = w.tid; e < NX; e += w.nthr)
+    out[M::fvx + e] = vx[e];
+  if (w.tid == 0) {
+    P.resume[unit] = (t - 1 >= t_beg) ? -2 - (t - 1) : -1;
+    if (failed)
+      atomicOr(&P.status[b], 1);
+  }
+}
+
 // ---- (2) the parameter part -------------------------------------------------------------------------------------------
 
 #ifndef GAR_CSEG_CHAIN_THREADS
@@ -276,12 +414,6 @@ __global__ void __launch_bounds__(GAR_CSEG_CHAIN_THREADS) gar_cseg_param_chain(C
   }
 }
 
-#ifndef GAR_CSEG_BK_BLOCKED
-#define GAR_CSEG_BK_BLOCKED 1
-#endif
-#ifndef GAR_CSEG_STAGE_THREADS
-#define GAR_CSEG_STAGE_THREADS 512
-#endif
 template <int NX, int NU, int NC> __host__ __device__ constexpr int cseg_stage_lds_doubles() {
   constexpr int NK = NU + NC;
   // Vn | Bm VB | Mk | Tm | Gh | Kt | yf | sub | piv | ctrl | wk (the blocked Bunch-Kaufman's panel)

@@ -32,10 +32,11 @@ struct CsegFwdParams {
 
 struct CsegKernels {
   void (*backward[3])(MfmaParams, int, int, const int *, int) = {nullptr, nullptr, nullptr}; // the chain: decoupled, coupled, LDS Bunch-Kaufman
+  void (*leg_end)(MfmaParams, int, int, const int *) = nullptr; // the leg-end stage of every non-final leg, a workgroup each
   void (*chain)(CsegParams) = nullptr;
   void (*stage)(CsegParams) = nullptr;
   void (*forward)(CsegFwdParams) = nullptr; // the roll-out, one wave per (leg, problem)
-  int backward_lds_doubles = 0, chain_lds_doubles = 0, stage_lds_doubles = 0, chain_threads = 0, stage_threads = 0;
+  int backward_lds_doubles = 0, leg_end_lds_doubles = 0, chain_lds_doubles = 0, stage_lds_doubles = 0, chain_threads = 0, stage_threads = 0;
   long long rec = 0;               // pitch of the scratch records (the terminal knot's at horizon * rec)
   long long (*scratch_doubles)(int horizon, int num_legs) = nullptr; // per problem
 };

@@ -1002,6 +1002,8 @@ int allocate(gar_hip_solver *s) {
       for (auto k : s->cseg.backward)
         HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(s->cseg.backward_lds_doubles * sizeof(double))));
+      HIP_TRY(hipFuncSetAttribute((const void *)s->cseg.leg_end, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(s->cseg.leg_end_lds_doubles * sizeof(double))));
       HIP_TRY(hipFuncSetAttribute((const void *)s->cseg.chain, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(s->cseg.chain_lds_doubles * sizeof(double))));
       HIP_TRY(hipFuncSetAttribute((const void *)s->cseg.stage, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -85,8 +85,18 @@ int launch_backward(gar_hip_solver *s, double mueq, int l0 = -1, int l1 = -1) {
         const char *sa = gar_option("GAR_HIP_SPD_ACCEPT");
         M.spd_accept = (sa && sa[0] == '0') ? 0 : 1;
       }
-      // the chain, leg by leg, in two rounds (gar_cstr_seg.hpp): decoupled stage -> coupled stage and LDS Bunch-Kaufman for
-      // ONE stage each (a leg end is where Bunch-Kaufman pivots), then the same again from the hand-over knot, to the end
+      // (gar_cstr_seg.hpp) the leg-end stages -- V' = 0: no MFMA work, and the matrix on which Bunch-Kaufman pivots -- by a
+      // workgroup each, then the chain once, leg by leg, from the knot below: decoupled -> coupled -> LDS Bunch-Kaufman;
+      // CSTR_SEG_LEG_END = 0: the leg ends through the chain too, which then runs in two rounds -- coupled stage and LDS
+      // Bunch-Kaufman for ONE stage each, then the same again from the hand-over knot, to the end
+      const char *le = gar_option("GAR_HIP_CSTR_SEG_LEG_END");
+      if (!(le && le[0] == '0')) {
+        hipLaunchKernelGGL(s->cseg.leg_end, grid, dim3((unsigned)s->cseg.stage_threads),
+                           (size_t)s->cseg.leg_end_lds_doubles * sizeof(double), s->stream, M, s->num_legs, l0, flagged);
+        for (int ph = 0; ph < 3; ++ph)
+          hipLaunchKernelGGL(s->cseg.backward[ph], grid, dim3(64), (size_t)s->cseg.backward_lds_doubles * sizeof(double),
+                             s->stream, M, s->num_legs, l0, flagged, ph == 0 ? gar::kCsegReenter : 0);
+      } else
       for (int round = 0; round < 2; ++round)
         for (int ph = 0; ph < 3; ++ph)
           hipLaunchKernelGGL(s->cseg.backward[ph], grid, dim3(64), (size_t)s->cseg.backward_lds_doubles * sizeof(double),

@@ -409,7 +409,9 @@ int gar_hip_debug_trace(gar_hip_solver *s, int enable, long long out[64]);
  *   LEGS = generic | LEG_WAVES = 1 | SEG_LEGS = 0 | FOLD = 0     leg mode: the any-dimension leg kernels / one wave
  *                                  per leg / no segment legs on the wide shape / constrained knots not folded
  *   CSTR_SEG_LEGS = 0              leg mode, problems with D != 0 on the any-dimension leg kernels instead of the
- *                                  constrained segment legs (csrc/gar_cstr_seg.hpp; (36,12,32), (16,8,8), (8,4,4))
+ *                                  constrained segment legs (csrc/gar_cstr_seg.hpp; (36,12,32), (16,8,8), (8,4,4));
+ *                                  CSTR_SEG_LEG_END = 0 (per launch): their leg ends through the stage chain (two rounds)
+ *                                  instead of the leg-end kernel; CSTR_SEG_FORWARD = generic: the any-dimension roll-out
  *   CONDENSED = generic | chain, CONDENSED_REDUCED = 0, CONDENSED_CR = 0 | <k>   the condensed solve: elimination
  *                                  chain instead of block cyclic reduction (specialised / any-dimension paths)
  *   STAGE_NT = 0 | 1, EAGER = 0    host staging with / without non-temporal stores; gar_hip_backward_blocks without

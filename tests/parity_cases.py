@@ -403,6 +403,18 @@ def check_constrained_legs_segments(lib_path=None, shapes=((8, 4, 4, 13, 3, 1e-6
                 if nx <= 16:
                     assert nsw > 0 and bk > 0, ("test must reach the LDS Bunch-Kaufman stage inside a leg", nsw, bk)
     assert reached_coupled > 0 and reached_bk > 0
+    # the leg ends through the stage chain itself (two rounds) instead of the leg-end kernel: the switch, per launch
+    os.environ["GAR_HIP_CSTR_SEG_LEG_END"] = "0"
+    try:
+        nx, nu, nc, horz, legs, mu = shapes[0]
+        rng = np.random.default_rng(17)
+        prob = synth.generate_lq_problem(rng, rng.standard_normal(nx), horz, nx, nu, nc=nc, mode="W")
+        for k in prob.stages[:-1]:
+            k.D[...] = rng.uniform(-1, 1, k.D.shape)
+        par = check_parallel(prob, mu, legs, tol, lib_path, conditioned=True)
+        assert sum(par._impl.constrained_bk_stages()) > 0
+    finally:
+        del os.environ["GAR_HIP_CSTR_SEG_LEG_END"]
     # one batch: a folded problem (D = 0), a coupled one, a folded one -- each family skips the other's problems
     nx, nu, nc, horz, legs, mu = shapes[0]
     rng = np.random.default_rng(3)
