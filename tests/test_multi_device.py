@@ -62,6 +62,22 @@ def test_multi_device_constrained_knots(emu):
     pc.check_parallel(prob, 1e-6, 3, 1e-7, emu, devices=[0, 1], conditioned=True)
 
 
+@pytest.mark.parametrize("legs,devices", [(3, [0, 1]), (5, [0, 1, 2])])
+def test_multi_device_coupled_constraints(emu, legs, devices):
+    """D != 0 in leg mode over several devices: every sub-solver runs the constrained segment legs (gar_cstr_seg.hpp) on
+    ITS legs (leg_begin > 0 on all but the first) -- plain part, leg-end kernel, parameter recursion, roll-out -- and the
+    boundary tuples travel as for every other family."""
+    rng = np.random.default_rng(4)
+    prob = synth.generate_lq_problem(rng, rng.standard_normal(8), 16, 8, 4, nc=4, mode="W")
+    for t, k in enumerate(prob.stages[:-1]):
+        k.C[...] = rng.uniform(-1, 1, k.C.shape)
+        k.D[...] = rng.uniform(-1, 1, k.D.shape)
+        if t % 4 == 0:
+            k.R[...] *= 1e-2                      # (knots on which Bunch-Kaufman pivots, inside legs too)
+    par = pc.check_parallel(prob, 1e-6, legs, 1e-7, emu, devices=devices, conditioned=True)
+    assert "wave_seg<8,4,4>" in par._impl.kernel_name
+
+
 @pytest.mark.parametrize("exchange", ["pull", "copy", "nopeer"])
 def test_multi_device_matches_the_reference_outputs(emu, monkeypatch, exchange):
     """The reference's own ParallelRiccatiSolver outputs (tests/golden/ref, compiled from /root/reference by

@@ -56,6 +56,24 @@ if mode == "horizon":
         f = s.impl.factor(t_own, 0)
         if f.nu > 0:
             assert np.abs(np.diag(f.kktMat)).max() > 0.0
+    # coupled constraints (D != 0) over the ranks: every rank runs the constrained segment legs (gar_cstr_seg.hpp) on ITS
+    # legs -- leg_begin > 0 on all but rank 0 -- against the serial oracle
+    crng = np.random.default_rng(12)
+    cprob = synth.generate_lq_problem(crng, crng.standard_normal(8), 17, 8, 4, nc=4, mode="W")
+    for k in cprob.stages[:-1]:
+        k.D[...] = crng.uniform(-1, 1, k.D.shape)
+    _, _, cref = pc.oracle_serial(cprob, 1e-6)
+    csc = pc.scale_of(cref)
+    for legs in (4, 5):
+        s = ShardedRiccatiSolver([k.dims for k in cprob.stages], cprob.nc0, legs, batch=1, lib_path=emu, on_device=False)
+        assert "wave_seg<8,4,4>" in s.impl.kernel_name, s.impl.kernel_name
+        s.impl.upload([cprob])
+        s.backward(1e-6)
+        s.forward()
+        csol = s.gather_solution(0)
+        for A, B in zip(csol, cref):
+            assert pc.maxdiff(A, B) <= 1e-7 * csc
+        assert max(lqrComputeKktError(cprob, *csol, mueq=1e-6)) <= 1e-7 * csc
     # the any-dimension leg kernels over two ranks: the gathered tuples go through the leg-parallel state elimination
     # and the block cyclic reduction of the reduced condensed system (gar_condensed_cr.hpp), redundantly on every rank
     os.environ["GAR_HIP_FORCE_GENERIC"] = "1"
