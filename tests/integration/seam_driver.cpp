@@ -27,7 +27,7 @@ using Knot = gar::LqrKnotTpl<double>;
 using Base = gar::RiccatiSolverBase<double>;
 using VectorXs = Eigen::Matrix<double, Eigen::Dynamic, 1>;
 
-static Problem make_problem(uint nx, uint nu, uint nc, uint N, unsigned seed) {
+static Problem make_problem(uint nx, uint nu, uint nc, uint N, unsigned seed, bool coupled = false) {
   std::mt19937 rng(seed);
   std::normal_distribution<double> n01(0.0, 1.0);
   std::uniform_real_distribution<double> u11(-1.0, 1.0);
@@ -61,6 +61,9 @@ static Problem make_problem(uint nx, uint nu, uint nc, uint N, unsigned seed) {
       k.d(c) = u11(rng);
       for (uint j = 0; j < nx; ++j)
         k.C(c, j) = u11(rng);
+      if (coupled) // (D != 0: the reduced KKT matrix [Rhat D^T; D -mu I] is really coupled, riccati-kernel.hxx:232-241)
+        for (uint j = 0; j < nut; ++j)
+          k.D(c, j) = u11(rng);
     }
     knots.push_back(std::move(k));
   }
@@ -127,12 +130,15 @@ extern "C" void emu_set_device_count(int n); // the emulator build's virtual dev
 int main() {
   int bad = 0;
   // ndev > 1: the legs split over that many devices behind the ONE RiccatiSolverBase object (gar_hip_multi_create)
-  struct Case { uint nx, nu, nc, N; int legs; double mu; const char *want; int ndev; };
+  struct Case { uint nx, nu, nc, N; int legs; double mu; const char *want; int ndev; bool coupled; };
 #ifndef SEAM_GPU
   emu_set_device_count(3);
   const Case cases[] = {{8, 4, 0, 12, 1, 1e-10, "<8,4>", 1},        {7, 3, 0, 9, 1, 1e-10, "<8,4>", 1}, // padded inside the C ABI
                         {8, 4, 3, 10, 1, 1e-6, "generic", 1},       {12, 6, 0, 14, 3, 1e-10, "wave_leg<12,8>", 1},
                         {8, 4, 2, 11, 2, 1e-6, "wave_leg<8,4>+fold", 1},
+                        // D != 0 in leg mode: the constrained segment legs (gar_cstr_seg.hpp) against the reference's
+                        // ParallelRiccatiSolver, one device and the legs over two
+                        {8, 4, 4, 13, 3, 1e-6, "wave_seg<8,4,4>", 1, true}, {8, 4, 4, 17, 4, 1e-6, "wave_seg<8,4,4>", 2, true},
                         {12, 6, 0, 14, 3, 1e-10, "wave_leg<12,8>", 3}, {8, 4, 0, 17, 5, 1e-10, "wave_leg<8,4>", 2},
                         {5, 2, 1, 11, 4, 1e-6, "generic", 3}};
 #else
@@ -142,11 +148,12 @@ int main() {
   const Case cases[] = {{36, 12, 0, 64, 1, 1e-10, "mfma<36,12>", 1},   {36, 12, 0, 96, 6, 1e-10, "wave_leg<36,12>", 1},
                         {56, 22, 0, 40, 1, 1e-10, "pair<56,24>", 1},    {56, 22, 0, 48, 6, 1e-10, "pair_leg<56,24>", 1},
                         {36, 12, 32, 32, 1, 1e-8, "wave<36,12,32>", 1}, {36, 12, 32, 36, 4, 1e-8, "fold", 1},
+                        {36, 12, 32, 36, 4, 1e-8, "wave_seg<36,12,32>", 1, true}, // (D != 0: the constrained segment legs)
                         {7, 3, 0, 9, 1, 1e-10, "<8,4>", 1},             {5, 2, 1, 11, 4, 1e-6, "generic", 1},
                         {36, 12, 0, 96, 6, 1e-10, "wave_leg<36,12>", 2}, {12, 6, 0, 30, 5, 1e-10, "wave_leg<12,8>", 2}};
 #endif
   for (const Case &c : cases) {
-    Problem pr = make_problem(c.nx, c.nu, c.nc, c.N, 7 + c.nx), ph = pr;
+    Problem pr = make_problem(c.nx, c.nu, c.nc, c.N, 7 + c.nx, c.coupled), ph = pr;
     Sol sr(pr), sh(ph);
     std::vector<double> gr, gh;
     std::unique_ptr<Base> ref, hip;
