@@ -200,6 +200,35 @@ __device__ __forceinline__ void cyc_update(const double *Wm, const double *Bm, d
     }
 }
 
+// U = W B^T alone, in the accumulator layout and MFMA order of cyc_update<NX, false>'s first half (bitwise the same U)
+template <int NX>
+__device__ __forceinline__ void cyc_form_u(const double *Wm, const double *Bm,
+                                           double4_t (&Ut)[CondCfg<NX>::TX][CondCfg<NX>::TX], int lane) {
+  using K = CondCfg<NX>;
+  constexpr int TX = K::TX, KS = K::KS;
+  const int li = lane & 15, lk = lane >> 4;
+  double opW[TX][KS], opB[TX][KS];
+#pragma unroll
+  for (int t = 0; t < TX; ++t) {
+    const int c = (16 * t + li) < NX ? (16 * t + li) : NX - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      opW[t][s] = Wm[(4 * s + lk) * NX + c];
+      opB[t][s] = Bm[(4 * s + lk) * NX + c];
+    }
+  }
+#pragma unroll
+  for (int ta = 0; ta < TX; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < TX; ++tb) {
+      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opW[ta][s], opB[tb][s], acc, 0, 0, 0);
+      Ut[ta][tb] = acc;
+    }
+}
+
 // Out = sgn * U^T Cm, U in accumulator registers (element (4s+lk, 16ta+li) of U is register s&3 of
 // tile (s>>2, ta): the A operand of the transposed product), Cm a column-major block in LDS;
 // the result goes to a column-major block in global memory
@@ -298,7 +327,63 @@ template <int NX> struct BlockRegs {
   }
 };
 
+// G0 (nc0 x NX, column-major pitch nc0, in the problem record) -> an NX x NX column-major LDS block padded with zero
+// rows; every load is issued before the first LDS write (a loop of load -> use iterations pays the memory latency
+// once per iteration on a lone wave)
+template <int NX>
+__device__ __forceinline__ void cyc_stage_G0(double *dst_lds, const double *G0, int nc0, int lane) {
+  constexpr int bs = NX * NX, NCH = (bs + 63) / 64;
+  double tmp[NCH];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    const int ec = (64 * q + 63 < bs || e < bs) ? e : bs - 1;
+    const int j = ec / NX, r = ec - j * NX;
+    tmp[q] = r < nc0 ? G0[j * nc0 + r] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int e = 64 * q + lane;
+    if (64 * q + 63 < bs || e < bs)
+      dst_lds[e] = tmp[q];
+  }
+}
+// sum_k M(row, k) x_k and sum_k M(k, row) x_k with ONE accumulator in the order k = 0, 1, ...: the order of the
+// loops over the rows of G0 these replace (zero padding adds exact zeros)
+template <int NX> __device__ __forceinline__ double cyc_matvec_seq(const double *Mc, double x, int row) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < NX; ++k)
+    s = __builtin_fma(Mc[k * NX + row], lane_bcast(x, k), s);
+  return s;
+}
+template <int NX> __device__ __forceinline__ double cyc_matvecT_seq(const double *Mc, double x, int row) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < NX; ++k)
+    s = __builtin_fma(Mc[row * NX + k], lane_bcast(x, k), s);
+  return s;
+}
+template <int NX> __device__ __forceinline__ double cyc_absmatvecT_seq(const double *Mc, double ax, int row) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < NX; ++k)
+    s = __builtin_fma(fabs(Mc[row * NX + k]), lane_bcast(ax, k), s);
+  return s;
+}
+template <int NX> __device__ __forceinline__ double cyc_absmatvec_seq(const double *Mc, double ax, int row) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < NX; ++k)
+    s = __builtin_fma(fabs(Mc[k * NX + row]), lane_bcast(ax, k), s);
+  return s;
+}
+
 // ---- 1. setup: eliminate the states, one wave per leg -----------------------------------------
+// Grid J + 2: leg 0 also owns the initial condition's row (S_0, r_0, C_0), which used to trail behind its wave's
+// regular work and made the launch a third longer than any other leg needs (37 us against 25 at NX = 36).  Two extra
+// waves take it over, each inverting Vxx_0 again for itself: role 1 (blockIdx.x == J) forms S_0 and r_0, role 2
+// (blockIdx.x == J + 1) C_0.  Same operations on the same operands: the results are bitwise what one wave produced.
 template <int NX>
 __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
   using L = CyclicLds<NX>;
@@ -306,7 +391,11 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
   constexpr int bs = NX * NX, TX = K::TX;
   const CondensedParams &P = Y.C;
   const int lane = (int)threadIdx.x & 63;
-  const int k = (int)blockIdx.x, b = (int)blockIdx.y, J = P.num_legs;
+  const int b = (int)blockIdx.y, J = P.num_legs;
+  const int role = (int)blockIdx.x < J ? 0 : (int)blockIdx.x - J + 1;
+  const int k = role == 0 ? (int)blockIdx.x : 0;
+  if (role == 2 && J < 2)
+    return; // no C_0 without a second leg
   double *sm = gar_smem;
   double *Dm = sm + L::oD, *Wm = sm + L::oW, *Bm = sm + L::oB, *Mm = sm + L::oM, *D2 = sm + L::oD2;
   CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
@@ -318,44 +407,54 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
   cond_copy_block<NX>(Dm, tup, lane); // Vxx_k
   wave_sync();
   int failed = cyc_inverse<NX>(sm, lane); // Wm = P_k
-  cyc_store_block<NX>(X.P + (long long)k * bs, Wm, lane);
-  const double pk = cyc_matvec<NX>(Wm, tup[3 * bs + row], row); // p_k = P vx
-  if (lane < NX)
-    X.p[k * NX + lane] = pk;
+  if (role == 0)
+    cyc_store_block<NX>(X.P + (long long)k * bs, Wm, lane);
+  double pk = 0.0;
+  if (role != 2) {
+    pk = cyc_matvec<NX>(Wm, tup[3 * bs + row], row); // p_k = P vx
+    if (role == 0 && lane < NX)
+      X.p[k * NX + lane] = pk;
+  }
   double4_t Qt[TX][TX];
-  if (has_next) {
+  if (has_next && role != 1) {
     cond_copy_block<NX>(Bm, tup + bs, lane);     // Vxt_k
     cond_copy_block<NX>(D2, tup + 2 * bs, lane); // Vtt_k
     wave_sync();
     // Q = P Vxt = W (Vxt^T)^T ; D2 = Vtt - Vxt^T Q  -> the part of S_{k+1} this leg owns
     cyc_update<NX, true>(Wm, Bm, D2, Qt, lane);
-    cyc_store_tiles<NX>(Qt, X.Q + (long long)k * bs, lane);
-    if (k >= 1)
-      cyc_store_tiles<NX>(Qt, X.C + (long long)k * bs, lane); // C_k = Q_k
-    wave_sync();
-    cyc_store_block<NX>(X.S + (long long)(k + 1) * bs, D2, lane);
-    // r_{k+1} (this leg's part) = -vt_k + Vxt^T p_k
-    const double rk = -tup[3 * bs + NX + row] + cyc_matvecT<NX>(Bm, pk, row);
-    if (lane < NX)
-      X.r[(k + 1) * NX + lane] = rk;
-  }
-  if (k == 0) {
-    // S_0 = -G0 P_0 G0^T (padded with -I), C_0 = -G0 Q_0, r_0 = -g0 + G0 p_0
-    for (int e = lane; e < bs; e += 64) {
-      const int j = e / NX, r = e - j * NX;
-      Mm[e] = r < nc0 ? prob[P.G0_off + j * nc0 + r] : 0.0; // G0 padded to NX rows
-      D2[e] = (r == j && r >= nc0) ? -1.0 : 0.0;
+    if (role == 0) {
+      cyc_store_tiles<NX>(Qt, X.Q + (long long)k * bs, lane);
+      if (k >= 1)
+        cyc_store_tiles<NX>(Qt, X.C + (long long)k * bs, lane); // C_k = Q_k
+      wave_sync();
+      cyc_store_block<NX>(X.S + (long long)(k + 1) * bs, D2, lane);
+      // r_{k+1} (this leg's part) = -vt_k + Vxt^T p_k
+      const double rk = -tup[3 * bs + NX + row] + cyc_matvecT<NX>(Bm, pk, row);
+      if (lane < NX)
+        X.r[(k + 1) * NX + lane] = rk;
     }
+  }
+  if (role != 0) {
+    // S_0 = -G0 P_0 G0^T (padded with -I), C_0 = -G0 Q_0, r_0 = -g0 + G0 p_0
     wave_sync();
-    double4_t Zt[TX][TX];
-    cyc_update<NX, false>(Wm, Mm, D2, Zt, lane); // Z = P G0^T ; D2 -= G0 Z
+    cyc_stage_G0<NX>(Mm, prob + P.G0_off, nc0, lane); // G0 padded to NX rows
+    if (role == 1)
+      for (int e = lane; e < bs; e += 64) {
+        const int j = e / NX, r = e - j * NX;
+        D2[e] = (r == j && r >= nc0) ? -1.0 : 0.0;
+      }
     wave_sync();
-    cyc_store_block<NX>(X.S, D2, lane);
-    double r0 = cyc_matvec<NX>(Mm, pk, row);
-    r0 += (row < nc0) ? -prob[P.g0_off + row] : 0.0;
-    if (lane < NX)
-      X.r[lane] = r0;
-    if (has_next) {
+    if (role == 1) {
+      double4_t Zt[TX][TX];
+      cyc_update<NX, false>(Wm, Mm, D2, Zt, lane); // Z = P G0^T ; D2 -= G0 Z
+      wave_sync();
+      cyc_store_block<NX>(X.S, D2, lane);
+      double r0 = cyc_matvec<NX>(Mm, pk, row);
+      r0 += (row < nc0) ? -prob[P.g0_off + row] : 0.0;
+      if (lane < NX)
+        X.r[lane] = r0;
+    }
+    if (role == 2) {
       // C_0 = -G0 Q_0 = -(G0^T)^T Q_0: the tiles of Z^T... computed as (G0^T)^T Q with G0^T's
       // accumulator-layout copy: G0^T = Mm^T, so use U := G0^T in tile registers
       double4_t Gt[TX][TX];
@@ -392,10 +491,17 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
 }
 
 // ---- 2. one reduction level -------------------------------------------------------------------
-// Two waves per survivor: wave 0 folds in the right neighbour, wave 1 the left one (each inverts
-// its neighbour in its own LDS slice); wave 0 then adds wave 1's contribution and stores.
+// Three waves per survivor: wave 0 folds in the right neighbour, wave 1 the left one (each inverts its neighbour in
+// its own LDS slice), wave 2 forms the survivor's new coupling -C_i W_{i+h} C_{i+h} from wave 0's inverse while
+// wave 0 updates S_i (it used to follow that update on wave 0: 7.8 k of a level's 59 k cycles); wave 0 then adds
+// wave 1's contribution and stores.  Wave 2 repeats wave 0's U = W_j C_i^T for itself, instruction by instruction:
+// the coupling is bitwise what wave 0 produced.
+template <int NX> struct CyclicReduceLds {
+  using L = CyclicLds<NX>;
+  static constexpr int oX = 2 * L::total, oC = oX + 64, total = oC + NX * NX; // r_i exchange | C_j of wave 2
+};
 template <int NX>
-__global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
+__global__ void __launch_bounds__(192, 1) gar_cyclic_reduce(CyclicParams Y) {
   using L = CyclicLds<NX>;
   using K = CondCfg<NX>;
   constexpr int bs = NX * NX, TX = K::TX;
@@ -406,11 +512,13 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
   if (i >= J)
     return;
   const bool first = (h == 1); // the -P_j / -p_j halves of S_j, r_j are still separate
-  double *sm = gar_smem + wave * L::total;
-  double *xch = gar_smem + 2 * L::total; // r_i contribution of wave 1
+  double *sm = gar_smem + (wave == 1 ? L::total : 0);
+  double *xch = gar_smem + CyclicReduceLds<NX>::oX; // r_i contribution of wave 1
+  double *Cx = gar_smem + CyclicReduceLds<NX>::oC;  // C_j (wave 2)
   double *Dm = sm + L::oD, *Wm = sm + L::oW, *Bm = sm + L::oB, *D2 = sm + L::oD2;
   CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
   const int row = lane < NX ? lane : NX - 1;
+  const bool has_right = i + h < J, has_left = i - h >= 0, has_coupling = i + 2 * h < J;
   int failed = 0;
   auto S_of = [&](int j) { return X.S + (long long)j * bs; };
   auto r_of = [&](int j) {
@@ -433,30 +541,47 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
 #define GAR_YMARK(id)
 #endif
   GAR_YMARK(0)
+  // ---- until the inverses are there ----
   double ri = 0.0;
-  BlockRegs<NX> own; // S_i: in flight while the neighbour is inverted
   if (wave == 0) {
+    BlockRegs<NX> own; // S_i: in flight while the neighbour is inverted
     own.issue_diff(S_of(i), X.P + (long long)i * bs, first && i >= 1, lane);
     ri = r_of(i);
-  } else {
-    for (int e = lane; e < bs; e += 64)
-      D2[e] = 0.0;
-  }
-  if (wave == 0 && i + h < J) { // right eliminated neighbour j = i + h
-    const int j = i + h;
-    BlockRegs<NX> rs, rc, rcj;
-    rs.issue_diff(S_of(j), X.P + (long long)j * bs, first && j >= 1, lane);
-    rc.issue(X.C + (long long)i * bs, lane); // C_i (row i, column j)
-    if (j + h < J)
-      rcj.issue(X.C + (long long)j * bs, lane); // C_j, for the new coupling
-    rs.commit(Dm, lane);
-    rc.commit(Bm, lane);
-    wave_sync();
-    GAR_YMARK(1)
-    failed |= cyc_inverse<NX>(sm, lane); // Wm = W_j
+    if (has_right) { // right eliminated neighbour j = i + h
+      const int j = i + h;
+      BlockRegs<NX> rs, rc;
+      rs.issue_diff(S_of(j), X.P + (long long)j * bs, first && j >= 1, lane);
+      rc.issue(X.C + (long long)i * bs, lane); // C_i (row i, column j)
+      rs.commit(Dm, lane);
+      rc.commit(Bm, lane);
+      wave_sync();
+      GAR_YMARK(1)
+      failed |= cyc_inverse<NX>(sm, lane); // Wm = W_j
+    }
     own.commit(D2, lane);
     wave_sync();
     GAR_YMARK(2)
+  } else if (wave == 1) {
+    for (int e = lane; e < bs; e += 64)
+      D2[e] = 0.0;
+    if (has_left) { // left eliminated neighbour j = i - h
+      const int j = i - h;
+      BlockRegs<NX> rs, rc;
+      rs.issue_diff(S_of(j), X.P + (long long)j * bs, first && j >= 1, lane);
+      rc.issue(X.C + (long long)j * bs, lane); // C_j (row j, column i)
+      rs.commit(Dm, lane);
+      rc.commit(Bm, lane);
+      wave_sync();
+      failed |= cyc_inverse<NX>(sm, lane);
+    }
+  } else if (has_coupling) {
+    cond_copy_block<NX>(Cx, X.C + (long long)(i + h) * bs, lane); // C_j, for the new coupling
+    wave_sync();
+  }
+  __syncthreads();
+  // ---- products ----
+  if (wave == 0 && has_right) {
+    const int j = i + h;
     cyc_store_block<NX>(X.W + (long long)j * bs, Wm, lane);
     cyc_store_block<NX>(X.Cl + (long long)j * bs, Bm, lane); // the coupling j had to its left
     GAR_YMARK(3)
@@ -466,28 +591,12 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
     const double y = cyc_matvec<NX>(Wm, r_of(j), row);
     ri -= cyc_matvec<NX>(Bm, y, row);
     GAR_YMARK(5)
-    if (j + h < J) { // new coupling (i, i + 2h) = -C_i W_j C_j = -U^T C_j
-      wave_sync();
-      rcj.commit(Dm, lane); // C_j into the dead S_j buffer
-      wave_sync();
-      GAR_YMARK(6)
-      cyc_ut_times<NX>(Ut, Dm, X.C + (long long)i * bs, -1.0, lane);
-    }
+    GAR_YMARK(6)
     wave_sync();
     GAR_YMARK(7)
-  } else if (wave == 0) {
-    own.commit(D2, lane);
-    wave_sync();
   }
-  if (wave == 1 && i - h >= 0) { // left eliminated neighbour j = i - h
+  if (wave == 1 && has_left) {
     const int j = i - h;
-    BlockRegs<NX> rs, rc;
-    rs.issue_diff(S_of(j), X.P + (long long)j * bs, first && j >= 1, lane);
-    rc.issue(X.C + (long long)j * bs, lane); // C_j (row j, column i)
-    rs.commit(Dm, lane);
-    rc.commit(Bm, lane);
-    wave_sync();
-    failed |= cyc_inverse<NX>(sm, lane);
     double4_t Ut[TX][TX];
     cyc_update<NX, true>(Wm, Bm, D2, Ut, lane); // U = W_j C_j ; S_i -= C_j^T U
     const double y = cyc_matvec<NX>(Wm, r_of(j), row);
@@ -496,11 +605,16 @@ __global__ void __launch_bounds__(128, 1) gar_cyclic_reduce(CyclicParams Y) {
   }
   if (wave == 1 && lane < NX)
     xch[lane] = ri;
+  if (wave == 2 && has_coupling) { // new coupling (i, i + 2h) = -C_i W_j C_j = -U^T C_j, from wave 0's W_j and C_i
+    double4_t Ut[TX][TX];
+    cyc_form_u<NX>(gar_smem + L::oW, gar_smem + L::oB, Ut, lane);
+    cyc_ut_times<NX>(Ut, Cx, X.C + (long long)i * bs, -1.0, lane);
+  }
   __syncthreads();
   GAR_YMARK(8)
   if (wave == 0) {
     const double *D2b = gar_smem + L::total + L::oD2;
-    if (i - h >= 0) {
+    if (has_left) {
       for (int e = lane; e < bs; e += 64)
         D2[e] += D2b[e];
       ri += xch[row];
@@ -599,12 +713,15 @@ __global__ void __launch_bounds__(64) gar_cyclic_recover(CyclicParams Y) {
   double *sol = P.csol + (long long)b * nblk * NX;
   const int row = lane < NX ? lane : NX - 1;
   const int nc0 = P.nc0;
-  auto G0T = [&](double lam) { // (G0^T lam)(row)
-    double g = 0.0;
-    for (int c = 0; c < nc0; ++c)
-      g += prob[P.G0_off + row * nc0 + c] * lane_bcast(lam, c);
-    return g;
-  };
+  // G0 is read by the waves of legs 0 and 1 alone; they stage it in LDS (zero rows past nc0) with every load in
+  // flight at once: five loops of `load a row of G0 -> use it` made leg 0's wave -- and with it the launch -- twice
+  // as long as any other leg's
+  double *G0p = gar_smem;
+  if (k <= 1) {
+    cyc_stage_G0<NX>(G0p, prob + P.G0_off, nc0, lane);
+    wave_sync();
+  }
+  auto G0T = [&](double lam) { return cyc_matvecT_seq<NX>(G0p, lam, row); }; // (G0^T lam)(row)
   auto state = [&](int kk, double lam, double lamn) {
     double x = -X.p[kk * NX + row];
     if (kk == 0)
@@ -638,11 +755,7 @@ __global__ void __launch_bounds__(64) gar_cyclic_recover(CyclicParams Y) {
   // without effect (parallel-solver.hxx:184-202) -- so the gate below also accepts on omega (info[2]).
   double dx = fabs(tup[3 * bs + row]) + cyc_absmatvec<NX>(tup, x, row);
   if (k == 0) {
-    double g = 0.0;
-    const double al = fabs(lam);
-    for (int c = 0; c < nc0; ++c)
-      g += fabs(prob[P.G0_off + row * nc0 + c]) * lane_bcast(al, c);
-    dx += g;
+    dx += cyc_absmatvecT_seq<NX>(G0p, fabs(lam), row);
   } else {
     dx += fabs(lam);
   }
@@ -651,16 +764,11 @@ __global__ void __launch_bounds__(64) gar_cyclic_recover(CyclicParams Y) {
   // lambda_k row
   double rl, dl = 0.0;
   if (k == 0) { // -g0 - G0 x_0
-    double s = 0.0;
-    for (int c = 0; c < NX; ++c)
-      s += (row < nc0 ? prob[P.G0_off + c * nc0 + row] : 0.0) * lane_bcast(x, c);
+    const double s = cyc_matvec_seq<NX>(G0p, x, row);
     rl = (row < nc0 ? -prob[P.g0_off + row] : 0.0) - s;
     if (lane >= nc0)
       rl = 0.0;
-    double sa = 0.0;
-    const double axx = fabs(x);
-    for (int c = 0; c < NX; ++c)
-      sa += (row < nc0 ? fabs(prob[P.G0_off + c * nc0 + row]) : 0.0) * lane_bcast(axx, c);
+    const double sa = cyc_absmatvec_seq<NX>(G0p, fabs(x), row);
     dl = (row < nc0 ? fabs(prob[P.g0_off + row]) : 0.0) + sa;
   } else { // -vt_{k-1} - Vxt_{k-1}^T x_{k-1} - Vtt_{k-1} lambda_k + x_k
     double lamp = X.z[(k - 1) * NX + row];

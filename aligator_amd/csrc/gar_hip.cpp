@@ -297,6 +297,7 @@ struct gar_hip_solver {
   void (*cyc_backlevel_kernel)(gar::CyclicParams) = nullptr;
   void (*cyc_recover_kernel)(gar::CyclicParams) = nullptr;
   int cyc_lds_doubles = 0;
+  int cyc_block_doubles = 0; // one NX x NX block of the cyclic-reduction kernels (gar_cyclic_recover's LDS)
   long long *d_trace = nullptr; // 64 cycle stamps (debug)
   // optional per-kernel timing of the sweep (bench.py's roofline figure): HIP events recorded on
   // the launch stream around the backward sweep kernel, the initial-stage kernel and the forward
@@ -1036,7 +1037,8 @@ int allocate(gar_hip_solver *s) {
     HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_setup_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_reduce_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds + 512));
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * lds + 512 + (int)(s->cyc_block_doubles * sizeof(double))));
     HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_top_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }

@@ -412,13 +412,14 @@ int launch_condensed(gar_hip_solver *s) {
     Y.h = 0;
     const int J = s->num_legs;
     const size_t lds = (size_t)s->cyc_lds_doubles * sizeof(double);
-    hipLaunchKernelGGL(s->cyc_setup_kernel, dim3((unsigned)J, (unsigned)s->batch), dim3(64), lds,
+    // J waves for the legs + two for the initial condition's row (S_0 / r_0 and C_0), see gar_cyclic_setup
+    hipLaunchKernelGGL(s->cyc_setup_kernel, dim3((unsigned)J + 2, (unsigned)s->batch), dim3(64), lds,
                        s->stream, Y);
     for (int h = 1; h < J; h *= 2) {
       Y.h = h;
       hipLaunchKernelGGL(s->cyc_reduce_kernel,
-                         dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch), dim3(128),
-                         2 * lds + 64 * sizeof(double), s->stream, Y);
+                         dim3((unsigned)((J + 2 * h - 1) / (2 * h)), (unsigned)s->batch), dim3(192),
+                         2 * lds + (64 + (size_t)s->cyc_block_doubles) * sizeof(double), s->stream, Y);
     }
     // back-substitution: the levels holding at most 4 blocks in one workgroup, the wider ones a
     // launch each; then the states and the residual, a wave per leg
@@ -436,8 +437,8 @@ int launch_condensed(gar_hip_solver *s) {
                          dim3((unsigned)((J / h + 1) / 2), (unsigned)s->batch), dim3(64), 0,
                          s->stream, Y);
     }
-    hipLaunchKernelGGL(s->cyc_recover_kernel, dim3((unsigned)J, (unsigned)s->batch), dim3(64), 0,
-                       s->stream, Y);
+    hipLaunchKernelGGL(s->cyc_recover_kernel, dim3((unsigned)J, (unsigned)s->batch), dim3(64),
+                       (size_t)s->cyc_block_doubles * sizeof(double), s->stream, Y); // LDS: G0, padded
     HIP_TRY(hipGetLastError());
     C.gated = 1; // the chain kernel (with refinement) re-solves only what missed the threshold
   }

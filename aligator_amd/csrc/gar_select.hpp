@@ -115,6 +115,7 @@ template <int NX, int NU> void bind_leg(gar_hip_solver *s) {
       s->cyc_backlevel_kernel = gar::gar_cyclic_backlevel<NX>;
       s->cyc_recover_kernel = gar::gar_cyclic_recover<NX>;
       s->cyc_lds_doubles = gar::CyclicLds<NX>::total;
+      s->cyc_block_doubles = NX * NX;
     }
   }
   s->kernel_name = "wave_leg<" + std::to_string(NX) + "," + std::to_string(NU) + ">";

@@ -132,3 +132,16 @@ if has csegab2; then
   for L in 32 6; do for lib in libgar_hip_cseg_bkplain.so libgar_hip.so; do LEGS=$L LIB=$lib timeout 200 python scripts/prof_coupled_legs.py 2>&1 | grep done; done; done | tee $O/cseg_ab_bk_blocked.log
   timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "segment_legs or fold" 2>&1 | tail -2 | tee -a $O/cseg_ab_bk_blocked.log
 fi
+if has cycab; then
+  echo "== A/B condensed solve (cyclic reduction): leg 0's wave also forming S_0, r_0, C_0 and reading G0 row by row | two extra waves for the initial condition's row, G0 staged in LDS =="
+  for L in 32 64 8; do LEGS=$L timeout 300 python scripts/ab_legs.py prev=libgar_hip_cycprev.so new=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab_cyclic_setup_recover.log
+  SHAPE=talos timeout 300 python scripts/ab_legs.py prev=libgar_hip_cycprev.so new=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee -a $O/ab_cyclic_setup_recover.log
+  echo "== kernel split, 32 legs, N = 256 =="
+  (cd /tmp && HORIZON=256 LEGS=32 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cycprof -o cyc -- python $R/scripts/prof_legs.py 2>&1 | grep -E "done|rror")
+  find $O/cycprof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/cyc_kernel_stats_32legs.csv; head -16 $O/cyc_kernel_stats_32legs.csv | cut -c1-150; rm -rf $O/cycprof
+  timeout 900 python -m pytest tests -m gpu -q -x -p no:xdist -k "parallel or leg or condensed or golden or cycle or multi or seam or binding" 2>&1 | tail -3 | tee $O/cyc_tests.log
+fi
+if has cycab2; then
+  echo "== A/B condensed solve: as it was | initial row on its own waves | + a third wave per survivor for the new coupling =="
+  for L in 32 64 8; do LEGS=$L timeout 300 python scripts/ab_legs.py prev=libgar_hip_cycprev.so setup=libgar_hip_cyc1.so third=${LIB3:-libgar_hip_cyc2.so} 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab_cyclic_third_wave.log
+fi
