@@ -10,6 +10,8 @@ from aligator_amd import synth
 from aligator_amd.gar import BatchedRiccatiSolver
 libs = {a.split("=")[0]: os.path.join(ROOT, "aligator_amd", a.split("=")[1]) for a in sys.argv[1:]}
 nx, nu = (56, 22) if os.environ.get("SHAPE") == "talos" else (36, 12)
+if os.environ.get("NX"):
+    nx, nu = int(os.environ["NX"]), int(os.environ.get("NU", "12"))
 N, legs, mu = 256, int(os.environ.get("LEGS", "32")), 1e-10
 prob = synth.generate_lq_problem(7, np.zeros(nx), N, nx, nu, mode="W")
 solvers = {}

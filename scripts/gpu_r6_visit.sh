@@ -145,3 +145,8 @@ if has cycab2; then
   echo "== A/B condensed solve: as it was | initial row on its own waves | + a third wave per survivor for the new coupling =="
   for L in 32 64 8; do LEGS=$L timeout 300 python scripts/ab_legs.py prev=libgar_hip_cycprev.so setup=libgar_hip_cyc1.so third=${LIB3:-libgar_hip_cyc2.so} 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab_cyclic_third_wave.log
 fi
+if has cycab3; then
+  echo "== A/B condensed solve: three waves per survivor | seven (products dealt by tile column; 256 registers per wave) | seven, S_i committed before the inverse =="
+  for L in 32 64; do LEGS=$L timeout 300 python scripts/ab_legs.py three=libgar_hip_cyc2.so seven=libgar_hip_cyc3.so seven_early=libgar_hip_cyc4.so 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab_cyclic_seven_waves.log
+  for S in "32 12" "16 8" "12 4"; do set -- $S; NX=$1 NU=$2 LEGS=32 timeout 300 python scripts/ab_legs.py three=libgar_hip_cyc2.so seven=libgar_hip_cyc3.so seven_early=libgar_hip_cyc4.so 2>&1 | grep -vE "amdgpu.ids"; done | tee -a $O/ab_cyclic_seven_waves.log
+fi
