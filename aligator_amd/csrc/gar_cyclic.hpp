@@ -384,6 +384,7 @@ template <int NX> __device__ __forceinline__ double cyc_absmatvec_seq(const doub
 // regular work and made the launch a third longer than any other leg needs (37 us against 25 at NX = 36).  Two extra
 // waves take it over, each inverting Vxx_0 again for itself: role 1 (blockIdx.x == J) forms S_0 and r_0, role 2
 // (blockIdx.x == J + 1) C_0.  Same operations on the same operands: the results are bitwise what one wave produced.
+// LDS: the plan of CyclicLds + one block (G0).
 template <int NX>
 __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
   using L = CyclicLds<NX>;
@@ -397,29 +398,49 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
   if (role == 2 && J < 2)
     return; // no C_0 without a second leg
   double *sm = gar_smem;
-  double *Dm = sm + L::oD, *Wm = sm + L::oW, *Bm = sm + L::oB, *Mm = sm + L::oM, *D2 = sm + L::oD2;
+  double *Dm = sm + L::oD, *Wm = sm + L::oW, *Bm = sm + L::oB, *D2 = sm + L::oD2;
+  double *Gm = sm + L::total; // G0 padded to NX rows (roles 1, 2): a block of its own, the inverse works in the plan's
   CyclicScratch<NX> X(P.scratch + (long long)b * P.scratch_stride, J);
   const double *prob = P.prob + (long long)b * P.prob_stride;
   const double *tup = cond_tuple(P, b, k);
   const int row = lane < NX ? lane : NX - 1;
   const int nc0 = P.nc0;
   const bool has_next = (k + 1 < J);
-  cond_copy_block<NX>(Dm, tup, lane); // Vxx_k
+  const bool need_q = has_next && role != 1;
+  // everything this wave reads is requested before the inverse (Vxt_k, Vtt_k and G0 used to be fetched behind it: a
+  // second round trip to memory on a lone wave); none of the LDS blocks they land in is touched by the inverse
+  BlockRegs<NX> rxx, rxt, rtt;
+  rxx.issue(tup, lane); // Vxx_k
+  if (need_q) {
+    rxt.issue(tup + bs, lane);     // Vxt_k
+    rtt.issue(tup + 2 * bs, lane); // Vtt_k
+  }
+  const double vxr = tup[3 * bs + row];
+  const double vtr = (role == 0 && has_next) ? tup[3 * bs + NX + row] : 0.0;
+  if (role != 0)
+    cyc_stage_G0<NX>(Gm, prob + P.G0_off, nc0, lane);
+  rxx.commit(Dm, lane);
+  if (need_q) {
+    rxt.commit(Bm, lane);
+    rtt.commit(D2, lane);
+  }
+  if (role == 1)
+    for (int e = lane; e < bs; e += 64) {
+      const int j = e / NX, r = e - j * NX;
+      D2[e] = (r == j && r >= nc0) ? -1.0 : 0.0;
+    }
   wave_sync();
   int failed = cyc_inverse<NX>(sm, lane); // Wm = P_k
   if (role == 0)
     cyc_store_block<NX>(X.P + (long long)k * bs, Wm, lane);
   double pk = 0.0;
   if (role != 2) {
-    pk = cyc_matvec<NX>(Wm, tup[3 * bs + row], row); // p_k = P vx
+    pk = cyc_matvec<NX>(Wm, vxr, row); // p_k = P vx
     if (role == 0 && lane < NX)
       X.p[k * NX + lane] = pk;
   }
   double4_t Qt[TX][TX];
-  if (has_next && role != 1) {
-    cond_copy_block<NX>(Bm, tup + bs, lane);     // Vxt_k
-    cond_copy_block<NX>(D2, tup + 2 * bs, lane); // Vtt_k
-    wave_sync();
+  if (need_q) {
     // Q = P Vxt = W (Vxt^T)^T ; D2 = Vtt - Vxt^T Q  -> the part of S_{k+1} this leg owns
     cyc_update<NX, true>(Wm, Bm, D2, Qt, lane);
     if (role == 0) {
@@ -429,21 +450,14 @@ __global__ void __launch_bounds__(64, 1) gar_cyclic_setup(CyclicParams Y) {
       wave_sync();
       cyc_store_block<NX>(X.S + (long long)(k + 1) * bs, D2, lane);
       // r_{k+1} (this leg's part) = -vt_k + Vxt^T p_k
-      const double rk = -tup[3 * bs + NX + row] + cyc_matvecT<NX>(Bm, pk, row);
+      const double rk = -vtr + cyc_matvecT<NX>(Bm, pk, row);
       if (lane < NX)
         X.r[(k + 1) * NX + lane] = rk;
     }
   }
   if (role != 0) {
     // S_0 = -G0 P_0 G0^T (padded with -I), C_0 = -G0 Q_0, r_0 = -g0 + G0 p_0
-    wave_sync();
-    cyc_stage_G0<NX>(Mm, prob + P.G0_off, nc0, lane); // G0 padded to NX rows
-    if (role == 1)
-      for (int e = lane; e < bs; e += 64) {
-        const int j = e / NX, r = e - j * NX;
-        D2[e] = (r == j && r >= nc0) ? -1.0 : 0.0;
-      }
-    wave_sync();
+    const double *Mm = Gm;
     if (role == 1) {
       double4_t Zt[TX][TX];
       cyc_update<NX, false>(Wm, Mm, D2, Zt, lane); // Z = P G0^T ; D2 -= G0 Z
@@ -664,10 +678,11 @@ __global__ void __launch_bounds__(256) gar_cyclic_top(CyclicParams Y) {
   while (2 * hmax < J)
     hmax *= 2;
   if (wave == 0) {
+    const double r0 = X.r[row]; // (requested with S_0, not behind the inverse)
     cond_copy_block<NX>(sm + L::oD, X.S, lane);
     wave_sync();
     const int failed = cyc_inverse<NX>(sm, lane);
-    const double z0 = cyc_matvec<NX>(sm + L::oW, X.r[row], row);
+    const double z0 = cyc_matvec<NX>(sm + L::oW, r0, row);
     if (lane < NX)
       X.z[lane] = z0;
     if (failed && lane == 0)

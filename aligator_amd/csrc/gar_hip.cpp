@@ -1034,8 +1034,8 @@ int allocate(gar_hip_solver *s) {
                                 (int)(s->mfma_lds_doubles * sizeof(double))));
   if (s->cyc_setup_kernel) {
     const int lds = (int)(s->cyc_lds_doubles * sizeof(double));
-    HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_setup_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds + (int)(s->cyc_block_doubles * sizeof(double))));
     HIP_TRY(hipFuncSetAttribute((const void *)s->cyc_reduce_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * lds + 512 + (int)(s->cyc_block_doubles * sizeof(double))));

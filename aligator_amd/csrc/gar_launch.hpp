@@ -413,8 +413,8 @@ int launch_condensed(gar_hip_solver *s) {
     const int J = s->num_legs;
     const size_t lds = (size_t)s->cyc_lds_doubles * sizeof(double);
     // J waves for the legs + two for the initial condition's row (S_0 / r_0 and C_0), see gar_cyclic_setup
-    hipLaunchKernelGGL(s->cyc_setup_kernel, dim3((unsigned)J + 2, (unsigned)s->batch), dim3(64), lds,
-                       s->stream, Y);
+    hipLaunchKernelGGL(s->cyc_setup_kernel, dim3((unsigned)J + 2, (unsigned)s->batch), dim3(64),
+                       lds + (size_t)s->cyc_block_doubles * sizeof(double), s->stream, Y);
     for (int h = 1; h < J; h *= 2) {
       Y.h = h;
       hipLaunchKernelGGL(s->cyc_reduce_kernel,

@@ -150,3 +150,17 @@ if has cycab3; then
   for L in 32 64; do LEGS=$L timeout 300 python scripts/ab_legs.py three=libgar_hip_cyc2.so seven=libgar_hip_cyc3.so seven_early=libgar_hip_cyc4.so 2>&1 | grep -vE "amdgpu.ids"; done | tee $O/ab_cyclic_seven_waves.log
   for S in "32 12" "16 8" "12 4"; do set -- $S; NX=$1 NU=$2 LEGS=32 timeout 300 python scripts/ab_legs.py three=libgar_hip_cyc2.so seven=libgar_hip_cyc3.so seven_early=libgar_hip_cyc4.so 2>&1 | grep -vE "amdgpu.ids"; done | tee -a $O/ab_cyclic_seven_waves.log
 fi
+if has seamab; then
+  echo "== A/B the seam (tests/cpp/_build/bench_lqr_loop --json, alternating, the library file swapped): before | set-up kernel's operands requested before the inverse + status words cleared while the host packs =="
+  L=$R/aligator_amd
+  cp $L/libgar_hip.so /tmp/new.so; cp $L/${PREV:-libgar_hip_cyc2b.so} /tmp/prev.so
+  for rep in 1 2 3; do for w in prev new; do cp /tmp/$w.so $L/libgar_hip.so
+    timeout 200 $R/tests/cpp/_build/bench_lqr_loop --json 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read())
+for k in ('nx36_nu12','nx56_nu22'):
+    v=d[k]['legs']; print('$w', k, v['us_per_newton_iteration'], v['host_us']['backward_blocks_pack_h2d_sweep_status_sync'], v['device_ms'])
+"; done; done | tee $O/ab_seam_setup_prefetch_status_clear.log
+  cp /tmp/new.so $L/libgar_hip.so
+  for L2 in 32 64; do LEGS=$L2 timeout 300 python scripts/ab_legs.py prev=${PREV:-libgar_hip_cyc2b.so} new=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids"; done | tee -a $O/ab_seam_setup_prefetch_status_clear.log
+  NX=32 NU=12 LEGS=32 timeout 300 python scripts/ab_legs.py prev=${PREV:-libgar_hip_cyc2b.so} new=libgar_hip.so 2>&1 | grep -vE "amdgpu.ids" | tee -a $O/ab_seam_setup_prefetch_status_clear.log
+fi
