@@ -41,6 +41,7 @@ SIGNATURES = {
     "gar_hip_batch": (C.c_int, [C.c_void_p]),
     "gar_hip_horizon": (C.c_int, [C.c_void_p]),
     "gar_hip_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "gar_hip_suggest_num_legs": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "gar_hip_stage_offsets": (C.c_int, [C.c_void_p, C.c_int, _PI64]),
     "gar_hip_init_offsets": (C.c_int, [C.c_void_p, _PI64]),
     "gar_hip_upload_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [_PD] * 16),

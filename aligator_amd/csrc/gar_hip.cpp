@@ -1441,6 +1441,15 @@ const char *gar_hip_kernel_name(const gar_hip_solver *s) {
   return s ? s->kernel_name.c_str() : "";
 }
 
+int gar_hip_suggest_num_legs(int horizon, int nx, int nu) {
+  (void)nu;
+  if (horizon < 1)
+    return 1;
+  const int per_leg = nx <= 36 ? 4 : 8; // stages per leg (measured at N = 256: include/gar_hip.h)
+  const int legs = (horizon + per_leg - 1) / per_leg;
+  return legs < 2 ? 2 : (legs > horizon + 1 ? horizon + 1 : legs);
+}
+
 const char *gar_hip_condensed_solver_name(const gar_hip_solver *s) {
   if (!s || s->num_legs < 2)
     return "";

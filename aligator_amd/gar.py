@@ -57,6 +57,12 @@ def get_option(name: str, lib_path=None) -> Optional[str]:
     return None if v is None else v.decode()
 
 
+def suggest_num_legs(horizon: int, nx: int, nu: int, lib_path=None) -> int:
+    """The library's measured table of leg counts for ONE problem in leg mode on one device
+    (gar_hip_suggest_num_legs, include/gar_hip.h; the reference's caller passes num_threads itself)."""
+    return int(_lib.load(lib_path).gar_hip_suggest_num_legs(int(horizon), int(nx), int(nu)))
+
+
 def get_work(horz: int, tid: int, num_threads: int):
     """gar/parallel-solver.hxx:23-28."""
     return (tid * (horz + 1) // num_threads, (tid + 1) * (horz + 1) // num_threads)

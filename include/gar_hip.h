@@ -166,6 +166,14 @@ int gar_hip_horizon(const gar_hip_solver *s);
 /* which kernel family serves this solver: "generic", "dense", or a specialised family such as "wave<36,12>",
  * "mfma<36,12>", "wave<36,12,32>", "pair<56,24>", "wave_leg<12,8>" -- under padding the PADDED family */
 const char *gar_hip_kernel_name(const gar_hip_solver *s);
+/* How many legs to ask for when ONE problem is to be solved in parallel-in-time mode on one device (the reference has
+ * no counterpart: its caller passes num_threads, parallel-solver.hxx:23-28).  A measured table, not a model: the Newton
+ * iteration through gar_hip_backward_blocks at N = 256 on one MI355X (profiles/r06_seam_leg_counts.log) is fastest
+ * with horizon / 4 legs on the families of one wave per leg (nx <= 36: 721-729 us with 64 legs, 736-740 with 32,
+ * 807-812 with 16) and with horizon / 8 on the wider ones ((56, 22): 1 909-1 942 us with 32, 1 916-1 924 with 64,
+ * 2 067 with 128): a leg is a sequential chain over its stages, a level of the condensed solve costs two to three
+ * stages.  Returns a value in [2, horizon + 1] (every leg needs a stage); 1 for horizon < 1. */
+int gar_hip_suggest_num_legs(int horizon, int nx, int nu);
 /* offsets (doubles) of stage t inside one packed problem / one solution record of the caller:
  * out[0]=knot record, out[1]=factor record (device), out[2..5]= x,u,v,lbda offsets */
 int gar_hip_stage_offsets(const gar_hip_solver *s, int t, int64_t out[6]);

@@ -256,6 +256,8 @@ public:
     return fb;
   }
   const char *kernelName() const { return gar_hip_kernel_name(h_); }
+  /// the measured-best leg count for ONE problem of this shape on one device (gar_hip_suggest_num_legs)
+  static int suggestedNumLegs(int horizon, int nx, int nu) { return gar_hip_suggest_num_legs(horizon, nx, nu); }
   /// leg mode: the fast solver of the condensed system ("cyclic", "reduced+cyclic", ...; gar_hip.h)
   const char *condensedSolverName() const { return gar_hip_condensed_solver_name(h_); }
 

@@ -227,19 +227,19 @@ int main(int argc, char **argv) {
     return 77;
   }
   const bool json = argc > 1 && std::string(argv[1]) == "--json";
-  const int json_legs = (json && argc > 2) ? std::atoi(argv[2]) : 0; // --json [legs]: the leg count (default N / 8)
+  const int json_legs = (json && argc > 2) ? std::atoi(argv[2]) : 0; // --json [legs]: the leg count (default: gar_hip_suggest_num_legs)
   const int N = (!json && argc > 1) ? std::atoi(argv[1]) : 256, iters = 20;
   const double mu = 1e-10; // bench/lqr.cpp: mu_init = 1e-10
   struct Shape { int dim, nu; const char *what; };
   const Shape shapes[] = {{36, 12, "north star (36, 12)"}, {56, 22, "bench/lqr.cpp (56, 22)"}};
-  if (json) { // one JSON object: per shape, serial and N/8 legs, phase by phase
+  if (json) { // one JSON object: per shape, serial and in leg mode, phase by phase
     std::printf("{\"workload\": \"one Newton iteration of bench/lqr.cpp's ProxDDP loop through the RiccatiSolverBase seam "
                 "(upload of %d knots, backward, forward, collapseFeedback, every stage's gains), N=%d, one problem\", ", N + 1, N);
     for (size_t i = 0; i < 2; ++i) {
       const Shape &sh = shapes[i];
       LqrProblem p = define_problem(N, sh.dim, sh.nu, 42), pp = define_problem(N, sh.dim, sh.nu, 42);
       std::string k1, k2;
-      const int legs = json_legs > 1 ? json_legs : N / 8;
+      const int legs = json_legs > 1 ? json_legs : gar_hip_suggest_num_legs(N, sh.dim, sh.nu); // the library's table
       const SeamPhases a = time_phases(p, 1, iters, mu, &k1), b = time_phases(pp, legs, iters, mu, &k2);
       std::printf("\"nx%d_nu%d\": {", sh.dim, sh.nu);
       print_phases_json("serial", a, k1, 1, false);

@@ -51,6 +51,15 @@ def test_version_and_layout_queries(lib):
     assert lib.gar_hip_knot_doubles(d) == 3684 + 32 * 36 + 32 * 12 + 32
 
 
+def test_suggested_leg_count(lib):
+    """The measured table behind gar_hip_suggest_num_legs (profiles/r06_seam_leg_counts.log): pure host logic."""
+    assert lib.gar_hip_suggest_num_legs(256, 36, 12) == 64
+    assert lib.gar_hip_suggest_num_legs(256, 56, 22) == 32
+    assert lib.gar_hip_suggest_num_legs(2048, 36, 12) == 512
+    assert lib.gar_hip_suggest_num_legs(5, 12, 4) == 2
+    assert lib.gar_hip_suggest_num_legs(1, 12, 4) == 2 and lib.gar_hip_suggest_num_legs(0, 12, 4) == 1
+
+
 def test_no_gpu_fails_loudly(lib):
     """There is no CPU fallback: without a HIP device solver creation raises."""
     if lib.gar_hip_device_count() > 0:
