@@ -557,7 +557,8 @@ def seam():
     """One Newton iteration of bench/lqr.cpp's ProxDDP loop through the RiccatiSolverBase seam, phase by phase --
     tests/cpp/bench_lqr_loop.cpp built without its oracle leg (tests/cpp/_build/seam_bench, made by
     __graft_entry__.build()): the call sequence of include/aligator/gar/hip-riccati.hpp over the C ABI, (36, 12) and
-    bench/lqr.cpp's / the Talos walk's (56, 22), N = 256, serial and N/8 legs.  None when the binary is absent."""
+    bench/lqr.cpp's / the Talos walk's (56, 22), N = 256, serial and in leg mode with the leg count the library's measured
+    table suggests (gar_hip_suggest_num_legs: 64 / 32), best of three runs of 20 iterations.  None when the binary is absent."""
     import subprocess
     # (bench_lqr_loop: the same program WITH its oracle leg -- the restated reference's iteration on this box's host,
     # one thread, beside every GPU figure; seam_bench is the build without it)

@@ -12,7 +12,7 @@
 // reference's classes over the C ABI): upload of N+1 knots (pinned staging, one H2D), the sweep, one
 // device-side gather + one D2H for all gains, one D2H for the solution.  Beside it: the oracle
 // (restated reference, one thread) on the same problem.  Shapes: bench/lqr.cpp's own (dim 56, nu 22:
-// no specialised kernels yet) and the north star (36, 12), N = 256, serial and with N/8 legs.
+// no specialised kernels yet) and the north star (36, 12), N = 256, serial and in leg mode (leg count: gar_hip_suggest_num_legs).
 //
 // build: make -C tests/cpp bench   (links libgar_hip.so and the oracle: test infrastructure)
 #include <chrono>
